@@ -1,0 +1,138 @@
+/* ORACLE -- CPU restatement of the vPBS proving hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (verifiable-fhe-paper_amd/) never links, imports or calls it.
+ *
+ * What it restates: the stages of plonky2 0.2.0 `plonk::prover::prove` that the reference reaches at
+ * /root/reference/src/vtfhe/ivc_based_vpbs.rs:302-308, :333-339, :364-370,
+ * plus the reference's own native negacyclic NTT (/root/reference/src/vtfhe/crypto/poly.rs:9-64).
+ * plonky2 0.2.0 / plonky2_field 0.2.0 / plonky2_util 0.2.0 are un-vendored crates.io dependencies
+ * (/root/reference/Cargo.lock:371-374, :396-399, :421-424); their algorithm is restated from the published
+ * crate.
+ *
+ * PARITY STATUS: Poseidon permutation pinned by the three upstream known-answer vectors
+ * (tests/golden/poseidon_kat.json); negacyclic NTT pinned by the reference's TESTG/TESTGHAT vectors
+ * (tests/golden/ntt_params_*.json).  Merkle/Challenger/FRI/serialisation conventions: **parity unpinned**
+ * (no golden proof exists in the reference; no Rust toolchain here) -- checked for self-consistency only by the
+ * verifier restated in fri.c.
+ */
+#ifndef VPBS_ORACLE_H
+#define VPBS_ORACLE_H
+#include "gl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- field helpers exported for ctypes ---- */
+u64 orc_gl_add(u64 a, u64 b);
+u64 orc_gl_sub(u64 a, u64 b);
+u64 orc_gl_mul(u64 a, u64 b);
+u64 orc_gl_inv(u64 a);
+u64 orc_gl_exp(u64 a, u64 e);
+u64 orc_gl_root_of_unity(unsigned k);
+void orc_ext_mul(const u64 a[2], const u64 b[2], u64 out[2]);
+void orc_ext_inv(const u64 a[2], u64 out[2]);
+
+/* ---- Poseidon (hash/poseidon.rs, hash/poseidon_goldilocks.rs, hash/hashing.rs) ---- */
+void orc_poseidon(u64 state[12]);
+void orc_poseidon_batch(u64* states, size_t n);                 /* n independent states, [n][12] */
+void orc_hash_no_pad(const u64* in, size_t n, u64 out[4]);      /* PoseidonHash::hash_no_pad   */
+void orc_hash_or_noop(const u64* in, size_t n, u64 out[4]);     /* H::hash_or_noop             */
+void orc_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]);/* H::two_to_one               */
+/* hash chain of verify_hash_output, /root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78 */
+void orc_hash_chain(const u64* data, size_t n_items, size_t item_len, u64 out[4]);
+
+/* ---- FFT for proving (plonky2_field fft.rs / polynomial/mod.rs) ---- */
+void orc_fft(u64* a, unsigned log_n);   /* coeffs -> values on <w_n>, natural order in and out */
+void orc_ifft(u64* a, unsigned log_n);  /* values -> coeffs */
+/* PolynomialCoeffs::lde(rate_bits).coset_fft(shift): out[t] = sum_i c_i (shift * w_{n<<rate}^t)^i, natural t */
+void orc_coset_lde(const u64* coeffs, unsigned log_n, unsigned rate_bits, u64 shift, u64* out);
+
+/* ---- Merkle tree with cap (hash/merkle_tree.rs, hash/merkle_proofs.rs) ---- */
+typedef struct orc_merkle orc_merkle;
+orc_merkle* orc_merkle_new(const u64* leaves, size_t n_leaves, size_t leaf_len, unsigned cap_height);
+void orc_merkle_free(orc_merkle*);
+void orc_merkle_cap(const orc_merkle*, u64* cap_out /* [2^cap_height][4] */);
+size_t orc_merkle_proof_len(const orc_merkle*);                  /* number of siblings */
+void orc_merkle_leaf(const orc_merkle*, size_t idx, u64* leaf_out);
+void orc_merkle_prove(const orc_merkle*, size_t idx, u64* siblings_out /* [proof_len][4] */);
+int orc_merkle_verify(const u64* leaf, size_t leaf_len, size_t idx, const u64* cap, unsigned cap_height,
+                      const u64* siblings, size_t n_siblings);   /* 1 = ok */
+
+/* ---- PolynomialBatch (fri/oracle.rs) ---- */
+typedef struct orc_batch orc_batch;
+/* values/coeffs: column-major [ncols][1<<log_n] */
+orc_batch* orc_batch_from_values(const u64* values, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height);
+orc_batch* orc_batch_from_coeffs(const u64* coeffs, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height);
+void orc_batch_free(orc_batch*);
+void orc_batch_cap(const orc_batch*, u64* cap_out);
+const u64* orc_batch_coeffs(const orc_batch*);                    /* [ncols][n] */
+const u64* orc_batch_leaves(const orc_batch*);                    /* [n<<rate][ncols], plonky2 leaf order */
+size_t orc_batch_ncols(const orc_batch*);
+/* get_lde_values(index, step): row index*step of the natural-order LDE */
+void orc_batch_lde_row(const orc_batch*, size_t index, size_t step, u64* out /* [ncols] */);
+/* p.to_extension().eval(zeta) for every polynomial: out [ncols][2] */
+void orc_batch_eval_ext(const orc_batch*, const u64 zeta[2], u64* out);
+void orc_batch_open(const orc_batch*, size_t leaf_index, u64* leaf_out, u64* siblings_out);
+
+/* ---- Challenger (iop/challenger.rs) ---- */
+typedef struct {
+    u64 sponge[12];
+    u64 input[8];
+    u64 output[8];
+    uint32_t input_len;
+    uint32_t output_len;
+} orc_challenger;
+void orc_challenger_init(orc_challenger*);
+void orc_challenger_observe(orc_challenger*, const u64* elems, size_t n);
+u64 orc_challenger_get(orc_challenger*);
+void orc_challenger_get_n(orc_challenger*, u64* out, size_t n);
+
+/* ---- FRI (fri/oracle.rs prove_openings, fri/prover.rs, fri/verifier.rs) ---- */
+typedef struct {
+    unsigned rate_bits;          /* 3 */
+    unsigned cap_height;         /* 4 */
+    unsigned pow_bits;           /* 16 */
+    unsigned num_query_rounds;   /* 28 */
+    unsigned n_rounds;           /* len(reduction_arity_bits) */
+    unsigned arity_bits[16];
+    int      mul_final_by_x;     /* 0 for plonky2 0.2.0 as recalled; switch kept until a golden proof pins it */
+} orc_fri_params;
+/* FriConfig::fri_params / ConstantArityBits(4,5) reduction strategy */
+void orc_fri_params_standard(unsigned degree_bits, orc_fri_params* out);
+
+typedef struct {               /* one FriBatchInfo: opening point + (oracle_index, poly_index) list */
+    u64 point[2];
+    size_t n_polys;
+    const uint32_t* oracle_index;
+    const uint32_t* poly_index;
+} orc_fri_batch_info;
+
+/* Flat FriProof layout (u64 words), identical to include/vpbs_prover.h:
+ *   caps[n_rounds][2^cap_height][4]
+ *   per query round q: per oracle o: leaf[ncols_o], siblings[log_lde - cap_height][4];
+ *                      per fold round i: evals[2 << arity_bits_i], siblings[..][4]
+ *   final_poly[len][2], pow_witness                                                         */
+size_t orc_fri_proof_words(const orc_fri_params*, unsigned degree_bits, const size_t* ncols, size_t n_oracles);
+
+/* PolynomialBatch::prove_openings -> fri_proof.  `forced_pow` : if != UINT64_MAX use this nonce
+ * (the reference's rayon find_any may return any valid nonce) else take the smallest valid one. */
+int orc_prove_openings(const orc_batch* const* oracles, size_t n_oracles, const orc_fri_batch_info* batches,
+                       size_t n_batches, orc_challenger* ch, const orc_fri_params* params, unsigned degree_bits,
+                       u64 forced_pow, u64* proof_out);
+/* verify_fri_proof restated; the challenger must be in the state it had before prove_openings;
+ * openings: per batch, the claimed evaluations [n_polys][2].  returns 1 when the proof verifies. */
+int orc_verify_fri(const u64* const* caps, const size_t* ncols, size_t n_oracles, const orc_fri_batch_info* batches,
+                   const u64* const* openings, size_t n_batches, orc_challenger* ch, const orc_fri_params* params,
+                   unsigned degree_bits, const u64* proof);
+
+/* ---- negacyclic NTT of the reference (src/vtfhe/crypto/poly.rs:9-64, src/ntt/gen_param_file.sage) ---- */
+void orc_negacyclic_params(unsigned log_n, u64* roots, u64* invroots, u64* ninv);
+void orc_negacyclic_forward(u64* a, unsigned log_n, const u64* roots);
+void orc_negacyclic_backward(u64* a, unsigned log_n, const u64* invroots, u64 ninv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
