@@ -1,0 +1,186 @@
+/* vpbs_prover.h -- C ABI of the MI355X-native prover for the vPBS step circuit.
+ *
+ * Drop-in boundary.  plonky2 0.2.0 has no plugin API; the reference reaches the hot path through
+ *   plonky2::plonk::prover::prove::<F, C, D>(&prover_only, &common, pw, &mut timing)
+ * at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302-308, :333-339, :364-370 (and CircuitData::prove in every test,
+ * e.g. /root/reference/src/ntt/mod.rs:99).  The seam a device backend replaces sits one level below, inside the
+ * un-vendored crate (pinned at /root/reference/Cargo.lock:371-374): fri/oracle.rs `PolynomialBatch::from_values`,
+ * `from_coeffs`, `get_lde_values`, `prove_openings` and plonk/proof.rs `OpeningSet::new`.  Each entry point below
+ * names the plonky2 function it replaces.  INTEGRATION.md shows the Rust `extern "C"` binding.
+ *
+ * Conventions: field elements are canonical u64 (< p = 2^64 - 2^32 + 1); GF(p^2) elements are [c0, c1]; polynomial
+ * matrices are column-major [col][row]; hashes are 4 u64.  Every function returns 0 on success and a negative
+ * vpbs_status on error (no exceptions cross the boundary; vpbs_last_error(ctx) has the text).  Host buffers are owned
+ * by the caller; vpbs_batch handles are device-resident and owned by the library until vpbs_batch_free.
+ * A vpbs_ctx is bound to one device and one HIP stream and is NOT re-entrant: use one ctx per host thread.
+ * `_dev` variants take device pointers valid on the ctx's device and enqueue on the ctx's stream.
+ */
+#ifndef VPBS_PROVER_H
+#define VPBS_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vpbs_ctx vpbs_ctx;
+typedef struct vpbs_batch vpbs_batch;
+
+typedef enum {
+    VPBS_OK = 0,
+    VPBS_ERR_INVALID = -1,   /* bad argument (size not a power of two, null pointer, ...) */
+    VPBS_ERR_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
+    VPBS_ERR_OOM = -3,       /* device allocation failed */
+    VPBS_ERR_POW = -4        /* forced proof-of-work nonce is not valid / search exhausted */
+} vpbs_status;
+
+#define VPBS_POW_ANY UINT64_MAX
+
+/* ---- context ---- */
+int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, unsigned cap_height, vpbs_ctx** out);
+void vpbs_ctx_destroy(vpbs_ctx* ctx);
+const char* vpbs_last_error(const vpbs_ctx* ctx);
+int vpbs_ctx_synchronize(vpbs_ctx* ctx);
+void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share device buffers with the ctx */
+
+/* ---- PolynomialBatch (plonky2 fri/oracle.rs) ---- */
+/* = PolynomialBatch::from_values(values, rate_bits, blinding=false, cap_height, ..): iFFT -> coset LDE -> Merkle */
+int vpbs_commit_values(vpbs_ctx* ctx, const uint64_t* values, unsigned ncols, unsigned log_n, vpbs_batch** out,
+                       uint64_t* cap_out /* [2^cap_height][4] */);
+/* = PolynomialBatch::from_coeffs */
+int vpbs_commit_coeffs(vpbs_ctx* ctx, const uint64_t* coeffs, unsigned ncols, unsigned log_n, vpbs_batch** out,
+                       uint64_t* cap_out);
+int vpbs_commit_values_dev(vpbs_ctx* ctx, const uint64_t* d_values, unsigned ncols, unsigned log_n, vpbs_batch** out,
+                           uint64_t* cap_out);
+int vpbs_commit_coeffs_dev(vpbs_ctx* ctx, const uint64_t* d_coeffs, unsigned ncols, unsigned log_n, vpbs_batch** out,
+                           uint64_t* cap_out);
+void vpbs_batch_free(vpbs_batch* batch);
+unsigned vpbs_batch_ncols(const vpbs_batch* batch);
+unsigned vpbs_batch_log_n(const vpbs_batch* batch);
+int vpbs_batch_cap(vpbs_batch* batch, uint64_t* cap_out);
+/* batch.polynomials: coefficient form, [ncols][n] */
+int vpbs_batch_coeffs(vpbs_batch* batch, uint64_t* out);
+/* = get_lde_values(index, step) for index = row_start .. row_start+nrows-1: out[k][c] = lde_c[(row_start+k)*step],
+ * natural LDE order (for a host-side quotient evaluation) */
+int vpbs_batch_lde_rows(vpbs_batch* batch, size_t row_start, size_t nrows, size_t step, uint64_t* out);
+/* = the commitment's share of OpeningSet::new: out[c] = polynomials[c].to_extension().eval(zeta) */
+int vpbs_batch_eval_ext(vpbs_batch* batch, const uint64_t zeta[2], uint64_t* out /* [ncols][2] */);
+/* = (merkle_tree.get(leaf_index), merkle_tree.prove(leaf_index)) */
+int vpbs_batch_open(vpbs_batch* batch, size_t leaf_index, uint64_t* leaf_out /* [ncols] */,
+                    uint64_t* siblings_out /* [log_lde - cap_height][4] */);
+
+/* ---- Challenger (plonky2 iop/challenger.rs); the state crosses the boundary explicitly ---- */
+typedef struct {
+    uint64_t sponge[12];
+    uint64_t input[8];
+    uint64_t output[8];
+    uint32_t input_len;
+    uint32_t output_len;
+} vpbs_challenger_state;
+void vpbs_challenger_init(vpbs_challenger_state* ch);
+void vpbs_challenger_observe(vpbs_challenger_state* ch, const uint64_t* elems, size_t n); /* observe_elements */
+uint64_t vpbs_challenger_get(vpbs_challenger_state* ch);                                 /* get_challenge   */
+/* PoseidonHash::hash_no_pad on the host (public-input hash, small inputs) */
+void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]);
+
+/* ---- FRI (plonky2 fri/oracle.rs prove_openings -> fri/prover.rs fri_proof) ---- */
+typedef struct {
+    unsigned rate_bits;        /* 3  */
+    unsigned cap_height;       /* 4  */
+    unsigned pow_bits;         /* 16 */
+    unsigned num_query_rounds; /* 28 */
+    unsigned n_rounds;         /* len(reduction_arity_bits) */
+    unsigned arity_bits[16];
+    int mul_final_by_x;        /* 0: plonky2 0.2.0 as restated (lower-confidence item) */
+} vpbs_fri_params;
+/* CircuitConfig::standard_recursion_config().fri_config.fri_params(degree_bits, hiding=false) */
+void vpbs_fri_params_standard(unsigned degree_bits, vpbs_fri_params* out);
+
+typedef struct { /* FriBatchInfo: opening point + FriPolynomialInfo list */
+    uint64_t point[2];
+    size_t n_polys;
+    const uint32_t* oracle_index;
+    const uint32_t* poly_index;
+} vpbs_fri_batch_info;
+typedef struct { /* FriInstanceInfo (oracles are passed separately) */
+    const vpbs_fri_batch_info* batches;
+    size_t n_batches;
+} vpbs_fri_instance;
+
+/* FriProof as flat u64 words, in plonky2's serialisation order (Merkle-proof length bytes omitted):
+ *   commit_phase_merkle_caps[n_rounds][2^cap_height][4]
+ *   query_round_proofs[q]: initial_trees_proof: per oracle { leaf[ncols_o], siblings[log_lde-cap_height][4] }
+ *                          steps[i]: { evals[2 << arity_bits_i], siblings[log(len_i) - cap_height][4] }
+ *   final_poly[len][2], pow_witness */
+size_t vpbs_fri_proof_words(const vpbs_fri_params* params, unsigned degree_bits, const size_t* ncols, size_t n_oracles);
+/* forced_pow: VPBS_POW_ANY -> smallest valid nonce; otherwise use the given nonce (the reference's rayon find_any
+ * may return any valid nonce, so byte parity with a reference proof is conditional on its pow_witness). */
+int vpbs_fri_prove(vpbs_ctx* ctx, vpbs_batch* const* oracles, size_t n_oracles, const vpbs_fri_instance* instance,
+                   const vpbs_fri_params* params, vpbs_challenger_state* challenger /* inout */, uint64_t forced_pow,
+                   uint64_t* proof_out);
+
+/* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
+typedef struct {
+    unsigned log_n;                   /* degree_bits: 15 for N=1024, 12 for N=8 */
+    unsigned n_wires;                 /* 135 */
+    unsigned n_zs_partial_products;   /* 20: [Z_0, Z_1, pp...] */
+    unsigned n_quotient;              /* 16 */
+    unsigned num_challenges;          /* 2 */
+    int inputs_on_device;             /* 1: the three pointers below are device pointers */
+    const uint64_t* wires_values;     /* [n_wires][n]   -> from_values */
+    const uint64_t* zs_pp_values;     /* [n_zs_pp][n]   -> from_values */
+    const uint64_t* quotient_coeffs;  /* [n_quotient][n]-> from_coeffs */
+    vpbs_batch* constants_sigmas;     /* committed once per circuit (prover_data.constants_sigmas_commitment) */
+    uint64_t circuit_digest[4];
+    const uint64_t* public_inputs;    /* host */
+    size_t n_public_inputs;
+    uint64_t forced_pow;              /* VPBS_POW_ANY or a nonce */
+} vpbs_step_inputs;
+
+/* sizes of the outputs of vpbs_prove_step, in u64 words */
+typedef struct {
+    size_t cap_words;       /* per cap: 4 << cap_height */
+    size_t openings_words;  /* 2 * (n_cs + n_wires + n_zs_pp + n_quotient + num_challenges) */
+    size_t fri_words;
+} vpbs_step_sizes;
+int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out);
+
+/* Runs: wires commit -> observe digest, PI hash, cap -> betas, gammas -> Z/pp commit -> alphas -> quotient commit ->
+ * zeta -> openings -> observe -> prove_openings/fri_proof.  (Partial products and quotient evaluation are host stages
+ * in this round -- SURVEY.md 8f-1 -- so their inputs arrive as data.)
+ * caps_out: [3][cap_words] (wires, zs_partial_products, quotient); openings_out: ext values in plonky2 field order
+ * constants, plonk_sigmas, wires, plonk_zs, partial_products, quotient_polys (all at zeta) then plonk_zs_next (g*zeta);
+ * challenges_out (optional, may be NULL): betas[nc], gammas[nc], alphas[nc], zeta[2]. */
+int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_out, uint64_t* openings_out,
+                    uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out);
+/* ProofWithPublicInputs::to_bytes layout (util/serialization); returns bytes written or <0.
+ * n_constants: how many leading columns of constants_sigmas are `constants` (the rest are plonk_sigmas). */
+long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants,
+                              const uint64_t* caps, const uint64_t* openings, const uint64_t* fri, uint8_t* out,
+                              size_t out_capacity);
+
+/* ---- kernel-level entry points (host buffers; used by parity tests and by callers outside the prover) ---- */
+int vpbs_k_poseidon_batch(vpbs_ctx* ctx, uint64_t* states /* [n][12] in place */, size_t n);
+int vpbs_k_hash_rows(vpbs_ctx* ctx, const uint64_t* rows /* [n][len] */, size_t n, unsigned len, uint64_t* out /* [n][4] */);
+int vpbs_k_intt(vpbs_ctx* ctx, const uint64_t* values, unsigned ncols, unsigned log_n, uint64_t* coeffs_out);
+/* out[c][j] = poly_c(shift * w^{bitrev(j)}), j < n << rate_bits (plonky2 leaf order) */
+int vpbs_k_coset_lde(vpbs_ctx* ctx, const uint64_t* coeffs, unsigned ncols, unsigned log_n, unsigned rate_bits,
+                     uint64_t shift, uint64_t* out);
+/* MerkleTree::new(leaves, cap_height) over row-major leaves [n_leaves][leaf_len]: cap_out [2^cap_height][4] */
+int vpbs_k_merkle_cap(vpbs_ctx* ctx, const uint64_t* leaves, size_t n_leaves, unsigned leaf_len, unsigned cap_height,
+                      uint64_t* cap_out);
+/* reference negacyclic NTT (/root/reference/src/vtfhe/crypto/poly.rs:27-64), batched, in place on [batch][1<<log_n] */
+int vpbs_k_negacyclic_ntt(vpbs_ctx* ctx, uint64_t* data, unsigned batch, unsigned log_n, int inverse);
+/* the params_{N}.rs tables (ROOTS, INVROOTS, NINV) regenerated per /root/reference/src/ntt/gen_param_file.sage */
+int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv);
+
+/* ---- per-kernel device timing (HIP events on the ctx stream) ---- */
+int vpbs_timing_enable(vpbs_ctx* ctx, int on);
+/* writes a JSON object {"kernel": {"ms": total, "count": launches}, ...} and resets the accumulators */
+int vpbs_timing_report(vpbs_ctx* ctx, char* buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,240 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+Bit-exact everywhere (64-bit modular integer work: no tolerance)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import step_oracle
+import vpbs_amd
+from vpbs_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+P = api.P
+rng = np.random.default_rng(20240807)
+
+
+def rand_field(*shape):
+    return rng.integers(0, P, size=shape, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = vpbs_amd.Context(0, log_n_max=16)
+    yield c
+    c.close()
+
+
+# ---------- Poseidon / sponge / Merkle ----------
+def test_poseidon_kats_and_random(ctx):
+    kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))
+    states = np.array([k["input"] for k in kat["kats"]], np.uint64)
+    out = ctx.poseidon_batch(states)
+    for i, k in enumerate(kat["kats"]):
+        assert [int(v) for v in out[i]] == k["output"], k["name"]
+    edge = np.array([[P - 1] * 12, [0] * 11 + [P - 1], [0xFFFFFFFF] * 12, [0xFFFFFFFF00000000] * 12, [1 << 63] * 12], np.uint64)
+    states = np.concatenate([edge, rand_field(3000, 12)])
+    want = states.copy()
+    orc.lib().orc_poseidon_batch(orc.ptr(want), want.shape[0])
+    assert (ctx.poseidon_batch(states) == want).all()
+
+
+@pytest.mark.parametrize("length", [5, 8, 9, 16, 20, 32, 85, 135])
+def test_hash_rows(ctx, length):
+    rows = rand_field(300, length)
+    got = ctx.hash_rows(rows)
+    for i in (0, 1, 150, 299):
+        assert list(got[i]) == list(orc.hash_no_pad(rows[i]))
+
+
+@pytest.mark.parametrize("leaf_len,n_leaves,cap_h", [(3, 64, 2), (4, 32, 4), (7, 256, 4), (20, 128, 0), (135, 512, 4), (32, 16, 4)])
+def test_merkle_cap(ctx, leaf_len, n_leaves, cap_h):
+    leaves = rand_field(n_leaves, leaf_len)
+    assert (ctx.merkle_cap(leaves, cap_h) == orc.Merkle(leaves, cap_h).cap()).all()
+
+
+# ---------- NTT ----------
+@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 15, 16])
+def test_intt(ctx, log_n):
+    vals = rand_field(3, 1 << log_n)
+    got = ctx.intt(vals)
+    for c in range(3):
+        assert (got[c] == orc.fft(vals[c], inverse=True)).all()
+
+
+@pytest.mark.parametrize("log_n,rate_bits,shift", [(1, 3, 7), (3, 3, 7), (7, 3, pow(7, 256, P)), (11, 3, pow(7, 16, P)), (12, 3, 7),
+                                                   (13, 0, 7), (15, 3, 7), (10, 1, 49), (14, 2, 7)])
+def test_coset_lde_leaf_order(ctx, log_n, rate_bits, shift):
+    coeffs = rand_field(2, 1 << log_n)
+    got = ctx.coset_lde(coeffs, rate_bits, shift)
+    log_big = log_n + rate_bits
+    idx = np.array([int(format(j, "0%db" % log_big)[::-1], 2) if log_big else 0 for j in range(1 << log_big)])
+    for c in range(2):
+        nat = orc.coset_lde(coeffs[c], rate_bits, shift)
+        assert (got[c] == nat[idx]).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ntt_params_*.json"))))
+def test_negacyclic_golden(ctx, path):
+    """reference KAT (crypto/poly.rs:195-208) on the device kernel, batched with random rows around it"""
+    g = json.load(open(path))
+    n = g["N"]
+    batch = np.concatenate([rand_field(2, n), np.array([g["TESTG"]], np.uint64), rand_field(1, n)])
+    fw = ctx.negacyclic_ntt(batch)
+    assert [int(v) for v in fw[2]] == g["TESTGHAT"]
+    bw = ctx.negacyclic_ntt(fw, inverse=True)
+    assert (bw == batch).all()
+    roots, inv, ninv = orc.negacyclic_params(g["LOGN"])
+    assert (fw[0] == orc.negacyclic_forward(batch[0], roots)).all()
+
+
+# ---------- PolynomialBatch ----------
+@pytest.mark.parametrize("log_n,ncols,from_values", [(5, 3, True), (6, 4, True), (10, 9, True), (12, 5, False), (13, 135, True)])
+def test_commit_matches_oracle(ctx, log_n, ncols, from_values):
+    data = rand_field(ncols, 1 << log_n)
+    want = orc.Batch(data, 3, 4, from_values=from_values)
+    got = (ctx.commit_values if from_values else ctx.commit_coeffs)(data)
+    assert (got.cap_at_commit == want.cap()).all() and (got.cap() == want.cap()).all()
+    assert (got.coeffs() == want.coeffs()).all()
+    L = 1 << (log_n + 3)
+    for idx in (0, 1, L // 2 + 3, L - 1):
+        leaf, sib = got.open(idx)
+        wleaf, wsib = want.open(idx)
+        assert (leaf == wleaf).all() and (sib == wsib).all()
+    rows = got.lde_rows(3, 5, step=2)
+    for k in range(5):
+        assert (rows[k] == want.lde_row(3 + k, 2)).all()
+    zeta = rand_field(2)
+    assert (got.eval_ext(zeta) == want.eval_ext(zeta)).all()
+    got.free()
+
+
+# ---------- FRI ----------
+def _fri_case(ctx, log_n, cols, **over):
+    datas = [rand_field(nc, 1 << log_n) for nc in cols]
+    o_batches = [orc.Batch(d, 3, 4, from_values=(i != 3)) for i, d in enumerate(datas)]
+    g_batches = [(ctx.commit_values if i != 3 else ctx.commit_coeffs)(d) for i, d in enumerate(datas)]
+    ch = orc.ChallengerState()
+    for o in o_batches:
+        ch.observe(o.cap())
+    zeta = ch.get_ext()
+    batches, zeta_next = step_oracle.step_batches(list(cols), 2, zeta, log_n)
+    openings = np.concatenate([o.eval_ext(zeta) for o in o_batches] + [o_batches[2].eval_ext(zeta_next)[:2]])
+    ch.observe(openings)
+    gch = api.ChallengerState()
+    for o in g_batches:
+        gch.observe(o.cap())
+    assert list(gch.get_ext()) == list(zeta)
+    gch.observe(openings)
+    return o_batches, g_batches, ch, gch, batches, openings, orc.fri_params(log_n, **over), api.fri_params(log_n, **over)
+
+
+@pytest.mark.parametrize("log_n,over", [(6, {}), (9, {}), (12, {}), (8, {"mul_final_by_x": 1}), (7, {"pow_bits": 5, "num_query_rounds": 3})])
+def test_fri_prove_bit_exact(ctx, log_n, over):
+    ob, gb, ch, gch, batches, openings, op, gp = _fri_case(ctx, log_n, (4, 6, 3, 2), **over)
+    ch_v = ch.clone()
+    want = orc.prove_openings(ob, batches, ch, op, log_n)
+    got = ctx.fri_prove(gb, batches, gch, gp)
+    assert got.shape == want.shape
+    assert (got == want).all()
+    assert gch.state_words() == ch.state_words()
+    total = sum(o.ncols for o in ob)
+    assert orc.verify_fri([o.cap() for o in ob], [o.ncols for o in ob], batches, [openings[:total], openings[total:]], ch_v, op, log_n, got)
+
+
+def test_fri_forced_pow_and_invalid(ctx):
+    ob, gb, ch, gch, batches, openings, op, gp = _fri_case(ctx, 6, (4, 6, 3, 2), pow_bits=6)
+    g2 = gch.clone()
+    got = ctx.fri_prove(gb, batches, gch, gp)
+    w = int(got[-1])
+    again = ctx.fri_prove(gb, batches, g2.clone(), gp, forced_pow=w)
+    assert (again == got).all()
+    bad = next(x for x in range(1, 1000) if x != w and not _pow_valid(g2, gb, batches, gp, ctx, x))
+    with pytest.raises(api.VpbsError):
+        ctx.fri_prove(gb, batches, g2.clone(), gp, forced_pow=bad)
+
+
+def _pow_valid(ch, gb, batches, gp, ctx, w):
+    try:
+        ctx.fri_prove(gb, batches, ch.clone(), gp, forced_pow=w)
+        return True
+    except api.VpbsError:
+        return False
+
+
+# ---------- step proof ----------
+DIGEST = np.array([11, 22, 33, 44], np.uint64)
+
+
+def _step(ctx, log_n, cols=None, instance=0):
+    inputs = synth.step_inputs(log_n, instance, cols)
+    pis = synth.field_elements(0xABCD + instance, 77)
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], inputs["zs_partial_products"], inputs["quotient"], cs, DIGEST, pis)
+    return inputs, pis, cs, si, ctx.prove_step(si)
+
+
+@pytest.mark.parametrize("log_n,cols", [(6, {"constants_sigmas": 5, "wires": 9, "zs_partial_products": 4, "quotient": 3}),
+                                        (9, None), (12, None)])
+def test_step_proof_bit_exact(ctx, log_n, cols):
+    """BASELINE config 1 sizes at log_n = 12 (N = 8 ring: degree 2^12, 135/20/16/85 columns)."""
+    inputs, pis, cs, si, got = _step(ctx, log_n, cols)
+    want = step_oracle.prove_step(inputs, DIGEST, pis, log_n)
+    assert (cs.cap() == want["cs_cap"]).all()
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (got[key] == want[key]).all(), key
+    assert got["challenger"].state_words() == want["challenger"].state_words()
+    assert step_oracle.verify_step(got, want["cs_cap"], want["ncols"], DIGEST, pis, log_n)
+    n_constants = min(5, want["ncols"][0])
+    assert ctx.step_proof_to_bytes(si, n_constants, got) == step_oracle.to_bytes(want, want["ncols"], n_constants, pis, log_n)
+
+
+def test_step_proof_device_inputs_match_host_inputs(ctx):
+    import torch
+    log_n = 8
+    inputs, pis, cs, si, want = _step(ctx, log_n)
+    dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
+    torch.cuda.synchronize()
+    si2 = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), dev["zs_partial_products"].data_ptr(), dev["quotient"].data_ptr(),
+                               cs, DIGEST, pis, on_device=True, shapes=(135, 20, 16))
+    got = ctx.prove_step(si2)
+    for key in ("caps", "openings", "fri"):
+        assert (got[key] == want[key]).all()
+
+
+def test_full_size_step_properties(ctx):
+    """BASELINE config 2 (N = 1024: degree 2^15, LDE 2^18, 135/20/16/85 columns).  The oracle prover would take
+    minutes here, so parity is carried by size-independent properties: the proof verifies under the restated
+    plonky2 verifier; Merkle paths open to the caps; openings are consistent with the committed LDE."""
+    log_n = 15
+    inputs, pis, cs, si, got = _step(ctx, log_n)
+    ncols = [85, 135, 20, 16]
+    assert step_oracle.verify_step(got, cs.cap(), ncols, DIGEST, pis, log_n)
+    # determinism
+    again = ctx.prove_step(si)
+    assert (again["fri"] == got["fri"]).all() and (again["caps"] == got["caps"]).all()
+    # tampered opening is rejected
+    bad = dict(got); bad["openings"] = got["openings"].copy(); bad["openings"][100][0] ^= np.uint64(1)
+    assert not step_oracle.verify_step(bad, cs.cap(), ncols, DIGEST, pis, log_n)
+    # wires commitment: leaves open to the cap, and the LDE row equals the polynomial evaluated at that point
+    wires = ctx.commit_values(inputs["wires"])
+    assert (wires.cap() == got["caps"][0]).all()
+    L = 1 << 18
+    w18 = orc.lib().orc_gl_root_of_unity(18)
+    for idx in (0, 12345, L - 1):
+        leaf, sib = wires.open(idx)
+        assert orc.merkle_verify(leaf, idx, got["caps"][0], 4, sib)
+        nat = int(format(idx, "018b")[::-1], 2)
+        x = orc.lib().orc_gl_mul(7, orc.lib().orc_gl_exp(w18, nat))
+        ev = wires.eval_ext(np.array([x, 0], np.uint64))
+        assert (ev[:, 0] == leaf).all() and (ev[:, 1] == 0).all()
+    # iNTT really inverts: coefficients evaluated back on H reproduce the trace column (spot check through the oracle FFT)
+    coeffs = wires.coeffs()
+    for c in (0, 134):
+        assert (orc.fft(coeffs[c]) == inputs["wires"][c]).all()
+    wires.free()

@@ -1,0 +1,135 @@
+"""CPU tests (-m "not gpu") of the product's host side: ABI surface, host Challenger/Poseidon, parameter tables,
+synthetic inputs, sharding plan (incl. a world_size-2 gloo run).  No device compute is called."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import vpbs_amd
+from vpbs_amd import api, sharding, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+P = api.P
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(api.LIB_PATH):
+        api.build_library()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vpbs_prover.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vpbs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    L = ctypes.CDLL(api.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing export: " + name
+    assert declared == set(api.SIGNATURES), declared ^ set(api.SIGNATURES)
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.VpbsError):
+        vpbs_amd.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "verifiable-fhe-paper_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "libvpbs_oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, f
+
+
+def test_host_challenger_matches_oracle():
+    rng = np.random.default_rng(7)
+    a, b = api.ChallengerState(), orc.ChallengerState()
+    for kind, k in [("o", 5), ("g", 3), ("o", 8), ("g", 1), ("o", 64), ("g", 10), ("o", 1), ("g", 2)]:
+        if kind == "o":
+            xs = rng.integers(0, P, size=k, dtype=np.uint64)
+            a.observe(xs); b.observe(xs)
+        else:
+            assert a.get_n(k) == b.get_n(k)
+    assert a.state_words() == b.state_words()
+
+
+def test_host_poseidon_kats_via_hash():
+    kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))
+    # hash_no_pad of 8 zeros = first 4 words of perm(0^12)
+    assert [int(v) for v in api.hash_no_pad(np.zeros(8, np.uint64))] == kat["kats"][0]["output"][:4]
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 8, 9, 24, 135, 4173):
+        x = rng.integers(0, P, size=n, dtype=np.uint64)
+        assert list(api.hash_no_pad(x)) == list(orc.hash_no_pad(x))
+
+
+@pytest.mark.parametrize("log_n", [3, 4, 5, 6, 7, 8, 9, 10, 11])
+def test_ntt_params_match_reference_tables(log_n):
+    g = json.load(open(os.path.join(GOLD, "ntt_params_%d.json" % (1 << log_n))))
+    roots, inv, ninv = api.ntt_params(log_n)
+    import hashlib, struct
+    assert ninv == g["NINV"]
+    assert hashlib.sha256(struct.pack("<%dQ" % g["N"], *[int(v) for v in roots])).hexdigest() == g["ROOTS_sha256"]
+    assert hashlib.sha256(struct.pack("<%dQ" % g["N"], *[int(v) for v in inv])).hexdigest() == g["INVROOTS_sha256"]
+
+
+def test_fri_params_and_proof_size_agree_with_oracle():
+    for d in (6, 12, 15, 16):
+        a, b = api.fri_params(d), orc.fri_params(d)
+        assert (a.n_rounds, list(a.arity_bits)) == (b.n_rounds, list(b.arity_bits))
+        ncols = [85, 135, 20, 16]
+        arr = (ctypes.c_size_t * 4)(*ncols)
+        assert api.lib().vpbs_fri_proof_words(ctypes.byref(a), d, arr, 4) == orc.lib().orc_fri_proof_words(ctypes.byref(b), d, arr, 4)
+
+
+def test_synth_inputs_are_canonical_and_seeded():
+    a = synth.trace(0x5EED0000, 3, 6)
+    b = synth.trace(0x5EED0000, 3, 6)
+    assert (a == b).all() and a.shape == (3, 64) and int(a.max()) < P
+    assert (synth.trace(0x5EED0001, 3, 6) != a).any()
+    s = synth.step_inputs(5)
+    assert {k: v.shape[0] for k, v in s.items()} == {"wires": 135, "zs_partial_products": 20, "quotient": 16, "constants_sigmas": 85}
+    # scalar splitmix64 reference for the first element
+    z = (0x5EED0000 + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    z ^= z >> 31
+    assert int(synth.splitmix64(0x5EED0000, 1)[0]) == z
+
+
+def test_sharding_plan():
+    # rate 8: 8 cosets; coset r fills leaf block brev3(r); 16 cap entries, 2 per coset
+    for world in (1, 2, 4, 8):
+        seen, caps = [], []
+        for rank in range(world):
+            seen += sharding.coset_assignment(3, rank, world)
+            lo, hi = sharding.cap_slice(3, 4, rank, world)
+            caps += list(range(lo, hi))
+        assert sorted(seen) == list(range(8)) and caps == list(range(16))
+    assert sharding.coset_assignment(3, 1, 2) == [1, 5, 3, 7]  # leaf blocks 4..7 <- cosets brev3(4..7)
+    assert sharding.replica_assignment(10, 0, 4) == [0, 1, 2] and sharding.replica_assignment(10, 3, 4) == [8, 9]
+    with pytest.raises(ValueError):
+        sharding.coset_assignment(3, 0, 3)
+
+
+def test_coset_sharded_commit_gloo_world2(tmp_path):
+    """world_size-2 gloo run of the sharded-commit plan: each rank builds the Merkle subtrees of its cosets (oracle as
+    the stand-in compute backend on CPU), one all_gather of cap hashes, result == single-process cap."""
+    script = os.path.join(ROOT, "tests", "gloo_sharded_commit.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SHARDED_COMMIT_OK" in r.stdout

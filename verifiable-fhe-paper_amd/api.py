@@ -1,0 +1,410 @@
+"""ctypes binding of include/vpbs_prover.h (libvpbs_hip.so).  No compute happens in Python."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libvpbs_hip.so")
+P = 0xFFFFFFFF00000001
+POW_ANY = 0xFFFFFFFFFFFFFFFF
+U64P = C.POINTER(C.c_uint64)
+U32P = C.POINTER(C.c_uint32)
+
+
+class VpbsError(RuntimeError):
+    pass
+
+
+class ChallengerStateC(C.Structure):
+    _fields_ = [("sponge", C.c_uint64 * 12), ("input", C.c_uint64 * 8), ("output", C.c_uint64 * 8),
+                ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+
+
+class FriParams(C.Structure):
+    _fields_ = [("rate_bits", C.c_uint), ("cap_height", C.c_uint), ("pow_bits", C.c_uint),
+                ("num_query_rounds", C.c_uint), ("n_rounds", C.c_uint), ("arity_bits", C.c_uint * 16),
+                ("mul_final_by_x", C.c_int)]
+
+
+class FriBatchInfoC(C.Structure):
+    _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_size_t), ("oracle_index", U32P), ("poly_index", U32P)]
+
+
+class FriInstanceC(C.Structure):
+    _fields_ = [("batches", C.POINTER(FriBatchInfoC)), ("n_batches", C.c_size_t)]
+
+
+class StepInputsC(C.Structure):
+    _fields_ = [("log_n", C.c_uint), ("n_wires", C.c_uint), ("n_zs_partial_products", C.c_uint), ("n_quotient", C.c_uint),
+                ("num_challenges", C.c_uint), ("inputs_on_device", C.c_int),
+                ("wires_values", C.c_void_p), ("zs_pp_values", C.c_void_p), ("quotient_coeffs", C.c_void_p),
+                ("constants_sigmas", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
+                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64)]
+
+
+class StepSizesC(C.Structure):
+    _fields_ = [("cap_words", C.c_size_t), ("openings_words", C.c_size_t), ("fri_words", C.c_size_t)]
+
+
+# every symbol include/vpbs_prover.h declares: name -> (restype, argtypes)
+_vp, _sz, _ui, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint, C.c_uint64, C.c_int
+SIGNATURES = {
+    "vpbs_ctx_create": (_i, [_i, _ui, _ui, _ui, C.POINTER(_vp)]),
+    "vpbs_ctx_destroy": (None, [_vp]),
+    "vpbs_last_error": (C.c_char_p, [_vp]),
+    "vpbs_ctx_synchronize": (_i, [_vp]),
+    "vpbs_ctx_stream": (_vp, [_vp]),
+    "vpbs_commit_values": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
+    "vpbs_commit_coeffs": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
+    "vpbs_commit_values_dev": (_i, [_vp, _vp, _ui, _ui, C.POINTER(_vp), U64P]),
+    "vpbs_commit_coeffs_dev": (_i, [_vp, _vp, _ui, _ui, C.POINTER(_vp), U64P]),
+    "vpbs_batch_free": (None, [_vp]),
+    "vpbs_batch_ncols": (_ui, [_vp]),
+    "vpbs_batch_log_n": (_ui, [_vp]),
+    "vpbs_batch_cap": (_i, [_vp, U64P]),
+    "vpbs_batch_coeffs": (_i, [_vp, U64P]),
+    "vpbs_batch_lde_rows": (_i, [_vp, _sz, _sz, _sz, U64P]),
+    "vpbs_batch_eval_ext": (_i, [_vp, U64P, U64P]),
+    "vpbs_batch_open": (_i, [_vp, _sz, U64P, U64P]),
+    "vpbs_challenger_init": (None, [C.POINTER(ChallengerStateC)]),
+    "vpbs_challenger_observe": (None, [C.POINTER(ChallengerStateC), U64P, _sz]),
+    "vpbs_challenger_get": (_u64, [C.POINTER(ChallengerStateC)]),
+    "vpbs_hash_no_pad": (None, [U64P, _sz, U64P]),
+    "vpbs_fri_params_standard": (None, [_ui, C.POINTER(FriParams)]),
+    "vpbs_fri_proof_words": (_sz, [C.POINTER(FriParams), _ui, C.POINTER(_sz), _sz]),
+    "vpbs_fri_prove": (_i, [_vp, C.POINTER(_vp), _sz, C.POINTER(FriInstanceC), C.POINTER(FriParams),
+                            C.POINTER(ChallengerStateC), _u64, U64P]),
+    "vpbs_step_sizes_get": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(StepSizesC)]),
+    "vpbs_prove_step": (_i, [_vp, C.POINTER(StepInputsC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
+    "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
+    "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
+    "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
+    "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
+    "vpbs_k_coset_lde": (_i, [_vp, U64P, _ui, _ui, _ui, _u64, U64P]),
+    "vpbs_k_merkle_cap": (_i, [_vp, U64P, _sz, _ui, _ui, U64P]),
+    "vpbs_k_negacyclic_ntt": (_i, [_vp, U64P, _ui, _ui, _i]),
+    "vpbs_ntt_params": (_i, [_ui, U64P, U64P, U64P]),
+    "vpbs_timing_enable": (_i, [_vp, _i]),
+    "vpbs_timing_report": (_i, [_vp, C.c_char_p, _sz]),
+}
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    args = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-j4"]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VpbsError("libvpbs_hip.so is missing: run __graft_entry__.build() (make -C verifiable-fhe-paper_amd/csrc). "
+                            "There is no CPU fallback for the proving path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(U64P)
+
+
+def _u64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+class ChallengerState:
+    """Host Challenger (plonky2 iop/challenger.rs) of the product library."""
+
+    def __init__(self):
+        self.c = ChallengerStateC()
+        lib().vpbs_challenger_init(C.byref(self.c))
+
+    def clone(self):
+        o = ChallengerState()
+        C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(ChallengerStateC))
+        return o
+
+    def observe(self, elems):
+        e = _u64(elems).reshape(-1)
+        lib().vpbs_challenger_observe(C.byref(self.c), _ptr(e), e.size)
+
+    def get(self):
+        return int(lib().vpbs_challenger_get(C.byref(self.c)))
+
+    def get_n(self, n):
+        return [self.get() for _ in range(n)]
+
+    def get_ext(self):
+        return np.array(self.get_n(2), np.uint64)
+
+    def state_words(self):
+        c = self.c
+        return (list(c.sponge), list(c.input)[:c.input_len], list(c.output)[:c.output_len])
+
+
+def hash_no_pad(x):
+    x = _u64(x).reshape(-1)
+    out = np.zeros(4, np.uint64)
+    lib().vpbs_hash_no_pad(_ptr(x), x.size, _ptr(out))
+    return out
+
+
+def fri_params(degree_bits, **over):
+    p = FriParams()
+    lib().vpbs_fri_params_standard(degree_bits, C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def ntt_params(log_n):
+    n = 1 << log_n
+    roots, inv, ninv = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(1, np.uint64)
+    rc = lib().vpbs_ntt_params(log_n, _ptr(roots), _ptr(inv), _ptr(ninv))
+    if rc:
+        raise VpbsError("vpbs_ntt_params failed: %d" % rc)
+    return roots, inv, int(ninv[0])
+
+
+class Batch:
+    """Device-resident PolynomialBatch handle (fri/oracle.rs)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        self.ncols = lib().vpbs_batch_ncols(handle)
+        self.log_n = lib().vpbs_batch_log_n(handle)
+        self.n = 1 << self.log_n
+
+    def free(self):
+        if self.h:
+            lib().vpbs_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def cap(self):
+        out = np.zeros((1 << self.ctx.cap_height, 4), np.uint64)
+        self.ctx._check(lib().vpbs_batch_cap(self.h, _ptr(out)))
+        return out
+
+    def coeffs(self):
+        out = np.zeros((self.ncols, self.n), np.uint64)
+        self.ctx._check(lib().vpbs_batch_coeffs(self.h, _ptr(out)))
+        return out
+
+    def lde_rows(self, row_start, nrows, step=1):
+        out = np.zeros((nrows, self.ncols), np.uint64)
+        self.ctx._check(lib().vpbs_batch_lde_rows(self.h, row_start, nrows, step, _ptr(out)))
+        return out
+
+    def eval_ext(self, zeta):
+        z = _u64(zeta)
+        out = np.zeros((self.ncols, 2), np.uint64)
+        self.ctx._check(lib().vpbs_batch_eval_ext(self.h, _ptr(z), _ptr(out)))
+        return out
+
+    def open(self, leaf_index):
+        nsib = self.log_n + self.ctx.rate_bits - self.ctx.cap_height
+        leaf, sib = np.zeros(self.ncols, np.uint64), np.zeros((nsib, 4), np.uint64)
+        self.ctx._check(lib().vpbs_batch_open(self.h, leaf_index, _ptr(leaf), _ptr(sib)))
+        return leaf, sib
+
+
+class Context:
+    """One device + one HIP stream (vpbs_ctx).  Not re-entrant: one Context per host thread."""
+
+    def __init__(self, device=0, log_n_max=16, rate_bits=3, cap_height=4):
+        self.h = C.c_void_p()
+        self.rate_bits, self.cap_height = rate_bits, cap_height
+        rc = lib().vpbs_ctx_create(device, log_n_max, rate_bits, cap_height, C.byref(self.h))
+        if rc:
+            self.h = None
+            raise VpbsError("vpbs_ctx_create(device=%d) failed with status %d (no MI355X visible?)" % (device, rc))
+
+    def close(self):
+        if self.h:
+            lib().vpbs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise VpbsError("status %d: %s" % (rc, lib().vpbs_last_error(self.h).decode()))
+
+    def synchronize(self):
+        self._check(lib().vpbs_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().vpbs_ctx_stream(self.h)
+
+    # ---- commits ----
+    def _commit(self, fn, data, ncols=None, log_n=None, want_cap=True):
+        out = C.c_void_p()
+        cap = np.zeros((1 << self.cap_height, 4), np.uint64) if want_cap else None
+        cap_p = _ptr(cap) if want_cap else None
+        if isinstance(data, np.ndarray):
+            data = _u64(data)
+            ncols, n = data.shape
+            log_n = n.bit_length() - 1
+            assert 1 << log_n == n
+            self._check(fn(self.h, _ptr(data), ncols, log_n, C.byref(out), cap_p))
+        else:  # device pointer (int)
+            self._check(fn(self.h, C.c_void_p(int(data)), ncols, log_n, C.byref(out), cap_p))
+        b = Batch(self, out)
+        b.cap_at_commit = cap
+        return b
+
+    def commit_values(self, values):
+        return self._commit(lib().vpbs_commit_values, values)
+
+    def commit_coeffs(self, coeffs):
+        return self._commit(lib().vpbs_commit_coeffs, coeffs)
+
+    def commit_values_dev(self, dptr, ncols, log_n, want_cap=True):
+        return self._commit(lib().vpbs_commit_values_dev, dptr, ncols, log_n, want_cap)
+
+    def commit_coeffs_dev(self, dptr, ncols, log_n, want_cap=True):
+        return self._commit(lib().vpbs_commit_coeffs_dev, dptr, ncols, log_n, want_cap)
+
+    # ---- FRI ----
+    def fri_prove(self, oracles, batches, challenger, params, forced_pow=POW_ANY):
+        """batches: [(point(2), [(oracle_index, poly_index), ...]), ...] -> flat FriProof words."""
+        degree_bits = oracles[0].log_n
+        ncols = (C.c_size_t * len(oracles))(*[o.ncols for o in oracles])
+        words = lib().vpbs_fri_proof_words(C.byref(params), degree_bits, ncols, len(oracles))
+        proof = np.zeros(words, np.uint64)
+        handles = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+        infos = (FriBatchInfoC * len(batches))()
+        keep = []
+        for i, (point, polys) in enumerate(batches):
+            oi = np.array([p[0] for p in polys], np.uint32)
+            pi = np.array([p[1] for p in polys], np.uint32)
+            keep += [oi, pi]
+            infos[i].point[0], infos[i].point[1] = int(point[0]), int(point[1])
+            infos[i].n_polys = len(polys)
+            infos[i].oracle_index = oi.ctypes.data_as(U32P)
+            infos[i].poly_index = pi.ctypes.data_as(U32P)
+        inst = FriInstanceC(infos, len(batches))
+        self._check(lib().vpbs_fri_prove(self.h, handles, len(oracles), C.byref(inst), C.byref(params),
+                                         C.byref(challenger.c), forced_pow, _ptr(proof)))
+        return proof
+
+    # ---- step proof ----
+    def make_step_inputs(self, log_n, wires, zs_pp, quotient, constants_sigmas, circuit_digest, public_inputs,
+                         num_challenges=2, forced_pow=POW_ANY, on_device=False, shapes=None):
+        """wires/zs_pp/quotient: numpy matrices [ncols][n] (host) or device pointers with shapes=(nw, nz, nq)."""
+        si = StepInputsC()
+        si.log_n = log_n
+        keep = []
+        if on_device:
+            nw, nz, nq = shapes
+            si.wires_values, si.zs_pp_values, si.quotient_coeffs = int(wires), int(zs_pp), int(quotient)
+        else:
+            wires, zs_pp, quotient = _u64(wires), _u64(zs_pp), _u64(quotient)
+            keep += [wires, zs_pp, quotient]
+            nw, nz, nq = wires.shape[0], zs_pp.shape[0], quotient.shape[0]
+            si.wires_values = wires.ctypes.data
+            si.zs_pp_values = zs_pp.ctypes.data
+            si.quotient_coeffs = quotient.ctypes.data
+        si.n_wires, si.n_zs_partial_products, si.n_quotient = nw, nz, nq
+        si.num_challenges = num_challenges
+        si.inputs_on_device = 1 if on_device else 0
+        si.constants_sigmas = constants_sigmas.h
+        for i in range(4):
+            si.circuit_digest[i] = int(circuit_digest[i])
+        pi = _u64(public_inputs).reshape(-1)
+        keep.append(pi)
+        si.public_inputs = _ptr(pi)
+        si.n_public_inputs = pi.size
+        si.forced_pow = forced_pow
+        si._keep = keep
+        return si
+
+    def prove_step(self, si):
+        sizes = StepSizesC()
+        self._check(lib().vpbs_step_sizes_get(self.h, C.byref(si), C.byref(sizes)))
+        caps = np.zeros((3, sizes.cap_words // 4, 4), np.uint64)
+        openings = np.zeros((sizes.openings_words // 2, 2), np.uint64)
+        fri = np.zeros(sizes.fri_words, np.uint64)
+        ch = ChallengerState()
+        chal = np.zeros(3 * si.num_challenges + 2, np.uint64)
+        self._check(lib().vpbs_prove_step(self.h, C.byref(si), _ptr(caps), _ptr(openings), _ptr(fri), C.byref(ch.c), _ptr(chal)))
+        return {"caps": caps, "openings": openings, "fri": fri, "challenger": ch, "challenges": chal}
+
+    def step_proof_to_bytes(self, si, n_constants, proof):
+        cap = 8 * (proof["caps"].size + proof["openings"].size + proof["fri"].size + si.n_public_inputs + 8) + 4096
+        buf = (C.c_uint8 * cap)()
+        n = lib().vpbs_step_proof_to_bytes(self.h, C.byref(si), n_constants, _ptr(proof["caps"]), _ptr(proof["openings"]),
+                                           _ptr(proof["fri"]), buf, cap)
+        if n < 0:
+            raise VpbsError("vpbs_step_proof_to_bytes failed: %d" % n)
+        return bytes(buf[:n])
+
+    # ---- kernel-level hooks ----
+    def poseidon_batch(self, states):
+        s = _u64(states).copy()
+        self._check(lib().vpbs_k_poseidon_batch(self.h, _ptr(s), s.shape[0]))
+        return s
+
+    def hash_rows(self, rows):
+        r = _u64(rows)
+        out = np.zeros((r.shape[0], 4), np.uint64)
+        self._check(lib().vpbs_k_hash_rows(self.h, _ptr(r), r.shape[0], r.shape[1], _ptr(out)))
+        return out
+
+    def intt(self, values):
+        v = _u64(values)
+        out = np.zeros_like(v)
+        self._check(lib().vpbs_k_intt(self.h, _ptr(v), v.shape[0], v.shape[1].bit_length() - 1, _ptr(out)))
+        return out
+
+    def coset_lde(self, coeffs, rate_bits=3, shift=7):
+        c = _u64(coeffs)
+        out = np.zeros((c.shape[0], c.shape[1] << rate_bits), np.uint64)
+        self._check(lib().vpbs_k_coset_lde(self.h, _ptr(c), c.shape[0], c.shape[1].bit_length() - 1, rate_bits, shift, _ptr(out)))
+        return out
+
+    def merkle_cap(self, leaves, cap_height):
+        l = _u64(leaves)
+        out = np.zeros((1 << cap_height, 4), np.uint64)
+        self._check(lib().vpbs_k_merkle_cap(self.h, _ptr(l), l.shape[0], l.shape[1], cap_height, _ptr(out)))
+        return out
+
+    def negacyclic_ntt(self, data, inverse=False):
+        d = _u64(data).copy()
+        self._check(lib().vpbs_k_negacyclic_ntt(self.h, _ptr(d), d.shape[0], d.shape[1].bit_length() - 1, 1 if inverse else 0))
+        return d
+
+    # ---- timing ----
+    def timing_enable(self, on=True):
+        self._check(lib().vpbs_timing_enable(self.h, 1 if on else 0))
+
+    def timing_report(self):
+        buf = C.create_string_buffer(8192)
+        self._check(lib().vpbs_timing_report(self.h, buf, 8192))
+        return json.loads(buf.value.decode())

@@ -1,0 +1,514 @@
+// extern "C" surface: context, PolynomialBatch handles, kernel-level hooks.  See include/vpbs_prover.h for the
+// plonky2 function each entry point replaces.
+#include <cstring>
+
+#include "context.h"
+#include "poseidon.h"
+
+using vpbs::DeviceError;
+using vpbs::u64;
+
+// ---------------- ctx internals ----------------
+void* vpbs_ctx::alloc_bytes(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_blocks.find(bytes);
+    if (it != free_blocks.end()) {
+        void* p = it->second;
+        free_blocks.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        trim();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) throw DeviceError{VPBS_ERR_OOM, "hipMalloc(" + std::to_string(bytes) + ") failed"};
+    block_size[p] = bytes;
+    pool_bytes += bytes;
+    return p;
+}
+void vpbs_ctx::release(void* p) {
+    if (!p) return;
+    free_blocks.emplace(block_size.at(p), p);
+}
+void vpbs_ctx::trim() {
+    (void)hipStreamSynchronize(stream);
+    for (auto& kv : free_blocks) {
+        pool_bytes -= kv.first;
+        block_size.erase(kv.second);
+        (void)hipFree(kv.second);
+    }
+    free_blocks.clear();
+}
+const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
+    auto key = std::make_pair(log_n, inverse);
+    auto it = root_tables.find(key);
+    if (it != root_tables.end()) return it->second;
+    u64* t = alloc_words(log_n == 0 ? 1 : ((size_t)1 << log_n) / 2);
+    vpbs::launch_root_table(stream, t, log_n, inverse);
+    root_tables[key] = t;
+    return t;
+}
+const u64* vpbs_ctx::prescale(unsigned log_n, unsigned rb, u64 shift) {
+    auto key = std::make_tuple(log_n, rb, shift);
+    auto it = prescale_tables.find(key);
+    if (it != prescale_tables.end()) return it->second;
+    u64* t = alloc_words((size_t)1 << (log_n + rb));
+    vpbs::launch_prescale_table(stream, t, log_n, rb, shift);
+    prescale_tables[key] = t;
+    return t;
+}
+int vpbs_ctx::timer_id(const char* name) {
+    for (size_t i = 0; i < timer_names.size(); ++i)
+        if (timer_names[i] == name) return (int)i;
+    timer_names.emplace_back(name);
+    return (int)timer_names.size() - 1;
+}
+hipEvent_t vpbs_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void vpbs_ctx::resolve_timing() {
+    if (pending.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto& p : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            auto& t = totals[timer_names[p.name_id]];
+            t.first += ms;
+            t.second += 1;
+        }
+        event_pool.push_back(p.start);
+        event_pool.push_back(p.stop);
+    }
+    pending.clear();
+}
+
+namespace vpbs {
+size_t merkle_layout(size_t n_leaves, unsigned cap_height, std::vector<size_t>& level_off) {
+    unsigned log_leaves = 0;
+    while (((size_t)1 << log_leaves) < n_leaves) ++log_leaves;
+    VPBS_REQUIRE(((size_t)1 << log_leaves) == n_leaves, "leaf count must be a power of two");
+    VPBS_REQUIRE(log_leaves >= cap_height, "tree smaller than its cap");
+    level_off.clear();
+    size_t off = 0;
+    for (unsigned k = 0; k + cap_height <= log_leaves; ++k) {
+        level_off.push_back(off);
+        off += 4 * (n_leaves >> k);
+    }
+    return off;
+}
+
+vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values) {
+    VPBS_REQUIRE(ncols > 0, "ncols == 0");
+    VPBS_REQUIRE(log_n <= ctx->log_n_max, "log_n exceeds the context's log_n_max");
+    auto* b = new vpbs_batch();
+    b->ctx = ctx;
+    b->ncols = ncols;
+    b->log_n = log_n;
+    const size_t n = b->n(), L = b->lde_len();
+    try {
+        b->d_coeffs = ctx->alloc_words((size_t)ncols * n);
+        b->d_lde = ctx->alloc_words((size_t)ncols * L);
+        const size_t dig_words = merkle_layout(L, ctx->cap_height, b->level_off);
+        b->d_digests = ctx->alloc_words(dig_words);
+        if (is_values) {
+            Timed t(ctx, "intt");
+            launch_intt(ctx->stream, d_in, b->d_coeffs, b->d_lde /* scratch */, ctx->roots(log_n, true), ncols, log_n);
+        } else {
+            VPBS_HIP(hipMemcpyAsync(b->d_coeffs, d_in, sizeof(u64) * ncols * n, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        const u64* roots = ctx->roots(log_n, false);
+        const u64* ps = ctx->prescale(log_n, ctx->rate_bits, gl::GENERATOR);
+        {
+            Timed t(ctx, "coset_lde");
+            launch_coset_lde(ctx->stream, b->d_coeffs, b->d_lde, roots, ps, ncols, log_n, ctx->rate_bits);
+        }
+        {
+            Timed t(ctx, "leaf_hash");
+            launch_leaf_hash(ctx->stream, b->d_lde, ncols, L, L, b->d_digests);
+        }
+        {
+            Timed t(ctx, "merkle_levels");
+            launch_merkle_tree(ctx->stream, b->d_digests, b->level_off.data(), b->n_levels(), L);
+        }
+        VPBS_HIP(hipGetLastError());
+    } catch (...) {
+        vpbs_batch_free(b);
+        throw;
+    }
+    return b;
+}
+
+void batch_cap_to_host(vpbs_batch* b, u64* cap_out) {
+    VPBS_HIP(hipMemcpyAsync(cap_out, b->d_digests + b->level_off.back(), sizeof(u64) * ((size_t)4 << b->ctx->cap_height),
+                            hipMemcpyDeviceToHost, b->ctx->stream));
+    VPBS_HIP(hipStreamSynchronize(b->ctx->stream));
+}
+}  // namespace vpbs
+
+// ---------------- error plumbing ----------------
+template <typename F>
+static int guarded(vpbs_ctx* ctx, F&& f) {
+    try {
+        f();
+        return VPBS_OK;
+    } catch (const DeviceError& e) {
+        if (ctx) ctx->err = e.what;
+        return e.status;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what();
+        return VPBS_ERR_INVALID;
+    }
+}
+
+namespace {
+// temporary device copy of a host matrix
+struct DevTemp {
+    vpbs_ctx* c;
+    u64* p;
+    DevTemp(vpbs_ctx* ctx, const u64* host, size_t words) : c(ctx), p(ctx->alloc_words(words)) {
+        if (host) {
+            hipError_t e = hipMemcpyAsync(p, host, words * sizeof(u64), hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                c->release(p);
+                throw DeviceError{VPBS_ERR_DEVICE, std::string("H2D copy: ") + hipGetErrorString(e)};
+            }
+        }
+    }
+    ~DevTemp() {
+        (void)hipStreamSynchronize(c->stream);
+        c->release(p);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, unsigned cap_height, vpbs_ctx** out) {
+    if (!out || log_n_max == 0 || log_n_max + rate_bits > 24 || rate_bits > 4) return VPBS_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_ordinal < 0 || device_ordinal >= count) return VPBS_ERR_DEVICE;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return VPBS_ERR_DEVICE;
+    auto* c = new vpbs_ctx();
+    c->device = device_ordinal;
+    c->log_n_max = log_n_max;
+    c->rate_bits = rate_bits;
+    c->cap_height = cap_height;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return VPBS_ERR_DEVICE;
+    }
+    *out = c;
+    return VPBS_OK;
+}
+
+void vpbs_ctx_destroy(vpbs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->root_tables) c->release(kv.second);
+    for (auto& kv : c->prescale_tables) c->release(kv.second);
+    c->resolve_timing();
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vpbs_last_error(const vpbs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int vpbs_ctx_synchronize(vpbs_ctx* c) {
+    return guarded(c, [&] { VPBS_HIP(hipStreamSynchronize(c->stream)); });
+}
+void* vpbs_ctx_stream(vpbs_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+static int commit_any(vpbs_ctx* c, const u64* data, bool on_device, bool is_values, unsigned ncols, unsigned log_n, vpbs_batch** out,
+                      u64* cap_out) {
+    if (!c || !data || !out) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        VPBS_HIP(hipSetDevice(c->device));
+        vpbs_batch* b = nullptr;
+        if (on_device) {
+            b = vpbs::commit_device(c, data, ncols, log_n, is_values);
+        } else {
+            VPBS_REQUIRE(log_n <= c->log_n_max, "log_n exceeds the context's log_n_max");
+            DevTemp tmp(c, data, (size_t)ncols << log_n);
+            b = vpbs::commit_device(c, tmp.p, ncols, log_n, is_values);
+        }
+        if (cap_out) {
+            try {
+                vpbs::batch_cap_to_host(b, cap_out);
+            } catch (...) {
+                vpbs_batch_free(b);
+                throw;
+            }
+        }
+        *out = b;
+    });
+}
+int vpbs_commit_values(vpbs_ctx* c, const uint64_t* v, unsigned ncols, unsigned log_n, vpbs_batch** out, uint64_t* cap) {
+    return commit_any(c, v, false, true, ncols, log_n, out, cap);
+}
+int vpbs_commit_coeffs(vpbs_ctx* c, const uint64_t* v, unsigned ncols, unsigned log_n, vpbs_batch** out, uint64_t* cap) {
+    return commit_any(c, v, false, false, ncols, log_n, out, cap);
+}
+int vpbs_commit_values_dev(vpbs_ctx* c, const uint64_t* v, unsigned ncols, unsigned log_n, vpbs_batch** out, uint64_t* cap) {
+    return commit_any(c, v, true, true, ncols, log_n, out, cap);
+}
+int vpbs_commit_coeffs_dev(vpbs_ctx* c, const uint64_t* v, unsigned ncols, unsigned log_n, vpbs_batch** out, uint64_t* cap) {
+    return commit_any(c, v, true, false, ncols, log_n, out, cap);
+}
+
+void vpbs_batch_free(vpbs_batch* b) {
+    if (!b) return;
+    // stream-ordered reuse: later work on the same stream may take these blocks; nothing else touches them
+    b->ctx->release(b->d_coeffs);
+    b->ctx->release(b->d_lde);
+    b->ctx->release(b->d_digests);
+    delete b;
+}
+unsigned vpbs_batch_ncols(const vpbs_batch* b) { return b ? b->ncols : 0; }
+unsigned vpbs_batch_log_n(const vpbs_batch* b) { return b ? b->log_n : 0; }
+
+int vpbs_batch_cap(vpbs_batch* b, uint64_t* cap_out) {
+    if (!b || !cap_out) return VPBS_ERR_INVALID;
+    return guarded(b->ctx, [&] { vpbs::batch_cap_to_host(b, cap_out); });
+}
+int vpbs_batch_coeffs(vpbs_batch* b, uint64_t* out) {
+    if (!b || !out) return VPBS_ERR_INVALID;
+    return guarded(b->ctx, [&] {
+        VPBS_HIP(hipMemcpyAsync(out, b->d_coeffs, sizeof(u64) * b->ncols * b->n(), hipMemcpyDeviceToHost, b->ctx->stream));
+        VPBS_HIP(hipStreamSynchronize(b->ctx->stream));
+    });
+}
+
+int vpbs_batch_lde_rows(vpbs_batch* b, size_t row_start, size_t nrows, size_t step, uint64_t* out) {
+    if (!b || !out) return VPBS_ERR_INVALID;
+    return guarded(b->ctx, [&] {
+        vpbs_ctx* c = b->ctx;
+        const size_t L = b->lde_len();
+        const unsigned log_L = b->log_n + c->rate_bits;
+        VPBS_REQUIRE(nrows <= vpbs::MAX_QUERIES * (size_t)4096, "too many rows in one call");
+        // reuse the query-open kernel: one "tree" without siblings, chunks of MAX_QUERIES rows
+        u64* d_out = c->alloc_words(nrows * b->ncols);
+        vpbs::OpenArgs* d_args = static_cast<vpbs::OpenArgs*>(c->alloc_bytes(sizeof(vpbs::OpenArgs)));
+        for (size_t done = 0; done < nrows; done += vpbs::MAX_QUERIES) {
+            vpbs::OpenArgs a{};
+            const unsigned cnt = (unsigned)std::min<size_t>(vpbs::MAX_QUERIES, nrows - done);
+            a.n_trees = 1;
+            a.n_queries = cnt;
+            a.record_words = b->ncols;
+            a.trees[0].data0 = b->d_lde;
+            a.trees[0].col_stride = L;
+            a.trees[0].leaf_len = b->ncols;
+            for (unsigned q = 0; q < cnt; ++q) {
+                const size_t idx = (row_start + done + q) * step;
+                VPBS_REQUIRE(idx < L, "LDE row out of range");
+                a.x_index[q] = gl::bitrev32((vpbs::u32)idx, log_L);
+            }
+            VPBS_HIP(hipMemcpyAsync(d_args, &a, sizeof a, hipMemcpyHostToDevice, c->stream));
+            vpbs::launch_open_queries(c->stream, d_args, 1, cnt, d_out + done * b->ncols);
+            VPBS_HIP(hipStreamSynchronize(c->stream));
+        }
+        VPBS_HIP(hipMemcpy(out, d_out, sizeof(u64) * nrows * b->ncols, hipMemcpyDeviceToHost));
+        c->release(d_out);
+        c->release(d_args);
+    });
+}
+
+int vpbs_batch_eval_ext(vpbs_batch* b, const uint64_t zeta[2], uint64_t* out) {
+    if (!b || !zeta || !out) return VPBS_ERR_INVALID;
+    return guarded(b->ctx, [&] {
+        vpbs_ctx* c = b->ctx;
+        const size_t n = b->n();
+        const unsigned chunks = (unsigned)((n + 4095) / 4096);
+        u64* zpow = c->alloc_words(2 * n);
+        u64* d_out = c->alloc_words(2 * (size_t)b->ncols * (1 + chunks));
+        vpbs::launch_ext_powers(c->stream, gl::Ext{zeta[0], zeta[1]}, n, zpow);
+        vpbs::launch_eval_ext(c->stream, b->d_coeffs, b->ncols, n, n, zpow, d_out);
+        VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * 2 * b->ncols, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+        c->release(zpow);
+        c->release(d_out);
+    });
+}
+
+int vpbs_batch_open(vpbs_batch* b, size_t leaf_index, uint64_t* leaf_out, uint64_t* siblings_out) {
+    if (!b || !leaf_out || !siblings_out) return VPBS_ERR_INVALID;
+    return guarded(b->ctx, [&] {
+        vpbs_ctx* c = b->ctx;
+        VPBS_REQUIRE(leaf_index < b->lde_len(), "leaf index out of range");
+        vpbs::OpenArgs a{};
+        a.n_trees = 1;
+        a.n_queries = 1;
+        vpbs::OpenTree& t = a.trees[0];
+        t.data0 = b->d_lde;
+        t.digests = b->d_digests;
+        t.col_stride = b->lde_len();
+        t.leaf_len = b->ncols;
+        t.n_siblings = b->n_levels() - 1;
+        for (unsigned k = 0; k < b->n_levels(); ++k) t.level_off[k] = b->level_off[k];
+        a.record_words = b->ncols + 4 * (size_t)t.n_siblings;
+        a.x_index[0] = leaf_index;
+        u64* d_out = c->alloc_words(a.record_words);
+        auto* d_args = static_cast<vpbs::OpenArgs*>(c->alloc_bytes(sizeof a));
+        VPBS_HIP(hipMemcpyAsync(d_args, &a, sizeof a, hipMemcpyHostToDevice, c->stream));
+        vpbs::launch_open_queries(c->stream, d_args, 1, 1, d_out);
+        std::vector<u64> rec(a.record_words);
+        VPBS_HIP(hipMemcpyAsync(rec.data(), d_out, sizeof(u64) * a.record_words, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+        std::memcpy(leaf_out, rec.data(), sizeof(u64) * b->ncols);
+        std::memcpy(siblings_out, rec.data() + b->ncols, sizeof(u64) * 4 * t.n_siblings);
+        c->release(d_out);
+        c->release(d_args);
+    });
+}
+
+// ---------------- kernel-level hooks ----------------
+int vpbs_k_poseidon_batch(vpbs_ctx* c, uint64_t* states, size_t n) {
+    if (!c || !states) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        DevTemp d(c, states, 12 * n);
+        vpbs::launch_permute_batch(c->stream, d.p, n);
+        VPBS_HIP(hipMemcpyAsync(states, d.p, sizeof(u64) * 12 * n, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int vpbs_k_hash_rows(vpbs_ctx* c, const uint64_t* rows, size_t n, unsigned len, uint64_t* out) {
+    if (!c || !rows || !out || len == 0) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        DevTemp d(c, rows, n * len);
+        DevTemp o(c, nullptr, 4 * n);
+        vpbs::launch_hash_rows(c->stream, d.p, n, len, o.p);
+        VPBS_HIP(hipMemcpyAsync(out, o.p, sizeof(u64) * 4 * n, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int vpbs_k_intt(vpbs_ctx* c, const uint64_t* values, unsigned ncols, unsigned log_n, uint64_t* coeffs_out) {
+    if (!c || !values || !coeffs_out) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        const size_t words = (size_t)ncols << log_n;
+        DevTemp in(c, values, words), out(c, nullptr, words), scratch(c, nullptr, words);
+        vpbs::launch_intt(c->stream, in.p, out.p, scratch.p, c->roots(log_n, true), ncols, log_n);
+        VPBS_HIP(hipMemcpyAsync(coeffs_out, out.p, sizeof(u64) * words, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int vpbs_k_coset_lde(vpbs_ctx* c, const uint64_t* coeffs, unsigned ncols, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                     uint64_t* out_host) {
+    if (!c || !coeffs || !out_host) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        const size_t words = (size_t)ncols << log_n;
+        DevTemp in(c, coeffs, words), out(c, nullptr, words << rate_bits);
+        vpbs::launch_coset_lde(c->stream, in.p, out.p, c->roots(log_n, false), c->prescale(log_n, rate_bits, shift), ncols, log_n,
+                               rate_bits);
+        VPBS_HIP(hipMemcpyAsync(out_host, out.p, sizeof(u64) * (words << rate_bits), hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int vpbs_k_merkle_cap(vpbs_ctx* c, const uint64_t* leaves, size_t n_leaves, unsigned leaf_len, unsigned cap_height, uint64_t* cap_out) {
+    if (!c || !leaves || !cap_out || leaf_len == 0) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        std::vector<size_t> off;
+        const size_t words = vpbs::merkle_layout(n_leaves, cap_height, off);
+        DevTemp in(c, leaves, n_leaves * leaf_len), dig(c, nullptr, words);
+        if (leaf_len <= 4) {
+            // hash_or_noop: padded copy
+            std::vector<u64> padded(4 * n_leaves, 0);
+            for (size_t i = 0; i < n_leaves; ++i)
+                for (unsigned k = 0; k < leaf_len; ++k) padded[4 * i + k] = leaves[i * leaf_len + k];
+            VPBS_HIP(hipMemcpyAsync(dig.p, padded.data(), sizeof(u64) * 4 * n_leaves, hipMemcpyHostToDevice, c->stream));
+            VPBS_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            vpbs::launch_hash_rows(c->stream, in.p, n_leaves, leaf_len, dig.p);
+        }
+        vpbs::launch_merkle_tree(c->stream, dig.p, off.data(), (unsigned)off.size(), n_leaves);
+        VPBS_HIP(hipMemcpyAsync(cap_out, dig.p + off.back(), sizeof(u64) * ((size_t)4 << cap_height), hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv) {
+    if (!roots || !invroots || !ninv || log_n == 0 || log_n > 16) return VPBS_ERR_INVALID;
+    // gen_param_file.sage: psi = 7^((p-1)/2N); ROOTS[j] = psi^bitrev(j); INVROOTS[j] = psi^-bitrev(j); NINV = N^-1
+    const size_t n = (size_t)1 << log_n;
+    const u64 psi = gl::pow(gl::GENERATOR, (gl::P - 1) / (2 * n)), psi_inv = gl::inv(psi);
+    for (size_t j = 0; j < n; ++j) {
+        const u64 e = gl::bitrev32((vpbs::u32)j, log_n);
+        roots[j] = gl::pow(psi, e);
+        invroots[j] = gl::pow(psi_inv, e);
+    }
+    *ninv = gl::inv((u64)n);
+    return VPBS_OK;
+}
+int vpbs_k_negacyclic_ntt(vpbs_ctx* c, uint64_t* data, unsigned batch, unsigned log_n, int inverse) {
+    if (!c || !data || log_n == 0 || log_n > 11) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        const size_t n = (size_t)1 << log_n;
+        std::vector<u64> roots(n), inv(n);
+        u64 ninv;
+        vpbs_ntt_params(log_n, roots.data(), inv.data(), &ninv);
+        DevTemp tab(c, inverse ? inv.data() : roots.data(), n), d(c, data, batch * n);
+        vpbs::launch_negacyclic(c->stream, d.p, tab.p, batch, log_n, inverse != 0, ninv);
+        VPBS_HIP(hipMemcpyAsync(data, d.p, sizeof(u64) * batch * n, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---------------- timing ----------------
+int vpbs_timing_enable(vpbs_ctx* c, int on) {
+    if (!c) return VPBS_ERR_INVALID;
+    c->resolve_timing();
+    c->timing = on != 0;
+    return VPBS_OK;
+}
+int vpbs_timing_report(vpbs_ctx* c, char* buf, size_t len) {
+    if (!c || !buf || len < 4) return VPBS_ERR_INVALID;
+    c->resolve_timing();
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : c->totals) {
+        char tmp[256];
+        std::snprintf(tmp, sizeof tmp, "%s\"%s\": {\"ms\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first,
+                      kv.second.second);
+        s += tmp;
+        first = false;
+    }
+    s += "}";
+    c->totals.clear();
+    if (s.size() + 1 > len) return VPBS_ERR_INVALID;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return VPBS_OK;
+}
+
+// ---------------- host-side Challenger / hashing (iop/challenger.rs, hash/hashing.rs) ----------------
+void vpbs_challenger_init(vpbs_challenger_state* ch) { std::memset(ch, 0, sizeof *ch); }
+static void duplexing(vpbs_challenger_state* ch) {
+    for (uint32_t i = 0; i < ch->input_len; ++i) ch->sponge[i] = ch->input[i];  // overwrite mode
+    ch->input_len = 0;
+    poseidon::permute(ch->sponge);
+    for (int i = 0; i < 8; ++i) ch->output[i] = ch->sponge[i];
+    ch->output_len = 8;
+}
+void vpbs_challenger_observe(vpbs_challenger_state* ch, const uint64_t* e, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        ch->output_len = 0;
+        ch->input[ch->input_len++] = e[i];
+        if (ch->input_len == 8) duplexing(ch);
+    }
+}
+uint64_t vpbs_challenger_get(vpbs_challenger_state* ch) {
+    if (ch->input_len != 0 || ch->output_len == 0) duplexing(ch);
+    return ch->output[--ch->output_len];
+}
+void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) { poseidon::hash_no_pad_host(in, n, out); }
+
+}  // extern "C"

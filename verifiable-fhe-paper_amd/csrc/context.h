@@ -1,0 +1,110 @@
+// Prover context: one device, one HIP stream, a size-keyed device-memory pool (steady-state step proofs allocate
+// nothing), cached twiddle / coset-power tables, and optional per-kernel HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vpbs_prover.h"
+#include "kernels.h"
+
+namespace vpbs {
+struct DeviceError {
+    int status;
+    std::string what;
+};
+
+#define VPBS_HIP(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            throw ::vpbs::DeviceError{e_ == hipErrorOutOfMemory ? VPBS_ERR_OOM : VPBS_ERR_DEVICE,              \
+                                      std::string(#expr) + ": " + hipGetErrorString(e_)};                      \
+    } while (0)
+#define VPBS_REQUIRE(cond, msg)                                         \
+    do {                                                                \
+        if (!(cond)) throw ::vpbs::DeviceError{VPBS_ERR_INVALID, msg};  \
+    } while (0)
+}  // namespace vpbs
+
+struct vpbs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned log_n_max = 0, rate_bits = 3, cap_height = 4;
+    std::string err;
+
+    // ---- device memory pool ----
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> block_size;
+    size_t pool_bytes = 0;
+    void* alloc_bytes(size_t bytes);
+    vpbs::u64* alloc_words(size_t words) { return static_cast<vpbs::u64*>(alloc_bytes(words * sizeof(vpbs::u64))); }
+    void release(void* p);
+    void trim();
+
+    // ---- tables ----
+    std::map<std::pair<unsigned, bool>, vpbs::u64*> root_tables;                 // (log_n, inverse)
+    std::map<std::tuple<unsigned, unsigned, vpbs::u64>, vpbs::u64*> prescale_tables;  // (log_n, rate_bits, shift)
+    const vpbs::u64* roots(unsigned log_n, bool inverse);
+    const vpbs::u64* prescale(unsigned log_n, unsigned rate_bits, vpbs::u64 shift);
+
+    // ---- timing ----
+    bool timing = false;
+    struct Pending {
+        int name_id;
+        hipEvent_t start, stop;
+    };
+    std::vector<std::string> timer_names;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<double, long>> totals;
+    int timer_id(const char* name);
+    hipEvent_t get_event();
+    void resolve_timing();
+};
+
+namespace vpbs {
+// RAII: HIP events around a group of launches on the ctx stream (no-op unless timing is enabled)
+struct Timed {
+    vpbs_ctx* c;
+    int id = -1;
+    hipEvent_t start = nullptr;
+    Timed(vpbs_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->timing) return;
+        id = c->timer_id(name);
+        start = c->get_event();
+        (void)hipEventRecord(start, c->stream);
+    }
+    ~Timed() {
+        if (id < 0) return;
+        hipEvent_t stop = c->get_event();
+        (void)hipEventRecord(stop, c->stream);
+        c->pending.push_back({id, start, stop});
+    }
+};
+}  // namespace vpbs
+
+struct vpbs_batch {
+    vpbs_ctx* ctx = nullptr;
+    unsigned ncols = 0, log_n = 0;
+    vpbs::u64* d_coeffs = nullptr;   // [ncols][n]
+    vpbs::u64* d_lde = nullptr;      // [ncols][n << rate_bits], leaf order
+    vpbs::u64* d_digests = nullptr;  // Merkle levels back to back
+    std::vector<size_t> level_off;   // word offset of each level; last level = cap
+    size_t n() const { return (size_t)1 << log_n; }
+    size_t lde_len() const { return n() << ctx->rate_bits; }
+    unsigned n_levels() const { return (unsigned)level_off.size(); }
+};
+
+namespace vpbs {
+// Merkle level layout for a tree with n_leaves leaves and cap height h: returns total words
+size_t merkle_layout(size_t n_leaves, unsigned cap_height, std::vector<size_t>& level_off);
+// commit a device-resident matrix (values or coefficients); returns a new batch
+vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values);
+void batch_cap_to_host(vpbs_batch* b, u64* cap_out);
+}  // namespace vpbs

@@ -1,0 +1,180 @@
+// Opening evaluation, alpha-combination, division by (X - z), FRI folding and query gathering for gfx950.
+// Replaces plonky2 0.2.0 plonk/proof.rs `OpeningSet::new` (p.to_extension().eval(z)), util/reducing.rs
+// `ReducingFactor::{reduce_polys_base, shift_poly}`, field polynomial `divide_by_linear`, fri/prover.rs
+// `fri_committed_trees` (reduce_with_powers fold) and `fri_prover_query_rounds` (tree.get / tree.prove gathers) --
+// reached from prove() at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364.
+// All of these are streaming passes over coefficient columns (HBM-bound).  Field arithmetic is exact, so the parallel
+// forms below (dot products with a power table, suffix-scan division) give the same canonical values as the
+// reference's sequential Horner loops.
+#include "kernels.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned THREADS = 256;
+
+__device__ __forceinline__ gl::Ext load_ext(const u64* p, size_t i) {
+    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(p)[i];
+    return gl::Ext{v.x, v.y};
+}
+__device__ __forceinline__ void store_ext(u64* p, size_t i, gl::Ext e) {
+    reinterpret_cast<ulonglong2*>(p)[i] = make_ulonglong2(e.c0, e.c1);
+}
+
+__global__ void ext_powers_kernel(gl::Ext z, size_t n, u64* out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) store_ext(out, i, gl::pow(z, i));
+}
+
+// block-wide sum of extension elements (blockDim.x == THREADS); result valid in thread 0
+__device__ gl::Ext block_sum(gl::Ext v, u64* sh /* [2*THREADS] */) {
+    sh[threadIdx.x] = v.c0;
+    sh[THREADS + threadIdx.x] = v.c1;
+    __syncthreads();
+    for (unsigned d = THREADS / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            sh[threadIdx.x] = gl::add(sh[threadIdx.x], sh[threadIdx.x + d]);
+            sh[THREADS + threadIdx.x] = gl::add(sh[THREADS + threadIdx.x], sh[THREADS + threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    return gl::Ext{sh[0], sh[THREADS]};
+}
+
+// grid (chunks, ncols): partial[c][chunk] = sum over the chunk of coeffs[c][i] * zpow[i]
+__global__ void __launch_bounds__(THREADS)
+eval_partial_kernel(const u64* __restrict__ coeffs, size_t n, size_t col_stride, const u64* __restrict__ zpow,
+                    unsigned chunk_len, u64* __restrict__ partial) {
+    __shared__ u64 sh[2 * THREADS];
+    const u64* col = coeffs + blockIdx.y * col_stride;
+    const size_t begin = (size_t)blockIdx.x * chunk_len;
+    gl::Ext acc = gl::ext(0);
+    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS)
+        acc = gl::add(acc, gl::mul(load_ext(zpow, i), col[i]));
+    const gl::Ext tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) store_ext(partial, (size_t)blockIdx.y * gridDim.x + blockIdx.x, tot);
+}
+__global__ void eval_finish_kernel(const u64* __restrict__ partial, unsigned chunks, unsigned ncols, u64* __restrict__ out) {
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    gl::Ext acc = gl::ext(0);
+    for (unsigned k = 0; k < chunks; ++k) acc = gl::add(acc, load_ext(partial, (size_t)c * chunks + k));
+    store_ext(out, c, acc);
+}
+
+__global__ void __launch_bounds__(THREADS)
+combine_kernel(const u64* const* __restrict__ polys, unsigned n_polys, const u64* __restrict__ alpha_pows, size_t n,
+               u64* __restrict__ f0, u64* __restrict__ f1) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n) return;
+    gl::Ext acc = gl::ext(0);
+    for (unsigned j = 0; j < n_polys; ++j) acc = gl::add(acc, gl::mul(load_ext(alpha_pows, j), polys[j][i]));
+    f0[i] = acc.c0;
+    f1[i] = acc.c1;
+}
+
+// Single workgroup of 1024 threads: q_k = z^-(k+1) * sum_{i>k} F_i z^i, final_k = final_k*scale + q_k, q_{n-1} = 0.
+__global__ void __launch_bounds__(1024)
+divide_accumulate_kernel(const u64* __restrict__ f0, const u64* __restrict__ f1, const u64* __restrict__ zpow,
+                         const u64* __restrict__ zinvpow, gl::Ext scale, size_t n, u64* __restrict__ fin0, u64* __restrict__ fin1) {
+    __shared__ u64 sh0[1024], sh1[1024];
+    const unsigned T = 1024;
+    const size_t per = (n + T - 1) / T;
+    const size_t begin = threadIdx.x * per, end = begin + per < n ? begin + per : n;
+    // local total of t_i = F_i z^i over the chunk
+    gl::Ext tot = gl::ext(0);
+    for (size_t i = begin; i < end; ++i) tot = gl::add(tot, gl::mul(gl::Ext{f0[i], f1[i]}, load_ext(zpow, i)));
+    sh0[threadIdx.x] = tot.c0;
+    sh1[threadIdx.x] = tot.c1;
+    __syncthreads();
+    // inclusive suffix scan over chunk totals (Hillis-Steele)
+    for (unsigned d = 1; d < T; d <<= 1) {
+        gl::Ext v = gl::Ext{sh0[threadIdx.x], sh1[threadIdx.x]};
+        if (threadIdx.x + d < T) v = gl::add(v, gl::Ext{sh0[threadIdx.x + d], sh1[threadIdx.x + d]});
+        __syncthreads();
+        sh0[threadIdx.x] = v.c0;
+        sh1[threadIdx.x] = v.c1;
+        __syncthreads();
+    }
+    // suffix sum over everything strictly after this chunk
+    gl::Ext run = threadIdx.x + 1 < T ? gl::Ext{sh0[threadIdx.x + 1], sh1[threadIdx.x + 1]} : gl::ext(0);
+    for (size_t k = end; k-- > begin;) {
+        // run == sum_{i>k} t_i
+        gl::Ext q = k + 1 < n ? gl::mul(run, load_ext(zinvpow, k + 1)) : gl::ext(0);
+        const gl::Ext f = gl::add(gl::mul(gl::Ext{fin0[k], fin1[k]}, scale), q);
+        run = gl::add(run, gl::mul(gl::Ext{f0[k], f1[k]}, load_ext(zpow, k)));
+        fin0[k] = f.c0;
+        fin1[k] = f.c1;
+    }
+}
+
+__global__ void shift_up_kernel(const u64* in0, const u64* in1, u64* c0, u64* c1, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    c0[i] = i ? in0[i - 1] : 0;
+    c1[i] = i ? in1[i - 1] : 0;
+}
+
+__global__ void __launch_bounds__(THREADS)
+fold_kernel(const u64* __restrict__ in0, const u64* __restrict__ in1, size_t n_out, unsigned arity_bits, gl::Ext beta,
+            u64* __restrict__ out0, u64* __restrict__ out1) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n_out) return;
+    const unsigned arity = 1u << arity_bits;
+    gl::Ext acc = gl::ext(0);
+    for (unsigned j = arity; j-- > 0;) acc = gl::add(gl::mul(acc, beta), gl::Ext{in0[(i << arity_bits) + j], in1[(i << arity_bits) + j]});
+    out0[i] = acc.c0;
+    out1[i] = acc.c1;
+}
+
+// grid (n_trees, n_queries): one workgroup copies one (leaf, Merkle path) record
+__global__ void __launch_bounds__(THREADS) open_queries_kernel(const OpenArgs* __restrict__ a, u64* __restrict__ out) {
+    const OpenTree& t = a->trees[blockIdx.x];
+    const size_t idx = a->x_index[blockIdx.y] >> t.index_shift;
+    u64* rec = out + blockIdx.y * a->record_words + t.out_off;
+    if (t.data1 == nullptr) {
+        for (unsigned e = threadIdx.x; e < t.leaf_len; e += THREADS) rec[e] = t.data0[e * t.col_stride + idx];
+    } else {
+        for (unsigned e = threadIdx.x; e < t.leaf_len; e += THREADS)
+            rec[e] = ((e & 1) ? t.data1 : t.data0)[(idx << t.arity_bits) + (e >> 1)];
+    }
+    for (unsigned w = threadIdx.x; w < 4 * t.n_siblings; w += THREADS) {
+        const unsigned k = w >> 2;
+        rec[t.leaf_len + w] = t.digests[t.level_off[k] + 4 * ((idx >> k) ^ 1) + (w & 3)];
+    }
+}
+}  // namespace
+
+void launch_ext_powers(hipStream_t s, gl::Ext z, size_t n, u64* out) {
+    hipLaunchKernelGGL(ext_powers_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z, n, out);
+}
+
+// scratch-free two-step evaluation: partial sums live at the tail of `out` (caller provides [ncols*(1+chunks)][2])
+void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n, size_t col_stride, const u64* zpow, u64* out) {
+    const unsigned chunk_len = 4096;
+    const unsigned chunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    u64* partial = out + 2 * (size_t)ncols;
+    hipLaunchKernelGGL(eval_partial_kernel, dim3(chunks, ncols), dim3(THREADS), 0, s, coeffs, n, col_stride, zpow, chunk_len, partial);
+    hipLaunchKernelGGL(eval_finish_kernel, dim3((ncols + 63) / 64), dim3(64), 0, s, (const u64*)partial, chunks, ncols, out);
+}
+
+void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1) {
+    hipLaunchKernelGGL(combine_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, polys, n_polys, alpha_pows, n, f0, f1);
+}
+
+void launch_divide_accumulate(hipStream_t s, const u64* f0, const u64* f1, const u64* zpow, const u64* zinvpow, gl::Ext scale,
+                              size_t n, u64* fin0, u64* fin1) {
+    hipLaunchKernelGGL(divide_accumulate_kernel, dim3(1), dim3(1024), 0, s, f0, f1, zpow, zinvpow, scale, n, fin0, fin1);
+}
+
+void launch_shift_up(hipStream_t s, const u64* in0, const u64* in1, u64* out0, u64* out1, size_t n) {
+    hipLaunchKernelGGL(shift_up_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in0, in1, out0, out1, n);
+}
+
+void launch_fold(hipStream_t s, const u64* in0, const u64* in1, size_t n_out, unsigned arity_bits, gl::Ext beta, u64* out0, u64* out1) {
+    hipLaunchKernelGGL(fold_kernel, dim3((n_out + THREADS - 1) / THREADS), dim3(THREADS), 0, s, in0, in1, n_out, arity_bits, beta, out0, out1);
+}
+
+void launch_open_queries(hipStream_t s, const OpenArgs* d_args, unsigned n_trees, unsigned n_queries, u64* out) {
+    hipLaunchKernelGGL(open_queries_kernel, dim3(n_trees, n_queries), dim3(THREADS), 0, s, d_args, out);
+}
+}  // namespace vpbs

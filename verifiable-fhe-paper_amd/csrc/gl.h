@@ -1,0 +1,140 @@
+// Goldilocks field GF(p), p = 2^64 - 2^32 + 1, and GF(p^2) = F[X]/(X^2 - 7): product arithmetic, host + gfx950.
+//
+// Role in the reference: the types behind `GoldilocksField` / `QuadraticExtension<GoldilocksField>` selected at
+// /root/reference/src/main.rs:33-35 (plonky2_field 0.2.0, pinned by /root/reference/Cargo.lock:396-399).
+// Device form: the 64x64->128 product is four v_mad_u64_u32 (measured 4.9 cyc/wave64 on gfx950, profiles/
+// r01_microbench_valu.txt -- integer multiply is NOT quarter-rate on CDNA4) followed by the 2^64 = 2^32-1,
+// 2^96 = -1 reduction.  "canonical" = value < p; the *_nc forms accept and return any u64 residue.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace gl {
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+constexpr u64 P = 0xFFFFFFFF00000001ull;
+constexpr u64 EPS = 0xFFFFFFFFull;
+constexpr u64 GENERATOR = 7;                          // MULTIPLICATIVE_GROUP_GENERATOR == coset_shift()
+constexpr u64 TWO_ADIC_GENERATOR = 1753635133440165772ull;  // 7^((p-1)/2^32)
+constexpr unsigned TWO_ADICITY = 32;
+
+GL_HD u64 canon(u64 x) { return x >= P ? x - P : x; }
+
+// canonical in, canonical out
+GL_HD u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a || s >= P) s -= P;
+    return s;
+}
+GL_HD u64 sub(u64 a, u64 b) {
+    u64 d = a - b;
+    if (a < b) d += P;
+    return d;
+}
+GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
+
+// any u64 residues in, any u64 residue out (no final conditional subtraction)
+GL_HD u64 add_nc(u64 a, u64 b_canonical) {
+    u64 s = a + b_canonical;
+    if (s < b_canonical) s += EPS;  // wrapped: 2^64 = eps; cannot wrap twice because b < p
+    return s;
+}
+
+GL_HD void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t0 = (u64)a0 * b0;
+    const u64 t1 = (u64)a1 * b0 + (t0 >> 32);
+    const u64 t2 = (u64)a0 * b1 + (u32)t1;
+    lo = (t2 << 32) | (u32)t0;
+    hi = (u64)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
+// reduce a 128-bit value to a u64 residue (not necessarily canonical)
+GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
+    const u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;            // borrow: -2^64 = -eps
+    const u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
+    u64 r = t0 + t1;
+    if (r < t1) r += EPS;
+    return r;
+}
+GL_HD u64 mul_nc(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    return reduce128_nc(lo, hi);
+}
+GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
+GL_HD u64 sqr(u64 a) { return mul(a, a); }
+
+GL_HD u64 pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+GL_HD u64 root_of_unity(unsigned k) {  // primitive_root_of_unity(k)
+    u64 g = TWO_ADIC_GENERATOR;
+    for (unsigned i = k; i < TWO_ADICITY; ++i) g = mul(g, g);
+    return g;
+}
+
+// ---- GF(p^2), W = 7 ----
+struct Ext {
+    u64 c0, c1;
+};
+GL_HD Ext ext(u64 a, u64 b = 0) { return Ext{a, b}; }
+GL_HD Ext add(Ext a, Ext b) { return Ext{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+GL_HD Ext sub(Ext a, Ext b) { return Ext{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+GL_HD Ext mul(Ext a, Ext b) {
+    const u64 a1b1 = mul(a.c1, b.c1);
+    // 7*x = 8x - x
+    const u64 seven = sub(mul(a1b1, 8), a1b1);
+    return Ext{add(mul(a.c0, b.c0), seven), add(mul(a.c0, b.c1), mul(a.c1, b.c0))};
+}
+GL_HD Ext mul(Ext a, u64 s) { return Ext{mul(a.c0, s), mul(a.c1, s)}; }
+GL_HD Ext pow(Ext b, u64 e) {
+    Ext r = ext(1);
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD Ext inv(Ext a) {
+    const u64 a1sq = mul(a.c1, a.c1);
+    const u64 norm = sub(mul(a.c0, a.c0), sub(mul(a1sq, 8), a1sq));
+    const u64 ni = inv(norm);
+    return Ext{mul(a.c0, ni), mul(neg(a.c1), ni)};
+}
+GL_HD bool eq(Ext a, Ext b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+
+GL_HD u32 bitrev32(u32 x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    u32 r = 0;
+    for (unsigned i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+#endif
+}
+}  // namespace gl

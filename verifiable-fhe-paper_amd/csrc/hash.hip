@@ -1,0 +1,152 @@
+// Batched Poseidon sponge over LDE rows, Merkle levels + cap, proof-of-work search, for gfx950.
+// Replaces plonky2 0.2.0 hash/merkle_tree.rs `MerkleTree::new` (leaf digests = H::hash_or_noop, parents =
+// H::two_to_one), hash/hashing.rs `hash_n_to_m_no_pad` (overwrite-mode sponge, rate 8) and fri/prover.rs
+// `fri_proof_of_work`, reached from prove() at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364
+// (SURVEY.md 8a rows a5/a6/a11).  One lane = one leaf / node / nonce: the column-major, leaf-ordered LDE makes every
+// absorb a fully coalesced 512-B wave read.  Integer-VALU bound (~21k instructions per permutation); no MFMA.
+#include "kernels.h"
+#include "poseidon.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned THREADS = 256;
+
+__global__ void __launch_bounds__(THREADS)
+leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* __restrict__ digests) {
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= n_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = 0;
+    if (ncols <= 4) {  // hash_or_noop: leaves of <= 4 elements are padded, not hashed
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((unsigned)k < ncols) s[k] = lde[k * col_stride + j];
+    } else {
+        for (unsigned c0 = 0; c0 < ncols; c0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < ncols) s[k] = lde[(size_t)(c0 + k) * col_stride + j];
+            poseidon::permute(s);
+        }
+    }
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * j);
+    d[0] = make_ulonglong2(s[0], s[1]);
+    d[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ void __launch_bounds__(THREADS)
+fri_leaf_hash_kernel(const u64* __restrict__ v0, const u64* __restrict__ v1, size_t n_leaves, unsigned arity_bits,
+                     u64* __restrict__ digests) {
+    const size_t l = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (l >= n_leaves) return;
+    const unsigned arity = 1u << arity_bits;
+    const size_t base = l << arity_bits;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = 0;
+    if (2 * arity <= 4) {
+        for (unsigned m = 0; m < arity; ++m) { s[2 * m] = v0[base + m]; s[2 * m + 1] = v1[base + m]; }
+    } else {
+        // leaf = [v_0.c0, v_0.c1, v_1.c0, ...]; one absorb block = 4 extension values
+        for (unsigned m0 = 0; m0 < arity; m0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m0 + k < arity) { s[2 * k] = v0[base + m0 + k]; s[2 * k + 1] = v1[base + m0 + k]; }
+            poseidon::permute(s);
+        }
+    }
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * l);
+    d[0] = make_ulonglong2(s[0], s[1]);
+    d[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ void __launch_bounds__(THREADS)
+merkle_level_kernel(const u64* __restrict__ children, u64* __restrict__ parents, size_t n_parents) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n_parents) return;
+    const ulonglong2* c = reinterpret_cast<const ulonglong2*>(children + 8 * i);
+    const ulonglong2 a = c[0], b = c[1], e = c[2], f = c[3];
+    u64 s[12] = {a.x, a.y, b.x, b.y, e.x, e.y, f.x, f.y, 0, 0, 0, 0};
+    poseidon::permute(s);
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(parents + 4 * i);
+    d[0] = make_ulonglong2(s[0], s[1]);
+    d[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ void __launch_bounds__(THREADS) permute_batch_kernel(u64* states, size_t n) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = states[12 * i + k];
+    poseidon::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) states[12 * i + k] = s[k];
+}
+
+__global__ void __launch_bounds__(THREADS)
+hash_rows_kernel(const u64* __restrict__ rows, size_t n, unsigned len, u64* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n) return;
+    const u64* row = rows + i * len;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = 0;
+    for (unsigned c0 = 0; c0 < len; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < len) s[k] = row[c0 + k];
+        poseidon::permute(s);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = s[k];
+}
+
+struct PowState {
+    u64 s[12];
+};
+
+__global__ void __launch_bounds__(THREADS)
+pow_search_kernel(PowState st, unsigned pos, unsigned pow_bits, u64 start, u64 count, unsigned long long* result) {
+    const u64 i = blockIdx.x * (u64)THREADS + threadIdx.x;
+    if (i >= count) return;
+    const u64 cand = start + i;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = (unsigned)k == pos ? cand : st.s[k];
+    poseidon::permute(s);
+    // pow_response = last element of squeeze() = state[7]; leading_zeros(response) >= pow_bits
+    if (pow_bits == 0 || (s[7] >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
+}
+}  // namespace
+
+void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests) {
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
+                       col_stride, digests);
+}
+void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests) {
+    hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, v0, v1, n_leaves,
+                       arity_bits, digests);
+}
+void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_t n_parents) {
+    hipLaunchKernelGGL(merkle_level_kernel, dim3((n_parents + THREADS - 1) / THREADS), dim3(THREADS), 0, s, children, parents,
+                       n_parents);
+}
+void launch_merkle_tree(hipStream_t s, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves) {
+    for (unsigned k = 1; k < n_levels; ++k)
+        launch_merkle_level(s, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
+}
+void launch_permute_batch(hipStream_t s, u64* states, size_t n) {
+    hipLaunchKernelGGL(permute_batch_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, states, n);
+}
+void launch_hash_rows(hipStream_t s, const u64* rows, size_t n, unsigned len, u64* out) {
+    hipLaunchKernelGGL(hash_rows_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, rows, n, len, out);
+}
+void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count, u64* d_result) {
+    PowState st;
+    for (int k = 0; k < 12; ++k) st.s[k] = state12_host[k];
+    hipLaunchKernelGGL(pow_search_kernel, dim3((unsigned)((count + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, st, pos, pow_bits,
+                       start, count, reinterpret_cast<unsigned long long*>(d_result));
+}
+}  // namespace vpbs

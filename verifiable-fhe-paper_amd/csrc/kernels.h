@@ -1,0 +1,83 @@
+// Launch wrappers of the gfx950 kernels (one HIP stream per prover context; no hidden synchronisation).
+// Buffers are device pointers unless stated; field elements are canonical u64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.h"
+
+namespace vpbs {
+using gl::u32;
+using gl::u64;
+
+// ---------- ntt.hip ----------
+// roots[j] = w^j, j < n/2, w = primitive n-th root (or its inverse for the inverse transform)
+void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse);
+// prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n
+void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift);
+// values -> coefficients, natural order in and out (PolynomialValues::ifft), batched over columns.
+// scratch: [ncols][n] device words (may alias nothing); in/out column-major.
+void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, const u64* inv_roots, unsigned ncols,
+                 unsigned log_n);
+// coefficients -> coset LDE in leaf order: out[c][brev_rate(r)*n + q] = value at natural index r + (brev_logn(q) << rate)
+// i.e. out[c][j] = poly_c(shift * w_{big}^{brev_big(j)})   (PolynomialCoeffs::lde + coset_fft + reverse_index_bits)
+void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* prescale, unsigned ncols,
+                      unsigned log_n, unsigned rate_bits);
+// batched negacyclic NTT of the reference (crypto/poly.rs:9-64): in place, [batch][n]; roots = ROOTS/INVROOTS table
+void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv);
+
+// ---------- hash.hip ----------
+// digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
+void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests);
+// FRI round leaves: leaf l = flatten(values[arity*l .. arity*(l+1))) of ext values stored SoA [2][m]
+void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests);
+// parents[i] = two_to_one(children[2i], children[2i+1])
+void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_t n_parents);
+// builds every level above `level0` up to the cap; levels are stored back to back: level k at digests + off[k]
+void launch_merkle_tree(hipStream_t s, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves);
+// batch of independent permutations (test hook)
+void launch_permute_batch(hipStream_t s, u64* states, size_t n);
+// hash_no_pad over rows of a row-major matrix [n][len] (test hook / chain hashing of key material)
+void launch_hash_rows(hipStream_t s, const u64* rows, size_t n, unsigned len, u64* out);
+// proof-of-work search: smallest nonce in [start, start+count) whose response has >= pow_bits leading zeros.
+// state12: duplex state with the pending inputs already overwritten; pos: slot of the nonce. *result = min nonce or ~0
+void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count,
+                       u64* d_result);
+
+// ---------- fri.hip ----------
+// out[i] = z^i (ext, AoS [n][2])
+void launch_ext_powers(hipStream_t s, gl::Ext z, size_t n, u64* out);
+// out[c] = sum_i coeffs[c][i] * zpow[i]   (p.to_extension().eval(z)); out AoS [ncols][2]
+void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n, size_t col_stride, const u64* zpow, u64* out);
+// F[i] = sum_j alpha^j * poly_j[i]  (ReducingFactor::reduce_polys_base); polys: device array of column pointers;
+// alpha_pows AoS [n_polys][2]; F SoA (f0[n], f1[n])
+void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1);
+// final <- final * scale + (F / (X - z))  with the quotient's top coefficient 0 (divide_by_linear + pad);
+// zpow/zinvpow: AoS power tables of z and z^-1 of length n; final SoA
+void launch_divide_accumulate(hipStream_t s, const u64* f0, const u64* f1, const u64* zpow, const u64* zinvpow, gl::Ext scale,
+                              size_t n, u64* fin0, u64* fin1);
+// out = in * X (coefficient shift; the top coefficient of `in` must be 0); in and out must not alias
+void launch_shift_up(hipStream_t s, const u64* in0, const u64* in1, u64* out0, u64* out1, size_t n);
+// out[i] = sum_{j<arity} in[arity*i + j] * beta^j
+void launch_fold(hipStream_t s, const u64* in0, const u64* in1, size_t n_out, unsigned arity_bits, gl::Ext beta, u64* out0, u64* out1);
+// Query openings (fri_prover_query_rounds: tree.get + tree.prove for every query and tree) in one launch.
+struct OpenTree {
+    const u64* data0;      // initial tree: column-major LDE; FRI tree: component-0 values
+    const u64* data1;      // FRI tree: component-1 values (nullptr for initial trees)
+    const u64* digests;    // level 0 at digests, level k at digests + level_off[k]
+    size_t col_stride;     // initial tree: distance between columns
+    size_t level_off[24];
+    u32 leaf_len;          // ncols, or 2 << arity_bits
+    u32 n_siblings;
+    u32 index_shift;       // leaf index = x_index >> index_shift
+    u32 arity_bits;        // FRI trees only
+    size_t out_off;        // word offset of this tree's record inside one query record
+};
+constexpr unsigned MAX_OPEN_TREES = 12, MAX_QUERIES = 128;
+struct OpenArgs {
+    OpenTree trees[MAX_OPEN_TREES];
+    u64 x_index[MAX_QUERIES];
+    u32 n_trees, n_queries;
+    size_t record_words;
+};
+// d_args: device copy of OpenArgs; out: [n_queries][record_words]
+void launch_open_queries(hipStream_t s, const OpenArgs* d_args, unsigned n_trees, unsigned n_queries, u64* out);
+}  // namespace vpbs

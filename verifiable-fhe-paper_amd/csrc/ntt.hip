@@ -1,0 +1,215 @@
+// Goldilocks radix-2 NTT / iNTT / coset LDE for gfx950 (replaces plonky2_field 0.2.0 fft.rs `fft_classic`,
+// `ifft_with_options`, polynomial/mod.rs `lde` + `coset_fft_with_options`, and plonky2_util `reverse_index_bits`,
+// reached from PolynomialBatch::from_values/from_coeffs under prove() -- /root/reference/src/vtfhe/
+// ivc_based_vpbs.rs:302,333,364).  Also the reference's own negacyclic NTT
+// (/root/reference/src/vtfhe/crypto/poly.rs:9-64) as a batched kernel.
+//
+// Design (MI355X): decimation-in-frequency, natural order in, bit-reversed order out -- which IS plonky2's leaf order,
+// so the transpose + reverse_index_bits passes of the reference disappear.  The rate-8 LDE is computed as 8
+// independent size-n coset transforms of coeff_i * (7 w^r)^i (never a zero-padded size-8n transform).
+// A transform is two launches: a strided pass (stages 0..log_r-1, tile = R rows x C adjacent columns in LDS, 128-B
+// row segments coalesced) and a contiguous pass (remaining stages on 2048-element tiles, in place).  Twiddles are
+// read from an HBM table of w^j (L2-resident: 128 KiB at n = 2^15).
+#include "kernels.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned TILE_LOG = 11;
+constexpr unsigned TILE = 1u << TILE_LOG;  // 2048 elements = 16 KiB of LDS
+constexpr unsigned THREADS = 256;
+
+__global__ void root_table_kernel(u64* roots, unsigned log_n, u64 w) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < ((size_t)1 << log_n) / 2 || (log_n == 0 && i == 0)) roots[i] = gl::pow(w, i);
+}
+
+__global__ void prescale_table_kernel(u64* table, unsigned log_n, unsigned rate_bits, u64 shift, u64 w_big) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned r = blockIdx.y;
+    if (i < ((size_t)1 << log_n)) table[((size_t)r << log_n) + i] = gl::pow(gl::mul(shift, gl::pow(w_big, r)), i);
+}
+
+// One DIF stage sweep over an LDS tile.  `dist` = butterfly distance inside the tile (power of two),
+// twiddle index of butterfly with low element at tile position t is tw_index(t).
+template <typename TwIndex>
+__device__ __forceinline__ void dif_stage(u64* tile, unsigned n_butterflies, unsigned dist, const u64* __restrict__ roots,
+                                          TwIndex tw_index) {
+    for (unsigned k = threadIdx.x; k < n_butterflies; k += THREADS) {
+        const unsigned lo = ((k / dist) * 2 * dist) + (k % dist);
+        const unsigned hi = lo + dist;
+        const u64 u = tile[lo], v = tile[hi];
+        tile[lo] = gl::add(u, v);
+        tile[hi] = gl::mul(gl::sub(u, v), roots[tw_index(lo)]);
+    }
+    __syncthreads();
+}
+
+// Strided pass: stages [0, log_r).  Tile = R rows x C cols, element (rho, gamma) <-> index rho*(n/R) + c0 + gamma.
+__global__ void __launch_bounds__(THREADS)
+ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
+                   const u64* __restrict__ roots, unsigned log_n, unsigned log_r, size_t in_col_stride,
+                   size_t out_col_stride, unsigned rate_bits) {
+    __shared__ u64 tile[TILE];
+    const unsigned log_c = TILE_LOG - log_r;
+    const unsigned C = 1u << log_c, R = 1u << log_r;
+    const unsigned row_stride = 1u << (log_n - log_r);  // n / R
+    const unsigned c0 = blockIdx.x << log_c;
+    const unsigned coset = blockIdx.z;
+    const u64* src = in + blockIdx.y * in_col_stride;
+    const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
+    for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
+        const unsigned rho = t >> log_c, gamma = t & (C - 1);
+        const unsigned idx = rho * row_stride + c0 + gamma;
+        u64 x = src[idx];
+        if (ps) x = gl::mul(x, ps[idx]);
+        tile[t] = x;
+    }
+    __syncthreads();
+    for (unsigned s = 0; s < log_r; ++s) {
+        const unsigned half_rows = R >> (s + 1);
+        dif_stage(tile, TILE / 2, half_rows << log_c, roots, [=](unsigned lo) {
+            const unsigned rho = lo >> log_c, gamma = lo & (C - 1);
+            return ((rho & (half_rows - 1)) * row_stride + c0 + gamma) << s;
+        });
+    }
+    u64* dst = out + blockIdx.y * out_col_stride + ((size_t)gl::bitrev32(coset, rate_bits) << log_n);
+    for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
+        const unsigned rho = t >> log_c, gamma = t & (C - 1);
+        dst[rho * row_stride + c0 + gamma] = tile[t];
+    }
+}
+
+// Contiguous pass: stages [s_begin, log_n) on blocks of B = n >> s_begin elements; one workgroup owns
+// min(TILE, n) consecutive elements.  If s_begin == 0 the input is read from `in` (with optional prescale), else the
+// transform continues in place in `out`.  bitrev_out: scatter to natural order and scale (inverse transform).
+__global__ void __launch_bounds__(THREADS)
+ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
+                  const u64* __restrict__ roots, unsigned log_n, unsigned s_begin, size_t in_col_stride,
+                  size_t out_col_stride, unsigned rate_bits, int bitrev_out, u64 scale) {
+    __shared__ u64 tile[TILE];
+    const unsigned n = 1u << log_n;
+    const unsigned tile_elems = n < TILE ? n : TILE;
+    const unsigned base = blockIdx.x * tile_elems;
+    const unsigned coset = blockIdx.z;
+    const size_t coset_off = (size_t)gl::bitrev32(coset, rate_bits) << log_n;
+    u64* dst_col = out + blockIdx.y * out_col_stride;
+    if (s_begin == 0) {
+        const u64* src = in + blockIdx.y * in_col_stride;
+        const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) {
+            u64 x = src[base + t];
+            if (ps) x = gl::mul(x, ps[base + t]);
+            tile[t] = x;
+        }
+    } else {
+        // in place continuation; for the inverse transform the strided pass wrote to `in` (scratch)
+        const u64* src = bitrev_out ? in + blockIdx.y * in_col_stride : dst_col + coset_off;
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[t] = src[base + t];
+    }
+    __syncthreads();
+    for (unsigned s = s_begin; s < log_n; ++s) {
+        const unsigned half = n >> (s + 1);
+        dif_stage(tile, tile_elems / 2, half, roots, [=](unsigned lo) { return ((base + lo) & (half - 1)) << s; });
+    }
+    if (bitrev_out) {
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS)
+            dst_col[gl::bitrev32(base + t, log_n)] = gl::mul(tile[t], scale);
+    } else {
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) dst_col[coset_off + base + t] = tile[t];
+    }
+}
+
+// Negacyclic transform of the reference, one polynomial per workgroup (n <= 2048 per LDS tile), in place.
+// forward (poly.rs:9-34): for m = 1,2,..: t = n/2m; (u, v*S[m+i]) -> (u+v, u-v)
+// backward (poly.rs:36-64): for m = n/2,..,1: (u, v) -> (u+v, (u-v)*S[m+i]); then * N^-1
+__global__ void __launch_bounds__(THREADS)
+negacyclic_kernel(u64* __restrict__ data, const u64* __restrict__ table, unsigned log_n, int inverse, u64 ninv) {
+    __shared__ u64 tile[TILE];
+    const unsigned n = 1u << log_n;
+    u64* p = data + (size_t)blockIdx.x * n;
+    for (unsigned t = threadIdx.x; t < n; t += THREADS) tile[t] = p[t];
+    __syncthreads();
+    if (!inverse) {
+        for (unsigned m = 1; m < n; m <<= 1) {
+            const unsigned t = n / (2 * m);
+            for (unsigned k = threadIdx.x; k < n / 2; k += THREADS) {
+                const unsigned i = k / t, j = 2 * i * t + (k % t);
+                const u64 u = tile[j], v = gl::mul(tile[j + t], table[m + i]);
+                tile[j] = gl::add(u, v);
+                tile[j + t] = gl::sub(u, v);
+            }
+            __syncthreads();
+        }
+        for (unsigned t = threadIdx.x; t < n; t += THREADS) p[t] = tile[t];
+    } else {
+        for (unsigned m = n >> 1; m >= 1; m >>= 1) {
+            const unsigned t = n / (2 * m);
+            for (unsigned k = threadIdx.x; k < n / 2; k += THREADS) {
+                const unsigned i = k / t, j = 2 * i * t + (k % t);
+                const u64 u = tile[j], v = tile[j + t];
+                tile[j] = gl::add(u, v);
+                tile[j + t] = gl::mul(gl::sub(u, v), table[m + i]);
+            }
+            __syncthreads();
+        }
+        for (unsigned t = threadIdx.x; t < n; t += THREADS) p[t] = gl::mul(tile[t], ninv);
+    }
+}
+
+unsigned split_log_r(unsigned log_n) { return log_n > TILE_LOG ? (log_n - 9 > 7 ? 7 : log_n - 9) : 0; }
+}  // namespace
+
+void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse) {
+    u64 w = gl::root_of_unity(log_n);
+    if (inverse) w = gl::inv(w);
+    const size_t cnt = log_n == 0 ? 1 : ((size_t)1 << log_n) / 2;
+    hipLaunchKernelGGL(root_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, roots, log_n, w);
+}
+
+void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(prescale_table_kernel, dim3((n + 255) / 256, 1u << rate_bits), dim3(256), 0, s, table, log_n, rate_bits,
+                       shift, gl::root_of_unity(log_n + rate_bits));
+}
+
+static void run_transform(hipStream_t s, const u64* in, u64* out, u64* scratch, const u64* prescale, const u64* roots,
+                          unsigned ncols, unsigned log_n, unsigned rate_bits, bool inverse, size_t in_stride, size_t out_stride) {
+    const unsigned n = 1u << log_n;
+    const unsigned cosets = 1u << rate_bits;
+    const unsigned log_r = split_log_r(log_n);
+    const u64 scale = inverse ? gl::inv((u64)n) : 1;
+    const unsigned tiles = n <= TILE ? 1 : n / TILE;
+    if (log_r == 0) {
+        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n, 0u,
+                           in_stride, out_stride, rate_bits, inverse ? 1 : 0, scale);
+        return;
+    }
+    if (inverse) {
+        // strided pass into scratch (layout [ncols][n]), contiguous pass scatters into `out`
+        hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, in, scratch, (const u64*)nullptr, roots,
+                           log_n, log_r, in_stride, (size_t)n, 0u);
+        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, (const u64*)scratch, out,
+                           (const u64*)nullptr, roots, log_n, log_r, (size_t)n, out_stride, 0u, 1, scale);
+    } else {
+        hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n,
+                           log_r, in_stride, out_stride, rate_bits);
+        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, (const u64*)nullptr, out,
+                           (const u64*)nullptr, roots, log_n, log_r, (size_t)0, out_stride, rate_bits, 0, scale);
+    }
+}
+
+void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, const u64* inv_roots, unsigned ncols, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    run_transform(s, values, coeffs, scratch, nullptr, inv_roots, ncols, log_n, 0, true, n, n);
+}
+
+void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* prescale, unsigned ncols,
+                      unsigned log_n, unsigned rate_bits) {
+    const size_t n = (size_t)1 << log_n;
+    run_transform(s, coeffs, out, nullptr, prescale, roots, ncols, log_n, rate_bits, false, n, n << rate_bits);
+}
+
+void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv) {
+    hipLaunchKernelGGL(negacyclic_kernel, dim3(batch), dim3(THREADS), 0, s, data, table, log_n, inverse ? 1 : 0, ninv);
+}
+}  // namespace vpbs

@@ -1,0 +1,551 @@
+// Host orchestration of the opening proof and of one step proof, on top of the gfx950 kernels.
+// Mirrors plonky2 0.2.0 fri/oracle.rs `PolynomialBatch::prove_openings`, fri/prover.rs `fri_proof` /
+// `fri_committed_trees` / `fri_proof_of_work` / `fri_prover_query_rounds`, and the transcript skeleton of
+// plonk/prover.rs `prove` -- the code behind
+// /root/reference/src/vtfhe/ivc_based_vpbs.rs:302-308, :333-339, :364-370.
+// The Fiat-Shamir transcript is strictly sequential: every cap / opening set comes back to the host (512 B..4 KiB),
+// is absorbed by the host Challenger, and the next challenge is passed to the next kernel as an argument.
+#include <algorithm>
+
+#include "host/plonky2_mirror.h"
+
+using vpbs::DeviceError;
+using vpbs::Timed;
+using vpbs::u32;
+using vpbs::u64;
+
+namespace plonky2 {
+
+size_t fri_proof_words(const FriParams& p, const std::vector<size_t>& ncols) {
+    const unsigned log_lde = p.lde_bits();
+    const size_t cap = (size_t)4 << p.config.cap_height;
+    size_t w = p.reduction_arity_bits.size() * cap;
+    size_t per_q = 0;
+    for (size_t nc : ncols) per_q += nc + 4 * (size_t)(log_lde - p.config.cap_height);
+    unsigned lg = log_lde;
+    for (unsigned ab : p.reduction_arity_bits) {
+        lg -= ab;
+        per_q += ((size_t)2 << ab) + 4 * (size_t)(lg - p.config.cap_height);
+    }
+    w += per_q * p.config.num_query_rounds;
+    w += (size_t)2 << p.final_poly_bits();
+    return w + 1;
+}
+
+namespace {
+struct FriRoundTree {
+    u64* values = nullptr;   // SoA [2][len], leaf order
+    u64* digests = nullptr;
+    std::vector<size_t> level_off;
+    size_t n_values = 0, n_leaves = 0;
+    unsigned arity_bits = 0;
+};
+
+// fri_proof_of_work: smallest nonce whose response has >= pow_bits leading zeros (or validate a forced one)
+u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forced) {
+    auto valid = [&](u64 w) {
+        Challenger c = ch;
+        c.observe_element(w);
+        const u64 r = c.get_challenge();
+        return pow_bits == 0 || (r >> (64 - pow_bits)) == 0;
+    };
+    u64 witness;
+    if (forced != VPBS_POW_ANY) {
+        if (forced >= gl::P || !valid(forced)) throw DeviceError{VPBS_ERR_POW, "forced proof-of-work nonce is not valid"};
+        witness = forced;
+    } else {
+        // duplex_intermediate_state: sponge with the buffered inputs already written; the nonce goes to slot input_len
+        u64 st[12];
+        for (int i = 0; i < 12; ++i) st[i] = ch.st.sponge[i];
+        for (u32 i = 0; i < ch.st.input_len; ++i) st[i] = ch.st.input[i];
+        const unsigned pos = ch.st.input_len;
+        u64* d_res = ctx->alloc_words(1);
+        witness = VPBS_POW_ANY;
+        const u64 span = (u64)1 << std::min(22u, pow_bits + 3);
+        for (u64 start = 0; witness == VPBS_POW_ANY; start += span) {
+            if (start > ((u64)1 << 40)) {
+                ctx->release(d_res);
+                throw DeviceError{VPBS_ERR_POW, "proof-of-work search exhausted"};
+            }
+            Timed t(ctx, "pow_search");
+            VPBS_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(u64), ctx->stream));
+            vpbs::launch_pow_search(ctx->stream, st, pos, pow_bits, start, span, d_res);
+            VPBS_HIP(hipMemcpyAsync(&witness, d_res, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->release(d_res);
+        if (!valid(witness)) throw DeviceError{VPBS_ERR_POW, "device proof-of-work result failed the host re-check"};
+    }
+    ch.observe_element(witness);
+    (void)ch.get_challenge();  // pow_response
+    return witness;
+}
+}  // namespace
+
+void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& instance, const std::vector<vpbs_batch*>& oracles,
+                                     Challenger& challenger, const FriParams& fp, u64 forced_pow, u64* proof_out) {
+    hipStream_t s = ctx->stream;
+    const unsigned degree_bits = fp.degree_bits, rate_bits = fp.config.rate_bits, cap_h = fp.config.cap_height;
+    const size_t n = (size_t)1 << degree_bits;
+    VPBS_REQUIRE(rate_bits == ctx->rate_bits && cap_h == ctx->cap_height, "FRI params disagree with the context");
+    VPBS_REQUIRE(fp.config.num_query_rounds <= vpbs::MAX_QUERIES, "too many query rounds");
+    VPBS_REQUIRE(oracles.size() + fp.reduction_arity_bits.size() <= vpbs::MAX_OPEN_TREES, "too many trees");
+    for (auto* o : oracles) VPBS_REQUIRE(o && o->log_n == degree_bits && o->ctx == ctx, "oracle does not match degree/context");
+
+    std::vector<void*> scratch;  // released at the end (stream-ordered pool)
+    auto words = [&](size_t w) {
+        u64* p = ctx->alloc_words(w);
+        scratch.push_back(p);
+        return p;
+    };
+    struct Cleanup {
+        vpbs_ctx* c;
+        std::vector<void*>& v;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(c->stream);
+            for (void* p : v) c->release(p);
+        }
+    } cleanup{ctx, scratch};
+
+    // ---- alpha-combination: final_poly = sum_i alpha^(k_i) (F_i - F_i(z_i)) / (X - z_i) ----
+    const Ext alpha = challenger.get_extension_challenge();
+    size_t max_polys = 0;
+    for (auto& b : instance.batches) max_polys = std::max(max_polys, b.polynomials.size());
+    std::vector<u64> h_apow(2 * max_polys);
+    {
+        Ext a = gl::ext(1);
+        for (size_t j = 0; j < max_polys; ++j) {
+            h_apow[2 * j] = a.c0;
+            h_apow[2 * j + 1] = a.c1;
+            a = gl::mul(a, alpha);
+        }
+    }
+    u64* d_apow = words(2 * max_polys);
+    VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * 2 * max_polys, hipMemcpyHostToDevice, s));
+    u64* fin = words(2 * n);  // SoA [2][n]
+    VPBS_HIP(hipMemsetAsync(fin, 0, sizeof(u64) * 2 * n, s));
+    u64* F = words(2 * n);
+    u64* zpow = words(2 * n);
+    u64* zinvpow = words(2 * n);
+    std::vector<std::vector<const u64*>> h_ptrs(instance.batches.size());
+    for (size_t b = 0; b < instance.batches.size(); ++b) {
+        const FriBatchInfo& bi = instance.batches[b];
+        const size_t np = bi.polynomials.size();
+        VPBS_REQUIRE(np > 0, "empty opening batch");
+        h_ptrs[b].resize(np);
+        for (size_t j = 0; j < np; ++j) {
+            const auto& pi = bi.polynomials[j];
+            VPBS_REQUIRE(pi.oracle_index < oracles.size() && pi.polynomial_index < oracles[pi.oracle_index]->ncols, "bad FriPolynomialInfo");
+            h_ptrs[b][j] = oracles[pi.oracle_index]->d_coeffs + (size_t)pi.polynomial_index * n;
+        }
+        const u64** d_ptrs = reinterpret_cast<const u64**>(words(np));
+        VPBS_HIP(hipMemcpyAsync(d_ptrs, h_ptrs[b].data(), sizeof(u64*) * np, hipMemcpyHostToDevice, s));
+        {
+            Timed t(ctx, "fri_combine");
+            vpbs::launch_combine(s, d_ptrs, (unsigned)np, d_apow, n, F, F + n);
+        }
+        VPBS_REQUIRE(!(bi.point.c0 == 0 && bi.point.c1 == 0), "opening point is zero");
+        {
+            Timed t(ctx, "fri_divide");
+            vpbs::launch_ext_powers(s, bi.point, n, zpow);
+            vpbs::launch_ext_powers(s, gl::inv(bi.point), n, zinvpow);
+            // shift_poly: final *= alpha^count (count = polynomials reduced in this batch), then += quotient
+            vpbs::launch_divide_accumulate(s, F, F + n, zpow, zinvpow, gl::pow(alpha, np), n, fin, fin + n);
+        }
+    }
+    if (fp.mul_final_by_x) {
+        u64* shifted = words(2 * n);
+        vpbs::launch_shift_up(s, fin, fin + n, shifted, shifted + n, n);
+        fin = shifted;
+    }
+
+    // ---- fri_committed_trees ----
+    const size_t n_rounds = fp.reduction_arity_bits.size();
+    const size_t cap_words = (size_t)4 << cap_h;
+    std::vector<FriRoundTree> trees(n_rounds);
+    u64* coeffs = fin;  // SoA [2][len]
+    unsigned log_len = degree_bits;
+    u64 shift = gl::GENERATOR;
+    u64* w = proof_out;
+    for (size_t r = 0; r < n_rounds; ++r) {
+        const unsigned ab = fp.reduction_arity_bits[r];
+        const size_t len = (size_t)1 << log_len, lde_len = len << rate_bits;
+        VPBS_REQUIRE(log_len >= ab, "arity larger than the polynomial");
+        FriRoundTree& t = trees[r];
+        t.arity_bits = ab;
+        t.n_values = lde_len;
+        t.n_leaves = lde_len >> ab;
+        t.values = words(2 * lde_len);
+        {
+            Timed tm(ctx, "fri_lde");
+            vpbs::launch_coset_lde(s, coeffs, t.values, ctx->roots(log_len, false), ctx->prescale(log_len, rate_bits, shift), 2, log_len,
+                                   rate_bits);
+        }
+        const size_t dig_words = vpbs::merkle_layout(t.n_leaves, cap_h, t.level_off);
+        t.digests = words(dig_words);
+        {
+            Timed tm(ctx, "fri_tree");
+            vpbs::launch_fri_leaf_hash(s, t.values, t.values + lde_len, t.n_leaves, ab, t.digests);
+            vpbs::launch_merkle_tree(s, t.digests, t.level_off.data(), (unsigned)t.level_off.size(), t.n_leaves);
+        }
+        VPBS_HIP(hipMemcpyAsync(w, t.digests + t.level_off.back(), sizeof(u64) * cap_words, hipMemcpyDeviceToHost, s));
+        VPBS_HIP(hipStreamSynchronize(s));
+        challenger.observe_cap(w, cap_words / 4);
+        w += cap_words;
+        const Ext beta = challenger.get_extension_challenge();
+        const size_t new_len = len >> ab;
+        u64* folded = words(2 * new_len);
+        {
+            Timed tm(ctx, "fri_fold");
+            vpbs::launch_fold(s, coeffs, coeffs + len, new_len, ab, beta, folded, folded + new_len);
+        }
+        coeffs = folded;
+        log_len -= ab;
+        shift = gl::pow(shift, (u64)1 << ab);
+    }
+    // final polynomial (the coefficients above len are the ones the reference truncates: they are zero)
+    const size_t final_len = (size_t)1 << log_len;
+    std::vector<u64> h_final(2 * final_len), final_words(2 * final_len);
+    VPBS_HIP(hipMemcpyAsync(h_final.data(), coeffs, sizeof(u64) * 2 * final_len, hipMemcpyDeviceToHost, s));
+    VPBS_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < final_len; ++i) {
+        final_words[2 * i] = h_final[i];
+        final_words[2 * i + 1] = h_final[final_len + i];
+    }
+    challenger.observe_elements(final_words.data(), final_words.size());
+
+    // ---- fri_proof_of_work ----
+    const u64 pow_witness = fri_proof_of_work(ctx, challenger, fp.config.proof_of_work_bits, forced_pow);
+
+    // ---- fri_prover_query_rounds ----
+    vpbs::OpenArgs args{};
+    args.n_queries = fp.config.num_query_rounds;
+    const size_t lde_size = fp.lde_size();
+    for (unsigned q = 0; q < args.n_queries; ++q) args.x_index[q] = challenger.get_challenge() % lde_size;
+    size_t off = 0;
+    unsigned nt = 0;
+    for (auto* o : oracles) {
+        vpbs::OpenTree& t = args.trees[nt++];
+        t.data0 = o->d_lde;
+        t.data1 = nullptr;
+        t.digests = o->d_digests;
+        t.col_stride = o->lde_len();
+        t.leaf_len = o->ncols;
+        t.n_siblings = o->n_levels() - 1;
+        t.index_shift = 0;
+        for (unsigned k = 0; k < o->n_levels(); ++k) t.level_off[k] = o->level_off[k];
+        t.out_off = off;
+        off += t.leaf_len + 4 * (size_t)t.n_siblings;
+    }
+    unsigned total_shift = 0;
+    for (size_t r = 0; r < n_rounds; ++r) {
+        const FriRoundTree& ft = trees[r];
+        total_shift += ft.arity_bits;
+        vpbs::OpenTree& t = args.trees[nt++];
+        t.data0 = ft.values;
+        t.data1 = ft.values + ft.n_values;
+        t.digests = ft.digests;
+        t.leaf_len = 2u << ft.arity_bits;
+        t.n_siblings = (unsigned)ft.level_off.size() - 1;
+        t.index_shift = total_shift;
+        t.arity_bits = ft.arity_bits;
+        for (size_t k = 0; k < ft.level_off.size(); ++k) t.level_off[k] = ft.level_off[k];
+        t.out_off = off;
+        off += t.leaf_len + 4 * (size_t)t.n_siblings;
+    }
+    args.n_trees = nt;
+    args.record_words = off;
+    auto* d_args = static_cast<vpbs::OpenArgs*>(ctx->alloc_bytes(sizeof args));
+    scratch.push_back(d_args);
+    u64* d_rec = words(off * args.n_queries);
+    VPBS_HIP(hipMemcpyAsync(d_args, &args, sizeof args, hipMemcpyHostToDevice, s));
+    {
+        Timed tm(ctx, "fri_open_queries");
+        vpbs::launch_open_queries(s, d_args, nt, args.n_queries, d_rec);
+    }
+    VPBS_HIP(hipMemcpyAsync(w, d_rec, sizeof(u64) * off * args.n_queries, hipMemcpyDeviceToHost, s));
+    VPBS_HIP(hipStreamSynchronize(s));
+    w += off * args.n_queries;
+    std::memcpy(w, final_words.data(), sizeof(u64) * final_words.size());
+    w += final_words.size();
+    *w++ = pow_witness;
+    VPBS_HIP(hipGetLastError());
+}
+}  // namespace plonky2
+
+// ---------------- C ABI ----------------
+template <typename F>
+static int guarded(vpbs_ctx* ctx, F&& f) {
+    try {
+        f();
+        return VPBS_OK;
+    } catch (const DeviceError& e) {
+        if (ctx) ctx->err = e.what;
+        return e.status;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what();
+        return VPBS_ERR_INVALID;
+    }
+}
+
+static plonky2::FriInstanceInfo instance_from_c(const vpbs_fri_instance* in) {
+    plonky2::FriInstanceInfo inst;
+    for (size_t b = 0; b < in->n_batches; ++b) {
+        plonky2::FriBatchInfo bi;
+        bi.point = gl::Ext{in->batches[b].point[0], in->batches[b].point[1]};
+        for (size_t j = 0; j < in->batches[b].n_polys; ++j)
+            bi.polynomials.push_back({in->batches[b].oracle_index[j], in->batches[b].poly_index[j]});
+        inst.batches.push_back(std::move(bi));
+    }
+    return inst;
+}
+
+// plonk/circuit_data.rs get_fri_instance: batch 0 = every polynomial of every oracle at zeta;
+// batch 1 = the num_challenges Z polynomials (oracle 2, first columns) at g * zeta
+static plonky2::FriInstanceInfo step_fri_instance(const std::vector<size_t>& ncols, unsigned num_challenges, gl::Ext zeta, unsigned degree_bits) {
+    plonky2::FriInstanceInfo inst;
+    plonky2::FriBatchInfo all, next;
+    all.point = zeta;
+    for (u32 o = 0; o < ncols.size(); ++o)
+        for (u32 p = 0; p < ncols[o]; ++p) all.polynomials.push_back({o, p});
+    // F::Extension::primitive_root_of_unity(degree_bits) lies in the base field (EXT generator squared = base generator)
+    next.point = gl::mul(zeta, gl::root_of_unity(degree_bits));
+    for (u32 p = 0; p < num_challenges; ++p) next.polynomials.push_back({2, p});
+    inst.batches = {all, next};
+    return inst;
+}
+
+extern "C" {
+
+void vpbs_fri_params_standard(unsigned degree_bits, vpbs_fri_params* out) {
+    const plonky2::FriParams p = plonky2::FriParams::standard(degree_bits);
+    std::memset(out, 0, sizeof *out);
+    out->rate_bits = p.config.rate_bits;
+    out->cap_height = p.config.cap_height;
+    out->pow_bits = p.config.proof_of_work_bits;
+    out->num_query_rounds = p.config.num_query_rounds;
+    out->n_rounds = (unsigned)p.reduction_arity_bits.size();
+    for (unsigned i = 0; i < out->n_rounds; ++i) out->arity_bits[i] = p.reduction_arity_bits[i];
+}
+
+size_t vpbs_fri_proof_words(const vpbs_fri_params* params, unsigned degree_bits, const size_t* ncols, size_t n_oracles) {
+    return plonky2::fri_proof_words(plonky2::FriParams::from_c(*params, degree_bits), std::vector<size_t>(ncols, ncols + n_oracles));
+}
+
+int vpbs_fri_prove(vpbs_ctx* ctx, vpbs_batch* const* oracles, size_t n_oracles, const vpbs_fri_instance* instance,
+                   const vpbs_fri_params* params, vpbs_challenger_state* challenger, uint64_t forced_pow, uint64_t* proof_out) {
+    if (!ctx || !oracles || !n_oracles || !instance || !params || !challenger || !proof_out) return VPBS_ERR_INVALID;
+    return guarded(ctx, [&] {
+        VPBS_HIP(hipSetDevice(ctx->device));
+        plonky2::Challenger ch(*challenger);
+        std::vector<vpbs_batch*> os(oracles, oracles + n_oracles);
+        plonky2::PolynomialBatch::prove_openings(ctx, instance_from_c(instance), os, ch,
+                                                 plonky2::FriParams::from_c(*params, os[0]->log_n), forced_pow, proof_out);
+        *challenger = ch.st;
+    });
+}
+
+int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out) {
+    if (!ctx || !in || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
+    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
+    const size_t n_cs = in->constants_sigmas->ncols;
+    out->cap_words = (size_t)4 << ctx->cap_height;
+    out->openings_words = 2 * (n_cs + in->n_wires + in->n_zs_partial_products + in->n_quotient + in->num_challenges);
+    out->fri_words = plonky2::fri_proof_words(fp, {n_cs, in->n_wires, in->n_zs_partial_products, in->n_quotient});
+    return VPBS_OK;
+}
+
+int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_out, uint64_t* openings_out, uint64_t* fri_out,
+                    vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
+    if (!ctx || !in || !caps_out || !openings_out || !fri_out || !in->constants_sigmas) return VPBS_ERR_INVALID;
+    return guarded(ctx, [&] {
+        using namespace plonky2;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const unsigned log_n = in->log_n, nc = in->num_challenges;
+        const size_t n = (size_t)1 << log_n;
+        VPBS_REQUIRE(in->constants_sigmas->log_n == log_n, "constants_sigmas degree mismatch");
+        VPBS_REQUIRE(nc <= in->n_zs_partial_products, "num_challenges exceeds the Z/partial-product batch");
+        const size_t cap_words = (size_t)4 << ctx->cap_height;
+
+        // stage the three matrices on the device if they arrive from the host
+        std::vector<void*> staged;
+        auto on_device = [&](const u64* p, size_t words) -> const u64* {
+            if (in->inputs_on_device) return p;
+            u64* d = ctx->alloc_words(words);
+            staged.push_back(d);
+            VPBS_HIP(hipMemcpyAsync(d, p, sizeof(u64) * words, hipMemcpyHostToDevice, s));
+            return d;
+        };
+        struct Cleanup {
+            vpbs_ctx* c;
+            std::vector<void*>& v;
+            ~Cleanup() {
+                (void)hipStreamSynchronize(c->stream);
+                for (void* p : v) c->release(p);
+            }
+        } cleanup{ctx, staged};
+        const u64* d_wires = on_device(in->wires_values, (size_t)in->n_wires * n);
+        const u64* d_zs = on_device(in->zs_pp_values, (size_t)in->n_zs_partial_products * n);
+        const u64* d_quot = on_device(in->quotient_coeffs, (size_t)in->n_quotient * n);
+
+        // prove(): public_inputs_hash, wires commitment, transcript
+        HashOut pi_hash;
+        vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
+        PolynomialBatch wires = PolynomialBatch::from_values(ctx, d_wires, in->n_wires, log_n);
+        wires.merkle_cap(caps_out);
+        Challenger challenger;
+        challenger.observe_elements(in->circuit_digest, 4);
+        challenger.observe_hash(pi_hash);
+        challenger.observe_cap(caps_out, cap_words / 4);
+        const std::vector<u64> betas = challenger.get_n_challenges(nc);
+        const std::vector<u64> gammas = challenger.get_n_challenges(nc);
+        // (host stage) all_wires_permutation_partial_products(betas, gammas) -> here: supplied data
+        PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n);
+        zs_pp.merkle_cap(caps_out + cap_words);
+        challenger.observe_cap(caps_out + cap_words, cap_words / 4);
+        const std::vector<u64> alphas = challenger.get_n_challenges(nc);
+        // (host stage) compute_quotient_polys(alphas) -> here: supplied coefficient chunks
+        PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n);
+        quotient.merkle_cap(caps_out + 2 * cap_words);
+        challenger.observe_cap(caps_out + 2 * cap_words, cap_words / 4);
+        const Ext zeta = challenger.get_extension_challenge();
+        // ensure!(zeta^(2^degree_bits) != 1, "Opening point is in the subgroup.")
+        {
+            Ext t = zeta;
+            for (unsigned i = 0; i < log_n; ++i) t = gl::mul(t, t);
+            VPBS_REQUIRE(!gl::eq(t, gl::ext(1)), "Opening point is in the subgroup.");
+        }
+        if (challenges_out) {
+            u64* c = challenges_out;
+            for (u64 v : betas) *c++ = v;
+            for (u64 v : gammas) *c++ = v;
+            for (u64 v : alphas) *c++ = v;
+            *c++ = zeta.c0;
+            *c++ = zeta.c1;
+        }
+
+        // OpeningSet::new: every polynomial at zeta, the Z polynomials also at g * zeta
+        std::vector<vpbs_batch*> oracles = {in->constants_sigmas, wires.h, zs_pp.h, quotient.h};
+        std::vector<size_t> ncols;
+        size_t total_cols = 0;
+        for (auto* o : oracles) {
+            ncols.push_back(o->ncols);
+            total_cols += o->ncols;
+        }
+        const FriInstanceInfo instance = step_fri_instance(ncols, nc, zeta, log_n);
+        const Ext zeta_next = instance.batches[1].point;
+        const unsigned chunks = (unsigned)((n + 4095) / 4096);
+        u64* zpow = ctx->alloc_words(2 * n);
+        u64* znpow = ctx->alloc_words(2 * n);
+        u64* d_open = ctx->alloc_words(2 * (total_cols + nc) * (size_t)(1 + chunks) + 64);
+        staged.push_back(zpow);
+        staged.push_back(znpow);
+        staged.push_back(d_open);
+        {
+            Timed t(ctx, "openings_eval");
+            vpbs::launch_ext_powers(s, zeta, n, zpow);
+            vpbs::launch_ext_powers(s, zeta_next, n, znpow);
+            size_t col = 0;
+            for (auto* o : oracles) {
+                // results for this oracle at d_open[2*col ..]; partial sums behind the block of final results
+                vpbs::launch_eval_ext(s, o->d_coeffs, o->ncols, n, n, zpow, d_open + 2 * col * (size_t)(1 + chunks));
+                col += o->ncols;
+            }
+            vpbs::launch_eval_ext(s, zs_pp.h->d_coeffs, nc, n, n, znpow, d_open + 2 * col * (size_t)(1 + chunks));
+        }
+        // gather the final results (each oracle block: [ncols][2] results followed by its partial sums)
+        std::vector<u64> h_open(2 * (total_cols + nc) * (size_t)(1 + chunks));
+        VPBS_HIP(hipMemcpyAsync(h_open.data(), d_open, sizeof(u64) * h_open.size(), hipMemcpyDeviceToHost, s));
+        VPBS_HIP(hipStreamSynchronize(s));
+        {
+            u64* w = openings_out;
+            size_t col = 0;
+            for (auto* o : oracles) {
+                std::memcpy(w, h_open.data() + 2 * col * (size_t)(1 + chunks), sizeof(u64) * 2 * o->ncols);
+                w += 2 * o->ncols;
+                col += o->ncols;
+            }
+            std::memcpy(w, h_open.data() + 2 * col * (size_t)(1 + chunks), sizeof(u64) * 2 * nc);
+        }
+        // challenger.observe_openings(&openings.to_fri_openings()): zeta batch then zeta_next batch
+        challenger.observe_elements(openings_out, 2 * (total_cols + nc));
+
+        FriParams fp = FriParams::standard(log_n);
+        PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out);
+        if (challenger_out) *challenger_out = challenger.st;
+    });
+}
+
+// ProofWithPublicInputs::to_bytes (util/serialization): caps, OpeningSet, FriProof, then public inputs
+long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants, const uint64_t* caps,
+                              const uint64_t* openings, const uint64_t* fri, uint8_t* out, size_t cap_bytes) {
+    if (!ctx || !in || !caps || !openings || !fri || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
+    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
+    const size_t n_cs = in->constants_sigmas->ncols;
+    if (n_constants > n_cs) return VPBS_ERR_INVALID;
+    size_t pos = 0;
+    bool overflow = false;
+    auto put_words = [&](const uint64_t* w, size_t cnt) {
+        if (pos + 8 * cnt > cap_bytes) { overflow = true; return; }
+        std::memcpy(out + pos, w, 8 * cnt);  // little-endian host
+        pos += 8 * cnt;
+    };
+    auto put_u8 = [&](uint8_t b) {
+        if (pos + 1 > cap_bytes) { overflow = true; return; }
+        out[pos++] = b;
+    };
+    const size_t cap_words = (size_t)4 << ctx->cap_height;
+    put_words(caps, 3 * cap_words);  // wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap
+    // OpeningSet field order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys,
+    // lookup_zs (empty), lookup_zs_next (empty).  `openings` holds [cs | wires | zs_pp | quotient | zs_next].
+    const unsigned nc = in->num_challenges;
+    const uint64_t* cs = openings;
+    const uint64_t* wires = cs + 2 * n_cs;
+    const uint64_t* zs_pp = wires + 2 * (size_t)in->n_wires;
+    const uint64_t* quot = zs_pp + 2 * (size_t)in->n_zs_partial_products;
+    const uint64_t* zs_next = quot + 2 * (size_t)in->n_quotient;
+    put_words(cs, 2 * (size_t)n_constants);
+    put_words(cs + 2 * (size_t)n_constants, 2 * (n_cs - n_constants));
+    put_words(wires, 2 * (size_t)in->n_wires);
+    put_words(zs_pp, 2 * (size_t)nc);
+    put_words(zs_next, 2 * (size_t)nc);
+    put_words(zs_pp + 2 * (size_t)nc, 2 * (size_t)(in->n_zs_partial_products - nc));
+    put_words(quot, 2 * (size_t)in->n_quotient);
+    // FriProof
+    const uint64_t* w = fri;
+    const size_t n_rounds = fp.reduction_arity_bits.size();
+    put_words(w, n_rounds * cap_words);
+    w += n_rounds * cap_words;
+    const unsigned log_lde = fp.lde_bits();
+    const size_t oracle_cols[4] = {n_cs, in->n_wires, in->n_zs_partial_products, in->n_quotient};
+    for (unsigned q = 0; q < fp.config.num_query_rounds; ++q) {
+        for (size_t o = 0; o < 4; ++o) {
+            const unsigned nsib = log_lde - fp.config.cap_height;
+            put_words(w, oracle_cols[o]);
+            w += oracle_cols[o];
+            put_u8((uint8_t)nsib);
+            put_words(w, 4 * (size_t)nsib);
+            w += 4 * (size_t)nsib;
+        }
+        unsigned lg = log_lde;
+        for (unsigned ab : fp.reduction_arity_bits) {
+            lg -= ab;
+            const unsigned nsib = lg - fp.config.cap_height;
+            put_words(w, (size_t)2 << ab);
+            w += (size_t)2 << ab;
+            put_u8((uint8_t)nsib);
+            put_words(w, 4 * (size_t)nsib);
+            w += 4 * (size_t)nsib;
+        }
+    }
+    const size_t final_words = (size_t)2 << fp.final_poly_bits();
+    put_words(w, final_words + 1);  // final_poly, pow_witness
+    // public inputs: length prefix (u64) + elements
+    const uint64_t n_pi = in->n_public_inputs;
+    put_words(&n_pi, 1);
+    put_words(in->public_inputs, in->n_public_inputs);
+    return overflow ? (long)VPBS_ERR_INVALID : (long)pos;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+"""Per-rank work plan for multi-GPU runs.
+
+Two modes:
+  * replicas  -- independent step proofs / vPBS chains per GPU (BASELINE config 3 across GPUs): no collective at all.
+  * coset     -- one commitment sharded by LDE coset: with rate 8 the LDE domain 7<w_18> is the union of 8 cosets of
+                 size n; coset r lands in the contiguous leaf range [brev3(r)*n, (brev3(r)+1)*n) = two of the 16 cap
+                 subtrees, so each rank hashes its own cosets and the only exchange is an all-gather of cap hashes
+                 (2^cap_height * 32 B per tree in total).
+This module is pure index arithmetic + one torch.distributed all_gather; the compute backend is injected.
+"""
+import numpy as np
+
+
+def brev(x, bits):
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (x & 1)
+        x >>= 1
+    return r
+
+
+def replica_assignment(n_items, rank, world_size):
+    """Items (independent proofs) owned by `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_items, world_size)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def coset_assignment(rate_bits, rank, world_size):
+    """Cosets r (natural index residue mod 2^rate_bits) owned by `rank`, chosen so that each rank owns a contiguous
+    range of leaf blocks (hence whole cap subtrees)."""
+    n_cosets = 1 << rate_bits
+    if n_cosets % world_size:
+        raise ValueError("world_size must divide the number of cosets (%d)" % n_cosets)
+    per = n_cosets // world_size
+    blocks = range(rank * per, (rank + 1) * per)            # leaf-block indices
+    return [brev(b, rate_bits) for b in blocks]             # coset whose rows fill that block
+
+
+def cap_slice(rate_bits, cap_height, rank, world_size):
+    """Half-open range of cap entries a rank produces."""
+    if cap_height < rate_bits:
+        raise ValueError("cap_height < rate_bits: a cap entry would span several cosets")
+    per_block = 1 << (cap_height - rate_bits)
+    per = ((1 << rate_bits) // world_size) * per_block
+    return rank * per, (rank + 1) * per
+
+
+def all_gather_cap(local_cap, group=None):
+    """RCCL/gloo all-gather of the cap entries each rank owns -> the full cap on every rank.
+
+    local_cap: torch.int64/uint64-compatible tensor [entries_per_rank, 4] on the rank's device."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = [torch.empty_like(local_cap) for _ in range(world)]
+    dist.all_gather(out, local_cap, group=group)
+    return torch.cat(out, dim=0)
