@@ -176,6 +176,7 @@ int vpbs_k_negacyclic_ntt(vpbs_ctx* ctx, uint64_t* data, unsigned batch, unsigne
 int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv);
 
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */
+/* on: 0 off, 1 every kernel group, 2 only the dominant kernel (leaf_hash) */
 int vpbs_timing_enable(vpbs_ctx* ctx, int on);
 /* writes a JSON object {"kernel": {"ms": total, "count": launches}, ...} and resets the accumulators */
 int vpbs_timing_report(vpbs_ctx* ctx, char* buf, size_t len);

@@ -3,6 +3,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -110,6 +111,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VpbsError("libvpbs_hip.so is missing: run __graft_entry__.build() (make -C verifiable-fhe-paper_amd/csrc). "
                             "There is no CPU fallback for the proving path.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HSA runtimes in one
+        # process cannot both own the GPU, so when torch is present it is imported FIRST: the dynamic loader then
+        # resolves this library's DT_NEEDED libamdhip64.so.7 to the copy torch already mapped (same soname).
+        if os.environ.get("VPBS_HIP_RUNTIME", "torch") == "torch":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -189,11 +198,14 @@ class Batch:
         self.ncols = lib().vpbs_batch_ncols(handle)
         self.log_n = lib().vpbs_batch_log_n(handle)
         self.n = 1 << self.log_n
+        ctx._batches.add(self)
 
     def free(self):
-        if self.h:
+        """vpbs_batch_free; a batch must not outlive its context (Context.close() frees the survivors)."""
+        if self.h and self.ctx.h:
             lib().vpbs_batch_free(self.h)
-            self.h = None
+        self.h = None
+        self.ctx._batches.discard(self)
 
     def __del__(self):
         try:
@@ -235,6 +247,7 @@ class Context:
     def __init__(self, device=0, log_n_max=16, rate_bits=3, cap_height=4):
         self.h = C.c_void_p()
         self.rate_bits, self.cap_height = rate_bits, cap_height
+        self._batches = weakref.WeakSet()
         rc = lib().vpbs_ctx_create(device, log_n_max, rate_bits, cap_height, C.byref(self.h))
         if rc:
             self.h = None
@@ -242,6 +255,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for b in list(self._batches):
+                b.free()
             lib().vpbs_ctx_destroy(self.h)
             self.h = None
 
@@ -401,8 +416,9 @@ class Context:
         return d
 
     # ---- timing ----
-    def timing_enable(self, on=True):
-        self._check(lib().vpbs_timing_enable(self.h, 1 if on else 0))
+    def timing_enable(self, on=1):
+        """0 off, 1 every kernel group, 2 only the dominant kernel (leaf_hash)."""
+        self._check(lib().vpbs_timing_enable(self.h, int(on)))
 
     def timing_report(self):
         buf = C.create_string_buffer(8192)

@@ -468,6 +468,7 @@ int vpbs_timing_enable(vpbs_ctx* c, int on) {
     if (!c) return VPBS_ERR_INVALID;
     c->resolve_timing();
     c->timing = on != 0;
+    c->timing_only = on == 2 ? "leaf_hash" : "";  // 2: dominant kernel only (bench.py timed region)
     return VPBS_OK;
 }
 int vpbs_timing_report(vpbs_ctx* c, char* buf, size_t len) {

@@ -55,6 +55,7 @@ struct vpbs_ctx {
 
     // ---- timing ----
     bool timing = false;
+    std::string timing_only;  // when non-empty, only this timer is recorded
     struct Pending {
         int name_id;
         hipEvent_t start, stop;
@@ -76,6 +77,7 @@ struct Timed {
     hipEvent_t start = nullptr;
     Timed(vpbs_ctx* ctx, const char* name) : c(ctx) {
         if (!c->timing) return;
+        if (!c->timing_only.empty() && c->timing_only != name) return;
         id = c->timer_id(name);
         start = c->get_event();
         (void)hipEventRecord(start, c->stream);
