@@ -32,7 +32,7 @@ COLS = synth.STEP_COLS
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-LEAF_HASH_INSTR_PER_PERM = 5900  # VALU instructions per permutation in leaf_hash (ISA count)
+LEAF_HASH_INSTR_PER_PERM = 27400  # dynamic VALU instructions per permutation (ISA count x round trip counts)
 
 
 def leaf_hash_bytes_per_step():
@@ -71,6 +71,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
+                    help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
+                         "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
+    ap.add_argument("--batch-chains", type=int, default=3,
+                    help="after the headline single-chain measurement, also time this many concurrent chains (1 GPU only)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -86,53 +91,108 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     log_n = args.log_n
-    ctx = vpbs_amd.Context(local_rank, log_n_max=16)
-    # this rank's chain: its own seeded instance (replica r proves instance r)
-    inputs = synth.step_inputs(log_n, instance=rank)
-    dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
-    cs = ctx.commit_values(inputs["constants_sigmas"])          # once per circuit, untimed
-    pis = synth.field_elements(0xABCD + rank, 77)
+    n_chains = max(1, args.chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
-    si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), dev["zs_partial_products"].data_ptr(), dev["quotient"].data_ptr(),
-                              cs, digest, pis, on_device=True,
-                              shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]))
+    ctxs, sis, keep = [], [], []
+    for c in range(n_chains):
+        ctx = vpbs_amd.Context(local_rank, log_n_max=16)
+        # chain c of rank r proves its own seeded instance
+        inst = rank * n_chains + c
+        inputs = synth.step_inputs(log_n, instance=inst)
+        dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
+        cs = ctx.commit_values(inputs["constants_sigmas"])          # once per circuit, untimed
+        pis = synth.field_elements(0xABCD + inst, 77)
+        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), dev["zs_partial_products"].data_ptr(),
+                                  dev["quotient"].data_ptr(), cs, digest, pis, on_device=True,
+                                  shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]))
+        ctxs.append(ctx); sis.append(si); keep.append((dev, cs, pis))
     torch.cuda.synchronize()
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for ctx in ctxs:
+            ctx.synchronize()
 
-    for _ in range(args.warmup):
-        ctx.prove_step(si)
-    ctx.timing_enable(2)        # HIP events around the dominant kernel only, on the prover's own stream
-    ctx.timing_report()
+    def run_steps(k):
+        """k step proofs on every chain; chains run concurrently (ctypes releases the GIL inside the library)."""
+        if n_chains == 1:
+            for _ in range(k):
+                ctxs[0].prove_step(sis[0])
+            return
+        import threading
+        errs = []
+
+        def work(i):
+            try:
+                for _ in range(k):
+                    ctxs[i].prove_step(sis[i])
+            except Exception as e:  # surfaced below: a failed chain must fail the bench
+                errs.append(e)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(n_chains)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if errs:
+            raise errs[0]
+
+    run_steps(args.warmup)
+    for ctx in ctxs:
+        ctx.timing_enable(2)    # HIP events around the dominant kernel only, on each prover's own stream
+        ctx.timing_report()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.prove_step(si)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    dominant = ctx.timing_report().get("leaf_hash", {"ms": 0.0, "count": 0})
-    ctx.timing_enable(0)
+    dominant = {"ms": 0.0, "count": 0}
+    for ctx in ctxs:
+        d = ctx.timing_report().get("leaf_hash", {"ms": 0.0, "count": 0})
+        dominant["ms"] += d["ms"]; dominant["count"] += d["count"]
+        ctx.timing_enable(0)
+
+    batch_result = None
+    if world == 1 and n_chains == 1 and args.batch_chains > 1:
+        extra = []
+        for c in range(1, args.batch_chains):
+            cx = vpbs_amd.Context(local_rank, log_n_max=16)
+            inp = synth.step_inputs(log_n, instance=c)
+            dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
+            csb = cx.commit_values(inp["constants_sigmas"])
+            pi2 = synth.field_elements(0xABCD + c, 77)
+            extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), dv["zs_partial_products"].data_ptr(),
+                                                  dv["quotient"].data_ptr(), csb, digest, pi2, on_device=True,
+                                                  shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"])), dv, csb, pi2))
+        ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
+        n_chains = len(ctxs)
+        run_steps(1)
+        barrier()
+        tb = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        eb = time.perf_counter() - tb
+        batch_result = {"chains": n_chains, "step_proofs_per_s": args.steps * n_chains / eb,
+                        "vpbs_proofs_per_s": args.steps * n_chains / eb / STEPS_PER_VPBS,
+                        "ms_per_step_proof": eb / (args.steps * n_chains) * 1e3}
+        n_chains = 1
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel breakdown of one extra (untimed) step, for the record
+    # per-kernel breakdown of one extra (untimed) step proof on chain 0 alone, for the record
+    ctx = ctxs[0]
     ctx.timing_enable(1)
-    ctx.prove_step(si)
+    ctx.prove_step(sis[0])
     breakdown = {k: round(v["ms"], 4) for k, v in ctx.timing_report().items()}
     ctx.timing_enable(0)
 
     if rank == 0:
-        steps_total = args.steps * world
+        steps_total = args.steps * world * n_chains
         step_rate = steps_total / elapsed
         scale = (1 << log_n) / float(1 << LOG_N)
-        per_step_ms = dominant["ms"] / max(1, args.steps)            # three leaf_hash launches per step
+        per_step_ms = dominant["ms"] / max(1, args.steps * n_chains)  # three leaf_hash launches per step proof
         bytes_step = leaf_hash_bytes_per_step() * scale
         achieved = bytes_step / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
         perms = leaf_hash_perms_per_step() * scale
@@ -144,6 +204,7 @@ def main():
         out = {
             "metric": "vPBS proofs/sec at N=1024", "value": step_rate / STEPS_PER_VPBS, "unit": "vPBS proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_proof": elapsed / (args.steps * n_chains) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
             "data": "synthetic", "step_proofs_per_s": step_rate, "steps_per_vpbs_proof": STEPS_PER_VPBS,
             "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
@@ -153,7 +214,8 @@ def main():
                                  "(combine, 3 arity-16 folds, 16-bit PoW, 28 queries) + Fiat-Shamir transcript; witness "
                                  "generation, partial products and quotient evaluation are host stages outside the timed "
                                  "region (SURVEY.md 8f-1/2)",
-                       "parallelism": "replicas: one independent chain per GPU, no data-path collective"},
+                       "parallelism": "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
+                       "chains_per_gpu": n_chains},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms_per_step": per_step_ms, "launches": dominant["count"],
@@ -163,11 +225,15 @@ def main():
                          "valu_frac": valu_rate / VALU_PEAK_TLANEOPS},
             "kernel_ms_one_step": breakdown,
         }
+        if world == 1 and n_chains == 1 and args.batch_chains > 1:
+            # BASELINE config 3 flavour on the same GPU: several independent chains in flight (extra contexts/streams)
+            out["batch"] = batch_result
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    ctx.close()
+    for ctx in ctxs:
+        ctx.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -159,6 +159,7 @@ void batch_cap_to_host(vpbs_batch* b, u64* cap_out) {
 template <typename F>
 static int guarded(vpbs_ctx* ctx, F&& f) {
     try {
+        if (ctx) VPBS_HIP(hipSetDevice(ctx->device));  // the current device is per host thread
         f();
         return VPBS_OK;
     } catch (const DeviceError& e) {

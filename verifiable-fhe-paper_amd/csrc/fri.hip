@@ -72,39 +72,52 @@ combine_kernel(const u64* const* __restrict__ polys, unsigned n_polys, const u64
     f1[i] = acc.c1;
 }
 
-// Single workgroup of 1024 threads: q_k = z^-(k+1) * sum_{i>k} F_i z^i, final_k = final_k*scale + q_k, q_{n-1} = 0.
-__global__ void __launch_bounds__(1024)
-divide_accumulate_kernel(const u64* __restrict__ f0, const u64* __restrict__ f1, const u64* __restrict__ zpow,
-                         const u64* __restrict__ zinvpow, gl::Ext scale, size_t n, u64* __restrict__ fin0, u64* __restrict__ fin1) {
-    __shared__ u64 sh0[1024], sh1[1024];
-    const unsigned T = 1024;
-    const size_t per = (n + T - 1) / T;
-    const size_t begin = threadIdx.x * per, end = begin + per < n ? begin + per : n;
-    // local total of t_i = F_i z^i over the chunk
-    gl::Ext tot = gl::ext(0);
-    for (size_t i = begin; i < end; ++i) tot = gl::add(tot, gl::mul(gl::Ext{f0[i], f1[i]}, load_ext(zpow, i)));
-    sh0[threadIdx.x] = tot.c0;
-    sh1[threadIdx.x] = tot.c1;
+// Division by (X - z) as a suffix scan: q_k = z^-(k+1) * sum_{i>k} F_i z^i  (q_{n-1} = 0), then
+// final_k = final_k * scale + q_k.  Two launches over 256-element chunks: chunk totals, then carry + local scan.
+__global__ void __launch_bounds__(THREADS)
+divide_totals_kernel(const u64* __restrict__ f0, const u64* __restrict__ f1, const u64* __restrict__ zpow, size_t n,
+                     u64* __restrict__ totals) {
+    __shared__ u64 sh[2 * THREADS];
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    gl::Ext t = gl::ext(0);
+    if (i < n) t = gl::mul(gl::Ext{f0[i], f1[i]}, load_ext(zpow, i));
+    const gl::Ext tot = block_sum(t, sh);
+    if (threadIdx.x == 0) store_ext(totals, blockIdx.x, tot);
+}
+__global__ void __launch_bounds__(THREADS)
+divide_finish_kernel(const u64* __restrict__ f0, const u64* __restrict__ f1, const u64* __restrict__ zpow,
+                     const u64* __restrict__ zinvpow, const u64* __restrict__ totals, gl::Ext scale, size_t n,
+                     u64* __restrict__ fin0, u64* __restrict__ fin1) {
+    __shared__ u64 sh[2 * THREADS];
+    __shared__ u64 carry_sh[2];
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    // carry = sum of the totals of all later chunks
+    gl::Ext c = gl::ext(0);
+    for (unsigned k = blockIdx.x + 1 + threadIdx.x; k < gridDim.x; k += THREADS) c = gl::add(c, load_ext(totals, k));
+    const gl::Ext carry = block_sum(c, sh);
+    if (threadIdx.x == 0) { carry_sh[0] = carry.c0; carry_sh[1] = carry.c1; }
     __syncthreads();
-    // inclusive suffix scan over chunk totals (Hillis-Steele)
-    for (unsigned d = 1; d < T; d <<= 1) {
-        gl::Ext v = gl::Ext{sh0[threadIdx.x], sh1[threadIdx.x]};
-        if (threadIdx.x + d < T) v = gl::add(v, gl::Ext{sh0[threadIdx.x + d], sh1[threadIdx.x + d]});
+    // inclusive suffix scan of t_i inside the chunk
+    gl::Ext t = gl::ext(0);
+    if (i < n) t = gl::mul(gl::Ext{f0[i], f1[i]}, load_ext(zpow, i));
+    sh[threadIdx.x] = t.c0;
+    sh[THREADS + threadIdx.x] = t.c1;
+    __syncthreads();
+    for (unsigned d = 1; d < THREADS; d <<= 1) {
+        gl::Ext v = gl::Ext{sh[threadIdx.x], sh[THREADS + threadIdx.x]};
+        if (threadIdx.x + d < THREADS) v = gl::add(v, gl::Ext{sh[threadIdx.x + d], sh[THREADS + threadIdx.x + d]});
         __syncthreads();
-        sh0[threadIdx.x] = v.c0;
-        sh1[threadIdx.x] = v.c1;
+        sh[threadIdx.x] = v.c0;
+        sh[THREADS + threadIdx.x] = v.c1;
         __syncthreads();
     }
-    // suffix sum over everything strictly after this chunk
-    gl::Ext run = threadIdx.x + 1 < T ? gl::Ext{sh0[threadIdx.x + 1], sh1[threadIdx.x + 1]} : gl::ext(0);
-    for (size_t k = end; k-- > begin;) {
-        // run == sum_{i>k} t_i
-        gl::Ext q = k + 1 < n ? gl::mul(run, load_ext(zinvpow, k + 1)) : gl::ext(0);
-        const gl::Ext f = gl::add(gl::mul(gl::Ext{fin0[k], fin1[k]}, scale), q);
-        run = gl::add(run, gl::mul(gl::Ext{f0[k], f1[k]}, load_ext(zpow, k)));
-        fin0[k] = f.c0;
-        fin1[k] = f.c1;
-    }
+    if (i >= n) return;
+    gl::Ext after = gl::Ext{carry_sh[0], carry_sh[1]};  // sum_{j > i} t_j
+    if (threadIdx.x + 1 < THREADS) after = gl::add(after, gl::Ext{sh[threadIdx.x + 1], sh[THREADS + threadIdx.x + 1]});
+    const gl::Ext q = i + 1 < n ? gl::mul(after, load_ext(zinvpow, i + 1)) : gl::ext(0);
+    const gl::Ext f = gl::add(gl::mul(gl::Ext{fin0[i], fin1[i]}, scale), q);
+    fin0[i] = f.c0;
+    fin1[i] = f.c1;
 }
 
 __global__ void shift_up_kernel(const u64* in0, const u64* in1, u64* c0, u64* c1, size_t n) {
@@ -162,8 +175,11 @@ void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, co
 }
 
 void launch_divide_accumulate(hipStream_t s, const u64* f0, const u64* f1, const u64* zpow, const u64* zinvpow, gl::Ext scale,
-                              size_t n, u64* fin0, u64* fin1) {
-    hipLaunchKernelGGL(divide_accumulate_kernel, dim3(1), dim3(1024), 0, s, f0, f1, zpow, zinvpow, scale, n, fin0, fin1);
+                              size_t n, u64* fin0, u64* fin1, u64* totals_scratch) {
+    const unsigned chunks = (unsigned)((n + THREADS - 1) / THREADS);
+    hipLaunchKernelGGL(divide_totals_kernel, dim3(chunks), dim3(THREADS), 0, s, f0, f1, zpow, n, totals_scratch);
+    hipLaunchKernelGGL(divide_finish_kernel, dim3(chunks), dim3(THREADS), 0, s, f0, f1, zpow, zinvpow, (const u64*)totals_scratch, scale,
+                       n, fin0, fin1);
 }
 
 void launch_shift_up(hipStream_t s, const u64* in0, const u64* in1, u64* out0, u64* out1, size_t n) {

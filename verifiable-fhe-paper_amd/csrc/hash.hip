@@ -4,6 +4,8 @@
 // `fri_proof_of_work`, reached from prove() at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364
 // (SURVEY.md 8a rows a5/a6/a11).  One lane = one leaf / node / nonce: the column-major, leaf-ordered LDE makes every
 // absorb a fully coalesced 512-B wave read.  Integer-VALU bound (~21k instructions per permutation); no MFMA.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "poseidon.h"
 
@@ -74,6 +76,36 @@ merkle_level_kernel(const u64* __restrict__ children, u64* __restrict__ parents,
     d[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// ---- 16-lanes-per-permutation variants for small node counts (latency-bound levels) ----
+__global__ void __launch_bounds__(THREADS)
+merkle_level_wide_kernel(const u64* __restrict__ children, u64* __restrict__ parents, size_t n_parents) {
+    __shared__ u64 lds[(THREADS / poseidon::WIDE_LANES) * poseidon::WIDE_LDS_WORDS];
+    const unsigned l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = blockIdx.x * (size_t)(THREADS / 16) + g;
+    const bool live = i < n_parents;
+    u64 x = (live && l < 8) ? children[8 * i + l] : 0;
+    x = poseidon::permute_wide(x, lds + g * poseidon::WIDE_LDS_WORDS, l);
+    if (live && l < 4) parents[4 * i + l] = x;
+}
+
+__global__ void __launch_bounds__(THREADS)
+fri_leaf_hash_wide_kernel(const u64* __restrict__ v0, const u64* __restrict__ v1, size_t n_leaves, unsigned arity_bits,
+                          u64* __restrict__ digests) {
+    __shared__ u64 lds[(THREADS / poseidon::WIDE_LANES) * poseidon::WIDE_LDS_WORDS];
+    const unsigned l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t leaf = blockIdx.x * (size_t)(THREADS / 16) + g;
+    const bool live = leaf < n_leaves;
+    const unsigned n_elems = 2u << arity_bits;  // > 4 guaranteed by the caller
+    const size_t base = leaf << arity_bits;
+    u64 x = 0;
+    for (unsigned e0 = 0; e0 < n_elems; e0 += 8) {
+        const unsigned e = e0 + l;
+        if (l < 8 && e < n_elems && live) x = ((e & 1) ? v1 : v0)[base + (e >> 1)];  // overwrite-mode absorb
+        x = poseidon::permute_wide(x, lds + g * poseidon::WIDE_LDS_WORDS, l);
+    }
+    if (live && l < 4) digests[4 * leaf + l] = x;
+}
+
 __global__ void __launch_bounds__(THREADS) permute_batch_kernel(u64* states, size_t n) {
     const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
     if (i >= n) return;
@@ -125,11 +157,30 @@ void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_le
     hipLaunchKernelGGL(leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
                        col_stride, digests);
 }
+// below this many independent permutations a launch is latency-bound and the 16-lane form wins (measured)
+static size_t wide_threshold() {
+    static const size_t t = [] {
+        const char* e = getenv("VPBS_WIDE_THRESHOLD");
+        return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
+    }();
+    return t;
+}
+
 void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests) {
+    if (n_leaves <= wide_threshold() && (2u << arity_bits) > 4) {
+        hipLaunchKernelGGL(fri_leaf_hash_wide_kernel, dim3((unsigned)((n_leaves * 16 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, v0,
+                           v1, n_leaves, arity_bits, digests);
+        return;
+    }
     hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, v0, v1, n_leaves,
                        arity_bits, digests);
 }
 void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_t n_parents) {
+    if (n_parents <= wide_threshold()) {
+        hipLaunchKernelGGL(merkle_level_wide_kernel, dim3((unsigned)((n_parents * 16 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
+                           children, parents, n_parents);
+        return;
+    }
     hipLaunchKernelGGL(merkle_level_kernel, dim3((n_parents + THREADS - 1) / THREADS), dim3(THREADS), 0, s, children, parents,
                        n_parents);
 }

@@ -52,8 +52,9 @@ void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n,
 void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1);
 // final <- final * scale + (F / (X - z))  with the quotient's top coefficient 0 (divide_by_linear + pad);
 // zpow/zinvpow: AoS power tables of z and z^-1 of length n; final SoA
+// totals_scratch: 2 * ceil(n / 256) device words
 void launch_divide_accumulate(hipStream_t s, const u64* f0, const u64* f1, const u64* zpow, const u64* zinvpow, gl::Ext scale,
-                              size_t n, u64* fin0, u64* fin1);
+                              size_t n, u64* fin0, u64* fin1, u64* totals_scratch);
 // out = in * X (coefficient shift; the top coefficient of `in` must be 0); in and out must not alias
 void launch_shift_up(hipStream_t s, const u64* in0, const u64* in1, u64* out0, u64* out1, size_t n);
 // out[i] = sum_{j<arity} in[arity*i + j] * beta^j

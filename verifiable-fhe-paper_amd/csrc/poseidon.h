@@ -95,6 +95,52 @@ GL_HD void permute(u64* s) {
     for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
 }
 
+#if defined(__HIPCC__)
+// Latency-oriented form: one permutation spread over 16 lanes (lane l < 12 owns state element l; lanes 12..15 idle).
+// Used where there are too few independent permutations to fill the chip (upper Merkle levels, FRI trees): the
+// lane-per-permutation form has a ~65 us dependent-instruction chain; here the 12 S-boxes of a full round and the 12
+// MDS rows run side by side and the state is exchanged through LDS (one ds_write_b64 + 12 ds_read_b64 per round).
+// `sh` points at this 16-lane group's private 24-word LDS window (element l is stored at l and l + 12 so the
+// circulant index needs no modulo).  All 64 lanes of the wave must call it together.  Returns the canonical value.
+constexpr int WIDE_LANES = 16, WIDE_LDS_WORDS = 48;  // 48-word stride keeps the four groups of a wave on disjoint banks
+__device__ __forceinline__ u64 permute_wide(u64 x, volatile u64* sh, unsigned l) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const unsigned row = l < 12 ? l : 0;
+    x = gl::add_nc(x, rc(row));
+    for (int r = 0; r < N_ROUNDS; ++r) {
+        const bool full = r < HALF_FULL || r >= HALF_FULL + N_PARTIAL;
+        if (full || l == 0) x = sbox(x);
+        __builtin_amdgcn_wave_barrier();
+        if (l < 12) {
+            sh[l] = x;
+            sh[l + 12] = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u64 k = r + 1 < N_ROUNDS ? rc(12 * (r + 1) + row) : 0;
+        u64 acc_lo = (u32)k, acc_hi = k >> 32;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const u64 v = sh[row + i];
+            acc_lo += (u64)(u32)v * C[i];
+            acc_hi += (v >> 32) * C[i];
+        }
+        if (l == 0) {
+            acc_lo += (u64)(u32)x * 8u;
+            acc_hi += (x >> 32) * 8u;
+        }
+        const u64 L = acc_lo + (acc_hi << 32);
+        const u64 H = (acc_hi >> 32) + (L < acc_lo ? 1 : 0);
+        const u64 t1 = (H << 32) - H;
+        u64 v = L + t1;
+        if (v < t1) v += gl::EPS;
+        x = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return gl::canon(x);
+}
+#endif
+
 // ---- host-side sponge helpers (hash/hashing.rs), used by the Challenger and for tiny inputs ----
 inline void hash_no_pad_host(const u64* in, size_t n, u64 out[4]) {
     u64 s[12] = {0};

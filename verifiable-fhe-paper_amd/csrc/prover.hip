@@ -61,7 +61,8 @@ u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forc
         const unsigned pos = ch.st.input_len;
         u64* d_res = ctx->alloc_words(1);
         witness = VPBS_POW_ANY;
-        const u64 span = (u64)1 << std::min(22u, pow_bits + 3);
+        // expected nonce ~2^pow_bits: a first chunk of 2^(pow_bits+1) candidates hits with probability 1 - e^-2
+        const u64 span = (u64)1 << std::min(22u, pow_bits + 1);
         for (u64 start = 0; witness == VPBS_POW_ANY; start += span) {
             if (start > ((u64)1 << 40)) {
                 ctx->release(d_res);
@@ -127,6 +128,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
     u64* F = words(2 * n);
     u64* zpow = words(2 * n);
     u64* zinvpow = words(2 * n);
+    u64* div_totals = words(2 * ((n + 255) / 256));
     std::vector<std::vector<const u64*>> h_ptrs(instance.batches.size());
     for (size_t b = 0; b < instance.batches.size(); ++b) {
         const FriBatchInfo& bi = instance.batches[b];
@@ -150,7 +152,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
             vpbs::launch_ext_powers(s, bi.point, n, zpow);
             vpbs::launch_ext_powers(s, gl::inv(bi.point), n, zinvpow);
             // shift_poly: final *= alpha^count (count = polynomials reduced in this batch), then += quotient
-            vpbs::launch_divide_accumulate(s, F, F + n, zpow, zinvpow, gl::pow(alpha, np), n, fin, fin + n);
+            vpbs::launch_divide_accumulate(s, F, F + n, zpow, zinvpow, gl::pow(alpha, np), n, fin, fin + n, div_totals);
         }
     }
     if (fp.mul_final_by_x) {
@@ -277,6 +279,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
 template <typename F>
 static int guarded(vpbs_ctx* ctx, F&& f) {
     try {
+        if (ctx) VPBS_HIP(hipSetDevice(ctx->device));  // the current device is per host thread
         f();
         return VPBS_OK;
     } catch (const DeviceError& e) {
