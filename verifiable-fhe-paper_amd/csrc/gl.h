@@ -73,11 +73,46 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
     if (r < t1) r += EPS;
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Hand-scheduled gfx950 forms (bit-identical residues are not required between forms; all results are congruent mod p
+// and every consumer accepts any u64 residue).  They use fixed scratch registers v80..v87 / s[80:85], declared as
+// clobbers, because a 64-bit inline-asm operand cannot name its halves and v_mad_u64_u32 needs aligned pairs.
+//   product: 4 v_mad_u64_u32 (the a1*b0 term is accumulated onto a0*b1 with its carry-out kept in an SGPR pair) + 3 adds
+//   reduce : u = hi_lo * (2^32-1) + lo as ONE v_mad_u64_u32 with carry-out c; r = u - hi_hi with borrow b;
+//            r += (c - b) * (2^32 - 1)  -- neither correction can wrap a second time
+// 18 VALU + 2 SALU instead of the 26 VALU hipcc emits for the C form below.
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
+    u32 r0, r1;
+    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
+        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
+        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
+        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
+        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
+        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
+        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
+        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
+        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+    return ((u64)r1 << 32) | r0;
+}
+#else
 GL_HD u64 mul_nc(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide(a, b, lo, hi);
     return reduce128_nc(lo, hi);
 }
+#endif
 GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 

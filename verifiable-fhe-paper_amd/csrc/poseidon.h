@@ -26,6 +26,19 @@ static __constant__ u64 RC_DEV[360] = {
 };
 #endif
 
+#include "poseidon_partial_groups.inc"
+static const PartialGroup PG_HOST[7] = POSEIDON_PARTIAL_GROUPS_INIT;
+#if defined(__HIPCC__)
+static __constant__ PartialGroup PG_DEV[7] = POSEIDON_PARTIAL_GROUPS_INIT;
+#endif
+GL_HD const PartialGroup& partial_group(int g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return PG_DEV[g];
+#else
+    return PG_HOST[g];
+#endif
+}
+
 GL_HD u64 rc(int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return RC_DEV[i];
@@ -41,9 +54,44 @@ GL_HD u64 sbox(u64 x) {
     return gl::mul_nc(x3, x4);
 }
 
+// acc_lo + acc_hi * 2^32 (both < 2^58) folded to a u64 residue with 2^64 = 2^32 - 1
+GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // L = acc_lo + (acc_hi << 32) with carry into H = acc_hi >> 32; r = H * (2^32 - 1) + L as one v_mad_u64_u32 whose
+    // carry-out selects the single +(2^32 - 1) correction (H < 2^27, so the corrected sum cannot wrap again)
+    u32 r0, r1;
+    asm("v_add_co_u32_e32 v81, vcc, %3, %4\n\t"
+        "v_addc_co_u32_e64 v84, vcc, %5, 0, vcc\n\t"
+        "v_mov_b32_e32 v80, %2\n\t"
+        "v_mad_u64_u32 v[80:81], vcc, v84, -1, v[80:81]\n\t"
+        "v_cndmask_b32_e64 v86, 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
+        "v_addc_co_u32_e64 %1, vcc, v81, 0, vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"((u32)acc_lo), "v"((u32)(acc_lo >> 32)), "v"((u32)acc_hi), "v"((u32)(acc_hi >> 32))
+        : "v80", "v81", "v84", "v86", "vcc");
+    return ((u64)r1 << 32) | r0;
+#else
+    const u64 L = acc_lo + (acc_hi << 32);
+    const u64 H = (acc_hi >> 32) + (L < acc_lo ? 1 : 0);
+    const u64 t1 = (H << 32) - H;
+    u64 v = L + t1;
+    if (v < t1) v += gl::EPS;
+    return v;
+#endif
+}
+
 // s <- MDS * s + k, where k = rc[k_off .. k_off+12) (k_off < 0: no constant).  s: any u64 residues.
 GL_HD void mds_add_const(u64* s, int k_off) {
-    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 D8 = 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the coefficients opaque (SGPRs): otherwise hipcc strength-reduces x16 / x2 / x8 into v_lshl_add_u64 on
+    // zero-extended register pairs, which costs two v_mov per term (-6 % instructions per permutation)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(C[i]));
+    asm volatile("" : "+s"(D8));
+#endif
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -60,16 +108,61 @@ GL_HD void mds_add_const(u64* s, int k_off) {
             acc_hi += (u64)hi[(i + r) % 12] * C[i];
         }
         if (r == 0) {  // MDS_MATRIX_DIAG[0] = 8
-            acc_lo += (u64)lo[0] * 8u;
-            acc_hi += (u64)hi[0] * 8u;
+            acc_lo += (u64)lo[0] * D8;
+            acc_hi += (u64)hi[0] * D8;
         }
-        // value = acc_lo + acc_hi * 2^32  (< 2^76): fold the part above 2^64 with 2^64 = 2^32 - 1
-        const u64 L = acc_lo + (acc_hi << 32);
-        const u64 H = (acc_hi >> 32) + (L < acc_lo ? 1 : 0);
-        const u64 t1 = (H << 32) - H;
-        u64 v = L + t1;
-        if (v < t1) v += gl::EPS;
-        s[r] = v;
+        s[r] = fold96(acc_lo, acc_hi);
+    }
+}
+
+// Three consecutive partial rounds in one dense pass (derivation and bounds: tools/gen_poseidon_partial_groups.py).
+// The MDS entries are so small that M^2 and M^3 still fit 32-bit multiplicands with room in 64-bit accumulators, so
+// instead of 3 x (288 multiply-adds + 12 folds) a group costs 288 (M^3) + 24 + 26 (row 0 of M, M^2) + 48 (the two
+// inner S-box corrections) multiply-adds and 14 folds.  s: x1 on entry (round constants included), x1' on exit.
+GL_HD void partial_group3(u64* s, int g) {
+    const PartialGroup& G = partial_group(g);
+    s[0] = sbox(s[0]);
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        lo[j] = (u32)s[j];
+        hi[j] = (u32)(s[j] >> 32);
+    }
+    // x2_0 = (M y)[0] + c2[0]
+    u64 a_lo = (u32)G.k2, a_hi = G.k2 >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        a_lo += (u64)lo[j] * MDS1[0][j];
+        a_hi += (u64)hi[j] * MDS1[0][j];
+    }
+    const u64 x2 = fold96(a_lo, a_hi);
+    const u64 d2 = gl::sub(gl::canon(sbox(x2)), gl::canon(x2));
+    const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+    // x3_0 = (M^2 y)[0] + M[0][0] d2 + (M c2)[0] + c3[0]
+    u64 b_lo = (u32)G.k3, b_hi = G.k3 >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        b_lo += (u64)lo[j] * MDS2[0][j];
+        b_hi += (u64)hi[j] * MDS2[0][j];
+    }
+    b_lo += (u64)d2l * MDS1[0][0];
+    b_hi += (u64)d2h * MDS1[0][0];
+    const u64 x3 = fold96(b_lo, b_hi);
+    const u64 d3 = gl::sub(gl::canon(sbox(x3)), gl::canon(x3));
+    const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
+    // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const u64 k = G.kvec[i];
+        u64 acc_lo = (u32)k, acc_hi = k >> 32;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            acc_lo += (u64)lo[j] * MDS3[i][j];
+            acc_hi += (u64)hi[j] * MDS3[i][j];
+        }
+        acc_lo += (u64)d2l * MDS2[i][0] + (u64)d3l * MDS1[i][0];
+        acc_hi += (u64)d2h * MDS2[i][0] + (u64)d3h * MDS1[i][0];
+        s[i] = fold96(acc_lo, acc_hi);
     }
 }
 
@@ -82,10 +175,10 @@ GL_HD void permute(u64* s) {
         for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
         mds_add_const(s, 12 * (r + 1));
     }
-    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; ++r) {
-        s[0] = sbox(s[0]);
-        mds_add_const(s, 12 * (r + 1));
-    }
+    // 22 partial rounds = 7 fused groups of 3 (rounds 4..24) + round 25
+    for (int g = 0; g < 7; ++g) partial_group3(s, g);
+    s[0] = sbox(s[0]);
+    mds_add_const(s, 12 * (HALF_FULL + N_PARTIAL));
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; ++r) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
@@ -103,20 +196,21 @@ GL_HD void permute(u64* s) {
 // `sh` points at this 16-lane group's private 24-word LDS window (element l is stored at l and l + 12 so the
 // circulant index needs no modulo).  All 64 lanes of the wave must call it together.  Returns the canonical value.
 constexpr int WIDE_LANES = 16, WIDE_LDS_WORDS = 48;  // 48-word stride keeps the four groups of a wave on disjoint banks
-__device__ __forceinline__ u64 permute_wide(u64 x, volatile u64* sh, unsigned l) {
+__device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const unsigned row = l < 12 ? l : 0;
     x = gl::add_nc(x, rc(row));
     for (int r = 0; r < N_ROUNDS; ++r) {
         const bool full = r < HALF_FULL || r >= HALF_FULL + N_PARTIAL;
         if (full || l == 0) x = sbox(x);
-        __builtin_amdgcn_wave_barrier();
+        // the 16 lanes of a group live in one wave: LDS operations of a wave execute in order, so a wavefront-scope
+        // fence (compiler ordering only) is all the synchronisation the exchange needs
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (l < 12) {
             sh[l] = x;
             sh[l + 12] = x;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const u64 k = r + 1 < N_ROUNDS ? rc(12 * (r + 1) + row) : 0;
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
 #pragma unroll
@@ -135,7 +229,6 @@ __device__ __forceinline__ u64 permute_wide(u64 x, volatile u64* sh, unsigned l)
         u64 v = L + t1;
         if (v < t1) v += gl::EPS;
         x = v;
-        __builtin_amdgcn_wave_barrier();
     }
     return gl::canon(x);
 }
