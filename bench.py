@@ -32,7 +32,7 @@ COLS = synth.STEP_COLS
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-LEAF_HASH_INSTR_PER_PERM = 27400  # dynamic VALU instructions per permutation (ISA count x round trip counts)
+LEAF_HASH_INSTR_PER_PERM = 15100  # dynamic VALU instructions per permutation (ISA count x loop trip counts)
 
 
 def leaf_hash_bytes_per_step():
@@ -76,6 +76,8 @@ def main():
                          "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
     ap.add_argument("--batch-chains", type=int, default=3,
                     help="after the headline single-chain measurement, also time this many concurrent chains (1 GPU only)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -86,9 +88,14 @@ def main():
     if distributed:
         assert world == args.gpus, "WORLD_SIZE must equal --gpus"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.device is not None:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     log_n = args.log_n
     n_chains = max(1, args.chains)
@@ -177,7 +184,7 @@ def main():
         n_chains = 1
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

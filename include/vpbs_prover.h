@@ -55,6 +55,14 @@ int vpbs_commit_values_dev(vpbs_ctx* ctx, const uint64_t* d_values, unsigned nco
                            uint64_t* cap_out);
 int vpbs_commit_coeffs_dev(vpbs_ctx* ctx, const uint64_t* d_coeffs, unsigned ncols, unsigned log_n, vpbs_batch** out,
                            uint64_t* cap_out);
+/* Multi-GPU coset sharding: rank `shard` of `n_shards` (a power of two <= 2^rate_bits) computes only
+ * its cosets of the LDE -- the contiguous leaf range [shard, shard+1) * (n << rate_bits) / n_shards -- hashes those
+ * leaves and builds its 2^cap_height / n_shards cap subtrees.  local_cap_out receives those cap entries; the full cap is
+ * the concatenation over ranks (one all-gather of 32-byte hashes: RCCL over xGMI in bench/production, gloo in the CPU
+ * tests).  The returned batch holds the shard only: vpbs_batch_open works for its own leaves; FRI over sharded
+ * oracles is not part of this round.  is_values: 1 = from_values (iNTT first), 0 = from_coeffs. */
+int vpbs_commit_sharded_dev(vpbs_ctx* ctx, const uint64_t* d_data, int is_values, unsigned ncols, unsigned log_n,
+                            unsigned shard, unsigned n_shards, vpbs_batch** out, uint64_t* local_cap_out);
 void vpbs_batch_free(vpbs_batch* batch);
 unsigned vpbs_batch_ncols(const vpbs_batch* batch);
 unsigned vpbs_batch_log_n(const vpbs_batch* batch);

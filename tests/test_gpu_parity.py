@@ -114,6 +114,36 @@ def test_commit_matches_oracle(ctx, log_n, ncols, from_values):
     got.free()
 
 
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_coset_sharded_commit_matches_unsharded(ctx, n_shards):
+    """each rank commits only its cosets; caps concatenate to the full cap; local leaves open to it.
+    (All shards run one after the other on the single GPU of the test box; the collective is covered by the gloo test.)"""
+    import torch
+    log_n, ncols = 10, 11
+    vals = rand_field(ncols, 1 << log_n)
+    full = ctx.commit_values(vals)
+    want_cap = full.cap()
+    assert (want_cap == orc.Batch(vals, 3, 4, True).cap()).all()
+    dev = torch.from_numpy(vals.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    L = 1 << (log_n + 3)
+    caps = []
+    for shard in range(n_shards):
+        b, local_cap = ctx.commit_sharded_dev(dev.data_ptr(), ncols, log_n, shard, n_shards)
+        caps.append(local_cap)
+        lo = shard * L // n_shards
+        for idx in (lo, lo + 17, lo + L // n_shards - 1):
+            leaf, sib = b.open(idx)
+            wleaf, wsib = full.open(idx)
+            assert (leaf == wleaf).all() and (sib == wsib).all()
+            assert orc.merkle_verify(leaf, idx, want_cap, 4, sib)
+        with pytest.raises(api.VpbsError):
+            b.open((lo + L // n_shards) % L)   # a leaf owned by another rank
+        b.free()
+    assert (np.concatenate(caps) == want_cap).all()
+    full.free()
+
+
 # ---------- FRI ----------
 def _fri_case(ctx, log_n, cols, **over):
     datas = [rand_field(nc, 1 << log_n) for nc in cols]

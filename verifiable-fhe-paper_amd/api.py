@@ -62,6 +62,7 @@ SIGNATURES = {
     "vpbs_commit_coeffs": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_commit_values_dev": (_i, [_vp, _vp, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_commit_coeffs_dev": (_i, [_vp, _vp, _ui, _ui, C.POINTER(_vp), U64P]),
+    "vpbs_commit_sharded_dev": (_i, [_vp, _vp, _i, _ui, _ui, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_batch_free": (None, [_vp]),
     "vpbs_batch_ncols": (_ui, [_vp]),
     "vpbs_batch_log_n": (_ui, [_vp]),
@@ -235,6 +236,7 @@ class Batch:
         return out
 
     def open(self, leaf_index):
+        """(leaf, siblings) for a GLOBAL leaf index (must lie in this batch's shard when it is sharded)."""
         nsib = self.log_n + self.ctx.rate_bits - self.ctx.cap_height
         leaf, sib = np.zeros(self.ncols, np.uint64), np.zeros((nsib, 4), np.uint64)
         self.ctx._check(lib().vpbs_batch_open(self.h, leaf_index, _ptr(leaf), _ptr(sib)))
@@ -305,6 +307,16 @@ class Context:
 
     def commit_coeffs_dev(self, dptr, ncols, log_n, want_cap=True):
         return self._commit(lib().vpbs_commit_coeffs_dev, dptr, ncols, log_n, want_cap)
+
+    def commit_sharded_dev(self, dptr, ncols, log_n, shard, n_shards, is_values=True):
+        """One rank's share of a coset-sharded commitment (device pointer in).  Returns (batch, local cap entries)."""
+        out = C.c_void_p()
+        cap = np.zeros(((1 << self.cap_height) // n_shards, 4), np.uint64)
+        self._check(lib().vpbs_commit_sharded_dev(self.h, C.c_void_p(int(dptr)), 1 if is_values else 0, ncols, log_n, shard, n_shards,
+                                                  C.byref(out), _ptr(cap)))
+        b = Batch(self, out)
+        b.shard, b.n_shards = shard, n_shards
+        return b, cap
 
     # ---- FRI ----
     def fri_prove(self, oracles, batches, challenger, params, forced_pow=POW_ANY):

@@ -107,18 +107,27 @@ size_t merkle_layout(size_t n_leaves, unsigned cap_height, std::vector<size_t>& 
     return off;
 }
 
-vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values) {
+vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values, unsigned shard,
+                          unsigned n_shards) {
     VPBS_REQUIRE(ncols > 0, "ncols == 0");
     VPBS_REQUIRE(log_n <= ctx->log_n_max, "log_n exceeds the context's log_n_max");
+    VPBS_REQUIRE(n_shards >= 1 && (n_shards & (n_shards - 1)) == 0 && n_shards <= (1u << ctx->rate_bits) && shard < n_shards,
+                 "n_shards must be a power of two <= 2^rate_bits and shard < n_shards");
+    VPBS_REQUIRE(((size_t)1 << ctx->cap_height) >= n_shards, "cap smaller than the shard count");
     auto* b = new vpbs_batch();
     b->ctx = ctx;
     b->ncols = ncols;
     b->log_n = log_n;
+    b->shard = shard;
+    b->n_shards = n_shards;
     const size_t n = b->n(), L = b->lde_len();
     try {
         b->d_coeffs = ctx->alloc_words((size_t)ncols * n);
         b->d_lde = ctx->alloc_words((size_t)ncols * L);
-        const size_t dig_words = merkle_layout(L, ctx->cap_height, b->level_off);
+        // a shard owns whole cap subtrees: its local tree stops at cap_len() roots, i.e. local cap height
+        unsigned local_cap_h = ctx->cap_height;
+        for (unsigned k = n_shards; k > 1; k >>= 1) --local_cap_h;
+        const size_t dig_words = merkle_layout(L, local_cap_h, b->level_off);
         b->d_digests = ctx->alloc_words(dig_words);
         if (is_values) {
             Timed t(ctx, "intt");
@@ -130,7 +139,8 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
         const u64* ps = ctx->prescale(log_n, ctx->rate_bits, gl::GENERATOR);
         {
             Timed t(ctx, "coset_lde");
-            launch_coset_lde(ctx->stream, b->d_coeffs, b->d_lde, roots, ps, ncols, log_n, ctx->rate_bits);
+            launch_coset_lde(ctx->stream, b->d_coeffs, b->d_lde, roots, ps, ncols, log_n, ctx->rate_bits, shard * b->blocks(),
+                             b->blocks());
         }
         {
             Timed t(ctx, "leaf_hash");
@@ -149,8 +159,8 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
 }
 
 void batch_cap_to_host(vpbs_batch* b, u64* cap_out) {
-    VPBS_HIP(hipMemcpyAsync(cap_out, b->d_digests + b->level_off.back(), sizeof(u64) * ((size_t)4 << b->ctx->cap_height),
-                            hipMemcpyDeviceToHost, b->ctx->stream));
+    VPBS_HIP(hipMemcpyAsync(cap_out, b->d_digests + b->level_off.back(), sizeof(u64) * 4 * b->cap_len(), hipMemcpyDeviceToHost,
+                            b->ctx->stream));
     VPBS_HIP(hipStreamSynchronize(b->ctx->stream));
 }
 }  // namespace vpbs
@@ -268,6 +278,23 @@ int vpbs_commit_coeffs_dev(vpbs_ctx* c, const uint64_t* v, unsigned ncols, unsig
     return commit_any(c, v, true, false, ncols, log_n, out, cap);
 }
 
+int vpbs_commit_sharded_dev(vpbs_ctx* c, const uint64_t* d_data, int is_values, unsigned ncols, unsigned log_n, unsigned shard,
+                            unsigned n_shards, vpbs_batch** out, uint64_t* local_cap_out) {
+    if (!c || !d_data || !out) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        vpbs_batch* b = vpbs::commit_device(c, d_data, ncols, log_n, is_values != 0, shard, n_shards);
+        if (local_cap_out) {
+            try {
+                vpbs::batch_cap_to_host(b, local_cap_out);
+            } catch (...) {
+                vpbs_batch_free(b);
+                throw;
+            }
+        }
+        *out = b;
+    });
+}
+
 void vpbs_batch_free(vpbs_batch* b) {
     if (!b) return;
     // stream-ordered reuse: later work on the same stream may take these blocks; nothing else touches them
@@ -295,6 +322,7 @@ int vpbs_batch_lde_rows(vpbs_batch* b, size_t row_start, size_t nrows, size_t st
     if (!b || !out) return VPBS_ERR_INVALID;
     return guarded(b->ctx, [&] {
         vpbs_ctx* c = b->ctx;
+        VPBS_REQUIRE(b->n_shards == 1, "get_lde_values is not available on a sharded batch");
         const size_t L = b->lde_len();
         const unsigned log_L = b->log_n + c->rate_bits;
         VPBS_REQUIRE(nrows <= vpbs::MAX_QUERIES * (size_t)4096, "too many rows in one call");
@@ -346,7 +374,9 @@ int vpbs_batch_open(vpbs_batch* b, size_t leaf_index, uint64_t* leaf_out, uint64
     if (!b || !leaf_out || !siblings_out) return VPBS_ERR_INVALID;
     return guarded(b->ctx, [&] {
         vpbs_ctx* c = b->ctx;
-        VPBS_REQUIRE(leaf_index < b->lde_len(), "leaf index out of range");
+        VPBS_REQUIRE(leaf_index >= b->leaf_offset() && leaf_index < b->leaf_offset() + b->lde_len(),
+                     "leaf index outside this batch's shard");
+        leaf_index -= b->leaf_offset();
         vpbs::OpenArgs a{};
         a.n_trees = 1;
         a.n_queries = 1;

@@ -98,8 +98,15 @@ struct vpbs_batch {
     vpbs::u64* d_lde = nullptr;      // [ncols][n << rate_bits], leaf order
     vpbs::u64* d_digests = nullptr;  // Merkle levels back to back
     std::vector<size_t> level_off;   // word offset of each level; last level = cap
+    // coset sharding: this batch holds leaf blocks [shard * per, (shard + 1) * per) of the 2^rate_bits
+    // blocks, per = 2^rate_bits / n_shards, i.e. the leaves [leaf_offset(), leaf_offset() + lde_len()) and the
+    // cap entries [shard * cap_len(), (shard + 1) * cap_len()).  n_shards == 1: the whole commitment.
+    unsigned shard = 0, n_shards = 1;
     size_t n() const { return (size_t)1 << log_n; }
-    size_t lde_len() const { return n() << ctx->rate_bits; }
+    unsigned blocks() const { return (1u << ctx->rate_bits) / n_shards; }
+    size_t lde_len() const { return n() * blocks(); }
+    size_t leaf_offset() const { return (size_t)shard * lde_len(); }
+    size_t cap_len() const { return ((size_t)1 << ctx->cap_height) / n_shards; }
     unsigned n_levels() const { return (unsigned)level_off.size(); }
 };
 
@@ -107,6 +114,7 @@ namespace vpbs {
 // Merkle level layout for a tree with n_leaves leaves and cap height h: returns total words
 size_t merkle_layout(size_t n_leaves, unsigned cap_height, std::vector<size_t>& level_off);
 // commit a device-resident matrix (values or coefficients); returns a new batch
-vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values);
+vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values, unsigned shard = 0,
+                          unsigned n_shards = 1);
 void batch_cap_to_host(vpbs_batch* b, u64* cap_out);
 }  // namespace vpbs

@@ -161,7 +161,7 @@ void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_le
 static size_t wide_threshold() {
     static const size_t t = [] {
         const char* e = getenv("VPBS_WIDE_THRESHOLD");
-        return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 15);
+        return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 14);
     }();
     return t;
 }

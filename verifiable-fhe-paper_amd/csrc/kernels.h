@@ -19,8 +19,10 @@ void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, co
                  unsigned log_n);
 // coefficients -> coset LDE in leaf order: out[c][brev_rate(r)*n + q] = value at natural index r + (brev_logn(q) << rate)
 // i.e. out[c][j] = poly_c(shift * w_{big}^{brev_big(j)})   (PolynomialCoeffs::lde + coset_fft + reverse_index_bits)
+// block_first / n_blocks: compute only the leaf blocks [block_first, block_first + n_blocks) of the 2^rate_bits blocks
+// (a block = one coset = n consecutive leaves); out is then [ncols][n_blocks * n].  n_blocks = 0 means all blocks.
 void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* prescale, unsigned ncols,
-                      unsigned log_n, unsigned rate_bits);
+                      unsigned log_n, unsigned rate_bits, unsigned block_first = 0, unsigned n_blocks = 0);
 // batched negacyclic NTT of the reference (crypto/poly.rs:9-64): in place, [batch][n]; roots = ROOTS/INVROOTS table
 void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv);
 

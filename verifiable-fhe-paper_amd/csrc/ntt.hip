@@ -48,13 +48,14 @@ __device__ __forceinline__ void dif_stage(u64* tile, unsigned n_butterflies, uns
 __global__ void __launch_bounds__(THREADS)
 ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
                    const u64* __restrict__ roots, unsigned log_n, unsigned log_r, size_t in_col_stride,
-                   size_t out_col_stride, unsigned rate_bits) {
+                   size_t out_col_stride, unsigned rate_bits, unsigned block_first) {
     __shared__ u64 tile[TILE];
     const unsigned log_c = TILE_LOG - log_r;
     const unsigned C = 1u << log_c, R = 1u << log_r;
     const unsigned row_stride = 1u << (log_n - log_r);  // n / R
     const unsigned c0 = blockIdx.x << log_c;
-    const unsigned coset = blockIdx.z;
+    // blockIdx.z = local leaf block; leaf block B holds coset brev(B)
+    const unsigned coset = gl::bitrev32(block_first + blockIdx.z, rate_bits);
     const u64* src = in + blockIdx.y * in_col_stride;
     const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
     for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
@@ -72,7 +73,7 @@ ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64*
             return ((rho & (half_rows - 1)) * row_stride + c0 + gamma) << s;
         });
     }
-    u64* dst = out + blockIdx.y * out_col_stride + ((size_t)gl::bitrev32(coset, rate_bits) << log_n);
+    u64* dst = out + blockIdx.y * out_col_stride + ((size_t)blockIdx.z << log_n);
     for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
         const unsigned rho = t >> log_c, gamma = t & (C - 1);
         dst[rho * row_stride + c0 + gamma] = tile[t];
@@ -85,13 +86,13 @@ ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64*
 __global__ void __launch_bounds__(THREADS)
 ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
                   const u64* __restrict__ roots, unsigned log_n, unsigned s_begin, size_t in_col_stride,
-                  size_t out_col_stride, unsigned rate_bits, int bitrev_out, u64 scale) {
+                  size_t out_col_stride, unsigned rate_bits, int bitrev_out, u64 scale, unsigned block_first) {
     __shared__ u64 tile[TILE];
     const unsigned n = 1u << log_n;
     const unsigned tile_elems = n < TILE ? n : TILE;
     const unsigned base = blockIdx.x * tile_elems;
-    const unsigned coset = blockIdx.z;
-    const size_t coset_off = (size_t)gl::bitrev32(coset, rate_bits) << log_n;
+    const unsigned coset = gl::bitrev32(block_first + blockIdx.z, rate_bits);
+    const size_t coset_off = (size_t)blockIdx.z << log_n;
     u64* dst_col = out + blockIdx.y * out_col_stride;
     if (s_begin == 0) {
         const u64* src = in + blockIdx.y * in_col_stride;
@@ -173,40 +174,42 @@ void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned r
 }
 
 static void run_transform(hipStream_t s, const u64* in, u64* out, u64* scratch, const u64* prescale, const u64* roots,
-                          unsigned ncols, unsigned log_n, unsigned rate_bits, bool inverse, size_t in_stride, size_t out_stride) {
+                          unsigned ncols, unsigned log_n, unsigned rate_bits, bool inverse, size_t in_stride, size_t out_stride,
+                          unsigned block_first, unsigned n_blocks) {
     const unsigned n = 1u << log_n;
-    const unsigned cosets = 1u << rate_bits;
+    const unsigned cosets = n_blocks;
     const unsigned log_r = split_log_r(log_n);
     const u64 scale = inverse ? gl::inv((u64)n) : 1;
     const unsigned tiles = n <= TILE ? 1 : n / TILE;
     if (log_r == 0) {
         hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n, 0u,
-                           in_stride, out_stride, rate_bits, inverse ? 1 : 0, scale);
+                           in_stride, out_stride, rate_bits, inverse ? 1 : 0, scale, block_first);
         return;
     }
     if (inverse) {
         // strided pass into scratch (layout [ncols][n]), contiguous pass scatters into `out`
         hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, in, scratch, (const u64*)nullptr, roots,
-                           log_n, log_r, in_stride, (size_t)n, 0u);
+                           log_n, log_r, in_stride, (size_t)n, 0u, 0u);
         hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, (const u64*)scratch, out,
-                           (const u64*)nullptr, roots, log_n, log_r, (size_t)n, out_stride, 0u, 1, scale);
+                           (const u64*)nullptr, roots, log_n, log_r, (size_t)n, out_stride, 0u, 1, scale, 0u);
     } else {
         hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n,
-                           log_r, in_stride, out_stride, rate_bits);
+                           log_r, in_stride, out_stride, rate_bits, block_first);
         hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, (const u64*)nullptr, out,
-                           (const u64*)nullptr, roots, log_n, log_r, (size_t)0, out_stride, rate_bits, 0, scale);
+                           (const u64*)nullptr, roots, log_n, log_r, (size_t)0, out_stride, rate_bits, 0, scale, block_first);
     }
 }
 
 void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, const u64* inv_roots, unsigned ncols, unsigned log_n) {
     const size_t n = (size_t)1 << log_n;
-    run_transform(s, values, coeffs, scratch, nullptr, inv_roots, ncols, log_n, 0, true, n, n);
+    run_transform(s, values, coeffs, scratch, nullptr, inv_roots, ncols, log_n, 0, true, n, n, 0, 1);
 }
 
 void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* prescale, unsigned ncols,
-                      unsigned log_n, unsigned rate_bits) {
+                      unsigned log_n, unsigned rate_bits, unsigned block_first, unsigned n_blocks) {
     const size_t n = (size_t)1 << log_n;
-    run_transform(s, coeffs, out, nullptr, prescale, roots, ncols, log_n, rate_bits, false, n, n << rate_bits);
+    if (n_blocks == 0) n_blocks = 1u << rate_bits;
+    run_transform(s, coeffs, out, nullptr, prescale, roots, ncols, log_n, rate_bits, false, n, n * n_blocks, block_first, n_blocks);
 }
 
 void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv) {

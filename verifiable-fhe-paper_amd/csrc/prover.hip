@@ -91,7 +91,8 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
     VPBS_REQUIRE(rate_bits == ctx->rate_bits && cap_h == ctx->cap_height, "FRI params disagree with the context");
     VPBS_REQUIRE(fp.config.num_query_rounds <= vpbs::MAX_QUERIES, "too many query rounds");
     VPBS_REQUIRE(oracles.size() + fp.reduction_arity_bits.size() <= vpbs::MAX_OPEN_TREES, "too many trees");
-    for (auto* o : oracles) VPBS_REQUIRE(o && o->log_n == degree_bits && o->ctx == ctx, "oracle does not match degree/context");
+    for (auto* o : oracles)
+        VPBS_REQUIRE(o && o->log_n == degree_bits && o->ctx == ctx && o->n_shards == 1, "oracle does not match degree/context (or is sharded)");
 
     std::vector<void*> scratch;  // released at the end (stream-ordered pool)
     auto words = [&](size_t w) {

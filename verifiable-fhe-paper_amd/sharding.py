@@ -56,3 +56,21 @@ def all_gather_cap(local_cap, group=None):
     out = [torch.empty_like(local_cap) for _ in range(world)]
     dist.all_gather(out, local_cap, group=group)
     return torch.cat(out, dim=0)
+
+
+def sharded_commit(ctx, d_values_ptr, ncols, log_n, is_values=True, group=None, device=None):
+    """Coset-sharded PolynomialBatch commit across the ranks of `group` (one GPU per rank).
+
+    Every rank holds the full input matrix (device pointer); it runs the (cheap) iNTT for all columns, the LDE, leaf
+    hashing and Merkle subtrees of ITS cosets only (vpbs_commit_sharded_dev), then one all-gather of the
+    2^cap_height / world cap hashes per rank assembles the cap on every rank.  Returns (local batch, full cap ndarray).
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    batch, local_cap = ctx.commit_sharded_dev(d_values_ptr, ncols, log_n, rank, world, is_values)
+    t = torch.from_numpy(local_cap.view(np.int64))
+    if device is not None:
+        t = t.to(device)
+    cap = all_gather_cap(t, group).cpu().numpy().view(np.uint64)
+    return batch, cap
