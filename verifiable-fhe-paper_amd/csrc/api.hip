@@ -42,6 +42,21 @@ void vpbs_ctx::trim() {
     }
     free_blocks.clear();
 }
+void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
+    constexpr size_t STAGE = (size_t)1 << 20;
+    if (!pinned) {
+        if (hipHostMalloc(&pinned, STAGE, hipHostMallocDefault) == hipSuccess) pinned_bytes = STAGE;
+        else pinned = nullptr;
+    }
+    if (pinned && bytes <= pinned_bytes) {
+        VPBS_HIP(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, stream));
+        VPBS_HIP(hipStreamSynchronize(stream));
+        std::memcpy(dst, pinned, bytes);
+    } else {
+        VPBS_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
+        VPBS_HIP(hipStreamSynchronize(stream));
+    }
+}
 const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
     auto key = std::make_pair(log_n, inverse);
     auto it = root_tables.find(key);
@@ -159,9 +174,7 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
 }
 
 void batch_cap_to_host(vpbs_batch* b, u64* cap_out) {
-    VPBS_HIP(hipMemcpyAsync(cap_out, b->d_digests + b->level_off.back(), sizeof(u64) * 4 * b->cap_len(), hipMemcpyDeviceToHost,
-                            b->ctx->stream));
-    VPBS_HIP(hipStreamSynchronize(b->ctx->stream));
+    b->ctx->d2h_sync(cap_out, b->d_digests + b->level_off.back(), sizeof(u64) * 4 * b->cap_len());
 }
 }  // namespace vpbs
 
@@ -231,6 +244,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     c->resolve_timing();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -47,6 +47,12 @@ struct vpbs_ctx {
     void release(void* p);
     void trim();
 
+    // ---- pinned staging for the small device->host results of the transcript (caps, openings, query records) ----
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // copy + stream synchronise; dst is ordinary (pageable) caller memory
+    void d2h_sync(void* dst, const void* d_src, size_t bytes);
+
     // ---- tables ----
     std::map<std::pair<unsigned, bool>, vpbs::u64*> root_tables;                 // (log_n, inverse)
     std::map<std::tuple<unsigned, unsigned, vpbs::u64>, vpbs::u64*> prescale_tables;  // (log_n, rate_bits, shift)

@@ -10,6 +10,8 @@
 // A transform is two launches: a strided pass (stages 0..log_r-1, tile = R rows x C adjacent columns in LDS, 128-B
 // row segments coalesced) and a contiguous pass (remaining stages on 2048-element tiles, in place).  Twiddles are
 // read from an HBM table of w^j (L2-resident: 128 KiB at n = 2^15).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace vpbs {
@@ -29,19 +31,77 @@ __global__ void prescale_table_kernel(u64* table, unsigned log_n, unsigned rate_
     if (i < ((size_t)1 << log_n)) table[((size_t)r << log_n) + i] = gl::pow(gl::mul(shift, gl::pow(w_big, r)), i);
 }
 
-// One DIF stage sweep over an LDS tile.  `dist` = butterfly distance inside the tile (power of two),
-// twiddle index of butterfly with low element at tile position t is tw_index(t).
+// Register radix-8 rounds over an LDS tile of TILE elements (THREADS x 8).  A round performs up to three consecutive
+// DIF stages on the 8 values a thread holds, so the tile crosses LDS once per 3 stages instead of once per stage.
+// Stage "bits": the butterfly distance of a stage is 2^bit in tile-index space.  In a round with stage bits
+// b1 > b2 > b3 the thread owns the 8 tile indices that differ only in those bits; rounds with fewer than three stages
+// left fill the spare positions with unused low/high bits (those values just ride along).
+// tw(idx_lo, stage) returns the twiddle-table index of the butterfly whose low element sits at tile index idx_lo.
+// LDS swizzle: physical slot = idx ^ ((idx >> 3) & 31).  It is GF(2)-linear and a bijection on every aligned group of
+// 32 elements, and it makes all three lane patterns of the radix-8 rounds conflict-free for ds_read/write_b64
+// (lanes varying index bits {0..4}, {0,1,2,6,7} or {3..7}: see DESIGN.md) -- the unswizzled tile had 4- and 8-way
+// bank conflicts in the second and third round.
+__device__ __forceinline__ unsigned sw(unsigned idx) { return idx ^ ((idx >> 3) & 31u); }
+
+__device__ __forceinline__ unsigned insert_zero_bit(unsigned x, unsigned pos) {
+    return ((x >> pos) << (pos + 1)) | (x & ((1u << pos) - 1));
+}
+
 template <typename TwIndex>
-__device__ __forceinline__ void dif_stage(u64* tile, unsigned n_butterflies, unsigned dist, const u64* __restrict__ roots,
-                                          TwIndex tw_index) {
-    for (unsigned k = threadIdx.x; k < n_butterflies; k += THREADS) {
-        const unsigned lo = ((k / dist) * 2 * dist) + (k % dist);
-        const unsigned hi = lo + dist;
-        const u64 u = tile[lo], v = tile[hi];
-        tile[lo] = gl::add(u, v);
-        tile[hi] = gl::mul(gl::sub(u, v), roots[tw_index(lo)]);
+__device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigned first_bit, const u64* __restrict__ roots,
+                                           TwIndex tw_index) {
+    // stage j (0-based inside this pass) has distance bit first_bit - j
+    for (unsigned j0 = 0; j0 < n_stages; j0 += 3) {
+        const unsigned ns = n_stages - j0 < 3 ? n_stages - j0 : 3;
+        // active bits, descending; spare bits chosen below the lowest active bit or above the highest
+        unsigned b[3];
+        b[0] = first_bit - j0;
+        b[1] = ns > 1 ? b[0] - 1 : (b[0] >= 1 ? b[0] - 1 : b[0] + 1);
+        b[2] = ns > 2 ? b[0] - 2 : (b[0] >= 2 ? b[0] - 2 : b[0] + (ns > 1 ? 1 : 2));
+        // sort descending so that zero-bit insertion goes from the lowest position up
+        unsigned p0 = b[0], p1 = b[1], p2 = b[2];
+        if (p0 < p1) { unsigned t = p0; p0 = p1; p1 = t; }
+        if (p1 < p2) { unsigned t = p1; p1 = p2; p2 = t; }
+        if (p0 < p1) { unsigned t = p0; p0 = p1; p1 = t; }
+        unsigned base = insert_zero_bit(insert_zero_bit(insert_zero_bit(threadIdx.x, p2), p1), p0);
+        const unsigned pbase = sw(base);  // sw is linear: sw(base | kbits) = sw(base) ^ sw(kbits), kbits wave-uniform
+        // element k: bit b[0] <- k>>2, b[1] <- (k>>1)&1, b[2] <- k&1   (b[] in stage order, not sorted order)
+        u64 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = tile[pbase ^ sw((((k >> 2) & 1u) << b[0]) | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]))];
+        // stage A: pairs (k, k+4)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned lo = base | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]);
+                const u64 u = x[k], v = x[k + 4];
+                x[k] = gl::add(u, v);
+                x[k + 4] = gl::mul(gl::sub(u, v), roots[tw_index(lo, j0)]);
+            }
+        }
+        if (ns > 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k & 2) continue;  // pairs (k, k+2)
+                const unsigned lo = base | (((k >> 2) & 1u) << b[0]) | ((k & 1u) << b[2]);
+                const u64 u = x[k], v = x[k + 2];
+                x[k] = gl::add(u, v);
+                x[k + 2] = gl::mul(gl::sub(u, v), roots[tw_index(lo, j0 + 1)]);
+            }
+        }
+        if (ns > 2) {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {  // pairs (k, k+1)
+                const unsigned lo = base | (((k >> 2) & 1u) << b[0]) | (((k >> 1) & 1u) << b[1]);
+                const u64 u = x[k], v = x[k + 1];
+                x[k] = gl::add(u, v);
+                x[k + 1] = gl::mul(gl::sub(u, v), roots[tw_index(lo, j0 + 2)]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[pbase ^ sw((((k >> 2) & 1u) << b[0]) | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]))] = x[k];
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // Strided pass: stages [0, log_r).  Tile = R rows x C cols, element (rho, gamma) <-> index rho*(n/R) + c0 + gamma.
@@ -63,20 +123,19 @@ ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64*
         const unsigned idx = rho * row_stride + c0 + gamma;
         u64 x = src[idx];
         if (ps) x = gl::mul(x, ps[idx]);
-        tile[t] = x;
+        tile[sw(t)] = x;
     }
     __syncthreads();
-    for (unsigned s = 0; s < log_r; ++s) {
+    // stage s: butterfly distance (R >> (s+1)) rows = tile bit log_c + log_r - 1 - s
+    dif_rounds(tile, log_r, log_c + log_r - 1, roots, [=](unsigned lo, unsigned s) {
         const unsigned half_rows = R >> (s + 1);
-        dif_stage(tile, TILE / 2, half_rows << log_c, roots, [=](unsigned lo) {
-            const unsigned rho = lo >> log_c, gamma = lo & (C - 1);
-            return ((rho & (half_rows - 1)) * row_stride + c0 + gamma) << s;
-        });
-    }
+        const unsigned rho = lo >> log_c, gamma = lo & (C - 1);
+        return ((rho & (half_rows - 1)) * row_stride + c0 + gamma) << s;
+    });
     u64* dst = out + blockIdx.y * out_col_stride + ((size_t)blockIdx.z << log_n);
     for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
         const unsigned rho = t >> log_c, gamma = t & (C - 1);
-        dst[rho * row_stride + c0 + gamma] = tile[t];
+        dst[rho * row_stride + c0 + gamma] = tile[sw(t)];
     }
 }
 
@@ -100,23 +159,39 @@ ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* 
         for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) {
             u64 x = src[base + t];
             if (ps) x = gl::mul(x, ps[base + t]);
-            tile[t] = x;
+            tile[sw(t)] = x;
         }
     } else {
         // in place continuation; for the inverse transform the strided pass wrote to `in` (scratch)
         const u64* src = bitrev_out ? in + blockIdx.y * in_col_stride : dst_col + coset_off;
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[t] = src[base + t];
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[sw(t)] = src[base + t];
     }
     __syncthreads();
-    for (unsigned s = s_begin; s < log_n; ++s) {
-        const unsigned half = n >> (s + 1);
-        dif_stage(tile, tile_elems / 2, half, roots, [=](unsigned lo) { return ((base + lo) & (half - 1)) << s; });
+    if (tile_elems == TILE) {
+        // stage s: distance n >> (s+1) = tile bit log_n - 1 - s
+        dif_rounds(tile, log_n - s_begin, log_n - 1 - s_begin, roots, [=](unsigned lo, unsigned j) {
+            const unsigned s = s_begin + j;
+            const unsigned half = n >> (s + 1);
+            return ((base + lo) & (half - 1)) << s;
+        });
+    } else {
+        // small transforms (n < 2048): plain radix-2 sweeps
+        for (unsigned s = s_begin; s < log_n; ++s) {
+            const unsigned half = n >> (s + 1);
+            for (unsigned k = threadIdx.x; k < tile_elems / 2; k += THREADS) {
+                const unsigned lo = ((k / half) * 2 * half) + (k % half);
+                const u64 u = tile[sw(lo)], v = tile[sw(lo + half)];
+                tile[sw(lo)] = gl::add(u, v);
+                tile[sw(lo + half)] = gl::mul(gl::sub(u, v), roots[((base + lo) & (half - 1)) << s]);
+            }
+            __syncthreads();
+        }
     }
     if (bitrev_out) {
         for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS)
-            dst_col[gl::bitrev32(base + t, log_n)] = gl::mul(tile[t], scale);
+            dst_col[gl::bitrev32(base + t, log_n)] = gl::mul(tile[sw(t)], scale);
     } else {
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) dst_col[coset_off + base + t] = tile[t];
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) dst_col[coset_off + base + t] = tile[sw(t)];
     }
 }
 

@@ -71,8 +71,7 @@ u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forc
             Timed t(ctx, "pow_search");
             VPBS_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(u64), ctx->stream));
             vpbs::launch_pow_search(ctx->stream, st, pos, pow_bits, start, span, d_res);
-            VPBS_HIP(hipMemcpyAsync(&witness, d_res, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->d2h_sync(&witness, d_res, sizeof(u64));
         }
         ctx->release(d_res);
         if (!valid(witness)) throw DeviceError{VPBS_ERR_POW, "device proof-of-work result failed the host re-check"};
@@ -191,8 +190,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
             vpbs::launch_fri_leaf_hash(s, t.values, t.values + lde_len, t.n_leaves, ab, t.digests);
             vpbs::launch_merkle_tree(s, t.digests, t.level_off.data(), (unsigned)t.level_off.size(), t.n_leaves);
         }
-        VPBS_HIP(hipMemcpyAsync(w, t.digests + t.level_off.back(), sizeof(u64) * cap_words, hipMemcpyDeviceToHost, s));
-        VPBS_HIP(hipStreamSynchronize(s));
+        ctx->d2h_sync(w, t.digests + t.level_off.back(), sizeof(u64) * cap_words);
         challenger.observe_cap(w, cap_words / 4);
         w += cap_words;
         const Ext beta = challenger.get_extension_challenge();
@@ -209,8 +207,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
     // final polynomial (the coefficients above len are the ones the reference truncates: they are zero)
     const size_t final_len = (size_t)1 << log_len;
     std::vector<u64> h_final(2 * final_len), final_words(2 * final_len);
-    VPBS_HIP(hipMemcpyAsync(h_final.data(), coeffs, sizeof(u64) * 2 * final_len, hipMemcpyDeviceToHost, s));
-    VPBS_HIP(hipStreamSynchronize(s));
+    ctx->d2h_sync(h_final.data(), coeffs, sizeof(u64) * 2 * final_len);
     for (size_t i = 0; i < final_len; ++i) {
         final_words[2 * i] = h_final[i];
         final_words[2 * i + 1] = h_final[final_len + i];
@@ -266,8 +263,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         Timed tm(ctx, "fri_open_queries");
         vpbs::launch_open_queries(s, d_args, nt, args.n_queries, d_rec);
     }
-    VPBS_HIP(hipMemcpyAsync(w, d_rec, sizeof(u64) * off * args.n_queries, hipMemcpyDeviceToHost, s));
-    VPBS_HIP(hipStreamSynchronize(s));
+    ctx->d2h_sync(w, d_rec, sizeof(u64) * off * args.n_queries);
     w += off * args.n_queries;
     std::memcpy(w, final_words.data(), sizeof(u64) * final_words.size());
     w += final_words.size();
@@ -460,8 +456,7 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
         }
         // gather the final results (each oracle block: [ncols][2] results followed by its partial sums)
         std::vector<u64> h_open(2 * (total_cols + nc) * (size_t)(1 + chunks));
-        VPBS_HIP(hipMemcpyAsync(h_open.data(), d_open, sizeof(u64) * h_open.size(), hipMemcpyDeviceToHost, s));
-        VPBS_HIP(hipStreamSynchronize(s));
+        ctx->d2h_sync(h_open.data(), d_open, sizeof(u64) * h_open.size());
         {
             u64* w = openings_out;
             size_t col = 0;
