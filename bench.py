@@ -4,8 +4,9 @@
 A "step" = one step proof of the vPBS IVC chain on the 2^15-row, 135-wire plonky2 circuit (BASELINE config 2:
 commit wires / Z+partial-products / quotient chunks -> openings -> FRI, Fiat-Shamir transcript included) with the
 inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  The
-witness-generation, partial-product and quotient-evaluation stages of plonky2's prove() are host stages outside this
-round's hot path and are NOT inside the timed region -- `config.stages` says so explicitly.
+witness-generation and quotient-evaluation stages of plonky2's prove() are host stages outside this round's hot path
+ and are NOT inside the timed region -- `config.stages` says so explicitly.  The permutation-argument
+partial products (row a12) ARE computed inside the step, on the GPU.
 
 Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode).
 Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: under torch.distributed.run, one rank per GPU)
@@ -29,6 +30,7 @@ from vpbs_amd import synth  # noqa: E402
 STEPS_PER_VPBS = 730       # n + 2 with n = 728 (reference src/main.rs:27, ivc_based_vpbs.rs:433-436)
 LOG_N = 15                 # degree of the step circuit at N = 1024 (ivc_based_vpbs.rs:57)
 COLS = synth.STEP_COLS
+N_CONSTANTS, N_ROUTED = 5, 80   # constants_sigmas = 5 selector/constant columns + 80 sigma columns (standard_recursion_config)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
@@ -58,7 +60,8 @@ def cpu_baseline():
     digest = np.array([11, 22, 33, 44], np.uint64)
     cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)   # committed once per circuit: untimed
     t0 = time.time()
-    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs)
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][N_CONSTANTS:N_CONSTANTS + N_ROUTED])
+    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED)
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": os.cpu_count(), "kind": "port",
@@ -106,12 +109,13 @@ def main():
         # chain c of rank r proves its own seeded instance
         inst = rank * n_chains + c
         inputs = synth.step_inputs(log_n, instance=inst)
-        dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
+        dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
         cs = ctx.commit_values(inputs["constants_sigmas"])          # once per circuit, untimed
         pis = synth.field_elements(0xABCD + inst, 77)
-        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), dev["zs_partial_products"].data_ptr(),
-                                  dev["quotient"].data_ptr(), cs, digest, pis, on_device=True,
-                                  shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]))
+        sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
+        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, dev["quotient"].data_ptr(), cs, digest, pis,
+                                  on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
+                                  sigmas=sig_ptr, n_routed=N_ROUTED)
         ctxs.append(ctx); sis.append(si); keep.append((dev, cs, pis))
     torch.cuda.synchronize()
 
@@ -164,12 +168,13 @@ def main():
         for c in range(1, args.batch_chains):
             cx = vpbs_amd.Context(local_rank, log_n_max=16)
             inp = synth.step_inputs(log_n, instance=c)
-            dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "zs_partial_products", "quotient")}
+            dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
             csb = cx.commit_values(inp["constants_sigmas"])
             pi2 = synth.field_elements(0xABCD + c, 77)
-            extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), dv["zs_partial_products"].data_ptr(),
-                                                  dv["quotient"].data_ptr(), csb, digest, pi2, on_device=True,
-                                                  shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"])), dv, csb, pi2))
+            sp = dv["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)
+            extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, dv["quotient"].data_ptr(), csb, digest, pi2,
+                                                  on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
+                                                  sigmas=sp, n_routed=N_ROUTED), dv, csb, pi2))
         ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
         n_chains = len(ctxs)
         run_steps(1)
@@ -217,10 +222,12 @@ def main():
             "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
                                    "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, 85 constant/sigma "
                                    "columns precommitted; inputs resident in HBM" % (log_n, log_n + 3),
-                       "stages": "iNTT + coset LDE + Poseidon Merkle (3 commits) + openings at zeta/g*zeta + FRI "
-                                 "(combine, 3 arity-16 folds, 16-bit PoW, 28 queries) + Fiat-Shamir transcript; witness "
-                                 "generation, partial products and quotient evaluation are host stages outside the timed "
-                                 "region (SURVEY.md 8f-1/2)",
+                       "stages": "wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> permutation Z + partial "
+                                 "products on the GPU -> commit -> alphas -> quotient-chunk commit -> zeta -> openings at "
+                                 "zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit PoW, 28 queries), Fiat-Shamir "
+                                 "transcript included.  NOT in the timed region (host stages of plonky2's prove(), SURVEY.md "
+                                 "8f): witness generation and quotient-polynomial evaluation (its output, the 16 quotient "
+                                 "chunks, is supplied as data)",
                        "parallelism": "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",

@@ -137,13 +137,18 @@ typedef struct {
     unsigned num_challenges;          /* 2 */
     int inputs_on_device;             /* 1: the three pointers below are device pointers */
     const uint64_t* wires_values;     /* [n_wires][n]   -> from_values */
-    const uint64_t* zs_pp_values;     /* [n_zs_pp][n]   -> from_values */
+    const uint64_t* zs_pp_values;     /* [n_zs_pp][n]   -> from_values; NULL: computed on the device from the wires, the
+                                         sigma values below and the transcript's betas/gammas (vpbs_partial_products) */
     const uint64_t* quotient_coeffs;  /* [n_quotient][n]-> from_coeffs */
     vpbs_batch* constants_sigmas;     /* committed once per circuit (prover_data.constants_sigmas_commitment) */
     uint64_t circuit_digest[4];
     const uint64_t* public_inputs;    /* host */
     size_t n_public_inputs;
     uint64_t forced_pow;              /* VPBS_POW_ANY or a nonce */
+    /* used only when zs_pp_values == NULL (same host/device residency as the other matrices): */
+    const uint64_t* sigmas_values;    /* [n_routed][n] sigma polynomial values on H (prover_data.sigmas, column-major) */
+    unsigned n_routed;                /* 80: config.num_routed_wires */
+    unsigned quotient_degree_factor;  /* 8: chunk size of the partial products */
 } vpbs_step_inputs;
 
 /* sizes of the outputs of vpbs_prove_step, in u64 words */
@@ -167,6 +172,15 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
 long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants,
                               const uint64_t* caps, const uint64_t* openings, const uint64_t* fri, uint8_t* out,
                               size_t out_capacity);
+
+/* = plonk/prover.rs all_wires_permutation_partial_products: Z polynomials and partial products of
+ * the permutation argument for every challenge.  wires [>= n_routed][n] and sigmas [n_routed][n] are values on the
+ * subgroup (column-major); k_is[j] = 7^j.  out: [num_challenges * (num_prods + 1)][n], num_prods =
+ * ceil(n_routed / max_degree) - 1, in the prover's batch order: Z_0..Z_{nc-1}, then the partial products of challenge
+ * 0, 1, ...  on_device: all three matrix pointers are device pointers.  VPBS_ERR_INVALID if a denominator is zero. */
+int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas, int on_device, unsigned n_routed,
+                          unsigned log_n, const uint64_t* betas, const uint64_t* gammas, unsigned num_challenges,
+                          unsigned max_degree, uint64_t* out);
 
 /* ---- kernel-level entry points (host buffers; used by parity tests and by callers outside the prover) ---- */
 int vpbs_k_poseidon_batch(vpbs_ctx* ctx, uint64_t* states /* [n][12] in place */, size_t n);

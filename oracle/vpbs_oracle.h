@@ -127,6 +127,16 @@ int orc_verify_fri(const u64* const* caps, const size_t* ncols, size_t n_oracles
                    const u64* const* openings, size_t n_batches, orc_challenger* ch, const orc_fri_params* params,
                    unsigned degree_bits, const u64* proof);
 
+/* ---- permutation argument: Z and partial products (plonk/prover.rs all_wires_permutation_partial_products,
+ *      wires_permutation_partial_products_and_zs; plonk/permutation_argument.rs get_unique_coset_shifts) ----
+ * wires: [>= n_routed][n] trace values; sigmas: [n_routed][n] sigma polynomial values on H (natural order);
+ * k_is[j] = 7^j; subgroup x_i = w_n^i.  Per challenge c and row i: num_j = w + beta*k_j*x + gamma,
+ * den_j = w + beta*sigma_j + gamma, quotients via batch inverse, products over chunks of `max_degree` (8) consecutive j,
+ * running product seeded with Z(x); stored per row: the num_prods partial products then Z(x) (Z(w^0) = 1).
+ * out: [num_challenges * (num_prods + 1)][n] in the prover's batch order: Z_0..Z_{nc-1}, then pp of challenge 0, 1, ... */
+int orc_partial_products(const u64* wires, const u64* sigmas, size_t n_routed, unsigned log_n, const u64* betas,
+                         const u64* gammas, size_t num_challenges, size_t max_degree, u64* out);
+
 /* ---- negacyclic NTT of the reference (src/vtfhe/crypto/poly.rs:9-64, src/ntt/gen_param_file.sage) ---- */
 void orc_negacyclic_params(unsigned log_n, u64* roots, u64* invroots, u64* ninv);
 void orc_negacyclic_forward(u64* a, unsigned log_n, const u64* roots);

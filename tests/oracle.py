@@ -77,6 +77,7 @@ def lib():
                                             C.POINTER(FriParams), ui, u64, U64P]),
             "orc_verify_fri": (C.c_int, [C.POINTER(U64P), C.POINTER(sz), sz, C.POINTER(FriBatchInfo), C.POINTER(U64P), sz,
                                         C.POINTER(Challenger), C.POINTER(FriParams), ui, U64P]),
+            "orc_partial_products": (C.c_int, [U64P, U64P, sz, ui, U64P, U64P, sz, sz, U64P]),
             "orc_negacyclic_params": (None, [ui, U64P, U64P, U64P]),
             "orc_negacyclic_forward": (None, [U64P, ui, U64P]),
             "orc_negacyclic_backward": (None, [U64P, ui, U64P, u64]),
@@ -152,6 +153,17 @@ def negacyclic_backward(a, invroots, ninv):
     a = u64arr(a).copy()
     lib().orc_negacyclic_backward(ptr(a), a.size.bit_length() - 1, ptr(u64arr(invroots)), ninv)
     return a
+
+
+def partial_products(wires, sigmas, betas, gammas, max_degree=8):
+    w, sg = u64arr(wires), u64arr(sigmas)
+    n_routed, n = sg.shape
+    nc = len(betas)
+    chunks = (n_routed + max_degree - 1) // max_degree
+    out = np.zeros((nc * chunks, n), np.uint64)
+    rc = lib().orc_partial_products(ptr(w), ptr(sg), n_routed, n.bit_length() - 1, ptr(u64arr(betas)), ptr(u64arr(gammas)), nc, max_degree, ptr(out))
+    assert rc == 0, rc
+    return out
 
 
 class Merkle:

@@ -26,7 +26,10 @@ def commit_inputs(inputs, rate_bits=3, cap_height=4):
     }
 
 
-def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, forced_pow=orc.POW_ANY, cs_batch=None):
+def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, forced_pow=orc.POW_ANY, cs_batch=None,
+               sigmas=None, n_routed=0):
+    """sigmas given: the Z / partial-product matrix is computed from the wires and the transcript's betas/gammas
+    (all_wires_permutation_partial_products) instead of being read from inputs["zs_partial_products"]."""
     rate_bits, cap_height = 3, 4
     cs = cs_batch if cs_batch is not None else orc.Batch(inputs["constants_sigmas"], rate_bits, cap_height, True)
     pi_hash = orc.hash_no_pad(public_inputs)
@@ -37,7 +40,9 @@ def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, f
     ch.observe(wires.cap())
     betas = ch.get_n(num_challenges)
     gammas = ch.get_n(num_challenges)
-    zs = orc.Batch(inputs["zs_partial_products"], rate_bits, cap_height, True)
+    zs_values = inputs["zs_partial_products"] if sigmas is None else \
+        orc.partial_products(inputs["wires"][:n_routed], sigmas, betas, gammas)
+    zs = orc.Batch(zs_values, rate_bits, cap_height, True)
     ch.observe(zs.cap())
     alphas = ch.get_n(num_challenges)
     quot = orc.Batch(inputs["quotient"], rate_bits, cap_height, False)

@@ -197,6 +197,25 @@ def _pow_valid(ch, gb, batches, gp, ctx, w):
         return False
 
 
+# ---------- permutation argument (a12) ----------
+@pytest.mark.parametrize("log_n,n_routed,deg,nc", [(3, 10, 4, 2), (8, 80, 8, 2), (11, 80, 8, 2), (9, 17, 8, 1), (10, 8, 8, 3)])
+def test_partial_products_match_oracle(ctx, log_n, n_routed, deg, nc):
+    wires, sig = rand_field(n_routed + 3, 1 << log_n), rand_field(n_routed, 1 << log_n)
+    betas, gammas = [int(x) for x in rand_field(nc)], [int(x) for x in rand_field(nc)]
+    got = ctx.partial_products(wires[:n_routed], sig, betas, gammas, deg)
+    want = orc.partial_products(wires[:n_routed], sig, betas, gammas, deg)
+    assert got.shape == want.shape and (got == want).all()
+    assert (got[:nc, 0] == 1).all()  # Z(1) = 1
+
+
+def test_partial_products_zero_denominator_is_an_error(ctx):
+    wires, sig = rand_field(8, 16), rand_field(8, 16)
+    beta, gamma = 5, 9
+    wires[3][7] = (-(beta * int(sig[3][7]) + gamma)) % P   # den_3(row 7) = 0
+    with pytest.raises(api.VpbsError):
+        ctx.partial_products(wires, sig, [beta], [gamma])
+
+
 # ---------- step proof ----------
 DIGEST = np.array([11, 22, 33, 44], np.uint64)
 
@@ -222,6 +241,23 @@ def test_step_proof_bit_exact(ctx, log_n, cols):
     assert step_oracle.verify_step(got, want["cs_cap"], want["ncols"], DIGEST, pis, log_n)
     n_constants = min(5, want["ncols"][0])
     assert ctx.step_proof_to_bytes(si, n_constants, got) == step_oracle.to_bytes(want, want["ncols"], n_constants, pis, log_n)
+
+
+@pytest.mark.parametrize("log_n", [7, 12])
+def test_step_proof_with_device_partial_products(ctx, log_n):
+    """The step with a12 inside: Z / partial products computed on the GPU from the wires, the sigma columns of the
+    constants_sigmas matrix and the transcript's betas/gammas -- bit-exact against the oracle doing the same."""
+    inputs = synth.step_inputs(log_n)
+    pis = synth.field_elements(0xBEEF, 40)
+    n_constants, n_routed = 5, 80
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs, DIGEST, pis, sigmas=sig, n_routed=n_routed)
+    got = ctx.prove_step(si)
+    want = step_oracle.prove_step(inputs, DIGEST, pis, log_n, sigmas=sig, n_routed=n_routed)
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (got[key] == want[key]).all(), key
+    assert step_oracle.verify_step(got, want["cs_cap"], want["ncols"], DIGEST, pis, log_n)
 
 
 def test_step_proof_device_inputs_match_host_inputs(ctx):

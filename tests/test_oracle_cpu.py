@@ -263,3 +263,64 @@ def test_fri_arity_schedule():
     for d, rounds in ((15, 3), (12, 2), (16, 3)):
         p = orc.fri_params(d)
         assert p.n_rounds == rounds and list(p.arity_bits)[:rounds] == [4] * rounds
+
+
+def test_partial_products_match_bigint_model():
+    """plonk/prover.rs wires_permutation_partial_products_and_zs restated; checked against a direct big-int evaluation
+    (num/den per element, chunk products, running Z) incl. a ragged last chunk."""
+    log_n, n_routed, deg = 3, 10, 4
+    n = 1 << log_n
+    wires, sig = rand_field(n_routed, n), rand_field(n_routed, n)
+    betas, gammas = [int(x) for x in rand_field(2)], [int(x) for x in rand_field(2)]
+    got = orc.partial_products(wires, sig, betas, gammas, max_degree=deg)
+    w = pymodel.root_of_unity(log_n)
+    chunks = (n_routed + deg - 1) // deg
+    assert got.shape == (2 * chunks, n)
+    for c in range(2):
+        z = 1
+        for i in range(n):
+            x = pow(w, i, P)
+            q = [(int(wires[j][i]) + betas[c] * pow(7, j, P) * x + gammas[c]) *
+                 pow(int(wires[j][i]) + betas[c] * int(sig[j][i]) + gammas[c], P - 2, P) % P for j in range(n_routed)]
+            assert int(got[c][i]) == z            # Z(w^i), Z(1) = 1
+            run = z
+            for k in range(chunks):
+                for j in range(deg * k, min(deg * k + deg, n_routed)):
+                    run = run * q[j] % P
+                if k < chunks - 1:
+                    assert int(got[2 + c * (chunks - 1) + k][i]) == run
+            z = run
+
+
+def test_partial_products_true_permutation_closes():
+    """With sigma a genuine permutation of the (column, row) positions and wire values constant on its cycles, the grand
+    product returns to 1: Z(w^n) = 1 (the property the PLONK permutation check relies on)."""
+    log_n, n_routed = 4, 8
+    n = 1 << log_n
+    w = pymodel.root_of_unity(log_n)
+    perm = rng.permutation(n_routed * n)
+    # wire values: equal along each cycle of perm
+    vals = np.zeros(n_routed * n, dtype=np.uint64)
+    seen = np.zeros(n_routed * n, bool)
+    for s0 in range(n_routed * n):
+        if not seen[s0]:
+            v = rand_field(1)[0]
+            t = s0
+            while not seen[t]:
+                seen[t] = True; vals[t] = v; t = perm[t]
+    wires = vals.reshape(n_routed, n)
+    sig = np.zeros((n_routed, n), np.uint64)
+    for pos in range(n_routed * n):
+        tc, tr = divmod(int(perm[pos]), n)
+        sig[pos // n][pos % n] = pow(7, tc, P) * pow(w, tr, P) % P
+    betas, gammas = [int(x) for x in rand_field(1)], [int(x) for x in rand_field(1)]
+    out = orc.partial_products(wires, sig, betas, gammas, max_degree=8)
+    assert int(out[0][0]) == 1
+    # Z(w^n) = Z(w^(n-1)) * (row n-1 product); num_prods = 0 here so recompute the last row product directly
+    x = pow(w, n - 1, P)
+    i = n - 1
+    rowp = 1
+    for j in range(n_routed):
+        rowp = rowp * (int(wires[j][i]) + betas[0] * pow(7, j, P) * x + gammas[0]) % P
+        rowp = rowp * pow(int(wires[j][i]) + betas[0] * int(sig[j][i]) + gammas[0], P - 2, P) % P
+    assert int(out[0][n - 1]) * rowp % P == 1

@@ -43,7 +43,8 @@ class StepInputsC(C.Structure):
                 ("num_challenges", C.c_uint), ("inputs_on_device", C.c_int),
                 ("wires_values", C.c_void_p), ("zs_pp_values", C.c_void_p), ("quotient_coeffs", C.c_void_p),
                 ("constants_sigmas", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
-                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64)]
+                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64),
+                ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint)]
 
 
 class StepSizesC(C.Structure):
@@ -82,6 +83,7 @@ SIGNATURES = {
     "vpbs_step_sizes_get": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(StepSizesC)]),
     "vpbs_prove_step": (_i, [_vp, C.POINTER(StepInputsC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
+    "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -343,21 +345,41 @@ class Context:
 
     # ---- step proof ----
     def make_step_inputs(self, log_n, wires, zs_pp, quotient, constants_sigmas, circuit_digest, public_inputs,
-                         num_challenges=2, forced_pow=POW_ANY, on_device=False, shapes=None):
-        """wires/zs_pp/quotient: numpy matrices [ncols][n] (host) or device pointers with shapes=(nw, nz, nq)."""
+                         num_challenges=2, forced_pow=POW_ANY, on_device=False, shapes=None, sigmas=None, n_routed=0,
+                         quotient_degree_factor=8):
+        """wires/zs_pp/quotient: numpy matrices [ncols][n] (host) or device pointers with shapes=(nw, nz, nq).
+        zs_pp=None: the Z / partial-product matrix is computed on the device from `sigmas` ([n_routed][n] values, same
+        residency as the other matrices); shapes[1] / n_zs then must equal num_challenges * ceil(n_routed / 8)."""
         si = StepInputsC()
         si.log_n = log_n
         keep = []
+        n_zs_auto = num_challenges * ((n_routed + quotient_degree_factor - 1) // quotient_degree_factor) if n_routed else 0
         if on_device:
             nw, nz, nq = shapes
-            si.wires_values, si.zs_pp_values, si.quotient_coeffs = int(wires), int(zs_pp), int(quotient)
+            si.wires_values, si.quotient_coeffs = int(wires), int(quotient)
+            si.zs_pp_values = int(zs_pp) if zs_pp is not None else None
+            if sigmas is not None:
+                si.sigmas_values = int(sigmas)
         else:
-            wires, zs_pp, quotient = _u64(wires), _u64(zs_pp), _u64(quotient)
-            keep += [wires, zs_pp, quotient]
-            nw, nz, nq = wires.shape[0], zs_pp.shape[0], quotient.shape[0]
+            wires, quotient = _u64(wires), _u64(quotient)
+            keep += [wires, quotient]
+            nw, nq = wires.shape[0], quotient.shape[0]
             si.wires_values = wires.ctypes.data
-            si.zs_pp_values = zs_pp.ctypes.data
             si.quotient_coeffs = quotient.ctypes.data
+            if zs_pp is not None:
+                zs_pp = _u64(zs_pp)
+                keep.append(zs_pp)
+                nz = zs_pp.shape[0]
+                si.zs_pp_values = zs_pp.ctypes.data
+            else:
+                nz = n_zs_auto
+                si.zs_pp_values = None
+            if sigmas is not None:
+                sigmas = _u64(sigmas)
+                keep.append(sigmas)
+                si.sigmas_values = sigmas.ctypes.data
+        si.n_routed = n_routed
+        si.quotient_degree_factor = quotient_degree_factor
         si.n_wires, si.n_zs_partial_products, si.n_quotient = nw, nz, nq
         si.num_challenges = num_challenges
         si.inputs_on_device = 1 if on_device else 0
@@ -391,6 +413,18 @@ class Context:
         if n < 0:
             raise VpbsError("vpbs_step_proof_to_bytes failed: %d" % n)
         return bytes(buf[:n])
+
+    def partial_products(self, wires, sigmas, betas, gammas, max_degree=8):
+        """all_wires_permutation_partial_products on host matrices -> [nc * chunks][n] (Z's first)."""
+        w, sg = _u64(wires), _u64(sigmas)
+        n_routed, n = sg.shape
+        nc = len(betas)
+        chunks = (n_routed + max_degree - 1) // max_degree
+        out = np.zeros((nc * chunks, n), np.uint64)
+        b, g = _u64(betas), _u64(gammas)
+        self._check(lib().vpbs_partial_products(self.h, w.ctypes.data, sg.ctypes.data, 0, n_routed, n.bit_length() - 1, _ptr(b), _ptr(g), nc,
+                                                max_degree, out.ctypes.data))
+        return out
 
     # ---- kernel-level hooks ----
     def poseidon_batch(self, states):

@@ -26,6 +26,15 @@ void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roo
 // batched negacyclic NTT of the reference (crypto/poly.rs:9-64): in place, [batch][n]; roots = ROOTS/INVROOTS table
 void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv);
 
+// ---------- permutation.hip ----------
+// Z and partial products (all_wires_permutation_partial_products): out [nc * (num_prods + 1)][n] in batch order
+// (Z_0..Z_{nc-1}, then the partial products of challenge 0, 1, ..); wires [>= n_routed][n], sigmas [n_routed][n] values
+// on H; roots = forward root table of size n; scratch: nc * (n + ceil(n/256)) words; *d_zero_flag |= 1 on a zero
+// denominator.  d_betas / d_gammas: device arrays of nc elements.
+void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas, const u64* roots, unsigned n_routed, unsigned log_n,
+                             unsigned max_degree, const u64* d_betas, const u64* d_gammas, unsigned num_challenges, u64* out,
+                             u64* scratch, unsigned* d_zero_flag);
+
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
 void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests);

@@ -1,0 +1,114 @@
+// Permutation-argument Z polynomials and partial products on gfx950.
+// Replaces plonky2 0.2.0 plonk/prover.rs `all_wires_permutation_partial_products` /
+// `wires_permutation_partial_products_and_zs` (+ `quotient_chunk_products`, `partial_products_and_z_gx`), the stage
+// between the wires commitment and the Z/partial-products commitment of prove() --
+// /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364; SURVEY.md 8a row a12, 8f-1, Appendix A.9.
+//
+// Per row i and challenge c: num_j = w_j + beta k_j x_i + gamma, den_j = w_j + beta sigma_j + gamma (j < n_routed,
+// k_j = 7^j, x_i = w_n^i); chunk quotient c_k = prod(num) / prod(den) over 8 consecutive j (one field inversion per
+// chunk instead of a per-element batch inverse: same field element); Z(w^0) = 1, Z(w^(i+1)) = Z(w^i) prod_k c_k;
+// pp_k(i) = Z(w^i) c_0 .. c_k.  The running product over rows is a two-level multiplicative scan.  Streaming over the
+// wire and sigma columns (coalesced across rows); exact arithmetic => bit-identical to the sequential reference.
+#include "kernels.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned THREADS = 256;
+
+// grid (n / 256, num_challenges).  cp: cumulative chunk products of the row; the first num_prods go to `pp` (to be
+// scaled by Z later), the full row product goes to `rowprod`.
+__global__ void __launch_bounds__(THREADS)
+pp_row_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ roots, unsigned n_routed,
+              unsigned log_n, unsigned max_degree, const u64* __restrict__ betas, const u64* __restrict__ gammas,
+              u64* __restrict__ pp, u64* __restrict__ rowprod, unsigned* __restrict__ zero_flag) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    const unsigned c = blockIdx.y;
+    if (i >= n) return;
+    const u64 beta = betas[c], gamma = gammas[c];
+    const u64 x = i < n / 2 ? roots[i] : gl::neg(roots[i - n / 2]);  // w^i (w^(n/2) = -1); n == 1 handled by the caller
+    u64 t = gl::mul(beta, x);  // beta * k_j * x, k_0 = 1
+    const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree;
+    const unsigned num_prods = n_chunks - 1;
+    u64 run = 1;
+    for (unsigned k = 0; k < n_chunks; ++k) {
+        u64 num = 1, den = 1;
+        for (unsigned j = k * max_degree; j < (k + 1) * max_degree && j < n_routed; ++j) {
+            const u64 w = wires[(size_t)j * n + i];
+            num = gl::mul(num, gl::add(gl::add(w, t), gamma));
+            den = gl::mul(den, gl::add(gl::add(w, gl::mul(beta, sigmas[(size_t)j * n + i])), gamma));
+            t = gl::mul(t, gl::GENERATOR);
+        }
+        if (den == 0) atomicOr(zero_flag, 1u);  // plonky2's batch inverse would panic here
+        run = gl::mul(run, gl::mul(num, gl::inv(den)));
+        if (k < num_prods) pp[((size_t)c * num_prods + k) * n + i] = run;
+    }
+    rowprod[(size_t)c * n + i] = run;
+}
+
+__device__ u64 block_product(u64 v, u64* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (unsigned d = THREADS / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] = gl::mul(sh[threadIdx.x], sh[threadIdx.x + d]);
+        __syncthreads();
+    }
+    const u64 r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(THREADS)
+pp_block_prod_kernel(const u64* __restrict__ rowprod, size_t n, u64* __restrict__ block_prod) {
+    __shared__ u64 sh[THREADS];
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    const u64 v = i < n ? rowprod[blockIdx.y * n + i] : 1;
+    const u64 p = block_product(v, sh);
+    if (threadIdx.x == 0) block_prod[blockIdx.y * gridDim.x + blockIdx.x] = p;
+}
+
+// Z(w^i) = product of the row products of all earlier rows; then scale the row's partial products by Z(w^i)
+__global__ void __launch_bounds__(THREADS)
+pp_finish_kernel(const u64* __restrict__ rowprod, const u64* __restrict__ block_prod, size_t n, unsigned num_prods,
+                 unsigned num_challenges, u64* __restrict__ out) {
+    __shared__ u64 sh[THREADS];
+    const unsigned c = blockIdx.y;
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    // carry = product of the earlier blocks
+    u64 acc = 1;
+    for (unsigned b = threadIdx.x; b < blockIdx.x; b += THREADS) acc = gl::mul(acc, block_prod[c * gridDim.x + b]);
+    const u64 carry = block_product(acc, sh);
+    // inclusive prefix product inside the block (Hillis-Steele)
+    sh[threadIdx.x] = i < n ? rowprod[c * n + i] : 1;
+    __syncthreads();
+    for (unsigned d = 1; d < THREADS; d <<= 1) {
+        u64 v = sh[threadIdx.x];
+        if (threadIdx.x >= d) v = gl::mul(v, sh[threadIdx.x - d]);
+        __syncthreads();
+        sh[threadIdx.x] = v;
+        __syncthreads();
+    }
+    if (i >= n) return;
+    const u64 z = threadIdx.x == 0 ? carry : gl::mul(carry, sh[threadIdx.x - 1]);  // exclusive: rows before i
+    out[(size_t)c * n + i] = z;                                                      // batch order: Z polynomials first
+    u64* pp = out + ((size_t)num_challenges + (size_t)c * num_prods) * n;
+    for (unsigned k = 0; k < num_prods; ++k) pp[(size_t)k * n + i] = gl::mul(pp[(size_t)k * n + i], z);
+}
+}  // namespace
+
+void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas, const u64* roots, unsigned n_routed, unsigned log_n,
+                             unsigned max_degree, const u64* d_betas, const u64* d_gammas, unsigned num_challenges, u64* out,
+                             u64* scratch, unsigned* d_zero_flag) {
+    const size_t n = (size_t)1 << log_n;
+    const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree, num_prods = n_chunks - 1;
+    const unsigned blocks = (unsigned)((n + THREADS - 1) / THREADS);
+    u64* rowprod = scratch;                                 // [nc][n]
+    u64* block_prod = scratch + (size_t)num_challenges * n;  // [nc][blocks]
+    u64* pp = out + (size_t)num_challenges * n;
+    hipLaunchKernelGGL(pp_row_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, wires, sigmas, roots, n_routed, log_n, max_degree,
+                       d_betas, d_gammas, pp, rowprod, d_zero_flag);
+    hipLaunchKernelGGL(pp_block_prod_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, n, block_prod);
+    hipLaunchKernelGGL(pp_finish_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, (const u64*)block_prod, n,
+                       num_prods, num_challenges, out);
+}
+}  // namespace vpbs

@@ -272,6 +272,40 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
 }
 }  // namespace plonky2
 
+namespace {
+// all_wires_permutation_partial_products on the device; d_out: [nc * (num_prods + 1)][n]
+void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sigmas, unsigned n_routed, unsigned log_n,
+                             const u64* betas, const u64* gammas, unsigned nc, unsigned max_degree, u64* d_out) {
+    VPBS_REQUIRE(log_n >= 1 && n_routed >= 1 && max_degree >= 1 && nc >= 1, "bad partial-product shape");
+    const size_t n = (size_t)1 << log_n;
+    hipStream_t s = ctx->stream;
+    u64* d_ch = ctx->alloc_words(2 * nc + 1);
+    u64* scratch = ctx->alloc_words((size_t)nc * (n + (n + 255) / 256));
+    std::vector<u64> h(2 * nc + 1, 0);
+    for (unsigned c = 0; c < nc; ++c) {
+        h[c] = betas[c];
+        h[nc + c] = gammas[c];
+    }
+    unsigned flag = 0;
+    try {
+        VPBS_HIP(hipMemcpyAsync(d_ch, h.data(), sizeof(u64) * h.size(), hipMemcpyHostToDevice, s));
+        {
+            Timed t(ctx, "partial_products");
+            vpbs::launch_partial_products(s, d_wires, d_sigmas, ctx->roots(log_n, false), n_routed, log_n, max_degree, d_ch, d_ch + nc, nc,
+                                          d_out, scratch, reinterpret_cast<unsigned*>(d_ch + 2 * nc));
+        }
+        ctx->d2h_sync(&flag, d_ch + 2 * nc, sizeof(unsigned));
+    } catch (...) {
+        ctx->release(d_ch);
+        ctx->release(scratch);
+        throw;
+    }
+    ctx->release(d_ch);
+    ctx->release(scratch);
+    VPBS_REQUIRE(flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
+}
+}  // namespace
+
 // ---------------- C ABI ----------------
 template <typename F>
 static int guarded(vpbs_ctx* ctx, F&& f) {
@@ -345,6 +379,45 @@ int vpbs_fri_prove(vpbs_ctx* ctx, vpbs_batch* const* oracles, size_t n_oracles, 
     });
 }
 
+int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas, int on_device, unsigned n_routed, unsigned log_n,
+                          const uint64_t* betas, const uint64_t* gammas, unsigned num_challenges, unsigned max_degree, uint64_t* out) {
+    if (!ctx || !wires || !sigmas || !betas || !gammas || !out || n_routed == 0 || max_degree == 0 || num_challenges == 0 || log_n == 0)
+        return VPBS_ERR_INVALID;
+    return guarded(ctx, [&] {
+        const size_t n = (size_t)1 << log_n;
+        const size_t chunks = (n_routed + max_degree - 1) / max_degree;
+        const size_t out_words = (size_t)num_challenges * chunks * n;
+        std::vector<void*> tmp;
+        struct Cleanup {
+            vpbs_ctx* c;
+            std::vector<void*>& v;
+            ~Cleanup() {
+                (void)hipStreamSynchronize(c->stream);
+                for (void* p : v) c->release(p);
+            }
+        } cleanup{ctx, tmp};
+        const u64 *d_w = wires, *d_s = sigmas;
+        u64* d_o = out;
+        if (!on_device) {
+            u64* a = ctx->alloc_words((size_t)n_routed * n);
+            tmp.push_back(a);
+            u64* b = ctx->alloc_words((size_t)n_routed * n);
+            tmp.push_back(b);
+            d_o = ctx->alloc_words(out_words);
+            tmp.push_back(d_o);
+            VPBS_HIP(hipMemcpyAsync(a, wires, sizeof(u64) * n_routed * n, hipMemcpyHostToDevice, ctx->stream));
+            VPBS_HIP(hipMemcpyAsync(b, sigmas, sizeof(u64) * n_routed * n, hipMemcpyHostToDevice, ctx->stream));
+            d_w = a;
+            d_s = b;
+        }
+        partial_products_device(ctx, d_w, d_s, n_routed, log_n, betas, gammas, num_challenges, max_degree, d_o);
+        if (!on_device) {
+            VPBS_HIP(hipMemcpyAsync(out, d_o, sizeof(u64) * out_words, hipMemcpyDeviceToHost, ctx->stream));
+            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    });
+}
+
 int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out) {
     if (!ctx || !in || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
     const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
@@ -386,8 +459,16 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
             }
         } cleanup{ctx, staged};
         const u64* d_wires = on_device(in->wires_values, (size_t)in->n_wires * n);
-        const u64* d_zs = on_device(in->zs_pp_values, (size_t)in->n_zs_partial_products * n);
+        const u64* d_zs = in->zs_pp_values ? on_device(in->zs_pp_values, (size_t)in->n_zs_partial_products * n) : nullptr;
         const u64* d_quot = on_device(in->quotient_coeffs, (size_t)in->n_quotient * n);
+        const u64* d_sigmas = nullptr;
+        if (!in->zs_pp_values) {
+            VPBS_REQUIRE(in->sigmas_values && in->n_routed >= 1 && in->n_routed <= in->n_wires && in->quotient_degree_factor >= 1,
+                         "zs_pp_values == NULL needs sigmas_values, n_routed and quotient_degree_factor");
+            const unsigned chunks = (in->n_routed + in->quotient_degree_factor - 1) / in->quotient_degree_factor;
+            VPBS_REQUIRE(in->n_zs_partial_products == nc * chunks, "n_zs_partial_products != num_challenges * (num_partial_products + 1)");
+            d_sigmas = on_device(in->sigmas_values, (size_t)in->n_routed * n);
+        }
 
         // prove(): public_inputs_hash, wires commitment, transcript
         HashOut pi_hash;
@@ -400,7 +481,14 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
         challenger.observe_cap(caps_out, cap_words / 4);
         const std::vector<u64> betas = challenger.get_n_challenges(nc);
         const std::vector<u64> gammas = challenger.get_n_challenges(nc);
-        // (host stage) all_wires_permutation_partial_products(betas, gammas) -> here: supplied data
+        // all_wires_permutation_partial_products(betas, gammas): on the device when no precomputed matrix is supplied
+        if (!d_zs) {
+            u64* d_pp = ctx->alloc_words((size_t)in->n_zs_partial_products * n);
+            staged.push_back(d_pp);
+            partial_products_device(ctx, d_wires, d_sigmas, in->n_routed, log_n, betas.data(), gammas.data(), nc,
+                                    in->quotient_degree_factor, d_pp);
+            d_zs = d_pp;
+        }
         PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n);
         zs_pp.merkle_cap(caps_out + cap_words);
         challenger.observe_cap(caps_out + cap_words, cap_words / 4);
