@@ -20,7 +20,9 @@ DOMINANT = "leaf_hash_kernel"
 
 
 def short(name):
-    return name.split("(anonymous namespace)::")[-1].split("(")[0].split("<")[0]
+    import re
+    m = re.search(r"(\w+)\s*(<[^(]*>)?\(", name.replace("(anonymous namespace)", "anon"))
+    return m.group(1) if m else name
 
 
 def one(pattern):
