@@ -1,5 +1,6 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
 Bit-exact everywhere (64-bit modular integer work: no tolerance)."""
+import ctypes
 import glob
 import json
 import os
@@ -144,6 +145,32 @@ def test_coset_sharded_commit_matches_unsharded(ctx, n_shards):
     full.free()
 
 
+@pytest.mark.parametrize("log_n,ncols", [(1, 3), (2, 4), (3, 1), (4, 2), (6, 5), (2, 9)])
+def test_commit_edge_shapes(ctx, log_n, ncols):
+    """tiny degrees (tree barely larger than its cap) and leaves of <= 4 elements (hash_or_noop does not hash them)"""
+    data = rand_field(ncols, 1 << log_n)
+    want = orc.Batch(data, 3, 4, from_values=True)
+    got = ctx.commit_values(data)
+    assert (got.cap() == want.cap()).all()
+    L = 1 << (log_n + 3)
+    for idx in (0, L - 1):
+        leaf, sib = got.open(idx)
+        wleaf, wsib = want.open(idx)
+        assert (leaf == wleaf).all() and sib.shape == wsib.shape and (sib == wsib).all()
+    got.free()
+
+
+def test_invalid_arguments_are_errors(ctx):
+    with pytest.raises(api.VpbsError):
+        ctx.commit_values(rand_field(2, 1 << 17))           # log_n > log_n_max of the context
+    b = ctx.commit_values(rand_field(2, 16))
+    with pytest.raises(api.VpbsError):
+        b.open(1 << 20)                                      # leaf index out of range
+    with pytest.raises(api.VpbsError):
+        b.lde_rows(0, 4, step=1 << 10)                       # row * step beyond the LDE
+    b.free()
+
+
 # ---------- FRI ----------
 def _fri_case(ctx, log_n, cols, **over):
     datas = [rand_field(nc, 1 << log_n) for nc in cols]
@@ -164,8 +191,10 @@ def _fri_case(ctx, log_n, cols, **over):
     return o_batches, g_batches, ch, gch, batches, openings, orc.fri_params(log_n, **over), api.fri_params(log_n, **over)
 
 
-@pytest.mark.parametrize("log_n,over", [(6, {}), (9, {}), (12, {}), (8, {"mul_final_by_x": 1}), (7, {"pow_bits": 5, "num_query_rounds": 3})])
+@pytest.mark.parametrize("log_n,over", [(5, {}), (6, {}), (9, {}), (12, {}), (8, {"mul_final_by_x": 1}), (7, {"pow_bits": 5, "num_query_rounds": 3}),
+                                        (10, {"pow_bits": 0})])
 def test_fri_prove_bit_exact(ctx, log_n, over):
+    """log_n = 5: ConstantArityBits(4,5) gives zero folding rounds (the final polynomial is the whole polynomial)."""
     ob, gb, ch, gch, batches, openings, op, gp = _fri_case(ctx, log_n, (4, 6, 3, 2), **over)
     ch_v = ch.clone()
     want = orc.prove_openings(ob, batches, ch, op, log_n)
@@ -271,6 +300,16 @@ def test_step_proof_device_inputs_match_host_inputs(ctx):
     got = ctx.prove_step(si2)
     for key in ("caps", "openings", "fri"):
         assert (got[key] == want[key]).all()
+
+
+def test_step_properties_2pow16(ctx):
+    """BASELINE config 5 shape (N = 2048 ring: degree 2^16 assumed, LDE 2^19, same column counts): the proof verifies
+    under the restated plonky2 verifier; FRI schedule [4,4,4] with a 16-coefficient final polynomial."""
+    log_n = 16
+    inputs, pis, cs, si, got = _step(ctx, log_n)
+    assert step_oracle.verify_step(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
+    assert got["fri"].size == api.lib().vpbs_fri_proof_words(ctypes.byref(api.fri_params(log_n)), log_n, (ctypes.c_size_t * 4)(85, 135, 20, 16), 4)
+    cs.free()
 
 
 def test_full_size_step_properties(ctx):

@@ -31,7 +31,8 @@ void* vpbs_ctx::alloc_bytes(size_t bytes) {
 }
 void vpbs_ctx::release(void* p) {
     if (!p) return;
-    free_blocks.emplace(block_size.at(p), p);
+    auto it = block_size.find(p);
+    if (it != block_size.end()) free_blocks.emplace(it->second, p);  // unknown pointers are ignored, never thrown on
 }
 void vpbs_ctx::trim() {
     (void)hipStreamSynchronize(stream);

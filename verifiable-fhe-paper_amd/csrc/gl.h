@@ -106,11 +106,64 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
         : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
+// Two independent products with their instruction streams interleaved (second register set v88..v95 / s[86:91]): used
+// where a single wave has to hide its own dependent-instruction latency (x^3 and x^4 of the S-box in the 16-lane
+// Poseidon).  r = a * b, q = c * d.
+__device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64& q) {
+    u32 r0, r1, q0, q1;
+    asm("v_mad_u64_u32 v[80:81], vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 v[88:89], vcc, %8, %10, 0\n\t"
+        "v_mad_u64_u32 v[82:83], vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 v[90:91], vcc, %8, %11, 0\n\t"
+        "v_mad_u64_u32 v[82:83], s[80:81], %5, %6, v[82:83]\n\t"
+        "v_mad_u64_u32 v[90:91], s[86:87], %9, %10, v[90:91]\n\t"
+        "v_mad_u64_u32 v[84:85], vcc, %5, %7, 0\n\t"
+        "v_mad_u64_u32 v[92:93], vcc, %9, %11, 0\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v94, 0, 1, s[86:87]\n\t"
+        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
+        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
+        "v_add_co_u32_e32 v89, vcc, v89, v90\n\t"
+        "v_addc_co_u32_e32 v92, vcc, v92, v91, vcc\n\t"
+        "v_addc_co_u32_e32 v93, vcc, v93, v94, vcc\n\t"
+        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
+        "v_mad_u64_u32 v[88:89], s[86:87], v92, -1, v[88:89]\n\t"
+        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
+        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
+        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "v_sub_co_u32_e32 v88, vcc, v88, v93\n\t"
+        "v_subbrev_co_u32_e32 v89, vcc, 0, v89, vcc\n\t"
+        "s_andn2_b64 s[88:89], s[86:87], vcc\n\t"
+        "s_andn2_b64 s[90:91], vcc, s[86:87]\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 v94, 0, 1, s[90:91]\n\t"
+        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 v94, v94, -1, s[88:89]\n\t"
+        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 v95, 0, -1, s[90:91]\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
+        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc\n\t"
+        "v_add_co_u32_e32 %2, vcc, v88, v94\n\t"
+        "v_addc_co_u32_e32 %3, vcc, v89, v95, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(q0), "=&v"(q1)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
+          "v"((u32)(d >> 32))
+        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "vcc", "scc",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+    r = ((u64)r1 << 32) | r0;
+    q = ((u64)q1 << 32) | q0;
+}
 #else
 GL_HD u64 mul_nc(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide(a, b, lo, hi);
     return reduce128_nc(lo, hi);
+}
+GL_HD void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64& q) {
+    r = mul_nc(a, b);
+    q = mul_nc(c, d);
 }
 #endif
 GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
