@@ -79,6 +79,10 @@ def main():
                          "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
     ap.add_argument("--batch-chains", type=int, default=3,
                     help="after the headline single-chain measurement, also time this many concurrent chains (1 GPU only)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N > 1: 'replicas' = independent chains per GPU (weak scaling, default, no data-path collective); "
+                         "'sharded' = ONE chain whose commitments are coset-sharded over the GPUs (strong scaling: per-step "
+                         "latency; collectives: all-gather of cap hashes + one all-reduce of query records per step)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
@@ -101,16 +105,25 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     log_n = args.log_n
-    n_chains = max(1, args.chains)
+    sharded = distributed and args.mode == "sharded"
+    comm = None
+    if sharded:
+        from vpbs_amd import sharding
+        comm = sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
+    n_chains = 1 if sharded else max(1, args.chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
     ctxs, sis, keep = [], [], []
     for c in range(n_chains):
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)
         # chain c of rank r proves its own seeded instance
-        inst = rank * n_chains + c
+        inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst)
         dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
-        cs = ctx.commit_values(inputs["constants_sigmas"])          # once per circuit, untimed
+        if sharded:
+            cs, _ = sharding.sharded_commit(ctx, dev["constants_sigmas"].data_ptr(), COLS["constants_sigmas"], log_n,
+                                            device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
+        else:
+            cs = ctx.commit_values(inputs["constants_sigmas"])      # once per circuit, untimed
         pis = synth.field_elements(0xABCD + inst, 77)
         sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
         si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, dev["quotient"].data_ptr(), cs, digest, pis,
@@ -130,7 +143,7 @@ def main():
         """k step proofs on every chain; chains run concurrently (ctypes releases the GIL inside the library)."""
         if n_chains == 1:
             for _ in range(k):
-                ctxs[0].prove_step(sis[0])
+                ctxs[0].prove_step(sis[0], comm)
             return
         import threading
         errs = []
@@ -196,15 +209,17 @@ def main():
     # per-kernel breakdown of one extra (untimed) step proof on chain 0 alone, for the record
     ctx = ctxs[0]
     ctx.timing_enable(1)
-    ctx.prove_step(sis[0])
+    ctx.prove_step(sis[0], comm)
     breakdown = {k: round(v["ms"], 4) for k, v in ctx.timing_report().items()}
     ctx.timing_enable(0)
 
     if rank == 0:
-        steps_total = args.steps * world * n_chains
+        steps_total = args.steps * (1 if sharded else world) * n_chains
         step_rate = steps_total / elapsed
         scale = (1 << log_n) / float(1 << LOG_N)
         per_step_ms = dominant["ms"] / max(1, args.steps * n_chains)  # three leaf_hash launches per step proof
+        if sharded:
+            scale /= world   # rank 0 hashed 1/world of the leaves
         bytes_step = leaf_hash_bytes_per_step() * scale
         achieved = bytes_step / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
         perms = leaf_hash_perms_per_step() * scale
@@ -217,7 +232,7 @@ def main():
             "metric": "vPBS proofs/sec at N=1024", "value": step_rate / STEPS_PER_VPBS, "unit": "vPBS proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_proof": elapsed / (args.steps * n_chains) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
             "data": "synthetic", "step_proofs_per_s": step_rate, "steps_per_vpbs_proof": STEPS_PER_VPBS,
             "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
                                    "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, 85 constant/sigma "
@@ -228,7 +243,9 @@ def main():
                                  "transcript included.  NOT in the timed region (host stages of plonky2's prove(), SURVEY.md "
                                  "8f): witness generation and quotient-polynomial evaluation (its output, the 16 quotient "
                                  "chunks, is supplied as data)",
-                       "parallelism": "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
+                       "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
+                                       "hashes + 1 all-reduce of query records (%s)" % (world, args.dist_backend)) if sharded else
+                                      "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -151,6 +151,18 @@ typedef struct {
     unsigned quotient_degree_factor;  /* 8: chunk size of the partial products */
 } vpbs_step_inputs;
 
+/* Collectives for a step proof sharded over the GPUs of one node: supplied by the host, so the library
+ * stays free of any communication dependency (bench.py / tests: torch.distributed = RCCL over xGMI or gloo; a C++ host
+ * would call rccl directly).  Payloads are tiny: 2^cap_height hashes per commitment, ~30 KB of query records per proof. */
+typedef int (*vpbs_allgather_fn)(void* user, const uint64_t* local, size_t local_words, uint64_t* full /* [world][local_words] */);
+typedef int (*vpbs_allreduce_sum_fn)(void* user, uint64_t* inout, size_t words); /* element-wise wrapping u64 sum */
+typedef struct {
+    unsigned rank, world;               /* world: power of two <= 2^rate_bits */
+    vpbs_allgather_fn allgather;
+    vpbs_allreduce_sum_fn allreduce_sum;
+    void* user;
+} vpbs_comm;
+
 /* sizes of the outputs of vpbs_prove_step, in u64 words */
 typedef struct {
     size_t cap_words;       /* per cap: 4 << cap_height */
@@ -167,6 +179,16 @@ int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_st
  * challenges_out (optional, may be NULL): betas[nc], gammas[nc], alphas[nc], zeta[2]. */
 int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_out, uint64_t* openings_out,
                     uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out);
+/* The same step proof with every commitment coset-sharded over comm->world ranks (one GPU each).  Every rank holds the
+ * full input matrices and runs the identical transcript; a rank computes the LDE, leaf hashes and Merkle subtrees of its
+ * own cosets only (1/world of the dominant work), caps are assembled with comm->allgather, the FRI rounds are computed
+ * redundantly on every rank (cheaper than exchanging them), and the query openings of the sharded oracles are answered
+ * by the owning rank and merged with comm->allreduce_sum.  in->constants_sigmas must be a batch committed with
+ * vpbs_commit_sharded_dev(.., comm->rank, comm->world, ..) (or an unsharded one).  Every rank returns the complete,
+ * identical proof -- bit-identical to vpbs_prove_step on one GPU. */
+int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out,
+                            uint64_t* openings_out, uint64_t* fri_out, vpbs_challenger_state* challenger_out,
+                            uint64_t* challenges_out);
 /* ProofWithPublicInputs::to_bytes layout (util/serialization); returns bytes written or <0.
  * n_constants: how many leading columns of constants_sigmas are `constants` (the rest are plonk_sigmas). */
 long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants,

@@ -1,0 +1,57 @@
+"""Launched under torch.distributed.run by test_gpu_parity.py (world_size 2, gloo, both ranks on the one GPU of the test
+box): a step proof with every commitment coset-sharded over the ranks is bit-identical, on every rank, to the
+single-GPU step proof, and verifies under the oracle's verifier."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import step_oracle  # noqa: E402
+import vpbs_amd  # noqa: E402
+from vpbs_amd import sharding, synth  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    log_n = int(os.environ.get("VPBS_TEST_LOG_N", "10"))
+    torch.cuda.set_device(0)
+    ctx = vpbs_amd.Context(0, log_n_max=16)
+    inputs = synth.step_inputs(log_n)
+    digest = np.array([5, 6, 7, 8], np.uint64)
+    pis = synth.field_elements(4242, 33)
+    n_constants, n_routed = 5, 80
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
+    # reference: the unsharded proof on this rank
+    cs_full = ctx.commit_values(inputs["constants_sigmas"])
+    si_full = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs_full, digest, pis, sigmas=sig, n_routed=n_routed)
+    want = ctx.prove_step(si_full)
+    # sharded: constants_sigmas committed per rank, then the sharded step
+    dev_cs = torch.from_numpy(inputs["constants_sigmas"].view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    cs_shard, cs_cap = sharding.sharded_commit(ctx, dev_cs.data_ptr(), 85, log_n)
+    assert (cs_cap == cs_full.cap()).all()
+    comm = sharding.make_comm()
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs_shard, digest, pis, sigmas=sig, n_routed=n_routed)
+    got = ctx.prove_step(si, comm)
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (got[key] == want[key]).all(), (rank, key)
+    assert got["challenger"].state_words() == want["challenger"].state_words()
+    assert step_oracle.verify_step(got, cs_cap, [85, 135, 20, 16], digest, pis, log_n)
+    # a replicated (unsharded) constants_sigmas batch is accepted too: rank 0 answers its queries
+    si2 = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs_full, digest, pis, sigmas=sig, n_routed=n_routed)
+    got2 = ctx.prove_step(si2, comm)
+    assert (got2["fri"] == want["fri"]).all()
+    dist.barrier()
+    ctx.close()
+    if rank == 0:
+        print("SHARDED_STEP_OK world=%d log_n=%d" % (world, log_n))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

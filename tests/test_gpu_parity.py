@@ -171,6 +171,21 @@ def test_invalid_arguments_are_errors(ctx):
     b.free()
 
 
+@pytest.mark.parametrize("world,log_n", [(2, 10), (4, 12)])
+def test_sharded_step_proof_multi_rank(world, log_n):
+    """SURVEY.md 8e / BASELINE config 4: one step proof sharded over `world` ranks (gloo collectives, all ranks on this
+    box's single GPU) == the single-GPU proof, bit for bit, on every rank."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tests", "gloo_sharded_step_gpu.py")
+    env = dict(os.environ, VPBS_TEST_LOG_N=str(log_n))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29540 + world), script],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SHARDED_STEP_OK world=%d" % world in r.stdout
+
+
 # ---------- FRI ----------
 def _fri_case(ctx, log_n, cols, **over):
     datas = [rand_field(nc, 1 << log_n) for nc in cols]

@@ -51,6 +51,15 @@ class StepSizesC(C.Structure):
     _fields_ = [("cap_words", C.c_size_t), ("openings_words", C.c_size_t), ("fri_words", C.c_size_t)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t, U64P)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t)
+
+
+class CommC(C.Structure):
+    _fields_ = [("rank", C.c_uint), ("world", C.c_uint), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
+                ("user", C.c_void_p)]
+
+
 # every symbol include/vpbs_prover.h declares: name -> (restype, argtypes)
 _vp, _sz, _ui, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint, C.c_uint64, C.c_int
 SIGNATURES = {
@@ -82,6 +91,7 @@ SIGNATURES = {
                             C.POINTER(ChallengerStateC), _u64, U64P]),
     "vpbs_step_sizes_get": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(StepSizesC)]),
     "vpbs_prove_step": (_i, [_vp, C.POINTER(StepInputsC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
+    "vpbs_prove_step_sharded": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(CommC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
@@ -394,7 +404,8 @@ class Context:
         si._keep = keep
         return si
 
-    def prove_step(self, si):
+    def prove_step(self, si, comm=None):
+        """comm: a CommC (sharding.make_comm) -> vpbs_prove_step_sharded, every rank returns the complete proof."""
         sizes = StepSizesC()
         self._check(lib().vpbs_step_sizes_get(self.h, C.byref(si), C.byref(sizes)))
         caps = np.zeros((3, sizes.cap_words // 4, 4), np.uint64)
@@ -402,7 +413,11 @@ class Context:
         fri = np.zeros(sizes.fri_words, np.uint64)
         ch = ChallengerState()
         chal = np.zeros(3 * si.num_challenges + 2, np.uint64)
-        self._check(lib().vpbs_prove_step(self.h, C.byref(si), _ptr(caps), _ptr(openings), _ptr(fri), C.byref(ch.c), _ptr(chal)))
+        if comm is None:
+            self._check(lib().vpbs_prove_step(self.h, C.byref(si), _ptr(caps), _ptr(openings), _ptr(fri), C.byref(ch.c), _ptr(chal)))
+        else:
+            self._check(lib().vpbs_prove_step_sharded(self.h, C.byref(si), C.byref(comm), _ptr(caps), _ptr(openings), _ptr(fri),
+                                                      C.byref(ch.c), _ptr(chal)))
         return {"caps": caps, "openings": openings, "fri": fri, "challenger": ch, "challenges": chal}
 
     def step_proof_to_bytes(self, si, n_constants, proof):

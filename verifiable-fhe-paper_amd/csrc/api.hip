@@ -353,6 +353,8 @@ int vpbs_batch_lde_rows(vpbs_batch* b, size_t row_start, size_t nrows, size_t st
             a.trees[0].data0 = b->d_lde;
             a.trees[0].col_stride = L;
             a.trees[0].leaf_len = b->ncols;
+            a.trees[0].leaf_lo = 0;
+            a.trees[0].leaf_hi = L;
             for (unsigned q = 0; q < cnt; ++q) {
                 const size_t idx = (row_start + done + q) * step;
                 VPBS_REQUIRE(idx < L, "LDE row out of range");
@@ -401,6 +403,8 @@ int vpbs_batch_open(vpbs_batch* b, size_t leaf_index, uint64_t* leaf_out, uint64
         t.col_stride = b->lde_len();
         t.leaf_len = b->ncols;
         t.n_siblings = b->n_levels() - 1;
+        t.leaf_lo = 0;
+        t.leaf_hi = b->lde_len();
         for (unsigned k = 0; k < b->n_levels(); ++k) t.level_off[k] = b->level_off[k];
         a.record_words = b->ncols + 4 * (size_t)t.n_siblings;
         a.x_index[0] = leaf_index;

@@ -142,8 +142,13 @@ fold_kernel(const u64* __restrict__ in0, const u64* __restrict__ in1, size_t n_o
 // grid (n_trees, n_queries): one workgroup copies one (leaf, Merkle path) record
 __global__ void __launch_bounds__(THREADS) open_queries_kernel(const OpenArgs* __restrict__ a, u64* __restrict__ out) {
     const OpenTree& t = a->trees[blockIdx.x];
-    const size_t idx = a->x_index[blockIdx.y] >> t.index_shift;
+    const size_t gidx = a->x_index[blockIdx.y] >> t.index_shift;
     u64* rec = out + blockIdx.y * a->record_words + t.out_off;
+    if (gidx < t.leaf_lo || gidx >= t.leaf_hi) {  // owned by another rank
+        for (unsigned w = threadIdx.x; w < t.leaf_len + 4 * t.n_siblings; w += THREADS) rec[w] = 0;
+        return;
+    }
+    const size_t idx = gidx - t.leaf_lo;
     if (t.data1 == nullptr) {
         for (unsigned e = threadIdx.x; e < t.leaf_len; e += THREADS) rec[e] = t.data0[e * t.col_stride + idx];
     } else {

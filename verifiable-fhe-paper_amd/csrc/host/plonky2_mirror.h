@@ -107,18 +107,34 @@ public:
     ~PolynomialBatch() { vpbs_batch_free(h); }
     // from_values(values, rate_bits, blinding, cap_height, timing, fft_root_table): rate_bits / cap_height come from
     // the ctx; blinding must be false (zero_knowledge is off in standard_recursion_config)
-    static PolynomialBatch from_values(vpbs_ctx* ctx, const u64* d_values, unsigned ncols, unsigned log_n, bool blinding = false) {
+    // comm != nullptr: coset-sharded commitment (this rank's share)
+    static PolynomialBatch from_values(vpbs_ctx* ctx, const u64* d_values, unsigned ncols, unsigned log_n, bool blinding = false,
+                                       const vpbs_comm* comm = nullptr) {
         VPBS_REQUIRE(!blinding, "blinding (zero-knowledge salts) is not part of the vPBS configuration");
-        return PolynomialBatch(vpbs::commit_device(ctx, d_values, ncols, log_n, true));
+        return PolynomialBatch(vpbs::commit_device(ctx, d_values, ncols, log_n, true, comm ? comm->rank : 0, comm ? comm->world : 1));
     }
-    static PolynomialBatch from_coeffs(vpbs_ctx* ctx, const u64* d_coeffs, unsigned ncols, unsigned log_n, bool blinding = false) {
+    static PolynomialBatch from_coeffs(vpbs_ctx* ctx, const u64* d_coeffs, unsigned ncols, unsigned log_n, bool blinding = false,
+                                       const vpbs_comm* comm = nullptr) {
         VPBS_REQUIRE(!blinding, "blinding (zero-knowledge salts) is not part of the vPBS configuration");
-        return PolynomialBatch(vpbs::commit_device(ctx, d_coeffs, ncols, log_n, false));
+        return PolynomialBatch(vpbs::commit_device(ctx, d_coeffs, ncols, log_n, false, comm ? comm->rank : 0, comm ? comm->world : 1));
     }
-    void merkle_cap(u64* out) const { vpbs::batch_cap_to_host(h, out); }
+    // merkle_tree.cap; for a sharded batch the ranks' cap entries are assembled with comm->allgather
+    void merkle_cap(u64* out, const vpbs_comm* comm = nullptr) const {
+        if (h->n_shards == 1) {
+            vpbs::batch_cap_to_host(h, out);
+            return;
+        }
+        VPBS_REQUIRE(comm && comm->allgather && comm->world == h->n_shards && comm->rank == h->shard, "sharded batch needs its communicator");
+        std::vector<u64> local(4 * h->cap_len());
+        vpbs::batch_cap_to_host(h, local.data());
+        if (comm->allgather(comm->user, local.data(), local.size(), out) != 0)
+            throw vpbs::DeviceError{VPBS_ERR_DEVICE, "cap all-gather failed"};
+    }
     // prove_openings(instance, oracles, challenger, fri_params, timing) -> FriProof as flat words (vpbs_prover.h)
+    // comm: needed when any oracle is sharded (query records are merged with comm->allreduce_sum)
     static void prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& instance, const std::vector<vpbs_batch*>& oracles,
-                               Challenger& challenger, const FriParams& fri_params, u64 forced_pow, u64* proof_out);
+                               Challenger& challenger, const FriParams& fri_params, u64 forced_pow, u64* proof_out,
+                               const vpbs_comm* comm = nullptr);
 };
 
 size_t fri_proof_words(const FriParams& p, const std::vector<size_t>& ncols);

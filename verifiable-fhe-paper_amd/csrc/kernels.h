@@ -82,6 +82,9 @@ struct OpenTree {
     u32 index_shift;       // leaf index = x_index >> index_shift
     u32 arity_bits;        // FRI trees only
     size_t out_off;        // word offset of this tree's record inside one query record
+    // multi-GPU: this rank fills the record only for leaf indices in [leaf_lo, leaf_hi) (zeros otherwise; the ranks'
+    // records are then summed).  Unsharded: [0, all).  data0/digests index with (leaf - leaf_lo).
+    size_t leaf_lo, leaf_hi;
 };
 constexpr unsigned MAX_OPEN_TREES = 12, MAX_QUERIES = 128;
 struct OpenArgs {

@@ -83,15 +83,20 @@ u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forc
 }  // namespace
 
 void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& instance, const std::vector<vpbs_batch*>& oracles,
-                                     Challenger& challenger, const FriParams& fp, u64 forced_pow, u64* proof_out) {
+                                     Challenger& challenger, const FriParams& fp, u64 forced_pow, u64* proof_out,
+                                     const vpbs_comm* comm) {
     hipStream_t s = ctx->stream;
     const unsigned degree_bits = fp.degree_bits, rate_bits = fp.config.rate_bits, cap_h = fp.config.cap_height;
     const size_t n = (size_t)1 << degree_bits;
     VPBS_REQUIRE(rate_bits == ctx->rate_bits && cap_h == ctx->cap_height, "FRI params disagree with the context");
     VPBS_REQUIRE(fp.config.num_query_rounds <= vpbs::MAX_QUERIES, "too many query rounds");
     VPBS_REQUIRE(oracles.size() + fp.reduction_arity_bits.size() <= vpbs::MAX_OPEN_TREES, "too many trees");
-    for (auto* o : oracles)
-        VPBS_REQUIRE(o && o->log_n == degree_bits && o->ctx == ctx && o->n_shards == 1, "oracle does not match degree/context (or is sharded)");
+    const bool multi = comm && comm->world > 1;
+    for (auto* o : oracles) {
+        VPBS_REQUIRE(o && o->log_n == degree_bits && o->ctx == ctx, "oracle does not match degree/context");
+        VPBS_REQUIRE(o->n_shards == 1 || (multi && comm->allreduce_sum && o->n_shards == comm->world && o->shard == comm->rank),
+                     "sharded oracle without a matching communicator");
+    }
 
     std::vector<void*> scratch;  // released at the end (stream-ordered pool)
     auto words = [&](size_t w) {
@@ -233,6 +238,10 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         t.leaf_len = o->ncols;
         t.n_siblings = o->n_levels() - 1;
         t.index_shift = 0;
+        // ownership: a sharded oracle answers for its own leaf range; a replicated one is answered by rank 0 only
+        t.leaf_lo = o->leaf_offset();
+        t.leaf_hi = o->leaf_offset() + o->lde_len();
+        if (multi && o->n_shards == 1 && comm->rank != 0) t.leaf_hi = t.leaf_lo = 0;
         for (unsigned k = 0; k < o->n_levels(); ++k) t.level_off[k] = o->level_off[k];
         t.out_off = off;
         off += t.leaf_len + 4 * (size_t)t.n_siblings;
@@ -249,6 +258,8 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         t.n_siblings = (unsigned)ft.level_off.size() - 1;
         t.index_shift = total_shift;
         t.arity_bits = ft.arity_bits;
+        t.leaf_lo = 0;
+        t.leaf_hi = (multi && comm->rank != 0) ? 0 : ft.n_leaves;  // FRI round trees are replicated: rank 0 answers
         for (size_t k = 0; k < ft.level_off.size(); ++k) t.level_off[k] = ft.level_off[k];
         t.out_off = off;
         off += t.leaf_len + 4 * (size_t)t.n_siblings;
@@ -264,6 +275,8 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         vpbs::launch_open_queries(s, d_args, nt, args.n_queries, d_rec);
     }
     ctx->d2h_sync(w, d_rec, sizeof(u64) * off * args.n_queries);
+    if (multi && comm->allreduce_sum(comm->user, w, off * args.n_queries) != 0)
+        throw DeviceError{VPBS_ERR_DEVICE, "query-record all-reduce failed"};
     w += off * args.n_queries;
     std::memcpy(w, final_words.data(), sizeof(u64) * final_words.size());
     w += final_words.size();
@@ -428,9 +441,12 @@ int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_st
     return VPBS_OK;
 }
 
-int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_out, uint64_t* openings_out, uint64_t* fri_out,
-                    vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
+static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
+                           uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
     if (!ctx || !in || !caps_out || !openings_out || !fri_out || !in->constants_sigmas) return VPBS_ERR_INVALID;
+    if (comm && (comm->world == 0 || comm->rank >= comm->world || (comm->world > 1 && (!comm->allgather || !comm->allreduce_sum))))
+        return VPBS_ERR_INVALID;
+    if (comm && comm->world == 1) comm = nullptr;
     return guarded(ctx, [&] {
         using namespace plonky2;
         VPBS_HIP(hipSetDevice(ctx->device));
@@ -473,8 +489,8 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
         // prove(): public_inputs_hash, wires commitment, transcript
         HashOut pi_hash;
         vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
-        PolynomialBatch wires = PolynomialBatch::from_values(ctx, d_wires, in->n_wires, log_n);
-        wires.merkle_cap(caps_out);
+        PolynomialBatch wires = PolynomialBatch::from_values(ctx, d_wires, in->n_wires, log_n, false, comm);
+        wires.merkle_cap(caps_out, comm);
         Challenger challenger;
         challenger.observe_elements(in->circuit_digest, 4);
         challenger.observe_hash(pi_hash);
@@ -489,13 +505,13 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
                                     in->quotient_degree_factor, d_pp);
             d_zs = d_pp;
         }
-        PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n);
-        zs_pp.merkle_cap(caps_out + cap_words);
+        PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n, false, comm);
+        zs_pp.merkle_cap(caps_out + cap_words, comm);
         challenger.observe_cap(caps_out + cap_words, cap_words / 4);
         const std::vector<u64> alphas = challenger.get_n_challenges(nc);
         // (host stage) compute_quotient_polys(alphas) -> here: supplied coefficient chunks
-        PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n);
-        quotient.merkle_cap(caps_out + 2 * cap_words);
+        PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);
+        quotient.merkle_cap(caps_out + 2 * cap_words, comm);
         challenger.observe_cap(caps_out + 2 * cap_words, cap_words / 4);
         const Ext zeta = challenger.get_extension_challenge();
         // ensure!(zeta^(2^degree_bits) != 1, "Opening point is in the subgroup.")
@@ -559,9 +575,19 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
         challenger.observe_elements(openings_out, 2 * (total_cols + nc));
 
         FriParams fp = FriParams::standard(log_n);
-        PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out);
+        PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out, comm);
         if (challenger_out) *challenger_out = challenger.st;
     });
+}
+
+int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_out, uint64_t* openings_out, uint64_t* fri_out,
+                    vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
+    return prove_step_impl(ctx, in, nullptr, caps_out, openings_out, fri_out, challenger_out, challenges_out);
+}
+int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
+                            uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
+    if (!comm) return VPBS_ERR_INVALID;
+    return prove_step_impl(ctx, in, comm, caps_out, openings_out, fri_out, challenger_out, challenges_out);
 }
 
 // ProofWithPublicInputs::to_bytes (util/serialization): caps, OpeningSet, FriProof, then public inputs

@@ -74,3 +74,53 @@ def sharded_commit(ctx, d_values_ptr, ncols, log_n, is_values=True, group=None, 
         t = t.to(device)
     cap = all_gather_cap(t, group).cpu().numpy().view(np.uint64)
     return batch, cap
+
+
+def make_comm(group=None, device=None):
+    """vpbs_comm backed by torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests).
+
+    The two collectives of a sharded step proof move a few KB: an all-gather of cap hashes per commitment and one
+    sum-all-reduce of the query records.  `device`: torch device for the staging tensors (required for nccl)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import api
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def _allgather(user, local, local_words, full):
+        try:
+            src = np.ctypeslib.as_array(local, shape=(local_words,)).view(np.int64)
+            t = torch.from_numpy(src.copy())
+            if device is not None:
+                t = t.to(device)
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t, group=group)
+            dst = np.ctypeslib.as_array(full, shape=(world * local_words,)).view(np.int64)
+            dst[:] = torch.cat(out).cpu().numpy()
+            return 0
+        except Exception:  # must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    def _allreduce(user, inout, words):
+        try:
+            buf = np.ctypeslib.as_array(inout, shape=(words,)).view(np.int64)
+            t = torch.from_numpy(buf.copy())
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # int64 wrap-around sum == u64 sum
+            buf[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    comm = api.CommC()
+    comm.rank, comm.world = rank, world
+    comm.allgather = api.ALLGATHER_FN(_allgather)
+    comm.allreduce_sum = api.ALLREDUCE_FN(_allreduce)
+    comm.user = None
+    comm._keep = (_allgather, _allreduce)
+    return comm
