@@ -65,7 +65,11 @@ def cpu_baseline():
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs) with the C oracle, OpenMP on all host cores"}
+            "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs, partial products included) with "
+                      "the C oracle, OpenMP on all host cores",
+            "note": "scalar restatement (naive Poseidon, ~8 us per permutation per core; PoW and Merkle top levels serial); "
+                    "plonky2's own AVX2 Poseidon is roughly an order of magnitude faster per core -- a reported baseline, "
+                    "not a tuned CPU prover"}
 
 
 def main():

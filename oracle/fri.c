@@ -84,11 +84,19 @@ int orc_prove_openings(const orc_batch* const* oracles, size_t n_oracles, const 
         ext2 z = ext_make(bi->point[0], bi->point[1]);
         memset(F, 0, sizeof(ext2) * n);
         ext2 apow = ext_from_base(1); /* reduce_polys_base: powers restart at alpha^0 for every batch */
-        for (size_t j = 0; j < bi->n_polys; ++j) {
-            const u64* c = orc_batch_coeffs(oracles[bi->oracle_index[j]]) + (size_t)bi->poly_index[j] * n;
-            for (size_t i = 0; i < n; ++i) F[i] = ext_add(F[i], ext_scalar_mul(apow, c[i]));
-            apow = ext_mul(apow, alpha);
+        ext2* apows = (ext2*)malloc(sizeof(ext2) * (bi->n_polys + 1));
+        for (size_t j = 0; j <= bi->n_polys; ++j) { apows[j] = apow; apow = ext_mul(apow, alpha); }
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; ++i) { /* same sums, evaluated coefficient-wise so the loop parallelises */
+            ext2 acc = ext_from_base(0);
+            for (size_t j = 0; j < bi->n_polys; ++j) {
+                const u64* c = orc_batch_coeffs(oracles[bi->oracle_index[j]]) + (size_t)bi->poly_index[j] * n;
+                acc = ext_add(acc, ext_scalar_mul(apows[j], c[i]));
+            }
+            F[i] = acc;
         }
+        apow = apows[bi->n_polys];
+        free(apows);
         /* apow == alpha^n_polys == the factor applied by shift_poly */
         for (size_t i = 0; i < n; ++i) final_poly[i] = ext_mul(final_poly[i], apow);
         /* divide_by_linear(z): synthetic division, remainder dropped, top coefficient padded with zero */

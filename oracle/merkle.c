@@ -88,17 +88,23 @@ orc_batch* orc_batch_from_coeffs(const u64* coeffs, size_t ncols, unsigned log_n
     b->coeffs = (u64*)malloc(sizeof(u64) * ncols * n);
     memcpy(b->coeffs, coeffs, sizeof(u64) * ncols * n);
     u64* leaves = (u64*)malloc(sizeof(u64) * big * ncols);
-#pragma omp parallel
-    {
-        u64* lde = (u64*)malloc(sizeof(u64) * big);
-#pragma omp for schedule(dynamic, 1)
-        for (size_t c = 0; c < ncols; ++c) {
-            orc_coset_lde(b->coeffs + c * n, log_n, rate_bits, GL_GENERATOR, lde);
-            /* transpose + reverse_index_bits_in_place: leaves[j][c] = lde_c[brev(j)] */
-            for (size_t j = 0; j < big; ++j) leaves[j * ncols + c] = lde[bitrev(j, log_big)];
+    u64* lde = (u64*)malloc(sizeof(u64) * big * ncols); /* column-major [ncols][big], natural order */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t c = 0; c < ncols; ++c) orc_coset_lde(b->coeffs + c * n, log_n, rate_bits, GL_GENERATOR, lde + c * big);
+    /* transpose + reverse_index_bits_in_place: leaves[j][c] = lde_c[brev(j)]; parallel over leaf rows so that no two
+     * threads write the same cache line */
+#pragma omp parallel for schedule(static)
+    for (size_t s0 = 0; s0 < big; s0 += 16) { /* 16 consecutive natural indices x 8 columns: 64-byte row segments */
+        size_t hi = s0 + 16 < big ? s0 + 16 : big;
+        size_t rows[16];
+        for (size_t t = s0; t < hi; ++t) rows[t - s0] = bitrev(t, log_big);
+        for (size_t c0 = 0; c0 < ncols; c0 += 8) {
+            size_t c1 = c0 + 8 < ncols ? c0 + 8 : ncols;
+            for (size_t t = s0; t < hi; ++t)
+                for (size_t c = c0; c < c1; ++c) leaves[rows[t - s0] * ncols + c] = lde[c * big + t];
         }
-        free(lde);
     }
+    free(lde);
     b->tree = orc_merkle_new(leaves, big, ncols, cap_height);
     free(leaves);
     if (!b->tree) { free(b->coeffs); free(b); return NULL; }

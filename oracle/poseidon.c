@@ -18,17 +18,17 @@ static inline u64 sbox7(u64 x) {
 
 void orc_poseidon(u64 s[12]) {
     for (int r = 0; r < 30; ++r) {
-        for (int i = 0; i < 12; ++i) s[i] = gl_add(s[i], POSEIDON_RC[12 * r + i]);
-        if (r < 4 || r >= 26) { for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]); }
-        else s[0] = sbox7(s[0]);
-        u64 t[12];
+        u64 d[24]; /* state after the constant + S-box layers, stored twice so the circulant index needs no modulo */
+        for (int i = 0; i < 12; ++i) d[i] = gl_add(s[i], POSEIDON_RC[12 * r + i]);
+        if (r < 4 || r >= 26) { for (int i = 0; i < 12; ++i) d[i] = sbox7(d[i]); }
+        else d[0] = sbox7(d[0]);
+        memcpy(d + 12, d, 12 * sizeof(u64));
         for (int row = 0; row < 12; ++row) {
             u128 acc = 0; /* 12 terms of < 2^64 * 2^6 : fits easily */
-            for (int i = 0; i < 12; ++i) acc += (u128)s[(i + row) % 12] * MDS_CIRC[i];
-            acc += (u128)s[row] * MDS_DIAG[row];
-            t[row] = gl_reduce128((u64)acc, (u64)(acc >> 64));
+            for (int i = 0; i < 12; ++i) acc += (u128)d[i + row] * MDS_CIRC[i];
+            acc += (u128)d[row] * MDS_DIAG[row];
+            s[row] = gl_reduce128((u64)acc, (u64)(acc >> 64));
         }
-        memcpy(s, t, sizeof t);
     }
 }
 

@@ -133,3 +133,21 @@ def test_coset_sharded_commit_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29531", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SHARDED_COMMIT_OK" in r.stdout
+
+
+def test_step_proof_byte_size_matches_paper_scale():
+    """ProofWithPublicInputs::to_bytes size for the N=1024 step circuit from the restated layout (SURVEY.md Appendix A.8):
+    3 caps + 258 extension openings + FRI proof (3 caps, 28 query rounds, 8-coefficient final poly, nonce) + 4173 public
+    inputs = ~180 kB, the scale the reference logs at ivc_based_vpbs.rs:488 ("proof ~200 kB" in
+    the paper).  A weak but real consistency pin of the restated proof shape."""
+    log_n, ncols, n_pi = 15, [85, 135, 20, 16], 4173
+    p = api.fri_params(log_n)
+    words = api.lib().vpbs_fri_proof_words(ctypes.byref(p), log_n, (ctypes.c_size_t * 4)(*ncols), 4)
+    cap = 16 * 4
+    openings = 2 * (sum(ncols) + 2)
+    merkle_len_bytes = 28 * (4 + 3)                      # one u8 per Merkle proof
+    total = 8 * (3 * cap + openings + words + 1 + n_pi) + merkle_len_bytes
+    assert 150_000 < total < 200_000, total
+    # closed form of the FRI part
+    per_query = sum(ncols) + 4 * 4 * 14 + sum(32 + 4 * k for k in (10, 6, 2))
+    assert words == 3 * cap + 28 * per_query + 2 * 8 + 1

@@ -54,6 +54,15 @@ GL_HD u64 sbox(u64 x) {
     return gl::mul_nc(x3, x4);
 }
 
+// two S-boxes with their multiplication chains interleaved (hides the dependent-instruction latency of the asm blocks)
+GL_HD void sbox2(u64& x, u64& y) {
+    u64 x2, y2, x3, y3, x4, y4;
+    gl::mul2_nc(x, x, y, y, x2, y2);
+    gl::mul2_nc(x2, x2, y2, y2, x4, y4);
+    gl::mul2_nc(x2, x, y2, y, x3, y3);
+    gl::mul2_nc(x3, x4, y3, y4, x, y);
+}
+
 // S-box with x^3 and x^4 computed side by side (three dependent multiplications deep instead of four)
 GL_HD u64 sbox_ilp(u64 x) {
     const u64 x2 = gl::mul_nc(x, x);
@@ -180,7 +189,7 @@ GL_HD void permute(u64* s) {
     for (int i = 0; i < 12; ++i) s[i] = gl::add_nc(s[i], rc(i));
     for (int r = 0; r < HALF_FULL; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+        for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
         mds_add_const(s, 12 * (r + 1));
     }
     // 22 partial rounds = 7 fused groups of 3 (rounds 4..24) + round 25
@@ -189,7 +198,7 @@ GL_HD void permute(u64* s) {
     mds_add_const(s, 12 * (HALF_FULL + N_PARTIAL));
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+        for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
         mds_add_const(s, r + 1 < N_ROUNDS ? 12 * (r + 1) : -1);
     }
 #pragma unroll
