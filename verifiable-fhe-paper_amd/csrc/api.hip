@@ -378,7 +378,8 @@ int vpbs_batch_eval_ext(vpbs_batch* b, const uint64_t zeta[2], uint64_t* out) {
         const unsigned chunks = (unsigned)((n + 4095) / 4096);
         u64* zpow = c->alloc_words(2 * n);
         u64* d_out = c->alloc_words(2 * (size_t)b->ncols * (1 + chunks));
-        vpbs::launch_ext_powers(c->stream, gl::Ext{zeta[0], zeta[1]}, n, zpow);
+        const gl::Ext zp{zeta[0], zeta[1]};
+        vpbs::launch_ext_powers(c->stream, &zp, 1, n, zpow);
         vpbs::launch_eval_ext(c->stream, b->d_coeffs, b->ncols, n, n, zpow, d_out);
         VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * 2 * b->ncols, hipMemcpyDeviceToHost, c->stream));
         VPBS_HIP(hipStreamSynchronize(c->stream));

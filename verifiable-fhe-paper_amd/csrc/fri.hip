@@ -20,9 +20,13 @@ __device__ __forceinline__ void store_ext(u64* p, size_t i, gl::Ext e) {
     reinterpret_cast<ulonglong2*>(p)[i] = make_ulonglong2(e.c0, e.c1);
 }
 
-__global__ void ext_powers_kernel(gl::Ext z, size_t n, u64* out) {
+struct PowerPoints {
+    gl::Ext z[4];
+};
+// grid (n / 256, count): table t (at out + 2 n t) holds z_t^i, i < n
+__global__ void ext_powers_kernel(PowerPoints pts, size_t n, u64* out) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) store_ext(out, i, gl::pow(z, i));
+    if (i < n) store_ext(out + 2 * n * blockIdx.y, i, gl::pow(pts.z[blockIdx.y], i));
 }
 
 // block-wide sum of extension elements (blockDim.x == THREADS); result valid in thread 0
@@ -61,15 +65,32 @@ __global__ void eval_finish_kernel(const u64* __restrict__ partial, unsigned chu
     store_ext(out, c, acc);
 }
 
+// grid (n / 256, groups): each workgroup row sums a slice of the polynomials (n = 2^15 coefficients alone would leave the
+// chip at half a wave per SIMD); the slices are added by combine_finish_kernel.
 __global__ void __launch_bounds__(THREADS)
 combine_kernel(const u64* const* __restrict__ polys, unsigned n_polys, const u64* __restrict__ alpha_pows, size_t n,
-               u64* __restrict__ f0, u64* __restrict__ f1) {
+               u64* __restrict__ part0, u64* __restrict__ part1) {
     const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
     if (i >= n) return;
+    const unsigned per = (n_polys + gridDim.y - 1) / gridDim.y;
+    const unsigned j0 = blockIdx.y * per, j1 = j0 + per < n_polys ? j0 + per : n_polys;
     gl::Ext acc = gl::ext(0);
-    for (unsigned j = 0; j < n_polys; ++j) acc = gl::add(acc, gl::mul(load_ext(alpha_pows, j), polys[j][i]));
-    f0[i] = acc.c0;
-    f1[i] = acc.c1;
+    for (unsigned j = j0; j < j1; ++j) acc = gl::add(acc, gl::mul(load_ext(alpha_pows, j), polys[j][i]));
+    part0[blockIdx.y * n + i] = acc.c0;
+    part1[blockIdx.y * n + i] = acc.c1;
+}
+__global__ void __launch_bounds__(THREADS)
+combine_finish_kernel(const u64* __restrict__ part0, const u64* __restrict__ part1, unsigned groups, size_t n,
+                      u64* __restrict__ f0, u64* __restrict__ f1) {
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (i >= n) return;
+    u64 a = 0, b = 0;
+    for (unsigned g = 0; g < groups; ++g) {
+        a = gl::add(a, part0[g * n + i]);
+        b = gl::add(b, part1[g * n + i]);
+    }
+    f0[i] = a;
+    f1[i] = b;
 }
 
 // Division by (X - z) as a suffix scan: q_k = z^-(k+1) * sum_{i>k} F_i z^i  (q_{n-1} = 0), then
@@ -162,8 +183,10 @@ __global__ void __launch_bounds__(THREADS) open_queries_kernel(const OpenArgs* _
 }
 }  // namespace
 
-void launch_ext_powers(hipStream_t s, gl::Ext z, size_t n, u64* out) {
-    hipLaunchKernelGGL(ext_powers_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z, n, out);
+void launch_ext_powers(hipStream_t s, const gl::Ext* points, unsigned count, size_t n, u64* out) {
+    PowerPoints pts{};
+    for (unsigned t = 0; t < count && t < 4; ++t) pts.z[t] = points[t];
+    hipLaunchKernelGGL(ext_powers_kernel, dim3((n + 255) / 256, count), dim3(256), 0, s, pts, n, out);
 }
 
 // scratch-free two-step evaluation: partial sums live at the tail of `out` (caller provides [ncols*(1+chunks)][2])
@@ -175,8 +198,18 @@ void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n,
     hipLaunchKernelGGL(eval_finish_kernel, dim3((ncols + 63) / 64), dim3(64), 0, s, (const u64*)partial, chunks, ncols, out);
 }
 
-void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1) {
-    hipLaunchKernelGGL(combine_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, polys, n_polys, alpha_pows, n, f0, f1);
+void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1,
+                    u64* partial_scratch) {
+    const unsigned groups = n_polys >= 64 ? COMBINE_GROUPS : 1;
+    if (groups == 1) {
+        hipLaunchKernelGGL(combine_kernel, dim3((n + THREADS - 1) / THREADS, 1), dim3(THREADS), 0, s, polys, n_polys, alpha_pows, n, f0, f1);
+        return;
+    }
+    u64* p0 = partial_scratch;
+    u64* p1 = partial_scratch + (size_t)groups * n;
+    hipLaunchKernelGGL(combine_kernel, dim3((n + THREADS - 1) / THREADS, groups), dim3(THREADS), 0, s, polys, n_polys, alpha_pows, n, p0, p1);
+    hipLaunchKernelGGL(combine_finish_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, (const u64*)p0, (const u64*)p1, groups, n,
+                       f0, f1);
 }
 
 void launch_divide_accumulate(hipStream_t s, const u64* f0, const u64* f1, const u64* zpow, const u64* zinvpow, gl::Ext scale,

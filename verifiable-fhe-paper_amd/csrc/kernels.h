@@ -29,7 +29,7 @@ void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batc
 // ---------- permutation.hip ----------
 // Z and partial products (all_wires_permutation_partial_products): out [nc * (num_prods + 1)][n] in batch order
 // (Z_0..Z_{nc-1}, then the partial products of challenge 0, 1, ..); wires [>= n_routed][n], sigmas [n_routed][n] values
-// on H; roots = forward root table of size n; scratch: nc * (n + ceil(n/256)) words; *d_zero_flag |= 1 on a zero
+// on H; roots = forward root table of size n; scratch: nc * (n + ceil(n/256) + n_chunks * n) words; *d_zero_flag |= 1 on a zero
 // denominator.  d_betas / d_gammas: device arrays of nc elements.
 void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas, const u64* roots, unsigned n_routed, unsigned log_n,
                              unsigned max_degree, const u64* d_betas, const u64* d_gammas, unsigned num_challenges, u64* out,
@@ -54,13 +54,16 @@ void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, uns
                        u64* d_result);
 
 // ---------- fri.hip ----------
-// out[i] = z^i (ext, AoS [n][2])
-void launch_ext_powers(hipStream_t s, gl::Ext z, size_t n, u64* out);
+// power tables of up to 4 points in one launch: out + 2 n t holds z_t^i (ext, AoS [n][2]), t < count
+void launch_ext_powers(hipStream_t s, const gl::Ext* points, unsigned count, size_t n, u64* out);
 // out[c] = sum_i coeffs[c][i] * zpow[i]   (p.to_extension().eval(z)); out AoS [ncols][2]
 void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n, size_t col_stride, const u64* zpow, u64* out);
 // F[i] = sum_j alpha^j * poly_j[i]  (ReducingFactor::reduce_polys_base); polys: device array of column pointers;
 // alpha_pows AoS [n_polys][2]; F SoA (f0[n], f1[n])
-void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1);
+// partial_scratch: 2 * COMBINE_GROUPS * n device words
+constexpr unsigned COMBINE_GROUPS = 16;
+void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1,
+                    u64* partial_scratch);
 // final <- final * scale + (F / (X - z))  with the quotient's top coefficient 0 (divide_by_linear + pad);
 // zpow/zinvpow: AoS power tables of z and z^-1 of length n; final SoA
 // totals_scratch: 2 * ceil(n / 256) device words

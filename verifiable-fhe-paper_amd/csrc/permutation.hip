@@ -15,32 +15,41 @@ namespace vpbs {
 namespace {
 constexpr unsigned THREADS = 256;
 
-// grid (n / 256, num_challenges).  cp: cumulative chunk products of the row; the first num_prods go to `pp` (to be
-// scaled by Z later), the full row product goes to `rowprod`.
+// grid (n / 256, num_challenges, n_chunks): one thread = one chunk quotient prod(num) / prod(den) of one row (one field
+// inversion each; 10x the threads of a row-per-thread kernel, which at n = 2^15 would run at one wave per SIMD).
 __global__ void __launch_bounds__(THREADS)
-pp_row_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ roots, unsigned n_routed,
-              unsigned log_n, unsigned max_degree, const u64* __restrict__ betas, const u64* __restrict__ gammas,
-              u64* __restrict__ pp, u64* __restrict__ rowprod, unsigned* __restrict__ zero_flag) {
+pp_chunk_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ roots, unsigned n_routed,
+                unsigned log_n, unsigned max_degree, const u64* __restrict__ betas, const u64* __restrict__ gammas,
+                u64* __restrict__ chunk_q, unsigned* __restrict__ zero_flag) {
     const size_t n = (size_t)1 << log_n;
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    const unsigned c = blockIdx.y, k = blockIdx.z, n_chunks = gridDim.z;
+    if (i >= n) return;
+    const u64 beta = betas[c], gamma = gammas[c];
+    const u64 x = i < n / 2 ? roots[i] : gl::neg(roots[i - n / 2]);  // w^i (w^(n/2) = -1)
+    u64 t = gl::mul(gl::mul(beta, x), gl::pow(gl::GENERATOR, (u64)k * max_degree));  // beta * k_j * x at j = k * max_degree
+    u64 num = 1, den = 1;
+    for (unsigned j = k * max_degree; j < (k + 1) * max_degree && j < n_routed; ++j) {
+        const u64 w = wires[(size_t)j * n + i];
+        num = gl::mul(num, gl::add(gl::add(w, t), gamma));
+        den = gl::mul(den, gl::add(gl::add(w, gl::mul(beta, sigmas[(size_t)j * n + i])), gamma));
+        t = gl::mul(t, gl::GENERATOR);
+    }
+    if (den == 0) atomicOr(zero_flag, 1u);  // plonky2's batch inverse would panic here
+    chunk_q[((size_t)c * n_chunks + k) * n + i] = gl::mul(num, gl::inv(den));
+}
+
+// grid (n / 256, num_challenges): cumulative products of the row's chunk quotients; the first num_prods go to `pp` (scaled by
+// Z later), the full row product to `rowprod`.
+__global__ void __launch_bounds__(THREADS)
+pp_row_kernel(const u64* __restrict__ chunk_q, size_t n, unsigned n_chunks, u64* __restrict__ pp, u64* __restrict__ rowprod) {
     const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
     const unsigned c = blockIdx.y;
     if (i >= n) return;
-    const u64 beta = betas[c], gamma = gammas[c];
-    const u64 x = i < n / 2 ? roots[i] : gl::neg(roots[i - n / 2]);  // w^i (w^(n/2) = -1); n == 1 handled by the caller
-    u64 t = gl::mul(beta, x);  // beta * k_j * x, k_0 = 1
-    const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree;
     const unsigned num_prods = n_chunks - 1;
     u64 run = 1;
     for (unsigned k = 0; k < n_chunks; ++k) {
-        u64 num = 1, den = 1;
-        for (unsigned j = k * max_degree; j < (k + 1) * max_degree && j < n_routed; ++j) {
-            const u64 w = wires[(size_t)j * n + i];
-            num = gl::mul(num, gl::add(gl::add(w, t), gamma));
-            den = gl::mul(den, gl::add(gl::add(w, gl::mul(beta, sigmas[(size_t)j * n + i])), gamma));
-            t = gl::mul(t, gl::GENERATOR);
-        }
-        if (den == 0) atomicOr(zero_flag, 1u);  // plonky2's batch inverse would panic here
-        run = gl::mul(run, gl::mul(num, gl::inv(den)));
+        run = gl::mul(run, chunk_q[((size_t)c * n_chunks + k) * n + i]);
         if (k < num_prods) pp[((size_t)c * num_prods + k) * n + i] = run;
     }
     rowprod[(size_t)c * n + i] = run;
@@ -102,11 +111,13 @@ void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas,
     const size_t n = (size_t)1 << log_n;
     const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree, num_prods = n_chunks - 1;
     const unsigned blocks = (unsigned)((n + THREADS - 1) / THREADS);
-    u64* rowprod = scratch;                                 // [nc][n]
-    u64* block_prod = scratch + (size_t)num_challenges * n;  // [nc][blocks]
+    u64* rowprod = scratch;                                         // [nc][n]
+    u64* block_prod = scratch + (size_t)num_challenges * n;          // [nc][blocks]
+    u64* chunk_q = block_prod + (size_t)num_challenges * blocks;     // [nc][n_chunks][n]
     u64* pp = out + (size_t)num_challenges * n;
-    hipLaunchKernelGGL(pp_row_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, wires, sigmas, roots, n_routed, log_n, max_degree,
-                       d_betas, d_gammas, pp, rowprod, d_zero_flag);
+    hipLaunchKernelGGL(pp_chunk_kernel, dim3(blocks, num_challenges, n_chunks), dim3(THREADS), 0, s, wires, sigmas, roots, n_routed, log_n,
+                       max_degree, d_betas, d_gammas, chunk_q, d_zero_flag);
+    hipLaunchKernelGGL(pp_row_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)chunk_q, n, n_chunks, pp, rowprod);
     hipLaunchKernelGGL(pp_block_prod_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, n, block_prod);
     hipLaunchKernelGGL(pp_finish_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, (const u64*)block_prod, n,
                        num_prods, num_challenges, out);

@@ -131,9 +131,24 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
     u64* fin = words(2 * n);  // SoA [2][n]
     VPBS_HIP(hipMemsetAsync(fin, 0, sizeof(u64) * 2 * n, s));
     u64* F = words(2 * n);
-    u64* zpow = words(2 * n);
-    u64* zinvpow = words(2 * n);
+    // power tables of every opening point and of its inverse, one launch (at most 2 batches = 4 tables per launch)
+    const size_t n_b = instance.batches.size();
+    u64* ztables = words(4 * n * n_b);  // batch b: z^i at ztables + 4 n b, z^-i at ztables + 4 n b + 2 n
+    {
+        Timed t(ctx, "fri_divide");
+        for (size_t b0 = 0; b0 < n_b; b0 += 2) {
+            Ext pts[4];
+            unsigned cnt = 0;
+            for (size_t b = b0; b < n_b && b < b0 + 2; ++b) {
+                VPBS_REQUIRE(!(instance.batches[b].point.c0 == 0 && instance.batches[b].point.c1 == 0), "opening point is zero");
+                pts[cnt++] = instance.batches[b].point;
+                pts[cnt++] = gl::inv(instance.batches[b].point);
+            }
+            vpbs::launch_ext_powers(s, pts, cnt, n, ztables + 4 * n * b0);
+        }
+    }
     u64* div_totals = words(2 * ((n + 255) / 256));
+    u64* combine_scratch = words(2 * (size_t)vpbs::COMBINE_GROUPS * n);
     std::vector<std::vector<const u64*>> h_ptrs(instance.batches.size());
     for (size_t b = 0; b < instance.batches.size(); ++b) {
         const FriBatchInfo& bi = instance.batches[b];
@@ -149,13 +164,12 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         VPBS_HIP(hipMemcpyAsync(d_ptrs, h_ptrs[b].data(), sizeof(u64*) * np, hipMemcpyHostToDevice, s));
         {
             Timed t(ctx, "fri_combine");
-            vpbs::launch_combine(s, d_ptrs, (unsigned)np, d_apow, n, F, F + n);
+            vpbs::launch_combine(s, d_ptrs, (unsigned)np, d_apow, n, F, F + n, combine_scratch);
         }
-        VPBS_REQUIRE(!(bi.point.c0 == 0 && bi.point.c1 == 0), "opening point is zero");
         {
             Timed t(ctx, "fri_divide");
-            vpbs::launch_ext_powers(s, bi.point, n, zpow);
-            vpbs::launch_ext_powers(s, gl::inv(bi.point), n, zinvpow);
+            const u64* zpow = ztables + 4 * n * b;
+            const u64* zinvpow = zpow + 2 * n;
             // shift_poly: final *= alpha^count (count = polynomials reduced in this batch), then += quotient
             vpbs::launch_divide_accumulate(s, F, F + n, zpow, zinvpow, gl::pow(alpha, np), n, fin, fin + n, div_totals);
         }
@@ -293,7 +307,8 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
     const size_t n = (size_t)1 << log_n;
     hipStream_t s = ctx->stream;
     u64* d_ch = ctx->alloc_words(2 * nc + 1);
-    u64* scratch = ctx->alloc_words((size_t)nc * (n + (n + 255) / 256));
+    const size_t n_chunks = (n_routed + max_degree - 1) / max_degree;
+    u64* scratch = ctx->alloc_words((size_t)nc * (n + (n + 255) / 256 + n_chunks * n));
     std::vector<u64> h(2 * nc + 1, 0);
     for (unsigned c = 0; c < nc; ++c) {
         h[c] = betas[c];
@@ -540,16 +555,15 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         const FriInstanceInfo instance = step_fri_instance(ncols, nc, zeta, log_n);
         const Ext zeta_next = instance.batches[1].point;
         const unsigned chunks = (unsigned)((n + 4095) / 4096);
-        u64* zpow = ctx->alloc_words(2 * n);
-        u64* znpow = ctx->alloc_words(2 * n);
+        u64* zpow = ctx->alloc_words(4 * n);
+        u64* znpow = zpow + 2 * n;
         u64* d_open = ctx->alloc_words(2 * (total_cols + nc) * (size_t)(1 + chunks) + 64);
         staged.push_back(zpow);
-        staged.push_back(znpow);
         staged.push_back(d_open);
         {
             Timed t(ctx, "openings_eval");
-            vpbs::launch_ext_powers(s, zeta, n, zpow);
-            vpbs::launch_ext_powers(s, zeta_next, n, znpow);
+            const Ext pts[2] = {zeta, zeta_next};
+            vpbs::launch_ext_powers(s, pts, 2, n, zpow);
             size_t col = 0;
             for (auto* o : oracles) {
                 // results for this oracle at d_open[2*col ..]; partial sums behind the block of final results
