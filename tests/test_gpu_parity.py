@@ -358,3 +358,28 @@ def test_full_size_step_properties(ctx):
     for c in (0, 134):
         assert (orc.fft(coeffs[c]) == inputs["wires"][c]).all()
     wires.free()
+
+
+def test_cxx_host_example_matches_python_path(ctx):
+    """examples/prove_step.cpp drives the C ABI from plain C++ (no Python, no torch in that process): same seeded step,
+    same proof bytes."""
+    import subprocess
+    import __graft_entry__ as entry
+    exe = entry.build_example()
+    log_n = 9
+    r = subprocess.run([exe, str(log_n)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fields = dict(kv.split("=") for kv in r.stdout.split())
+    inputs = synth.step_inputs(log_n)
+    pis = synth.field_elements(0xABCD, 77)
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][5:85])
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs, DIGEST, pis, sigmas=sig, n_routed=80)
+    got = ctx.prove_step(si)
+    blob = ctx.step_proof_to_bytes(si, 5, got)
+    h = 0xcbf29ce484222325
+    for b in blob:
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    assert int(fields["proof_bytes"]) == len(blob)
+    assert int(fields["pow"]) == int(got["fri"][-1])
+    assert fields["fnv1a"] == "%016x" % h

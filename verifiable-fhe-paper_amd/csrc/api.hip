@@ -1,5 +1,7 @@
 // extern "C" surface: context, PolynomialBatch handles, kernel-level hooks.  See include/vpbs_prover.h for the
 // plonky2 function each entry point replaces.
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "context.h"
@@ -43,7 +45,17 @@ void vpbs_ctx::trim() {
     }
     free_blocks.clear();
 }
+static double trace_now_us() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
 void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
+    static const bool trace = getenv("VPBS_TRACE") != nullptr;
+    const double t_begin = trace ? trace_now_us() : 0;
+    struct Tr {
+        bool on; double t0; size_t b;
+        ~Tr() { if (on) std::fprintf(stderr, "[vpbs trace] d2h_sync %zu B: host arrived %.1f us, returned %.1f us (waited %.1f)\n", b, t0, trace_now_us(), trace_now_us() - t0); }
+    } tr{trace, t_begin, bytes};
     constexpr size_t STAGE = (size_t)1 << 20;
     if (!pinned) {
         if (hipHostMalloc(&pinned, STAGE, hipHostMallocDefault) == hipSuccess) pinned_bytes = STAGE;
