@@ -80,7 +80,7 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 //   product: 4 v_mad_u64_u32 (the a1*b0 term is accumulated onto a0*b1 with its carry-out kept in an SGPR pair) + 3 adds
 //   reduce : u = hi_lo * (2^32-1) + lo as ONE v_mad_u64_u32 with carry-out c; r = u - hi_hi with borrow b;
 //            r += (c - b) * (2^32 - 1)  -- neither correction can wrap a second time
-// 18 VALU + 2 SALU instead of the 26 VALU hipcc emits for the C form below.
+// 16 VALU + 2 SALU instead of the 26 VALU hipcc emits for the C form below.
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     u32 r0, r1;
     asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
