@@ -4,9 +4,10 @@
 A "step" = one step proof of the vPBS IVC chain on the 2^15-row, 135-wire plonky2 circuit (BASELINE config 2:
 commit wires / Z+partial-products / quotient chunks -> openings -> FRI, Fiat-Shamir transcript included) with the
 inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  The
-witness-generation and quotient-evaluation stages of plonky2's prove() are host stages outside this round's hot path
+witness generation and the gate-constraint terms of the quotient are host stages of plonky2's prove() outside this round's hot path
  and are NOT inside the timed region -- `config.stages` says so explicitly.  The permutation-argument
-partial products (row a12) ARE computed inside the step, on the GPU.
+partial products (row a12) and the permutation part of the quotient polynomials (row a13: everything but the gate
+constraint terms) ARE computed inside the step, on the GPU.
 
 Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode).
 Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: under torch.distributed.run, one rank per GPU)
@@ -61,7 +62,8 @@ def cpu_baseline():
     cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)   # committed once per circuit: untimed
     t0 = time.time()
     sig = np.ascontiguousarray(inputs["constants_sigmas"][N_CONSTANTS:N_CONSTANTS + N_ROUTED])
-    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED)
+    inputs["quotient"] = None   # quotient chunks evaluated (permutation-argument constraints), like the GPU step
+    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS)
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": os.cpu_count(), "kind": "port",
@@ -123,6 +125,9 @@ def main():
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst)
         dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
+        # single-GPU steps evaluate the quotient chunks on the device; the sharded step takes them as data (its quotient
+        # evaluation over sharded LDEs is not built yet)
+        quot_ptr = dev["quotient"].data_ptr() if sharded else None
         if sharded:
             cs, _ = sharding.sharded_commit(ctx, dev["constants_sigmas"].data_ptr(), COLS["constants_sigmas"], log_n,
                                             device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
@@ -130,9 +135,9 @@ def main():
             cs = ctx.commit_values(inputs["constants_sigmas"])      # once per circuit, untimed
         pis = synth.field_elements(0xABCD + inst, 77)
         sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
-        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, dev["quotient"].data_ptr(), cs, digest, pis,
+        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, quot_ptr, cs, digest, pis,
                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
-                                  sigmas=sig_ptr, n_routed=N_ROUTED)
+                                  sigmas=sig_ptr, n_routed=N_ROUTED, n_constants=N_CONSTANTS)
         ctxs.append(ctx); sis.append(si); keep.append((dev, cs, pis))
     torch.cuda.synchronize()
 
@@ -189,9 +194,9 @@ def main():
             csb = cx.commit_values(inp["constants_sigmas"])
             pi2 = synth.field_elements(0xABCD + c, 77)
             sp = dv["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)
-            extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, dv["quotient"].data_ptr(), csb, digest, pi2,
+            extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, None, csb, digest, pi2,
                                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
-                                                  sigmas=sp, n_routed=N_ROUTED), dv, csb, pi2))
+                                                  sigmas=sp, n_routed=N_ROUTED, n_constants=N_CONSTANTS), dv, csb, pi2))
         ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
         n_chains = len(ctxs)
         run_steps(1)
@@ -242,11 +247,13 @@ def main():
                                    "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, 85 constant/sigma "
                                    "columns precommitted; inputs resident in HBM" % (log_n, log_n + 3),
                        "stages": "wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> permutation Z + partial "
-                                 "products on the GPU -> commit -> alphas -> quotient-chunk commit -> zeta -> openings at "
-                                 "zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit PoW, 28 queries), Fiat-Shamir "
-                                 "transcript included.  NOT in the timed region (host stages of plonky2's prove(), SURVEY.md "
-                                 "8f): witness generation and quotient-polynomial evaluation (its output, the 16 quotient "
-                                 "chunks, is supplied as data)",
+                                 "products (GPU) -> commit -> alphas -> quotient polynomials (GPU: vanishing terms of the "
+                                 "permutation argument over the 2^18 coset, / Z_H, coset iNTT, 16 chunks) -> commit -> zeta -> "
+                                 "openings at zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit PoW, 28 queries), "
+                                 "Fiat-Shamir transcript included.  NOT in the timed region (host stages of plonky2's prove(), "
+                                 "SURVEY.md 8f): witness generation and the gate-constraint terms of the quotient (the ~15 gate "
+                                 "types of the step circuit; the quotient kernel accepts them as a pre-folded input)"
+                                 + ("; sharded mode: quotient chunks supplied as data" if sharded else ""),
                        "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
                                        "hashes + 1 all-reduce of query records (%s)" % (world, args.dist_backend)) if sharded else
                                       "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,

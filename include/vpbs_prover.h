@@ -139,7 +139,9 @@ typedef struct {
     const uint64_t* wires_values;     /* [n_wires][n]   -> from_values */
     const uint64_t* zs_pp_values;     /* [n_zs_pp][n]   -> from_values; NULL: computed on the device from the wires, the
                                          sigma values below and the transcript's betas/gammas (vpbs_partial_products) */
-    const uint64_t* quotient_coeffs;  /* [n_quotient][n]-> from_coeffs */
+    const uint64_t* quotient_coeffs;  /* [n_quotient][n]-> from_coeffs; NULL: the quotient chunks are computed on the device
+                                         from the committed LDEs with the permutation-argument constraints only
+                                         (vpbs_quotient_permutation; needs sigmas via constants_sigmas + n_constants) */
     vpbs_batch* constants_sigmas;     /* committed once per circuit (prover_data.constants_sigmas_commitment) */
     uint64_t circuit_digest[4];
     const uint64_t* public_inputs;    /* host */
@@ -149,6 +151,7 @@ typedef struct {
     const uint64_t* sigmas_values;    /* [n_routed][n] sigma polynomial values on H (prover_data.sigmas, column-major) */
     unsigned n_routed;                /* 80: config.num_routed_wires */
     unsigned quotient_degree_factor;  /* 8: chunk size of the partial products */
+    unsigned n_constants;             /* leading columns of constants_sigmas that are not sigmas (quotient on device) */
 } vpbs_step_inputs;
 
 /* Collectives for a step proof sharded over the GPUs of one node: supplied by the host, so the library
@@ -203,6 +206,18 @@ long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, u
 int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* sigmas, int on_device, unsigned n_routed,
                           unsigned log_n, const uint64_t* betas, const uint64_t* gammas, unsigned num_challenges,
                           unsigned max_degree, uint64_t* out);
+
+/* = plonk/prover.rs compute_quotient_polys for the permutation-argument constraints: the vanishing
+ * terms L_0(x)(Z_c(x) - 1) and the partial-product checks, folded with every alpha, plus optional pre-folded gate terms,
+ * divided by Z_H on the coset 7<w_8n>, coset-iFFT'd and split into 8 chunks of n coefficients per challenge.
+ * All inputs are device-resident committed batches (nothing is downloaded): sigma columns are columns
+ * [n_constants, n_constants + n_routed) of constants_sigmas, the routed wires are the first n_routed columns of `wires`.
+ * d_gate_terms: NULL or device [num_challenges][8n] in leaf order: sum_g gate_g(x) alpha^g per challenge (multiplied here
+ * by alpha^(n_perm_terms)).  out: [num_challenges * 8][n] coefficients, host (out_on_device = 0) or device. */
+int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* constants_sigmas, unsigned n_constants, vpbs_batch* wires,
+                              vpbs_batch* zs_partial_products, unsigned n_routed, const uint64_t* betas,
+                              const uint64_t* gammas, const uint64_t* alphas, unsigned num_challenges, unsigned max_degree,
+                              const uint64_t* d_gate_terms, uint64_t* out, int out_on_device);
 
 /* ---- kernel-level entry points (host buffers; used by parity tests and by callers outside the prover) ---- */
 int vpbs_k_poseidon_batch(vpbs_ctx* ctx, uint64_t* states /* [n][12] in place */, size_t n);

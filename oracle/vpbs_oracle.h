@@ -137,6 +137,28 @@ int orc_verify_fri(const u64* const* caps, const size_t* ncols, size_t n_oracles
 int orc_partial_products(const u64* wires, const u64* sigmas, size_t n_routed, unsigned log_n, const u64* betas,
                          const u64* gammas, size_t num_challenges, size_t max_degree, u64* out);
 
+/* ---- quotient polynomials, permutation-argument part (plonk/prover.rs compute_quotient_polys, plonk/vanishing_poly.rs
+ *      eval_vanishing_poly_base_batch, plonk/plonk_common.rs ZeroPolyOnCoset / reduce_with_powers_multi,
+ *      util/partial_products.rs check_partial_products) ----
+ * Evaluated on the coset 7<w_{8n}> (quotient_degree_factor = 8 = 2^rate_bits).  Vanishing terms, in order:
+ *   L_0(x) (Z_c(x) - 1) for every challenge c; then for every challenge the (num_prods + 1) partial-product checks
+ *   prev * prod(num) - next * prod(den) with prev = [Z(x), pp_0..], next = [pp_0.., Z(g x)]; then the gate-constraint
+ *   terms (supplied already alpha-folded per challenge as gate_terms[c][t], natural coset order, may be NULL = none).
+ * Per challenge a: q_a(x) = (sum_i term_i alpha_a^i + alpha_a^(n_terms) * gate_terms_a(x)) / Z_H(x); coset iFFT;
+ * split into 8 chunks of n coefficients.  out: [num_challenges * 8][n].
+ * wires/sigmas/zs_pp are COEFFICIENT matrices ([..][n]); zs_pp in batch order (Z's first). */
+int orc_quotient_permutation(const u64* wires_coeffs, const u64* sigmas_coeffs, const u64* zs_pp_coeffs, size_t n_routed,
+                             unsigned log_n, const u64* betas, const u64* gammas, const u64* alphas, size_t num_challenges,
+                             size_t max_degree, const u64* gate_terms, u64* out);
+/* verifier side of the same identity at an extension point zeta (plonk/verifier.rs + eval_vanishing_poly): given the
+ * openings of the routed wires, sigmas, Z, Z(g zeta), partial products and the quotient chunks, checks for every
+ * challenge  vanishing(zeta) == Z_H(zeta) * sum_m chunk_m(zeta) zeta^(n m).  gate_terms_zeta: [num_challenges][2] or NULL.
+ * returns 1 when the identity holds for all challenges. */
+int orc_check_vanishing_at_zeta(const u64* wires_z, const u64* sigmas_z, const u64* zs_z, const u64* zs_next_z,
+                                const u64* pps_z, const u64* quotient_z, size_t n_routed, unsigned log_n,
+                                const u64* betas, const u64* gammas, const u64* alphas, size_t num_challenges,
+                                size_t max_degree, const u64 zeta[2], const u64* gate_terms_zeta);
+
 /* ---- negacyclic NTT of the reference (src/vtfhe/crypto/poly.rs:9-64, src/ntt/gen_param_file.sage) ---- */
 void orc_negacyclic_params(unsigned log_n, u64* roots, u64* invroots, u64* ninv);
 void orc_negacyclic_forward(u64* a, unsigned log_n, const u64* roots);

@@ -78,6 +78,8 @@ def lib():
             "orc_verify_fri": (C.c_int, [C.POINTER(U64P), C.POINTER(sz), sz, C.POINTER(FriBatchInfo), C.POINTER(U64P), sz,
                                         C.POINTER(Challenger), C.POINTER(FriParams), ui, U64P]),
             "orc_partial_products": (C.c_int, [U64P, U64P, sz, ui, U64P, U64P, sz, sz, U64P]),
+            "orc_quotient_permutation": (C.c_int, [U64P, U64P, U64P, sz, ui, U64P, U64P, U64P, sz, sz, U64P, U64P]),
+            "orc_check_vanishing_at_zeta": (C.c_int, [U64P, U64P, U64P, U64P, U64P, U64P, sz, ui, U64P, U64P, U64P, sz, sz, U64P, U64P]),
             "orc_negacyclic_params": (None, [ui, U64P, U64P, U64P]),
             "orc_negacyclic_forward": (None, [U64P, ui, U64P]),
             "orc_negacyclic_backward": (None, [U64P, ui, U64P, u64]),
@@ -163,6 +165,44 @@ def partial_products(wires, sigmas, betas, gammas, max_degree=8):
     out = np.zeros((nc * chunks, n), np.uint64)
     rc = lib().orc_partial_products(ptr(w), ptr(sg), n_routed, n.bit_length() - 1, ptr(u64arr(betas)), ptr(u64arr(gammas)), nc, max_degree, ptr(out))
     assert rc == 0, rc
+    return out
+
+
+def quotient_permutation(wires_coeffs, sigmas_coeffs, zs_pp_coeffs, betas, gammas, alphas, max_degree=8, gate_terms=None):
+    """compute_quotient_polys restricted to the permutation argument: -> [nc * 8][n] coefficient chunks."""
+    w, sg, zp = u64arr(wires_coeffs), u64arr(sigmas_coeffs), u64arr(zs_pp_coeffs)
+    n_routed, n = sg.shape
+    nc = len(betas)
+    out = np.zeros((nc * 8, n), np.uint64)
+    gt = ptr(u64arr(gate_terms)) if gate_terms is not None else None
+    rc = lib().orc_quotient_permutation(ptr(w), ptr(sg), ptr(zp), n_routed, n.bit_length() - 1, ptr(u64arr(betas)), ptr(u64arr(gammas)),
+                                        ptr(u64arr(alphas)), nc, max_degree, gt, ptr(out))
+    assert rc == 0
+    return out
+
+
+def check_vanishing_at_zeta(wires_z, sigmas_z, zs_z, zs_next_z, pps_z, quotient_z, log_n, betas, gammas, alphas, zeta, max_degree=8,
+                            gate_terms_zeta=None):
+    a = [u64arr(x) for x in (wires_z, sigmas_z, zs_z, zs_next_z, pps_z, quotient_z)]
+    n_routed = a[1].shape[0]
+    pps_ptr = ptr(a[4]) if a[4].size else ptr(np.zeros(2, np.uint64))
+    gt = ptr(u64arr(gate_terms_zeta)) if gate_terms_zeta is not None else None
+    return bool(lib().orc_check_vanishing_at_zeta(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), pps_ptr, ptr(a[5]), n_routed, log_n,
+                                                  ptr(u64arr(betas)), ptr(u64arr(gammas)), ptr(u64arr(alphas)), len(betas), max_degree,
+                                                  ptr(u64arr(zeta)), gt))
+
+
+def eval_coeffs_ext(coeffs, zeta):
+    """[ncols][n] coefficient matrix -> [ncols][2] evaluations at the extension point zeta (Horner, C)."""
+    c = u64arr(coeffs)
+    out = np.zeros((c.shape[0], 2), np.uint64)
+    z = (int(zeta[0]), int(zeta[1]))
+    P_ = P
+    for k in range(c.shape[0]):
+        a0 = a1 = 0
+        for v in c[k][::-1]:
+            a0, a1 = (a0 * z[0] + 7 * a1 * z[1] + int(v)) % P_, (a0 * z[1] + a1 * z[0]) % P_
+        out[k] = (a0, a1)
     return out
 
 

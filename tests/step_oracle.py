@@ -27,7 +27,7 @@ def commit_inputs(inputs, rate_bits=3, cap_height=4):
 
 
 def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, forced_pow=orc.POW_ANY, cs_batch=None,
-               sigmas=None, n_routed=0):
+               sigmas=None, n_routed=0, n_constants=0):
     """sigmas given: the Z / partial-product matrix is computed from the wires and the transcript's betas/gammas
     (all_wires_permutation_partial_products) instead of being read from inputs["zs_partial_products"]."""
     rate_bits, cap_height = 3, 4
@@ -45,7 +45,12 @@ def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, f
     zs = orc.Batch(zs_values, rate_bits, cap_height, True)
     ch.observe(zs.cap())
     alphas = ch.get_n(num_challenges)
-    quot = orc.Batch(inputs["quotient"], rate_bits, cap_height, False)
+    if inputs.get("quotient") is None:   # compute_quotient_polys, permutation-argument constraints only
+        sig_c = cs.coeffs()[n_constants:n_constants + n_routed]
+        q_coeffs = orc.quotient_permutation(wires.coeffs()[:n_routed], sig_c, zs.coeffs(), betas, gammas, alphas)
+    else:
+        q_coeffs = inputs["quotient"]
+    quot = orc.Batch(q_coeffs, rate_bits, cap_height, False)
     ch.observe(quot.cap())
     zeta = ch.get_ext()
     oracles = [cs, wires, zs, quot]

@@ -260,6 +260,104 @@ def test_partial_products_zero_denominator_is_an_error(ctx):
         ctx.partial_products(wires, sig, [beta], [gamma])
 
 
+# ---------- quotient, permutation part (a13) ----------
+def _leaf_order(nat, log_big):
+    idx = np.array([int(format(j, "0%db" % log_big)[::-1], 2) for j in range(1 << log_big)])
+    return np.ascontiguousarray(nat[:, idx])
+
+
+@pytest.mark.parametrize("log_n,n_routed,n_constants,with_gates", [(4, 8, 0, False), (6, 20, 3, True), (9, 80, 5, False), (8, 80, 5, True)])
+def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, with_gates):
+    import torch
+    n = 1 << log_n
+    wires_v, sig_v, const_v = rand_field(n_routed + 4, n), rand_field(n_routed, n), rand_field(n_constants, n)
+    betas, gammas, alphas = ([int(x) for x in rand_field(2)] for _ in range(3))
+    zs_v = orc.partial_products(wires_v[:n_routed], sig_v, betas, gammas)
+    cs = ctx.commit_values(np.concatenate([const_v, sig_v]) if n_constants else sig_v)
+    wb, zb = ctx.commit_values(wires_v), ctx.commit_values(zs_v)
+    gate_nat, gate_dev = None, None
+    if with_gates:
+        gate_nat = rand_field(2, 8 * n)
+        gate_dev = torch.from_numpy(_leaf_order(gate_nat, log_n + 3).view(np.int64)).cuda()
+        torch.cuda.synchronize()
+    got = ctx.quotient_permutation(cs, n_constants, wb, zb, n_routed, betas, gammas, alphas,
+                                   gate_terms_dev=gate_dev.data_ptr() if with_gates else None)
+    want = orc.quotient_permutation(wb.coeffs()[:n_routed], cs.coeffs()[n_constants:], zb.coeffs(), betas, gammas, alphas,
+                                    gate_terms=gate_nat)
+    assert got.shape == want.shape and (got == want).all()
+
+
+def _copy_constraint_instance(log_n, n_routed):
+    n = 1 << log_n
+    w = orc.lib().orc_gl_root_of_unity(log_n)
+    perm = rng.permutation(n_routed * n)
+    vals = np.zeros(n_routed * n, dtype=np.uint64)
+    seen = np.zeros(n_routed * n, bool)
+    for s0 in range(n_routed * n):
+        if not seen[s0]:
+            v = rand_field(1)[0]
+            t = s0
+            while not seen[t]:
+                seen[t] = True; vals[t] = v; t = perm[t]
+    sig = np.zeros((n_routed, n), np.uint64)
+    wp = [pow(w, r, P) for r in range(n)]
+    kp = [pow(7, c, P) for c in range(n_routed)]
+    for pos in range(n_routed * n):
+        tc, tr = divmod(int(perm[pos]), n)
+        sig[pos // n][pos % n] = kp[tc] * wp[tr] % P
+    return vals.reshape(n_routed, n), sig
+
+
+@pytest.mark.parametrize("log_n", [6, 10])
+def test_copy_constraint_proof_end_to_end(ctx, log_n):
+    """A complete proof of a copy-constraint-only circuit, every prover stage on the GPU (wires commit -> Z / partial
+    products -> commit -> quotient -> commit -> openings -> FRI), checked by the restated plonky2 verifier: the FRI
+    proof verifies AND vanishing(zeta) == Z_H(zeta) * t(zeta).  A witness that violates one copy constraint still yields
+    consistent commitments but fails the vanishing identity."""
+    n_routed, n_constants, n_wires = 80, 5, 135
+    n = 1 << log_n
+    routed, sig = _copy_constraint_instance(log_n, n_routed)
+    consts = rand_field(n_constants, n)
+    pis = synth.field_elements(77, 12)
+
+    def prove_and_check(routed_vals):
+        wires = np.concatenate([routed_vals, rand_field(n_wires - n_routed, n)])   # advice wires are unconstrained
+        cs = ctx.commit_values(np.concatenate([consts, sig]))
+        si = ctx.make_step_inputs(log_n, wires, None, None, cs, DIGEST, pis, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+        proof = ctx.prove_step(si)
+        ncols = [n_constants + n_routed, n_wires, 20, 16]
+        assert step_oracle.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n)
+        op = proof["openings"]
+        cs_z, w_z = op[:ncols[0]], op[ncols[0]:ncols[0] + n_wires]
+        zs_all = op[ncols[0] + n_wires:ncols[0] + n_wires + 20]
+        q_z = op[ncols[0] + n_wires + 20:ncols[0] + n_wires + 36]
+        zs_next = op[ncols[0] + n_wires + 36:]
+        ch = proof["challenges"]
+        betas, gammas, alphas, zeta = ch[0:2], ch[2:4], ch[4:6], ch[6:8]
+        ok = orc.check_vanishing_at_zeta(w_z[:n_routed], cs_z[n_constants:], zs_all[:2], zs_next, zs_all[2:], q_z, log_n,
+                                         [int(b) for b in betas], [int(g) for g in gammas], [int(a) for a in alphas], zeta)
+        cs.free()
+        return ok
+
+    assert prove_and_check(routed)
+    bad = routed.copy(); bad[7][5] = (int(bad[7][5]) + 1) % P
+    assert not prove_and_check(bad)
+
+
+def test_step_proof_with_device_quotient_bit_exact(ctx):
+    log_n, n_constants, n_routed = 8, 5, 80
+    inputs = synth.step_inputs(log_n)
+    inputs["quotient"] = None
+    pis = synth.field_elements(0xD00D, 20)
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs, DIGEST, pis, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    got = ctx.prove_step(si)
+    want = step_oracle.prove_step(inputs, DIGEST, pis, log_n, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (got[key] == want[key]).all(), key
+
+
 # ---------- step proof ----------
 DIGEST = np.array([11, 22, 33, 44], np.uint64)
 

@@ -324,3 +324,50 @@ def test_partial_products_true_permutation_closes():
         rowp = rowp * (int(wires[j][i]) + betas[0] * pow(7, j, P) * x + gammas[0]) % P
         rowp = rowp * pow(int(wires[j][i]) + betas[0] * int(sig[j][i]) + gammas[0], P - 2, P) % P
     assert int(out[0][n - 1]) * rowp % P == 1
+
+
+def _copy_constraint_instance(log_n, n_routed):
+    """wires constant on the cycles of a random permutation of the (column, row) cells + its sigma polynomials (values)"""
+    n = 1 << log_n
+    w = pymodel.root_of_unity(log_n)
+    perm = rng.permutation(n_routed * n)
+    vals = np.zeros(n_routed * n, dtype=np.uint64)
+    seen = np.zeros(n_routed * n, bool)
+    for s0 in range(n_routed * n):
+        if not seen[s0]:
+            v = rand_field(1)[0]
+            t = s0
+            while not seen[t]:
+                seen[t] = True; vals[t] = v; t = perm[t]
+    sig = np.zeros((n_routed, n), np.uint64)
+    for pos in range(n_routed * n):
+        tc, tr = divmod(int(perm[pos]), n)
+        sig[pos // n][pos % n] = pow(7, tc, P) * pow(w, tr, P) % P
+    return vals.reshape(n_routed, n), sig
+
+
+@pytest.mark.parametrize("log_n,n_routed", [(4, 8), (5, 16), (4, 20)])
+def test_quotient_permutation_satisfies_verifier_identity(log_n, n_routed):
+    """a12 + a13 (permutation part) end to end on the CPU oracle: for a witness that satisfies its copy constraints the
+    quotient chunks satisfy vanishing(zeta) = Z_H(zeta) * t(zeta) at a random extension point; a broken witness does not."""
+    wires, sig = _copy_constraint_instance(log_n, n_routed)
+    betas, gammas, alphas = ([int(x) for x in rand_field(2)] for _ in range(3))
+    nc = 2
+    n_chunks = (n_routed + 7) // 8
+
+    def run(wv):
+        zs_pp = orc.partial_products(wv, sig, betas, gammas)
+        coeffs = lambda m: np.stack([orc.fft(r, inverse=True) for r in m])
+        wc, sc, zc = coeffs(wv), coeffs(sig), coeffs(zs_pp)
+        q = orc.quotient_permutation(wc, sc, zc, betas, gammas, alphas)
+        zeta = rand_field(2)
+        g = pymodel.root_of_unity(log_n)
+        zeta_next = np.array([int(zeta[0]) * g % P, int(zeta[1]) * g % P], np.uint64)
+        ev = orc.eval_coeffs_ext
+        zs_z, zs_next = ev(zc[:nc], zeta), ev(zc[:nc], zeta_next)
+        pps = ev(zc[nc:], zeta) if n_chunks > 1 else np.zeros((0, 2), np.uint64)
+        return orc.check_vanishing_at_zeta(ev(wc, zeta), ev(sc, zeta), zs_z, zs_next, pps, ev(q, zeta), log_n, betas, gammas, alphas, zeta)
+
+    assert run(wires)
+    bad = wires.copy(); bad[1][3] = (int(bad[1][3]) + 1) % P   # breaks one copy constraint
+    assert not run(bad)

@@ -44,7 +44,8 @@ class StepInputsC(C.Structure):
                 ("wires_values", C.c_void_p), ("zs_pp_values", C.c_void_p), ("quotient_coeffs", C.c_void_p),
                 ("constants_sigmas", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64),
-                ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint)]
+                ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint),
+                ("n_constants", C.c_uint)]
 
 
 class StepSizesC(C.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     "vpbs_prove_step_sharded": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(CommC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
+    "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -356,26 +358,36 @@ class Context:
     # ---- step proof ----
     def make_step_inputs(self, log_n, wires, zs_pp, quotient, constants_sigmas, circuit_digest, public_inputs,
                          num_challenges=2, forced_pow=POW_ANY, on_device=False, shapes=None, sigmas=None, n_routed=0,
-                         quotient_degree_factor=8):
+                         quotient_degree_factor=8, n_constants=0):
         """wires/zs_pp/quotient: numpy matrices [ncols][n] (host) or device pointers with shapes=(nw, nz, nq).
         zs_pp=None: the Z / partial-product matrix is computed on the device from `sigmas` ([n_routed][n] values, same
-        residency as the other matrices); shapes[1] / n_zs then must equal num_challenges * ceil(n_routed / 8)."""
+        residency as the other matrices); shapes[1] / n_zs then must equal num_challenges * ceil(n_routed / 8).
+        quotient=None: the 8 * num_challenges quotient chunks are evaluated on the device for the permutation argument
+        (sigma LDE columns are taken from constants_sigmas[n_constants : n_constants + n_routed])."""
         si = StepInputsC()
         si.log_n = log_n
         keep = []
         n_zs_auto = num_challenges * ((n_routed + quotient_degree_factor - 1) // quotient_degree_factor) if n_routed else 0
         if on_device:
             nw, nz, nq = shapes
-            si.wires_values, si.quotient_coeffs = int(wires), int(quotient)
+            si.wires_values = int(wires)
+            si.quotient_coeffs = int(quotient) if quotient is not None else None
             si.zs_pp_values = int(zs_pp) if zs_pp is not None else None
             if sigmas is not None:
                 si.sigmas_values = int(sigmas)
         else:
-            wires, quotient = _u64(wires), _u64(quotient)
-            keep += [wires, quotient]
-            nw, nq = wires.shape[0], quotient.shape[0]
+            wires = _u64(wires)
+            keep.append(wires)
+            nw = wires.shape[0]
             si.wires_values = wires.ctypes.data
-            si.quotient_coeffs = quotient.ctypes.data
+            if quotient is not None:
+                quotient = _u64(quotient)
+                keep.append(quotient)
+                nq = quotient.shape[0]
+                si.quotient_coeffs = quotient.ctypes.data
+            else:
+                nq = 8 * num_challenges
+                si.quotient_coeffs = None
             if zs_pp is not None:
                 zs_pp = _u64(zs_pp)
                 keep.append(zs_pp)
@@ -390,6 +402,7 @@ class Context:
                 si.sigmas_values = sigmas.ctypes.data
         si.n_routed = n_routed
         si.quotient_degree_factor = quotient_degree_factor
+        si.n_constants = n_constants
         si.n_wires, si.n_zs_partial_products, si.n_quotient = nw, nz, nq
         si.num_challenges = num_challenges
         si.inputs_on_device = 1 if on_device else 0
@@ -439,6 +452,17 @@ class Context:
         b, g = _u64(betas), _u64(gammas)
         self._check(lib().vpbs_partial_products(self.h, w.ctypes.data, sg.ctypes.data, 0, n_routed, n.bit_length() - 1, _ptr(b), _ptr(g), nc,
                                                 max_degree, out.ctypes.data))
+        return out
+
+    def quotient_permutation(self, cs_batch, n_constants, wires_batch, zs_batch, n_routed, betas, gammas, alphas, max_degree=8,
+                             gate_terms_dev=None):
+        """compute_quotient_polys (permutation part) from committed batches -> [nc * 8][n] coefficient chunks (host)."""
+        nc = len(betas)
+        out = np.zeros((nc * 8, wires_batch.n), np.uint64)
+        b, g, a = _u64(betas), _u64(gammas), _u64(alphas)
+        self._check(lib().vpbs_quotient_permutation(self.h, cs_batch.h, n_constants, wires_batch.h, zs_batch.h, n_routed, _ptr(b), _ptr(g),
+                                                    _ptr(a), nc, max_degree, C.c_void_p(gate_terms_dev) if gate_terms_dev else None,
+                                                    out.ctypes.data, 0))
         return out
 
     # ---- kernel-level hooks ----

@@ -35,6 +35,17 @@ void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas,
                              unsigned max_degree, const u64* d_betas, const u64* d_gammas, unsigned num_challenges, u64* out,
                              u64* scratch, unsigned* d_zero_flag);
 
+// ---------- quotient.hip ----------
+// compute_quotient_polys restricted to the permutation argument (+ optional alpha-folded gate terms, leaf order, [nc][8n]).
+// *_lde: committed LDE columns (column stride 8n, leaf order): routed wires, sigmas, Z/partial products (batch order).
+// roots_big / inv_roots_big: root tables of size 8n; unshift_table[i] = 7^-i (i < 8n); d_apow: [nc][n_terms + 1] powers of the
+// alphas (n_terms = nc * (1 + ceil(n_routed / max_degree))); betas/gammas: host arrays; q_leaf, q_nat: [nc][8n] scratch;
+// out_coeffs: [nc * 2^rate_bits][n] quotient chunks.  nc <= 4, rate_bits <= 3.
+void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
+                                 const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms, const u64* d_apow,
+                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
+                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs);
+
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
 void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests);

@@ -332,6 +332,51 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
     ctx->release(scratch);
     VPBS_REQUIRE(flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
 }
+
+// compute_quotient_polys (permutation part) on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks
+void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constants, vpbs_batch* wires, vpbs_batch* zs_pp,
+                                 unsigned n_routed, const u64* betas, const u64* gammas, const u64* alphas, unsigned nc,
+                                 unsigned max_degree, const u64* d_gate_terms, u64* d_out) {
+    VPBS_REQUIRE(cs && wires && zs_pp && cs->ctx == ctx && wires->ctx == ctx && zs_pp->ctx == ctx, "batches of another context");
+    VPBS_REQUIRE(cs->n_shards == 1 && wires->n_shards == 1 && zs_pp->n_shards == 1, "quotient over sharded batches is not supported");
+    const unsigned log_n = wires->log_n, rate_bits = ctx->rate_bits;
+    VPBS_REQUIRE(cs->log_n == log_n && zs_pp->log_n == log_n && log_n >= 1, "degree mismatch");
+    VPBS_REQUIRE(nc >= 1 && nc <= 4 && rate_bits <= 3 && max_degree >= 1, "unsupported quotient shape");
+    VPBS_REQUIRE(n_routed >= 1 && n_routed <= wires->ncols && n_constants + n_routed <= cs->ncols, "routed wires / sigma columns out of range");
+    const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree;
+    VPBS_REQUIRE(zs_pp->ncols == nc * n_chunks, "Z/partial-product batch has the wrong number of columns");
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big;
+    const unsigned n_terms = nc + nc * n_chunks;
+    hipStream_t s = ctx->stream;
+    std::vector<u64> h_apow((size_t)nc * (n_terms + 1));
+    for (unsigned a = 0; a < nc; ++a) {
+        u64 p = 1;
+        for (unsigned i = 0; i <= n_terms; ++i) {
+            h_apow[(size_t)a * (n_terms + 1) + i] = p;
+            p = gl::mul(p, alphas[a]);
+        }
+    }
+    u64* d_apow = ctx->alloc_words(h_apow.size());
+    u64* q_leaf = ctx->alloc_words((size_t)nc * big);
+    u64* q_nat = ctx->alloc_words((size_t)nc * big);
+    try {
+        VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, s));
+        Timed t(ctx, "quotient_permutation");
+        vpbs::launch_quotient_permutation(s, wires->d_lde, cs->d_lde + (size_t)n_constants * big, zs_pp->d_lde, ctx->roots(log_big, false),
+                                          ctx->roots(log_big, true), ctx->prescale(log_big, 0, gl::inv(gl::GENERATOR)), d_gate_terms, d_apow,
+                                          betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, q_leaf, q_nat, d_out);
+        VPBS_HIP(hipGetLastError());
+    } catch (...) {
+        (void)hipStreamSynchronize(s);
+        ctx->release(d_apow); ctx->release(q_leaf); ctx->release(q_nat);
+        throw;
+    }
+    // stream-ordered reuse of the scratch blocks is safe: later work is enqueued on the same stream
+    ctx->release(d_apow);
+    ctx->release(q_leaf);
+    ctx->release(q_nat);
+}
 }  // namespace
 
 // ---------------- C ABI ----------------
@@ -446,6 +491,30 @@ int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* 
     });
 }
 
+int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constants, vpbs_batch* wires, vpbs_batch* zs_pp, unsigned n_routed,
+                              const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, unsigned nc, unsigned max_degree,
+                              const uint64_t* d_gate_terms, uint64_t* out, int out_on_device) {
+    if (!ctx || !cs || !wires || !zs_pp || !betas || !gammas || !alphas || !out) return VPBS_ERR_INVALID;
+    return guarded(ctx, [&] {
+        const size_t words = ((size_t)nc << ctx->rate_bits) << wires->log_n;
+        if (out_on_device) {
+            quotient_permutation_device(ctx, cs, n_constants, wires, zs_pp, n_routed, betas, gammas, alphas, nc, max_degree, d_gate_terms, out);
+            return;
+        }
+        u64* d_out = ctx->alloc_words(words);
+        try {
+            quotient_permutation_device(ctx, cs, n_constants, wires, zs_pp, n_routed, betas, gammas, alphas, nc, max_degree, d_gate_terms, d_out);
+            VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * words, hipMemcpyDeviceToHost, ctx->stream));
+            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        } catch (...) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->release(d_out);
+            throw;
+        }
+        ctx->release(d_out);
+    });
+}
+
 int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out) {
     if (!ctx || !in || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
     const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
@@ -491,7 +560,12 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         } cleanup{ctx, staged};
         const u64* d_wires = on_device(in->wires_values, (size_t)in->n_wires * n);
         const u64* d_zs = in->zs_pp_values ? on_device(in->zs_pp_values, (size_t)in->n_zs_partial_products * n) : nullptr;
-        const u64* d_quot = on_device(in->quotient_coeffs, (size_t)in->n_quotient * n);
+        const u64* d_quot = in->quotient_coeffs ? on_device(in->quotient_coeffs, (size_t)in->n_quotient * n) : nullptr;
+        if (!in->quotient_coeffs) {
+            VPBS_REQUIRE(!comm, "device quotient evaluation is not available in the sharded step");
+            VPBS_REQUIRE(in->n_quotient == nc * (1u << ctx->rate_bits) && in->n_routed >= 1 && in->quotient_degree_factor >= 1,
+                         "quotient_coeffs == NULL needs n_quotient = num_challenges * 8, n_routed and quotient_degree_factor");
+        }
         const u64* d_sigmas = nullptr;
         if (!in->zs_pp_values) {
             VPBS_REQUIRE(in->sigmas_values && in->n_routed >= 1 && in->n_routed <= in->n_wires && in->quotient_degree_factor >= 1,
@@ -524,7 +598,15 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         zs_pp.merkle_cap(caps_out + cap_words, comm);
         challenger.observe_cap(caps_out + cap_words, cap_words / 4);
         const std::vector<u64> alphas = challenger.get_n_challenges(nc);
-        // (host stage) compute_quotient_polys(alphas) -> here: supplied coefficient chunks
+        // compute_quotient_polys(alphas): supplied coefficient chunks, or evaluated on the device for the permutation
+        // argument (the gate-constraint terms of the step circuit are a host stage)
+        if (!d_quot) {
+            u64* d_q = ctx->alloc_words((size_t)in->n_quotient * n);
+            staged.push_back(d_q);
+            quotient_permutation_device(ctx, in->constants_sigmas, in->n_constants, wires.h, zs_pp.h, in->n_routed, betas.data(),
+                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, nullptr, d_q);
+            d_quot = d_q;
+        }
         PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);
         quotient.merkle_cap(caps_out + 2 * cap_words, comm);
         challenger.observe_cap(caps_out + 2 * cap_words, cap_words / 4);

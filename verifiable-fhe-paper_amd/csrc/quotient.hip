@@ -1,0 +1,126 @@
+// Quotient polynomials, permutation-argument part, on gfx950.
+// Replaces plonky2 0.2.0 plonk/prover.rs `compute_quotient_polys` + plonk/vanishing_poly.rs
+// `eval_vanishing_poly_base_batch` (the L_0 (Z - 1) terms and `check_partial_products`), the Z_H division of
+// plonk/plonk_common.rs `ZeroPolyOnCoset`, the coset iFFT and the split into degree-n chunks -- the stage between the
+// Z/partial-products commitment and the quotient commitment of prove() (/root/reference/src/vtfhe/
+// ivc_based_vpbs.rs:302,333,364).  The gate-constraint terms of the ~15 gate
+// types are NOT evaluated here: they enter as an optional, already alpha-folded input per challenge.
+//
+// One thread per LDE point: it reads the committed LDE columns of the routed wires, the sigmas and the Z / partial
+// products straight from the batches' HBM buffers (column-major, leaf order => coalesced), so nothing is downloaded
+// (the reference's get_lde_values path moves 283 MB per step through the host).  Streaming, ~180 columns x 8 B per point.
+#include "kernels.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned THREADS = 256;
+
+struct QuotientConsts {
+    u64 zh[8], zh_inv[8];  // Z_H on the 2^rate_bits cosets: 7^n w_8^r - 1, and its inverse
+    u64 beta[4], gamma[4];
+    u64 n_field;            // n as a field element
+};
+
+// grid (8n / 256).  apow: [nc][n_terms + 1] powers of alpha_a.  q: [nc][8n] in leaf order.
+__global__ void __launch_bounds__(THREADS)
+quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ zs_pp,
+                     const u64* __restrict__ roots_big, const u64* __restrict__ gate_terms, const u64* __restrict__ apow,
+                     QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc,
+                     u64* __restrict__ q) {
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big;
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= big) return;
+    const unsigned t = gl::bitrev32((u32)j, log_big);                                 // natural index of this leaf
+    const unsigned t_next = (t + (1u << rate_bits)) & (unsigned)(big - 1);            // g * x: next trace row
+    const size_t j_next = gl::bitrev32(t_next, log_big);
+    const u64 wt = t < big / 2 ? roots_big[t] : gl::neg(roots_big[t - big / 2]);      // w_{8n}^t
+    const u64 x = gl::mul(gl::GENERATOR, wt);
+    const unsigned r = t & ((1u << rate_bits) - 1);
+    const u64 l0 = gl::mul(k.zh[r], gl::inv(gl::mul(k.n_field, gl::sub(x, 1))));     // ZeroPolyOnCoset::eval_l_0
+    const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree, num_prods = n_chunks - 1;
+    const unsigned n_terms = nc + nc * n_chunks;
+    u64 acc[4] = {0, 0, 0, 0};  // sum_i term_i alpha_a^i for each challenge a (nc <= 4)
+    // every per-challenge array is indexed with compile-time indices (loops unrolled to 4 and predicated): no scratch
+    auto add_term = [&](unsigned i, u64 term) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if ((unsigned)a < nc) acc[a] = gl::add(acc[a], gl::mul(term, apow[a * (n_terms + 1) + i]));
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if ((unsigned)c < nc) add_term(c, gl::mul(l0, gl::sub(zs_pp[(size_t)c * big + j], 1)));
+    // numerators / denominators: every column value is loaded once and used for all challenges
+    u64 sid[4];  // beta_c * k_j * x, k_j = 7^j
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sid[c] = (unsigned)c < nc ? gl::mul(k.beta[c], x) : 0;
+    for (unsigned kk = 0; kk < n_chunks; ++kk) {
+        u64 num[4] = {1, 1, 1, 1}, den[4] = {1, 1, 1, 1};
+        for (unsigned col = kk * max_degree; col < (kk + 1) * max_degree && col < n_routed; ++col) {
+            const u64 w = wires[(size_t)col * big + j];
+            const u64 s = sigmas[(size_t)col * big + j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if ((unsigned)c >= nc) continue;
+                num[c] = gl::mul(num[c], gl::add(gl::add(w, sid[c]), k.gamma[c]));
+                den[c] = gl::mul(den[c], gl::add(gl::add(w, gl::mul(k.beta[c], s)), k.gamma[c]));
+                sid[c] = gl::mul(sid[c], gl::GENERATOR);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((unsigned)c >= nc) continue;
+            const u64* zc = zs_pp + (size_t)c * big;
+            const u64* ppc = zs_pp + ((size_t)nc + (size_t)c * num_prods) * big;
+            const u64 prev = kk == 0 ? zc[j] : ppc[(size_t)(kk - 1) * big + j];
+            const u64 next = kk == num_prods ? zc[j_next] : ppc[(size_t)kk * big + j];
+            add_term(nc + c * n_chunks + kk, gl::sub(gl::mul(prev, num[c]), gl::mul(next, den[c])));  // check_partial_products
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if ((unsigned)a >= nc) continue;
+        u64 v = acc[a];
+        if (gate_terms) v = gl::add(v, gl::mul(gate_terms[(size_t)a * big + j], apow[a * (n_terms + 1) + n_terms]));
+        q[(size_t)a * big + j] = gl::mul(v, k.zh_inv[r]);
+    }
+}
+
+// out[a][t] = in[a][bitrev(t)]  (leaf order -> natural order)
+__global__ void bitrev_copy_kernel(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_len) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t len = (size_t)1 << log_len;
+    if (t < len) out[blockIdx.y * len + t] = in[blockIdx.y * len + gl::bitrev32((u32)t, log_len)];
+}
+__global__ void mul_table_kernel(u64* __restrict__ data, const u64* __restrict__ table, size_t len) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < len) data[blockIdx.y * len + i] = gl::mul(data[blockIdx.y * len + i], table[i]);
+}
+}  // namespace
+
+void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
+                                 const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms, const u64* d_apow,
+                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
+                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs) {
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big, n = (size_t)1 << log_n;
+    QuotientConsts k{};
+    const u64 seven_n = gl::pow(gl::GENERATOR, n), w8 = gl::root_of_unity(rate_bits);
+    for (unsigned r = 0; r < (1u << rate_bits) && r < 8; ++r) {
+        k.zh[r] = gl::sub(gl::mul(seven_n, gl::pow(w8, r)), 1);
+        k.zh_inv[r] = gl::inv(k.zh[r]);
+    }
+    for (unsigned c = 0; c < nc; ++c) {
+        k.beta[c] = betas[c];
+        k.gamma[c] = gammas[c];
+    }
+    k.n_field = (u64)n;
+    hipLaunchKernelGGL(quotient_perm_kernel, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde, sigmas_lde,
+                       zs_pp_lde, roots_big, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
+    // PolynomialValues::coset_ifft(7): natural order -> iNTT of size 8n -> coefficient i times 7^-i; chunk m of challenge a is
+    // out_coeffs[(a * 8 + m) * n ..]
+    hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, (const u64*)q_leaf, q_nat, log_big);
+    launch_intt(s, q_nat, out_coeffs, q_leaf /* scratch */, inv_roots_big, nc, log_big);
+    hipLaunchKernelGGL(mul_table_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, out_coeffs, unshift_table, big);
+}
+}  // namespace vpbs
