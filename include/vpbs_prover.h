@@ -219,6 +219,26 @@ int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* constants_sigmas, unsig
                               const uint64_t* gammas, const uint64_t* alphas, unsigned num_challenges, unsigned max_degree,
                               const uint64_t* d_gate_terms, uint64_t* out, int out_on_device);
 
+/* ---- verifier (host only; plonky2 plonk/verifier.rs `verify` -> fri/verifier.rs `verify_fri_proof`; the reference calls it
+ *      as cd.verify(proof) at /root/reference/src/vtfhe/ivc_based_vpbs.rs:443-447).  Replays the transcript of
+ *      vpbs_prove_step, checks proof-of-work, every Merkle path, the alpha-combination, the arity-16 folds and the final
+ *      polynomial; with check_permutation it also checks vanishing(zeta) == Z_H(zeta) * t(zeta) for the permutation-
+ *      argument constraints (+ gate_terms_zeta, the alpha-folded gate constraints at zeta, when the circuit has gates). */
+typedef struct {
+    unsigned log_n, rate_bits, cap_height;
+    unsigned n_constants_sigmas, n_wires, n_zs_partial_products, n_quotient, num_challenges;
+    const uint64_t* constants_sigmas_cap;   /* verifier_only.constants_sigmas_cap: [2^cap_height][4] */
+    uint64_t circuit_digest[4];
+    const uint64_t* public_inputs;
+    size_t n_public_inputs;
+    int check_permutation;                  /* 0: FRI / transcript only */
+    unsigned n_constants, n_routed, quotient_degree_factor;
+    const uint64_t* gate_terms_zeta;        /* [num_challenges][2] or NULL */
+} vpbs_verify_inputs;
+/* returns 1 = proof accepted, 0 = rejected, < 0 = malformed arguments */
+int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][cap] */, const uint64_t* openings,
+                     const uint64_t* fri);
+
 /* ---- kernel-level entry points (host buffers; used by parity tests and by callers outside the prover) ---- */
 int vpbs_k_poseidon_batch(vpbs_ctx* ctx, uint64_t* states /* [n][12] in place */, size_t n);
 int vpbs_k_hash_rows(vpbs_ctx* ctx, const uint64_t* rows /* [n][len] */, size_t n, unsigned len, uint64_t* out /* [n][4] */);

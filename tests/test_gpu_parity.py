@@ -336,6 +336,10 @@ def test_copy_constraint_proof_end_to_end(ctx, log_n):
         betas, gammas, alphas, zeta = ch[0:2], ch[2:4], ch[4:6], ch[6:8]
         ok = orc.check_vanishing_at_zeta(w_z[:n_routed], cs_z[n_constants:], zs_all[:2], zs_next, zs_all[2:], q_z, log_n,
                                          [int(b) for b in betas], [int(g) for g in gammas], [int(a) for a in alphas], zeta)
+        # the product's own host verifier must reach the same verdict (FRI alone is fine either way)
+        assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n)
+        assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants,
+                               n_routed=n_routed) == ok
         cs.free()
         return ok
 
@@ -433,6 +437,7 @@ def test_full_size_step_properties(ctx):
     inputs, pis, cs, si, got = _step(ctx, log_n)
     ncols = [85, 135, 20, 16]
     assert step_oracle.verify_step(got, cs.cap(), ncols, DIGEST, pis, log_n)
+    assert api.verify_step(got, cs.cap(), ncols, DIGEST, pis, log_n)     # the product's own verifier agrees
     # determinism
     again = ctx.prove_step(si)
     assert (again["fri"] == got["fri"]).all() and (again["caps"] == got["caps"]).all()

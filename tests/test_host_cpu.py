@@ -151,3 +151,31 @@ def test_step_proof_byte_size_matches_paper_scale():
     # closed form of the FRI part
     per_query = sum(ncols) + 4 * 4 * 14 + sum(32 + 4 * k for k in (10, 6, 2))
     assert words == 3 * cap + 28 * per_query + 2 * 8 + 1
+
+
+def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
+    """vpbs_verify_step is host-only, so it runs here: it must agree with the oracle's verifier on oracle-made proofs."""
+    import step_oracle
+    log_n = 6
+    cols = {"constants_sigmas": 9, "wires": 12, "zs_partial_products": 4, "quotient": 16}
+    inputs = synth.step_inputs(log_n, cols=cols)
+    inputs["quotient"] = None
+    pis = synth.field_elements(5, 9)
+    digest = np.array([9, 8, 7, 6], np.uint64)
+    n_constants, n_routed = 1, 8
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
+    # zs batch must have num_challenges * ceil(8/8) = 2 columns when computed from sigmas
+    proof = step_oracle.prove_step(inputs, digest, pis, log_n, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    ncols = proof["ncols"]
+    assert ncols == [9, 12, 2, 16]
+    assert step_oracle.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n)
+    assert api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n)
+    # random sigmas are not a permutation of the wires: the FRI part verifies, the vanishing identity does not
+    assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n, check_permutation=True, n_constants=n_constants,
+                               n_routed=n_routed)
+    for key, pos in (("fri", 0), ("fri", proof["fri"].size // 2), ("fri", proof["fri"].size - 1), ("openings", 3), ("caps", 5)):
+        bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in proof.items()}
+        flat = bad[key].reshape(-1)
+        flat[pos] = (int(flat[pos]) + 1) % P
+        assert not api.verify_step(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
+    assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs

@@ -48,6 +48,14 @@ class StepInputsC(C.Structure):
                 ("n_constants", C.c_uint)]
 
 
+class VerifyInputsC(C.Structure):
+    _fields_ = [("log_n", C.c_uint), ("rate_bits", C.c_uint), ("cap_height", C.c_uint),
+                ("n_constants_sigmas", C.c_uint), ("n_wires", C.c_uint), ("n_zs_partial_products", C.c_uint), ("n_quotient", C.c_uint),
+                ("num_challenges", C.c_uint), ("constants_sigmas_cap", U64P), ("circuit_digest", C.c_uint64 * 4),
+                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("check_permutation", C.c_int),
+                ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P)]
+
+
 class StepSizesC(C.Structure):
     _fields_ = [("cap_words", C.c_size_t), ("openings_words", C.c_size_t), ("fri_words", C.c_size_t)]
 
@@ -96,6 +104,7 @@ SIGNATURES = {
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),
+    "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -186,6 +195,31 @@ def hash_no_pad(x):
     out = np.zeros(4, np.uint64)
     lib().vpbs_hash_no_pad(_ptr(x), x.size, _ptr(out))
     return out
+
+
+def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=False, n_constants=0,
+                n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4):
+    """Host-side verifier of the product library (plonky2 verify / verify_fri_proof).  True = accepted."""
+    v = VerifyInputsC()
+    v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
+    v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
+    v.num_challenges = num_challenges
+    cap = _u64(cs_cap)
+    v.constants_sigmas_cap = _ptr(cap)
+    for i in range(4):
+        v.circuit_digest[i] = int(circuit_digest[i])
+    pi = _u64(public_inputs).reshape(-1)
+    v.public_inputs = _ptr(pi)
+    v.n_public_inputs = pi.size
+    v.check_permutation = 1 if check_permutation else 0
+    v.n_constants, v.n_routed, v.quotient_degree_factor = n_constants, n_routed, quotient_degree_factor
+    gt = _u64(gate_terms_zeta) if gate_terms_zeta is not None else None
+    v.gate_terms_zeta = _ptr(gt) if gt is not None else None
+    caps, openings, fri = _u64(proof["caps"]), _u64(proof["openings"]), _u64(proof["fri"])
+    rc = lib().vpbs_verify_step(C.byref(v), _ptr(caps), _ptr(openings), _ptr(fri))
+    if rc < 0:
+        raise VpbsError("vpbs_verify_step: malformed arguments (%d)" % rc)
+    return rc == 1
 
 
 def fri_params(degree_bits, **over):

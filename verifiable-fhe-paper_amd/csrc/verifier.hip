@@ -1,0 +1,238 @@
+// Host-side verifier of step proofs (no device work): mirrors plonky2 0.2.0 plonk/verifier.rs `verify_with_challenges`,
+// plonk/get_challenges.rs, fri/verifier.rs `verify_fri_proof` / `fri_verifier_query_round` / `fri_combine_initial` /
+// `compute_evaluation`, hash/merkle_proofs.rs `verify_merkle_proof_to_cap` and plonk/vanishing_poly.rs
+// `eval_vanishing_poly` (permutation part).  The reference calls it as `cd.verify(proof)` at
+// /root/reference/src/vtfhe/ivc_based_vpbs.rs:443-447.  Product code: written against gl.h /
+// poseidon.h, independent of the test oracle.
+#include <cstring>
+#include <vector>
+
+#include "host/plonky2_mirror.h"
+#include "poseidon.h"
+
+using gl::Ext;
+using gl::u64;
+
+namespace {
+void two_to_one(const u64* l, const u64* r, u64* out) {
+    u64 s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+    poseidon::permute(s);
+    std::memcpy(out, s, 4 * sizeof(u64));
+}
+void hash_or_noop(const u64* leaf, size_t len, u64* out) {
+    if (len <= 4) {
+        std::memset(out, 0, 4 * sizeof(u64));
+        std::memcpy(out, leaf, len * sizeof(u64));
+    } else {
+        poseidon::hash_no_pad_host(leaf, len, out);
+    }
+}
+// verify_merkle_proof_to_cap
+bool merkle_verify(const u64* leaf, size_t leaf_len, size_t idx, const u64* cap, const u64* siblings, size_t n_sib) {
+    u64 cur[4], nxt[4];
+    hash_or_noop(leaf, leaf_len, cur);
+    for (size_t k = 0; k < n_sib; ++k) {
+        if (idx & 1) two_to_one(siblings + 4 * k, cur, nxt);
+        else two_to_one(cur, siblings + 4 * k, nxt);
+        std::memcpy(cur, nxt, sizeof cur);
+        idx >>= 1;
+    }
+    return std::memcmp(cur, cap + 4 * idx, sizeof cur) == 0;
+}
+Ext ext_at(const u64* p, size_t i) { return Ext{p[2 * i], p[2 * i + 1]}; }
+size_t bitrev(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+// interpolate {(xs[i], ys[i])} and evaluate at t (arity <= 16)
+Ext interpolate(const u64* xs, const Ext* ys, size_t k, Ext t) {
+    Ext res = gl::ext(0);
+    for (size_t i = 0; i < k; ++i) {
+        Ext num = ys[i];
+        u64 den = 1;
+        for (size_t j = 0; j < k; ++j)
+            if (j != i) {
+                num = gl::mul(num, gl::sub(t, gl::ext(xs[j])));
+                den = gl::mul(den, gl::sub(xs[i], xs[j]));
+            }
+        res = gl::add(res, gl::mul(num, gl::inv(den)));
+    }
+    return res;
+}
+
+bool check_permutation_identity(const vpbs_verify_inputs* in, const u64* openings, const u64* betas, const u64* gammas,
+                                const u64* alphas, Ext zeta) {
+    const unsigned nc = in->num_challenges, n_routed = in->n_routed, deg = in->quotient_degree_factor;
+    const unsigned n_chunks = (n_routed + deg - 1) / deg, num_prods = n_chunks - 1;
+    const size_t n = (size_t)1 << in->log_n;
+    const u64* cs_z = openings;
+    const u64* wires_z = cs_z + 2 * (size_t)in->n_constants_sigmas;
+    const u64* zs_pp_z = wires_z + 2 * (size_t)in->n_wires;
+    const u64* quot_z = zs_pp_z + 2 * (size_t)in->n_zs_partial_products;
+    const u64* zs_next_z = quot_z + 2 * (size_t)in->n_quotient;
+    const u64* sig_z = cs_z + 2 * (size_t)in->n_constants;
+    const u64* pps_z = zs_pp_z + 2 * (size_t)nc;
+    Ext zeta_n = zeta;
+    for (unsigned i = 0; i < in->log_n; ++i) zeta_n = gl::mul(zeta_n, zeta_n);
+    const Ext one = gl::ext(1);
+    const Ext z_h = gl::sub(zeta_n, one);
+    const Ext l0 = gl::mul(z_h, gl::inv(gl::mul(gl::sub(zeta, one), (u64)n)));
+    std::vector<Ext> terms(nc + nc * n_chunks);
+    std::vector<u64> k_is(n_routed);
+    u64 k = 1;
+    for (unsigned j = 0; j < n_routed; ++j) { k_is[j] = k; k = gl::mul(k, gl::GENERATOR); }
+    for (unsigned c = 0; c < nc; ++c) {
+        terms[c] = gl::mul(l0, gl::sub(ext_at(zs_pp_z, c), one));
+        for (unsigned kk = 0; kk < n_chunks; ++kk) {
+            Ext num = one, den = one;
+            for (unsigned j = kk * deg; j < (kk + 1) * deg && j < n_routed; ++j) {
+                const Ext w = ext_at(wires_z, j), g = gl::ext(gammas[c]);
+                num = gl::mul(num, gl::add(gl::add(w, gl::mul(zeta, gl::mul(betas[c], k_is[j]))), g));
+                den = gl::mul(den, gl::add(gl::add(w, gl::mul(ext_at(sig_z, j), betas[c])), g));
+            }
+            const Ext prev = kk == 0 ? ext_at(zs_pp_z, c) : ext_at(pps_z, c * num_prods + kk - 1);
+            const Ext next = kk == num_prods ? ext_at(zs_next_z, c) : ext_at(pps_z, c * num_prods + kk);
+            terms[nc + c * n_chunks + kk] = gl::sub(gl::mul(prev, num), gl::mul(next, den));  // check_partial_products
+        }
+    }
+    const unsigned chunks_per = 1u << in->rate_bits;
+    for (unsigned a = 0; a < nc; ++a) {
+        Ext acc = in->gate_terms_zeta ? ext_at(in->gate_terms_zeta, a) : gl::ext(0);
+        for (size_t i = terms.size(); i-- > 0;) acc = gl::add(gl::mul(acc, alphas[a]), terms[i]);  // reduce_with_powers
+        Ext q = gl::ext(0);
+        for (unsigned m = chunks_per; m-- > 0;) q = gl::add(gl::mul(q, zeta_n), ext_at(quot_z, a * chunks_per + m));
+        if (!gl::eq(acc, gl::mul(z_h, q))) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps, const uint64_t* openings, const uint64_t* fri) {
+    using namespace plonky2;
+    if (!in || !caps || !openings || !fri || !in->constants_sigmas_cap || (in->n_public_inputs && !in->public_inputs)) return VPBS_ERR_INVALID;
+    if (in->rate_bits > 3 || in->cap_height > 8 || in->log_n == 0 || in->log_n + in->rate_bits > 24 || in->num_challenges == 0 ||
+        in->num_challenges > in->n_zs_partial_products)
+        return VPBS_ERR_INVALID;
+    if (in->check_permutation) {
+        const unsigned deg = in->quotient_degree_factor;
+        if (deg == 0 || in->n_routed == 0 || in->n_routed > in->n_wires || in->n_constants + in->n_routed > in->n_constants_sigmas ||
+            in->n_zs_partial_products != in->num_challenges * ((in->n_routed + deg - 1) / deg) ||
+            in->n_quotient != (in->num_challenges << in->rate_bits))
+            return VPBS_ERR_INVALID;
+    }
+    FriParams fp = FriParams::standard(in->log_n);
+    fp.config.rate_bits = in->rate_bits;
+    fp.config.cap_height = in->cap_height;
+    const unsigned nc = in->num_challenges, log_n = in->log_n;
+    const unsigned log_lde = log_n + in->rate_bits;
+    const size_t lde = (size_t)1 << log_lde, cap_words = (size_t)4 << in->cap_height;
+    const size_t ncols[4] = {in->n_constants_sigmas, in->n_wires, in->n_zs_partial_products, in->n_quotient};
+    size_t total_cols = 0;
+    for (size_t c : ncols) total_cols += c;
+
+    // ---- transcript (plonk/get_challenges.rs) ----
+    HashOut pi_hash;
+    vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
+    Challenger ch;
+    ch.observe_elements(in->circuit_digest, 4);
+    ch.observe_hash(pi_hash);
+    ch.observe_cap(caps, cap_words / 4);
+    const std::vector<u64> betas = ch.get_n_challenges(nc), gammas = ch.get_n_challenges(nc);
+    ch.observe_cap(caps + cap_words, cap_words / 4);
+    const std::vector<u64> alphas = ch.get_n_challenges(nc);
+    ch.observe_cap(caps + 2 * cap_words, cap_words / 4);
+    const Ext zeta = ch.get_extension_challenge();
+    ch.observe_elements(openings, 2 * (total_cols + nc));
+    if (in->check_permutation && !check_permutation_identity(in, openings, betas.data(), gammas.data(), alphas.data(), zeta)) return 0;
+
+    // ---- FRI challenges ----
+    const Ext fri_alpha = ch.get_extension_challenge();
+    const size_t n_rounds = fp.reduction_arity_bits.size();
+    const size_t final_len = (size_t)1 << fp.final_poly_bits();
+    const size_t total = fri_proof_words(fp, {ncols[0], ncols[1], ncols[2], ncols[3]});
+    const u64* final_words = fri + total - 1 - 2 * final_len;
+    const u64 pow_witness = fri[total - 1];
+    const u64* w = fri;
+    std::vector<const u64*> fri_caps(n_rounds);
+    std::vector<Ext> fri_betas(n_rounds);
+    for (size_t r = 0; r < n_rounds; ++r) {
+        fri_caps[r] = w;
+        ch.observe_cap(w, cap_words / 4);
+        w += cap_words;
+        fri_betas[r] = ch.get_extension_challenge();
+    }
+    ch.observe_elements(final_words, 2 * final_len);
+    if (pow_witness >= gl::P) return 0;
+    ch.observe_element(pow_witness);
+    const u64 pow_response = ch.get_challenge();
+    if (fp.config.proof_of_work_bits && (pow_response >> (64 - fp.config.proof_of_work_bits)) != 0) return 0;
+
+    // ---- PrecomputedReducedOpenings: batch 0 = every polynomial at zeta, batch 1 = Z polynomials at g * zeta ----
+    const Ext zeta_next = gl::mul(zeta, gl::root_of_unity(log_n));
+    Ext reduced0 = gl::ext(0), reduced1 = gl::ext(0);
+    for (size_t j = total_cols; j-- > 0;) reduced0 = gl::add(gl::mul(reduced0, fri_alpha), ext_at(openings, j));
+    for (size_t j = nc; j-- > 0;) reduced1 = gl::add(gl::mul(reduced1, fri_alpha), ext_at(openings, total_cols + j));
+    const u64* oracle_caps[4] = {in->constants_sigmas_cap, caps, caps + cap_words, caps + 2 * cap_words};
+
+    for (unsigned q = 0; q < fp.config.num_query_rounds; ++q) {
+        size_t x_index = (size_t)(ch.get_challenge() % lde);
+        const u64* leaf[4];
+        const size_t nsib0 = log_lde - in->cap_height;
+        for (size_t o = 0; o < 4; ++o) {  // fri_verify_initial_proof
+            leaf[o] = w;
+            if (!merkle_verify(w, ncols[o], x_index, oracle_caps[o], w + ncols[o], nsib0)) return 0;
+            w += ncols[o] + 4 * nsib0;
+        }
+        u64 subgroup_x = gl::mul(gl::GENERATOR, gl::pow(gl::root_of_unity(log_lde), bitrev(x_index, log_lde)));
+        // fri_combine_initial
+        Ext sum = gl::ext(0);
+        {
+            Ext acc = gl::ext(0), apow = gl::ext(1);
+            for (size_t o = 0; o < 4; ++o)
+                for (size_t p = 0; p < ncols[o]; ++p) {
+                    acc = gl::add(acc, gl::mul(apow, leaf[o][p]));
+                    apow = gl::mul(apow, fri_alpha);
+                }
+            sum = gl::mul(gl::sub(acc, reduced0), gl::inv(gl::sub(gl::ext(subgroup_x), zeta)));
+            acc = gl::ext(0);
+            apow = gl::ext(1);
+            for (size_t p = 0; p < nc; ++p) {
+                acc = gl::add(acc, gl::mul(apow, leaf[2][p]));
+                apow = gl::mul(apow, fri_alpha);
+            }
+            sum = gl::add(gl::mul(sum, apow), gl::mul(gl::sub(acc, reduced1), gl::inv(gl::sub(gl::ext(subgroup_x), zeta_next))));
+        }
+        Ext old_eval = sum;
+        unsigned lg = log_lde;
+        for (size_t r = 0; r < n_rounds; ++r) {
+            const unsigned ab = fp.reduction_arity_bits[r];
+            const size_t arity = (size_t)1 << ab;
+            const u64* evals = w;
+            const size_t coset_index = x_index >> ab, within = x_index & (arity - 1);
+            if (evals[2 * within] != old_eval.c0 || evals[2 * within + 1] != old_eval.c1) return 0;
+            // compute_evaluation
+            const u64 g = gl::root_of_unity(ab);
+            const u64 coset_start = gl::mul(subgroup_x, gl::pow(g, arity - bitrev(within, ab)));
+            u64 xs[16];
+            Ext ys[16];
+            u64 y = 1;
+            for (size_t i = 0; i < arity; ++i) {
+                xs[i] = gl::mul(coset_start, y);
+                ys[i] = ext_at(evals, bitrev(i, ab));
+                y = gl::mul(y, g);
+            }
+            old_eval = interpolate(xs, ys, arity, fri_betas[r]);
+            lg -= ab;
+            const size_t nsib = lg - in->cap_height;
+            if (!merkle_verify(evals, 2 * arity, coset_index, fri_caps[r], evals + 2 * arity, nsib)) return 0;
+            w += 2 * arity + 4 * nsib;
+            for (unsigned k = 0; k < ab; ++k) subgroup_x = gl::mul(subgroup_x, subgroup_x);
+            x_index = coset_index;
+        }
+        Ext acc = gl::ext(0);
+        for (size_t i = final_len; i-- > 0;) acc = gl::add(gl::mul(acc, subgroup_x), ext_at(final_words, i));
+        if (!gl::eq(acc, old_eval)) return 0;
+    }
+    return 1;
+}
