@@ -79,6 +79,14 @@ const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
     root_tables[key] = t;
     return t;
 }
+const u64* vpbs_ctx::l0_table(unsigned log_n) {
+    auto it = l0_tables.find(log_n);
+    if (it != l0_tables.end()) return it->second;
+    u64* t = alloc_words((size_t)1 << (log_n + rate_bits));
+    vpbs::launch_l0_table(stream, roots(log_n + rate_bits, false), log_n, rate_bits, t);
+    l0_tables[log_n] = t;
+    return t;
+}
 const u64* vpbs_ctx::prescale(unsigned log_n, unsigned rb, u64 shift) {
     auto key = std::make_tuple(log_n, rb, shift);
     auto it = prescale_tables.find(key);
@@ -254,6 +262,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->root_tables) c->release(kv.second);
     for (auto& kv : c->prescale_tables) c->release(kv.second);
+    for (auto& kv : c->l0_tables) c->release(kv.second);
     c->resolve_timing();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);

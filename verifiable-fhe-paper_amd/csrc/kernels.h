@@ -41,8 +41,11 @@ void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas,
 // roots_big / inv_roots_big: root tables of size 8n; unshift_table[i] = 7^-i (i < 8n); d_apow: [nc][n_terms + 1] powers of the
 // alphas (n_terms = nc * (1 + ceil(n_routed / max_degree))); betas/gammas: host arrays; q_leaf, q_nat: [nc][8n] scratch;
 // out_coeffs: [nc * 2^rate_bits][n] quotient chunks.  nc <= 4, rate_bits <= 3.
+// l0[j] = L_0(7 w^brev(j)) for the 8n coset points in leaf order (computed once per degree)
+void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsigned rate_bits, u64* l0);
 void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
-                                 const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms, const u64* d_apow,
+                                 const u64* l0_table, const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms,
+                                 const u64* d_apow,
                                  const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
                                  unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs);
 

@@ -363,7 +363,8 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
     try {
         VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, s));
         Timed t(ctx, "quotient_permutation");
-        vpbs::launch_quotient_permutation(s, wires->d_lde, cs->d_lde + (size_t)n_constants * big, zs_pp->d_lde, ctx->roots(log_big, false),
+        const u64* l0 = ctx->l0_table(log_n);
+        vpbs::launch_quotient_permutation(s, wires->d_lde, cs->d_lde + (size_t)n_constants * big, zs_pp->d_lde, ctx->roots(log_big, false), l0,
                                           ctx->roots(log_big, true), ctx->prescale(log_big, 0, gl::inv(gl::GENERATOR)), d_gate_terms, d_apow,
                                           betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, q_leaf, q_nat, d_out);
         VPBS_HIP(hipGetLastError());

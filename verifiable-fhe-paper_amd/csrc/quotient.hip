@@ -21,10 +21,28 @@ struct QuotientConsts {
     u64 n_field;            // n as a field element
 };
 
+// L_0 on the coset in leaf order (ZeroPolyOnCoset::eval_l_0): Z_H(x) / (n (x - 1)).  Depends on the degree only, so a
+// context computes it once (one field inversion per point) and the quotient kernel just reads it.
+__global__ void __launch_bounds__(THREADS)
+l0_table_kernel(const u64* __restrict__ roots_big, QuotientConsts k, unsigned log_n, unsigned rate_bits, u64* __restrict__ l0) {
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big;
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= big) return;
+    const unsigned t = gl::bitrev32((u32)j, log_big);
+    const u64 wt = t < big / 2 ? roots_big[t] : gl::neg(roots_big[t - big / 2]);
+    const u64 x = gl::mul(gl::GENERATOR, wt);
+    l0[j] = gl::mul(k.zh[t & ((1u << rate_bits) - 1)], gl::inv(gl::mul(k.n_field, gl::sub(x, 1))));
+}
+
 // grid (8n / 256).  apow: [nc][n_terms + 1] powers of alpha_a.  q: [nc][8n] in leaf order.
+// DEG: compile-time chunk size (8 = plonky2's quotient_degree_factor) so that the 16 loads of a chunk are issued
+// together; DEG = 0 selects the generic run-time loop.
+template <unsigned DEG>
 __global__ void __launch_bounds__(THREADS)
 quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ zs_pp,
-                     const u64* __restrict__ roots_big, const u64* __restrict__ gate_terms, const u64* __restrict__ apow,
+                     const u64* __restrict__ roots_big, const u64* __restrict__ l0_table, const u64* __restrict__ gate_terms,
+                     const u64* __restrict__ apow,
                      QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc,
                      u64* __restrict__ q) {
     const unsigned log_big = log_n + rate_bits;
@@ -37,7 +55,7 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
     const u64 wt = t < big / 2 ? roots_big[t] : gl::neg(roots_big[t - big / 2]);      // w_{8n}^t
     const u64 x = gl::mul(gl::GENERATOR, wt);
     const unsigned r = t & ((1u << rate_bits) - 1);
-    const u64 l0 = gl::mul(k.zh[r], gl::inv(gl::mul(k.n_field, gl::sub(x, 1))));     // ZeroPolyOnCoset::eval_l_0
+    const u64 l0 = l0_table[j];                                                       // ZeroPolyOnCoset::eval_l_0
     const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree, num_prods = n_chunks - 1;
     const unsigned n_terms = nc + nc * n_chunks;
     u64 acc[4] = {0, 0, 0, 0};  // sum_i term_i alpha_a^i for each challenge a (nc <= 4)
@@ -56,9 +74,7 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
     for (int c = 0; c < 4; ++c) sid[c] = (unsigned)c < nc ? gl::mul(k.beta[c], x) : 0;
     for (unsigned kk = 0; kk < n_chunks; ++kk) {
         u64 num[4] = {1, 1, 1, 1}, den[4] = {1, 1, 1, 1};
-        for (unsigned col = kk * max_degree; col < (kk + 1) * max_degree && col < n_routed; ++col) {
-            const u64 w = wires[(size_t)col * big + j];
-            const u64 s = sigmas[(size_t)col * big + j];
+        auto absorb = [&](u64 w, u64 s) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if ((unsigned)c >= nc) continue;
@@ -66,6 +82,19 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
                 den[c] = gl::mul(den[c], gl::add(gl::add(w, gl::mul(k.beta[c], s)), k.gamma[c]));
                 sid[c] = gl::mul(sid[c], gl::GENERATOR);
             }
+        };
+        if (DEG != 0 && (kk + 1) * DEG <= n_routed) {
+            u64 wv[DEG ? DEG : 1], sv[DEG ? DEG : 1];
+#pragma unroll
+            for (unsigned u = 0; u < DEG; ++u) {
+                wv[u] = wires[(size_t)(kk * DEG + u) * big + j];
+                sv[u] = sigmas[(size_t)(kk * DEG + u) * big + j];
+            }
+#pragma unroll
+            for (unsigned u = 0; u < DEG; ++u) absorb(wv[u], sv[u]);
+        } else {
+            for (unsigned col = kk * max_degree; col < (kk + 1) * max_degree && col < n_routed; ++col)
+                absorb(wires[(size_t)col * big + j], sigmas[(size_t)col * big + j]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -98,25 +127,43 @@ __global__ void mul_table_kernel(u64* __restrict__ data, const u64* __restrict__
 }
 }  // namespace
 
-void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
-                                 const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms, const u64* d_apow,
-                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
-                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs) {
-    const unsigned log_big = log_n + rate_bits;
-    const size_t big = (size_t)1 << log_big, n = (size_t)1 << log_n;
+static QuotientConsts make_consts(unsigned log_n, unsigned rate_bits) {
     QuotientConsts k{};
+    const size_t n = (size_t)1 << log_n;
     const u64 seven_n = gl::pow(gl::GENERATOR, n), w8 = gl::root_of_unity(rate_bits);
     for (unsigned r = 0; r < (1u << rate_bits) && r < 8; ++r) {
         k.zh[r] = gl::sub(gl::mul(seven_n, gl::pow(w8, r)), 1);
         k.zh_inv[r] = gl::inv(k.zh[r]);
     }
+    k.n_field = (u64)n;
+    return k;
+}
+
+void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsigned rate_bits, u64* l0) {
+    const size_t big = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(l0_table_kernel, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, roots_big,
+                       make_consts(log_n, rate_bits), log_n, rate_bits, l0);
+}
+
+void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
+                                 const u64* l0_table, const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms,
+                                 const u64* d_apow,
+                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
+                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs) {
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big, n = (size_t)1 << log_n;
+    QuotientConsts k = make_consts(log_n, rate_bits);
     for (unsigned c = 0; c < nc; ++c) {
         k.beta[c] = betas[c];
         k.gamma[c] = gammas[c];
     }
-    k.n_field = (u64)n;
-    hipLaunchKernelGGL(quotient_perm_kernel, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde, sigmas_lde,
-                       zs_pp_lde, roots_big, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
+    (void)n;
+    if (max_degree == 8)
+        hipLaunchKernelGGL(quotient_perm_kernel<8>, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde,
+                           sigmas_lde, zs_pp_lde, roots_big, l0_table, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
+    else
+        hipLaunchKernelGGL(quotient_perm_kernel<0>, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde,
+                           sigmas_lde, zs_pp_lde, roots_big, l0_table, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
     // PolynomialValues::coset_ifft(7): natural order -> iNTT of size 8n -> coefficient i times 7^-i; chunk m of challenge a is
     // out_coeffs[(a * 8 + m) * n ..]
     hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, (const u64*)q_leaf, q_nat, log_big);
