@@ -115,7 +115,8 @@ def main():
     comm = None
     if sharded:
         from vpbs_amd import sharding
-        comm = sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
+        comm = sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None,
+                                  stage_words=(2 << (args.log_n + 3)) // world, stage_device=torch.device("cuda", local_rank))
     n_chains = 1 if sharded else max(1, args.chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
     ctxs, sis, keep = [], [], []
@@ -125,9 +126,7 @@ def main():
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst)
         dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
-        # single-GPU steps evaluate the quotient chunks on the device; the sharded step takes them as data (its quotient
-        # evaluation over sharded LDEs is not built yet)
-        quot_ptr = dev["quotient"].data_ptr() if sharded else None
+        quot_ptr = None   # quotient chunks are evaluated on the device (sharded: values all-gathered between the GPUs)
         if sharded:
             cs, _ = sharding.sharded_commit(ctx, dev["constants_sigmas"].data_ptr(), COLS["constants_sigmas"], log_n,
                                             device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
@@ -253,9 +252,10 @@ def main():
                                  "Fiat-Shamir transcript included.  NOT in the timed region (host stages of plonky2's prove(), "
                                  "SURVEY.md 8f): witness generation and the gate-constraint terms of the quotient (the ~15 gate "
                                  "types of the step circuit; the quotient kernel accepts them as a pre-folded input)"
-                                 + ("; sharded mode: quotient chunks supplied as data" if sharded else ""),
+,
                        "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
-                                       "hashes + 1 all-reduce of query records (%s)" % (world, args.dist_backend)) if sharded else
+                                       "hashes, 1 device all-gather of quotient values (4 MiB) + 1 all-reduce of query records (%s)"
+                                       % (world, args.dist_backend)) if sharded else
                                       "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",

@@ -159,11 +159,20 @@ typedef struct {
  * would call rccl directly).  Payloads are tiny: 2^cap_height hashes per commitment, ~30 KB of query records per proof. */
 typedef int (*vpbs_allgather_fn)(void* user, const uint64_t* local, size_t local_words, uint64_t* full /* [world][local_words] */);
 typedef int (*vpbs_allreduce_sum_fn)(void* user, uint64_t* inout, size_t words); /* element-wise wrapping u64 sum */
+/* device-resident all-gather: the library has written `local_words` words to d_stage_local (its stream is synchronised);
+ * the callback must leave rank r's words at d_stage_full + r * local_words on every rank and return after the data is
+ * visible to later work on any stream (e.g. ncclAllGather + stream synchronise). */
+typedef int (*vpbs_allgather_dev_fn)(void* user, size_t local_words);
 typedef struct {
     unsigned rank, world;               /* world: power of two <= 2^rate_bits */
     vpbs_allgather_fn allgather;
     vpbs_allreduce_sum_fn allreduce_sum;
     void* user;
+    /* optional (needed only when the quotient is evaluated on the device in a sharded step): */
+    vpbs_allgather_dev_fn allgather_dev;
+    uint64_t* d_stage_local;            /* device buffer, stage_capacity_words words */
+    uint64_t* d_stage_full;             /* device buffer, world * stage_capacity_words words */
+    size_t stage_capacity_words;
 } vpbs_comm;
 
 /* sizes of the outputs of vpbs_prove_step, in u64 words */
@@ -186,7 +195,9 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
  * full input matrices and runs the identical transcript; a rank computes the LDE, leaf hashes and Merkle subtrees of its
  * own cosets only (1/world of the dominant work), caps are assembled with comm->allgather, the FRI rounds are computed
  * redundantly on every rank (cheaper than exchanging them), and the query openings of the sharded oracles are answered
- * by the owning rank and merged with comm->allreduce_sum.  in->constants_sigmas must be a batch committed with
+ * by the owning rank and merged with comm->allreduce_sum.  With quotient_coeffs == NULL every rank evaluates the quotient
+ * values of its own cosets (the next-row access stays inside a coset), the values are all-gathered on the device
+ * (comm->allgather_dev, 2^18 * 16 B per step) and the cheap size-8n iNTT is replicated.  in->constants_sigmas must be a batch committed with
  * vpbs_commit_sharded_dev(.., comm->rank, comm->world, ..) (or an unsharded one).  Every rank returns the complete,
  * identical proof -- bit-identical to vpbs_prove_step on one GPU. */
 int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out,

@@ -35,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     cs_shard, cs_cap = sharding.sharded_commit(ctx, dev_cs.data_ptr(), 85, log_n)
     assert (cs_cap == cs_full.cap()).all()
-    comm = sharding.make_comm()
+    comm = sharding.make_comm(stage_words=(2 << (log_n + 3)) // world)
     si = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs_shard, digest, pis, sigmas=sig, n_routed=n_routed)
     got = ctx.prove_step(si, comm)
     for key in ("caps", "challenges", "openings", "fri"):
@@ -46,6 +46,13 @@ def main():
     si2 = ctx.make_step_inputs(log_n, inputs["wires"], None, inputs["quotient"], cs_full, digest, pis, sigmas=sig, n_routed=n_routed)
     got2 = ctx.prove_step(si2, comm)
     assert (got2["fri"] == want["fri"]).all()
+    # quotient evaluated on the device: sharded (values all-gathered between the ranks) == single GPU
+    si3 = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs_full, digest, pis, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    want3 = ctx.prove_step(si3)
+    si4 = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs_shard, digest, pis, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    got4 = ctx.prove_step(si4, comm)
+    for key in ("caps", "openings", "fri"):
+        assert (got4[key] == want3[key]).all(), (rank, "device quotient", key)
     dist.barrier()
     ctx.close()
     if rank == 0:

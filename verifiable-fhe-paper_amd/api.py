@@ -62,11 +62,13 @@ class StepSizesC(C.Structure):
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t, U64P)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t)
+ALLGATHER_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
 
 
 class CommC(C.Structure):
     _fields_ = [("rank", C.c_uint), ("world", C.c_uint), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
-                ("user", C.c_void_p)]
+                ("user", C.c_void_p), ("allgather_dev", ALLGATHER_DEV_FN), ("d_stage_local", C.c_void_p),
+                ("d_stage_full", C.c_void_p), ("stage_capacity_words", C.c_size_t)]
 
 
 # every symbol include/vpbs_prover.h declares: name -> (restype, argtypes)

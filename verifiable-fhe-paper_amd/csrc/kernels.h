@@ -43,11 +43,15 @@ void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas,
 // out_coeffs: [nc * 2^rate_bits][n] quotient chunks.  nc <= 4, rate_bits <= 3.
 // l0[j] = L_0(7 w^brev(j)) for the 8n coset points in leaf order (computed once per degree)
 void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsigned rate_bits, u64* l0);
-void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
-                                 const u64* l0_table, const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms,
-                                 const u64* d_apow,
-                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
-                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs);
+// phase 1: quotient values q[a][j_local] for the local leaves [leaf_offset, leaf_offset + local_len) (column stride of the
+// *_lde arrays = local_len; gate terms, if any, in the same local leaf order [nc][local_len]); l0_table is the full table.
+void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
+                            const u64* l0_table, const u64* d_gate_terms, const u64* d_apow, const u64* betas, const u64* gammas,
+                            unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc, size_t leaf_offset,
+                            size_t local_len, u64* q_leaf_local);
+// phase 2: q_gathered is rank-major [world][nc][local_len] (world * local_len = 8n); q_nat, scratch: [nc][8n]
+void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
+                            unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs);
 
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)

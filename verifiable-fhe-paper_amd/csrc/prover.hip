@@ -336,9 +336,14 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
 // compute_quotient_polys (permutation part) on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks
 void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constants, vpbs_batch* wires, vpbs_batch* zs_pp,
                                  unsigned n_routed, const u64* betas, const u64* gammas, const u64* alphas, unsigned nc,
-                                 unsigned max_degree, const u64* d_gate_terms, u64* d_out) {
+                                 unsigned max_degree, const u64* d_gate_terms, u64* d_out, const vpbs_comm* comm = nullptr) {
     VPBS_REQUIRE(cs && wires && zs_pp && cs->ctx == ctx && wires->ctx == ctx && zs_pp->ctx == ctx, "batches of another context");
-    VPBS_REQUIRE(cs->n_shards == 1 && wires->n_shards == 1 && zs_pp->n_shards == 1, "quotient over sharded batches is not supported");
+    const unsigned world = wires->n_shards;
+    VPBS_REQUIRE(cs->n_shards == world && zs_pp->n_shards == world && cs->shard == wires->shard && zs_pp->shard == wires->shard,
+                 "quotient: the three batches must be sharded the same way");
+    if (world > 1)
+        VPBS_REQUIRE(comm && comm->world == world && comm->rank == wires->shard && comm->allgather_dev && comm->d_stage_local &&
+                         comm->d_stage_full, "quotient over sharded batches needs comm->allgather_dev and its device staging buffers");
     const unsigned log_n = wires->log_n, rate_bits = ctx->rate_bits;
     VPBS_REQUIRE(cs->log_n == log_n && zs_pp->log_n == log_n && log_n >= 1, "degree mismatch");
     VPBS_REQUIRE(nc >= 1 && nc <= 4 && rate_bits <= 3 && max_degree >= 1, "unsupported quotient shape");
@@ -360,14 +365,32 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
     u64* d_apow = ctx->alloc_words(h_apow.size());
     u64* q_leaf = ctx->alloc_words((size_t)nc * big);
     u64* q_nat = ctx->alloc_words((size_t)nc * big);
+    const size_t local_len = wires->lde_len(), leaf_offset = wires->leaf_offset();
     try {
         VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, s));
-        Timed t(ctx, "quotient_permutation");
         const u64* l0 = ctx->l0_table(log_n);
-        vpbs::launch_quotient_permutation(s, wires->d_lde, cs->d_lde + (size_t)n_constants * big, zs_pp->d_lde, ctx->roots(log_big, false), l0,
-                                          ctx->roots(log_big, true), ctx->prescale(log_big, 0, gl::inv(gl::GENERATOR)), d_gate_terms, d_apow,
-                                          betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, q_leaf, q_nat, d_out);
+        const u64* gathered = q_leaf;
+        {
+            Timed t(ctx, "quotient_permutation");
+            u64* q_local = world > 1 ? comm->d_stage_local : q_leaf;
+            if (world > 1) VPBS_REQUIRE((size_t)nc * local_len <= comm->stage_capacity_words, "comm staging buffers too small for the quotient values");
+            vpbs::launch_quotient_values(s, wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde, ctx->roots(log_big, false), l0,
+                                         d_gate_terms, d_apow, betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len,
+                                         q_local);
+        }
+        if (world > 1) {
+            // every rank needs all 8n values for the (cheap, replicated) inverse transform: device all-gather, 16 B per point
+            VPBS_HIP(hipStreamSynchronize(s));
+            if (comm->allgather_dev(comm->user, (size_t)nc * local_len) != 0) throw DeviceError{VPBS_ERR_DEVICE, "quotient all-gather failed"};
+            gathered = comm->d_stage_full;
+        }
+        {
+            Timed t(ctx, "quotient_permutation");
+            vpbs::launch_quotient_finish(s, gathered, local_len, ctx->roots(log_big, true), ctx->prescale(log_big, 0, gl::inv(gl::GENERATOR)), log_n,
+                                         rate_bits, nc, q_nat, q_leaf, d_out);
+        }
         VPBS_HIP(hipGetLastError());
+        if (world > 1) VPBS_HIP(hipStreamSynchronize(s));  // the staging buffers belong to the communicator: done with them
     } catch (...) {
         (void)hipStreamSynchronize(s);
         ctx->release(d_apow); ctx->release(q_leaf); ctx->release(q_nat);
@@ -563,7 +586,6 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         const u64* d_zs = in->zs_pp_values ? on_device(in->zs_pp_values, (size_t)in->n_zs_partial_products * n) : nullptr;
         const u64* d_quot = in->quotient_coeffs ? on_device(in->quotient_coeffs, (size_t)in->n_quotient * n) : nullptr;
         if (!in->quotient_coeffs) {
-            VPBS_REQUIRE(!comm, "device quotient evaluation is not available in the sharded step");
             VPBS_REQUIRE(in->n_quotient == nc * (1u << ctx->rate_bits) && in->n_routed >= 1 && in->quotient_degree_factor >= 1,
                          "quotient_coeffs == NULL needs n_quotient = num_challenges * 8, n_routed and quotient_degree_factor");
         }
@@ -605,7 +627,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             u64* d_q = ctx->alloc_words((size_t)in->n_quotient * n);
             staged.push_back(d_q);
             quotient_permutation_device(ctx, in->constants_sigmas, in->n_constants, wires.h, zs_pp.h, in->n_routed, betas.data(),
-                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, nullptr, d_q);
+                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, nullptr, d_q, comm);
             d_quot = d_q;
         }
         PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);

@@ -44,18 +44,21 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
                      const u64* __restrict__ roots_big, const u64* __restrict__ l0_table, const u64* __restrict__ gate_terms,
                      const u64* __restrict__ apow,
                      QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc,
-                     u64* __restrict__ q) {
+                     size_t leaf_offset, size_t local_len, u64* __restrict__ q) {
+    // The column arrays hold the leaves [leaf_offset, leaf_offset + local_len) only (a whole number of cosets; the full
+    // LDE when unsharded): `big` below is their column stride and j the LOCAL leaf index.
     const unsigned log_big = log_n + rate_bits;
-    const size_t big = (size_t)1 << log_big;
+    const size_t big = local_len;
     const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
-    if (j >= big) return;
-    const unsigned t = gl::bitrev32((u32)j, log_big);                                 // natural index of this leaf
-    const unsigned t_next = (t + (1u << rate_bits)) & (unsigned)(big - 1);            // g * x: next trace row
-    const size_t j_next = gl::bitrev32(t_next, log_big);
-    const u64 wt = t < big / 2 ? roots_big[t] : gl::neg(roots_big[t - big / 2]);      // w_{8n}^t
+    if (j >= local_len) return;
+    const size_t full = (size_t)1 << log_big;
+    const unsigned t = gl::bitrev32((u32)(leaf_offset + j), log_big);                 // natural index of this leaf
+    const unsigned t_next = (t + (1u << rate_bits)) & (unsigned)(full - 1);           // g * x: next trace row (same coset)
+    const size_t j_next = gl::bitrev32(t_next, log_big) - leaf_offset;
+    const u64 wt = t < full / 2 ? roots_big[t] : gl::neg(roots_big[t - full / 2]);    // w_{8n}^t
     const u64 x = gl::mul(gl::GENERATOR, wt);
     const unsigned r = t & ((1u << rate_bits) - 1);
-    const u64 l0 = l0_table[j];                                                       // ZeroPolyOnCoset::eval_l_0
+    const u64 l0 = l0_table[leaf_offset + j];                                                       // ZeroPolyOnCoset::eval_l_0
     const unsigned n_chunks = (n_routed + max_degree - 1) / max_degree, num_prods = n_chunks - 1;
     const unsigned n_terms = nc + nc * n_chunks;
     u64 acc[4] = {0, 0, 0, 0};  // sum_i term_i alpha_a^i for each challenge a (nc <= 4)
@@ -115,11 +118,15 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
     }
 }
 
-// out[a][t] = in[a][bitrev(t)]  (leaf order -> natural order)
-__global__ void bitrev_copy_kernel(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_len) {
+// out[a][t] = value of challenge a at leaf bitrev(t)  (leaf order -> natural order).  `in` is rank-major
+// [world][nc][local_len] (the layout an all-gather of per-rank [nc][local_len] buffers produces; world = 1: [nc][len]).
+__global__ void bitrev_copy_kernel(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_len, size_t local_len, unsigned nc) {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t len = (size_t)1 << log_len;
-    if (t < len) out[blockIdx.y * len + t] = in[blockIdx.y * len + gl::bitrev32((u32)t, log_len)];
+    if (t >= len) return;
+    const size_t j = gl::bitrev32((u32)t, log_len);
+    const size_t rank = j / local_len, jl = j - rank * local_len;
+    out[blockIdx.y * len + t] = in[(rank * nc + blockIdx.y) * local_len + jl];
 }
 __global__ void mul_table_kernel(u64* __restrict__ data, const u64* __restrict__ table, size_t len) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -145,29 +152,32 @@ void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsign
                        make_consts(log_n, rate_bits), log_n, rate_bits, l0);
 }
 
-void launch_quotient_permutation(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
-                                 const u64* l0_table, const u64* inv_roots_big, const u64* unshift_table, const u64* d_gate_terms,
-                                 const u64* d_apow,
-                                 const u64* betas, const u64* gammas, unsigned n_routed, unsigned log_n, unsigned rate_bits,
-                                 unsigned max_degree, unsigned nc, u64* q_leaf, u64* q_nat, u64* out_coeffs) {
-    const unsigned log_big = log_n + rate_bits;
-    const size_t big = (size_t)1 << log_big, n = (size_t)1 << log_n;
+void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
+                            const u64* l0_table, const u64* d_gate_terms, const u64* d_apow, const u64* betas, const u64* gammas,
+                            unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc, size_t leaf_offset,
+                            size_t local_len, u64* q_leaf_local) {
     QuotientConsts k = make_consts(log_n, rate_bits);
     for (unsigned c = 0; c < nc; ++c) {
         k.beta[c] = betas[c];
         k.gamma[c] = gammas[c];
     }
-    (void)n;
+    const dim3 grid((unsigned)((local_len + THREADS - 1) / THREADS));
     if (max_degree == 8)
-        hipLaunchKernelGGL(quotient_perm_kernel<8>, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde,
-                           sigmas_lde, zs_pp_lde, roots_big, l0_table, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
+        hipLaunchKernelGGL(quotient_perm_kernel<8>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
+                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local);
     else
-        hipLaunchKernelGGL(quotient_perm_kernel<0>, dim3((unsigned)((big + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires_lde,
-                           sigmas_lde, zs_pp_lde, roots_big, l0_table, d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, q_leaf);
+        hipLaunchKernelGGL(quotient_perm_kernel<0>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
+                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local);
+}
+
+void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
+                            unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs) {
+    const unsigned log_big = log_n + rate_bits;
+    const size_t big = (size_t)1 << log_big;
     // PolynomialValues::coset_ifft(7): natural order -> iNTT of size 8n -> coefficient i times 7^-i; chunk m of challenge a is
     // out_coeffs[(a * 8 + m) * n ..]
-    hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, (const u64*)q_leaf, q_nat, log_big);
-    launch_intt(s, q_nat, out_coeffs, q_leaf /* scratch */, inv_roots_big, nc, log_big);
+    hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, q_gathered, q_nat, log_big, local_len, nc);
+    launch_intt(s, q_nat, out_coeffs, scratch, inv_roots_big, nc, log_big);
     hipLaunchKernelGGL(mul_table_kernel, dim3((unsigned)((big + 255) / 256), nc), dim3(256), 0, s, out_coeffs, unshift_table, big);
 }
 }  // namespace vpbs

@@ -76,11 +76,14 @@ def sharded_commit(ctx, d_values_ptr, ncols, log_n, is_values=True, group=None, 
     return batch, cap
 
 
-def make_comm(group=None, device=None):
+def make_comm(group=None, device=None, stage_words=0, stage_device=None):
     """vpbs_comm backed by torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests).
 
-    The two collectives of a sharded step proof move a few KB: an all-gather of cap hashes per commitment and one
-    sum-all-reduce of the query records.  `device`: torch device for the staging tensors (required for nccl)."""
+    The host collectives of a sharded step proof move a few KB: an all-gather of cap hashes per commitment and one
+    sum-all-reduce of the query records.  `device`: torch device for their staging tensors (required for nccl).
+    stage_words > 0 additionally provides the device-resident all-gather used by the on-device quotient (per rank
+    stage_words u64 on `stage_device`, e.g. 2 * 2^18 / world for the N = 1024 step): with nccl it is one
+    all_gather_into_tensor between device buffers; with gloo the payload takes a detour through host memory."""
     import ctypes as C
     import torch
     import torch.distributed as dist
@@ -122,5 +125,35 @@ def make_comm(group=None, device=None):
     comm.allgather = api.ALLGATHER_FN(_allgather)
     comm.allreduce_sum = api.ALLREDUCE_FN(_allreduce)
     comm.user = None
-    comm._keep = (_allgather, _allreduce)
+    keep = [_allgather, _allreduce]
+    if stage_words:
+        sdev = stage_device if stage_device is not None else torch.device("cuda", torch.cuda.current_device())
+        local_t = torch.zeros(stage_words, dtype=torch.int64, device=sdev)
+        full_t = torch.zeros(stage_words * world, dtype=torch.int64, device=sdev)
+        on_gpu_collective = dist.get_backend(group) == "nccl"
+
+        def _allgather_dev(user, local_words):
+            try:
+                src, dst = local_t[:local_words], full_t[:local_words * world]
+                if on_gpu_collective:
+                    dist.all_gather_into_tensor(dst, src, group=group)
+                    torch.cuda.synchronize(sdev)
+                else:
+                    parts = [torch.empty(local_words, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(parts, src.cpu(), group=group)
+                    dst.copy_(torch.cat(parts))
+                    torch.cuda.synchronize(sdev)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = api.ALLGATHER_DEV_FN(_allgather_dev)
+        comm.allgather_dev = cb
+        comm.d_stage_local = local_t.data_ptr()
+        comm.d_stage_full = full_t.data_ptr()
+        comm.stage_capacity_words = stage_words
+        keep += [cb, _allgather_dev, local_t, full_t]
+    comm._keep = tuple(keep)
     return comm
