@@ -35,7 +35,7 @@ N_CONSTANTS, N_ROUTED = 5, 80   # constants_sigmas = 5 selector/constant columns
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-LEAF_HASH_INSTR_PER_PERM = 15100  # dynamic VALU instructions per permutation (ISA count x loop trip counts)
+LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py)
 
 
 def leaf_hash_bytes_per_step():
