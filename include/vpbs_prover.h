@@ -265,6 +265,25 @@ int vpbs_k_negacyclic_ntt(vpbs_ctx* ctx, uint64_t* data, unsigned batch, unsigne
 /* the params_{N}.rs tables (ROOTS, INVROOTS, NINV) regenerated per /root/reference/src/ntt/gen_param_file.sage */
 int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv);
 
+/* ---- native TFHE data path of a step (witness-generation core) ----
+ * One step of the verifiable PBS exactly as the step circuit computes it (/root/reference/src/vtfhe/ivc_based_vpbs.rs:99-125):
+ *   first_step : acc_out = rotate(acc_in, -mask)                                  (the LWE body)
+ *   otherwise  : x = last_step ? acc_in : rotate(acc_in, mask) - acc_in           (mod.rs:80-117: mod switch to 2N, rounded)
+ *                acc_out = GGSW (x) x  [+ acc_in unless last_step]                 (ggsw_ct.rs:98-112, glev_ct.rs:92-110,
+ *                signed base-2^LOGB decomposition glwe_poly.rs:28-50, top ELL limbs, negacyclic NTT crypto/poly.rs:9-64)
+ * batched over independent accumulators.  acc: [batch][K][N]; masks: [batch]; ggsw: NTT-domain bootstrapping-key element in
+ * the order of Ggsw::flatten() = [K glevs][ELL glwes][K polys][N] (crypto/ggsw.rs:61-63), one for all instances or
+ * (ggsw_per_instance) [batch] of them; all canonical field elements; host or device pointers (on_device). */
+typedef struct {
+    unsigned log_N; /* ring dimension N = 2^log_N (<= 2048) */
+    unsigned K;     /* GLWE dimension + 1 */
+    unsigned ELL;   /* decomposition levels kept */
+    unsigned LOGB;  /* log2 of the decomposition base */
+} vpbs_tfhe_params;
+int vpbs_blind_rotate_step(vpbs_ctx* ctx, const vpbs_tfhe_params* params, unsigned batch, const uint64_t* acc_in,
+                           const uint64_t* masks, const uint64_t* ggsw, int ggsw_per_instance, int first_step, int last_step,
+                           uint64_t* acc_out, int on_device);
+
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */
 /* on: 0 off, 1 every kernel group, 2 only the dominant kernel (leaf_hash) */
 int vpbs_timing_enable(vpbs_ctx* ctx, int on);

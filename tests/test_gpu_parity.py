@@ -486,3 +486,46 @@ def test_cxx_host_example_matches_python_path(ctx):
     assert int(fields["proof_bytes"]) == len(blob)
     assert int(fields["pow"]) == int(got["fri"][-1])
     assert fields["fnv1a"] == "%016x" % h
+
+
+# ---------- native TFHE step (witness-generation core) ----------
+@pytest.mark.parametrize("log_N,K,ELL,LOGB,batch", [(3, 2, 8, 8, 3), (6, 2, 4, 5, 2), (10, 2, 4, 5, 2), (5, 3, 3, 7, 2), (11, 2, 4, 5, 1)])
+def test_blind_rotate_step_matches_oracle(ctx, log_N, K, ELL, LOGB, batch):
+    """paper parameters (N=1024, K=2, ELL=4, LOGB=5: reference src/main.rs:23-30) and the reference's test parameters
+    (N=8, LOGB=8, ELL=8: mod.rs:224-227); first / middle / last step semantics of ivc_based_vpbs.rs:99-125"""
+    import tfhe_oracle as T
+    N = 1 << log_N
+    ring = T.Ring(log_N)
+    acc = rand_field(batch, K, N)
+    masks = rand_field(batch)
+    ggsw = rand_field(batch, K * ELL * K * N)
+    hat = lambda b: [[[list(map(int, ggsw[b][((p * ELL + l) * K + r) * N:((p * ELL + l) * K + r + 1) * N])) for r in range(K)]
+                      for l in range(ELL)] for p in range(K)]
+    for first, last in ((False, False), (True, False), (False, True)):
+        got = ctx.blind_rotate_step(acc, masks, ggsw, K, ELL, LOGB, first_step=first, last_step=last)
+        for b in range(batch):
+            want = T.step(ring, [list(map(int, acc[b][p])) for p in range(K)], int(masks[b]), hat(b), K, ELL, LOGB, first, last)
+            assert [[int(v) for v in got[b][p]] for p in range(K)] == want, (first, last, b)
+    # one GGSW shared by every instance
+    got = ctx.blind_rotate_step(acc, masks, ggsw[0], K, ELL, LOGB)
+    b = batch - 1
+    want = T.step(ring, [list(map(int, acc[b][p])) for p in range(K)], int(masks[b]), hat(0), K, ELL, LOGB)
+    assert [[int(v) for v in got[b][p]] for p in range(K)] == want
+
+
+@pytest.mark.parametrize("log_N,ELL,LOGB", [(3, 8, 8), (6, 8, 8)])
+def test_blind_rotate_step_decrypts_like_the_reference_test(ctx, log_N, ELL, LOGB):
+    """the reference's own check (test_blind_rot_step, mod.rs:223-279): noise-free GLWE / GGSW encryptions, one CMUX
+    step on the device, decrypt: bit = 0 leaves the message, bit = 1 rotates it by the mod-switched mask"""
+    import tfhe_oracle as T
+    K, N = 2, 1 << log_N
+    ring = T.Ring(log_N)
+    for bit in (0, 1):
+        s = [[int(v) for v in rng.integers(0, 2, size=N)] for _ in range(K - 1)]
+        m = list(range(N))
+        ct = T.glwe_encrypt(ring, rng, s, m, K)
+        gg = T.ggsw_encrypt_hat(ring, rng, s, [bit] + [0] * (N - 1), K, ELL, LOGB)
+        ai = int(rand_field(1)[0])
+        out = ctx.blind_rotate_step(np.array([ct], dtype=np.uint64), [ai], T.flatten_ggsw(gg), K, ELL, LOGB)
+        m_out = T.glwe_decrypt(ring, s, [[int(v) for v in out[0][p]] for p in range(K)], K)
+        assert m_out == (m if bit == 0 else T.rotate(m, T.mod_switch(ai, log_N)))

@@ -371,3 +371,25 @@ def test_quotient_permutation_satisfies_verifier_identity(log_n, n_routed):
     assert run(wires)
     bad = wires.copy(); bad[1][3] = (int(bad[1][3]) + 1) % P   # breaks one copy constraint
     assert not run(bad)
+
+
+def test_tfhe_oracle_reference_properties():
+    """tests/tfhe_oracle.py restates the in-circuit TFHE step; pin it with the reference's own test properties:
+    test_decompose (glwe_poly.rs:239: sum limb_i B^i == x, digits centred) and test_blind_rot_step (mod.rs:223-279)."""
+    import tfhe_oracle as T
+    for logb in (8, 5, 4, 7):
+        for x in [0, 1, P - 1, P - 2, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF] + [int(v) for v in rand_field(30)]:
+            d = T.decompose(x, logb)
+            assert sum(di * pow(2, logb * i, P) for i, di in enumerate(d)) % P == x % P
+            assert all(-(1 << (logb - 1)) <= (di if di < P // 2 else di - P) <= (1 << (logb - 1)) for di in d)
+    ring = T.Ring(3); K, ELL, LOGB = 2, 8, 8
+    for bit in (0, 1):
+        s = [[int(v) for v in rng.integers(0, 2, size=8)] for _ in range(K - 1)]
+        m = list(range(8))
+        ct = T.glwe_encrypt(ring, rng, s, m, K)
+        gg = T.ggsw_encrypt_hat(ring, rng, s, [bit] + [0] * 7, K, ELL, LOGB)
+        ai = int(rand_field(1)[0])
+        assert T.glwe_decrypt(ring, s, T.step(ring, ct, ai, gg, K, ELL, LOGB), K) == (m if bit == 0 else T.rotate(m, T.mod_switch(ai, 3)))
+        # first step: pure rotation by -mask; last step: plain external product (no CMUX add)
+        assert T.glwe_decrypt(ring, s, T.step(ring, ct, ai, gg, K, ELL, LOGB, first_step=True), K) == T.rotate(m, T.mod_switch((P - ai) % P, 3))
+        assert T.glwe_decrypt(ring, s, T.step(ring, ct, ai, gg, K, ELL, LOGB, last_step=True), K) == [bit * v for v in m]

@@ -1,0 +1,136 @@
+"""CPU restatement of the native TFHE data path of one vPBS step (TEST INFRASTRUCTURE).
+
+What it follows in the reference (/root/reference/src/vtfhe/):
+  * step semantics            ivc_based_vpbs.rs:99-125  (first step: rotate by -mask; middle: CMUX; last: external product only)
+  * rotate_poly / mod switch  mod.rs:80-107 (round-to-nearest of the top log2(2N) bits, built from power-of-two rotations),
+                              glwe_poly.rs:132-148 (`rotate`: multiplication by X^shift, negacyclic), crypto/lwe.rs:28-34
+  * signed decomposition      glwe_poly.rs:28-50 (`decompose`), :150-166
+  * GLEV / GGSW products      glev_ct.rs:92-110 (`mul`: top ELL limbs, NTT, vec_inner with the GLEV rows),
+                              ggsw_ct.rs:98-112 (`external_product`: glev_muls[K-1] - sum of the others, inverse NTT)
+  * plain crypto for tests    crypto/glwe.rs:49-63 (encrypt/decrypt), crypto/glev.rs:26-38, crypto/ggsw.rs:26-36
+The negacyclic NTT itself is the C oracle's (pinned by TESTG/TESTGHAT).  Pure Python big-int arithmetic otherwise.
+"""
+import numpy as np
+
+import oracle as orc
+
+P = 0xFFFFFFFF00000001
+
+
+def num_limbs(logb):
+    return -(-64 // logb)
+
+
+def mod_switch(mask, log_n_ring):
+    """rotation amount in [0, 2N]: top log2(2N) bits of the canonical value, rounded with the next bit (mod.rs:85-106)"""
+    log2n = log_n_ring + 1
+    x = int(mask)
+    return (x >> (64 - log2n)) + ((x >> (64 - log2n - 1)) & 1)
+
+
+def rotate(poly, shift):
+    """multiplication by X^shift modulo X^N + 1, 0 <= shift <= 2N (composition of GlwePoly::rotate steps)"""
+    n = len(poly)
+    out = [0] * n
+    for i, c in enumerate(poly):
+        j = i + shift
+        sign = (j // n) & 1
+        out[j % n] = (P - int(c)) % P if sign else int(c)
+    return out
+
+
+def decompose(x, logb):
+    """glwe_poly.rs:28-50: centred base-2^logb digits (little-endian) as field elements"""
+    nl = num_limbs(logb)
+    tb = nl * logb
+    x = int(x)
+    sgn = (x >> (tb - 1)) & 1 if tb <= 64 else 0
+    xc = (P - x) % P if sgn else x
+    out, carry = [], 0
+    for l in range(nl):
+        k = (xc >> (l * logb)) & ((1 << logb) - 1)
+        kw = k + carry
+        carry = (k >> (logb - 1)) & 1
+        bal = (kw - (carry << logb)) % P
+        out.append((P - bal) % P if sgn else bal)
+    return out
+
+
+class Ring:
+    def __init__(self, log_n):
+        self.log_n, self.n = log_n, 1 << log_n
+        self.roots, self.invroots, self.ninv = orc.negacyclic_params(log_n)
+
+    def fw(self, poly):
+        return [int(v) for v in orc.negacyclic_forward(np.array(poly, dtype=np.uint64), self.roots)]
+
+    def bw(self, poly):
+        return [int(v) for v in orc.negacyclic_backward(np.array(poly, dtype=np.uint64), self.invroots, self.ninv)]
+
+    def mul(self, a, b):
+        return self.bw([x * y % P for x, y in zip(self.fw(a), self.fw(b))])
+
+
+def external_product(ring, ggsw_hat, glwe, K, ELL, logb):
+    """ggsw_hat[p][l][r] = NTT-domain polynomial r of GLWE l of GLEV p; glwe: K coefficient polynomials"""
+    nl = num_limbs(logb)
+    muls = []
+    for p in range(K):
+        digits = [decompose(c, logb) for c in glwe[p]]
+        limbs_hat = [ring.fw([d[nl - ELL + l] for d in digits]) for l in range(ELL)]
+        muls.append([[sum(limbs_hat[l][i] * ggsw_hat[p][l][r][i] for l in range(ELL)) % P for i in range(ring.n)] for r in range(K)])
+    out = []
+    for r in range(K):
+        acc = [(muls[K - 1][r][i] - sum(muls[p][r][i] for p in range(K - 1))) % P for i in range(ring.n)]
+        out.append(ring.bw(acc))
+    return out
+
+
+def step(ring, acc_in, mask, ggsw_hat, K, ELL, logb, first_step=False, last_step=False):
+    """ivc_based_vpbs.rs:99-125"""
+    m = (P - int(mask)) % P if first_step else int(mask)
+    s = mod_switch(m, ring.log_n)
+    shifted = [rotate(p, s) for p in acc_in]
+    if first_step:
+        return shifted
+    diff = [[(a - b) % P for a, b in zip(sp, ap)] for sp, ap in zip(shifted, acc_in)]
+    xin = [list(map(int, p)) for p in acc_in] if last_step else diff
+    xout = external_product(ring, ggsw_hat, xin, K, ELL, logb)
+    if last_step:
+        return xout
+    return [[(a + int(b)) % P for a, b in zip(xp, ap)] for xp, ap in zip(xout, acc_in)]
+
+
+# ---- noise-free plain TFHE for the property tests (crypto/*.rs with sigma = 0) ----
+def glwe_encrypt(ring, rng, s, m, K):
+    mask = [[int(v) for v in rng.integers(0, P, size=ring.n, dtype=np.uint64)] for _ in range(K - 1)]
+    body = [0] * ring.n
+    for a, sk in zip(mask, s):
+        body = [(x + y) % P for x, y in zip(body, ring.mul(a, sk))]
+    return mask + [[(b + int(mi)) % P for b, mi in zip(body, m)]]
+
+
+def glwe_decrypt(ring, s, ct, K):
+    mask = [0] * ring.n
+    for a, sk in zip(ct[:K - 1], s):
+        mask = [(x + y) % P for x, y in zip(mask, ring.mul(a, sk))]
+    return [(b - x) % P for b, x in zip(ct[K - 1], mask)]
+
+
+def ggsw_encrypt_hat(ring, rng, s, m, K, ELL, logb):
+    """Ggsw::encrypt(...).ntt_forward(): GLEV p encrypts m * s_p (p < K-1) or m (p = K-1), gadget B^(first_limb + l)"""
+    first = num_limbs(logb) - ELL
+    out = []
+    for p in range(K):
+        mp = ring.mul(m, s[p]) if p < K - 1 else list(m)
+        glev = []
+        for l in range(ELL):
+            scale = pow(2, logb * (first + l), P)
+            ct = glwe_encrypt(ring, rng, s, [x * scale % P for x in mp], K)
+            glev.append([ring.fw(poly) for poly in ct])
+        out.append(glev)
+    return out
+
+
+def flatten_ggsw(ggsw_hat):
+    return np.array([c for glev in ggsw_hat for glwe in glev for poly in glwe for c in poly], dtype=np.uint64)

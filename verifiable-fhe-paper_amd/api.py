@@ -56,6 +56,10 @@ class VerifyInputsC(C.Structure):
                 ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P)]
 
 
+class TfheParamsC(C.Structure):
+    _fields_ = [("log_N", C.c_uint), ("K", C.c_uint), ("ELL", C.c_uint), ("LOGB", C.c_uint)]
+
+
 class StepSizesC(C.Structure):
     _fields_ = [("cap_words", C.c_size_t), ("openings_words", C.c_size_t), ("fri_words", C.c_size_t)]
 
@@ -107,6 +111,7 @@ SIGNATURES = {
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
+    "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -499,6 +504,22 @@ class Context:
         self._check(lib().vpbs_quotient_permutation(self.h, cs_batch.h, n_constants, wires_batch.h, zs_batch.h, n_routed, _ptr(b), _ptr(g),
                                                     _ptr(a), nc, max_degree, C.c_void_p(gate_terms_dev) if gate_terms_dev else None,
                                                     out.ctypes.data, 0))
+        return out
+
+    def blind_rotate_step(self, acc_in, masks, ggsw, K, ELL, LOGB, first_step=False, last_step=False):
+        """One vPBS step on a batch of accumulators (host arrays): acc_in [B][K][N], masks [B], ggsw [K*ELL*K*N] shared or
+        [B][K*ELL*K*N] per instance (NTT domain, Ggsw::flatten order) -> acc_out [B][K][N]."""
+        acc = _u64(acc_in)
+        B, K_, N = acc.shape
+        assert K_ == K
+        m = _u64(masks).reshape(-1)
+        prm = TfheParamsC(N.bit_length() - 1, K, ELL, LOGB)
+        out = np.zeros_like(acc)
+        g = _u64(ggsw) if ggsw is not None else None
+        per_instance = 1 if (g is not None and g.ndim == 2) else 0
+        self._check(lib().vpbs_blind_rotate_step(self.h, C.byref(prm), B, acc.ctypes.data, m.ctypes.data,
+                                                 g.ctypes.data if g is not None else None, per_instance, 1 if first_step else 0,
+                                                 1 if last_step else 0, out.ctypes.data, 0))
         return out
 
     # ---- kernel-level hooks ----

@@ -79,6 +79,19 @@ const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
     root_tables[key] = t;
     return t;
 }
+const u64* vpbs_ctx::ring_table(unsigned log_n_ring) {
+    auto it = ring_tables.find(log_n_ring);
+    if (it != ring_tables.end()) return it->second;
+    const size_t n = (size_t)1 << log_n_ring;
+    std::vector<u64> h(2 * n);
+    u64 ninv;
+    if (vpbs_ntt_params(log_n_ring, h.data(), h.data() + n, &ninv) != 0) throw DeviceError{VPBS_ERR_INVALID, "unsupported ring dimension"};
+    u64* t = alloc_words(2 * n);
+    VPBS_HIP(hipMemcpyAsync(t, h.data(), sizeof(u64) * 2 * n, hipMemcpyHostToDevice, stream));
+    VPBS_HIP(hipStreamSynchronize(stream));
+    ring_tables[log_n_ring] = t;
+    return t;
+}
 const u64* vpbs_ctx::l0_table(unsigned log_n) {
     auto it = l0_tables.find(log_n);
     if (it != l0_tables.end()) return it->second;
@@ -263,6 +276,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     for (auto& kv : c->root_tables) c->release(kv.second);
     for (auto& kv : c->prescale_tables) c->release(kv.second);
     for (auto& kv : c->l0_tables) c->release(kv.second);
+    for (auto& kv : c->ring_tables) c->release(kv.second);
     c->resolve_timing();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
@@ -532,6 +546,57 @@ int vpbs_k_negacyclic_ntt(vpbs_ctx* c, uint64_t* data, unsigned batch, unsigned 
         vpbs::launch_negacyclic(c->stream, d.p, tab.p, batch, log_n, inverse != 0, ninv);
         VPBS_HIP(hipMemcpyAsync(data, d.p, sizeof(u64) * batch * n, hipMemcpyDeviceToHost, c->stream));
         VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int vpbs_blind_rotate_step(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigned batch, const uint64_t* acc_in, const uint64_t* masks,
+                           const uint64_t* ggsw, int ggsw_per_instance, int first_step, int last_step, uint64_t* acc_out, int on_device) {
+    if (!c || !prm || !acc_in || !masks || !acc_out || batch == 0 || (!first_step && !ggsw)) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        const unsigned log_n = prm->log_N, K = prm->K, ELL = prm->ELL, LOGB = prm->LOGB;
+        VPBS_REQUIRE(log_n >= 1 && log_n <= 11 && K >= 1 && K <= 8 && LOGB >= 1 && LOGB <= 32, "unsupported TFHE parameters");
+        const unsigned nl = (64 + LOGB - 1) / LOGB;
+        VPBS_REQUIRE(ELL >= 1 && ELL <= nl, "ELL exceeds the number of limbs");
+        const size_t n = (size_t)1 << log_n;
+        VPBS_REQUIRE(ELL * n * sizeof(u64) <= 128 * 1024, "ELL * N does not fit the LDS budget");
+        VPBS_REQUIRE(!(first_step && last_step), "a step cannot be both the first and the last");
+        const size_t acc_words = (size_t)batch * K * n, ggsw_words = (size_t)K * ELL * K * n * (ggsw_per_instance ? batch : 1);
+        const u64* tab = c->ring_table(log_n);
+        u64 ninv = gl::inv((u64)n);
+        std::vector<void*> tmp;
+        struct Cleanup {
+            vpbs_ctx* c;
+            std::vector<void*>& v;
+            ~Cleanup() {
+                (void)hipStreamSynchronize(c->stream);
+                for (void* p : v) c->release(p);
+            }
+        } cleanup{c, tmp};
+        auto stage = [&](const u64* host, size_t words) -> u64* {
+            u64* d = c->alloc_words(words);
+            tmp.push_back(d);
+            if (host) VPBS_HIP(hipMemcpyAsync(d, host, sizeof(u64) * words, hipMemcpyHostToDevice, c->stream));
+            return d;
+        };
+        const u64 *d_acc = acc_in, *d_masks = masks, *d_ggsw = ggsw;
+        u64* d_out = acc_out;
+        if (!on_device) {
+            d_acc = stage(acc_in, acc_words);
+            d_masks = stage(masks, batch);
+            d_ggsw = first_step ? nullptr : stage(ggsw, ggsw_words);
+            d_out = stage(nullptr, acc_words);
+        }
+        u64* limbs = stage(nullptr, (size_t)batch * K * ELL * n);
+        {
+            vpbs::Timed t(c, "blind_rotate_step");
+            vpbs::launch_blind_rotate_step(c->stream, d_acc, d_masks, d_ggsw, ggsw_per_instance ? (size_t)K * ELL * K * n : 0, tab, tab + n, ninv,
+                                           log_n, K, ELL, LOGB, batch, first_step, last_step, limbs, d_out);
+        }
+        VPBS_HIP(hipGetLastError());
+        if (!on_device) {
+            VPBS_HIP(hipMemcpyAsync(acc_out, d_out, sizeof(u64) * acc_words, hipMemcpyDeviceToHost, c->stream));
+            VPBS_HIP(hipStreamSynchronize(c->stream));
+        }
     });
 }
 

@@ -53,6 +53,14 @@ void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigm
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
                             unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs);
 
+// ---------- tfhe.hip ----------
+// One step of the verifiable PBS on `batch` independent accumulators (reference ivc_based_vpbs.rs:99-125): acc [batch][K][N],
+// masks [batch], ggsw in NTT domain [K][ELL][K][N] (ggsw_instance_stride = 0: shared by all instances) ; roots/invroots: the
+// params_{N} tables on the device; limbs_hat: scratch [batch][K][ELL][N].  ELL * N * 8 B of LDS per workgroup.
+void launch_blind_rotate_step(hipStream_t s, const u64* acc_in, const u64* masks, const u64* ggsw, size_t ggsw_instance_stride,
+                              const u64* roots, const u64* invroots, u64 ninv, unsigned log_n, unsigned K, unsigned ELL, unsigned LOGB,
+                              unsigned batch, int first_step, int last_step, u64* limbs_hat, u64* acc_out);
+
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
 void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests);
