@@ -284,6 +284,15 @@ int vpbs_blind_rotate_step(vpbs_ctx* ctx, const vpbs_tfhe_params* params, unsign
                            const uint64_t* masks, const uint64_t* ggsw, int ggsw_per_instance, int first_step, int last_step,
                            uint64_t* acc_out, int on_device);
 
+/* The whole accumulator chain of one PBS, as verified_pbs drives it (/root/reference/src/vtfhe/ivc_based_vpbs.rs:280-371):
+ *   step 0      first_step with mask = lwe_ct[n] (the body), acc_init = (0, .., 0, testv)
+ *   step 1..n   CMUX with bsk[x], mask = lwe_ct[x]
+ *   step n+1    last_step with the key-switching key (mask 0)
+ * lwe_ct: [n + 1]; bsk: [n][K*ELL*K*N] (NTT domain, Ggsw::flatten order); ksk: [K*ELL*K*N].  accs_out receives every
+ * intermediate accumulator, [n + 2][K][N] -- the `current accumulator` public inputs of the n + 2 step proofs (host memory). */
+int vpbs_pbs_accumulator_chain(vpbs_ctx* ctx, const vpbs_tfhe_params* params, unsigned n, const uint64_t* acc_init,
+                               const uint64_t* lwe_ct, const uint64_t* bsk, const uint64_t* ksk, uint64_t* accs_out);
+
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */
 /* on: 0 off, 1 every kernel group, 2 only the dominant kernel (leaf_hash) */
 int vpbs_timing_enable(vpbs_ctx* ctx, int on);

@@ -529,3 +529,25 @@ def test_blind_rotate_step_decrypts_like_the_reference_test(ctx, log_N, ELL, LOG
         out = ctx.blind_rotate_step(np.array([ct], dtype=np.uint64), [ai], T.flatten_ggsw(gg), K, ELL, LOGB)
         m_out = T.glwe_decrypt(ring, s, [[int(v) for v in out[0][p]] for p in range(K)], K)
         assert m_out == (m if bit == 0 else T.rotate(m, T.mod_switch(ai, log_N)))
+
+
+def test_pbs_accumulator_chain_end_to_end(ctx):
+    """the native side of src/main.rs:40-65 with noise-free keys: LWE encryption of a bit, the n + 2 accumulators on the
+    device (= the accumulator public inputs of the n + 2 step proofs), bit-exact against the oracle chain; decrypting the
+    key-switched output under the partial key gives the bit back."""
+    import tfhe_oracle as T
+    log_N, K, ELL, LOGB, n, p = 6, 2, 8, 8, 5, 2
+    ring = T.Ring(log_N)
+    s_to, s_lwe, s_glwe, bsk, ksk = T.pbs_setup(ring, rng, n, K, ELL, LOGB, p)
+    delta = T.get_delta(2 * p)
+    testv = T.get_testv(ring, p, delta)
+    acc_init = [[0] * ring.n for _ in range(K - 1)] + [testv]
+    for m in (0, 1):
+        ct = T.lwe_encrypt(rng, s_lwe, delta * m % P)
+        got = ctx.pbs_accumulator_chain(np.array(acc_init, np.uint64), ct, np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk), K, ELL, LOGB)
+        want = T.pbs_chain(ring, acc_init, ct, bsk, ksk, K, ELL, LOGB)
+        assert got.shape == (n + 2, K, ring.n)
+        for step_i in range(n + 2):
+            assert [[int(v) for v in got[step_i][q]] for q in range(K)] == want[step_i], step_i
+        m_bar = T.glwe_decrypt(ring, s_to, [[int(v) for v in got[-1][q]] for q in range(K)], K)[0]
+        assert round(m_bar / delta) % (2 * p) == m          # src/main.rs:59-65

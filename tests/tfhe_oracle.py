@@ -134,3 +134,49 @@ def ggsw_encrypt_hat(ring, rng, s, m, K, ELL, logb):
 
 def flatten_ggsw(ggsw_hat):
     return np.array([c for glev in ggsw_hat for glwe in glev for poly in glwe for c in poly], dtype=np.uint64)
+
+
+# ---- the PBS around the accumulator chain (src/main.rs:40-65, crypto/mod.rs:17-45, crypto/lwe.rs, crypto/ggsw.rs:38-48) ----
+def get_delta(two_p):
+    return P >> (two_p - 1).bit_length()          # F::order() >> log2_ceil(2p)
+
+
+def get_testv(ring, p, delta):
+    block = ring.n // p
+    coeffs = [i * delta % P for i in range(p) for _ in range(block)]
+    s = block // 2                                  # Poly::left_shift(block / 2): c[i] <- c[i+s], wrapped terms negated
+    return [coeffs[i + s] if i < ring.n - s else (P - coeffs[i - ring.n + s]) % P for i in range(ring.n)]
+
+
+def pbs_setup(ring, rng, n, K, ELL, logb, p=2):
+    """noise-free keys as main.rs builds them: partial key s_to (first n coefficients binary), LWE key = those
+    coefficients, GLWE key, bootstrapping key (NTT domain), key-switching key"""
+    s_to = [[int(v) for v in rng.integers(0, 2, size=n)] + [0] * (ring.n - n)] + [[0] * ring.n for _ in range(K - 1)]
+    s_lwe = s_to[0][:n]
+    s_glwe = [[int(v) for v in rng.integers(0, 2, size=ring.n)] for _ in range(K - 1)]
+    bsk = [ggsw_encrypt_hat(ring, rng, s_glwe, [si] + [0] * (ring.n - 1), K, ELL, logb) for si in s_lwe]
+    first = num_limbs(logb) - ELL
+    ksk = []
+    for i in range(K):                              # compute_ksk: GLEV i encrypts s_from[i] (i < K-1) or 1, under s_to
+        msg = s_glwe[i] if i < K - 1 else [1] + [0] * (ring.n - 1)
+        glev = []
+        for l in range(ELL):
+            scale = pow(2, logb * (first + l), P)
+            ct = glwe_encrypt(ring, rng, s_to, [x * scale % P for x in msg], K)
+            glev.append([ring.fw(poly) for poly in ct])
+        ksk.append(glev)
+    return s_to, s_lwe, s_glwe, bsk, ksk
+
+
+def lwe_encrypt(rng, s, m):
+    mask = [int(v) for v in rng.integers(0, P, size=len(s), dtype=np.uint64)]
+    return mask + [(sum(a * b for a, b in zip(mask, s)) + m) % P]
+
+
+def pbs_chain(ring, acc_init, ct, bsk, ksk, K, ELL, logb):
+    n = len(ct) - 1
+    accs = [step(ring, acc_init, ct[n], None, K, ELL, logb, first_step=True)]
+    for x in range(n):
+        accs.append(step(ring, accs[-1], ct[x], bsk[x], K, ELL, logb))
+    accs.append(step(ring, accs[-1], 0, ksk, K, ELL, logb, last_step=True))
+    return accs

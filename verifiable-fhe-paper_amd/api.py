@@ -112,6 +112,7 @@ SIGNATURES = {
     "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
+    "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -520,6 +521,18 @@ class Context:
         self._check(lib().vpbs_blind_rotate_step(self.h, C.byref(prm), B, acc.ctypes.data, m.ctypes.data,
                                                  g.ctypes.data if g is not None else None, per_instance, 1 if first_step else 0,
                                                  1 if last_step else 0, out.ctypes.data, 0))
+        return out
+
+    def pbs_accumulator_chain(self, acc_init, lwe_ct, bsk, ksk, K, ELL, LOGB):
+        """All n + 2 accumulators of one PBS (verified_pbs order): acc_init [K][N], lwe_ct [n+1], bsk [n][K*ELL*K*N], ksk."""
+        acc = _u64(acc_init)
+        K_, N = acc.shape
+        ct, b, k = _u64(lwe_ct).reshape(-1), _u64(bsk), _u64(ksk).reshape(-1)
+        n = ct.size - 1
+        assert K_ == K and b.shape == (n, K * ELL * K * N)
+        prm = TfheParamsC(N.bit_length() - 1, K, ELL, LOGB)
+        out = np.zeros((n + 2, K, N), np.uint64)
+        self._check(lib().vpbs_pbs_accumulator_chain(self.h, C.byref(prm), n, _ptr(acc), _ptr(ct), _ptr(b), _ptr(k), _ptr(out)))
         return out
 
     # ---- kernel-level hooks ----

@@ -600,6 +600,41 @@ int vpbs_blind_rotate_step(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigned ba
     });
 }
 
+int vpbs_pbs_accumulator_chain(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigned n_lwe, const uint64_t* acc_init, const uint64_t* lwe_ct,
+                               const uint64_t* bsk, const uint64_t* ksk, uint64_t* accs_out) {
+    if (!c || !prm || !acc_init || !lwe_ct || !bsk || !ksk || !accs_out || n_lwe == 0) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        const unsigned log_n = prm->log_N, K = prm->K, ELL = prm->ELL, LOGB = prm->LOGB;
+        VPBS_REQUIRE(log_n >= 1 && log_n <= 11 && K >= 1 && K <= 8 && LOGB >= 1 && LOGB <= 32, "unsupported TFHE parameters");
+        VPBS_REQUIRE(ELL >= 1 && ELL <= (64 + LOGB - 1) / LOGB, "ELL exceeds the number of limbs");
+        const size_t n = (size_t)1 << log_n;
+        VPBS_REQUIRE(ELL * n * sizeof(u64) <= 128 * 1024, "ELL * N does not fit the LDS budget");
+        const size_t acc_words = (size_t)K * n, ggsw_words = (size_t)K * ELL * K * n;
+        const u64* tab = c->ring_table(log_n);
+        const u64 ninv = gl::inv((u64)n);
+        // device: every accumulator of the chain (so each step reads its predecessor in place), masks in step order, keys
+        DevTemp accs(c, nullptr, (size_t)(n_lwe + 3) * acc_words), keys(c, bsk, (size_t)n_lwe * ggsw_words), kk(c, ksk, ggsw_words);
+        std::vector<u64> h_masks(n_lwe + 2);
+        h_masks[0] = lwe_ct[n_lwe];
+        for (unsigned x = 0; x < n_lwe; ++x) h_masks[1 + x] = lwe_ct[x];
+        h_masks[n_lwe + 1] = 0;
+        DevTemp masks(c, h_masks.data(), h_masks.size()), limbs(c, nullptr, (size_t)K * ELL * n);
+        VPBS_HIP(hipMemcpyAsync(accs.p, acc_init, sizeof(u64) * acc_words, hipMemcpyHostToDevice, c->stream));
+        {
+            vpbs::Timed t(c, "pbs_accumulator_chain");
+            for (unsigned step = 0; step < n_lwe + 2; ++step) {
+                const bool first = step == 0, last = step == n_lwe + 1;
+                const u64* ggsw = first ? nullptr : (last ? kk.p : keys.p + (size_t)(step - 1) * ggsw_words);
+                vpbs::launch_blind_rotate_step(c->stream, accs.p + (size_t)step * acc_words, masks.p + step, ggsw, 0, tab, tab + n, ninv, log_n, K,
+                                               ELL, LOGB, 1, first, last, limbs.p, accs.p + (size_t)(step + 1) * acc_words);
+            }
+        }
+        VPBS_HIP(hipGetLastError());
+        VPBS_HIP(hipMemcpyAsync(accs_out, accs.p + acc_words, sizeof(u64) * (size_t)(n_lwe + 2) * acc_words, hipMemcpyDeviceToHost, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
 // ---------------- timing ----------------
 int vpbs_timing_enable(vpbs_ctx* c, int on) {
     if (!c) return VPBS_ERR_INVALID;
