@@ -99,7 +99,7 @@ GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
 }
 
 // s <- MDS * s + k, where k = rc[k_off .. k_off+12) (k_off < 0: no constant).  s: any u64 residues.
-GL_HD void mds_add_const(u64* s, int k_off) {
+GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in registers (or nullptr) */) {
     u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 D8 = 8;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -117,7 +117,7 @@ GL_HD void mds_add_const(u64* s, int k_off) {
     }
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        u64 k = k_off >= 0 ? rc(k_off + r) : 0;
+        const u64 k = kc ? kc[r] : 0;
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -138,6 +138,11 @@ GL_HD void mds_add_const(u64* s, int k_off) {
 // inner S-box corrections) multiply-adds and 14 folds.  s: x1 on entry (round constants included), x1' on exit.
 GL_HD void partial_group3(u64* s, int g) {
     const PartialGroup& G = partial_group(g);
+    // request the group's constants before the first S-box (scalar-load latency hidden under it)
+    const u64 k2 = G.k2, k3 = G.k3;
+    u64 kv[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) kv[i] = G.kvec[i];
     s[0] = sbox(s[0]);
     u32 lo[12], hi[12];
 #pragma unroll
@@ -146,7 +151,7 @@ GL_HD void partial_group3(u64* s, int g) {
         hi[j] = (u32)(s[j] >> 32);
     }
     // x2_0 = (M y)[0] + c2[0]
-    u64 a_lo = (u32)G.k2, a_hi = G.k2 >> 32;
+    u64 a_lo = (u32)k2, a_hi = k2 >> 32;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         a_lo += (u64)lo[j] * MDS1[0][j];
@@ -156,7 +161,7 @@ GL_HD void partial_group3(u64* s, int g) {
     const u64 d2 = gl::sub(gl::canon(sbox(x2)), gl::canon(x2));
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
     // x3_0 = (M^2 y)[0] + M[0][0] d2 + (M c2)[0] + c3[0]
-    u64 b_lo = (u32)G.k3, b_hi = G.k3 >> 32;
+    u64 b_lo = (u32)k3, b_hi = k3 >> 32;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         b_lo += (u64)lo[j] * MDS2[0][j];
@@ -170,7 +175,7 @@ GL_HD void partial_group3(u64* s, int g) {
     // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        const u64 k = G.kvec[i];
+        const u64 k = kv[i];
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -187,19 +192,33 @@ GL_HD void partial_group3(u64* s, int g) {
 GL_HD void permute(u64* s) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_nc(s[i], rc(i));
+    // the next round's constants are requested (scalar loads) BEFORE the S-boxes so their latency hides under ~800
+    // instructions instead of parking the wave right in front of the MDS layer (17 % of wave cycles in the first version)
     for (int r = 0; r < HALF_FULL; ++r) {
+        u64 kc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(12 * (r + 1) + i);
 #pragma unroll
         for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
-        mds_add_const(s, 12 * (r + 1));
+        mds_add_const(s, kc);
     }
     // 22 partial rounds = 7 fused groups of 3 (rounds 4..24) + round 25
     for (int g = 0; g < 7; ++g) partial_group3(s, g);
-    s[0] = sbox(s[0]);
-    mds_add_const(s, 12 * (HALF_FULL + N_PARTIAL));
+    {
+        u64 kc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(12 * (HALF_FULL + N_PARTIAL) + i);
+        s[0] = sbox(s[0]);
+        mds_add_const(s, kc);
+    }
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; ++r) {
+        u64 kc[12];
+        const int next = r + 1 < N_ROUNDS ? 12 * (r + 1) : 0;  // the last round adds nothing (zeros selected below)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(next + i);
 #pragma unroll
         for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
-        mds_add_const(s, r + 1 < N_ROUNDS ? 12 * (r + 1) : -1);
+        mds_add_const(s, r + 1 < N_ROUNDS ? kc : nullptr);
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
