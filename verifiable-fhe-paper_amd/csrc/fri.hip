@@ -6,6 +6,7 @@
 // All of these are streaming passes over coefficient columns (HBM-bound).  Field arithmetic is exact, so the parallel
 // forms below (dot products with a power table, suffix-scan division) give the same canonical values as the
 // reference's sequential Horner loops.
+#define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
 
 namespace vpbs {

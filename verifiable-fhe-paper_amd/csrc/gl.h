@@ -81,29 +81,57 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 //   reduce : u = hi_lo * (2^32-1) + lo as ONE v_mad_u64_u32 with carry-out c; r = u - hi_hi with borrow b;
 //            r += (c - b) * (2^32 - 1)  -- neither correction can wrap a second time
 // 16 VALU + 2 SALU instead of the 26 VALU hipcc emits for the C form below.
+// Scratch registers of the single-product form.  A translation unit whose kernels need few registers of their own (the
+// NTT kernels) defines GL_ASM_SCRATCH_LOW before including this header: the scratch block then sits at v24..v31 instead
+// of v80..v87, so those kernels are not pushed from ~50 to 96 VGPRs (5 -> 8 waves per SIMD).
+#if defined(GL_ASM_SCRATCH_LOW)
+#define GL_R0 "v24"
+#define GL_R1 "v25"
+#define GL_R2 "v26"
+#define GL_R3 "v27"
+#define GL_R4 "v28"
+#define GL_R5 "v29"
+#define GL_R6 "v30"
+#define GL_R7 "v31"
+#define GL_P01 "v[24:25]"
+#define GL_P23 "v[26:27]"
+#define GL_P45 "v[28:29]"
+#else
+#define GL_R0 "v80"
+#define GL_R1 "v81"
+#define GL_R2 "v82"
+#define GL_R3 "v83"
+#define GL_R4 "v84"
+#define GL_R5 "v85"
+#define GL_R6 "v86"
+#define GL_R7 "v87"
+#define GL_P01 "v[80:81]"
+#define GL_P23 "v[82:83]"
+#define GL_P45 "v[84:85]"
+#endif
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     u32 r0, r1;
-    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
-        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
-        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
-        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
-        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
-        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
-        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
-        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
-        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
-        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+    asm("v_mad_u64_u32 " GL_P01 ", vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", s[80:81], %3, %4, " GL_P23 "\n\t"
+        "v_mad_u64_u32 " GL_P45 ", vcc, %3, %5, 0\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[80:81]\n\t"
+        "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R2 "\n\t"
+        "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_R3 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_R6 ", vcc\n\t"
+        "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
+        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
         "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
         "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
-        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
-        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
 // Two independent products with their instruction streams interleaved (second register set v88..v95 / s[86:91]): used

@@ -12,6 +12,7 @@
 // read from an HBM table of w^j (L2-resident: 128 KiB at n = 2^15).
 #include <cstdlib>
 
+#define GL_ASM_SCRATCH_LOW 1  // these kernels need ~40 VGPRs of their own: keep the asm scratch block low (occupancy)
 #include "kernels.h"
 
 namespace vpbs {

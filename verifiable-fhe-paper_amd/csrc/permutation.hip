@@ -9,6 +9,7 @@
 // chunk instead of a per-element batch inverse: same field element); Z(w^0) = 1, Z(w^(i+1)) = Z(w^i) prod_k c_k;
 // pp_k(i) = Z(w^i) c_0 .. c_k.  The running product over rows is a two-level multiplicative scan.  Streaming over the
 // wire and sigma columns (coalesced across rows); exact arithmetic => bit-identical to the sequential reference.
+#define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
 
 namespace vpbs {

@@ -9,6 +9,7 @@
 // One thread per LDE point: it reads the committed LDE columns of the routed wires, the sigmas and the Z / partial
 // products straight from the batches' HBM buffers (column-major, leaf order => coalesced), so nothing is downloaded
 // (the reference's get_lde_values path moves 283 MB per step through the host).  Streaming, ~180 columns x 8 B per point.
+#define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
 
 namespace vpbs {

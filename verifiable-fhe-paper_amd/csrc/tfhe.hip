@@ -6,6 +6,7 @@
 // native core of witness generation.  The negacyclic transform is the reference's
 // (crypto/poly.rs:9-64, tables per src/ntt/params_{N}.rs; pinned by TESTG/TESTGHAT).
 // One workgroup per (instance, polynomial); everything for a polynomial stays in LDS (ELL x N x 8 B <= 128 KiB).
+#define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
 
 namespace vpbs {
