@@ -28,7 +28,7 @@ def short(name):
 def one(pattern):
     files = glob.glob(pattern, recursive=True)
     assert files, pattern
-    return files[0]
+    return max(files, key=os.path.getmtime)   # gpurun merges runs into one directory: take the newest
 
 
 def counter_rows(d, counter):
