@@ -128,6 +128,66 @@ int vpbs_fri_prove(vpbs_ctx* ctx, vpbs_batch* const* oracles, size_t n_oracles, 
                    const vpbs_fri_params* params, vpbs_challenger_state* challenger /* inout */, uint64_t forced_pow,
                    uint64_t* proof_out);
 
+/* ---- gate constraints (plonky2 0.2.0 gates/ `eval_unfiltered`, gates/gate.rs `eval_filtered_base_batch` /
+ *      `compute_filter`, gates/selectors.rs `selector_polynomials`, plonk/vanishing_poly.rs
+ *      `evaluate_gate_constraints_base_batch`).  The gate types are the ones a circuit built with
+ *      CircuitBuilder + standard_recursion_config can contain (/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-157 builds the
+ *      step circuit from arithmetic, base-sum, Poseidon and the recursive-verifier gadgets).  Restated from the published
+ *      crate: wire layouts, constraint order and the id strings used for sorting are parity-unpinned (no golden circuit). */
+typedef enum {
+    VPBS_GATE_NOOP = 0,            /* NoopGate */
+    VPBS_GATE_CONSTANT,            /* ConstantGate { num_consts = p0 } */
+    VPBS_GATE_PUBLIC_INPUT,        /* PublicInputGate */
+    VPBS_GATE_ARITHMETIC,          /* ArithmeticGate { num_ops = p0 } */
+    VPBS_GATE_BASE_SUM,            /* BaseSumGate<B = p1> { num_limbs = p0 } */
+    VPBS_GATE_POSEIDON,            /* PoseidonGate */
+    VPBS_GATE_POSEIDON_MDS,        /* PoseidonMdsGate */
+    VPBS_GATE_ARITHMETIC_EXT,      /* ArithmeticExtensionGate { num_ops = p0 } */
+    VPBS_GATE_MUL_EXT,             /* MulExtensionGate { num_ops = p0 } */
+    VPBS_GATE_REDUCING,            /* ReducingGate { num_coeffs = p0 } */
+    VPBS_GATE_REDUCING_EXT,        /* ReducingExtensionGate { num_coeffs = p0 } */
+    VPBS_GATE_RANDOM_ACCESS,       /* RandomAccessGate { bits = p0, num_copies = p1, num_extra_constants = p2 } */
+    VPBS_GATE_EXPONENTIATION,      /* ExponentiationGate { num_power_bits = p0 } */
+    VPBS_GATE_COSET_INTERPOLATION, /* CosetInterpolationGate { subgroup_bits = p0, degree = p1 } */
+    VPBS_GATE_KINDS
+} vpbs_gate_kind;
+typedef struct {
+    unsigned kind, p0, p1, p2;        /* set by the caller */
+    /* filled by vpbs_gates_layout: */
+    unsigned degree, num_constraints, num_constants, num_wires;
+    unsigned selector_index;          /* which selector polynomial (leading constants column) carries this gate */
+    unsigned group_start, group_end;  /* the selector group [start, end) of sorted gate indices */
+    unsigned index;                   /* position in the sorted gate list = the selector's value on this gate's rows */
+} vpbs_gate;
+#define VPBS_UNUSED_SELECTOR 0xFFFFFFFFu
+/* Fills the derived fields with the standard parameters of CircuitConfig::standard_recursion_config (135 wires, 80
+ * routed, 2 constants) when p0 == 0:  *_from_config constructors.  */
+int vpbs_gate_default_params(vpbs_gate* gate);
+/* CircuitBuilder::build's gate ordering + selectors.rs selector_polynomials: sorts `gates` by (degree, id), groups them
+ * greedily so that group size + gate degree <= max_degree, assigns selector_index / group / index.  max_degree is
+ * quotient_degree_factor + 1 (9 under standard_recursion_config), as CircuitBuilder::build passes it.  Outputs the number
+ * of selector polynomials and max over gates of num_constraints (CommonCircuitData::num_gate_constraints). */
+int vpbs_gates_layout(vpbs_gate* gates, unsigned n_gates, unsigned max_degree, unsigned* num_selectors,
+                      unsigned* num_gate_constraints);
+/* Gate::id() (the Debug string plonky2 sorts by); returns the length or < 0 */
+int vpbs_gate_id(const vpbs_gate* gate, char* buf, size_t len);
+/* = evaluate_gate_constraints_base_batch folded with the alphas: for every point x of the LDE coset (leaf order) and
+ * every challenge a, d_out[a][x] = sum_i alpha_a^i * sum_g filter_g(x) * constraint_{g,i}(x).  Reads the committed LDEs in
+ * HBM: selectors = constants_sigmas columns [0, num_selectors), gate constants = columns [num_selectors, ..).
+ * d_out: device, [num_challenges][local LDE length of the batches].  Feed it to vpbs_quotient_permutation. */
+int vpbs_gate_terms(vpbs_ctx* ctx, vpbs_batch* constants_sigmas, vpbs_batch* wires, const vpbs_gate* gates, unsigned n_gates,
+                    unsigned num_selectors, const uint64_t public_inputs_hash[4], const uint64_t* alphas,
+                    unsigned num_challenges, uint64_t* d_out);
+/* the same sum at one extension point (verifier side, host only, gates/gate.rs eval_filtered): constants [..][2] are the
+ * openings of the constants columns (selectors first), wires [..][2] the wire openings; out [num_challenges][2] */
+int vpbs_gate_terms_at(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, const uint64_t* constants_at,
+                       unsigned n_constants, const uint64_t* wires_at, unsigned n_wires, const uint64_t public_inputs_hash[4],
+                       const uint64_t* alphas, unsigned num_challenges, uint64_t* out);
+/* Witness rows (iop/generator.rs SimpleGenerator::run_once of each gate): given the gate's free
+ * inputs already present in `row` ([num_wires], one trace row) fills the wires the gate's generators own (outputs,
+ * S-box inputs, limbs, intermediate accumulators ...).  constants: the gate constants of that row.  Host only. */
+int vpbs_gate_fill_row(const vpbs_gate* gate, const uint64_t* constants, uint64_t* row);
+
 /* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
 typedef struct {
     unsigned log_n;                   /* degree_bits: 15 for N=1024, 12 for N=8 */
@@ -152,6 +212,10 @@ typedef struct {
     unsigned n_routed;                /* 80: config.num_routed_wires */
     unsigned quotient_degree_factor;  /* 8: chunk size of the partial products */
     unsigned n_constants;             /* leading columns of constants_sigmas that are not sigmas (quotient on device) */
+    /* gate constraints of the circuit (quotient on device only): NULL / 0 = none (permutation argument only) */
+    const vpbs_gate* gates;           /* laid out by vpbs_gates_layout */
+    unsigned n_gates;
+    unsigned num_selectors;           /* leading constants columns that are selector polynomials */
 } vpbs_step_inputs;
 
 /* Collectives for a step proof sharded over the GPUs of one node: supplied by the host, so the library
@@ -244,7 +308,9 @@ typedef struct {
     size_t n_public_inputs;
     int check_permutation;                  /* 0: FRI / transcript only */
     unsigned n_constants, n_routed, quotient_degree_factor;
-    const uint64_t* gate_terms_zeta;        /* [num_challenges][2] or NULL */
+    const uint64_t* gate_terms_zeta;        /* [num_challenges][2] or NULL (ignored when gates != NULL) */
+    const vpbs_gate* gates;                 /* the circuit's gates: their constraints are evaluated at zeta from the openings */
+    unsigned n_gates, num_selectors;
 } vpbs_verify_inputs;
 /* returns 1 = proof accepted, 0 = rejected, < 0 = malformed arguments */
 int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][cap] */, const uint64_t* openings,

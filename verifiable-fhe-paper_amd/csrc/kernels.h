@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gl.h"
+#include "../../include/vpbs_prover.h"
 
 namespace vpbs {
 using gl::u32;
@@ -52,6 +53,18 @@ void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigm
 // phase 2: q_gathered is rank-major [world][nc][local_len] (world * local_len = 8n); q_nat, scratch: [nc][8n]
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
                             unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs);
+
+// ---------- gates.hip ----------
+// evaluate_gate_constraints_base_batch folded with the alphas: d_out[a][j] = sum_i alpha_a^i sum_g filter_g(j) c_{g,i}(j) for the
+// `len` local leaves of the wires / constants LDEs (column stride len).  d_apow: [nc][pow_stride] powers of the alphas,
+// pow_stride >= max num_constraints.  gates: laid out by vpbs_gates_layout (host array).
+void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
+                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out);
+// throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
+void validate_gates(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned n_constants_cols, unsigned n_wires);
+// host, GF(p^2): the same folded sum at one point from openings ([..][2] arrays); out [nc][2]
+void gate_terms_at(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, const u64* constants_at, unsigned n_constants,
+                   const u64* wires_at, unsigned n_wires, const u64 pi_hash[4], const u64* alphas, unsigned nc, u64* out);
 
 // ---------- tfhe.hip ----------
 // One step of the verifiable PBS on `batch` independent accumulators (reference ivc_based_vpbs.rs:99-125): acc [batch][K][N],

@@ -333,6 +333,37 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
     VPBS_REQUIRE(flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
 }
 
+// evaluate_gate_constraints_base_batch folded with the alphas, on the device; d_out: [nc][local LDE length]
+void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors,
+                       const u64 pi_hash[4], const u64* alphas, unsigned nc, u64* d_out) {
+    VPBS_REQUIRE(cs && wires && cs->ctx == ctx && wires->ctx == ctx, "batches of another context");
+    VPBS_REQUIRE(cs->log_n == wires->log_n && cs->n_shards == wires->n_shards && cs->shard == wires->shard, "gate terms: batches differ in shape");
+    VPBS_REQUIRE(nc >= 1 && nc <= 4, "unsupported number of challenges");
+    vpbs::validate_gates(gs, n_gates, num_selectors, cs->ncols, wires->ncols);
+    unsigned stride = 1;
+    for (unsigned i = 0; i < n_gates; ++i) stride = std::max(stride, gs[i].num_constraints);
+    std::vector<u64> h_apow((size_t)nc * stride);
+    for (unsigned a = 0; a < nc; ++a) {
+        u64 p = 1;
+        for (unsigned i = 0; i < stride; ++i) {
+            h_apow[(size_t)a * stride + i] = p;
+            p = gl::mul(p, alphas[a]);
+        }
+    }
+    u64* d_apow = ctx->alloc_words(h_apow.size());
+    try {
+        VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
+        Timed t(ctx, "gate_constraints");
+        vpbs::launch_gate_terms(ctx->stream, wires->d_lde, cs->d_lde, wires->lde_len(), gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, d_out);
+        VPBS_HIP(hipGetLastError());
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->release(d_apow);
+        throw;
+    }
+    ctx->release(d_apow);
+}
+
 // compute_quotient_polys (permutation part) on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks
 void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constants, vpbs_batch* wires, vpbs_batch* zs_pp,
                                  unsigned n_routed, const u64* betas, const u64* gammas, const u64* alphas, unsigned nc,
@@ -539,6 +570,12 @@ int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constant
     });
 }
 
+int vpbs_gate_terms(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors,
+                    const uint64_t pi_hash[4], const uint64_t* alphas, unsigned nc, uint64_t* d_out) {
+    if (!ctx || !cs || !wires || !gates || !pi_hash || !alphas || !d_out) return VPBS_ERR_INVALID;
+    return guarded(ctx, [&] { gate_terms_device(ctx, cs, wires, gates, n_gates, num_selectors, pi_hash, alphas, nc, d_out); });
+}
+
 int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out) {
     if (!ctx || !in || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
     const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
@@ -621,13 +658,20 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         zs_pp.merkle_cap(caps_out + cap_words, comm);
         challenger.observe_cap(caps_out + cap_words, cap_words / 4);
         const std::vector<u64> alphas = challenger.get_n_challenges(nc);
-        // compute_quotient_polys(alphas): supplied coefficient chunks, or evaluated on the device for the permutation
-        // argument (the gate-constraint terms of the step circuit are a host stage)
+        // compute_quotient_polys(alphas): supplied coefficient chunks, or evaluated on the device (permutation argument +
+        // the gate constraints of in->gates)
         if (!d_quot) {
             u64* d_q = ctx->alloc_words((size_t)in->n_quotient * n);
             staged.push_back(d_q);
+            u64* d_gate = nullptr;
+            if (in->gates && in->n_gates) {  // evaluate_gate_constraints_base_batch for the circuit's gate set
+                VPBS_REQUIRE(in->num_selectors <= in->n_constants, "selector columns must be leading constants columns");
+                d_gate = ctx->alloc_words((size_t)nc * wires.h->lde_len());
+                staged.push_back(d_gate);
+                gate_terms_device(ctx, in->constants_sigmas, wires.h, in->gates, in->n_gates, in->num_selectors, pi_hash.data(), alphas.data(), nc, d_gate);
+            }
             quotient_permutation_device(ctx, in->constants_sigmas, in->n_constants, wires.h, zs_pp.h, in->n_routed, betas.data(),
-                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, nullptr, d_q, comm);
+                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, d_gate, d_q, comm);
             d_quot = d_q;
         }
         PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);

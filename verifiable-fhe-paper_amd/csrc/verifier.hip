@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "host/plonky2_mirror.h"
+#include "kernels.h"
 #include "poseidon.h"
 
 using gl::Ext;
@@ -62,7 +63,7 @@ Ext interpolate(const u64* xs, const Ext* ys, size_t k, Ext t) {
 }
 
 bool check_permutation_identity(const vpbs_verify_inputs* in, const u64* openings, const u64* betas, const u64* gammas,
-                                const u64* alphas, Ext zeta) {
+                                const u64* alphas, Ext zeta, const u64* gate_terms_zeta) {
     const unsigned nc = in->num_challenges, n_routed = in->n_routed, deg = in->quotient_degree_factor;
     const unsigned n_chunks = (n_routed + deg - 1) / deg, num_prods = n_chunks - 1;
     const size_t n = (size_t)1 << in->log_n;
@@ -98,7 +99,7 @@ bool check_permutation_identity(const vpbs_verify_inputs* in, const u64* opening
     }
     const unsigned chunks_per = 1u << in->rate_bits;
     for (unsigned a = 0; a < nc; ++a) {
-        Ext acc = in->gate_terms_zeta ? ext_at(in->gate_terms_zeta, a) : gl::ext(0);
+        Ext acc = gate_terms_zeta ? ext_at(gate_terms_zeta, a) : gl::ext(0);
         for (size_t i = terms.size(); i-- > 0;) acc = gl::add(gl::mul(acc, alphas[a]), terms[i]);  // reduce_with_powers
         Ext q = gl::ext(0);
         for (unsigned m = chunks_per; m-- > 0;) q = gl::add(gl::mul(q, zeta_n), ext_at(quot_z, a * chunks_per + m));
@@ -144,7 +145,23 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     ch.observe_cap(caps + 2 * cap_words, cap_words / 4);
     const Ext zeta = ch.get_extension_challenge();
     ch.observe_elements(openings, 2 * (total_cols + nc));
-    if (in->check_permutation && !check_permutation_identity(in, openings, betas.data(), gammas.data(), alphas.data(), zeta)) return 0;
+    if (in->check_permutation) {
+        // eval_vanishing_poly: the gate constraints at zeta come from the openings of the constants and the wires
+        const u64* gate_terms = in->gate_terms_zeta;
+        std::vector<u64> gt(2 * (size_t)nc);
+        if (in->gates && in->n_gates) {
+            if (in->num_selectors > in->n_constants) return VPBS_ERR_INVALID;
+            try {
+                vpbs::validate_gates(in->gates, in->n_gates, in->num_selectors, in->n_constants, in->n_wires);
+            } catch (const vpbs::DeviceError&) {
+                return VPBS_ERR_INVALID;
+            }
+            vpbs::gate_terms_at(in->gates, in->n_gates, in->num_selectors, openings, in->n_constants, openings + 2 * (size_t)in->n_constants_sigmas,
+                                in->n_wires, pi_hash.data(), alphas.data(), nc, gt.data());
+            gate_terms = gt.data();
+        }
+        if (!check_permutation_identity(in, openings, betas.data(), gammas.data(), alphas.data(), zeta, gate_terms)) return 0;
+    }
 
     // ---- FRI challenges ----
     const Ext fri_alpha = ch.get_extension_challenge();
