@@ -3,11 +3,11 @@
 
 A "step" = one step proof of the vPBS IVC chain on the 2^15-row, 135-wire plonky2 circuit (BASELINE config 2:
 commit wires / Z+partial-products / quotient chunks -> openings -> FRI, Fiat-Shamir transcript included) with the
-inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  The
-witness generation and the gate-constraint terms of the quotient are host stages of plonky2's prove() outside this round's hot path
- and are NOT inside the timed region -- `config.stages` says so explicitly.  The permutation-argument
-partial products (row a12) and the permutation part of the quotient polynomials (row a13: everything but the gate
-constraint terms) ARE computed inside the step, on the GPU.
+inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  Witness
+generation is a host stage of plonky2's prove() outside this round's hot path and is NOT inside the timed
+region -- `config.stages` says so explicitly.  The permutation-argument partial products (row a12) and the quotient
+polynomials (row a13: permutation argument + the constraints of all 14 gate types of a standard_recursion_config
+circuit, over random columns -- the cost is data-independent) ARE computed inside the step, on the GPU.
 
 Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode).
 Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: under torch.distributed.run, one rank per GPU)
@@ -30,8 +30,12 @@ from vpbs_amd import synth  # noqa: E402
 
 STEPS_PER_VPBS = 730       # n + 2 with n = 728 (reference src/main.rs:27, ivc_based_vpbs.rs:433-436)
 LOG_N = 15                 # degree of the step circuit at N = 1024 (ivc_based_vpbs.rs:57)
-COLS = synth.STEP_COLS
-N_CONSTANTS, N_ROUTED = 5, 80   # constants_sigmas = 5 selector/constant columns + 80 sigma columns (standard_recursion_config)
+# the gate set of a recursive plonky2 circuit under standard_recursion_config (ivc_based_vpbs.rs:80-157 builds the step circuit from
+# arithmetic / base-sum / Poseidon gadgets and a recursive verifier); selector_polynomials gives it 4 selector columns
+GATES = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext", "reducing",
+         "reducing_ext", ("random_access", 4), "exponentiation", "coset_interpolation"]
+N_CONSTANTS, N_ROUTED = 6, 80   # constants_sigmas = 4 selectors + 2 gate constants + 80 sigma columns
+COLS = dict(synth.STEP_COLS, constants_sigmas=N_CONSTANTS + N_ROUTED)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
@@ -53,22 +57,24 @@ def leaf_hash_perms_per_step():
 def cpu_baseline():
     """One full step proof on the host cores with the CPU oracle (kind 'port': restated algorithm, OpenMP)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gates_oracle
     import oracle as orc
     import step_oracle
     orc.build()
-    inputs = synth.step_inputs(LOG_N)
+    inputs = synth.step_inputs(LOG_N, cols=COLS)
     pis = synth.field_elements(0xABCD, 77)
     digest = np.array([11, 22, 33, 44], np.uint64)
     cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)   # committed once per circuit: untimed
     t0 = time.time()
     sig = np.ascontiguousarray(inputs["constants_sigmas"][N_CONSTANTS:N_CONSTANTS + N_ROUTED])
     inputs["quotient"] = None   # quotient chunks evaluated (permutation-argument constraints), like the GPU step
-    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS)
+    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS,
+                           gates=gates_oracle.GateSet(GATES))
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs, partial products included) with "
-                      "the C oracle, OpenMP on all host cores",
+            "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
+                      "and quotient included) with the C oracle, OpenMP on all host cores",
             "note": "scalar restatement (naive Poseidon, ~8 us per permutation per core; PoW and Merkle top levels serial); "
                     "plonky2's own AVX2 Poseidon is roughly an order of magnitude faster per core -- a reported baseline, "
                     "not a tuned CPU prover"}
@@ -119,12 +125,14 @@ def main():
                                   stage_words=(2 << (args.log_n + 3)) // world, stage_device=torch.device("cuda", local_rank))
     n_chains = 1 if sharded else max(1, args.chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
+    gates = vpbs_amd.api.GateSet(GATES)
+    assert gates.num_selectors + gates.num_constants == N_CONSTANTS
     ctxs, sis, keep = [], [], []
     for c in range(n_chains):
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)
         # chain c of rank r proves its own seeded instance
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
-        inputs = synth.step_inputs(log_n, instance=inst)
+        inputs = synth.step_inputs(log_n, instance=inst, cols=COLS)
         dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
         quot_ptr = None   # quotient chunks are evaluated on the device (sharded: values all-gathered between the GPUs)
         if sharded:
@@ -136,7 +144,7 @@ def main():
         sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
         si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, quot_ptr, cs, digest, pis,
                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
-                                  sigmas=sig_ptr, n_routed=N_ROUTED, n_constants=N_CONSTANTS)
+                                  sigmas=sig_ptr, n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates)
         ctxs.append(ctx); sis.append(si); keep.append((dev, cs, pis))
     torch.cuda.synchronize()
 
@@ -188,14 +196,14 @@ def main():
         extra = []
         for c in range(1, args.batch_chains):
             cx = vpbs_amd.Context(local_rank, log_n_max=16)
-            inp = synth.step_inputs(log_n, instance=c)
+            inp = synth.step_inputs(log_n, instance=c, cols=COLS)
             dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
             csb = cx.commit_values(inp["constants_sigmas"])
             pi2 = synth.field_elements(0xABCD + c, 77)
             sp = dv["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)
             extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, None, csb, digest, pi2,
                                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
-                                                  sigmas=sp, n_routed=N_ROUTED, n_constants=N_CONSTANTS), dv, csb, pi2))
+                                                  sigmas=sp, n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates), dv, csb, pi2))
         ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
         n_chains = len(ctxs)
         run_steps(1)
@@ -243,16 +251,14 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
             "data": "synthetic", "step_proofs_per_s": step_rate, "steps_per_vpbs_proof": STEPS_PER_VPBS,
             "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
-                                   "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, 85 constant/sigma "
-                                   "columns precommitted; inputs resident in HBM" % (log_n, log_n + 3),
+                                   "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, %d constant/sigma "
+                                   "columns precommitted; inputs resident in HBM" % (log_n, log_n + 3, COLS["constants_sigmas"]),
                        "stages": "wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> permutation Z + partial "
-                                 "products (GPU) -> commit -> alphas -> quotient polynomials (GPU: vanishing terms of the "
-                                 "permutation argument over the 2^18 coset, / Z_H, coset iNTT, 16 chunks) -> commit -> zeta -> "
-                                 "openings at zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit PoW, 28 queries), "
-                                 "Fiat-Shamir transcript included.  NOT in the timed region (host stages of plonky2's prove(), "
-                                 "SURVEY.md 8f): witness generation and the gate-constraint terms of the quotient (the ~15 gate "
-                                 "types of the step circuit; the quotient kernel accepts them as a pre-folded input)"
-,
+                                 "products (GPU) -> commit -> alphas -> quotient polynomials (GPU: constraints of %d gate types with "
+                                 "their selector filters + the permutation argument over the 2^18 coset, / Z_H, coset iNTT, 16 "
+                                 "chunks) -> commit -> zeta -> openings at zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit "
+                                 "PoW, 28 queries), Fiat-Shamir transcript included.  NOT in the timed region (host stage of "
+                                 "plonky2's prove(), SURVEY.md 8f-2): witness generation" % gates.n,
                        "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
                                        "hashes, 1 device all-gather of quotient values (4 MiB) + 1 all-reduce of query records (%s)"
                                        % (world, args.dist_backend)) if sharded else

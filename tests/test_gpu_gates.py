@@ -148,8 +148,7 @@ def test_gate_terms_full_size_spot_check(ctx):
     cs, wb = ctx.commit_values(consts), ctx.commit_values(wires)
     got = _device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas)   # leaf order
     for leaf in (0, 1, 77777, (1 << 18) - 1, 131072):
-        c_row = cs.lde_rows(leaf, 1)[0]
-        w_row = wb.lde_rows(leaf, 1)[0]
+        c_row, w_row = cs.open(leaf)[0], wb.open(leaf)[0]   # MerkleTree::get: the LDE row at this leaf index
         cz = np.stack([c_row, np.zeros_like(c_row)], axis=1)
         wz = np.stack([w_row, np.zeros_like(w_row)], axis=1)
         want = gs.terms_zeta(cz, wz, pi_hash, alphas)
