@@ -31,7 +31,15 @@ template <> struct Fld<u64> {
 template <> struct Fld<Ext> {
     static GL_HD Ext lift(u64 c) { return gl::ext(c); }
 };
-GL_HD u64 mulc(u64 a, u64 c) { return gl::mul(a, c); }  // field element times a base-field constant
+// field element times a base-field constant.  On the GPU a constant below 2^32 (MDS entries, 7, bases, weights are NOT) takes
+// two multiply-adds and one fold instead of a full modular multiplication.
+GL_HD u64 mulc(u64 a, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_constant_p(c) && c < (1ull << 26))
+        return gl::canon(poseidon::fold96((u64)(u32)a * (u32)c, (u64)(u32)(a >> 32) * (u32)c));
+#endif
+    return gl::mul(a, c);
+}
 GL_HD Ext mulc(Ext a, u64 c) { return gl::mul(a, c); }
 
 // a + b X, X^2 = 7 over F: QuadraticExtension (F = base) or ExtensionAlgebra<F::Extension, 2> (F = GF(p^2))
@@ -104,6 +112,7 @@ template <class F, class V, class S> GATES_FN void eval_public_input(const vpbs_
 // gates/arithmetic_base.rs: output - (m0 m1 c0 + addend c1), wires 4i .. 4i+3
 template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_gate& g, const V& v, S& s) {
     const F c0 = v.constant(0), c1 = v.constant(1);
+#pragma unroll 4
     for (unsigned i = 0; i < g.p0; ++i) {
         const F m0 = v.wire(4 * i), m1 = v.wire(4 * i + 1), addend = v.wire(4 * i + 2), out = v.wire(4 * i + 3);
         s.push(gl::sub(out, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(addend, c1))));
@@ -112,14 +121,31 @@ template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_ga
 // gates/base_sum.rs: reduce_with_powers(limbs, B) - sum; then prod_{k < B} (limb - k) per limb
 template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate& g, const V& v, S& s) {
     const unsigned n = g.p0, B = g.p1;
+    // limbs are read in batches of 8 so that the loads of a batch are in flight together (the GPU thread is otherwise bound by
+    // one memory latency per limb)
     F acc = Fld<F>::lift(0);
-    for (unsigned i = n; i-- > 0;) acc = gl::add(mulc(acc, B), v.wire(1 + i));
+    for (unsigned hi = n; hi > 0;) {
+        const unsigned lo = hi >= 8 ? hi - 8 : 0;
+        F l[8];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) l[u] = lo + u < hi ? v.wire(1 + lo + u) : Fld<F>::lift(0);
+#pragma unroll
+        for (unsigned u = 8; u-- > 0;)
+            if (lo + u < hi) acc = gl::add(mulc(acc, B), l[u]);
+        hi = lo;
+    }
     s.push(gl::sub(acc, v.wire(0)));
-    for (unsigned i = 0; i < n; ++i) {
-        const F limb = v.wire(1 + i);
-        F prod = limb;
-        for (unsigned k = 1; k < B; ++k) prod = gl::mul(prod, gl::sub(limb, Fld<F>::lift(k)));
-        s.push(prod);
+    for (unsigned i0 = 0; i0 < n; i0 += 8) {
+        F l[8];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) l[u] = i0 + u < n ? v.wire(1 + i0 + u) : Fld<F>::lift(0);
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) {
+            if (i0 + u >= n) break;
+            F prod = l[u];
+            for (unsigned k = 1; k < B; ++k) prod = gl::mul(prod, gl::sub(l[u], Fld<F>::lift(k)));
+            s.push(prod);
+        }
     }
 }
 // gates/poseidon.rs.  Wires: input 0..12, output 12..24, swap 24, delta 25..29, full_sbox_0(r=1..3) 29.., partial_sbox
@@ -193,6 +219,7 @@ template <class F, class V, class S> GATES_FN void eval_poseidon_mds(const vpbs_
 // gates/arithmetic_extension.rs: wires 8i: m0, m1, addend, output (2 each)
 template <class F, class V, class S> GATES_FN void eval_arithmetic_ext(const vpbs_gate& g, const V& v, S& s) {
     const F c0 = v.constant(0), c1 = v.constant(1);
+#pragma unroll 2
     for (unsigned i = 0; i < g.p0; ++i) {
         const Alg<F> m0 = wire_alg<F>(v, 8 * i), m1 = wire_alg<F>(v, 8 * i + 2), addend = wire_alg<F>(v, 8 * i + 4),
                      out = wire_alg<F>(v, 8 * i + 6);
@@ -202,6 +229,7 @@ template <class F, class V, class S> GATES_FN void eval_arithmetic_ext(const vpb
 // gates/multiplication_extension.rs: wires 6i: m0, m1, output
 template <class F, class V, class S> GATES_FN void eval_mul_ext(const vpbs_gate& g, const V& v, S& s) {
     const F c0 = v.constant(0);
+#pragma unroll 2
     for (unsigned i = 0; i < g.p0; ++i) {
         const Alg<F> m0 = wire_alg<F>(v, 6 * i), m1 = wire_alg<F>(v, 6 * i + 2), out = wire_alg<F>(v, 6 * i + 4);
         push_alg(s, out - scale(m0 * m1, c0));
@@ -212,6 +240,7 @@ template <class F, class V, class S> GATES_FN void eval_reducing(const vpbs_gate
     const unsigned n = g.p0;
     const Alg<F> alpha = wire_alg<F>(v, 2);
     Alg<F> acc = wire_alg<F>(v, 4);
+#pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + n + 2 * i);
         Alg<F> c = acc * alpha;
@@ -225,6 +254,7 @@ template <class F, class V, class S> GATES_FN void eval_reducing_ext(const vpbs_
     const unsigned n = g.p0;
     const Alg<F> alpha = wire_alg<F>(v, 2);
     Alg<F> acc = wire_alg<F>(v, 4);
+#pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + 2 * n + 2 * i);
         push_alg(s, acc * alpha + wire_alg<F>(v, 6 + 2 * i) - next);
@@ -277,6 +307,7 @@ template <class F, class V, class S> GATES_FN void eval_exponentiation(const vpb
     const unsigned n = g.p0;
     const F base = v.wire(0), one = Fld<F>::lift(1);
     F prev = one;
+#pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const F sq = i == 0 ? one : gl::mul(prev, prev);
         const F bit = v.wire(1 + (n - 1 - i));
@@ -295,6 +326,7 @@ struct CosetTables {
 };
 template <class F, class V>
 GL_HD void partial_interpolate(const CosetTables& t, const V& v, unsigned from, unsigned to, Alg<F> x, Alg<F>& eval, Alg<F>& prod) {
+#pragma unroll 4
     for (unsigned i = from; i < to; ++i) {
         const Alg<F> val = scalec(wire_alg<F>(v, 1 + 2 * i), t.weights[i]);
         const Alg<F> term = sub_base(x, t.domain[i]);

@@ -10,6 +10,7 @@
 // into out[challenge][point].  The constraints of different gates share constraint indices (plonky2 adds them: at most one
 // filter is non-zero on a trace row), hence the accumulation.  HBM traffic: each gate reads only its own wires once.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,25 +35,149 @@ struct DevVars {
     __device__ __forceinline__ u64 constant(unsigned i) const { return consts[(size_t)i * stride + j]; }
     __device__ __forceinline__ u64 pi_hash(unsigned i) const { return pih.h[i]; }
 };
-struct DevSink {
+// reduce_with_powers over the constraints, with the reduction mod p deferred to the end of the gate: the four 32x32
+// partial products of constraint * alpha^i are accumulated with v_mad_u64_u32 into three 64-bit lanes at bit offsets 0 / 32 /
+// 64 (carries counted on the side), 8-12 instructions per (constraint, challenge) instead of a full modular multiply-add.
+struct LazyAcc {
+    u64 e, m, h;      // sum of c0*a0 | c0*a1 + c1*a0 | c1*a1   (mod 2^64 each)
+    u32 ce, cm, ch;   // wrap-arounds of e, m, h
+    __device__ __forceinline__ void mac(u32 c0, u32 c1, u32 a0, u32 a1) {
+        // a0 / a1 (halves of a power of alpha) are wave-uniform: scalar operands
+        asm("v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %7, %8, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\t"
+            "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc"
+            : "+v"(e), "+v"(m), "+v"(h), "+v"(ce), "+v"(cm), "+v"(ch)
+            : "v"(c0), "v"(c1), "s"(a0), "s"(a1)
+            : "vcc");
+    }
+    // e + 2^32 m + 2^64 h + 2^64 ce + 2^96 cm + 2^128 ch  (mod p), canonical;  2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32
+    __device__ __forceinline__ u64 reduce() const {
+        u64 r = gl::canon(gl::reduce128_nc(e, h));                                   // e + 2^64 h
+        r = gl::add(r, gl::canon(gl::reduce128_nc(m << 32, m >> 32)));               // 2^32 m
+        r = gl::add(r, gl::mul((u64)ce, gl::EPS));
+        r = gl::sub(r, (u64)cm);
+        r = gl::sub(r, gl::canon((u64)ch << 32));
+        return r;
+    }
+};
+template <int NC> struct DevSinkT {
     const u64* apow;  // [nc][pow_stride]
     unsigned pow_stride, nc, idx;
-    u64 acc[4];
+    LazyAcc acc[NC];
     __device__ __forceinline__ void push(u64 c) {
+        const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if ((unsigned)a < nc) acc[a] = gl::add(acc[a], gl::mul(c, apow[a * pow_stride + idx]));
+        for (int a = 0; a < NC; ++a)
+            if ((unsigned)a < nc) {
+                const u64 p = apow[a * pow_stride + idx];
+                acc[a].mac(c0, c1, (u32)p, (u32)(p >> 32));
+            }
         ++idx;
     }
 };
 
-template <unsigned KIND> __device__ __forceinline__ void eval_kind(const vpbs_gate& g, const gates::CosetTables& t, const DevVars& v, DevSink& s) {
+// PoseidonMdsGate on the GPU: the MDS acts on the two components of the algebra elements separately, so it is two runs of the
+// hashing kernels' multiply-add MDS layer (poseidon.h) instead of 2 x 156 modular multiplications by MDS entries.
+template <class DevSink> __device__ __forceinline__ void poseidon_mds_dev(const DevVars& v, DevSink& s) {
+    u64 a[12], b[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        a[i] = v.wire(2 * i);
+        b[i] = v.wire(2 * i + 1);
+    }
+    poseidon::mds_add_const(a, nullptr);
+    poseidon::mds_add_const(b, nullptr);
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        s.push(gl::sub(v.wire(24 + 2 * r), gl::canon(a[r])));
+        s.push(gl::sub(v.wire(25 + 2 * r), gl::canon(b[r])));
+    }
+}
+
+// PoseidonGate on the GPU (same constraints, same order as gates::eval_poseidon): the hashing kernels' round functions with the
+// S-box inputs swapped for the gate's wires -- paired S-boxes, multiply-add MDS with the next round's constants folded in, and the
+// 22 partial rounds as 7 fused groups of three (one dense M^3 pass per group, poseidon.h) + 1.
+template <class DevSink> __device__ __forceinline__ void poseidon_gate_dev(const DevVars& v, DevSink& s) {
+    using poseidon::rc;
+    const u64 swap = v.wire(24);
+    s.push(gl::mul(swap, gl::sub(swap, 1)));
+    u64 st[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u64 lhs = v.wire(i), rhs = v.wire(i + 4), delta = v.wire(25 + i);
+        s.push(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+        st[i] = gl::add(lhs, delta);
+        st[i + 4] = gl::sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; ++i) st[i] = v.wire(i);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], rc(i));
+    for (int r = 0; r < 4; ++r) {  // first full rounds (round index r)
+        u64 kc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(12 * (r + 1) + i);
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const u64 in = v.wire(29 + 12 * (r - 1) + i);
+                s.push(gl::sub(gl::canon(st[i]), in));
+                st[i] = in;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) poseidon::sbox2(st[i], st[i + 1]);
+        poseidon::mds_add_const(st, kc);
+    }
+    for (int g = 0; g < 7; ++g) {  // partial rounds 0..20
+        u64 w[3], x[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = v.wire(65 + 3 * g + i);
+        s.push(gl::sub(gl::canon(st[0]), w[0]));
+        poseidon::partial_group3_core<true>(st, g, w, x);
+        s.push(gl::sub(x[0], w[1]));
+        s.push(gl::sub(x[1], w[2]));
+    }
+    {  // partial round 21
+        u64 kc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(12 * 26 + i);
+        const u64 in = v.wire(65 + 21);
+        s.push(gl::sub(gl::canon(st[0]), in));
+        st[0] = poseidon::sbox(in);
+        poseidon::mds_add_const(st, kc);
+    }
+    for (int r = 0; r < 4; ++r) {  // second full rounds (round index 26 + r)
+        u64 kc[12];
+        const int next = r < 3 ? 12 * (27 + r) : 0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc[i] = rc(next + i);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const u64 in = v.wire(87 + 12 * r + i);
+            s.push(gl::sub(gl::canon(st[i]), in));
+            st[i] = in;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) poseidon::sbox2(st[i], st[i + 1]);
+        poseidon::mds_add_const(st, r < 3 ? kc : nullptr);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), gl::canon(st[i])));
+}
+
+template <unsigned KIND, class DevSink> __device__ __forceinline__ void eval_kind(const vpbs_gate& g, const gates::CosetTables& t, const DevVars& v, DevSink& s) {
     if constexpr (KIND == VPBS_GATE_CONSTANT) gates::eval_constant<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_PUBLIC_INPUT) gates::eval_public_input<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_ARITHMETIC) gates::eval_arithmetic<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_BASE_SUM) gates::eval_base_sum<u64>(g, v, s);
-    if constexpr (KIND == VPBS_GATE_POSEIDON) gates::eval_poseidon<u64>(g, v, s);
-    if constexpr (KIND == VPBS_GATE_POSEIDON_MDS) gates::eval_poseidon_mds<u64>(g, v, s);
+    if constexpr (KIND == VPBS_GATE_POSEIDON) poseidon_gate_dev(v, s);
+    if constexpr (KIND == VPBS_GATE_POSEIDON_MDS) poseidon_mds_dev(v, s);
     if constexpr (KIND == VPBS_GATE_ARITHMETIC_EXT) gates::eval_arithmetic_ext<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_MUL_EXT) gates::eval_mul_ext<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_REDUCING) gates::eval_reducing<u64>(g, v, s);
@@ -63,33 +188,38 @@ template <unsigned KIND> __device__ __forceinline__ void eval_kind(const vpbs_ga
 }
 
 // grid: ceil(len / 256).  wires / consts: LDE columns with column stride `len` (the local leaves of the batches).
-template <unsigned KIND>
+template <unsigned KIND, int NC>
 __global__ void __launch_bounds__(THREADS)
-gate_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, vpbs_gate g, unsigned num_selectors,
-            gates::CosetTables tables, const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out,
-            int accumulate) {
-    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
-    if (j >= len) return;
+gate_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, size_t j0, size_t j1, vpbs_gate g,
+            unsigned num_selectors, gates::CosetTables tables, const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih,
+            u64* __restrict__ out, int accumulate) {
+    const size_t j = j0 + blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= j1) return;
     DevVars v{wires, consts + (size_t)num_selectors * len, len, j, pih};
-    DevSink s{apow, pow_stride, nc, 0, {0, 0, 0, 0}};
+    DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
     eval_kind<KIND>(g, tables, v, s);
     const u64 filter = gates::compute_filter<u64>(g, consts[(size_t)g.selector_index * len + j], num_selectors > 1);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NC; ++a) {
         if ((unsigned)a >= nc) continue;
-        u64 r = gl::mul(filter, s.acc[a]);
+        u64 r = gl::mul(filter, s.acc[a].reduce());
         if (accumulate) r = gl::add(r, out[(size_t)a * len + j]);
         out[(size_t)a * len + j] = r;
     }
 }
 
 template <unsigned KIND>
-void launch_one(hipStream_t s, const u64* wires, const u64* consts, size_t len, const vpbs_gate& g, unsigned num_selectors, const u64* apow,
-                unsigned pow_stride, unsigned nc, const PiHash& pih, u64* out, int accumulate) {
+void launch_one(hipStream_t s, const u64* wires, const u64* consts, size_t len, size_t j0, size_t j1, const vpbs_gate& g, unsigned num_selectors,
+                const u64* apow, unsigned pow_stride, unsigned nc, const PiHash& pih, u64* out, int accumulate) {
     gates::CosetTables t{};
     if (KIND == VPBS_GATE_COSET_INTERPOLATION) t = gates::coset_tables(g.p0);
-    hipLaunchKernelGGL(gate_kernel<KIND>, dim3((unsigned)((len + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, wires, consts, len, g,
-                       num_selectors, t, apow, pow_stride, nc, pih, out, accumulate);
+    const dim3 grid((unsigned)((j1 - j0 + THREADS - 1) / THREADS));
+    if (nc <= 2)  // plonky2's num_challenges = 2: two accumulators keep the kernels at their natural register count
+        hipLaunchKernelGGL((gate_kernel<KIND, 2>), grid, dim3(THREADS), 0, s, wires, consts, len, j0, j1, g, num_selectors, t, apow, pow_stride, nc,
+                           pih, out, accumulate);
+    else
+        hipLaunchKernelGGL((gate_kernel<KIND, 4>), grid, dim3(THREADS), 0, s, wires, consts, len, j0, j1, g, num_selectors, t, apow, pow_stride, nc,
+                           pih, out, accumulate);
 }
 
 // ---- host: Gate::id() strings, derived parameters, sorting ----
@@ -225,29 +355,37 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
                        unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out) {
     PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
     int acc = 0;
-    for (unsigned i = 0; i < n_gates; ++i) {
-        const vpbs_gate& g = gs[i];
-        if (g.num_constraints == 0) continue;
+    // (Splitting the points into row chunks so that one chunk's columns stay in the 256 MB memory-side cache across the 13
+    // kernels was measured and is slower at every chunk count: the kernels need the whole 2^18-point grid to hide latency.)
+    const size_t chunk = len;
+    for (size_t j0 = 0; j0 < len; j0 += chunk) {
+        const size_t j1 = std::min(len, j0 + chunk);
+        int acc_chunk = 0;
+        for (unsigned i = 0; i < n_gates; ++i) {
+            const vpbs_gate& g = gs[i];
+            if (g.num_constraints == 0) continue;
 #define VPBS_GATE_CASE(K) \
-    case K: launch_one<K>(s, wires_lde, consts_lde, len, g, num_selectors, d_apow, pow_stride, nc, pih, d_out, acc); break;
-        switch (g.kind) {
-            VPBS_GATE_CASE(VPBS_GATE_CONSTANT)
-            VPBS_GATE_CASE(VPBS_GATE_PUBLIC_INPUT)
-            VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC)
-            VPBS_GATE_CASE(VPBS_GATE_BASE_SUM)
-            VPBS_GATE_CASE(VPBS_GATE_POSEIDON)
-            VPBS_GATE_CASE(VPBS_GATE_POSEIDON_MDS)
-            VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC_EXT)
-            VPBS_GATE_CASE(VPBS_GATE_MUL_EXT)
-            VPBS_GATE_CASE(VPBS_GATE_REDUCING)
-            VPBS_GATE_CASE(VPBS_GATE_REDUCING_EXT)
-            VPBS_GATE_CASE(VPBS_GATE_RANDOM_ACCESS)
-            VPBS_GATE_CASE(VPBS_GATE_EXPONENTIATION)
-            VPBS_GATE_CASE(VPBS_GATE_COSET_INTERPOLATION)
-            default: continue;
-        }
+    case K: launch_one<K>(s, wires_lde, consts_lde, len, j0, j1, g, num_selectors, d_apow, pow_stride, nc, pih, d_out, acc_chunk); break;
+            switch (g.kind) {
+                VPBS_GATE_CASE(VPBS_GATE_CONSTANT)
+                VPBS_GATE_CASE(VPBS_GATE_PUBLIC_INPUT)
+                VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC)
+                VPBS_GATE_CASE(VPBS_GATE_BASE_SUM)
+                VPBS_GATE_CASE(VPBS_GATE_POSEIDON)
+                VPBS_GATE_CASE(VPBS_GATE_POSEIDON_MDS)
+                VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC_EXT)
+                VPBS_GATE_CASE(VPBS_GATE_MUL_EXT)
+                VPBS_GATE_CASE(VPBS_GATE_REDUCING)
+                VPBS_GATE_CASE(VPBS_GATE_REDUCING_EXT)
+                VPBS_GATE_CASE(VPBS_GATE_RANDOM_ACCESS)
+                VPBS_GATE_CASE(VPBS_GATE_EXPONENTIATION)
+                VPBS_GATE_CASE(VPBS_GATE_COSET_INTERPOLATION)
+                default: continue;
+            }
 #undef VPBS_GATE_CASE
-        acc = 1;
+            acc_chunk = 1;
+            acc = 1;
+        }
     }
     if (!acc) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
 }

@@ -136,14 +136,17 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
 // The MDS entries are so small that M^2 and M^3 still fit 32-bit multiplicands with room in 64-bit accumulators, so
 // instead of 3 x (288 multiply-adds + 12 folds) a group costs 288 (M^3) + 24 + 26 (row 0 of M, M^2) + 48 (the two
 // inner S-box corrections) multiply-adds and 14 folds.  s: x1 on entry (round constants included), x1' on exit.
-GL_HD void partial_group3(u64* s, int g) {
+// GATE = true is the PoseidonGate form of the same three rounds (gates.hip): the S-box inputs are the gate's partial_sbox wires
+// w[0..3) instead of the computed values, and the computed inputs of rounds 2 and 3 are returned (canonical) in x_out[0..2)
+// for the constraints "computed - wire" (round 1's input is s[0] on entry).
+template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w, u64* x_out) {
     const PartialGroup& G = partial_group(g);
     // request the group's constants before the first S-box (scalar-load latency hidden under it)
     const u64 k2 = G.k2, k3 = G.k3;
     u64 kv[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) kv[i] = G.kvec[i];
-    s[0] = sbox(s[0]);
+    s[0] = sbox(GATE ? w[0] : s[0]);
     u32 lo[12], hi[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
@@ -157,8 +160,9 @@ GL_HD void partial_group3(u64* s, int g) {
         a_lo += (u64)lo[j] * MDS1[0][j];
         a_hi += (u64)hi[j] * MDS1[0][j];
     }
-    const u64 x2 = fold96(a_lo, a_hi);
-    const u64 d2 = gl::sub(gl::canon(sbox(x2)), gl::canon(x2));
+    const u64 x2 = gl::canon(fold96(a_lo, a_hi));
+    if (GATE) x_out[0] = x2;
+    const u64 d2 = gl::sub(gl::canon(sbox(GATE ? w[1] : x2)), x2);
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
     // x3_0 = (M^2 y)[0] + M[0][0] d2 + (M c2)[0] + c3[0]
     u64 b_lo = (u32)k3, b_hi = k3 >> 32;
@@ -169,8 +173,9 @@ GL_HD void partial_group3(u64* s, int g) {
     }
     b_lo += (u64)d2l * MDS1[0][0];
     b_hi += (u64)d2h * MDS1[0][0];
-    const u64 x3 = fold96(b_lo, b_hi);
-    const u64 d3 = gl::sub(gl::canon(sbox(x3)), gl::canon(x3));
+    const u64 x3 = gl::canon(fold96(b_lo, b_hi));
+    if (GATE) x_out[1] = x3;
+    const u64 d3 = gl::sub(gl::canon(sbox(GATE ? w[2] : x3)), x3);
     const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
     // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec
 #pragma unroll
@@ -187,6 +192,7 @@ GL_HD void partial_group3(u64* s, int g) {
         s[i] = fold96(acc_lo, acc_hi);
     }
 }
+GL_HD void partial_group3(u64* s, int g) { partial_group3_core<false>(s, g, nullptr, nullptr); }
 
 // in/out: canonical field elements
 GL_HD void permute(u64* s) {
