@@ -6,6 +6,7 @@
 // absorb a fully coalesced 512-B wave read.  Integer-VALU bound (~21k instructions per permutation); no MFMA.
 #include <cstdlib>
 
+#include <algorithm>
 #include "kernels.h"
 #include "poseidon.h"
 
@@ -86,6 +87,44 @@ merkle_level_wide_kernel(const u64* __restrict__ children, u64* __restrict__ par
     u64 x = (live && l < 8) ? children[8 * i + l] : 0;
     x = poseidon::permute_wide(x, lds + g * poseidon::WIDE_LDS_WORDS, l);
     if (live && l < 4) parents[4 * i + l] = x;
+}
+
+// Several consecutive (small) levels in one launch: a workgroup owns 2^levels adjacent nodes and climbs to their common
+// ancestor, keeping the intermediate digests in LDS (and writing every level to the tree, which is kept for the query
+// openings).  The upper levels of a tree are a chain of dependent permutations; per-level launches cost a launch + drain
+// (~6 us) on top of each ~10 us permutation, this form only the permutation.
+constexpr unsigned CLIMB_THREADS = 512, CLIMB_MAX_LEVELS = 6;
+struct ClimbArgs {
+    const u64* children;          // 2^levels nodes per workgroup, consecutive
+    u64* out[CLIMB_MAX_LEVELS];   // out[k]: level k + 1 above the children (n_children >> (k + 1) nodes)
+    unsigned levels;
+};
+__global__ void __launch_bounds__(CLIMB_THREADS) merkle_climb_wide_kernel(ClimbArgs a) {
+    constexpr unsigned G = CLIMB_THREADS / poseidon::WIDE_LANES;   // 32 permutations per pass
+    __shared__ u64 lds[G * poseidon::WIDE_LDS_WORDS];
+    __shared__ u64 buf[2][4 << (CLIMB_MAX_LEVELS - 1)];           // digests of the current / next level
+    const unsigned l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const unsigned in_per_wg = 1u << a.levels;
+    const u64* src = a.children + (size_t)blockIdx.x * in_per_wg * 4;
+    for (unsigned k = 0; k < a.levels; ++k) {
+        const unsigned m = in_per_wg >> (k + 1);  // parents of this level inside the workgroup
+        u64* dst = a.out[k] + (size_t)blockIdx.x * m * 4;
+        for (unsigned i0 = 0; i0 < m; i0 += G) {
+            // a wave (4 groups) whose groups all lie beyond m skips the pass as a whole: permute_wide needs the 64 lanes of a
+            // wave together, not the workgroup, and the idle waves then cost no issue slots
+            if (i0 + (g & ~3u) >= m) continue;
+            const unsigned i = i0 + g;
+            const bool live = i < m;
+            u64 x = 0;
+            if (live && l < 8) x = k == 0 ? src[8 * i + l] : buf[(k - 1) & 1][8 * i + l];
+            x = poseidon::permute_wide(x, lds + g * poseidon::WIDE_LDS_WORDS, l);
+            if (live && l < 4) {
+                dst[4 * i + l] = x;
+                buf[k & 1][4 * i + l] = x;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -185,8 +224,27 @@ void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_
                        n_parents);
 }
 void launch_merkle_tree(hipStream_t s, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves) {
-    for (unsigned k = 1; k < n_levels; ++k)
+    unsigned k = 1;
+    // big levels: one launch each (the chip is full)
+    for (; k < n_levels && (n_leaves >> k) > wide_threshold(); ++k)
         launch_merkle_level(s, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
+    // the latency-bound rest: up to CLIMB_MAX_LEVELS levels per launch
+    static const bool fused = [] { const char* e = getenv("VPBS_MERKLE_CLIMB"); return !e || atoi(e) != 0; }();
+    while (k < n_levels) {
+        const size_t n_children = n_leaves >> (k - 1);
+        unsigned levels = std::min(CLIMB_MAX_LEVELS, n_levels - k);
+        if (!fused || levels < 2) {
+            launch_merkle_level(s, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
+            ++k;
+            continue;
+        }
+        ClimbArgs a{};
+        a.children = digests + level_off[k - 1];
+        a.levels = levels;
+        for (unsigned j = 0; j < levels; ++j) a.out[j] = digests + level_off[k + j];
+        hipLaunchKernelGGL(merkle_climb_wide_kernel, dim3((unsigned)(n_children >> levels)), dim3(CLIMB_THREADS), 0, s, a);
+        k += levels;
+    }
 }
 void launch_permute_batch(hipStream_t s, u64* states, size_t n) {
     hipLaunchKernelGGL(permute_batch_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, states, n);
