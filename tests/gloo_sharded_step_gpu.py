@@ -53,6 +53,24 @@ def main():
     got4 = ctx.prove_step(si4, comm)
     for key in ("caps", "openings", "fri"):
         assert (got4[key] == want3[key]).all(), (rank, "device quotient", key)
+    # ... and with the gate constraints of all 14 gate types in the quotient (each rank evaluates them on its own cosets)
+    gates = vpbs_amd.api.GateSet(["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext",
+                                  "mul_ext", "reducing", "reducing_ext", ("random_access", 4), "exponentiation", "coset_interpolation"])
+    assert gates.num_selectors + gates.num_constants <= n_constants + 1
+    nc6 = gates.num_selectors + gates.num_constants
+    cs6_vals = np.ascontiguousarray(synth.trace(0xBEEF, nc6 + n_routed, log_n))
+    sig6 = np.ascontiguousarray(cs6_vals[nc6:])
+    cs6_full = ctx.commit_values(cs6_vals)
+    dev_cs6 = torch.from_numpy(cs6_vals.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    cs6_shard, cs6_cap = sharding.sharded_commit(ctx, dev_cs6.data_ptr(), nc6 + n_routed, log_n)
+    si5 = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs6_full, digest, pis, sigmas=sig6, n_routed=n_routed, n_constants=nc6, gates=gates)
+    want5 = ctx.prove_step(si5)
+    si6 = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs6_shard, digest, pis, sigmas=sig6, n_routed=n_routed, n_constants=nc6, gates=gates)
+    got6 = ctx.prove_step(si6, comm)
+    for key in ("caps", "openings", "fri"):
+        assert (got6[key] == want5[key]).all(), (rank, "device quotient with gates", key)
+    assert not (want5["caps"][2] == want3["caps"][2]).all()   # the gate terms really are in the quotient
     dist.barrier()
     ctx.close()
     if rank == 0:
