@@ -448,14 +448,19 @@ def demo_circuit(rng, gs, log_n, public_inputs, n_routed=NUM_ROUTED):
             assert r < n
             put(r, g)
             r += 1
-    while r < n:
-        put(r, noop)
-        r += 1
+    if r < n:  # NoopGate rows: unconstrained wires, filled in bulk (the full-size test has 2^15 of them)
+        seed = rng.getrandbits(63)
+        fill = np.random.default_rng(seed).integers(0, P, size=(NUM_WIRES, n - r), dtype=np.uint64)
+        wires[:, r:] = fill
+        sel = gs.selector_values(noop)
+        for s_i, v in enumerate(sel):
+            constants[s_i, r:] = v
     # sigma: identity except one cycle per class (plonk/permutation_argument.rs: sigma maps a position to the next in its class)
     w = pymodel.root_of_unity(log_n)
     wp = [pow(w, i, P) for i in range(n)]
     kp = [pow(7, c, P) for c in range(n_routed)]
-    sigma = np.array([[kp[c] * wp[i] % P for i in range(n)] for c in range(n_routed)], np.uint64)
+    wp_arr = np.array(wp, dtype=object)
+    sigma = np.stack([np.array((wp_arr * kp[c]) % P, dtype=np.uint64) for c in range(n_routed)])
     # merge overlapping pairs into equivalence classes (the copy-constraint forest of CircuitBuilder), one cycle per class
     parent = {}
 

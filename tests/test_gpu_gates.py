@@ -168,3 +168,44 @@ def test_gate_argument_errors_device(ctx):
     cs2 = ctx.commit_values(rand_field(8, 16))
     with pytest.raises(api.VpbsError):   # PoseidonGate needs 135 wires
         ctx.gate_terms(cs2, small, ps, [0] * 4, [1, 2], out.data_ptr())
+
+
+def test_full_size_gate_circuit_proof_verifies(ctx):
+    """BASELINE config 2 size (degree 2^15, LDE 2^18) with a satisfiable circuit: public-input hash, Poseidon chain, arithmetic
+    chain, rows of every gate type, copy constraints, 2^15 - 33 NoopGate rows.  The oracle prover would take minutes, so parity is
+    carried by the identity itself: the GPU proof is accepted by the oracle's FRI verifier, the vanishing identity holds at zeta with
+    the gate terms re-evaluated from the openings by the ORACLE (and by the product's host verifier); one wrong witness value
+    anywhere breaks it."""
+    r = random.Random(2024)
+    log_n, n_routed = 15, 80
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    pis = [r.randrange(P) for _ in range(4)]
+    constants, wires, sigma, pi_hash = go.demo_circuit(r, gs, log_n, pis)
+    n_constants = constants.shape[0]
+    ncols = [n_constants + n_routed, 135, 20, 16]
+    cs_values = np.concatenate([constants, sigma])
+
+    def accepted(w):
+        cs = ctx.commit_values(cs_values)
+        si = ctx.make_step_inputs(log_n, w, None, None, cs, DIGEST, pis, sigmas=sigma, n_routed=n_routed, n_constants=n_constants, gates=ps)
+        proof = ctx.prove_step(si)
+        cap = cs.cap()
+        cs.free()
+        assert step_oracle.verify_step(proof, cap, ncols, DIGEST, pis, log_n)
+        op = proof["openings"]
+        n_cs, n_w, n_z, n_q = ncols
+        cs_z, w_z = op[:n_cs], op[n_cs:n_cs + n_w]
+        zs_all, q_z, zs_next = op[n_cs + n_w:n_cs + n_w + n_z], op[n_cs + n_w + n_z:n_cs + n_w + n_z + n_q], op[n_cs + n_w + n_z + n_q:]
+        ch = [int(x) for x in proof["challenges"]]
+        betas, gammas, alphas, zeta = ch[0:2], ch[2:4], ch[4:6], ch[6:8]
+        gt = gs.terms_zeta(cs_z[:n_constants], w_z, pi_hash, alphas)
+        ok = orc.check_vanishing_at_zeta(w_z[:n_routed], cs_z[n_constants:], zs_all[:2], zs_next, zs_all[2:], q_z, log_n, betas, gammas,
+                                         alphas, zeta, gate_terms_zeta=gt)
+        assert api.verify_step(proof, cap, ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed,
+                               gates=ps) == ok
+        return ok
+
+    assert accepted(wires)
+    bad = wires.copy()
+    bad[70, 2] = (int(bad[70, 2]) + 5) % P   # a partial-round S-box wire of a Poseidon row
+    assert not accepted(bad)
