@@ -19,8 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = "leaf_hash_kernel"
 
 
+GATE_KINDS = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext",
+              "reducing", "reducing_ext", "random_access", "exponentiation", "coset_interpolation"]
+
+
 def short(name):
     import re
+    g = re.search(r"gate_kernel<(\d+)u", name)
+    if g:
+        return "gate_kernel<%s>" % GATE_KINDS[int(g.group(1))]
     m = re.search(r"(\w+)\s*(<[^(]*>)?\(", name.replace("(anonymous namespace)", "anon"))
     return m.group(1) if m else name
 
@@ -64,7 +71,7 @@ def main():
     fetch = [float(r["Counter_Value"]) for r in counter_rows(fetch_dir, "FETCH_SIZE") if short(r["Kernel_Name"]) == dominant]
     write = [float(r["Counter_Value"]) for r in counter_rows(write_dir, "WRITE_SIZE") if short(r["Kernel_Name"]) == dominant]
     kinds_p = ["constants_sigmas"] + ["wires", "zs_partial_products", "quotient"] * ((len(fetch) - 1) // 3)
-    cols = {"constants_sigmas": 85, "wires": 135, "zs_partial_products": 20, "quotient": 16}
+    cols = {"constants_sigmas": 86, "wires": 135, "zs_partial_products": 20, "quotient": 16}
     lde = 1 << 18
     per_kind = {}
     for kind in cols:
