@@ -183,10 +183,34 @@ int vpbs_gate_terms(vpbs_ctx* ctx, vpbs_batch* constants_sigmas, vpbs_batch* wir
 int vpbs_gate_terms_at(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, const uint64_t* constants_at,
                        unsigned n_constants, const uint64_t* wires_at, unsigned n_wires, const uint64_t public_inputs_hash[4],
                        const uint64_t* alphas, unsigned num_challenges, uint64_t* out);
-/* Witness rows (iop/generator.rs SimpleGenerator::run_once of each gate): given the gate's free
+/* ---- witness generation (host only; iop/generator.rs, iop/witness.rs, plonk/permutation_argument.rs) ----
+ * Witness rows (SimpleGenerator::run_once of each gate): given the gate's free
  * inputs already present in `row` ([num_wires], one trace row) fills the wires the gate's generators own (outputs,
- * S-box inputs, limbs, intermediate accumulators ...).  constants: the gate constants of that row.  Host only. */
+ * S-box inputs, limbs, intermediate accumulators ...).  constants: the gate constants of that row. */
 int vpbs_gate_fill_row(const vpbs_gate* gate, const uint64_t* constants, uint64_t* row);
+/* A circuit over the supported gates, as CircuitBuilder::build leaves it in ProverOnlyCircuitData / CommonCircuitData:
+ * the gate instance of every row, the constants columns, and the copy constraints between routed wires. */
+typedef struct {
+    unsigned log_n, n_wires, n_routed;   /* degree_bits, config.num_wires (135), config.num_routed_wires (80) */
+    const vpbs_gate* gates;              /* laid out by vpbs_gates_layout */
+    unsigned n_gates, num_selectors;
+    const uint32_t* row_gate;            /* [n]: index into gates of the gate instance on each row */
+    const uint64_t* constants;           /* [n_constants_cols][n] column-major: selector columns, then the gate constants */
+    unsigned n_constants_cols;
+    const uint32_t* copies;              /* [n_copies][2]: wire positions (column * n + row, column < n_routed) constrained equal */
+    size_t n_copies;
+} vpbs_circuit;
+/* gates/selectors.rs selector_polynomials: out [num_selectors][n] = the gate's index on its selector, UNUSED elsewhere */
+int vpbs_selector_columns(const vpbs_circuit* circuit, uint64_t* out);
+/* WirePartition::get_sigma_polys: sigma values [n_routed][n]; every copy-constraint class becomes one cycle (members in
+ * (row, column) order), everything else maps to itself: sigma[col][row] = k_col' * w^row' of the image position */
+int vpbs_sigma_values(const vpbs_circuit* circuit, uint64_t* out);
+/* generate_partial_witness + full_witness: starting from the preset targets (PartialWitness: positions column * n + row and
+ * values) runs every gate generator whose watched wires are set, propagating values through the copy-constraint classes,
+ * until all have run.  wires_out: [n_wires][n] (unset wires are 0).  Errors (VPBS_ERR_INVALID, message in err): a class set
+ * twice with different values, generators that could not run, a value that does not fit its gate. */
+int vpbs_generate_witness(const vpbs_circuit* circuit, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
+                          uint64_t* wires_out, char* err, size_t err_len);
 
 /* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
 typedef struct {

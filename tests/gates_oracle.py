@@ -394,7 +394,7 @@ def interpolate_check(row, gate):
     return total == (row[s_value], row[s_value + 1])
 
 
-def demo_circuit(rng, gs, log_n, public_inputs, n_routed=NUM_ROUTED):
+def demo_circuit(rng, gs, log_n, public_inputs, n_routed=NUM_ROUTED, describe=False):
     """A small but real circuit over the gate set gs (must contain public_input, poseidon, arithmetic, noop; any other gate of
     gs gets a few unconnected rows):
       row 0            PublicInputGate: wires 0..4 = hash of the public inputs
@@ -477,8 +477,17 @@ def demo_circuit(rng, gs, log_n, public_inputs, n_routed=NUM_ROUTED):
     for x in list(parent):
         merged.setdefault(find(x), []).append(x)
     for cl in merged.values():
-        cl.sort()
+        cl.sort(key=lambda x: (x[1], x[0]))   # WirePartition order: by (row, column)
         assert all(c < n_routed for c, _ in cl) and len({int(wires[c, rr]) for c, rr in cl}) == 1
         for (c, rr), (c2, r2) in zip(cl, cl[1:] + cl[:1]):
             sigma[c, rr] = kp[c2] * wp[r2] % P
+    if describe:
+        # the circuit as data (what CircuitBuilder::build leaves behind) + the PartialWitness a caller would set: every wire
+        # that no gate generator owns and that is not reachable through a copy constraint from a generated wire
+        row_gate = np.zeros(n, np.uint32)
+        for rr in range(n):
+            sel = [int(x) for x in constants[:gs.num_selectors, rr]]
+            row_gate[rr] = next(g.index for g in gs.gates if gs.selector_values(g) == sel)
+        pairs = [(a[0] * n + a[1], b[0] * n + b[1]) for cl in classes for a, b in zip(cl, cl[1:])]
+        return constants, wires, sigma, pi_hash, {"row_gate": row_gate, "copies": pairs, "classes": [sorted(c) for c in merged.values()]}
     return constants, wires, sigma, pi_hash

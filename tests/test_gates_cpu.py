@@ -309,3 +309,61 @@ def test_demo_circuit_oracle_proof_verifies_under_both_verifiers():
                                        n_constants=n_constants, n_routed=n_routed)
             assert not api.verify_step(proof, proof["cs_cap"], ncols, DIGEST, [pis[0] ^ 1] + pis[1:], log_n, check_permutation=True,
                                        n_constants=n_constants, n_routed=n_routed, gates=ps)
+
+
+def _free_inputs(gate):
+    """wires a caller must provide for a stand-alone gate row: everything the gate uses minus what its generators own"""
+    owned = set(_owned_wires(gate))
+    return [w for w in range(gate.num_wires) if w not in owned]
+
+
+def test_witness_generation_reproduces_the_demo_circuit():
+    """Product host code (vpbs_generate_witness, vpbs_sigma_values, vpbs_selector_columns) against the independent Python build of
+    the same circuit: from the PartialWitness alone (public inputs, free gate inputs) the scheduler regenerates every generated
+    wire -- through the copy constraints: Poseidon chain, arithmetic chain, in-circuit public-input hash -- and the trace
+    satisfies every gate and every copy constraint."""
+    rng = random.Random(31)
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    log_n = 6
+    n = 1 << log_n
+    pis = [rng.randrange(P) for _ in range(4)]
+    constants, wires, sigma, pi_hash, desc = go.demo_circuit(rng, gs, log_n, pis, describe=True)
+    circ = api.Circuit(ps, log_n, desc["row_gate"], constants, desc["copies"])
+    assert (circ.selector_columns() == constants[:gs.num_selectors]).all()
+    assert (circ.sigma_values() == sigma).all()
+    # PartialWitness: free inputs of every gate row that are not fed by a copy constraint from a generated wire
+    generated = set()
+    for r in range(n):
+        g = gs.gates[int(desc["row_gate"][r])]
+        generated |= {(w, r) for w in _owned_wires(g)}
+    fed = set()
+    for cl in desc["classes"]:
+        if any(tuple(x) in generated for x in cl):
+            fed |= {tuple(x) for x in cl}
+    presets = {}
+    for r in range(n):
+        g = gs.gates[int(desc["row_gate"][r])]
+        if g.kind == "public_input":
+            continue   # its wires are copy-constrained to the in-circuit hash
+        for w in _free_inputs(g):
+            if (w, r) not in fed:
+                presets[(w, r)] = int(wires[w, r])
+    got = circ.generate_witness(presets)
+    for r in range(n):
+        g = gs.gates[int(desc["row_gate"][r])]
+        used = range(g.num_wires)
+        assert [int(got[w, r]) for w in used] == [int(wires[w, r]) for w in used], (r, g.kind)
+        consts = [int(x) for x in constants[gs.num_selectors:gs.num_selectors + g.num_constants, r]]
+        assert not gs.eval_row(g, got[:, r], consts, pi_hash).any()
+    for cl in desc["classes"]:
+        assert len({int(got[c, r]) for c, r in cl}) == 1
+    assert [int(got[i, 0]) for i in range(4)] == pi_hash   # PublicInputGate wires = hash_no_pad(public inputs), via the circuit
+    # errors: a conflicting preset, a missing input
+    bad = dict(presets)
+    bad[(12, 1)] = (int(wires[12, 1]) + 1) % P     # an output the Poseidon generator will set differently
+    with pytest.raises(api.VpbsError, match="set twice"):
+        circ.generate_witness(bad)
+    missing = dict(presets)
+    del missing[(0, 1)]
+    with pytest.raises(api.VpbsError, match="weren't run"):
+        circ.generate_witness(missing)

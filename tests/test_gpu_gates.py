@@ -209,3 +209,42 @@ def test_full_size_gate_circuit_proof_verifies(ctx):
     bad = wires.copy()
     bad[70, 2] = (int(bad[70, 2]) + 5) % P   # a partial-round S-box wire of a Poseidon row
     assert not accepted(bad)
+
+
+def test_product_witness_to_proof(ctx):
+    """Everything product-side: circuit data -> vpbs_selector_columns / vpbs_sigma_values / vpbs_generate_witness (host) -> step proof on
+    the GPU -> vpbs_verify_step.  The Python circuit builder only supplies the circuit description and the PartialWitness."""
+    import test_gates_cpu as tg
+    r = random.Random(404)
+    log_n, n_routed = 7, 80
+    n = 1 << log_n
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    pis = [r.randrange(P) for _ in range(4)]
+    constants, wires, _, pi_hash, desc = go.demo_circuit(r, gs, log_n, pis, describe=True)
+    circ = api.Circuit(ps, log_n, desc["row_gate"], constants, desc["copies"])
+    generated = set()
+    for row in range(n):
+        generated |= {(w, row) for w in tg._owned_wires(gs.gates[int(desc["row_gate"][row])])}
+    fed = set()
+    for cl in desc["classes"]:
+        if any(tuple(x) in generated for x in cl):
+            fed |= {tuple(x) for x in cl}
+    presets = {}
+    for row in range(n):
+        g = gs.gates[int(desc["row_gate"][row])]
+        if g.kind != "public_input":
+            presets.update({(w, row): int(wires[w, row]) for w in tg._free_inputs(g) if (w, row) not in fed})
+    witness = circ.generate_witness(presets)
+    sigma = circ.sigma_values()
+    cs_values = np.concatenate([circ.selector_columns(), constants[gs.num_selectors:], sigma])
+    n_constants = constants.shape[0]
+    ncols = [n_constants + n_routed, 135, 20, 16]
+    cs = ctx.commit_values(cs_values)
+    si = ctx.make_step_inputs(log_n, witness, None, None, cs, DIGEST, pis, sigmas=sigma, n_routed=n_routed, n_constants=n_constants, gates=ps)
+    proof = ctx.prove_step(si)
+    assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed, gates=ps)
+    assert step_oracle.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n)
+    # other public inputs: the in-circuit hash no longer matches the PublicInputGate constraint
+    assert not api.verify_step(proof, cs.cap(), ncols, DIGEST, [pis[0] ^ 1] + pis[1:], log_n, check_permutation=True, n_constants=n_constants,
+                               n_routed=n_routed, gates=ps)
+    cs.free()

@@ -45,6 +45,13 @@ class GateC(C.Structure):
                 ("selector_index", C.c_uint), ("group_start", C.c_uint), ("group_end", C.c_uint), ("index", C.c_uint)]
 
 
+class CircuitC(C.Structure):
+    """vpbs_circuit"""
+    _fields_ = [("log_n", C.c_uint), ("n_wires", C.c_uint), ("n_routed", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint),
+                ("num_selectors", C.c_uint), ("row_gate", U32P), ("constants", U64P), ("n_constants_cols", C.c_uint),
+                ("copies", U32P), ("n_copies", C.c_size_t)]
+
+
 GATE_KINDS = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext",
               "reducing", "reducing_ext", "random_access", "exponentiation", "coset_interpolation"]
 UNUSED_SELECTOR = 0xFFFFFFFF
@@ -129,6 +136,9 @@ SIGNATURES = {
     "vpbs_gate_terms": (_i, [_vp, _vp, _vp, C.POINTER(GateC), _ui, _ui, U64P, U64P, _ui, _vp]),
     "vpbs_gate_terms_at": (_i, [C.POINTER(GateC), _ui, _ui, U64P, _ui, U64P, _ui, U64P, U64P, _ui, U64P]),
     "vpbs_gate_fill_row": (_i, [C.POINTER(GateC), U64P, U64P]),
+    "vpbs_selector_columns": (_i, [C.POINTER(CircuitC), U64P]),
+    "vpbs_sigma_values": (_i, [C.POINTER(CircuitC), U64P]),
+    "vpbs_generate_witness": (_i, [C.POINTER(CircuitC), U32P, U64P, _sz, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
@@ -281,6 +291,48 @@ class GateSet:
         if rc:
             raise VpbsError("vpbs_gate_fill_row failed: %d" % rc)
         return row
+
+
+class Circuit:
+    """vpbs_circuit: gate instance per row, constants columns, copy constraints (host-side description of a circuit)."""
+
+    def __init__(self, gates, log_n, row_gate, constants, copies, n_wires=135, n_routed=80):
+        n = 1 << log_n
+        self.gates, self.log_n, self.n, self.n_wires, self.n_routed = gates, log_n, n, n_wires, n_routed
+        self.row_gate = np.ascontiguousarray(row_gate, dtype=np.uint32)
+        self.constants = _u64(constants)
+        self.copies = np.ascontiguousarray(np.asarray(copies, dtype=np.uint32).reshape(-1, 2))
+        assert self.row_gate.shape == (n,) and self.constants.shape[1] == n
+        c = CircuitC()
+        c.log_n, c.n_wires, c.n_routed = log_n, n_wires, n_routed
+        c.gates, c.n_gates, c.num_selectors = gates.arr, gates.n, gates.num_selectors
+        c.row_gate = self.row_gate.ctypes.data_as(U32P)
+        c.constants, c.n_constants_cols = _ptr(self.constants), self.constants.shape[0]
+        c.copies, c.n_copies = self.copies.ctypes.data_as(U32P), self.copies.shape[0]
+        self.c = c
+
+    def selector_columns(self):
+        out = np.zeros((self.gates.num_selectors, self.n), np.uint64)
+        if lib().vpbs_selector_columns(C.byref(self.c), _ptr(out)):
+            raise VpbsError("vpbs_selector_columns failed")
+        return out
+
+    def sigma_values(self):
+        out = np.zeros((self.n_routed, self.n), np.uint64)
+        if lib().vpbs_sigma_values(C.byref(self.c), _ptr(out)):
+            raise VpbsError("vpbs_sigma_values failed")
+        return out
+
+    def generate_witness(self, presets):
+        """presets: {(column, row): value} (the PartialWitness) -> wires [n_wires][n]"""
+        pos = np.array([c * self.n + r for (c, r) in presets], dtype=np.uint32)
+        val = _u64([int(v) for v in presets.values()])
+        out = np.zeros((self.n_wires, self.n), np.uint64)
+        err = C.create_string_buffer(512)
+        rc = lib().vpbs_generate_witness(C.byref(self.c), pos.ctypes.data_as(U32P), _ptr(val) if val.size else None, pos.size, _ptr(out), err, 512)
+        if rc:
+            raise VpbsError("vpbs_generate_witness: " + err.value.decode())
+        return out
 
 
 def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=False, n_constants=0,

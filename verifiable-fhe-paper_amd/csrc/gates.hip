@@ -304,51 +304,6 @@ struct HostSink {
     void push(gl::Ext x) { c.push_back(x); }
 };
 
-// ---- witness rows ----
-void poseidon_fill(u64* row) {
-    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    auto mds = [&](u64* s) {
-        u64 o[12];
-        for (int r = 0; r < 12; ++r) {
-            u64 acc = 0;
-            for (int i = 0; i < 12; ++i) acc = gl::add(acc, gl::mul(s[(i + r) % 12], C[i]));
-            if (r == 0) acc = gl::add(acc, gl::mul(s[0], 8));
-            o[r] = acc;
-        }
-        std::memcpy(s, o, sizeof o);
-    };
-    auto sbox = [](u64 x) { const u64 x2 = gl::mul(x, x), x4 = gl::mul(x2, x2); return gl::mul(gl::mul(x2, x), x4); };
-    const u64 swap = row[24];
-    u64 st[12];
-    for (int i = 0; i < 4; ++i) {
-        const u64 delta = gl::mul(swap, gl::sub(row[i + 4], row[i]));
-        row[25 + i] = delta;
-        st[i] = gl::add(row[i], delta);
-        st[i + 4] = gl::sub(row[i + 4], delta);
-    }
-    for (int i = 8; i < 12; ++i) st[i] = row[i];
-    for (int round = 0; round < 30; ++round) {
-        for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::rc(12 * round + i));
-        if (round < 4 || round >= 26) {
-            for (int i = 0; i < 12; ++i) {
-                if (round >= 1 && round < 4) row[29 + 12 * (round - 1) + i] = st[i];
-                if (round >= 26) row[87 + 12 * (round - 26) + i] = st[i];
-                st[i] = sbox(st[i]);
-            }
-        } else {
-            row[65 + (round - 4)] = st[0];
-            st[0] = sbox(st[0]);
-        }
-        mds(st);
-    }
-    for (int i = 0; i < 12; ++i) row[12 + i] = st[i];
-}
-using A = gates::Alg<u64>;
-A ralg(const u64* row, unsigned i) { return A{row[i], row[i + 1]}; }
-void walg(u64* row, unsigned i, A x) {
-    row[i] = x.a;
-    row[i + 1] = x.b;
-}
 }  // namespace
 
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
@@ -544,118 +499,6 @@ int vpbs_gate_terms_at(const vpbs_gate* gs, unsigned n_gates, unsigned num_selec
         return VPBS_ERR_INVALID;
     }
     vpbs::gate_terms_at(gs, n_gates, num_selectors, constants_at, n_constants, wires_at, n_wires, pi_hash, alphas, nc, out);
-    return VPBS_OK;
-}
-
-int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t* row) {
-    if (!gp || !row) return VPBS_ERR_INVALID;
-    using namespace vpbs;
-    vpbs_gate g = *gp;
-    if (!derive(g)) return VPBS_ERR_INVALID;
-    if (g.num_constants && !constants) return VPBS_ERR_INVALID;
-    switch (g.kind) {
-        case VPBS_GATE_NOOP:
-        case VPBS_GATE_PUBLIC_INPUT: break;  // the public-input hash wires are set by the prover (set_target from pi hash)
-        case VPBS_GATE_CONSTANT:
-            for (unsigned i = 0; i < g.p0; ++i) row[i] = constants[i];
-            break;
-        case VPBS_GATE_ARITHMETIC:
-            for (unsigned i = 0; i < g.p0; ++i)
-                row[4 * i + 3] = gl::add(gl::mul(gl::mul(row[4 * i], row[4 * i + 1]), constants[0]), gl::mul(row[4 * i + 2], constants[1]));
-            break;
-        case VPBS_GATE_BASE_SUM: {  // BaseSplitGenerator: little-endian base-B digits of the canonical sum
-            u64 x = row[0];
-            for (unsigned i = 0; i < g.p0; ++i) {
-                row[1 + i] = x % g.p1;
-                x /= g.p1;
-            }
-            if (x != 0) return VPBS_ERR_INVALID;  // "Integer too large to fit in given number of limbs"
-            break;
-        }
-        case VPBS_GATE_POSEIDON: poseidon_fill(row); break;
-        case VPBS_GATE_POSEIDON_MDS: {
-            const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-            for (unsigned r = 0; r < 12; ++r) {
-                A acc{0, 0};
-                for (unsigned i = 0; i < 12; ++i) acc = acc + gates::scalec(ralg(row, 2 * ((i + r) % 12)), C[i]);
-                if (r == 0) acc = acc + gates::scalec(ralg(row, 0), 8);
-                walg(row, 2 * (12 + r), acc);
-            }
-            break;
-        }
-        case VPBS_GATE_ARITHMETIC_EXT:
-            for (unsigned i = 0; i < g.p0; ++i)
-                walg(row, 8 * i + 6, gates::scale(ralg(row, 8 * i) * ralg(row, 8 * i + 2), constants[0]) + gates::scale(ralg(row, 8 * i + 4), constants[1]));
-            break;
-        case VPBS_GATE_MUL_EXT:
-            for (unsigned i = 0; i < g.p0; ++i) walg(row, 6 * i + 4, gates::scale(ralg(row, 6 * i) * ralg(row, 6 * i + 2), constants[0]));
-            break;
-        case VPBS_GATE_REDUCING:
-        case VPBS_GATE_REDUCING_EXT: {
-            const bool ext = g.kind == VPBS_GATE_REDUCING_EXT;
-            const unsigned n = g.p0, start_accs = ext ? 6 + 2 * n : 6 + n;
-            const A alpha = ralg(row, 2);
-            A acc = ralg(row, 4);
-            for (unsigned i = 0; i < n; ++i) {
-                const A coeff = ext ? ralg(row, 6 + 2 * i) : A{row[6 + i], 0};
-                acc = acc * alpha + coeff;
-                walg(row, i == n - 1 ? 0 : start_accs + 2 * i, acc);
-            }
-            break;
-        }
-        case VPBS_GATE_RANDOM_ACCESS: {
-            const unsigned bits = g.p0, vec = 1u << bits, routed = (2 + vec) * g.p1 + g.p2;
-            for (unsigned c = 0; c < g.p1; ++c) {
-                const unsigned base = (2 + vec) * c;
-                const u64 idx = row[base];
-                if (idx >= vec) return VPBS_ERR_INVALID;
-                row[base + 1] = row[base + 2 + idx];
-                for (unsigned b = 0; b < bits; ++b) row[routed + c * bits + b] = (idx >> b) & 1;
-            }
-            for (unsigned i = 0; i < g.p2; ++i) row[(2 + vec) * g.p1 + i] = constants[i];
-            break;
-        }
-        case VPBS_GATE_EXPONENTIATION: {
-            const unsigned n = g.p0;
-            u64 prev = 1;
-            for (unsigned i = 0; i < n; ++i) {
-                const u64 sq = i == 0 ? 1 : gl::mul(prev, prev);
-                const u64 bit = row[1 + (n - 1 - i)];
-                if (bit > 1) return VPBS_ERR_INVALID;
-                prev = bit ? gl::mul(sq, row[0]) : sq;
-                row[2 + n + i] = prev;
-            }
-            row[1 + n] = prev;
-            break;
-        }
-        case VPBS_GATE_COSET_INTERPOLATION: {
-            const unsigned points = 1u << g.p0, degree = g.p1, ni = (points - 2) / (degree - 1);
-            const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
-            const unsigned start_shifted = start_inter + 4 * ni;
-            if (row[0] == 0) return VPBS_ERR_INVALID;
-            const gates::CosetTables t = gates::coset_tables(g.p0);
-            const A shifted = gates::scale(ralg(row, start_point), gl::inv(row[0]));
-            walg(row, start_shifted, shifted);
-            A eval{0, 0}, prod{1, 0};
-            auto run = [&](unsigned from, unsigned to) {
-                for (unsigned i = from; i < to; ++i) {
-                    const A term = gates::sub_base(shifted, t.domain[i]);
-                    eval = eval * term + gates::scalec(ralg(row, 1 + 2 * i), t.weights[i]) * prod;
-                    prod = prod * term;
-                }
-            };
-            run(0, std::min(degree, points));
-            for (unsigned i = 0; i < ni; ++i) {
-                walg(row, start_inter + 2 * i, eval);
-                walg(row, start_inter + 2 * (ni + i), prod);
-                const unsigned from = 1 + (degree - 1) * (i + 1);
-                run(from, std::min(from + degree - 1, points));
-            }
-            walg(row, start_value, eval);
-            break;
-        }
-        default: return VPBS_ERR_INVALID;
-    }
     return VPBS_OK;
 }
 

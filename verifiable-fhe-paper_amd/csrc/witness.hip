@@ -1,0 +1,414 @@
+// Witness generation for circuits made of the supported gates (host only; no device code in this file).
+// Replaces plonky2 0.2.0 iop/generator.rs `generate_partial_witness` (run every generator whose watched targets are set,
+// propagate through the copy-constraint partition, repeat), iop/witness.rs `PartitionWitness::full_witness`, the gates' own
+// `SimpleGenerator::run_once` implementations (gates/*.rs), plonk/permutation_argument.rs `WirePartition::get_sigma_polys` and
+// the selector columns of gates/selectors.rs -- the first stage of prove() reached from
+// /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364.  The gadget-level generators of the
+// reference's own circuit builder (vec_arithmetic, the recursive verifier) are outside: the caller presets their targets.
+// Restated from the published crate: parity unpinned; checked against an independent Python restatement and against the
+// gate constraints (every generated row must satisfy them).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "gates.h"
+#include "../../include/vpbs_prover.h"
+
+namespace vpbs {
+namespace {
+using gl::u32;
+using gl::u64;
+using A = gates::Alg<u64>;
+
+struct GenError {
+    std::string what;
+};
+
+// A gate instance owns `gen_count` generators (one per operation / copy, like plonky2); generator `sub` watches `deps` wires of
+// its row and writes the wires it owns.
+unsigned gen_count(const vpbs_gate& g) {
+    switch (g.kind) {
+        case VPBS_GATE_CONSTANT:
+        case VPBS_GATE_ARITHMETIC:
+        case VPBS_GATE_ARITHMETIC_EXT:
+        case VPBS_GATE_MUL_EXT: return g.p0;
+        case VPBS_GATE_RANDOM_ACCESS: return g.p1 + g.p2;  // one per copy + RandomAccessExtraConstants
+        case VPBS_GATE_BASE_SUM:
+        case VPBS_GATE_POSEIDON:
+        case VPBS_GATE_POSEIDON_MDS:
+        case VPBS_GATE_REDUCING:
+        case VPBS_GATE_REDUCING_EXT:
+        case VPBS_GATE_EXPONENTIATION:
+        case VPBS_GATE_COSET_INTERPOLATION: return 1;
+        default: return 0;  // NoopGate, PublicInputGate (its wires are copy-constrained to the in-circuit hash)
+    }
+}
+
+void gen_deps(const vpbs_gate& g, unsigned sub, std::vector<unsigned>& d) {
+    d.clear();
+    auto range = [&](unsigned a, unsigned b) { for (unsigned i = a; i < b; ++i) d.push_back(i); };
+    switch (g.kind) {
+        case VPBS_GATE_ARITHMETIC: range(4 * sub, 4 * sub + 3); break;
+        case VPBS_GATE_ARITHMETIC_EXT: range(8 * sub, 8 * sub + 6); break;
+        case VPBS_GATE_MUL_EXT: range(6 * sub, 6 * sub + 4); break;
+        case VPBS_GATE_BASE_SUM: d.push_back(0); break;
+        case VPBS_GATE_POSEIDON: range(0, 12); d.push_back(24); break;
+        case VPBS_GATE_POSEIDON_MDS: range(0, 24); break;
+        case VPBS_GATE_REDUCING: range(2, 6 + g.p0); break;
+        case VPBS_GATE_REDUCING_EXT: range(2, 6 + 2 * g.p0); break;
+        case VPBS_GATE_RANDOM_ACCESS:
+            if (sub < g.p1) {
+                const unsigned vec = 1u << g.p0, base = (2 + vec) * sub;
+                d.push_back(base);
+                range(base + 2, base + 2 + vec);
+            }
+            break;
+        case VPBS_GATE_EXPONENTIATION: range(0, 1 + g.p0); break;
+        case VPBS_GATE_COSET_INTERPOLATION: range(0, 1 + 2 * (1u << g.p0) + 2); break;
+        default: break;
+    }
+}
+
+// R: get(wire) -> u64, set(wire, value)
+template <class R> A ralg(R& r, unsigned i) { return A{r.get(i), r.get(i + 1)}; }
+template <class R> void walg(R& r, unsigned i, A x) {
+    r.set(i, x.a);
+    r.set(i + 1, x.b);
+}
+
+template <class R> void poseidon_generate(R& r) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    auto mds = [&](u64* s) {
+        u64 o[12];
+        for (int row = 0; row < 12; ++row) {
+            u64 acc = 0;
+            for (int i = 0; i < 12; ++i) acc = gl::add(acc, gl::mul(s[(i + row) % 12], C[i]));
+            if (row == 0) acc = gl::add(acc, gl::mul(s[0], 8));
+            o[row] = acc;
+        }
+        std::memcpy(s, o, sizeof o);
+    };
+    auto sbox = [](u64 x) { const u64 x2 = gl::mul(x, x), x4 = gl::mul(x2, x2); return gl::mul(gl::mul(x2, x), x4); };
+    const u64 swap = r.get(24);
+    if (swap > 1) throw GenError{"PoseidonGate: swap wire is not boolean"};
+    u64 st[12];
+    for (int i = 0; i < 4; ++i) {
+        const u64 lhs = r.get(i), rhs = r.get(i + 4);
+        const u64 delta = gl::mul(swap, gl::sub(rhs, lhs));
+        r.set(25 + i, delta);
+        st[i] = gl::add(lhs, delta);
+        st[i + 4] = gl::sub(rhs, delta);
+    }
+    for (int i = 8; i < 12; ++i) st[i] = r.get(i);
+    for (int round = 0; round < 30; ++round) {
+        for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::rc(12 * round + i));
+        if (round < 4 || round >= 26) {
+            for (int i = 0; i < 12; ++i) {
+                if (round >= 1 && round < 4) r.set(29 + 12 * (round - 1) + i, st[i]);
+                if (round >= 26) r.set(87 + 12 * (round - 26) + i, st[i]);
+                st[i] = sbox(st[i]);
+            }
+        } else {
+            r.set(65 + (round - 4), st[0]);
+            st[0] = sbox(st[0]);
+        }
+        mds(st);
+    }
+    for (int i = 0; i < 12; ++i) r.set(12 + i, st[i]);
+}
+
+template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, R& r) {
+    switch (g.kind) {
+        case VPBS_GATE_CONSTANT: r.set(sub, c[sub]); break;
+        case VPBS_GATE_ARITHMETIC:
+            r.set(4 * sub + 3, gl::add(gl::mul(gl::mul(r.get(4 * sub), r.get(4 * sub + 1)), c[0]), gl::mul(r.get(4 * sub + 2), c[1])));
+            break;
+        case VPBS_GATE_BASE_SUM: {  // BaseSplitGenerator: little-endian base-B digits of the canonical sum
+            u64 x = r.get(0);
+            for (unsigned i = 0; i < g.p0; ++i) {
+                r.set(1 + i, x % g.p1);
+                x /= g.p1;
+            }
+            if (x != 0) throw GenError{"BaseSumGate: integer too large to fit in the given number of limbs"};
+            break;
+        }
+        case VPBS_GATE_POSEIDON: poseidon_generate(r); break;
+        case VPBS_GATE_POSEIDON_MDS: {
+            const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+            A in[12];
+            for (unsigned i = 0; i < 12; ++i) in[i] = ralg(r, 2 * i);
+            for (unsigned row = 0; row < 12; ++row) {
+                A acc{0, 0};
+                for (unsigned i = 0; i < 12; ++i) acc = acc + gates::scalec(in[(i + row) % 12], C[i]);
+                if (row == 0) acc = acc + gates::scalec(in[0], 8);
+                walg(r, 2 * (12 + row), acc);
+            }
+            break;
+        }
+        case VPBS_GATE_ARITHMETIC_EXT:
+            walg(r, 8 * sub + 6, gates::scale(ralg(r, 8 * sub) * ralg(r, 8 * sub + 2), c[0]) + gates::scale(ralg(r, 8 * sub + 4), c[1]));
+            break;
+        case VPBS_GATE_MUL_EXT: walg(r, 6 * sub + 4, gates::scale(ralg(r, 6 * sub) * ralg(r, 6 * sub + 2), c[0])); break;
+        case VPBS_GATE_REDUCING:
+        case VPBS_GATE_REDUCING_EXT: {
+            const bool ext = g.kind == VPBS_GATE_REDUCING_EXT;
+            const unsigned n = g.p0, start_accs = ext ? 6 + 2 * n : 6 + n;
+            const A alpha = ralg(r, 2);
+            A acc = ralg(r, 4);
+            for (unsigned i = 0; i < n; ++i) {
+                const A coeff = ext ? ralg(r, 6 + 2 * i) : A{r.get(6 + i), 0};
+                acc = acc * alpha + coeff;
+                walg(r, i == n - 1 ? 0 : start_accs + 2 * i, acc);
+            }
+            break;
+        }
+        case VPBS_GATE_RANDOM_ACCESS: {
+            const unsigned bits = g.p0, vec = 1u << bits, routed = (2 + vec) * g.p1 + g.p2;
+            if (sub >= g.p1) {  // RandomAccessExtraConstantsGenerator
+                const unsigned i = sub - g.p1;
+                r.set((2 + vec) * g.p1 + i, c[i]);
+                break;
+            }
+            const unsigned base = (2 + vec) * sub;
+            const u64 idx = r.get(base);
+            if (idx >= vec) throw GenError{"RandomAccessGate: access index out of range"};
+            r.set(base + 1, r.get(base + 2 + (unsigned)idx));
+            for (unsigned b = 0; b < bits; ++b) r.set(routed + sub * bits + b, (idx >> b) & 1);
+            break;
+        }
+        case VPBS_GATE_EXPONENTIATION: {
+            const unsigned n = g.p0;
+            const u64 base = r.get(0);
+            u64 prev = 1;
+            for (unsigned i = 0; i < n; ++i) {
+                const u64 sq = i == 0 ? 1 : gl::mul(prev, prev);
+                const u64 bit = r.get(1 + (n - 1 - i));
+                if (bit > 1) throw GenError{"ExponentiationGate: power bit is not boolean"};
+                prev = bit ? gl::mul(sq, base) : sq;
+                r.set(2 + n + i, prev);
+            }
+            r.set(1 + n, prev);
+            break;
+        }
+        case VPBS_GATE_COSET_INTERPOLATION: {
+            const unsigned points = 1u << g.p0, degree = g.p1, ni = (points - 2) / (degree - 1);
+            const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
+            const unsigned start_shifted = start_inter + 4 * ni;
+            const u64 shift = r.get(0);
+            if (shift == 0) throw GenError{"CosetInterpolationGate: zero shift"};
+            const gates::CosetTables t = gates::coset_tables(g.p0);
+            const A shifted = gates::scale(ralg(r, start_point), gl::inv(shift));
+            walg(r, start_shifted, shifted);
+            A eval{0, 0}, prod{1, 0};
+            auto run = [&](unsigned from, unsigned to) {
+                for (unsigned i = from; i < to; ++i) {
+                    const A term = gates::sub_base(shifted, t.domain[i]);
+                    eval = eval * term + gates::scalec(ralg(r, 1 + 2 * i), t.weights[i]) * prod;
+                    prod = prod * term;
+                }
+            };
+            run(0, std::min(degree, points));
+            for (unsigned i = 0; i < ni; ++i) {
+                walg(r, start_inter + 2 * i, eval);
+                walg(r, start_inter + 2 * (ni + i), prod);
+                const unsigned from = 1 + (degree - 1) * (i + 1);
+                run(from, std::min(from + degree - 1, points));
+            }
+            walg(r, start_value, eval);
+            break;
+        }
+        default: break;
+    }
+}
+
+struct PlainRow {
+    u64* w;
+    u64 get(unsigned i) const { return w[i]; }
+    void set(unsigned i, u64 v) { w[i] = v; }
+};
+
+// ---- the copy-constraint partition (plonk/copy_constraint.rs + permutation_argument.rs Forest) ----
+struct Partition {
+    std::vector<u32> parent;
+    explicit Partition(size_t n) : parent(n) { std::iota(parent.begin(), parent.end(), 0u); }
+    u32 find(u32 x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    }
+    void merge(u32 a, u32 b) {
+        a = find(a);
+        b = find(b);
+        if (a != b) parent[a] = b;
+    }
+};
+
+bool check_circuit(const vpbs_circuit* c) {
+    if (!c || !c->gates || !c->n_gates || !c->row_gate || c->log_n == 0 || c->log_n > 24 || c->n_routed > c->n_wires) return false;
+    if (c->n_copies && !c->copies) return false;
+    const size_t n = (size_t)1 << c->log_n;
+    for (size_t r = 0; r < n; ++r)
+        if (c->row_gate[r] >= c->n_gates) return false;
+    for (size_t i = 0; i < 2 * c->n_copies; ++i)
+        if (c->copies[i] >= (size_t)c->n_routed * n) return false;
+    for (unsigned i = 0; i < c->n_gates; ++i)
+        if (c->gates[i].num_wires > c->n_wires) return false;
+    return true;
+}
+}  // namespace
+}  // namespace vpbs
+
+extern "C" {
+
+int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t* row) {
+    if (!gp || !row) return VPBS_ERR_INVALID;
+    vpbs_gate g = *gp;
+    if (vpbs_gate_default_params(&g) != VPBS_OK) return VPBS_ERR_INVALID;
+    if (g.num_constants && !constants) return VPBS_ERR_INVALID;
+    vpbs::PlainRow r{row};
+    try {
+        for (unsigned sub = 0; sub < vpbs::gen_count(g); ++sub) vpbs::gen_run(g, sub, constants, r);
+    } catch (const vpbs::GenError&) {
+        return VPBS_ERR_INVALID;
+    }
+    return VPBS_OK;
+}
+
+int vpbs_selector_columns(const vpbs_circuit* c, uint64_t* out) {
+    if (!vpbs::check_circuit(c) || !out) return VPBS_ERR_INVALID;
+    const size_t n = (size_t)1 << c->log_n;
+    for (unsigned s = 0; s < c->num_selectors; ++s)
+        for (size_t r = 0; r < n; ++r) {
+            const vpbs_gate& g = c->gates[c->row_gate[r]];
+            out[s * n + r] = g.selector_index == s ? g.index : VPBS_UNUSED_SELECTOR;
+        }
+    return VPBS_OK;
+}
+
+int vpbs_sigma_values(const vpbs_circuit* c, uint64_t* out) {
+    if (!vpbs::check_circuit(c) || !out) return VPBS_ERR_INVALID;
+    using namespace vpbs;
+    const size_t n = (size_t)1 << c->log_n, total = (size_t)c->n_routed * n;
+    Partition part(total);
+    for (size_t i = 0; i < c->n_copies; ++i) part.merge(c->copies[2 * i], c->copies[2 * i + 1]);
+    // subsets in WirePartition order: members sorted by (row, column); sigma maps each member to the next, cyclically
+    std::vector<u32> order(total);
+    std::iota(order.begin(), order.end(), 0u);
+    auto key = [&](u32 p) { return ((u64)(p % n) << 32) | (u64)(p / n); };
+    std::vector<std::pair<u64, u32>> tagged;  // (representative, position) for positions in non-trivial subsets
+    std::vector<u32> size(total, 0);
+    for (u32 p = 0; p < total; ++p) ++size[part.find(p)];
+    for (u32 p = 0; p < total; ++p)
+        if (size[part.find(p)] > 1) tagged.push_back({part.find(p), p});
+    std::sort(tagged.begin(), tagged.end(), [&](const auto& a, const auto& b) {
+        return a.first != b.first ? a.first < b.first : key(a.second) < key(b.second);
+    });
+    std::vector<u32> sigma(total);
+    std::iota(sigma.begin(), sigma.end(), 0u);
+    for (size_t i = 0; i < tagged.size();) {
+        size_t j = i;
+        while (j < tagged.size() && tagged[j].first == tagged[i].first) ++j;
+        for (size_t k = i; k < j; ++k) sigma[tagged[k].second] = tagged[k + 1 < j ? k + 1 : i].second;
+        i = j;
+    }
+    std::vector<u64> subgroup(n), k_is(c->n_routed);
+    const u64 w = gl::root_of_unity(c->log_n);
+    u64 x = 1;
+    for (size_t i = 0; i < n; ++i, x = gl::mul(x, w)) subgroup[i] = x;
+    x = 1;
+    for (unsigned j = 0; j < c->n_routed; ++j, x = gl::mul(x, gl::GENERATOR)) k_is[j] = x;
+    for (size_t p = 0; p < total; ++p) out[p] = gl::mul(k_is[sigma[p] / n], subgroup[sigma[p] % n]);
+    return VPBS_OK;
+}
+
+int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
+                          uint64_t* wires_out, char* err, size_t err_len) {
+    auto fail = [&](const std::string& m) {
+        if (err && err_len) {
+            std::strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return VPBS_ERR_INVALID;
+    };
+    if (!vpbs::check_circuit(c) || !wires_out || (n_preset && (!preset_pos || !preset_val))) return fail("malformed circuit description");
+    using namespace vpbs;
+    const size_t n = (size_t)1 << c->log_n, total = (size_t)c->n_wires * n, routed = (size_t)c->n_routed * n;
+    unsigned max_consts = 0;
+    for (unsigned i = 0; i < c->n_gates; ++i) max_consts = std::max(max_consts, c->gates[i].num_constants);
+    if (c->num_selectors + max_consts > c->n_constants_cols || (max_consts && !c->constants)) return fail("constants columns missing");
+    Partition part(total);  // advice wires (>= routed) are singletons
+    for (size_t i = 0; i < c->n_copies; ++i) part.merge(c->copies[2 * i], c->copies[2 * i + 1]);
+    (void)routed;
+    std::vector<u64> val(total, 0);
+    std::vector<uint8_t> is_set(total, 0);
+    std::string error;
+    auto set_pos = [&](u32 p, u64 v) {
+        const u32 r = part.find(p);
+        if (v >= gl::P) v -= gl::P;
+        if (is_set[r] && val[r] != v && error.empty())
+            error = "partition containing wire (column " + std::to_string(p / n) + ", row " + std::to_string(p % n) +
+                    ") was set twice with different values";
+        val[r] = v;
+        is_set[r] = 1;
+    };
+    for (size_t i = 0; i < n_preset; ++i) {
+        if (preset_pos[i] >= total) return fail("preset position out of range");
+        set_pos(preset_pos[i], preset_val[i]);
+    }
+    if (!error.empty()) return fail(error);
+    struct RowAcc {
+        size_t n, row;
+        Partition& part;
+        std::vector<u64>& val;
+        decltype(set_pos)& setter;
+        u64 get(unsigned w) { return val[part.find((u32)(w * n + row))]; }
+        void set(unsigned w, u64 v) { setter((u32)(w * n + row), v); }
+    };
+    struct Pending {
+        u32 row, sub;
+    };
+    std::vector<Pending> pending;
+    for (size_t r = 0; r < n; ++r)
+        for (unsigned sub = 0; sub < gen_count(c->gates[c->row_gate[r]]); ++sub) pending.push_back({(u32)r, sub});
+    std::vector<unsigned> deps;
+    std::vector<u64> consts(std::max(1u, max_consts));
+    // generate_partial_witness: run whatever is ready until nothing changes
+    while (!pending.empty()) {
+        std::vector<Pending> later;
+        for (const Pending& p : pending) {
+            const vpbs_gate& g = c->gates[c->row_gate[p.row]];
+            gen_deps(g, p.sub, deps);
+            bool ready = true;
+            for (unsigned w : deps)
+                if (!is_set[part.find((u32)(w * n + p.row))]) {
+                    ready = false;
+                    break;
+                }
+            if (!ready) {
+                later.push_back(p);
+                continue;
+            }
+            for (unsigned k = 0; k < g.num_constants; ++k) consts[k] = c->constants[(size_t)(c->num_selectors + k) * n + p.row];
+            RowAcc acc{n, p.row, part, val, set_pos};
+            try {
+                gen_run(g, p.sub, consts.data(), acc);
+            } catch (const GenError& e) {
+                return fail(e.what + " (row " + std::to_string(p.row) + ")");
+            }
+            if (!error.empty()) return fail(error);
+        }
+        if (later.size() == pending.size())  // generate_partial_witness: assert_eq!(remaining_generators, 0, "{} generators weren't run")
+            return fail(std::to_string(later.size()) + " generators weren't run (first: row " + std::to_string(later[0].row) + ")");
+        pending.swap(later);
+    }
+    // full_witness: every wire takes its representative's value (unset -> 0)
+    for (size_t p = 0; p < total; ++p) wires_out[p] = val[part.find((u32)p)];
+    if (err && err_len) err[0] = 0;
+    return VPBS_OK;
+}
+
+}  // extern "C"
