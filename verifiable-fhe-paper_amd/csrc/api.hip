@@ -667,7 +667,7 @@ void vpbs_challenger_init(vpbs_challenger_state* ch) { std::memset(ch, 0, sizeof
 static void duplexing(vpbs_challenger_state* ch) {
     for (uint32_t i = 0; i < ch->input_len; ++i) ch->sponge[i] = ch->input[i];  // overwrite mode
     ch->input_len = 0;
-    poseidon::permute(ch->sponge);
+    poseidon::permute_host(ch->sponge);
     for (int i = 0; i < 8; ++i) ch->output[i] = ch->sponge[i];
     ch->output_len = 8;
 }

@@ -636,9 +636,9 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         }
 
         // prove(): public_inputs_hash, wires commitment, transcript
-        HashOut pi_hash;
-        vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
         PolynomialBatch wires = PolynomialBatch::from_values(ctx, d_wires, in->n_wires, log_n, false, comm);
+        HashOut pi_hash;  // hashed on the host while the device works on the wires commitment
+        vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
         wires.merkle_cap(caps_out, comm);
         Challenger challenger;
         challenger.observe_elements(in->circuit_digest, 4);
