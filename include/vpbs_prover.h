@@ -91,6 +91,10 @@ void vpbs_challenger_observe(vpbs_challenger_state* ch, const uint64_t* elems, s
 uint64_t vpbs_challenger_get(vpbs_challenger_state* ch);                                 /* get_challenge   */
 /* PoseidonHash::hash_no_pad on the host (public-input hash, small inputs) */
 void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]);
+/* the hash chain of verify_hash_output (/root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78): h_0 = 0^4,
+ * h_{k+1} = hash_no_pad(h_k || item_k) over n_items items of item_len elements each (row-major); host only.
+ * returns 1 if the chain ends in `claimed` (or claimed == NULL: just computes), 0 otherwise; out may be NULL. */
+int vpbs_hash_chain(const uint64_t* items, size_t n_items, size_t item_len, const uint64_t claimed[4], uint64_t out[4]);
 
 /* ---- FRI (plonky2 fri/oracle.rs prove_openings -> fri/prover.rs fri_proof) ---- */
 typedef struct {

@@ -179,3 +179,19 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
         flat[pos] = (int(flat[pos]) + 1) % P
         assert not api.verify_step(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
     assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs
+
+
+def test_hash_chain_matches_oracle_and_reference_semantics():
+    """verify_hash_output (/root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78): h <- hash_no_pad(h || item) from h = 0."""
+    rng = np.random.default_rng(3)
+    for n_items, item_len in [(1, 1), (3, 5), (4, 12), (2, 100), (5, 4)]:
+        items = rng.integers(0, P, size=(n_items, item_len), dtype=np.uint64)
+        want = np.zeros(4, np.uint64)
+        orc.lib().orc_hash_chain(orc.ptr(np.ascontiguousarray(items)), n_items, item_len, orc.ptr(want))
+        h = np.zeros(4, np.uint64)
+        for k in range(n_items):   # the reference's loop, with the product's own hash_no_pad
+            h = api.hash_no_pad(np.concatenate([h, items[k]]))
+        got, ok = api.hash_chain(items, claimed=want)
+        assert ok and (got == want).all() and (h == want).all()
+        bad = want.copy(); bad[0] ^= np.uint64(1)
+        assert not api.hash_chain(items, claimed=bad)[1]

@@ -120,6 +120,7 @@ SIGNATURES = {
     "vpbs_challenger_observe": (None, [C.POINTER(ChallengerStateC), U64P, _sz]),
     "vpbs_challenger_get": (_u64, [C.POINTER(ChallengerStateC)]),
     "vpbs_hash_no_pad": (None, [U64P, _sz, U64P]),
+    "vpbs_hash_chain": (_i, [U64P, _sz, _sz, U64P, U64P]),
     "vpbs_fri_params_standard": (None, [_ui, C.POINTER(FriParams)]),
     "vpbs_fri_proof_words": (_sz, [C.POINTER(FriParams), _ui, C.POINTER(_sz), _sz]),
     "vpbs_fri_prove": (_i, [_vp, C.POINTER(_vp), _sz, C.POINTER(FriInstanceC), C.POINTER(FriParams),
@@ -333,6 +334,17 @@ class Circuit:
         if rc:
             raise VpbsError("vpbs_generate_witness: " + err.value.decode())
         return out
+
+
+def hash_chain(items, claimed=None):
+    """verify_hash_output of the reference (ivc_based_vpbs.rs:64-78): -> (chain hash, matches claimed)"""
+    it = _u64(items)
+    out = np.zeros(4, np.uint64)
+    cl = _u64(claimed) if claimed is not None else None
+    rc = lib().vpbs_hash_chain(_ptr(it), it.shape[0], it.shape[1], _ptr(cl) if cl is not None else None, _ptr(out))
+    if rc < 0:
+        raise VpbsError("vpbs_hash_chain failed")
+    return out, rc == 1
 
 
 def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=False, n_constants=0,

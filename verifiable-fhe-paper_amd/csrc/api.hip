@@ -684,4 +684,25 @@ uint64_t vpbs_challenger_get(vpbs_challenger_state* ch) {
 }
 void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) { poseidon::hash_no_pad_host(in, n, out); }
 
+int vpbs_hash_chain(const uint64_t* items, size_t n_items, size_t item_len, const uint64_t claimed[4], uint64_t out[4]) {
+    if (n_items && !items) return VPBS_ERR_INVALID;
+    u64 h[4] = {0, 0, 0, 0};
+    u64 s[12];
+    for (size_t k = 0; k < n_items; ++k) {
+        // hash_no_pad(h || item): overwrite-mode sponge over the 4 + item_len elements, without materialising the concatenation
+        for (int i = 0; i < 12; ++i) s[i] = 0;
+        const u64* item = items + k * item_len;
+        const size_t total = 4 + item_len;
+        for (size_t off = 0; off < total; off += 8) {
+            const size_t len = total - off < 8 ? total - off : 8;
+            for (size_t i = 0; i < len; ++i) s[i] = off + i < 4 ? h[off + i] : item[off + i - 4];
+            poseidon::permute_host(s);
+        }
+        for (int i = 0; i < 4; ++i) h[i] = s[i];
+    }
+    if (out) std::memcpy(out, h, sizeof h);
+    if (!claimed) return 1;
+    return std::memcmp(h, claimed, sizeof h) == 0 ? 1 : 0;
+}
+
 }  // extern "C"
