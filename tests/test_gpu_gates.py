@@ -248,3 +248,67 @@ def test_product_witness_to_proof(ctx):
     assert not api.verify_step(proof, cs.cap(), ncols, DIGEST, [pis[0] ^ 1] + pis[1:], log_n, check_permutation=True, n_constants=n_constants,
                                n_routed=n_routed, gates=ps)
     cs.free()
+
+
+def test_bsk_hash_subcircuit_of_the_step_circuit(ctx):
+    """The bootstrapping-key hash of the reference's step circuit (/root/reference/src/vtfhe/ivc_based_vpbs.rs:126-133:
+    current_bsk_hash_out = hash_n_to_hash_no_pad(current_bsk_hash_in || ggsw.flatten()), registered as public inputs) as a circuit of
+    its own, at the paper's parameters (K = 2, ELL = 4, N = 1024: 4 + 16384 elements -> 2049 chained PoseidonGate rows, overwrite-mode
+    sponge through copy constraints).  Witness generated by the product (vpbs_generate_witness), proof on the GPU, verified by the
+    product's verifier; the public inputs equal the native chain hash of verify_hash_output (ivc_based_vpbs.rs:64-78)."""
+    spec = ["noop", "public_input", "poseidon"]
+    gs, ps = go.GateSet(spec), api.GateSet(spec)
+    K, ELL, N = 2, 4, 1024
+    item = synth.field_elements(0xB5C, K * ELL * K * N)             # Ggsw::flatten() of one bootstrapping-key element
+    h_in = np.zeros(4, np.uint64)                                    # current_bsk_hash_in of the first CMUX step
+    data = np.concatenate([h_in, item])
+    n_chunks = (data.size + 7) // 8
+    log_n = 12
+    n = 1 << log_n
+    pos_gate, pi_gate, noop = ps.by_kind("poseidon"), ps.by_kind("public_input"), ps.by_kind("noop")
+    row_gate = np.full(n, noop.index, np.uint32)
+    row_gate[0] = pi_gate.index
+    row_gate[1:2 + n_chunks] = pos_gate.index                       # rows 1..n_chunks: the sponge; row n_chunks + 1: public-input hash
+    presets, copies = {}, []
+    P_ = lambda c, r: c * n + r
+    for k in range(n_chunks):
+        r = 1 + k
+        chunk = data[8 * k:8 * k + 8]
+        for i in range(12):
+            if i < chunk.size:
+                presets[(i, r)] = int(chunk[i])                      # overwrite mode: the new block
+            elif k == 0:
+                presets[(i, r)] = 0                                  # initial state
+            else:
+                copies.append((P_(12 + i, r - 1), P_(i, r)))        # the rest of the state carries over
+        presets[(24, r)] = 0                                         # swap
+    r_pi = 1 + n_chunks
+    for i in range(12):
+        if i < 4:
+            copies.append((P_(12 + i, r_pi - 1), P_(i, r_pi)))      # public inputs = the hash output ...
+            copies.append((P_(12 + i, r_pi), P_(i, 0)))             # ... and their hash feeds the PublicInputGate
+        else:
+            presets[(i, r_pi)] = 0
+    presets[(24, r_pi)] = 0
+    constants = np.zeros((ps.num_selectors + max(1, ps.num_constants), n), np.uint64)
+    circ = api.Circuit(ps, log_n, row_gate, constants, copies)
+    constants[:ps.num_selectors] = circ.selector_columns()
+    circ = api.Circuit(ps, log_n, row_gate, constants, copies)
+    wires = circ.generate_witness(presets)
+    out = wires[12:16, r_pi - 1]
+    native, ok = api.hash_chain(item[None, :], claimed=out)         # verify_hash_output with one item
+    assert ok and (native == out).all() and (native == orc.hash_no_pad(data)).all()
+    pis = [int(x) for x in out]
+    assert [int(wires[i, 0]) for i in range(4)] == [int(x) for x in api.hash_no_pad(out)]
+    sigma = circ.sigma_values()
+    n_constants, n_routed = constants.shape[0], 80
+    cs = ctx.commit_values(np.concatenate([constants, sigma]))
+    si = ctx.make_step_inputs(log_n, wires, None, None, cs, DIGEST, pis, sigmas=sigma, n_routed=n_routed, n_constants=n_constants, gates=ps)
+    proof = ctx.prove_step(si)
+    ncols = [n_constants + n_routed, 135, 20, 16]
+    assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants, n_routed=n_routed, gates=ps)
+    assert step_oracle.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n)
+    wrong = list(pis); wrong[2] ^= 1
+    assert not api.verify_step(proof, cs.cap(), ncols, DIGEST, wrong, log_n, check_permutation=True, n_constants=n_constants,
+                               n_routed=n_routed, gates=ps)
+    cs.free()
