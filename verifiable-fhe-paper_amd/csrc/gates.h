@@ -357,7 +357,7 @@ template <class F, class V, class S> GATES_FN void eval_coset_interpolation(cons
     }
     push_alg(s, wire_alg<F>(v, start_value) - eval);
 }
-inline CosetTables coset_tables(unsigned bits) {
+inline CosetTables make_coset_tables(unsigned bits) {
     CosetTables t{};
     const unsigned n = 1u << bits;
     const u64 g = gl::root_of_unity(bits);
@@ -370,6 +370,12 @@ inline CosetTables coset_tables(unsigned bits) {
         t.weights[i] = gl::inv(d);
     }
     return t;
+}
+// computed once per subgroup size (the inversions cost tens of microseconds of host time, and the prover asks every step)
+inline const CosetTables& coset_tables(unsigned bits) {
+    static const CosetTables tables[6] = {make_coset_tables(0), make_coset_tables(1), make_coset_tables(2),
+                                          make_coset_tables(3), make_coset_tables(4), make_coset_tables(5)};
+    return tables[bits <= 5 ? bits : 0];
 }
 
 // gates/gate.rs compute_filter: prod_{i in group, i != index} (i - s) [* (UNUSED_SELECTOR - s) with several selectors]
