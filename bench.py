@@ -269,6 +269,7 @@ def main():
                          "traffic": traffic, "kernel_ms_per_step": per_step_ms, "launches": dominant["count"],
                          "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation; valu_* = achieved "
                                  "lane-ops/s vs 256CU*4SIMD*32 lanes*2.4GHz" % LEAF_HASH_INSTR_PER_PERM,
+                         "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
                          "valu_achieved_tlaneops": valu_rate, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS,
                          "valu_frac": valu_rate / VALU_PEAK_TLANEOPS},
             "kernel_ms_one_step": breakdown,
