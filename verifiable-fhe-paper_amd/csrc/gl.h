@@ -195,6 +195,31 @@ GL_HD void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64& q) {
 }
 #endif
 GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
+
+// x * 2^24, x * 2^48, x * 2^72 (canonical in and out).  These are the 8th roots of unity up to sign: w_8 = 2^120 = -2^24,
+// w_8^2 = w_4 = 2^48, w_8^3 = -2^72 (2^96 = -1), so a radix-8 NTT butterfly needs shifts, not multiplications, inside.
+GL_HD u64 mul_2e24(u64 x) {
+    const u64 lo = x << 24, hi = x >> 40;      // x 2^24 = lo + hi 2^64 = lo + hi (2^32 - 1)
+    const u64 t = (hi << 32) - hi;             // < 2^56
+    u64 r = lo + t;
+    if (r < t) r += EPS;                       // wrapped: the true sum was r + 2^64
+    return canon(r);
+}
+GL_HD u64 mul_2e48(u64 x) {
+    const u64 lo = x << 48, h = x >> 16;       // x 2^48 = lo + h 2^64, h = h1 2^32 + h0 -> h0 (2^32 - 1) - h1   (2^96 = -1)
+    const u64 h0 = h & EPS, h1 = h >> 32;
+    const u64 t = (h0 << 32) - h0;             // < 2^64 - 2^33 + 1
+    u64 r = lo + t;
+    if (r < t) r += EPS;
+    r = canon(r);
+    return sub(r, h1);
+}
+GL_HD u64 mul_2e72(u64 x) {
+    // x 2^72 = (x 2^8) 2^64, x 2^8 = c 2^64 + b 2^32 + a  ->  a (2^32 - 1) - b - c 2^32   (2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32)
+    const u64 a = (x << 8) & EPS, b = (x >> 24) & EPS, c = x >> 56;
+    const u64 pos = (a << 32) - a;             // <= (2^32 - 1)^2 < p
+    return sub(pos, b + (c << 32));            // b + c 2^32 < 2^40
+}
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 
 GL_HD u64 pow(u64 b, u64 e) {

@@ -10,7 +10,7 @@ using gl::u32;
 using gl::u64;
 
 // ---------- ntt.hip ----------
-// roots[j] = w^j, j < n/2, w = primitive n-th root (or its inverse for the inverse transform)
+// roots[j] = w^j, j < n, w = primitive n-th root (or its inverse for the inverse transform)
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse);
 // prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n
 void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift);
