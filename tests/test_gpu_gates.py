@@ -312,3 +312,18 @@ def test_bsk_hash_subcircuit_of_the_step_circuit(ctx):
     assert not api.verify_step(proof, cs.cap(), ncols, DIGEST, wrong, log_n, check_permutation=True, n_constants=n_constants,
                                n_routed=n_routed, gates=ps)
     cs.free()
+
+
+def test_cxx_circuit_example(ctx):
+    """examples/prove_bsk_hash.cpp: the same bootstrapping-key hash circuit driven from plain C++ through the C ABI only (layout,
+    selector columns, sigma values, witness generation, commit, prove with gates, verify): exits 0 and prints the hash that
+    vpbs_hash_chain / the oracle compute natively."""
+    import subprocess
+    import __graft_entry__ as entry
+    exe = entry.build_example("prove_bsk_hash")
+    r = subprocess.run([exe, "2", "2", "64"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "proof verified: 1; with a wrong public input: 0" in r.stdout
+    item = synth.field_elements(0xB5C, 2 * 2 * 2 * 64)
+    want = orc.hash_no_pad(np.concatenate([np.zeros(4, np.uint64), item]))
+    assert " ".join("%016x" % int(x) for x in want) in r.stdout
