@@ -66,6 +66,23 @@ __global__ void eval_finish_kernel(const u64* __restrict__ partial, unsigned chu
     store_ext(out, c, acc);
 }
 
+// the same for several coefficient matrices in one launch (the openings of a step proof: four oracles at zeta + the Z columns
+// at g zeta): blockIdx.y = global column over all segments
+__global__ void __launch_bounds__(THREADS)
+eval_partial_multi_kernel(EvalSegments segs, size_t n, unsigned chunk_len, u64* __restrict__ partial) {
+    __shared__ u64 sh[2 * THREADS];
+    unsigned c = blockIdx.y, k = 0;
+    while (k + 1 < segs.count && c >= segs.seg[k].ncols) c -= segs.seg[k++].ncols;
+    const u64* col = segs.seg[k].coeffs + (size_t)c * segs.seg[k].col_stride;
+    const u64* zpow = segs.seg[k].zpow;
+    const size_t begin = (size_t)blockIdx.x * chunk_len;
+    gl::Ext acc = gl::ext(0);
+    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS)
+        acc = gl::add(acc, gl::mul(load_ext(zpow, i), col[i]));
+    const gl::Ext tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) store_ext(partial, (size_t)blockIdx.y * gridDim.x + blockIdx.x, tot);
+}
+
 // grid (n / 256, groups): each workgroup row sums a slice of the polynomials (n = 2^15 coefficients alone would leave the
 // chip at half a wave per SIMD); the slices are added by combine_finish_kernel.
 __global__ void __launch_bounds__(THREADS)
@@ -197,6 +214,16 @@ void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n,
     u64* partial = out + 2 * (size_t)ncols;
     hipLaunchKernelGGL(eval_partial_kernel, dim3(chunks, ncols), dim3(THREADS), 0, s, coeffs, n, col_stride, zpow, chunk_len, partial);
     hipLaunchKernelGGL(eval_finish_kernel, dim3((ncols + 63) / 64), dim3(64), 0, s, (const u64*)partial, chunks, ncols, out);
+}
+
+void launch_eval_ext_multi(hipStream_t s, const EvalSegments& segs, size_t n, u64* out) {
+    const unsigned chunk_len = 4096;
+    const unsigned chunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    unsigned total = 0;
+    for (unsigned k = 0; k < segs.count; ++k) total += segs.seg[k].ncols;
+    u64* partial = out + 2 * (size_t)total;
+    hipLaunchKernelGGL(eval_partial_multi_kernel, dim3(chunks, total), dim3(THREADS), 0, s, segs, n, chunk_len, partial);
+    hipLaunchKernelGGL(eval_finish_kernel, dim3((total + 63) / 64), dim3(64), 0, s, (const u64*)partial, chunks, total, out);
 }
 
 void launch_combine(hipStream_t s, const u64* const* polys, unsigned n_polys, const u64* alpha_pows, size_t n, u64* f0, u64* f1,

@@ -97,6 +97,18 @@ void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, uns
 void launch_ext_powers(hipStream_t s, const gl::Ext* points, unsigned count, size_t n, u64* out);
 // out[c] = sum_i coeffs[c][i] * zpow[i]   (p.to_extension().eval(z)); out AoS [ncols][2]
 void launch_eval_ext(hipStream_t s, const u64* coeffs, unsigned ncols, size_t n, size_t col_stride, const u64* zpow, u64* out);
+// the same for up to 8 coefficient matrices ("segments", each with its own point-power table) in ONE pair of launches; results
+// for all columns back to back: out [sum ncols][2], followed by scratch for [sum ncols * ceil(n / 4096)][2] partial sums
+struct EvalSegments {
+    struct Seg {
+        const u64* coeffs;
+        const u64* zpow;
+        size_t col_stride;
+        unsigned ncols;
+    } seg[8];
+    unsigned count;
+};
+void launch_eval_ext_multi(hipStream_t s, const EvalSegments& segs, size_t n, u64* out);
 // F[i] = sum_j alpha^j * poly_j[i]  (ReducingFactor::reduce_polys_base); polys: device array of column pointers;
 // alpha_pows AoS [n_polys][2]; F SoA (f0[n], f1[n])
 // partial_scratch: 2 * COMBINE_GROUPS * n device words

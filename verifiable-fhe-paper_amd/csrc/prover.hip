@@ -713,27 +713,13 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             Timed t(ctx, "openings_eval");
             const Ext pts[2] = {zeta, zeta_next};
             vpbs::launch_ext_powers(s, pts, 2, n, zpow);
-            size_t col = 0;
-            for (auto* o : oracles) {
-                // results for this oracle at d_open[2*col ..]; partial sums behind the block of final results
-                vpbs::launch_eval_ext(s, o->d_coeffs, o->ncols, n, n, zpow, d_open + 2 * col * (size_t)(1 + chunks));
-                col += o->ncols;
-            }
-            vpbs::launch_eval_ext(s, zs_pp.h->d_coeffs, nc, n, n, znpow, d_open + 2 * col * (size_t)(1 + chunks));
+            // every oracle at zeta and the Z columns at g * zeta in one pair of launches; results land in openings order
+            vpbs::EvalSegments segs{};
+            for (auto* o : oracles) segs.seg[segs.count++] = {o->d_coeffs, zpow, n, o->ncols};
+            segs.seg[segs.count++] = {zs_pp.h->d_coeffs, znpow, n, nc};
+            vpbs::launch_eval_ext_multi(s, segs, n, d_open);
         }
-        // gather the final results (each oracle block: [ncols][2] results followed by its partial sums)
-        std::vector<u64> h_open(2 * (total_cols + nc) * (size_t)(1 + chunks));
-        ctx->d2h_sync(h_open.data(), d_open, sizeof(u64) * h_open.size());
-        {
-            u64* w = openings_out;
-            size_t col = 0;
-            for (auto* o : oracles) {
-                std::memcpy(w, h_open.data() + 2 * col * (size_t)(1 + chunks), sizeof(u64) * 2 * o->ncols);
-                w += 2 * o->ncols;
-                col += o->ncols;
-            }
-            std::memcpy(w, h_open.data() + 2 * col * (size_t)(1 + chunks), sizeof(u64) * 2 * nc);
-        }
+        ctx->d2h_sync(openings_out, d_open, sizeof(u64) * 2 * (total_cols + nc));
         // challenger.observe_openings(&openings.to_fri_openings()): zeta batch then zeta_next batch
         challenger.observe_elements(openings_out, 2 * (total_cols + nc));
 
