@@ -231,7 +231,23 @@ GL_HD u64 pow(u64 b, u64 e) {
     }
     return r;
 }
-GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+// a^(p-2) with p - 2 = 2^64 - 2^32 - 1 = (2^32 - 2) 2^32 + (2^32 - 1): an addition chain on the exponents 2^k - 1
+// (k = 2, 3, 6, 12, 24, 30, 31, 32) -- 64 squarings + 9 multiplications instead of the 127 of square-and-multiply.  inv(0) = 0.
+GL_HD u64 inv(u64 a) {
+    auto sqn = [](u64 x, int n) {
+        for (int i = 0; i < n; ++i) x = mul_nc(x, x);
+        return x;
+    };
+    const u64 t2 = mul_nc(mul_nc(a, a), a);     // a^(2^2 - 1)
+    const u64 t3 = mul_nc(mul_nc(t2, t2), a);   // a^(2^3 - 1)
+    const u64 t6 = mul_nc(sqn(t3, 3), t3);
+    const u64 t12 = mul_nc(sqn(t6, 6), t6);
+    const u64 t24 = mul_nc(sqn(t12, 12), t12);
+    const u64 t30 = mul_nc(sqn(t24, 6), t6);
+    const u64 t31 = mul_nc(mul_nc(t30, t30), a);
+    const u64 t32 = mul_nc(mul_nc(t31, t31), a);  // a^(2^32 - 1)
+    return canon(mul_nc(sqn(t31, 33), t32));       // (a^(2^31 - 1))^(2^33) * a^(2^32 - 1)
+}
 GL_HD u64 root_of_unity(unsigned k) {  // primitive_root_of_unity(k)
     u64 g = TWO_ADIC_GENERATOR;
     for (unsigned i = k; i < TWO_ADICITY; ++i) g = mul(g, g);
