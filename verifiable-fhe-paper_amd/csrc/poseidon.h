@@ -118,7 +118,11 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
         const u64 k = kc ? kc[r] : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        u64 acc_lo = 0, acc_hi = 0;  // the constant joins below as a multiply-add by 1 on 32-bit scalars (see partial_group3_core)
+#else
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
+#endif
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             acc_lo += (u64)lo[(i + r) % 12] * C[i];
@@ -128,6 +132,14 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
             acc_lo += (u64)lo[0] * D8;
             acc_hi += (u64)hi[0] * D8;
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (kc)
+            asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
+                "v_mad_u64_u32 %1, vcc, %3, 1, %1"
+                : "+v"(acc_lo), "+v"(acc_hi)
+                : "s"((u32)k), "s"((u32)(k >> 32))
+                : "vcc");
+#endif
         s[r] = fold96(acc_lo, acc_hi);
     }
 }
@@ -181,7 +193,14 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const u64 k = kv[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // The group constant enters as one more multiply-add (k_half * 1) on a 32-bit scalar.  As the accumulators' initial value it
+        // needs a zero-extended SGPR PAIR per half: 48 SGPRs for the group, which hipcc spills to VGPR lanes and reads back with
+        // 48 v_readlane (+ wait states) per group.
+        u64 acc_lo = 0, acc_hi = 0;
+#else
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
+#endif
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             acc_lo += (u64)lo[j] * MDS3[i][j];
@@ -189,6 +208,13 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
         }
         acc_lo += (u64)d2l * MDS2[i][0] + (u64)d3l * MDS1[i][0];
         acc_hi += (u64)d2h * MDS2[i][0] + (u64)d3h * MDS1[i][0];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %3, 1, %1"
+            : "+v"(acc_lo), "+v"(acc_hi)
+            : "s"((u32)k), "s"((u32)(k >> 32))
+            : "vcc");
+#endif
         s[i] = fold96(acc_lo, acc_hi);
     }
 }
