@@ -40,6 +40,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py)
+# measured issue cost of the kernel's instruction mix on gfx950 (profiles/r01_microbench_valu.txt): half v_mad_u64_u32 at 4.89 cycles
+# per wave64, half other integer VALU at ~4.2; shader clock under this load 2.39 GHz (tools/sample_clocks.sh)
+INT_CYCLES_PER_INSTR, SCLK_HZ = 0.5 * 4.89 + 0.5 * 4.2, 2.39e9
 
 
 def leaf_hash_bytes_per_step():
@@ -271,7 +274,11 @@ def main():
                                  "lane-ops/s vs 256CU*4SIMD*32 lanes*2.4GHz" % LEAF_HASH_INSTR_PER_PERM,
                          "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
                          "valu_achieved_tlaneops": valu_rate, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS,
-                         "valu_frac": valu_rate / VALU_PEAK_TLANEOPS},
+                         "valu_frac": valu_rate / VALU_PEAK_TLANEOPS,
+                         # the same instruction stream priced at the MEASURED per-instruction issue costs of integer VALU on gfx950
+                         # (the fp32-FMA rate above is not reachable by integer VOP3 / v_mad_u64_u32): ~1.0 = no issue slack left
+                         "int_issue_frac": (perms * LEAF_HASH_INSTR_PER_PERM / (256 * 4 * 64) * INT_CYCLES_PER_INSTR / SCLK_HZ)
+                                           / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0},
             "kernel_ms_one_step": breakdown,
         }
         if world == 1 and n_chains == 1 and args.batch_chains > 1:
