@@ -37,12 +37,15 @@ GATES = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon
 N_CONSTANTS, N_ROUTED = 6, 80   # constants_sigmas = 4 selectors + 2 gate constants + 80 sigma columns
 COLS = dict(synth.STEP_COLS, constants_sigmas=N_CONSTANTS + N_ROUTED)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# full-rate 32-bit integer VALU issue: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz
-VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# VALU issue ceiling: a wave64 instruction occupies a 16-lane SIMD for 4 cycles (measured 4.1-4.2 for integer multiply / VOP3 / carry
+# ops AND for v_fma_f32 / v_fma_f64, profiles/r01_microbench_valu.txt; only trivial VOP2 integer ops and packed fp32 go faster):
+# 256 CUs x 4 SIMD x 16 lanes/clk x 2.4 GHz
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py)
-# measured issue cost of the kernel's instruction mix on gfx950 (profiles/r01_microbench_valu.txt): half v_mad_u64_u32 at 4.89 cycles
-# per wave64, half other integer VALU at ~4.2; shader clock under this load 2.39 GHz (tools/sample_clocks.sh)
-INT_CYCLES_PER_INSTR, SCLK_HZ = 0.5 * 4.89 + 0.5 * 4.2, 2.39e9
+# measured issue cost of the kernel's instruction mix on gfx950 (profiles/r01_microbench_valu.txt): half v_mad_u64_u32 at 4.61 cycles
+# per wave64, half other integer VALU (carry adds 4.56, cndmask / 64-bit shifts 4.2); shader clock under this load 2.39 GHz
+# (tools/sample_clocks.sh)
+INT_CYCLES_PER_INSTR, SCLK_HZ = 0.5 * 4.61 + 0.5 * 4.35, 2.39e9
 
 
 def leaf_hash_bytes_per_step():
@@ -271,7 +274,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms_per_step": per_step_ms, "launches": dominant["count"],
                          "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation; valu_* = achieved "
-                                 "lane-ops/s vs 256CU*4SIMD*32 lanes*2.4GHz" % LEAF_HASH_INSTR_PER_PERM,
+                                 "lane-ops/s vs 256CU*4SIMD*16 lanes*2.4GHz" % LEAF_HASH_INSTR_PER_PERM,
                          "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
                          "valu_achieved_tlaneops": valu_rate, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS,
                          "valu_frac": valu_rate / VALU_PEAK_TLANEOPS,

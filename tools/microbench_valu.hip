@@ -44,20 +44,58 @@ __global__ void __launch_bounds__(256) name(uint32_t* out, uint32_t seed) { \
     asm volatile(ins " %0, 3, %0" : "+v"(q4)); asm volatile(ins " %0, 3, %0" : "+v"(q5)); \
     asm volatile(ins " %0, 3, %0" : "+v"(q6)); asm volatile(ins " %0, 3, %0" : "+v"(q7));
 
-KERNEL_BEGIN(k_add_u32) OP32("v_add_u32") KERNEL_END
-KERNEL_BEGIN(k_xor_b32) OP32("v_xor_b32") KERNEL_END
-KERNEL_BEGIN(k_mul_lo_u32) OP32("v_mul_lo_u32") KERNEL_END
-KERNEL_BEGIN(k_mul_hi_u32) OP32("v_mul_hi_u32") KERNEL_END
-KERNEL_BEGIN(k_mul_u32_u24) OP32("v_mul_u32_u24") KERNEL_END
-KERNEL_BEGIN(k_mad_u32_u24) OP32_3("v_mad_u32_u24") KERNEL_END
-KERNEL_BEGIN(k_mad_u64_u32) OP64_MAD("v_mad_u64_u32") KERNEL_END
-KERNEL_BEGIN(k_lshlrev_b64) OP64_SHIFT("v_lshlrev_b64") KERNEL_END
-KERNEL_BEGIN(k_dot4_u32_u8) OP32_3("v_dot4_u32_u8") KERNEL_END
-KERNEL_BEGIN(k_add3_u32) OP32_3("v_add3_u32") KERNEL_END
-KERNEL_BEGIN(k_lshl_add_u32) OP32_3("v_lshl_add_u32") KERNEL_END
-KERNEL_BEGIN(k_mad_u32_u16) OP32_3("v_mad_u32_u16") KERNEL_END
-KERNEL_BEGIN(k_perm_b32) OP32_3("v_perm_b32") KERNEL_END
-KERNEL_BEGIN(k_alignbit) OP32_3("v_alignbit_b32") KERNEL_END
+#define R4(x) x x x x
+KERNEL_BEGIN(k_add_u32) R4(OP32("v_add_u32")) KERNEL_END
+KERNEL_BEGIN(k_xor_b32) R4(OP32("v_xor_b32")) KERNEL_END
+KERNEL_BEGIN(k_mul_lo_u32) R4(OP32("v_mul_lo_u32")) KERNEL_END
+KERNEL_BEGIN(k_mul_hi_u32) R4(OP32("v_mul_hi_u32")) KERNEL_END
+KERNEL_BEGIN(k_mul_u32_u24) R4(OP32("v_mul_u32_u24")) KERNEL_END
+KERNEL_BEGIN(k_mad_u32_u24) R4(OP32_3("v_mad_u32_u24")) KERNEL_END
+KERNEL_BEGIN(k_mad_u64_u32) R4(OP64_MAD("v_mad_u64_u32")) KERNEL_END
+KERNEL_BEGIN(k_lshlrev_b64) R4(OP64_SHIFT("v_lshlrev_b64")) KERNEL_END
+KERNEL_BEGIN(k_dot4_u32_u8) R4(OP32_3("v_dot4_u32_u8")) KERNEL_END
+KERNEL_BEGIN(k_add3_u32) R4(OP32_3("v_add3_u32")) KERNEL_END
+KERNEL_BEGIN(k_lshl_add_u32) R4(OP32_3("v_lshl_add_u32")) KERNEL_END
+KERNEL_BEGIN(k_mad_u32_u16) R4(OP32_3("v_mad_u32_u16")) KERNEL_END
+KERNEL_BEGIN(k_perm_b32) R4(OP32_3("v_perm_b32")) KERNEL_END
+KERNEL_BEGIN(k_alignbit) R4(OP32_3("v_alignbit_b32")) KERNEL_END
+
+KERNEL_BEGIN(k_and_b32) R4(OP32("v_and_b32")) KERNEL_END
+KERNEL_BEGIN(k_lshlrev_b32) R4(OP32("v_lshlrev_b32")) KERNEL_END
+KERNEL_BEGIN(k_sub_u32) R4(OP32("v_sub_u32")) KERNEL_END
+KERNEL_BEGIN(k_add_u32_e64) R4(OP32("v_add_u32_e64")) KERNEL_END
+KERNEL_BEGIN(k_max_u32) R4(OP32("v_max_u32")) KERNEL_END
+#define OP_ADDCO(dummy) \
+    asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a0) : "v"(b) : "vcc"); asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a1) : "v"(b) : "vcc"); \
+    asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a2) : "v"(b) : "vcc"); asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a3) : "v"(b) : "vcc"); \
+    asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a4) : "v"(b) : "vcc"); asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a5) : "v"(b) : "vcc"); \
+    asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a6) : "v"(b) : "vcc"); asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a7) : "v"(b) : "vcc");
+KERNEL_BEGIN(k_add_co) R4(OP_ADDCO(0)) KERNEL_END
+#define OP_CNDMASK32(dummy) \
+    asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a0) : "v"(b) : ); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a1) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a2) : "v"(b) : ); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a3) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a4) : "v"(b) : ); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a5) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a6) : "v"(b) : ); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a7) : "v"(b) : );
+KERNEL_BEGIN(k_cndmask_e32) R4(OP_CNDMASK32(0)) KERNEL_END
+#define OP_CNDMASK64(dummy) \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a0) : "v"(b) : ); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a1) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a2) : "v"(b) : ); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a3) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a4) : "v"(b) : ); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a5) : "v"(b) : ); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a6) : "v"(b) : ); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a7) : "v"(b) : );
+KERNEL_BEGIN(k_cndmask_e64) R4(OP_CNDMASK64(0)) KERNEL_END
+#define OP_LSHLADD64(dummy) \
+    asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q0)); asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q1)); \
+    asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q2)); asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q3)); \
+    asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q4)); asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q5)); \
+    asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q6)); asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q7));
+KERNEL_BEGIN(k_lshl_add_u64) R4(OP_LSHLADD64(0)) KERNEL_END
+#define OP_FMA64(dummy) \
+    asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q0)); asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q1)); \
+    asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q2)); asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q3)); \
+    asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q4)); asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q5)); \
+    asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q6)); asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(q7));
+KERNEL_BEGIN(k_fma_f64) R4(OP_FMA64(0)) KERNEL_END
+KERNEL_BEGIN(k_fma_f32) R4(OP32_3("v_fma_f32")) KERNEL_END
 
 // 64-bit add with carry chain: v_add_co_u32 + v_addc_co_u32 (counted as 2 instructions)
 __global__ void __launch_bounds__(256) k_add_u64(uint32_t* out, uint32_t seed) {
@@ -106,7 +144,10 @@ int main() {
         {"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_mad_u32_u24", k_mad_u32_u24, 8}, {"v_mad_u64_u32", k_mad_u64_u32, 8},
         {"v_lshlrev_b64", k_lshlrev_b64, 8}, {"v_dot4_u32_u8", k_dot4_u32_u8, 8}, {"v_add3_u32", k_add3_u32, 8},
         {"v_lshl_add_u32", k_lshl_add_u32, 8}, {"v_mad_u32_u16", k_mad_u32_u16, 8}, {"v_perm_b32", k_perm_b32, 8}, {"v_alignbit_b32", k_alignbit, 8},
-        {"add_u64(2 instr)", k_add_u64, 8}, {"gl_mul(modmul)", k_gl_mul, 8},
+        {"v_and_b32", k_and_b32, 8}, {"v_lshlrev_b32", k_lshlrev_b32, 8}, {"v_sub_u32", k_sub_u32, 8}, {"v_add_u32_e64", k_add_u32_e64, 8},
+        {"v_max_u32", k_max_u32, 8}, {"v_add_co_u32_e32", k_add_co, 8}, {"v_cndmask_b32_e32", k_cndmask_e32, 8}, {"v_cndmask_b32_e64", k_cndmask_e64, 8},
+        {"v_lshl_add_u64", k_lshl_add_u64, 8}, {"v_fma_f64", k_fma_f64, 8}, {"v_fma_f32", k_fma_f32, 8},
+        {"add_u64(2 instr)", k_add_u64, 2}, {"gl_mul(modmul)", k_gl_mul, 2},
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (auto& e : es) {
@@ -119,7 +160,7 @@ int main() {
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         }
-        double lane_ops = (double)blocks * threads * ITERS * e.ops_per_iter;
+        double lane_ops = (double)blocks * threads * ITERS * (e.ops_per_iter == 2 ? 8 : 32);
         double rate = lane_ops / (best * 1e-3);         // lane-ops / s, whole chip
         double per_cu_clk = rate / cus / 2.4e9;         // lane-ops per CU per (2.4 GHz) clock
         printf("%-20s %8.3f ms  %8.2f Tlane-op/s  %7.1f lane-op/clk/CU (@2.4GHz)  => %5.2f cyc per wave64-instr per SIMD\n",
