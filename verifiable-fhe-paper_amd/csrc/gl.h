@@ -214,6 +214,14 @@ GL_HD u64 mul_2e48(u64 x) {
     r = canon(r);
     return sub(r, h1);
 }
+// 7 x = 8 x - x (canonical in and out): the coset generator steps k_j = 7^j of the permutation argument
+GL_HD u64 mul7(u64 x) {
+    const u64 lo = x << 3, hi = x >> 61;       // 8 x = lo + hi 2^64 = lo + hi (2^32 - 1), hi < 8
+    const u64 t = (hi << 32) - hi;
+    u64 r = lo + t;
+    if (r < t) r += EPS;
+    return sub(canon(r), x);
+}
 GL_HD u64 mul_2e72(u64 x) {
     // x 2^72 = (x 2^8) 2^64, x 2^8 = c 2^64 + b 2^32 + a  ->  a (2^32 - 1) - b - c 2^32   (2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32)
     const u64 a = (x << 8) & EPS, b = (x >> 24) & EPS, c = x >> 56;

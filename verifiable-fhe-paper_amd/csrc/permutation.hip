@@ -34,7 +34,7 @@ pp_chunk_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, c
         const u64 w = wires[(size_t)j * n + i];
         num = gl::mul(num, gl::add(gl::add(w, t), gamma));
         den = gl::mul(den, gl::add(gl::add(w, gl::mul(beta, sigmas[(size_t)j * n + i])), gamma));
-        t = gl::mul(t, gl::GENERATOR);
+        t = gl::mul7(t);
     }
     if (den == 0) atomicOr(zero_flag, 1u);  // plonky2's batch inverse would panic here
     chunk_q[((size_t)c * n_chunks + k) * n + i] = gl::mul(num, gl::inv(den));

@@ -84,7 +84,7 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
                 if ((unsigned)c >= nc) continue;
                 num[c] = gl::mul(num[c], gl::add(gl::add(w, sid[c]), k.gamma[c]));
                 den[c] = gl::mul(den[c], gl::add(gl::add(w, gl::mul(k.beta[c], s)), k.gamma[c]));
-                sid[c] = gl::mul(sid[c], gl::GENERATOR);
+                sid[c] = gl::mul7(sid[c]);
             }
         };
         if (DEG != 0 && (kk + 1) * DEG <= n_routed) {
