@@ -327,3 +327,19 @@ def test_cxx_circuit_example(ctx):
     item = synth.field_elements(0xB5C, 2 * 2 * 2 * 64)
     want = orc.hash_no_pad(np.concatenate([np.zeros(4, np.uint64), item]))
     assert " ".join("%016x" % int(x) for x in want) in r.stdout
+
+
+def test_product_reproduces_frozen_step_proofs(ctx):
+    """the same regression vectors through the HIP path (C ABI): bit-identical caps, challenges, openings and FRI proofs"""
+    import regression_cases as rc
+    for case in rc.cases():
+        b = rc.build(case)
+        cs = ctx.commit_values(b["inputs"]["constants_sigmas"])
+        if b["gates"] is None:
+            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], b["inputs"]["zs_partial_products"], b["inputs"]["quotient"], cs, rc.DIGEST,
+                                      b["pis"])
+        else:
+            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], None, None, cs, rc.DIGEST, b["pis"], sigmas=b["sigma"], n_routed=80,
+                                      n_constants=b["n_constants"], gates=api.GateSet(b["gates"]))
+        rc.check(case, ctx.prove_step(si))
+        cs.free()

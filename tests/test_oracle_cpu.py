@@ -393,3 +393,19 @@ def test_tfhe_oracle_reference_properties():
         # first step: pure rotation by -mask; last step: plain external product (no CMUX add)
         assert T.glwe_decrypt(ring, s, T.step(ring, ct, ai, gg, K, ELL, LOGB, first_step=True), K) == T.rotate(m, T.mod_switch((P - ai) % P, 3))
         assert T.glwe_decrypt(ring, s, T.step(ring, ct, ai, gg, K, ELL, LOGB, last_step=True), K) == [bit * v for v in m]
+
+
+def test_oracle_reproduces_frozen_step_proofs():
+    """regression vectors (tests/golden/regression_step_proofs.json, produced by THIS oracle at an earlier commit -- not reference
+    vectors): caps, challenges, openings, FRI proof and pow witness of four seeded step proofs must not drift."""
+    import gates_oracle as go
+    import regression_cases as rc
+    import step_oracle
+    for case in rc.cases():
+        b = rc.build(case)
+        if b["gates"] is None:
+            p = step_oracle.prove_step(b["inputs"], rc.DIGEST, b["pis"], b["log_n"])
+        else:
+            p = step_oracle.prove_step(b["inputs"], rc.DIGEST, b["pis"], b["log_n"], sigmas=b["sigma"], n_routed=80,
+                                       n_constants=b["n_constants"], gates=go.GateSet(b["gates"]))
+        rc.check(case, p)
