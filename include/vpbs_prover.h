@@ -215,6 +215,13 @@ int vpbs_sigma_values(const vpbs_circuit* circuit, uint64_t* out);
  * twice with different values, generators that could not run, a value that does not fit its gate. */
 int vpbs_generate_witness(const vpbs_circuit* circuit, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
                           uint64_t* wires_out, char* err, size_t err_len);
+/* Checks a complete witness against the circuit on the host: every row satisfies the constraints of its gate (evaluated on the
+ * trace values themselves, i.e. on the subgroup) and every copy constraint holds.  Returns 1 = satisfied, 0 = violated (err names the
+ * first violation: row, gate, constraint index or the two wire positions), < 0 = malformed arguments.  This is the integration aid
+ * for a witness produced elsewhere (e.g. by the reference's Rust generators): if it passes here, the quotient computed by
+ * vpbs_prove_step is a polynomial and the proof will verify. */
+int vpbs_check_witness(const vpbs_circuit* circuit, const uint64_t* wires /* [n_wires][n] */, const uint64_t public_inputs_hash[4],
+                       char* err, size_t err_len);
 
 /* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
 typedef struct {

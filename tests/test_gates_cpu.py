@@ -358,6 +358,22 @@ def test_witness_generation_reproduces_the_demo_circuit():
     for cl in desc["classes"]:
         assert len({int(got[c, r]) for c, r in cl}) == 1
     assert [int(got[i, 0]) for i in range(4)] == pi_hash   # PublicInputGate wires = hash_no_pad(public inputs), via the circuit
+    # the witness checker (integration aid): accepts the generated and the Python-built witness, names the first violation otherwise
+    assert circ.check_witness(got, pi_hash) == (True, "")
+    assert circ.check_witness(wires, pi_hash)[0]
+    broken = got.copy()
+    broken[3, 6] = (int(broken[3, 6]) + 1) % P                     # output of arithmetic op 0 on row 6
+    ok, msg = circ.check_witness(broken, pi_hash)
+    assert not ok and "row 6" in msg and "ArithmeticGate" in msg
+    broken = got.copy()
+    broken[0, 2] = (int(broken[0, 2]) + 1) % P                     # an input of the Poseidon chain: gate row 2 breaks first
+    ok, msg = circ.check_witness(broken, pi_hash)
+    assert not ok and "row 2" in msg
+    broken = wires.copy()
+    broken[:, 40] = 0                                              # a NoopGate row: nothing to violate ...
+    assert circ.check_witness(broken, pi_hash)[0]
+    ok, msg = circ.check_witness(got, [1, 2, 3, 4])                # ... but a wrong public-input hash breaks the PublicInputGate row
+    assert not ok and "row 0" in msg and "PublicInputGate" in msg
     # errors: a conflicting preset, a missing input
     bad = dict(presets)
     bad[(12, 1)] = (int(wires[12, 1]) + 1) % P     # an output the Poseidon generator will set differently

@@ -140,6 +140,7 @@ SIGNATURES = {
     "vpbs_selector_columns": (_i, [C.POINTER(CircuitC), U64P]),
     "vpbs_sigma_values": (_i, [C.POINTER(CircuitC), U64P]),
     "vpbs_generate_witness": (_i, [C.POINTER(CircuitC), U32P, U64P, _sz, U64P, C.c_char_p, _sz]),
+    "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
@@ -323,6 +324,16 @@ class Circuit:
         if lib().vpbs_sigma_values(C.byref(self.c), _ptr(out)):
             raise VpbsError("vpbs_sigma_values failed")
         return out
+
+    def check_witness(self, wires, pi_hash):
+        """vpbs_check_witness -> (ok, message of the first violation)"""
+        w, h = _u64(wires), _u64(pi_hash)
+        assert w.shape == (self.n_wires, self.n)
+        err = C.create_string_buffer(512)
+        rc = lib().vpbs_check_witness(C.byref(self.c), _ptr(w), _ptr(h), err, 512)
+        if rc < 0:
+            raise VpbsError("vpbs_check_witness: " + err.value.decode())
+        return rc == 1, err.value.decode()
 
     def generate_witness(self, presets):
         """presets: {(column, row): value} (the PartialWitness) -> wires [n_wires][n]"""

@@ -411,4 +411,66 @@ int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, con
     return VPBS_OK;
 }
 
+int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint64_t pi_hash[4], char* err, size_t err_len) {
+    auto report = [&](const std::string& m) {
+        if (err && err_len) {
+            std::strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+    };
+    if (!vpbs::check_circuit(c) || !wires || !pi_hash) {
+        report("malformed circuit description");
+        return VPBS_ERR_INVALID;
+    }
+    using namespace vpbs;
+    const size_t n = (size_t)1 << c->log_n;
+    unsigned max_consts = 0;
+    for (unsigned i = 0; i < c->n_gates; ++i) max_consts = std::max(max_consts, c->gates[i].num_constants);
+    if (c->num_selectors + max_consts > c->n_constants_cols || (max_consts && !c->constants)) {
+        report("constants columns missing");
+        return VPBS_ERR_INVALID;
+    }
+    struct RowVars {
+        using F = u64;
+        const u64* wires;
+        const u64* constants;
+        size_t n, row;
+        unsigned n_wires, first_const, n_const_cols;
+        const u64* pih;
+        u64 wire(unsigned i) const { return i < n_wires ? wires[(size_t)i * n + row] : 0; }
+        u64 constant(unsigned i) const { return first_const + i < n_const_cols ? constants[(size_t)(first_const + i) * n + row] : 0; }
+        u64 pi_hash(unsigned i) const { return pih[i]; }
+    };
+    struct Sink {
+        std::vector<u64> c;
+        void push(u64 x) { c.push_back(x); }
+    };
+    for (size_t r = 0; r < n; ++r) {
+        const vpbs_gate& g = c->gates[c->row_gate[r]];
+        if (g.num_constraints == 0) continue;
+        RowVars v{wires, c->constants, n, r, c->n_wires, c->num_selectors, c->n_constants_cols, pi_hash};
+        Sink s;
+        const gates::CosetTables* t = g.kind == VPBS_GATE_COSET_INTERPOLATION ? &gates::coset_tables(g.p0) : nullptr;
+        gates::eval_gate<u64>(g, t, v, s);
+        for (size_t k = 0; k < s.c.size(); ++k)
+            if (s.c[k] != 0) {
+                char id[256] = "gate";
+                (void)vpbs_gate_id(&g, id, sizeof id);
+                id[60] = 0;
+                report("row " + std::to_string(r) + ": constraint " + std::to_string(k) + " of " + id + " is not satisfied");
+                return 0;
+            }
+    }
+    for (size_t i = 0; i < c->n_copies; ++i) {
+        const uint32_t a = c->copies[2 * i], b = c->copies[2 * i + 1];
+        if (wires[a] != wires[b]) {
+            report("copy constraint violated: (column " + std::to_string(a / n) + ", row " + std::to_string(a % n) + ") != (column " +
+                   std::to_string(b / n) + ", row " + std::to_string(b % n) + ")");
+            return 0;
+        }
+    }
+    if (err && err_len) err[0] = 0;
+    return 1;
+}
+
 }  // extern "C"
