@@ -1,0 +1,176 @@
+"""Parity against a golden proof captured from real plonky2 0.2.0 (tests/golden/PLONKY2_FIXTURE_FORMAT.md).
+
+The fixture cannot be produced in this repository's environment (no Rust toolchain), so these tests are skipped unless
+tests/golden/plonky2_step/ (or $VPBS_PLONKY2_FIXTURE) exists.  The loader and the comparison logic themselves are exercised by
+test_fixture_roundtrip_with_an_oracle_made_fixture, which writes a fixture from the CPU oracle into a temporary directory."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import step_oracle
+from vpbs_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.environ.get("VPBS_PLONKY2_FIXTURE", os.path.join(ROOT, "tests", "golden", "plonky2_step"))
+
+
+def load_fixture(path):
+    meta = json.load(open(os.path.join(path, "meta.json")))
+    n = 1 << meta["log_n"]
+    nc = meta["num_challenges"]
+
+    def arr(name, *shape):
+        a = np.fromfile(os.path.join(path, name + ".u64"), dtype="<u8")
+        return a.reshape(shape) if shape else a
+    n_cs = meta["n_constants"] + meta["n_routed"]
+    fx = {"meta": meta, "n": n,
+          "constants_sigmas_values": arr("constants_sigmas_values", n_cs, n), "circuit_digest": arr("circuit_digest"),
+          "public_inputs": arr("public_inputs"), "witness_wires": arr("witness_wires", meta["n_wires"], n),
+          "zs_partial_products_values": arr("zs_partial_products_values", -1, n), "quotient_coeffs": arr("quotient_coeffs", -1, n),
+          "caps": arr("caps", 3, -1, 4), "constants_sigmas_cap": arr("constants_sigmas_cap", -1, 4), "challenges": arr("challenges"),
+          "openings": arr("openings", -1, 2), "fri": arr("fri")}
+    pb = os.path.join(path, "proof_bytes.bin")
+    fx["proof_bytes"] = open(pb, "rb").read() if os.path.exists(pb) else None
+    assert fx["challenges"].size == 3 * nc + 2
+    return fx
+
+
+def write_fixture(path, fx):
+    os.makedirs(path, exist_ok=True)
+    json.dump(fx["meta"], open(os.path.join(path, "meta.json"), "w"))
+    for k, v in fx.items():
+        if k in ("meta", "n", "proof_bytes") or v is None:
+            continue
+        np.ascontiguousarray(v, dtype="<u8").tofile(os.path.join(path, k + ".u64"))
+    if fx.get("proof_bytes") is not None:
+        open(os.path.join(path, "proof_bytes.bin"), "wb").write(fx["proof_bytes"])
+
+
+def check_with_oracle(fx):
+    """the CPU oracle against the fixture"""
+    m = fx["meta"]
+    inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"],
+              "zs_partial_products": fx["zs_partial_products_values"], "quotient": fx["quotient_coeffs"]}
+    p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=m["num_challenges"],
+                               forced_pow=int(fx["fri"][-1]))
+    assert (p["cs_cap"] == fx["constants_sigmas_cap"]).all(), "constants_sigmas cap"
+    for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
+        assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
+    assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
+    assert (p["openings"] == fx["openings"]).all(), "openings"
+    assert (p["fri"] == fx["fri"]).all(), "FRI proof"
+    if fx["proof_bytes"] is not None:
+        got = step_oracle.to_bytes(p, p["ncols"], m["n_constants"], fx["public_inputs"], m["log_n"], num_challenges=m["num_challenges"])
+        assert got == fx["proof_bytes"], "proof bytes"
+    # the permutation argument's partial products are recomputable from the wires and the transcript
+    nc = m["num_challenges"]
+    ch = [int(x) for x in fx["challenges"]]
+    zs = orc.partial_products(fx["witness_wires"][:m["n_routed"]], fx["constants_sigmas_values"][m["n_constants"]:], ch[:nc], ch[nc:2 * nc])
+    assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
+
+
+def check_with_product(ctx, fx):
+    """the HIP path (through the C ABI) against the fixture"""
+    m = fx["meta"]
+    log_n, nc = m["log_n"], m["num_challenges"]
+    cs = ctx.commit_values(fx["constants_sigmas_values"])
+    assert (cs.cap() == fx["constants_sigmas_cap"]).all(), "constants_sigmas cap"
+    si = ctx.make_step_inputs(log_n, fx["witness_wires"], fx["zs_partial_products_values"], fx["quotient_coeffs"], cs, fx["circuit_digest"],
+                              fx["public_inputs"], num_challenges=nc, forced_pow=int(fx["fri"][-1]))
+    p = ctx.prove_step(si)
+    for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
+        assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
+    assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
+    assert (p["openings"] == fx["openings"]).all(), "openings"
+    assert (p["fri"] == fx["fri"]).all(), "FRI proof"
+    if fx["proof_bytes"] is not None:
+        assert ctx.step_proof_to_bytes(si, m["n_constants"], p) == fx["proof_bytes"], "proof bytes"
+    ncols = [cs.ncols, m["n_wires"], fx["zs_partial_products_values"].shape[0], fx["quotient_coeffs"].shape[0]]
+    assert api.verify_step(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
+    # device partial products / quotient from the wires alone
+    sig = np.ascontiguousarray(fx["constants_sigmas_values"][m["n_constants"]:])
+    ch = [int(x) for x in fx["challenges"]]
+    zs = ctx.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
+    assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
+    if m.get("gates"):
+        gates = api.GateSet([(api.GATE_KINDS[k] if isinstance(k, int) else k, p0, p1, p2) for k, p0, p1, p2 in m["gates"]])
+        si2 = ctx.make_step_inputs(log_n, fx["witness_wires"], None, None, cs, fx["circuit_digest"], fx["public_inputs"], num_challenges=nc,
+                                   forced_pow=int(fx["fri"][-1]), sigmas=sig, n_routed=m["n_routed"], n_constants=m["n_constants"], gates=gates)
+        p2 = ctx.prove_step(si2)
+        assert (p2["caps"] == fx["caps"]).all(), "caps with the quotient evaluated on the device (gate constraints + permutation argument)"
+        assert (p2["fri"] == fx["fri"]).all(), "FRI proof with the quotient evaluated on the device"
+    cs.free()
+
+
+have_fixture = os.path.isdir(FIXTURE)
+
+
+@pytest.mark.skipif(not have_fixture, reason="no plonky2 golden fixture (tests/golden/PLONKY2_FIXTURE_FORMAT.md): parity stays unpinned")
+def test_oracle_matches_plonky2_golden_proof():
+    check_with_oracle(load_fixture(FIXTURE))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_fixture, reason="no plonky2 golden fixture (tests/golden/PLONKY2_FIXTURE_FORMAT.md): parity stays unpinned")
+def test_product_matches_plonky2_golden_proof():
+    import vpbs_amd
+    ctx = vpbs_amd.Context(0, log_n_max=16)
+    try:
+        check_with_product(ctx, load_fixture(FIXTURE))
+    finally:
+        ctx.close()
+
+
+def _oracle_made_fixture(tmp_path, with_gates):
+    """a stand-in fixture written by the CPU oracle: exercises write -> load -> compare"""
+    import random
+    import gates_oracle as go
+    import regression_cases as rc
+    log_n = 6
+    rnd = random.Random(99)
+    gs = go.GateSet(rc.GATES)
+    pis = [rnd.randrange(go.P) for _ in range(4)]
+    constants, wires, sigma, _ = go.demo_circuit(rnd, gs, log_n, pis)
+    cs_values = np.concatenate([constants, sigma])
+    digest = np.array([9, 8, 7, 6], np.uint64)
+    p = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, digest, pis, log_n, sigmas=sigma, n_routed=80,
+                               n_constants=constants.shape[0], gates=gs)
+    ch = [int(x) for x in p["challenges"]]
+    zs = orc.partial_products(wires[:80], sigma, ch[:2], ch[2:4])
+    w_b, z_b = orc.Batch(wires, 3, 4, True), orc.Batch(zs, 3, 4, True)
+    cs_b = orc.Batch(cs_values, 3, 4, True)
+    gt = gs.terms_coset(cs_b.coeffs()[:constants.shape[0]], w_b.coeffs(), orc.hash_no_pad(pis), ch[4:6])
+    q = orc.quotient_permutation(w_b.coeffs()[:80], cs_b.coeffs()[constants.shape[0]:], z_b.coeffs(), ch[:2], ch[2:4], ch[4:6], gate_terms=gt)
+    meta = {"log_n": log_n, "n_wires": 135, "n_routed": 80, "num_challenges": 2, "n_constants": int(constants.shape[0]), "n_public_inputs": 4}
+    if with_gates:
+        meta["gates"] = [[g.kind, g.p0, g.p1, g.p2] for g in gs.gates]
+    fx = {"meta": meta, "constants_sigmas_values": cs_values, "circuit_digest": digest, "public_inputs": np.array(pis, np.uint64),
+          "witness_wires": wires, "zs_partial_products_values": zs, "quotient_coeffs": q, "caps": p["caps"], "constants_sigmas_cap": p["cs_cap"],
+          "challenges": p["challenges"], "openings": p["openings"], "fri": p["fri"],
+          "proof_bytes": step_oracle.to_bytes(p, p["ncols"], constants.shape[0], pis, log_n)}
+    path = os.path.join(str(tmp_path), "fixture")
+    write_fixture(path, fx)
+    return path
+
+
+def test_fixture_roundtrip_with_an_oracle_made_fixture(tmp_path):
+    path = _oracle_made_fixture(tmp_path, with_gates=False)
+    fx = load_fixture(path)
+    check_with_oracle(fx)
+    fx["openings"][3][0] ^= np.uint64(1)
+    with pytest.raises(AssertionError, match="openings"):
+        check_with_oracle(fx)
+
+
+@pytest.mark.gpu
+def test_product_against_an_oracle_made_fixture(tmp_path):
+    import vpbs_amd
+    path = _oracle_made_fixture(tmp_path, with_gates=True)
+    ctx = vpbs_amd.Context(0, log_n_max=16)
+    try:
+        check_with_product(ctx, load_fixture(path))
+    finally:
+        ctx.close()
