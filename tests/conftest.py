@@ -9,5 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# PyTorch must be imported before the oracle's first OpenMP region: torch brings its own OpenMP runtime, and when it is loaded AFTER
+# libgomp has already spun up the oracle's thread pool, every later oracle call on a many-core box runs ~7x slower (measured on the
+# 256-thread GPU host: 23 s -> 160 s for the GPU suite).  The product library imports torch anyway (it shares torch's HIP runtime).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is part of the image
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

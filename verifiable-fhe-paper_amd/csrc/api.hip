@@ -70,6 +70,12 @@ void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
         VPBS_HIP(hipStreamSynchronize(stream));
     }
 }
+void vpbs_ctx::ensure_gate_lanes() {
+    if (gate_fork) return;
+    for (auto& st : gate_streams) VPBS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    VPBS_HIP(hipEventCreateWithFlags(&gate_fork, hipEventDisableTiming));
+    for (auto& e : gate_join) VPBS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+}
 const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
     auto key = std::make_pair(log_n, inverse);
     auto it = root_tables.find(key);
@@ -281,6 +287,11 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto st : c->gate_streams)
+        if (st) (void)hipStreamDestroy(st);
+    if (c->gate_fork) (void)hipEventDestroy(c->gate_fork);
+    for (auto e : c->gate_join)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -63,6 +63,11 @@ struct vpbs_ctx {
     const vpbs::u64* roots(unsigned log_n, bool inverse);
     const vpbs::u64* prescale(unsigned log_n, unsigned rate_bits, vpbs::u64 shift);
 
+    // ---- helper streams for the gate-constraint kernels (created on first use) ----
+    hipStream_t gate_streams[2] = {nullptr, nullptr};
+    hipEvent_t gate_fork = nullptr, gate_join[2] = {nullptr, nullptr};
+    void ensure_gate_lanes();
+
     // ---- timing ----
     bool timing = false;
     std::string timing_only;  // when non-empty, only this timer is recorded

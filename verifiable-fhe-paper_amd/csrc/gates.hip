@@ -306,43 +306,99 @@ struct HostSink {
 
 }  // namespace
 
-void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
-                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out) {
-    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
-    int acc = 0;
-    // (Splitting the points into row chunks so that one chunk's columns stay in the 256 MB memory-side cache across the 13
-    // kernels was measured and is slower at every chunk count: the kernels need the whole 2^18-point grid to hide latency.)
-    const size_t chunk = len;
-    for (size_t j0 = 0; j0 < len; j0 += chunk) {
-        const size_t j1 = std::min(len, j0 + chunk);
-        int acc_chunk = 0;
-        for (unsigned i = 0; i < n_gates; ++i) {
-            const vpbs_gate& g = gs[i];
-            if (g.num_constraints == 0) continue;
+namespace {
+// one gate's kernel on stream s, into out (accumulate = 0: overwrite)
+bool launch_gate(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate& g, unsigned num_selectors,
+                 const u64* d_apow, unsigned pow_stride, unsigned nc, const PiHash& pih, u64* out, int accumulate) {
 #define VPBS_GATE_CASE(K) \
-    case K: launch_one<K>(s, wires_lde, consts_lde, len, j0, j1, g, num_selectors, d_apow, pow_stride, nc, pih, d_out, acc_chunk); break;
-            switch (g.kind) {
-                VPBS_GATE_CASE(VPBS_GATE_CONSTANT)
-                VPBS_GATE_CASE(VPBS_GATE_PUBLIC_INPUT)
-                VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC)
-                VPBS_GATE_CASE(VPBS_GATE_BASE_SUM)
-                VPBS_GATE_CASE(VPBS_GATE_POSEIDON)
-                VPBS_GATE_CASE(VPBS_GATE_POSEIDON_MDS)
-                VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC_EXT)
-                VPBS_GATE_CASE(VPBS_GATE_MUL_EXT)
-                VPBS_GATE_CASE(VPBS_GATE_REDUCING)
-                VPBS_GATE_CASE(VPBS_GATE_REDUCING_EXT)
-                VPBS_GATE_CASE(VPBS_GATE_RANDOM_ACCESS)
-                VPBS_GATE_CASE(VPBS_GATE_EXPONENTIATION)
-                VPBS_GATE_CASE(VPBS_GATE_COSET_INTERPOLATION)
-                default: continue;
-            }
+    case K: launch_one<K>(s, wires_lde, consts_lde, len, 0, len, g, num_selectors, d_apow, pow_stride, nc, pih, out, accumulate); return true;
+    switch (g.kind) {
+        VPBS_GATE_CASE(VPBS_GATE_CONSTANT)
+        VPBS_GATE_CASE(VPBS_GATE_PUBLIC_INPUT)
+        VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC)
+        VPBS_GATE_CASE(VPBS_GATE_BASE_SUM)
+        VPBS_GATE_CASE(VPBS_GATE_POSEIDON)
+        VPBS_GATE_CASE(VPBS_GATE_POSEIDON_MDS)
+        VPBS_GATE_CASE(VPBS_GATE_ARITHMETIC_EXT)
+        VPBS_GATE_CASE(VPBS_GATE_MUL_EXT)
+        VPBS_GATE_CASE(VPBS_GATE_REDUCING)
+        VPBS_GATE_CASE(VPBS_GATE_REDUCING_EXT)
+        VPBS_GATE_CASE(VPBS_GATE_RANDOM_ACCESS)
+        VPBS_GATE_CASE(VPBS_GATE_EXPONENTIATION)
+        VPBS_GATE_CASE(VPBS_GATE_COSET_INTERPOLATION)
+        default: return false;
+    }
 #undef VPBS_GATE_CASE
-            acc_chunk = 1;
-            acc = 1;
+}
+// measured kernel time per gate at 2^18 points (us): the weights of the lane assignment below
+unsigned gate_weight(const vpbs_gate& g) {
+    switch (g.kind) {
+        case VPBS_GATE_POSEIDON: return 180;
+        case VPBS_GATE_CONSTANT:
+        case VPBS_GATE_PUBLIC_INPUT: return 9;
+        case VPBS_GATE_COSET_INTERPOLATION: return 55;
+        case VPBS_GATE_BASE_SUM: return 58;
+        default: return 8 + g.num_wires / 2;  // the HBM-bound gates: time follows the number of wire columns read
+    }
+}
+__global__ void add_lanes_kernel(u64* __restrict__ out, const u64* __restrict__ a, const u64* __restrict__ b, size_t words) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    u64 r = out[i];
+    if (a) r = gl::add(r, a[i]);
+    if (b) r = gl::add(r, b[i]);
+    out[i] = r;
+}
+}  // namespace
+
+// (Splitting the points into row chunks so that one chunk's columns stay in the 256 MB memory-side cache across the 13
+// kernels was measured and is slower at every chunk count: the kernels need the whole 2^18-point grid to hide latency.)
+//
+// lanes: the gates are spread over up to three streams (the caller's + two helpers, forked and joined with events) so that the
+// VALU-bound PoseidonGate kernel overlaps the HBM-bound ones instead of queueing behind them; each lane accumulates into its own
+// buffer (lane_out[1], lane_out[2]: [nc][len] scratch, may be null = single lane) and the lanes are summed at the join.
+void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
+                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
+                       const GateLanes* lanes) {
+    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+    const unsigned n_lanes = lanes ? 3 : 1;
+    // longest-processing-time-first assignment
+    std::vector<unsigned> order;
+    for (unsigned i = 0; i < n_gates; ++i)
+        if (gs[i].num_constraints) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return gate_weight(gs[a]) > gate_weight(gs[b]); });
+    std::vector<unsigned> lane_of(n_gates, 0);
+    unsigned load[3] = {0, 0, 0};
+    for (unsigned i : order) {
+        unsigned best = 0;
+        for (unsigned l = 1; l < n_lanes; ++l)
+            if (load[l] < load[best]) best = l;
+        lane_of[i] = best;
+        load[best] += gate_weight(gs[i]);
+    }
+    hipStream_t st[3] = {s, lanes ? lanes->stream[0] : nullptr, lanes ? lanes->stream[1] : nullptr};
+    u64* out[3] = {d_out, lanes ? lanes->out[0] : nullptr, lanes ? lanes->out[1] : nullptr};
+    if (n_lanes > 1) {
+        (void)hipEventRecord(lanes->fork, s);
+        for (unsigned l = 1; l < 3; ++l) (void)hipStreamWaitEvent(st[l], lanes->fork, 0);
+    }
+    bool used[3] = {false, false, false};
+    for (unsigned l = 0; l < n_lanes; ++l)
+        for (unsigned i : order)
+            if (lane_of[i] == l && launch_gate(st[l], wires_lde, consts_lde, len, gs[i], num_selectors, d_apow, pow_stride, nc, pih, out[l], used[l] ? 1 : 0))
+                used[l] = true;
+    if (!used[0]) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
+    if (n_lanes > 1) {
+        for (unsigned l = 1; l < 3; ++l) {
+            (void)hipEventRecord(lanes->join[l - 1], st[l]);
+            (void)hipStreamWaitEvent(s, lanes->join[l - 1], 0);
+        }
+        if (used[1] || used[2]) {
+            const size_t words = (size_t)nc * len;
+            hipLaunchKernelGGL(add_lanes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, d_out, used[1] ? out[1] : (const u64*)nullptr,
+                               used[2] ? out[2] : (const u64*)nullptr, words);
         }
     }
-    if (!acc) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
 }
 
 // checks a laid-out gate list against the batches it will be evaluated on

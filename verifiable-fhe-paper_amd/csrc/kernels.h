@@ -58,8 +58,16 @@ void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_l
 // evaluate_gate_constraints_base_batch folded with the alphas: d_out[a][j] = sum_i alpha_a^i sum_g filter_g(j) c_{g,i}(j) for the
 // `len` local leaves of the wires / constants LDEs (column stride len).  d_apow: [nc][pow_stride] powers of the alphas,
 // pow_stride >= max num_constraints.  gates: laid out by vpbs_gates_layout (host array).
+// lanes (optional): two helper streams + events + two scratch outputs [nc][len]; the gate kernels are then spread over three streams
+// (fork / join on s) so that VALU-bound and HBM-bound gates overlap
+struct GateLanes {
+    hipStream_t stream[2];
+    hipEvent_t fork, join[2];
+    u64* out[2];
+};
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
-                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out);
+                       unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
+                       const GateLanes* lanes = nullptr);
 // throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
 void validate_gates(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned n_constants_cols, unsigned n_wires);
 // host, GF(p^2): the same folded sum at one point from openings ([..][2] arrays); out [nc][2]

@@ -351,17 +351,35 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
         }
     }
     u64* d_apow = ctx->alloc_words(h_apow.size());
+    // three lanes (streams) when the gate set is large enough to be worth the fork / join: VPBS_GATE_LANES=1 keeps one stream
+    static const bool multi = [] { const char* e = getenv("VPBS_GATE_LANES"); return !e || atoi(e) != 1; }();
+    const size_t len = wires->lde_len();
+    u64* lane_buf = nullptr;
     try {
         VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
+        vpbs::GateLanes lanes{};
+        const bool use_lanes = multi && n_gates >= 4;
+        if (use_lanes) {
+            ctx->ensure_gate_lanes();
+            lane_buf = ctx->alloc_words(2 * (size_t)nc * len);
+            lanes = {{ctx->gate_streams[0], ctx->gate_streams[1]}, ctx->gate_fork, {ctx->gate_join[0], ctx->gate_join[1]},
+                     {lane_buf, lane_buf + (size_t)nc * len}};
+        }
         Timed t(ctx, "gate_constraints");
-        vpbs::launch_gate_terms(ctx->stream, wires->d_lde, cs->d_lde, wires->lde_len(), gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, d_out);
+        vpbs::launch_gate_terms(ctx->stream, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, d_out,
+                                use_lanes ? &lanes : nullptr);
         VPBS_HIP(hipGetLastError());
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
+        for (auto st : ctx->gate_streams)
+            if (st) (void)hipStreamSynchronize(st);
         ctx->release(d_apow);
+        if (lane_buf) ctx->release(lane_buf);
         throw;
     }
+    // the helper streams were joined into ctx->stream, so stream-ordered reuse of these blocks is safe
     ctx->release(d_apow);
+    if (lane_buf) ctx->release(lane_buf);
 }
 
 // compute_quotient_polys (permutation part) on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks
