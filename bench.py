@@ -136,6 +136,8 @@ def main():
     ctxs, sis, keep = [], [], []
     for c in range(n_chains):
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)
+        if n_chains > 1:
+            ctx.set_gate_lanes(1)   # several chains keep the device busy by themselves: one stream per context is the better setting
         # chain c of rank r proves its own seeded instance
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst, cols=COLS)
@@ -202,6 +204,7 @@ def main():
         extra = []
         for c in range(1, args.batch_chains):
             cx = vpbs_amd.Context(local_rank, log_n_max=16)
+            cx.set_gate_lanes(1)
             inp = synth.step_inputs(log_n, instance=c, cols=COLS)
             dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
             csb = cx.commit_values(inp["constants_sigmas"])
@@ -210,6 +213,7 @@ def main():
             extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, None, csb, digest, pi2,
                                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
                                                   sigmas=sp, n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates), dv, csb, pi2))
+        ctxs[0].set_gate_lanes(1)   # batch mode: one stream per chain
         ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
         n_chains = len(ctxs)
         run_steps(1)
@@ -222,6 +226,7 @@ def main():
                         "vpbs_proofs_per_s": args.steps * n_chains / eb / STEPS_PER_VPBS,
                         "ms_per_step_proof": eb / (args.steps * n_chains) * 1e3}
         n_chains = 1
+        ctxs[0].set_gate_lanes(3)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")

@@ -42,6 +42,10 @@ int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, 
 void vpbs_ctx_destroy(vpbs_ctx* ctx);
 const char* vpbs_last_error(const vpbs_ctx* ctx);
 int vpbs_ctx_synchronize(vpbs_ctx* ctx);
+/* Streams used for the gate-constraint kernels of a step proof: 3 (default) overlaps the VALU-bound PoseidonGate kernel with the
+ * HBM-bound gates (-18 % on that stage, best latency for one chain); 1 keeps them on the context's stream, which is slightly better
+ * for throughput when several contexts already keep the device busy (-2 % with three chains otherwise). */
+int vpbs_ctx_set_gate_lanes(vpbs_ctx* ctx, unsigned lanes);
 void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share device buffers with the ctx */
 
 /* ---- PolynomialBatch (plonky2 fri/oracle.rs) ---- */

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vpbs_ctx_destroy": (None, [_vp]),
     "vpbs_last_error": (C.c_char_p, [_vp]),
     "vpbs_ctx_synchronize": (_i, [_vp]),
+    "vpbs_ctx_set_gate_lanes": (_i, [_vp, _ui]),
     "vpbs_ctx_stream": (_vp, [_vp]),
     "vpbs_commit_values": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_commit_coeffs": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
@@ -485,6 +486,10 @@ class Context:
 
     def synchronize(self):
         self._check(lib().vpbs_ctx_synchronize(self.h))
+
+    def set_gate_lanes(self, lanes):
+        """3 (default): gate-constraint kernels over three streams (best single-chain latency); 1: one stream (multi-chain throughput)"""
+        self._check(lib().vpbs_ctx_set_gate_lanes(self.h, lanes))
 
     @property
     def stream(self):

@@ -296,6 +296,11 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     delete c;
 }
 
+int vpbs_ctx_set_gate_lanes(vpbs_ctx* c, unsigned lanes) {
+    if (!c || (lanes != 1 && lanes != 3)) return VPBS_ERR_INVALID;
+    c->gate_lanes = lanes;
+    return VPBS_OK;
+}
 const char* vpbs_last_error(const vpbs_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int vpbs_ctx_synchronize(vpbs_ctx* c) {
     return guarded(c, [&] { VPBS_HIP(hipStreamSynchronize(c->stream)); });

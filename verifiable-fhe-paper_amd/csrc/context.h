@@ -67,6 +67,7 @@ struct vpbs_ctx {
     hipStream_t gate_streams[2] = {nullptr, nullptr};
     hipEvent_t gate_fork = nullptr, gate_join[2] = {nullptr, nullptr};
     void ensure_gate_lanes();
+    unsigned gate_lanes = 3;
 
     // ---- timing ----
     bool timing = false;

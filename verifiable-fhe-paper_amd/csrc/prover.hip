@@ -351,8 +351,10 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
         }
     }
     u64* d_apow = ctx->alloc_words(h_apow.size());
-    // three lanes (streams) when the gate set is large enough to be worth the fork / join: VPBS_GATE_LANES=1 keeps one stream
-    static const bool multi = [] { const char* e = getenv("VPBS_GATE_LANES"); return !e || atoi(e) != 1; }();
+    // three lanes (streams) when the gate set is large enough to be worth the fork / join (vpbs_ctx_set_gate_lanes; the environment
+    // variable VPBS_GATE_LANES=1 forces one stream for every context)
+    static const bool env_single = [] { const char* e = getenv("VPBS_GATE_LANES"); return e && atoi(e) == 1; }();
+    const bool multi = !env_single && ctx->gate_lanes == 3;
     const size_t len = wires->lde_len();
     u64* lane_buf = nullptr;
     try {
