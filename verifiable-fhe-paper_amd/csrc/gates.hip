@@ -359,7 +359,7 @@ __global__ void add_lanes_kernel(u64* __restrict__ out, const u64* __restrict__ 
 // buffer (lane_out[1], lane_out[2]: [nc][len] scratch, may be null = single lane) and the lanes are summed at the join.
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
                        unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
-                       const GateLanes* lanes) {
+                       GateLanes* lanes) {
     PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
     const unsigned n_lanes = lanes ? 3 : 1;
     // longest-processing-time-first assignment
@@ -369,6 +369,11 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
     std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return gate_weight(gs[a]) > gate_weight(gs[b]); });
     std::vector<unsigned> lane_of(n_gates, 0);
     unsigned load[3] = {0, 0, 0};
+    unsigned extra_lane = 0;
+    if (lanes && lanes->extra) {  // the heaviest item after the Poseidon gate: placed first on the emptiest helper lane
+        extra_lane = 1;
+        load[1] += lanes->extra_weight;
+    }
     for (unsigned i : order) {
         unsigned best = 0;
         for (unsigned l = 1; l < n_lanes; ++l)
@@ -383,17 +388,19 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
         for (unsigned l = 1; l < 3; ++l) (void)hipStreamWaitEvent(st[l], lanes->fork, 0);
     }
     bool used[3] = {false, false, false};
+    if (lanes && lanes->extra) lanes->extra(st[extra_lane], lanes->extra_arg);
     for (unsigned l = 0; l < n_lanes; ++l)
         for (unsigned i : order)
             if (lane_of[i] == l && launch_gate(st[l], wires_lde, consts_lde, len, gs[i], num_selectors, d_apow, pow_stride, nc, pih, out[l], used[l] ? 1 : 0))
                 used[l] = true;
-    if (!used[0]) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
+    if (!used[0] && !(lanes && lanes->skip_sum)) (void)hipMemsetAsync(d_out, 0, sizeof(u64) * nc * len, s);
     if (n_lanes > 1) {
         for (unsigned l = 1; l < 3; ++l) {
             (void)hipEventRecord(lanes->join[l - 1], st[l]);
             (void)hipStreamWaitEvent(s, lanes->join[l - 1], 0);
         }
-        if (used[1] || used[2]) {
+        for (unsigned l = 0; l < 3; ++l) lanes->used[l] = used[l];
+        if (!lanes->skip_sum && (used[1] || used[2])) {
             const size_t words = (size_t)nc * len;
             hipLaunchKernelGGL(add_lanes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, d_out, used[1] ? out[1] : (const u64*)nullptr,
                                used[2] ? out[2] : (const u64*)nullptr, words);

@@ -49,7 +49,11 @@ void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsign
 void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
                             const u64* l0_table, const u64* d_gate_terms, const u64* d_apow, const u64* betas, const u64* gammas,
                             unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc, size_t leaf_offset,
-                            size_t local_len, u64* q_leaf_local);
+                            size_t local_len, u64* q_leaf_local, bool raw = false);
+// raw = true leaves out the gate terms and the division by Z_H; this joins them in afterwards:
+// q <- (q + alpha_a^(n_terms) (g0 + g1 + g2)) / Z_H   (g*: [nc][local_len] gate-term lanes, null = unused; apow_last: host [nc])
+void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u64* g1, const u64* g2, const u64* apow_last, unsigned log_n,
+                             unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len);
 // phase 2: q_gathered is rank-major [world][nc][local_len] (world * local_len = 8n); q_nat, scratch: [nc][8n]
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
                             unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs);
@@ -64,10 +68,16 @@ struct GateLanes {
     hipStream_t stream[2];
     hipEvent_t fork, join[2];
     u64* out[2];
+    // optional independent work that joins the lane assignment (the permutation part of the quotient): run(stream, arg)
+    void (*extra)(hipStream_t, void*) = nullptr;
+    void* extra_arg = nullptr;
+    unsigned extra_weight = 0;
+    bool skip_sum = false;      // leave the lanes unsummed (the caller combines them)
+    bool used[3] = {false, false, false};  // out: which lanes received gate kernels (lane 0 = d_out)
 };
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                        unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
-                       const GateLanes* lanes = nullptr);
+                       GateLanes* lanes = nullptr);
 // throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
 void validate_gates(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned n_constants_cols, unsigned n_wires);
 // host, GF(p^2): the same folded sum at one point from openings ([..][2] arrays); out [nc][2]

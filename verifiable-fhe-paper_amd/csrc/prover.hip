@@ -384,10 +384,30 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
     if (lane_buf) ctx->release(lane_buf);
 }
 
-// compute_quotient_polys (permutation part) on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks
+// the circuit's gates, evaluated CONCURRENTLY with the permutation part of the quotient (three streams, fork / join on ctx->stream)
+struct GateWork {
+    const vpbs_gate* gates;
+    unsigned n_gates, num_selectors;
+    const u64* pi_hash;
+};
+struct QuotientValuesCall {  // launch_quotient_values(raw) as the "extra" item of the gate lanes
+    const u64 *wires, *sigmas, *zs_pp, *roots, *l0, *d_apow, *betas, *gammas;
+    unsigned n_routed, log_n, rate_bits, max_degree, nc;
+    size_t leaf_offset, local_len;
+    u64* q_local;
+    static void run(hipStream_t s, void* p) {
+        auto* c = static_cast<QuotientValuesCall*>(p);
+        vpbs::launch_quotient_values(s, c->wires, c->sigmas, c->zs_pp, c->roots, c->l0, nullptr, c->d_apow, c->betas, c->gammas, c->n_routed, c->log_n,
+                                     c->rate_bits, c->max_degree, c->nc, c->leaf_offset, c->local_len, c->q_local, true);
+    }
+};
+
+// compute_quotient_polys on the device; d_out: [nc * 2^rate_bits][n] coefficient chunks.  Gate terms: none, precomputed
+// (d_gate_terms), or evaluated here next to the permutation part (gw)
 void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constants, vpbs_batch* wires, vpbs_batch* zs_pp,
                                  unsigned n_routed, const u64* betas, const u64* gammas, const u64* alphas, unsigned nc,
-                                 unsigned max_degree, const u64* d_gate_terms, u64* d_out, const vpbs_comm* comm = nullptr) {
+                                 unsigned max_degree, const u64* d_gate_terms, u64* d_out, const vpbs_comm* comm = nullptr,
+                                 const GateWork* gw = nullptr) {
     VPBS_REQUIRE(cs && wires && zs_pp && cs->ctx == ctx && wires->ctx == ctx && zs_pp->ctx == ctx, "batches of another context");
     const unsigned world = wires->n_shards;
     VPBS_REQUIRE(cs->n_shards == world && zs_pp->n_shards == world && cs->shard == wires->shard && zs_pp->shard == wires->shard,
@@ -416,15 +436,55 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
     u64* d_apow = ctx->alloc_words(h_apow.size());
     u64* q_leaf = ctx->alloc_words((size_t)nc * big);
     u64* q_nat = ctx->alloc_words((size_t)nc * big);
+    u64 *d_gpow = nullptr, *lane_buf = nullptr;
     const size_t local_len = wires->lde_len(), leaf_offset = wires->leaf_offset();
     try {
         VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, s));
         const u64* l0 = ctx->l0_table(log_n);
         const u64* gathered = q_leaf;
-        {
+        u64* q_local = world > 1 ? comm->d_stage_local : q_leaf;
+        if (world > 1) VPBS_REQUIRE((size_t)nc * local_len <= comm->stage_capacity_words, "comm staging buffers too small for the quotient values");
+        if (gw) {
+            // gate constraints on three streams with the permutation part riding along as one more independent item
+            vpbs::validate_gates(gw->gates, gw->n_gates, gw->num_selectors, cs->ncols, wires->ncols);
+            VPBS_REQUIRE(gw->num_selectors <= n_constants, "selector columns must be leading constants columns");
+            unsigned stride = 1;
+            for (unsigned i = 0; i < gw->n_gates; ++i) stride = std::max(stride, gw->gates[i].num_constraints);
+            std::vector<u64> h_gpow((size_t)nc * stride);
+            for (unsigned a = 0; a < nc; ++a) {
+                u64 p = 1;
+                for (unsigned i = 0; i < stride; ++i) {
+                    h_gpow[(size_t)a * stride + i] = p;
+                    p = gl::mul(p, alphas[a]);
+                }
+            }
+            d_gpow = ctx->alloc_words(h_gpow.size());
+            lane_buf = ctx->alloc_words(3 * (size_t)nc * local_len);
+            VPBS_HIP(hipMemcpyAsync(d_gpow, h_gpow.data(), sizeof(u64) * h_gpow.size(), hipMemcpyHostToDevice, s));
+            ctx->ensure_gate_lanes();
+            QuotientValuesCall call{wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde, ctx->roots(log_big, false), l0, d_apow,
+                                    betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_local};
+            vpbs::GateLanes lanes{};
+            lanes.stream[0] = ctx->gate_streams[0];
+            lanes.stream[1] = ctx->gate_streams[1];
+            lanes.fork = ctx->gate_fork;
+            lanes.join[0] = ctx->gate_join[0];
+            lanes.join[1] = ctx->gate_join[1];
+            lanes.out[0] = lane_buf + (size_t)nc * local_len;
+            lanes.out[1] = lane_buf + 2 * (size_t)nc * local_len;
+            lanes.extra = &QuotientValuesCall::run;
+            lanes.extra_arg = &call;
+            lanes.extra_weight = 165;
+            lanes.skip_sum = true;
+            u64 apow_last[4] = {0, 0, 0, 0};
+            for (unsigned a = 0; a < nc; ++a) apow_last[a] = h_apow[(size_t)a * (n_terms + 1) + n_terms];
+            Timed t(ctx, "gate_constraints");  // gates + permutation part, overlapped
+            vpbs::launch_gate_terms(s, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride, nc,
+                                    lane_buf, &lanes);
+            vpbs::launch_quotient_combine(s, q_local, lanes.used[0] ? lane_buf : nullptr, lanes.used[1] ? lanes.out[0] : nullptr,
+                                          lanes.used[2] ? lanes.out[1] : nullptr, apow_last, log_n, rate_bits, nc, leaf_offset, local_len);
+        } else {
             Timed t(ctx, "quotient_permutation");
-            u64* q_local = world > 1 ? comm->d_stage_local : q_leaf;
-            if (world > 1) VPBS_REQUIRE((size_t)nc * local_len <= comm->stage_capacity_words, "comm staging buffers too small for the quotient values");
             vpbs::launch_quotient_values(s, wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde, ctx->roots(log_big, false), l0,
                                          d_gate_terms, d_apow, betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len,
                                          q_local);
@@ -444,13 +504,19 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
         if (world > 1) VPBS_HIP(hipStreamSynchronize(s));  // the staging buffers belong to the communicator: done with them
     } catch (...) {
         (void)hipStreamSynchronize(s);
+        for (auto st : ctx->gate_streams)
+            if (st) (void)hipStreamSynchronize(st);
         ctx->release(d_apow); ctx->release(q_leaf); ctx->release(q_nat);
+        if (d_gpow) ctx->release(d_gpow);
+        if (lane_buf) ctx->release(lane_buf);
         throw;
     }
-    // stream-ordered reuse of the scratch blocks is safe: later work is enqueued on the same stream
+    // stream-ordered reuse of the scratch blocks is safe: later work is enqueued on the same stream (the helper streams were joined)
     ctx->release(d_apow);
     ctx->release(q_leaf);
     ctx->release(q_nat);
+    if (d_gpow) ctx->release(d_gpow);
+    if (lane_buf) ctx->release(lane_buf);
 }
 }  // namespace
 
@@ -684,14 +750,17 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             u64* d_q = ctx->alloc_words((size_t)in->n_quotient * n);
             staged.push_back(d_q);
             u64* d_gate = nullptr;
-            if (in->gates && in->n_gates) {  // evaluate_gate_constraints_base_batch for the circuit's gate set
+            static const bool env_single = [] { const char* e = getenv("VPBS_GATE_LANES"); return e && atoi(e) == 1; }();
+            const bool overlapped = in->gates && in->n_gates >= 4 && ctx->gate_lanes == 3 && !env_single;
+            if (in->gates && in->n_gates && !overlapped) {  // evaluate_gate_constraints_base_batch for the circuit's gate set
                 VPBS_REQUIRE(in->num_selectors <= in->n_constants, "selector columns must be leading constants columns");
                 d_gate = ctx->alloc_words((size_t)nc * wires.h->lde_len());
                 staged.push_back(d_gate);
                 gate_terms_device(ctx, in->constants_sigmas, wires.h, in->gates, in->n_gates, in->num_selectors, pi_hash.data(), alphas.data(), nc, d_gate);
             }
+            const GateWork gw{in->gates, in->n_gates, in->num_selectors, pi_hash.data()};
             quotient_permutation_device(ctx, in->constants_sigmas, in->n_constants, wires.h, zs_pp.h, in->n_routed, betas.data(),
-                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, d_gate, d_q, comm);
+                                        gammas.data(), alphas.data(), nc, in->quotient_degree_factor, d_gate, d_q, comm, overlapped ? &gw : nullptr);
             d_quot = d_q;
         }
         PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);

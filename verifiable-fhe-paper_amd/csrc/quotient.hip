@@ -45,7 +45,7 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
                      const u64* __restrict__ roots_big, const u64* __restrict__ l0_table, const u64* __restrict__ gate_terms,
                      const u64* __restrict__ apow,
                      QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc,
-                     size_t leaf_offset, size_t local_len, u64* __restrict__ q) {
+                     size_t leaf_offset, size_t local_len, u64* __restrict__ q, int raw) {
     // The column arrays hold the leaves [leaf_offset, leaf_offset + local_len) only (a whole number of cosets; the full
     // LDE when unsharded): `big` below is their column stride and j the LOCAL leaf index.
     const unsigned log_big = log_n + rate_bits;
@@ -114,9 +114,32 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
     for (int a = 0; a < 4; ++a) {
         if ((unsigned)a >= nc) continue;
         u64 v = acc[a];
+        if (raw) {  // the gate terms and the division by Z_H are applied by quotient_combine_kernel (the gates run concurrently)
+            q[(size_t)a * big + j] = v;
+            continue;
+        }
         if (gate_terms) v = gl::add(v, gl::mul(gate_terms[(size_t)a * big + j], apow[a * (n_terms + 1) + n_terms]));
         q[(size_t)a * big + j] = gl::mul(v, k.zh_inv[r]);
     }
+}
+
+// q[a][j] <- (q[a][j] + alpha_a^(n_terms) * (g0 + g1 + g2)[a][j]) / Z_H(x_j): joins the permutation part (raw) with the gate terms of
+// up to three lanes (null = unused)
+struct CombineConsts {
+    u64 zh_inv[8], apow_last[4];
+};
+__global__ void __launch_bounds__(THREADS)
+quotient_combine_kernel(u64* __restrict__ q, const u64* __restrict__ g0, const u64* __restrict__ g1, const u64* __restrict__ g2,
+                        CombineConsts k, unsigned log_big, unsigned rate_bits, size_t leaf_offset, size_t local_len) {
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= local_len) return;
+    const unsigned a = blockIdx.y;
+    const unsigned t = gl::bitrev32((u32)(leaf_offset + j), log_big);
+    const size_t i = (size_t)a * local_len + j;
+    u64 g = g0 ? g0[i] : 0;
+    if (g1) g = gl::add(g, g1[i]);
+    if (g2) g = gl::add(g, g2[i]);
+    q[i] = gl::mul(gl::add(q[i], gl::mul(g, k.apow_last[a])), k.zh_inv[t & ((1u << rate_bits) - 1)]);
 }
 
 // out[a][t] = value of challenge a at leaf bitrev(t)  (leaf order -> natural order).  `in` is rank-major
@@ -156,7 +179,7 @@ void launch_l0_table(hipStream_t s, const u64* roots_big, unsigned log_n, unsign
 void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigmas_lde, const u64* zs_pp_lde, const u64* roots_big,
                             const u64* l0_table, const u64* d_gate_terms, const u64* d_apow, const u64* betas, const u64* gammas,
                             unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc, size_t leaf_offset,
-                            size_t local_len, u64* q_leaf_local) {
+                            size_t local_len, u64* q_leaf_local, bool raw) {
     QuotientConsts k = make_consts(log_n, rate_bits);
     for (unsigned c = 0; c < nc; ++c) {
         k.beta[c] = betas[c];
@@ -165,10 +188,20 @@ void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigm
     const dim3 grid((unsigned)((local_len + THREADS - 1) / THREADS));
     if (max_degree == 8)
         hipLaunchKernelGGL(quotient_perm_kernel<8>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
-                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local);
+                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local, raw ? 1 : 0);
     else
         hipLaunchKernelGGL(quotient_perm_kernel<0>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
-                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local);
+                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local, raw ? 1 : 0);
+}
+
+void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u64* g1, const u64* g2, const u64* apow_last, unsigned log_n,
+                             unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len) {
+    const QuotientConsts qc = make_consts(log_n, rate_bits);
+    CombineConsts k{};
+    for (unsigned r = 0; r < 8; ++r) k.zh_inv[r] = qc.zh_inv[r];
+    for (unsigned a = 0; a < nc; ++a) k.apow_last[a] = apow_last[a];
+    hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((local_len + THREADS - 1) / THREADS), nc), dim3(THREADS), 0, s, q_local, g0, g1, g2, k,
+                       log_n + rate_bits, rate_bits, leaf_offset, local_len);
 }
 
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
