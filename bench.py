@@ -35,6 +35,9 @@ LOG_N = 15                 # degree of the step circuit at N = 1024 (ivc_based_v
 GATES = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext", "reducing",
          "reducing_ext", ("random_access", 4), "exponentiation", "coset_interpolation"]
 N_CONSTANTS, N_ROUTED = 6, 80   # constants_sigmas = 4 selectors + 2 gate constants + 80 sigma columns
+# public inputs of a step proof at N = 1024, K = 2 (ivc_based_vpbs.rs:196-207): acc_init 2048 + counter + current
+# accumulator 2048 + two chain hashes 8 + verifier data 68
+N_PUBLIC_INPUTS = 4173
 COLS = dict(synth.STEP_COLS, constants_sigmas=N_CONSTANTS + N_ROUTED)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU issue ceiling: a wave64 instruction occupies a 16-lane SIMD for 4 cycles (measured 4.1-4.2 for integer multiply / VOP3 / carry
@@ -68,7 +71,7 @@ def cpu_baseline():
     import step_oracle
     orc.build()
     inputs = synth.step_inputs(LOG_N, cols=COLS)
-    pis = synth.field_elements(0xABCD, 77)
+    pis = synth.field_elements(0xABCD, N_PUBLIC_INPUTS)
     digest = np.array([11, 22, 33, 44], np.uint64)
     cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)   # committed once per circuit: untimed
     t0 = time.time()
@@ -148,7 +151,7 @@ def main():
                                             device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
         else:
             cs = ctx.commit_values(inputs["constants_sigmas"])      # once per circuit, untimed
-        pis = synth.field_elements(0xABCD + inst, 77)
+        pis = synth.field_elements(0xABCD + inst, N_PUBLIC_INPUTS)
         sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
         si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, quot_ptr, cs, digest, pis,
                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
@@ -208,7 +211,7 @@ def main():
             inp = synth.step_inputs(log_n, instance=c, cols=COLS)
             dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
             csb = cx.commit_values(inp["constants_sigmas"])
-            pi2 = synth.field_elements(0xABCD + c, 77)
+            pi2 = synth.field_elements(0xABCD + c, N_PUBLIC_INPUTS)
             sp = dv["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)
             extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, None, csb, digest, pi2,
                                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
