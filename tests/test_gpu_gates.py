@@ -343,3 +343,24 @@ def test_product_reproduces_frozen_step_proofs(ctx):
                                       n_constants=b["n_constants"], gates=api.GateSet(b["gates"]))
         rc.check(case, ctx.prove_step(si))
         cs.free()
+
+
+def test_gate_lanes_setting_does_not_change_the_proof(ctx):
+    """one stream or three (gate kernels + permutation part overlapped): identical proof"""
+    r = random.Random(11)
+    log_n, n_routed = 8, 80
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    pis = [r.randrange(P) for _ in range(4)]
+    constants, wires, sigma, _ = go.demo_circuit(r, gs, log_n, pis)
+    cs = ctx.commit_values(np.concatenate([constants, sigma]))
+    si = ctx.make_step_inputs(log_n, wires, None, None, cs, DIGEST, pis, sigmas=sigma, n_routed=n_routed, n_constants=constants.shape[0], gates=ps)
+    proofs = []
+    for lanes in (3, 1, 3):
+        ctx.set_gate_lanes(lanes)
+        proofs.append(ctx.prove_step(si))
+    ctx.set_gate_lanes(3)
+    for key in ("caps", "openings", "fri"):
+        assert (proofs[0][key] == proofs[1][key]).all() and (proofs[0][key] == proofs[2][key]).all()
+    with pytest.raises(api.VpbsError):
+        ctx.set_gate_lanes(2)
+    cs.free()
