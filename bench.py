@@ -81,9 +81,10 @@ def cpu_baseline():
                            gates=gates_oracle.GateSet(GATES))
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
-            "cores": os.cpu_count(), "kind": "port",
+            "cores": orc.effective_cpus(), "kind": "port",
             "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
-                      "and quotient included) with the C oracle, OpenMP on all host cores",
+                      "and quotient included) with the C oracle, OpenMP on every CPU the container may use "
+                      "(cgroup CPU quota; os.cpu_count() = %d)" % (os.cpu_count() or 0),
             "note": "scalar restatement (naive Poseidon, ~8 us per permutation per core; PoW and Merkle top levels serial); "
                     "plonky2's own AVX2 Poseidon is roughly an order of magnitude faster per core -- a reported baseline, "
                     "not a tuned CPU prover"}

@@ -7,6 +7,10 @@
 #include "vpbs_oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define ORC_TRACE(label, t0) do { if (getenv("ORC_TRACE")) fprintf(stderr, "[orc] %-22s %.3f s\n", label, orc_now() - (t0)); } while (0)
 
 struct orc_merkle {
     size_t n_leaves, leaf_len;
@@ -22,12 +26,15 @@ orc_merkle* orc_merkle_new(const u64* leaves, size_t n_leaves, size_t leaf_len, 
     orc_merkle* t = (orc_merkle*)calloc(1, sizeof *t);
     t->n_leaves = n_leaves; t->leaf_len = leaf_len; t->log_leaves = log_leaves; t->cap_height = cap_height;
     t->leaves = (u64*)malloc(sizeof(u64) * n_leaves * leaf_len);
+    double t0 = orc_now();
     memcpy(t->leaves, leaves, sizeof(u64) * n_leaves * leaf_len);
+    ORC_TRACE("  leaves memcpy", t0); t0 = orc_now();
     unsigned n_levels = log_leaves - cap_height + 1;
     t->levels = (u64**)calloc(n_levels, sizeof(u64*));
     t->levels[0] = (u64*)malloc(sizeof(u64) * 4 * n_leaves);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n_leaves; ++i) orc_hash_or_noop(t->leaves + i * leaf_len, leaf_len, t->levels[0] + 4 * i);
+    ORC_TRACE("  leaf hashing", t0); t0 = orc_now();
     for (unsigned k = 1; k < n_levels; ++k) {
         size_t cnt = n_leaves >> k;
         t->levels[k] = (u64*)malloc(sizeof(u64) * 4 * cnt);
@@ -35,6 +42,7 @@ orc_merkle* orc_merkle_new(const u64* leaves, size_t n_leaves, size_t leaf_len, 
         for (size_t i = 0; i < cnt; ++i)
             orc_two_to_one(t->levels[k - 1] + 8 * i, t->levels[k - 1] + 8 * i + 4, t->levels[k] + 4 * i);
     }
+    ORC_TRACE("  levels", t0);
     return t;
 }
 
@@ -89,8 +97,10 @@ orc_batch* orc_batch_from_coeffs(const u64* coeffs, size_t ncols, unsigned log_n
     memcpy(b->coeffs, coeffs, sizeof(u64) * ncols * n);
     u64* leaves = (u64*)malloc(sizeof(u64) * big * ncols);
     u64* lde = (u64*)malloc(sizeof(u64) * big * ncols); /* column-major [ncols][big], natural order */
+    double t0 = orc_now();
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < ncols; ++c) orc_coset_lde(b->coeffs + c * n, log_n, rate_bits, GL_GENERATOR, lde + c * big);
+    ORC_TRACE("lde", t0); t0 = orc_now();
     /* transpose + reverse_index_bits_in_place: leaves[j][c] = lde_c[brev(j)]; parallel over leaf rows so that no two
      * threads write the same cache line */
 #pragma omp parallel for schedule(static)
@@ -104,8 +114,10 @@ orc_batch* orc_batch_from_coeffs(const u64* coeffs, size_t ncols, unsigned log_n
                 for (size_t c = c0; c < c1; ++c) leaves[rows[t - s0] * ncols + c] = lde[c * big + t];
         }
     }
+    ORC_TRACE("transpose", t0); t0 = orc_now();
     free(lde);
     b->tree = orc_merkle_new(leaves, big, ncols, cap_height);
+    ORC_TRACE("merkle_new", t0);
     free(leaves);
     if (!b->tree) { free(b->coeffs); free(b); return NULL; }
     return b;

@@ -7,6 +7,9 @@
 #include "vpbs_oracle.h"
 #include "poseidon_constants.h"
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static const u64 MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 static const u64 MDS_DIAG[12] = {8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -88,4 +91,14 @@ void orc_ext_mul(const u64 a[2], const u64 b[2], u64 out[2]) {
 void orc_ext_inv(const u64 a[2], u64 out[2]) {
     ext2 r = ext_inv(ext_make(a[0], a[1]));
     out[0] = r.c[0]; out[1] = r.c[1];
+}
+
+/* number of OpenMP threads the oracle uses (the test harness sets it to the CPU quota of the container: a 256-CPU host with a
+ * 16-core cgroup quota runs 256 threads far slower than 16) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

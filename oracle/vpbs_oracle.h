@@ -24,6 +24,8 @@
 extern "C" {
 #endif
 
+void orc_set_num_threads(int n); /* OpenMP threads used by every parallel loop of the oracle */
+
 /* ---- field helpers exported for ctypes ---- */
 u64 orc_gl_add(u64 a, u64 b);
 u64 orc_gl_sub(u64 a, u64 b);

@@ -43,6 +43,26 @@ class FriBatchInfo(C.Structure):
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process can really use: the scheduler affinity capped by the cgroup CPU quota (containers on many-core hosts)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -87,6 +107,8 @@ def lib():
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        L.orc_set_num_threads.restype, L.orc_set_num_threads.argtypes = None, [C.c_int]
+        L.orc_set_num_threads(effective_cpus())
         _lib = L
     return _lib
 
