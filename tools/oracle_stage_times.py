@@ -31,6 +31,6 @@ batches, zeta_next = step_oracle.step_batches(ncols, 2, zeta, log_n)
 openings = timed("openings", lambda: np.concatenate([o.eval_ext(zeta) for o in oracles] + [zb.eval_ext(zeta_next)[:2]]))
 ch.observe(openings)
 fri = timed("fri (prove_openings)", lambda: orc.prove_openings(oracles, batches, ch, orc.fri_params(log_n), log_n))
-print("total %.2f s on %d cpus" % (time.time() - t_all, os.cpu_count()))
+print("total %.2f s with %d OpenMP threads (os.cpu_count() = %d)" % (time.time() - t_all, orc.effective_cpus(), os.cpu_count()))
 for k, v in T.items():
     print("  %-22s %.3f s" % (k, v))
