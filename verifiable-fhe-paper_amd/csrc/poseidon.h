@@ -267,9 +267,14 @@ constexpr int WIDE_LANES = 16, WIDE_LDS_WORDS = 48;  // 48-word stride keeps the
 __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const unsigned row = l < 12 ? l : 0;
+    // this lane's row of M^3 and its entries of the first columns of M^2 and M (fused partial rounds below)
+    u32 m3[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) m3[j] = MDS3[row][j];
+    const u32 m2c = MDS2[row][0], m1c = MDS1[row][0];
     x = gl::add_nc(x, rc(row));
-    for (int r = 0; r < N_ROUNDS; ++r) {
-        const bool full = r < HALF_FULL || r >= HALF_FULL + N_PARTIAL;
+    // one plain round: S-box (full: every lane; partial: lane 0), exchange through LDS, this lane's MDS row + next constants
+    auto plain_round = [&](int r, bool full) {
         if (full || l == 0) x = sbox_ilp(x);
         // the 16 lanes of a group live in one wave: LDS operations of a wave execute in order, so a wavefront-scope
         // fence (compiler ordering only) is all the synchronisation the exchange needs
@@ -293,7 +298,48 @@ __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
             ah[1] += (x >> 32) * 8u;
         }
         x = fold96(al[0] + al[1] + al[2], ah[0] + ah[1] + ah[2]);
+    };
+    for (int r = 0; r < HALF_FULL; ++r) plain_round(r, true);
+    // 21 partial rounds as 7 fused groups of three (same algebra as partial_group3_core): ONE exchange per group.  After it every
+    // lane holds the whole post-S-box state y, so every lane computes the two inner S-box inputs x2_0 = (M y)[0] + k2 and
+    // x3_0 = (M^2 y)[0] + M00 d2 + k3 redundantly (no broadcast), and its own row of M^3 y + d2 M^2[:,0] + d3 M[:,0] + kvec.
+    // The M^3 row and most of the x3 dot product do not depend on the inner S-boxes: independent work for the scheduler to place
+    // inside their dependent chains.  Critical path per group: 3 S-boxes + 1 LDS round trip instead of 3 + 3.
+    for (int g = 0; g < 7; ++g) {
+        const PartialGroup& G = partial_group(g);
+        const u64 k2 = G.k2, k3 = G.k3, kv = G.kvec[row];
+        if (l == 0) x = sbox_ilp(x);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (l < 12) sh[l] = x;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        u32 lo[12], hi[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const u64 v = sh[j];
+            lo[j] = (u32)v;
+            hi[j] = (u32)(v >> 32);
+        }
+        u64 a_lo[2] = {(u32)k2, 0}, a_hi[2] = {k2 >> 32, 0};      // x2_0
+        u64 b_lo[2] = {(u32)k3, 0}, b_hi[2] = {k3 >> 32, 0};      // x3_0 without the d2 term
+        u64 c_lo[3] = {(u32)kv, 0, 0}, c_hi[3] = {kv >> 32, 0, 0};  // this lane's row of M^3 y + kvec
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            a_lo[j % 2] += (u64)lo[j] * MDS1[0][j];
+            a_hi[j % 2] += (u64)hi[j] * MDS1[0][j];
+            b_lo[j % 2] += (u64)lo[j] * MDS2[0][j];
+            b_hi[j % 2] += (u64)hi[j] * MDS2[0][j];
+            c_lo[j % 3] += (u64)lo[j] * m3[j];
+            c_hi[j % 3] += (u64)hi[j] * m3[j];
+        }
+        const u64 x2 = gl::canon(fold96(a_lo[0] + a_lo[1], a_hi[0] + a_hi[1]));
+        const u64 d2 = gl::sub(gl::canon(sbox_ilp(x2)), x2);
+        const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+        const u64 x3 = gl::canon(fold96(b_lo[0] + b_lo[1] + (u64)d2l * MDS1[0][0], b_hi[0] + b_hi[1] + (u64)d2h * MDS1[0][0]));
+        const u64 d3 = gl::sub(gl::canon(sbox_ilp(x3)), x3);
+        const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
+        x = fold96(c_lo[0] + c_lo[1] + c_lo[2] + (u64)d2l * m2c + (u64)d3l * m1c, c_hi[0] + c_hi[1] + c_hi[2] + (u64)d2h * m2c + (u64)d3h * m1c);
     }
+    for (int r = HALF_FULL + N_PARTIAL - 1; r < N_ROUNDS; ++r) plain_round(r, r >= HALF_FULL + N_PARTIAL);
     return gl::canon(x);
 }
 #endif
