@@ -273,8 +273,18 @@ __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
     for (int j = 0; j < 12; ++j) m3[j] = MDS3[row][j];
     const u32 m2c = MDS2[row][0], m1c = MDS1[row][0];
     x = gl::add_nc(x, rc(row));
+    // this lane's round constants are fetched up front (16 independent loads, one memory latency) instead of one exposed
+    // lane-indexed load per round on the dependent chain
+    u64 kplain[9], kgroup[7];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = i < 4 ? i : HALF_FULL + N_PARTIAL - 1 + (i - 4);  // plain rounds: 0..3, 25, 26..29
+        kplain[i] = r + 1 < N_ROUNDS ? rc(12 * (r + 1) + row) : 0;
+    }
+#pragma unroll
+    for (int g = 0; g < 7; ++g) kgroup[g] = partial_group(g).kvec[row];
     // one plain round: S-box (full: every lane; partial: lane 0), exchange through LDS, this lane's MDS row + next constants
-    auto plain_round = [&](int r, bool full) {
+    auto plain_round = [&](u64 k, bool full) {
         if (full || l == 0) x = sbox_ilp(x);
         // the 16 lanes of a group live in one wave: LDS operations of a wave execute in order, so a wavefront-scope
         // fence (compiler ordering only) is all the synchronisation the exchange needs
@@ -284,7 +294,6 @@ __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
             sh[l + 12] = x;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const u64 k = r + 1 < N_ROUNDS ? rc(12 * (r + 1) + row) : 0;
         // three independent accumulator chains per half (latency: 4 dependent multiply-adds instead of 12)
         u64 al[3] = {(u32)k, 0, 0}, ah[3] = {k >> 32, 0, 0};
 #pragma unroll
@@ -299,15 +308,17 @@ __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
         }
         x = fold96(al[0] + al[1] + al[2], ah[0] + ah[1] + ah[2]);
     };
-    for (int r = 0; r < HALF_FULL; ++r) plain_round(r, true);
+#pragma unroll
+    for (int i = 0; i < HALF_FULL; ++i) plain_round(kplain[i], true);
     // 21 partial rounds as 7 fused groups of three (same algebra as partial_group3_core): ONE exchange per group.  After it every
     // lane holds the whole post-S-box state y, so every lane computes the two inner S-box inputs x2_0 = (M y)[0] + k2 and
     // x3_0 = (M^2 y)[0] + M00 d2 + k3 redundantly (no broadcast), and its own row of M^3 y + d2 M^2[:,0] + d3 M[:,0] + kvec.
     // The M^3 row and most of the x3 dot product do not depend on the inner S-boxes: independent work for the scheduler to place
     // inside their dependent chains.  Critical path per group: 3 S-boxes + 1 LDS round trip instead of 3 + 3.
+#pragma unroll
     for (int g = 0; g < 7; ++g) {
         const PartialGroup& G = partial_group(g);
-        const u64 k2 = G.k2, k3 = G.k3, kv = G.kvec[row];
+        const u64 k2 = G.k2, k3 = G.k3, kv = kgroup[g];
         if (l == 0) x = sbox_ilp(x);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (l < 12) sh[l] = x;
@@ -339,7 +350,8 @@ __device__ __forceinline__ u64 permute_wide(u64 x, u64* sh, unsigned l) {
         const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
         x = fold96(c_lo[0] + c_lo[1] + c_lo[2] + (u64)d2l * m2c + (u64)d3l * m1c, c_hi[0] + c_hi[1] + c_hi[2] + (u64)d2h * m2c + (u64)d3h * m1c);
     }
-    for (int r = HALF_FULL + N_PARTIAL - 1; r < N_ROUNDS; ++r) plain_round(r, r >= HALF_FULL + N_PARTIAL);
+#pragma unroll
+    for (int i = 4; i < 9; ++i) plain_round(kplain[i], i > 4);
     return gl::canon(x);
 }
 #endif
