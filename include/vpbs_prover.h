@@ -287,8 +287,9 @@ typedef struct {
 int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out);
 
 /* Runs: wires commit -> observe digest, PI hash, cap -> betas, gammas -> Z/pp commit -> alphas -> quotient commit ->
- * zeta -> openings -> observe -> prove_openings/fri_proof.  (Partial products and quotient evaluation are host stages
- * in this round -- SURVEY.md 8f-1 -- so their inputs arrive as data.)
+ * zeta -> openings -> observe -> prove_openings/fri_proof.  The Z / partial-product values and the quotient chunks are either
+ * supplied (zs_pp_values / quotient_coeffs) or computed on the device (NULL: vpbs_partial_products; gate constraints of in->gates +
+ * permutation argument, vpbs_gate_terms + vpbs_quotient_permutation).
  * caps_out: [3][cap_words] (wires, zs_partial_products, quotient); openings_out: ext values in plonky2 field order
  * constants, plonk_sigmas, wires, plonk_zs, partial_products, quotient_polys (all at zeta) then plonk_zs_next (g*zeta);
  * challenges_out (optional, may be NULL): betas[nc], gammas[nc], alphas[nc], zeta[2]. */

@@ -3,8 +3,9 @@
 // `eval_vanishing_poly_base_batch` (the L_0 (Z - 1) terms and `check_partial_products`), the Z_H division of
 // plonk/plonk_common.rs `ZeroPolyOnCoset`, the coset iFFT and the split into degree-n chunks -- the stage between the
 // Z/partial-products commitment and the quotient commitment of prove() (/root/reference/src/vtfhe/
-// ivc_based_vpbs.rs:302,333,364).  The gate-constraint terms of the ~15 gate
-// types are NOT evaluated here: they enter as an optional, already alpha-folded input per challenge.
+// ivc_based_vpbs.rs:302,333,364).  The gate-constraint terms are evaluated by
+// gates.hip; they enter here already alpha-folded per challenge (quotient_perm_kernel) or are joined in by quotient_combine_kernel
+// when the gates ran concurrently with the permutation part.
 //
 // One thread per LDE point: it reads the committed LDE columns of the routed wires, the sigmas and the Z / partial
 // products straight from the batches' HBM buffers (column-major, leaf order => coalesced), so nothing is downloaded
