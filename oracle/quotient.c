@@ -4,8 +4,8 @@
  * `check_partial_products`), plonk/plonk_common.rs `ZeroPolyOnCoset` (Z_H on the coset, eval_l_0) and
  * `reduce_with_powers_multi`, plonk/verifier.rs (the check vanishing(zeta) == Z_H(zeta) * reduce(chunks, zeta^n)) --
  * SURVEY.md 8a row a13, Appendix A.9; reached from prove() at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364
- * and cd.verify() at :446.  Gate-constraint terms are an input (alpha-folded per challenge): evaluating the ~15 gate
- * types of the step circuit is not restated.  parity unpinned against real plonky2; prover and verifier sides are
+ * and cd.verify() at :446.  Gate-constraint terms are an input (alpha-folded per challenge), produced by gates.c.
+ * parity unpinned against real plonky2; prover and verifier sides are
  * checked against each other (a valid copy-constraint witness must verify, an invalid one must not). */
 #include "vpbs_oracle.h"
 #include <stdlib.h>

@@ -3,7 +3,7 @@
 // H::two_to_one), hash/hashing.rs `hash_n_to_m_no_pad` (overwrite-mode sponge, rate 8) and fri/prover.rs
 // `fri_proof_of_work`, reached from prove() at /root/reference/src/vtfhe/ivc_based_vpbs.rs:302,333,364
 // (SURVEY.md 8a rows a5/a6/a11).  One lane = one leaf / node / nonce: the column-major, leaf-ordered LDE makes every
-// absorb a fully coalesced 512-B wave read.  Integer-VALU bound (~21k instructions per permutation); no MFMA.
+// absorb a fully coalesced 512-B wave read.  Integer-VALU bound (~15.3k instructions per permutation); no MFMA.
 #include <cstdlib>
 
 #include <algorithm>
