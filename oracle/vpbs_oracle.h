@@ -4,7 +4,9 @@
  * (verifiable-fhe-paper_amd/) never links, imports or calls it.
  *
  * What it restates: the stages of plonky2 0.2.0 `plonk::prover::prove` that the reference reaches at
- * /root/reference/src/vtfhe/ivc_based_vpbs.rs:302-308, :333-339, :364-370,
+ * /root/reference/src/vtfhe/ivc_based_vpbs.rs:302-308, :333-339, :364-370 (field, FFT/LDE, Poseidon,
+ * Merkle, PolynomialBatch, Challenger, openings, FRI prover AND verifier, permutation partial products, quotient polynomials with
+ * the constraints of 14 gate types),
  * plus the reference's own native negacyclic NTT (/root/reference/src/vtfhe/crypto/poly.rs:9-64).
  * plonky2 0.2.0 / plonky2_field 0.2.0 / plonky2_util 0.2.0 are un-vendored crates.io dependencies
  * (/root/reference/Cargo.lock:371-374, :396-399, :421-424); their algorithm is restated from the published
