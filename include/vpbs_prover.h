@@ -196,6 +196,24 @@ int vpbs_gate_terms_at(const vpbs_gate* gates, unsigned n_gates, unsigned num_se
  * inputs already present in `row` ([num_wires], one trace row) fills the wires the gate's generators own (outputs,
  * S-box inputs, limbs, intermediate accumulators ...).  constants: the gate constants of that row. */
 int vpbs_gate_fill_row(const vpbs_gate* gate, const uint64_t* constants, uint64_t* row);
+/* Gadget-level generators (the ones the reference's own gadgets instantiate outside the recursive verifier: builder.is_equal ->
+ * EqualityGenerator, le_sum -> BaseSumGenerator, split_le -> WireSplitGenerator; /root/reference/src/vtfhe/ivc_based_vpbs.rs:104-107
+ * and the decomposition / rotation gadgets).  Targets are wire positions (column * n + row): a virtual target is identified with a
+ * wire it is connected to. */
+typedef enum {
+    VPBS_GEN_EQUALITY = 0, /* gadgets/arithmetic.rs EqualityGenerator: in = [x, y]; out = [equal, inv]: equal = (x == y), inv = (x - y)^-1 or 0 */
+    VPBS_GEN_BASE_SUM,     /* gates/base_sum.rs BaseSumGenerator (le_sum): p0 = base B; in = limbs (little endian); out = [sum] */
+    VPBS_GEN_WIRE_SPLIT    /* gadgets/split_join.rs WireSplitGenerator (split_le): p0 = limbs per gate; in = [integer]; out = the BaseSumGate sum wire of
+                              every gate: chunk k = bits [k p0, (k+1) p0) of the canonical integer; error if bits remain */
+} vpbs_generator_kind;
+typedef struct {
+    unsigned kind, p0;
+    const uint32_t* in;
+    unsigned n_in;
+    const uint32_t* out;
+    unsigned n_out;
+} vpbs_generator;
+
 /* A circuit over the supported gates, as CircuitBuilder::build leaves it in ProverOnlyCircuitData / CommonCircuitData:
  * the gate instance of every row, the constants columns, and the copy constraints between routed wires. */
 typedef struct {
@@ -207,6 +225,8 @@ typedef struct {
     unsigned n_constants_cols;
     const uint32_t* copies;              /* [n_copies][2]: wire positions (column * n + row, column < n_routed) constrained equal */
     size_t n_copies;
+    const vpbs_generator* generators;    /* gadget-level generators (may be NULL / 0) */
+    size_t n_generators;
 } vpbs_circuit;
 /* gates/selectors.rs selector_polynomials: out [num_selectors][n] = the gate's index on its selector, UNUSED elsewhere */
 int vpbs_selector_columns(const vpbs_circuit* circuit, uint64_t* out);

@@ -383,3 +383,74 @@ def test_witness_generation_reproduces_the_demo_circuit():
     del missing[(0, 1)]
     with pytest.raises(api.VpbsError, match="weren't run"):
         circ.generate_witness(missing)
+
+
+def test_gadget_level_generators_is_equal_split_le_le_sum():
+    """The generator kinds the reference's own gadgets add outside the recursive verifier (builder.is_equal, cb.split_le, cb.le_sum:
+    /root/reference/src/vtfhe/ivc_based_vpbs.rs:104-107 and the decomposition gadgets), scheduled together with the gate generators:
+      is_equal(x, y):  EqualityGenerator -> (equal, inv); ArithmeticGate ops check diff * inv = 1 - equal and diff * equal = 0
+      split_le(v, 64): WireSplitGenerator -> the sum wires of two BaseSumGate<2> rows (63 + 1 bits), BaseSplitGenerator -> limbs
+      le_sum(bits):    BaseSumGenerator -> sum wire of a third BaseSumGate row fed with copies of the low bits
+    The witness must satisfy every gate and copy constraint (vpbs_check_witness) and mean what the gadgets mean."""
+    rng = random.Random(77)
+    spec = ["noop", "arithmetic", "base_sum"]
+    ps = api.GateSet(spec)
+    ar, bs, noop = ps.by_kind("arithmetic"), ps.by_kind("base_sum"), ps.by_kind("noop")
+    log_n = 3
+    n = 1 << log_n
+    for x, y, v in [(5, 5, 0xFFFFFFFF00000000), (rng.randrange(P), rng.randrange(P), rng.randrange(P)), (7, 8, 1), (0, 0, (1 << 63) + 12345)]:
+        row_gate = np.full(n, noop.index, np.uint32)
+        row_gate[0] = row_gate[1] = ar.index          # row 0: constants (1, -1): sub ; row 1: constants (1, 0): mul
+        row_gate[2] = row_gate[3] = row_gate[4] = bs.index
+        constants = np.zeros((ps.num_selectors + 2, n), np.uint64)
+        constants[ps.num_selectors, 0], constants[ps.num_selectors + 1, 0] = 1, P - 1
+        constants[ps.num_selectors, 1], constants[ps.num_selectors + 1, 1] = 1, 0
+        pos = lambda c, r: (c, r)
+        copies, presets, gens = [], {}, []
+        cp = lambda a, b: copies.append((a[0] * n + a[1], b[0] * n + b[1]))
+        # diff = x * 1 + (-1) * y           (row 0, op 0: wires 0..3)
+        presets[(0, 0)], presets[(1, 0)], presets[(2, 0)] = x, 1, y
+        # EqualityGenerator on (x, y) -> equal at (4, 1), inv at (1, 1)
+        gens.append(("equality", 0, [pos(0, 0), pos(2, 0)], [pos(4, 1), pos(1, 1)]))
+        # row 1 op 0: diff * inv            (wires 0..3: m0 = diff, m1 = inv, addend = 0)
+        cp(pos(3, 0), pos(0, 1))
+        presets[(2, 1)] = 0
+        # row 1 op 1: diff * equal          (wires 4..7: m0 = equal, m1 = diff, addend = 0)
+        cp(pos(3, 0), pos(5, 1))
+        presets[(6, 1)] = 0
+        # unused ops of rows 0, 1: free inputs
+        for r in (0, 1):
+            for op in range(2 if r else 1, ar.p0):
+                for k in range(3):
+                    presets[(4 * op + k, r)] = rng.randrange(P)
+        # split_le(v, 64): rows 2 (bits 0..62) and 3 (bit 63)
+        presets[(10, 5)] = v                                   # the integer lives on a noop row
+        gens.append(("wire_split", 63, [pos(10, 5)], [pos(0, 2), pos(0, 3)]))
+        # le_sum of the 20 low bits: row 4's limbs 0..19 are copies of row 2's, the others 0
+        for i in range(bs.p0):
+            if i < 20:
+                cp(pos(1 + i, 2), pos(1 + i, 4))
+            else:
+                presets[(1 + i, 4)] = 0
+        gens.append(("base_sum", 2, [pos(1 + i, 4) for i in range(bs.p0)], [pos(0, 4)]))
+        circ = api.Circuit(ps, log_n, row_gate, constants, copies, generators=gens)
+        constants[:ps.num_selectors] = circ.selector_columns()
+        circ = api.Circuit(ps, log_n, row_gate, constants, copies, generators=gens)
+        # row 3 would be generated twice for its sum wire: once by WireSplit (sum) and its limbs by the gate's BaseSplitGenerator
+        # (gate generator watches the sum); row 4's BaseSplitGenerator also runs once le_sum has set the sum: consistent by construction
+        w = circ.generate_witness(presets)
+        ok, msg = circ.check_witness(w, [0, 0, 0, 0])
+        assert ok, msg
+        diff = (x - y) % P
+        assert int(w[3, 0]) == diff and int(w[4, 1]) == (1 if x == y else 0)
+        assert int(w[3, 1]) == (0 if x == y else 1)             # diff * inv
+        assert int(w[7, 1]) == 0                                 # diff * equal
+        bits = [int(w[1 + i, 2]) for i in range(63)] + [int(w[1, 3])]
+        assert sum(b << i for i, b in enumerate(bits)) == v and all(int(w[1 + i, 3]) == 0 for i in range(1, 63))
+        assert int(w[0, 4]) == v & ((1 << 20) - 1)
+    # an integer that does not fit: split_le(v, 63) of a 64-bit value
+    gens_bad = [("wire_split", 63, [(10, 5)], [(0, 2)])]
+    row_gate = np.full(n, noop.index, np.uint32); row_gate[2] = bs.index
+    circ = api.Circuit(ps, log_n, row_gate, np.zeros((ps.num_selectors + 2, n), np.uint64), [], generators=gens_bad)
+    with pytest.raises(api.VpbsError, match="too large"):
+        circ.generate_witness({(10, 5): 1 << 63})

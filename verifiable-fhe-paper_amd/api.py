@@ -45,11 +45,19 @@ class GateC(C.Structure):
                 ("selector_index", C.c_uint), ("group_start", C.c_uint), ("group_end", C.c_uint), ("index", C.c_uint)]
 
 
+class GeneratorC(C.Structure):
+    """vpbs_generator"""
+    _fields_ = [("kind", C.c_uint), ("p0", C.c_uint), ("inp", U32P), ("n_in", C.c_uint), ("out", U32P), ("n_out", C.c_uint)]
+
+
+GENERATOR_KINDS = ["equality", "base_sum", "wire_split"]
+
+
 class CircuitC(C.Structure):
     """vpbs_circuit"""
     _fields_ = [("log_n", C.c_uint), ("n_wires", C.c_uint), ("n_routed", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint),
                 ("num_selectors", C.c_uint), ("row_gate", U32P), ("constants", U64P), ("n_constants_cols", C.c_uint),
-                ("copies", U32P), ("n_copies", C.c_size_t)]
+                ("copies", U32P), ("n_copies", C.c_size_t), ("generators", C.POINTER(GeneratorC)), ("n_generators", C.c_size_t)]
 
 
 GATE_KINDS = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext",
@@ -299,7 +307,8 @@ class GateSet:
 class Circuit:
     """vpbs_circuit: gate instance per row, constants columns, copy constraints (host-side description of a circuit)."""
 
-    def __init__(self, gates, log_n, row_gate, constants, copies, n_wires=135, n_routed=80):
+    def __init__(self, gates, log_n, row_gate, constants, copies, n_wires=135, n_routed=80, generators=()):
+        """generators: [(kind name, p0, [input positions (column, row)], [output positions]), ...] gadget-level generators"""
         n = 1 << log_n
         self.gates, self.log_n, self.n, self.n_wires, self.n_routed = gates, log_n, n, n_wires, n_routed
         self.row_gate = np.ascontiguousarray(row_gate, dtype=np.uint32)
@@ -312,6 +321,17 @@ class Circuit:
         c.row_gate = self.row_gate.ctypes.data_as(U32P)
         c.constants, c.n_constants_cols = _ptr(self.constants), self.constants.shape[0]
         c.copies, c.n_copies = self.copies.ctypes.data_as(U32P), self.copies.shape[0]
+        self._gen_keep = []
+        if generators:
+            arr = (GeneratorC * len(generators))()
+            for g, (kind, p0, ins, outs) in zip(arr, generators):
+                i = np.array([cc * n + rr for cc, rr in ins], dtype=np.uint32)
+                o = np.array([cc * n + rr for cc, rr in outs], dtype=np.uint32)
+                self._gen_keep += [i, o]
+                g.kind, g.p0 = GENERATOR_KINDS.index(kind), p0
+                g.inp, g.n_in, g.out, g.n_out = i.ctypes.data_as(U32P), i.size, o.ctypes.data_as(U32P), o.size
+            c.generators, c.n_generators = arr, len(generators)
+            self._gen_keep.append(arr)
         self.c = c
 
     def selector_columns(self):

@@ -257,6 +257,20 @@ bool check_circuit(const vpbs_circuit* c) {
         if (c->copies[i] >= (size_t)c->n_routed * n) return false;
     for (unsigned i = 0; i < c->n_gates; ++i)
         if (c->gates[i].num_wires > c->n_wires) return false;
+    if (c->n_generators && !c->generators) return false;
+    const size_t total = (size_t)c->n_wires * n;
+    for (size_t i = 0; i < c->n_generators; ++i) {
+        const vpbs_generator& g = c->generators[i];
+        if ((g.n_in && !g.in) || (g.n_out && !g.out)) return false;
+        for (unsigned k = 0; k < g.n_in; ++k)
+            if (g.in[k] >= total) return false;
+        for (unsigned k = 0; k < g.n_out; ++k)
+            if (g.out[k] >= total) return false;
+        if (g.kind == VPBS_GEN_EQUALITY && (g.n_in != 2 || g.n_out != 2)) return false;
+        if (g.kind == VPBS_GEN_BASE_SUM && (g.p0 < 2 || g.n_out != 1)) return false;
+        if (g.kind == VPBS_GEN_WIRE_SPLIT && (g.p0 < 1 || g.p0 > 63 || g.n_in != 1 || g.n_out < 1)) return false;
+        if (g.kind > VPBS_GEN_WIRE_SPLIT) return false;
+    }
     return true;
 }
 }  // namespace
@@ -369,17 +383,62 @@ int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, con
         void set(unsigned w, u64 v) { setter((u32)(w * n + row), v); }
     };
     struct Pending {
-        u32 row, sub;
+        u32 row, sub;  // row == NO_ROW: gadget-level generator number `sub`
     };
+    constexpr u32 NO_ROW = 0xFFFFFFFFu;
     std::vector<Pending> pending;
     for (size_t r = 0; r < n; ++r)
         for (unsigned sub = 0; sub < gen_count(c->gates[c->row_gate[r]]); ++sub) pending.push_back({(u32)r, sub});
+    for (size_t i = 0; i < c->n_generators; ++i) pending.push_back({NO_ROW, (u32)i});
+    auto get_pos = [&](u32 p) { return val[part.find(p)]; };
+    auto run_gadget = [&](const vpbs_generator& g) {
+        switch (g.kind) {
+            case VPBS_GEN_EQUALITY: {
+                const u64 x = get_pos(g.in[0]), y = get_pos(g.in[1]);
+                set_pos(g.out[0], x == y ? 1 : 0);
+                set_pos(g.out[1], x == y ? 0 : gl::inv(gl::sub(x, y)));
+                break;
+            }
+            case VPBS_GEN_BASE_SUM: {
+                u64 sum = 0;
+                for (unsigned k = g.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, g.p0), get_pos(g.in[k]));
+                set_pos(g.out[0], sum);
+                break;
+            }
+            case VPBS_GEN_WIRE_SPLIT: {
+                u64 x = get_pos(g.in[0]);
+                for (unsigned k = 0; k < g.n_out; ++k) {
+                    set_pos(g.out[k], x & (((u64)1 << g.p0) - 1));
+                    x >>= g.p0;
+                }
+                if (x != 0) throw GenError{"WireSplitGenerator: integer too large to fit in the given number of limbs"};
+                break;
+            }
+            default: break;
+        }
+    };
     std::vector<unsigned> deps;
     std::vector<u64> consts(std::max(1u, max_consts));
     // generate_partial_witness: run whatever is ready until nothing changes
     while (!pending.empty()) {
         std::vector<Pending> later;
         for (const Pending& p : pending) {
+            if (p.row == NO_ROW) {
+                const vpbs_generator& gg = c->generators[p.sub];
+                bool ready = true;
+                for (unsigned k = 0; k < gg.n_in && ready; ++k) ready = is_set[part.find(gg.in[k])];
+                if (!ready) {
+                    later.push_back(p);
+                    continue;
+                }
+                try {
+                    run_gadget(gg);
+                } catch (const GenError& e) {
+                    return fail(e.what + " (generator " + std::to_string(p.sub) + ")");
+                }
+                if (!error.empty()) return fail(error);
+                continue;
+            }
             const vpbs_gate& g = c->gates[c->row_gate[p.row]];
             gen_deps(g, p.sub, deps);
             bool ready = true;
@@ -402,7 +461,8 @@ int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, con
             if (!error.empty()) return fail(error);
         }
         if (later.size() == pending.size())  // generate_partial_witness: assert_eq!(remaining_generators, 0, "{} generators weren't run")
-            return fail(std::to_string(later.size()) + " generators weren't run (first: row " + std::to_string(later[0].row) + ")");
+            return fail(std::to_string(later.size()) + " generators weren't run (first: " +
+                        (later[0].row == NO_ROW ? "gadget generator " + std::to_string(later[0].sub) : "row " + std::to_string(later[0].row)) + ")");
         pending.swap(later);
     }
     // full_witness: every wire takes its representative's value (unset -> 0)
