@@ -454,3 +454,28 @@ def test_gadget_level_generators_is_equal_split_le_le_sum():
     circ = api.Circuit(ps, log_n, row_gate, np.zeros((ps.num_selectors + 2, n), np.uint64), [], generators=gens_bad)
     with pytest.raises(api.VpbsError, match="too large"):
         circ.generate_witness({(10, 5): 1 << 63})
+
+
+def test_malformed_circuit_descriptions_are_errors():
+    ps = api.GateSet(["noop", "arithmetic"])
+    n = 8
+    ok_rows = np.zeros(n, np.uint32)
+    consts = np.zeros((ps.num_selectors + 2, n), np.uint64)
+    for bad in (dict(row_gate=np.full(n, 7, np.uint32)),                      # gate index out of range
+                dict(copies=[(80 * n, 0)]),                                    # copy constraint on a non-routed wire
+                dict(generators=[("equality", 0, [(0, 0)], [(1, 0), (2, 0)])]),  # EqualityGenerator needs two inputs
+                dict(generators=[("wire_split", 64, [(0, 0)], [(1, 0)])]),     # more than 63 bits per BaseSumGate
+                dict(generators=[("base_sum", 2, [(200, 0)], [(1, 0)])])):     # position beyond the trace
+        kw = dict(row_gate=ok_rows, copies=[], generators=())
+        kw.update(bad)
+        circ = api.Circuit(ps, 3, kw["row_gate"], consts, kw["copies"], generators=kw["generators"])
+        with pytest.raises(api.VpbsError):
+            circ.sigma_values()
+        with pytest.raises(api.VpbsError):
+            circ.generate_witness({})
+        with pytest.raises(api.VpbsError):
+            circ.check_witness(np.zeros((135, n), np.uint64), [0] * 4)
+    # too few constants columns for the gate set
+    circ = api.Circuit(ps, 3, np.full(n, ps.by_kind("arithmetic").index, np.uint32), np.zeros((1, n), np.uint64), [])
+    with pytest.raises(api.VpbsError, match="constants columns"):
+        circ.generate_witness({})
