@@ -551,3 +551,32 @@ def test_pbs_accumulator_chain_end_to_end(ctx):
             assert [[int(v) for v in got[step_i][q]] for q in range(K)] == want[step_i], step_i
         m_bar = T.glwe_decrypt(ring, s_to, [[int(v) for v in got[-1][q]] for q in range(K)], K)[0]
         assert round(m_bar / delta) % (2 * p) == m          # src/main.rs:59-65
+
+
+@pytest.mark.parametrize("kind", ["zeros", "pminus1", "same_column", "edge_mix"])
+def test_step_proof_degenerate_inputs(ctx, kind):
+    """all-zero / all-(p-1) / identical / edge-valued trace columns through the whole device path (partial products, quotient,
+    commitments, openings, FRI) against the oracle: canonical-form and carry corner cases of the field arithmetic."""
+    log_n, n_constants, n_routed = 6, 5, 80
+    n = 1 << log_n
+    inputs = synth.step_inputs(log_n)
+    if kind == "zeros":
+        wires = np.zeros((135, n), np.uint64)
+    elif kind == "pminus1":
+        wires = np.full((135, n), P - 1, np.uint64)
+    elif kind == "same_column":
+        wires = np.tile(rand_field(1, n), (135, 1))
+    else:
+        edge = np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 1 << 63], np.uint64)
+        wires = edge[rng.integers(0, edge.size, size=(135, n))]
+    inputs["wires"] = np.ascontiguousarray(wires)
+    inputs["quotient"] = None
+    pis = synth.field_elements(0xED6E, 5)
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs, DIGEST, pis, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    got = ctx.prove_step(si)
+    want = step_oracle.prove_step(inputs, DIGEST, pis, log_n, sigmas=sig, n_routed=n_routed, n_constants=n_constants)
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (got[key] == want[key]).all(), key
+    cs.free()
