@@ -239,6 +239,19 @@ int vpbs_sigma_values(const vpbs_circuit* circuit, uint64_t* out);
  * twice with different values, generators that could not run, a value that does not fit its gate. */
 int vpbs_generate_witness(const vpbs_circuit* circuit, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
                           uint64_t* wires_out, char* err, size_t err_len);
+/* The same, compiled: which generator can run when depends only on the circuit and on WHICH targets the PartialWitness sets, never
+ * on their values, so the readiness loop of generate_partial_witness is run once and recorded as a straight-line schedule over one
+ * value slot per copy-constraint class.  vpbs_witness_plan_run then replays it for one PartialWitness (values in the order of
+ * preset_pos given at creation) and writes the full witness with `threads` host threads (0 = default).  A plan is immutable and may be
+ * run from several host threads at once -- the step circuit is proven n + 2 times per PBS (ivc_based_vpbs.rs:302,333,364) with one
+ * plan.  Creation fails like vpbs_generate_witness when generators cannot run; a run fails on value errors (a class set twice with
+ * different values, a value that does not fit its gate). */
+typedef struct vpbs_witness_plan vpbs_witness_plan;
+int vpbs_witness_plan_create(const vpbs_circuit* circuit, const uint32_t* preset_pos, size_t n_preset, vpbs_witness_plan** out,
+                             char* err, size_t err_len);
+int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out /* [n_wires][n] */,
+                          char* err, size_t err_len);
+void vpbs_witness_plan_free(vpbs_witness_plan* plan);
 /* Checks a complete witness against the circuit on the host: every row satisfies the constraints of its gate (evaluated on the
  * trace values themselves, i.e. on the subgroup) and every copy constraint holds.  Returns 1 = satisfied, 0 = violated (err names the
  * first violation: row, gate, constraint index or the two wire positions), < 0 = malformed arguments.  This is the integration aid

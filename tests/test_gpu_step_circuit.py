@@ -1,0 +1,147 @@
+"""GPU tests (-m gpu): the reference's step circuit without the recursive verifier (build_step_circuit,
+/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155; described by tests/step_circuit.py) through the whole product: compiled witness
+generation on the host (vpbs_witness_plan), the native TFHE data path on the device for the expected accumulators
+(vpbs_pbs_accumulator_chain / vpbs_blind_rotate_step), step proofs on the device with the gate constraints of the six gate types the
+circuit uses, the host verifier -- a verifiable PBS with the IVC hand-over (accumulator, counter, hash chains) done by the caller
+instead of the in-circuit verifier."""
+import time
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import step_circuit as sc
+import step_oracle
+import tfhe_oracle as T
+import vpbs_amd
+from vpbs_amd import api
+
+pytestmark = pytest.mark.gpu
+P = api.P
+DIGEST = [0xA, 0xB, 0xC, 0xD]
+N_ROUTED = 80
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = vpbs_amd.Context(0, log_n_max=16)
+    yield c
+    c.close()
+
+
+class Prover:
+    """circuit data committed once (constants + sigmas), one witness plan, then witness -> proof -> verification per step"""
+
+    def __init__(self, ctx, circ):
+        self.ctx, self.circ, b = ctx, circ, circ.built
+        self.sigma = b.circuit.sigma_values()
+        self.n_constants = b.constants.shape[0]
+        self.cs = ctx.commit_values(np.concatenate([b.constants, self.sigma]))
+        self.ncols = [self.n_constants + N_ROUTED, 135, 20, 16]
+        self.targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat +
+                        [circ.counter, circ.mask] + circ.bsk_hash_in + circ.lwe_hash_in)
+        self.plan = b.circuit.witness_plan([b.pos(t) for t in self.targets])
+
+    def witness(self, acc_init, acc_in, ggsw_flat, counter, mask, bsk_hash_in, lwe_hash_in, out=None):
+        values = np.concatenate([np.asarray(acc_init, np.uint64).reshape(-1), np.asarray(acc_in, np.uint64).reshape(-1),
+                                 np.asarray(ggsw_flat, np.uint64).reshape(-1), np.array([counter, mask], np.uint64),
+                                 np.asarray(bsk_hash_in, np.uint64), np.asarray(lwe_hash_in, np.uint64)])
+        return self.plan.run(values, out=out)
+
+    def prove(self, wires):
+        b = self.circ.built
+        pis = self.circ.public_inputs(wires)
+        si = self.ctx.make_step_inputs(b.log_n, wires, None, None, self.cs, DIGEST, pis, sigmas=self.sigma, n_routed=N_ROUTED,
+                                       n_constants=self.n_constants, gates=b.gates)
+        return self.ctx.prove_step(si), pis
+
+    def verify(self, proof, pis):
+        b = self.circ.built
+        return api.verify_step(proof, self.cs.cap(), self.ncols, DIGEST, pis, b.log_n, check_permutation=True, n_constants=self.n_constants,
+                               n_routed=N_ROUTED, gates=b.gates)
+
+    def close(self):
+        self.plan.free()
+        self.cs.free()
+
+
+def test_verifiable_pbs_every_step_proven(ctx):
+    """src/main.rs:40-65 + verified_pbs (ivc_based_vpbs.rs:276-371) at N = 8, n = 3 with noise-free keys: n + 2 step proofs, each
+    step's public inputs (accumulator, counter, bootstrapping-key and LWE hash chains) handed to the next step's witness by the
+    caller; accumulators equal the device's native chain, hashes equal verify_hash_output's chain, every proof verifies, the
+    key-switched output decrypts to the message."""
+    rng = np.random.default_rng(77)
+    log_N, K, ELL, LOGB, n, p = 3, 2, 8, 8, 3, 2
+    ring = T.Ring(log_N)
+    N = ring.n
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n, orc.negacyclic_params(log_N))
+    pr = Prover(ctx, circ)
+    s_to, s_lwe, s_glwe, bsk, ksk = T.pbs_setup(ring, rng, n, K, ELL, LOGB, p)
+    delta = T.get_delta(2 * p)
+    acc_init = np.array([[0] * N for _ in range(K - 1)] + [T.get_testv(ring, p, delta)], np.uint64)
+    bsk_flat, ksk_flat = np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk)
+    for m in (0, 1):
+        ct = T.lwe_encrypt(rng, s_lwe, delta * m % P)
+        accs = ctx.pbs_accumulator_chain(acc_init, ct, bsk_flat, ksk_flat, K, ELL, LOGB)       # the native data path (device)
+        dummy = np.zeros(K * ELL * K * N, np.uint64)                                            # Ggsw::dummy_ct() of step 0
+        ggsws = [dummy] + list(bsk_flat) + [ksk_flat]
+        masks = [int(ct[n])] + [int(v) for v in ct[:n]] + [0]
+        acc_in, bsk_hash, lwe_hash = acc_init, np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+        for step in range(n + 2):
+            wires = pr.witness(acc_init, acc_in, ggsws[step], step + 1, masks[step], bsk_hash, lwe_hash)
+            proof, pis = pr.prove(wires)
+            assert pr.verify(proof, pis)
+            assert step_oracle.verify_step(proof, pr.cs.cap(), pr.ncols, DIGEST, pis, circ.built.log_n)
+            acc_out = np.array(pis[K * N + 1:2 * K * N + 1], np.uint64).reshape(K, N)
+            assert pis[:K * N] == [int(v) for v in acc_init.reshape(-1)] and pis[K * N] == step + 1
+            assert (acc_out == accs[step]).all(), step
+            bsk_hash, lwe_hash = np.array(pis[-8:-4], np.uint64), np.array(pis[-4:], np.uint64)
+            want_bsk, _ = api.hash_chain(np.stack(ggsws[:step + 1]))
+            want_lwe, _ = api.hash_chain(np.array(masks[:step + 1], np.uint64).reshape(-1, 1))
+            assert (bsk_hash == want_bsk).all() and (lwe_hash == want_lwe).all()
+            wrong = list(pis)
+            wrong[K * N + 1] ^= 1                                                              # another accumulator
+            assert not pr.verify(proof, wrong)
+            acc_in = acc_out
+        m_bar = T.glwe_decrypt(ring, s_to, [[int(v) for v in acc_in[q]] for q in range(K)], K)[0]
+        assert round(m_bar / delta) % (2 * p) == m
+    pr.close()
+
+
+def test_step_circuit_at_the_papers_parameters(ctx):
+    """N = 1024, k = 1, ELL = 4, LOGB = 5, n = 728 (src/main.rs:20-28): 38 312 gate rows -> degree 2^16, the degree of the reference's
+    step circuit.  A CMUX step and the key-switch step: witness by the compiled plan, accumulator equal to the device's native step,
+    proof on the device, verified on the host."""
+    rng = np.random.default_rng(1024)
+    N, K, ELL, LOGB, n = 1024, 2, 4, 5, 728
+    t0 = time.perf_counter()
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n, orc.negacyclic_params(10))
+    t_build = time.perf_counter() - t0
+    assert circ.built.log_n == 16
+    t0 = time.perf_counter()
+    pr = Prover(ctx, circ)
+    t_setup = time.perf_counter() - t0
+    f = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)
+    wires = np.zeros((135, circ.built.n), np.uint64)
+    report = []
+    for counter in (5, n + 2):
+        acc_init, acc_in, ggsw, mask, h1, h2 = f(K, N), f(K, N), f(K * ELL * K * N), int(f(1)[0]), f(4), f(4)
+        t0 = time.perf_counter()
+        pr.witness(acc_init, acc_in, ggsw, counter, mask, h1, h2, out=wires)
+        t_wit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        proof, pis = pr.prove(wires)
+        t_prove = time.perf_counter() - t0
+        want = ctx.blind_rotate_step(acc_in[None], [mask], ggsw, K, ELL, LOGB, last_step=counter == n + 2)[0]
+        assert pis[K * N + 1:2 * K * N + 1] == [int(v) for v in want.reshape(-1)]
+        assert pis[-8:-4] == [int(v) for v in orc.hash_no_pad(np.concatenate([h1, ggsw]))]
+        ok, msg = circ.built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+        assert ok, msg
+        assert pr.verify(proof, pis)
+        wrong = list(pis)
+        wrong[-1] ^= 1
+        assert not pr.verify(proof, wrong)
+        report.append((counter, t_wit, t_prove))
+    print("\nstep circuit N=1024: %d rows, builder %.1f s, setup (sigma, commit, plan) %.2f s; " % (circ.built.used_rows, t_build, t_setup) +
+          "; ".join("counter %d: witness %.0f ms, proof (incl. H2D of the wires) %.1f ms" % (c, 1e3 * a, 1e3 * b) for c, a, b in report))
+    pr.close()

@@ -1,0 +1,185 @@
+"""CPU tests (-m "not gpu"): the reference's step circuit without the recursive verifier (build_step_circuit,
+/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155) described by the test-side builder (tests/step_circuit.py), witness generated and
+checked by the PRODUCT's host code (vpbs_generate_witness / vpbs_check_witness), public inputs compared with the native restatement
+of the same step (tests/tfhe_oracle.py) and the native hash chain.  No device compute."""
+import numpy as np
+import pytest
+
+import oracle as orc
+import step_circuit as sc
+import tfhe_oracle as tf
+from vpbs_amd import api
+
+P = orc.P
+
+
+def _ring(log_n):
+    roots, inv, ninv = orc.negacyclic_params(log_n)
+    return roots, inv, ninv
+
+
+@pytest.fixture(scope="module")
+def small():
+    N, K, ELL, LOGB, n_lwe = 8, 2, 4, 5, 6
+    return sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, _ring(3))
+
+
+def _inputs(seed, N, K, ELL):
+    rng = np.random.default_rng(seed)
+    f = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)
+    return dict(acc_init=f(K, N), acc_in=f(K, N), ggsw=f(K, ELL, K, N), mask=int(f(1)[0]), bsk_hash_in=f(4), lwe_hash_in=f(4))
+
+
+def _expected(circ, x, counter):
+    N, K, ELL, LOGB, n_lwe = circ.shape
+    ring = tf.Ring(N.bit_length() - 1)
+    ggsw_hat = [[[list(map(int, x["ggsw"][p][l][r])) for r in range(K)] for l in range(ELL)] for p in range(K)]
+    acc_out = tf.step(ring, [list(map(int, p)) for p in x["acc_in"]], x["mask"], ggsw_hat, K, ELL, LOGB, first_step=counter == 1,
+                      last_step=counter == n_lwe + 2)
+    bsk_hash = orc.hash_no_pad(np.concatenate([x["bsk_hash_in"], x["ggsw"].reshape(-1)]))
+    lwe_hash = orc.hash_no_pad(np.concatenate([x["lwe_hash_in"], np.array([x["mask"]], np.uint64)]))
+    return ([int(v) for v in x["acc_init"].reshape(-1)] + [counter] + [int(v) % P for p in acc_out for v in p] + [int(v) for v in bsk_hash] +
+            [int(v) for v in lwe_hash])
+
+
+@pytest.mark.parametrize("which", ["first", "middle", "last"])
+def test_step_circuit_public_inputs_match_the_native_step(small, which):
+    N, K, ELL, LOGB, n_lwe = small.shape
+    counter = {"first": 1, "middle": 3, "last": n_lwe + 2}[which]
+    x = _inputs(100 + counter, N, K, ELL)
+    wires = small.witness(x["acc_init"], x["ggsw"].reshape(-1), x["acc_in"], counter, x["mask"], x["bsk_hash_in"], x["lwe_hash_in"])
+    pis = small.public_inputs(wires)
+    assert pis == _expected(small, x, counter)
+    ok, msg = small.built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+    assert ok, msg
+    # the public-input hash row feeds the PublicInputGate
+    assert small.built.row_kinds[-1] == "public_input"
+
+
+def test_step_circuit_rejects_a_wrong_witness(small):
+    N, K, ELL, LOGB, n_lwe = small.shape
+    x = _inputs(7, N, K, ELL)
+    wires = small.witness(x["acc_init"], x["ggsw"].reshape(-1), x["acc_in"], 2, x["mask"], x["bsk_hash_in"], x["lwe_hash_in"])
+    pis = small.public_inputs(wires)
+    h = api.hash_no_pad(np.array(pis, np.uint64))
+    col, row = small.built.pos(small.acc_out[0][0])
+    bad = wires.copy()
+    bad[col, row] ^= np.uint64(1)
+    ok, msg = small.built.circuit.check_witness(bad, h)
+    assert not ok and msg
+    # a preset that contradicts the circuit: acc_out is determined by the inputs
+    a = small.built.presets({small.acc_out[0][0]: (pis[K * N + 1] + 1) % P})
+    presets = small.built.presets(dict(zip([t for p in small.acc_in for t in p], x["acc_in"].reshape(-1))))
+    with pytest.raises(api.VpbsError):
+        small.built.circuit.generate_witness({**presets, **a})
+
+
+def test_step_circuit_other_parameters():
+    """K = 3 polynomials per GLWE (two GLEVs summed before the subtraction, ggsw_ct.rs:106-111), base 2^8, two levels"""
+    N, K, ELL, LOGB, n_lwe = 8, 3, 2, 8, 4
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, _ring(3))
+    for counter in (1, 2, n_lwe + 2):
+        x = _inputs(50 + counter, N, K, ELL)
+        wires = circ.witness(x["acc_init"], x["ggsw"].reshape(-1), x["acc_in"], counter, x["mask"], x["bsk_hash_in"], x["lwe_hash_in"])
+        pis = circ.public_inputs(wires)
+        assert pis == _expected(circ, x, counter)
+        ok, msg = circ.built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+        assert ok, msg
+
+
+def _assignment(circ, x, counter):
+    a = {}
+    for targets, values in ((circ.acc_init, x["acc_init"]), (circ.acc_in, x["acc_in"])):
+        for tp, vp in zip(targets, values):
+            a.update(zip(tp, vp))
+    a.update(zip(circ.ggsw_flat, x["ggsw"].reshape(-1)))
+    a[circ.counter], a[circ.mask] = counter, x["mask"]
+    a.update(zip(circ.bsk_hash_in, x["bsk_hash_in"]))
+    a.update(zip(circ.lwe_hash_in, x["lwe_hash_in"]))
+    return circ.built.presets(a)
+
+
+def test_witness_plan_replays_the_generators(small):
+    """vpbs_witness_plan: created once for the step circuit's PartialWitness targets, run for the first / CMUX / last step -- the
+    same wires as vpbs_generate_witness, for any thread count, also when several host threads share the plan"""
+    import threading
+    N, K, ELL, LOGB, n_lwe = small.shape
+    cases = [(c, _inputs(900 + c, N, K, ELL)) for c in (1, 2, n_lwe + 2, 4)]
+    presets = [_assignment(small, x, c) for c, x in cases]
+    positions = list(presets[0])
+    assert all(list(p) == positions for p in presets)
+    plan = small.built.circuit.witness_plan(positions)
+    expected = [small.built.circuit.generate_witness(p) for p in presets]
+    for p, want, (c, x) in zip(presets, expected, cases):
+        for threads in (0, 1, 3):
+            got = plan.run(list(p.values()), threads=threads)
+            assert (got == want).all()
+        assert small.public_inputs(got) == _expected(small, x, c)
+    results = [None] * len(presets)
+
+    def work(i):
+        for _ in range(5):
+            results[i] = plan.run(list(presets[i].values()), threads=2)
+
+    pool = [threading.Thread(target=work, args=(i,)) for i in range(len(presets))]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
+    assert all((r == w).all() for r, w in zip(results, expected))
+    plan.free()
+
+
+def test_witness_plan_errors(small):
+    N, K, ELL, LOGB, n_lwe = small.shape
+    x = _inputs(31, N, K, ELL)
+    presets = _assignment(small, x, 2)
+    # a target the generators need is not part of the PartialWitness: found when the plan is made
+    missing = dict(presets)
+    del missing[small.built.pos(small.mask)]
+    with pytest.raises(api.VpbsError, match="weren't run"):
+        small.built.circuit.witness_plan(list(missing))
+    # a value that contradicts the circuit: found by the run
+    wires = small.built.circuit.generate_witness(presets)
+    out_pos = small.built.pos(small.acc_out[1][3])
+    plan = small.built.circuit.witness_plan(list(presets) + [out_pos])
+    good = list(presets.values()) + [int(wires[out_pos])]
+    assert (plan.run(good) == wires).all()
+    with pytest.raises(api.VpbsError, match="set twice"):
+        plan.run(good[:-1] + [(good[-1] + 1) % P])
+    with pytest.raises(api.VpbsError):
+        small.built.circuit.witness_plan([(0, small.built.n)])          # position out of range
+
+
+def test_pbs_chain_of_step_witnesses():
+    """verified_pbs (ivc_based_vpbs.rs:276-371) at witness level, N = 8, n = 3, noise-free keys: the n + 2 step witnesses, each fed
+    with the previous step's public inputs (accumulator, counter + 1, hash chains); accumulators equal the native chain, hashes equal
+    verify_hash_output's chain, the key-switched output decrypts to the message.  (The proofs of the same chain: test_gpu_step_circuit.)"""
+    rng = np.random.default_rng(77)
+    log_N, K, ELL, LOGB, n, p = 3, 2, 8, 8, 3, 2
+    ring = tf.Ring(log_N)
+    N = ring.n
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n, _ring(log_N))
+    s_to, s_lwe, s_glwe, bsk, ksk = tf.pbs_setup(ring, rng, n, K, ELL, LOGB, p)
+    delta = tf.get_delta(2 * p)
+    acc_init = np.array([[0] * N for _ in range(K - 1)] + [tf.get_testv(ring, p, delta)], np.uint64)
+    bsk_flat, ksk_flat = np.stack([tf.flatten_ggsw(g) for g in bsk]), tf.flatten_ggsw(ksk)
+    for m in (0, 1):
+        ct = tf.lwe_encrypt(rng, s_lwe, delta * m % P)
+        accs = tf.pbs_chain(ring, [list(map(int, q)) for q in acc_init], ct, bsk, ksk, K, ELL, LOGB)
+        ggsws = [np.zeros(K * ELL * K * N, np.uint64)] + list(bsk_flat) + [ksk_flat]    # Ggsw::dummy_ct() in step 0
+        masks = [int(ct[n])] + [int(v) for v in ct[:n]] + [0]
+        acc_in, bsk_hash, lwe_hash = acc_init, np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+        for step in range(n + 2):
+            wires = circ.witness(acc_init, ggsws[step], acc_in, step + 1, masks[step], bsk_hash, lwe_hash)
+            pis = circ.public_inputs(wires)
+            acc_out = np.array(pis[K * N + 1:2 * K * N + 1], np.uint64).reshape(K, N)
+            assert [[int(v) for v in q] for q in acc_out] == accs[step], step
+            bsk_hash, lwe_hash = np.array(pis[-8:-4], np.uint64), np.array(pis[-4:], np.uint64)
+            assert (bsk_hash == api.hash_chain(np.stack(ggsws[:step + 1]))[0]).all()
+            assert (lwe_hash == api.hash_chain(np.array(masks[:step + 1], np.uint64).reshape(-1, 1))[0]).all()
+            ok, msg = circ.built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+            assert ok, msg
+            acc_in = acc_out
+        m_bar = tf.glwe_decrypt(ring, s_to, [[int(v) for v in acc_in[q]] for q in range(K)], K)[0]
+        assert round(m_bar / delta) % (2 * p) == m

@@ -149,6 +149,9 @@ SIGNATURES = {
     "vpbs_selector_columns": (_i, [C.POINTER(CircuitC), U64P]),
     "vpbs_sigma_values": (_i, [C.POINTER(CircuitC), U64P]),
     "vpbs_generate_witness": (_i, [C.POINTER(CircuitC), U32P, U64P, _sz, U64P, C.c_char_p, _sz]),
+    "vpbs_witness_plan_create": (_i, [C.POINTER(CircuitC), U32P, _sz, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
+    "vpbs_witness_plan_run": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.c_char_p, _sz]),
+    "vpbs_witness_plan_free": (None, [C.c_void_p]),
     "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
@@ -366,6 +369,48 @@ class Circuit:
         if rc:
             raise VpbsError("vpbs_generate_witness: " + err.value.decode())
         return out
+
+
+    def witness_plan(self, positions):
+        """vpbs_witness_plan_create for a PartialWitness that sets `positions` [(column, row), ...] -> WitnessPlan"""
+        return WitnessPlan(self, positions)
+
+
+class WitnessPlan:
+    """vpbs_witness_plan: the compiled witness generator of one circuit (create once, run per PartialWitness)."""
+
+    def __init__(self, circuit, positions):
+        self.circuit = circuit
+        pos = np.array([c * circuit.n + r for (c, r) in positions], dtype=np.uint32)
+        self.n_preset = pos.size
+        h, err = C.c_void_p(), C.create_string_buffer(512)
+        rc = lib().vpbs_witness_plan_create(C.byref(circuit.c), pos.ctypes.data_as(U32P), pos.size, C.byref(h), err, 512)
+        if rc:
+            raise VpbsError("vpbs_witness_plan_create: " + err.value.decode())
+        self.h = h
+
+    def run(self, values, threads=0, out=None):
+        """values in the order of the positions given at creation -> wires [n_wires][n]"""
+        val = _u64(values)
+        assert val.size == self.n_preset
+        if out is None:
+            out = np.empty((self.circuit.n_wires, self.circuit.n), np.uint64)
+        err = C.create_string_buffer(512)
+        rc = lib().vpbs_witness_plan_run(self.h, _ptr(val) if val.size else None, threads, _ptr(out), err, 512)
+        if rc:
+            raise VpbsError("vpbs_witness_plan_run: " + err.value.decode())
+        return out
+
+    def free(self):
+        if self.h:
+            lib().vpbs_witness_plan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def hash_chain(items, claimed=None):

@@ -8,9 +8,14 @@
 // Restated from the published crate: parity unpinned; checked against an independent Python restatement and against the
 // gate constraints (every generated row must satisfy them).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gates.h"
@@ -79,18 +84,6 @@ template <class R> void walg(R& r, unsigned i, A x) {
 }
 
 template <class R> void poseidon_generate(R& r) {
-    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    auto mds = [&](u64* s) {
-        u64 o[12];
-        for (int row = 0; row < 12; ++row) {
-            u64 acc = 0;
-            for (int i = 0; i < 12; ++i) acc = gl::add(acc, gl::mul(s[(i + row) % 12], C[i]));
-            if (row == 0) acc = gl::add(acc, gl::mul(s[0], 8));
-            o[row] = acc;
-        }
-        std::memcpy(s, o, sizeof o);
-    };
-    auto sbox = [](u64 x) { const u64 x2 = gl::mul(x, x), x4 = gl::mul(x2, x2); return gl::mul(gl::mul(x2, x), x4); };
     const u64 swap = r.get(24);
     if (swap > 1) throw GenError{"PoseidonGate: swap wire is not boolean"};
     u64 st[12];
@@ -102,21 +95,25 @@ template <class R> void poseidon_generate(R& r) {
         st[i + 4] = gl::sub(rhs, delta);
     }
     for (int i = 8; i < 12; ++i) st[i] = r.get(i);
+    // st holds the S-box inputs of the current round as arbitrary u64 residues; the MDS layer adds the next round's constants
+    for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], poseidon::rc(i));
     for (int round = 0; round < 30; ++round) {
-        for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], poseidon::rc(12 * round + i));
         if (round < 4 || round >= 26) {
             for (int i = 0; i < 12; ++i) {
-                if (round >= 1 && round < 4) r.set(29 + 12 * (round - 1) + i, st[i]);
-                if (round >= 26) r.set(87 + 12 * (round - 26) + i, st[i]);
-                st[i] = sbox(st[i]);
+                if (round >= 1 && round < 4) r.set(29 + 12 * (round - 1) + i, gl::canon(st[i]));
+                if (round >= 26) r.set(87 + 12 * (round - 26) + i, gl::canon(st[i]));
+                st[i] = poseidon::sbox(st[i]);
             }
         } else {
-            r.set(65 + (round - 4), st[0]);
-            st[0] = sbox(st[0]);
+            r.set(65 + (round - 4), gl::canon(st[0]));
+            st[0] = poseidon::sbox(st[0]);
         }
-        mds(st);
+        u64 kc[12];
+        if (round + 1 < 30)
+            for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * (round + 1) + i);
+        poseidon::mds_add_const(st, round + 1 < 30 ? kc : nullptr);
     }
-    for (int i = 0; i < 12; ++i) r.set(12 + i, st[i]);
+    for (int i = 0; i < 12; ++i) r.set(12 + i, gl::canon(st[i]));
 }
 
 template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, R& r) {
@@ -127,9 +124,13 @@ template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, 
             break;
         case VPBS_GATE_BASE_SUM: {  // BaseSplitGenerator: little-endian base-B digits of the canonical sum
             u64 x = r.get(0);
-            for (unsigned i = 0; i < g.p0; ++i) {
-                r.set(1 + i, x % g.p1);
-                x /= g.p1;
+            if (g.p1 == 2) {
+                for (unsigned i = 0; i < g.p0; ++i, x >>= 1) r.set(1 + i, x & 1);
+            } else {
+                for (unsigned i = 0; i < g.p0; ++i) {
+                    r.set(1 + i, x % g.p1);
+                    x /= g.p1;
+                }
             }
             if (x != 0) throw GenError{"BaseSumGate: integer too large to fit in the given number of limbs"};
             break;
@@ -273,6 +274,305 @@ bool check_circuit(const vpbs_circuit* c) {
     }
     return true;
 }
+// ---- compiled witness generation -------------------------------------------------------------------------------------------------
+// Which generator can run when depends only on the circuit and on WHICH targets the PartialWitness sets, never on the values: the
+// readiness loop of generate_partial_witness is therefore run once, at plan creation, and recorded as a straight-line schedule over
+// value slots (one slot per copy-constraint class).  A run is then: presets -> slots, the schedule in order (no readiness checks, no
+// union-find), slots -> wires (full_witness) in parallel.  The step circuit is proven n + 2 times per PBS with the same plan.
+}  // namespace
+}  // namespace vpbs
+
+struct vpbs_witness_plan {
+    using u32 = vpbs::u32;
+    using u64 = vpbs::u64;
+    size_t n = 0, total = 0, n_slots = 0;
+    unsigned max_consts = 0;
+    std::vector<vpbs_gate> gates;
+    std::vector<u32> row_gate;                  // [n]
+    std::vector<u64> consts;                    // [n][max_consts]: the gate constants of every row
+    std::vector<u32> row_off, row_slots;        // row -> offset into row_slots: the slot of every wire of a row that owns generators
+    struct Gadget {
+        unsigned kind, p0;
+        u32 at, n_in, n_out;                    // gadget_slots / gadget_pos [at, at + n_in) inputs, then n_out outputs
+    };
+    std::vector<Gadget> gadgets;
+    std::vector<u32> gadget_slots, gadget_pos;
+    struct Step {
+        u32 row, sub;                           // row == NO_ROW: gadget number `sub`
+    };
+    std::vector<Step> schedule;
+    std::vector<u32> preset_slot, preset_pos;
+    std::vector<u32> out_pos, out_slot;         // every position that carries a slot, ascending (full_witness)
+};
+
+namespace vpbs {
+namespace {
+constexpr u32 NO_ROW = 0xFFFFFFFFu, NONE = 0xFFFFFFFFu;
+
+void report(char* err, size_t err_len, const std::string& m) {
+    if (err && err_len) {
+        std::strncpy(err, m.c_str(), err_len - 1);
+        err[err_len - 1] = 0;
+    }
+}
+
+// plan creation: generators "run" on readiness flags only (every read returns 1, which no generator rejects)
+struct FlagRow {
+    std::vector<uint8_t>& ready;
+    const u32* rs;
+    u64 get(unsigned) { return 1; }
+    void set(unsigned w, u64) { ready[rs[w]] = 1; }
+};
+
+struct SlotState {
+    std::vector<u64> val;
+    std::vector<uint8_t> is_set;
+    size_t n;
+    std::string error;
+    void set(u32 slot, u64 v, u32 pos) {
+        if (v >= gl::P) v -= gl::P;
+        if (is_set[slot] && val[slot] != v && error.empty())
+            error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
+                    ") was set twice with different values";
+        val[slot] = v;
+        is_set[slot] = 1;
+    }
+};
+
+struct SlotRow {
+    SlotState& s;
+    const u32* rs;
+    u32 row;
+    u64 get(unsigned w) { return s.val[rs[w]]; }
+    void set(unsigned w, u64 v) { s.set(rs[w], v, (u32)(w * s.n + row)); }
+};
+
+int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, vpbs_witness_plan** out, std::string& err) {
+    auto fail = [&](const std::string& m) {
+        err = m;
+        return VPBS_ERR_INVALID;
+    };
+    if (!check_circuit(c) || !out || (n_preset && !preset_pos)) return fail("malformed circuit description");
+    const size_t n = (size_t)1 << c->log_n, total = (size_t)c->n_wires * n;
+    unsigned max_consts = 0;
+    for (unsigned i = 0; i < c->n_gates; ++i) max_consts = std::max(max_consts, c->gates[i].num_constants);
+    if (c->num_selectors + max_consts > c->n_constants_cols || (max_consts && !c->constants)) return fail("constants columns missing");
+    for (size_t i = 0; i < n_preset; ++i)
+        if (preset_pos[i] >= total) return fail("preset position out of range");
+    auto plan = std::make_unique<vpbs_witness_plan>();
+    vpbs_witness_plan& p = *plan;
+    p.n = n;
+    p.total = total;
+    p.max_consts = max_consts;
+    p.gates.assign(c->gates, c->gates + c->n_gates);
+    p.row_gate.assign(c->row_gate, c->row_gate + n);
+    p.consts.assign((size_t)std::max(1u, max_consts) * n, 0);
+    for (size_t r = 0; r < n; ++r)
+        for (unsigned k = 0; k < p.gates[p.row_gate[r]].num_constants; ++k)
+            p.consts[r * std::max(1u, max_consts) + k] = c->constants[(size_t)(c->num_selectors + k) * n + r];
+    // copy-constraint classes; advice wires are singletons
+    Partition part(total);
+    for (size_t i = 0; i < c->n_copies; ++i) part.merge(c->copies[2 * i], c->copies[2 * i + 1]);
+    std::vector<uint8_t> touched(total, 0);
+    for (size_t r = 0; r < n; ++r)
+        for (unsigned w = 0; w < p.gates[p.row_gate[r]].num_wires; ++w) touched[(size_t)w * n + r] = 1;
+    for (size_t i = 0; i < 2 * c->n_copies; ++i) touched[c->copies[i]] = 1;
+    for (size_t i = 0; i < n_preset; ++i) touched[preset_pos[i]] = 1;
+    for (size_t i = 0; i < c->n_generators; ++i) {
+        for (unsigned k = 0; k < c->generators[i].n_in; ++k) touched[c->generators[i].in[k]] = 1;
+        for (unsigned k = 0; k < c->generators[i].n_out; ++k) touched[c->generators[i].out[k]] = 1;
+    }
+    std::vector<u32> slot_of_root(total, NONE);
+    u32 n_slots = 0;
+    for (size_t pos = 0; pos < total; ++pos) {
+        if (!touched[pos]) continue;
+        u32& s = slot_of_root[part.find((u32)pos)];
+        if (s == NONE) s = n_slots++;
+        p.out_pos.push_back((u32)pos);
+        p.out_slot.push_back(s);
+    }
+    p.n_slots = n_slots;
+    auto slot_at = [&](u32 pos) { return slot_of_root[part.find(pos)]; };
+    p.row_off.assign(n, NONE);
+    for (size_t r = 0; r < n; ++r) {
+        const vpbs_gate& g = p.gates[p.row_gate[r]];
+        if (gen_count(g) == 0) continue;
+        p.row_off[r] = (u32)p.row_slots.size();
+        for (unsigned w = 0; w < g.num_wires; ++w) p.row_slots.push_back(slot_at((u32)(w * n + r)));
+    }
+    for (size_t i = 0; i < c->n_generators; ++i) {
+        const vpbs_generator& g = c->generators[i];
+        p.gadgets.push_back({g.kind, g.p0, (u32)p.gadget_slots.size(), g.n_in, g.n_out});
+        for (unsigned k = 0; k < g.n_in + g.n_out; ++k) {
+            const u32 pos = k < g.n_in ? g.in[k] : g.out[k - g.n_in];
+            p.gadget_slots.push_back(slot_at(pos));
+            p.gadget_pos.push_back(pos);
+        }
+    }
+    p.preset_pos.assign(preset_pos, preset_pos + n_preset);
+    for (size_t i = 0; i < n_preset; ++i) p.preset_slot.push_back(slot_at(preset_pos[i]));
+    // generate_partial_witness on readiness flags: run whatever is ready until nothing changes
+    std::vector<uint8_t> ready(n_slots, 0);
+    for (u32 s : p.preset_slot) ready[s] = 1;
+    std::vector<vpbs_witness_plan::Step> pending, later;
+    for (size_t r = 0; r < n; ++r)
+        for (unsigned sub = 0; sub < gen_count(p.gates[p.row_gate[r]]); ++sub) pending.push_back({(u32)r, sub});
+    for (size_t i = 0; i < p.gadgets.size(); ++i) pending.push_back({NO_ROW, (u32)i});
+    std::vector<unsigned> deps;
+    while (!pending.empty()) {
+        later.clear();
+        for (const auto& st : pending) {
+            bool ok = true;
+            if (st.row == NO_ROW) {
+                const auto& gg = p.gadgets[st.sub];
+                for (unsigned k = 0; k < gg.n_in && ok; ++k) ok = ready[p.gadget_slots[gg.at + k]];
+                if (ok)
+                    for (unsigned k = 0; k < gg.n_out; ++k) ready[p.gadget_slots[gg.at + gg.n_in + k]] = 1;
+            } else {
+                const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+                const u32* rs = p.row_slots.data() + p.row_off[st.row];
+                gen_deps(g, st.sub, deps);
+                for (unsigned w : deps)
+                    if (!ready[rs[w]]) {
+                        ok = false;
+                        break;
+                    }
+                if (ok) {
+                    FlagRow fr{ready, rs};
+                    try {
+                        gen_run(g, st.sub, p.consts.data() + (size_t)st.row * std::max(1u, max_consts), fr);
+                    } catch (const GenError& e) {
+                        return fail(e.what + " (row " + std::to_string(st.row) + ")");
+                    }
+                }
+            }
+            if (ok) p.schedule.push_back(st);
+            else later.push_back(st);
+        }
+        if (later.size() == pending.size())  // generate_partial_witness: assert_eq!(remaining_generators, 0, "{} generators weren't run")
+            return fail(std::to_string(later.size()) + " generators weren't run (first: " +
+                        (later[0].row == NO_ROW ? "gadget generator " + std::to_string(later[0].sub) : "row " + std::to_string(later[0].row)) + ")");
+        pending.swap(later);
+    }
+    // renumber the slots in the order the run first touches them (presets, then the schedule): values produced close in time
+    // sit close in memory, instead of one cache line per wire column
+    {
+        std::vector<u32> renum(n_slots, NONE);
+        u32 next = 0;
+        auto visit = [&](u32& s) {
+            if (renum[s] == NONE) renum[s] = next++;
+        };
+        for (u32& s : p.preset_slot) visit(s);
+        std::vector<uint8_t> row_seen(n, 0);
+        for (const auto& st : p.schedule) {
+            if (st.row == NO_ROW) {
+                const auto& gg = p.gadgets[st.sub];
+                for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) visit(p.gadget_slots[gg.at + k]);
+            } else if (!row_seen[st.row]) {
+                row_seen[st.row] = 1;
+                const unsigned nw = p.gates[p.row_gate[st.row]].num_wires;
+                for (unsigned w = 0; w < nw; ++w) visit(p.row_slots[p.row_off[st.row] + w]);
+            }
+        }
+        for (u32 s = 0; s < n_slots; ++s) visit(s);
+        for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot})
+            for (u32& s : *v) s = renum[s];
+    }
+    *out = plan.release();
+    return VPBS_OK;
+}
+
+void run_gadget(const vpbs_witness_plan& p, const vpbs_witness_plan::Gadget& g, SlotState& s) {
+    const u32 *in = p.gadget_slots.data() + g.at, *out = in + g.n_in, *out_pos = p.gadget_pos.data() + g.at + g.n_in;
+    switch (g.kind) {
+        case VPBS_GEN_EQUALITY: {
+            const u64 x = s.val[in[0]], y = s.val[in[1]];
+            s.set(out[0], x == y ? 1 : 0, out_pos[0]);
+            s.set(out[1], x == y ? 0 : gl::inv(gl::sub(x, y)), out_pos[1]);
+            break;
+        }
+        case VPBS_GEN_BASE_SUM: {
+            u64 sum = 0;
+            for (unsigned k = g.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, g.p0), s.val[in[k]]);
+            s.set(out[0], sum, out_pos[0]);
+            break;
+        }
+        case VPBS_GEN_WIRE_SPLIT: {
+            u64 x = s.val[in[0]];
+            for (unsigned k = 0; k < g.n_out; ++k) {
+                s.set(out[k], x & (((u64)1 << g.p0) - 1), out_pos[k]);
+                x >>= g.p0;
+            }
+            if (x != 0) throw GenError{"WireSplitGenerator: integer too large to fit in the given number of limbs"};
+            break;
+        }
+        default: break;
+    }
+}
+
+int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned threads, u64* wires_out, std::string& err) {
+    if (!pp || !wires_out || (!pp->preset_slot.empty() && !preset_val)) {
+        err = "malformed arguments";
+        return VPBS_ERR_INVALID;
+    }
+    const vpbs_witness_plan& p = *pp;
+    const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t1 = std::chrono::steady_clock::now();
+        if (trace) std::fprintf(stderr, "[witness] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    SlotState s{std::vector<u64>(p.n_slots, 0), std::vector<uint8_t>(p.n_slots, 0), p.n, {}};
+    for (size_t i = 0; i < p.preset_slot.size(); ++i) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+    if (!s.error.empty()) {
+        err = s.error;
+        return VPBS_ERR_INVALID;
+    }
+    lap("presets");
+    const unsigned mc = std::max(1u, p.max_consts);
+    double kind_ms[32] = {0};
+    for (const auto& st : p.schedule) {
+        const auto k0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        struct Tick {
+            bool on; decltype(k0) a; double* acc;
+            ~Tick() { if (on) *acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); }
+        } tick{trace, k0, &kind_ms[st.row == NO_ROW ? 31 : p.gates[p.row_gate[st.row]].kind]};
+        try {
+            if (st.row == NO_ROW) {
+                run_gadget(p, p.gadgets[st.sub], s);
+            } else {
+                SlotRow r{s, p.row_slots.data() + p.row_off[st.row], st.row};
+                gen_run(p.gates[p.row_gate[st.row]], st.sub, p.consts.data() + (size_t)st.row * mc, r);
+            }
+        } catch (const GenError& e) {
+            err = e.what + (st.row == NO_ROW ? " (generator " + std::to_string(st.sub) + ")" : " (row " + std::to_string(st.row) + ")");
+            return VPBS_ERR_INVALID;
+        }
+        if (!s.error.empty()) {
+            err = s.error;
+            return VPBS_ERR_INVALID;
+        }
+    }
+    lap("generators");
+    if (trace)
+        for (int k = 0; k < 32; ++k)
+            if (kind_ms[k] > 0) std::fprintf(stderr, "[witness]   kind %d: %.2f ms\n", k, kind_ms[k]);
+    // full_witness: every wire takes its class's value (unset -> 0), position ranges in parallel
+    if (threads == 0) threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    auto fill = [&](unsigned t) {
+        const size_t lo = p.total * t / threads, hi = p.total * (t + 1) / threads;
+        std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
+        const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
+        for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fill, t);
+    fill(0);
+    for (auto& th : pool) th.join();
+    lap("full_witness");
+    return VPBS_OK;
+}
 }  // namespace
 }  // namespace vpbs
 
@@ -339,136 +639,34 @@ int vpbs_sigma_values(const vpbs_circuit* c, uint64_t* out) {
     return VPBS_OK;
 }
 
+int vpbs_witness_plan_create(const vpbs_circuit* c, const uint32_t* preset_pos, size_t n_preset, vpbs_witness_plan** out, char* err,
+                             size_t err_len) {
+    std::string msg;
+    const int rc = vpbs::plan_create(c, preset_pos, n_preset, out, msg);
+    vpbs::report(err, err_len, msg);
+    return rc;
+}
+
+int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out, char* err,
+                          size_t err_len) {
+    std::string msg;
+    const int rc = vpbs::plan_run(plan, preset_val, threads, wires_out, msg);
+    vpbs::report(err, err_len, msg);
+    return rc;
+}
+
+void vpbs_witness_plan_free(vpbs_witness_plan* plan) { delete plan; }
+
 int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
                           uint64_t* wires_out, char* err, size_t err_len) {
-    auto fail = [&](const std::string& m) {
-        if (err && err_len) {
-            std::strncpy(err, m.c_str(), err_len - 1);
-            err[err_len - 1] = 0;
-        }
-        return VPBS_ERR_INVALID;
-    };
-    if (!vpbs::check_circuit(c) || !wires_out || (n_preset && (!preset_pos || !preset_val))) return fail("malformed circuit description");
-    using namespace vpbs;
-    const size_t n = (size_t)1 << c->log_n, total = (size_t)c->n_wires * n, routed = (size_t)c->n_routed * n;
-    unsigned max_consts = 0;
-    for (unsigned i = 0; i < c->n_gates; ++i) max_consts = std::max(max_consts, c->gates[i].num_constants);
-    if (c->num_selectors + max_consts > c->n_constants_cols || (max_consts && !c->constants)) return fail("constants columns missing");
-    Partition part(total);  // advice wires (>= routed) are singletons
-    for (size_t i = 0; i < c->n_copies; ++i) part.merge(c->copies[2 * i], c->copies[2 * i + 1]);
-    (void)routed;
-    std::vector<u64> val(total, 0);
-    std::vector<uint8_t> is_set(total, 0);
-    std::string error;
-    auto set_pos = [&](u32 p, u64 v) {
-        const u32 r = part.find(p);
-        if (v >= gl::P) v -= gl::P;
-        if (is_set[r] && val[r] != v && error.empty())
-            error = "partition containing wire (column " + std::to_string(p / n) + ", row " + std::to_string(p % n) +
-                    ") was set twice with different values";
-        val[r] = v;
-        is_set[r] = 1;
-    };
-    for (size_t i = 0; i < n_preset; ++i) {
-        if (preset_pos[i] >= total) return fail("preset position out of range");
-        set_pos(preset_pos[i], preset_val[i]);
-    }
-    if (!error.empty()) return fail(error);
-    struct RowAcc {
-        size_t n, row;
-        Partition& part;
-        std::vector<u64>& val;
-        decltype(set_pos)& setter;
-        u64 get(unsigned w) { return val[part.find((u32)(w * n + row))]; }
-        void set(unsigned w, u64 v) { setter((u32)(w * n + row), v); }
-    };
-    struct Pending {
-        u32 row, sub;  // row == NO_ROW: gadget-level generator number `sub`
-    };
-    constexpr u32 NO_ROW = 0xFFFFFFFFu;
-    std::vector<Pending> pending;
-    for (size_t r = 0; r < n; ++r)
-        for (unsigned sub = 0; sub < gen_count(c->gates[c->row_gate[r]]); ++sub) pending.push_back({(u32)r, sub});
-    for (size_t i = 0; i < c->n_generators; ++i) pending.push_back({NO_ROW, (u32)i});
-    auto get_pos = [&](u32 p) { return val[part.find(p)]; };
-    auto run_gadget = [&](const vpbs_generator& g) {
-        switch (g.kind) {
-            case VPBS_GEN_EQUALITY: {
-                const u64 x = get_pos(g.in[0]), y = get_pos(g.in[1]);
-                set_pos(g.out[0], x == y ? 1 : 0);
-                set_pos(g.out[1], x == y ? 0 : gl::inv(gl::sub(x, y)));
-                break;
-            }
-            case VPBS_GEN_BASE_SUM: {
-                u64 sum = 0;
-                for (unsigned k = g.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, g.p0), get_pos(g.in[k]));
-                set_pos(g.out[0], sum);
-                break;
-            }
-            case VPBS_GEN_WIRE_SPLIT: {
-                u64 x = get_pos(g.in[0]);
-                for (unsigned k = 0; k < g.n_out; ++k) {
-                    set_pos(g.out[k], x & (((u64)1 << g.p0) - 1));
-                    x >>= g.p0;
-                }
-                if (x != 0) throw GenError{"WireSplitGenerator: integer too large to fit in the given number of limbs"};
-                break;
-            }
-            default: break;
-        }
-    };
-    std::vector<unsigned> deps;
-    std::vector<u64> consts(std::max(1u, max_consts));
-    // generate_partial_witness: run whatever is ready until nothing changes
-    while (!pending.empty()) {
-        std::vector<Pending> later;
-        for (const Pending& p : pending) {
-            if (p.row == NO_ROW) {
-                const vpbs_generator& gg = c->generators[p.sub];
-                bool ready = true;
-                for (unsigned k = 0; k < gg.n_in && ready; ++k) ready = is_set[part.find(gg.in[k])];
-                if (!ready) {
-                    later.push_back(p);
-                    continue;
-                }
-                try {
-                    run_gadget(gg);
-                } catch (const GenError& e) {
-                    return fail(e.what + " (generator " + std::to_string(p.sub) + ")");
-                }
-                if (!error.empty()) return fail(error);
-                continue;
-            }
-            const vpbs_gate& g = c->gates[c->row_gate[p.row]];
-            gen_deps(g, p.sub, deps);
-            bool ready = true;
-            for (unsigned w : deps)
-                if (!is_set[part.find((u32)(w * n + p.row))]) {
-                    ready = false;
-                    break;
-                }
-            if (!ready) {
-                later.push_back(p);
-                continue;
-            }
-            for (unsigned k = 0; k < g.num_constants; ++k) consts[k] = c->constants[(size_t)(c->num_selectors + k) * n + p.row];
-            RowAcc acc{n, p.row, part, val, set_pos};
-            try {
-                gen_run(g, p.sub, consts.data(), acc);
-            } catch (const GenError& e) {
-                return fail(e.what + " (row " + std::to_string(p.row) + ")");
-            }
-            if (!error.empty()) return fail(error);
-        }
-        if (later.size() == pending.size())  // generate_partial_witness: assert_eq!(remaining_generators, 0, "{} generators weren't run")
-            return fail(std::to_string(later.size()) + " generators weren't run (first: " +
-                        (later[0].row == NO_ROW ? "gadget generator " + std::to_string(later[0].sub) : "row " + std::to_string(later[0].row)) + ")");
-        pending.swap(later);
-    }
-    // full_witness: every wire takes its representative's value (unset -> 0)
-    for (size_t p = 0; p < total; ++p) wires_out[p] = val[part.find((u32)p)];
-    if (err && err_len) err[0] = 0;
-    return VPBS_OK;
+    std::string msg;
+    vpbs_witness_plan* plan = nullptr;
+    int rc = wires_out ? vpbs::plan_create(c, preset_pos, n_preset, &plan, msg) : VPBS_ERR_INVALID;
+    if (rc == VPBS_OK) rc = vpbs::plan_run(plan, preset_val, 0, wires_out, msg);
+    delete plan;
+    if (rc != VPBS_OK && msg.empty()) msg = "malformed circuit description";
+    vpbs::report(err, err_len, msg);
+    return rc;
 }
 
 int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint64_t pi_hash[4], char* err, size_t err_len) {
