@@ -60,7 +60,7 @@ def test_merkle_cap(ctx, leaf_len, n_leaves, cap_h):
 
 
 # ---------- NTT ----------
-@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 15, 16])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20])   # 19 = the quotient's transform at degree 2^16
 def test_intt(ctx, log_n):
     vals = rand_field(3, 1 << log_n)
     got = ctx.intt(vals)
@@ -266,7 +266,8 @@ def _leaf_order(nat, log_big):
     return np.ascontiguousarray(nat[:, idx])
 
 
-@pytest.mark.parametrize("log_n,n_routed,n_constants,with_gates", [(4, 8, 0, False), (6, 20, 3, True), (9, 80, 5, False), (8, 80, 5, True)])
+@pytest.mark.parametrize("log_n,n_routed,n_constants,with_gates", [(4, 8, 0, False), (6, 20, 3, True), (9, 80, 5, False), (8, 80, 5, True),
+                                                                  (16, 80, 4, False)])
 def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, with_gates):
     import torch
     n = 1 << log_n

@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #define GL_ASM_SCRATCH_LOW 1  // these kernels need ~40 VGPRs of their own: keep the asm scratch block low (occupancy)
+#include "context.h"
 #include "kernels.h"
 
 namespace vpbs {
@@ -264,7 +265,14 @@ negacyclic_kernel(u64* __restrict__ data, const u64* __restrict__ table, unsigne
     }
 }
 
-unsigned split_log_r(unsigned log_n) { return log_n > TILE_LOG ? (log_n - 9 > 7 ? 7 : log_n - 9) : 0; }
+// Two passes cover log_n <= 2 * TILE_LOG: the strided pass does log_r stages, the contiguous pass the remaining log_n - log_r, which
+// must fit one tile.  log_r = 7 keeps 16-element (128 B) runs in the strided pass; above 2^18 points it has to grow (2^19: the
+// quotient's inverse transform at degree 2^16 -- the first version kept 7 there and left 12 stages to an 11-stage tile).
+unsigned split_log_r(unsigned log_n) {
+    if (log_n <= TILE_LOG) return 0;
+    const unsigned want = log_n - 9 > 7 ? 7 : log_n - 9, need = log_n - TILE_LOG;
+    return want > need ? want : need;
+}
 }  // namespace
 
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse) {
@@ -285,6 +293,7 @@ static void run_transform(hipStream_t s, const u64* in, u64* out, u64* scratch, 
                           unsigned block_first, unsigned n_blocks) {
     const unsigned n = 1u << log_n;
     const unsigned cosets = n_blocks;
+    if (log_n > 2 * TILE_LOG) throw DeviceError{VPBS_ERR_INVALID, "transform larger than 2^22 points"};
     const unsigned log_r = split_log_r(log_n);
     const u64 scale = inverse ? gl::inv((u64)n) : 1;
     const unsigned tiles = n <= TILE ? 1 : n / TILE;
