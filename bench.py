@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: vPBS proofs/s at N = 1024 on N GPUs (BASELINE.json metric).
 
-A "step" = one step proof of the vPBS IVC chain on the 2^15-row, 135-wire plonky2 circuit (BASELINE config 2:
-commit wires / Z+partial-products / quotient chunks -> openings -> FRI, Fiat-Shamir transcript included) with the
-inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  Witness
+A "step" = one step proof of the vPBS IVC chain on the 2^16-row, 135-wire plonky2 circuit (BASELINE config 2 at the degree the
+reference really builds for N = 1024, see LOG_N below: commit wires / Z+partial-products / quotient chunks -> openings -> FRI,
+Fiat-Shamir transcript included) with the inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  Witness
 generation is a host stage of plonky2's prove() outside this round's hot path and is NOT inside the timed
 region -- `config.stages` says so explicitly.  The permutation-argument partial products (row a12) and the quotient
 polynomials (row a13: permutation argument + the constraints of all 14 gate types of a standard_recursion_config
@@ -29,7 +29,14 @@ import vpbs_amd  # noqa: E402
 from vpbs_amd import synth  # noqa: E402
 
 STEPS_PER_VPBS = 730       # n + 2 with n = 728 (reference src/main.rs:27, ivc_based_vpbs.rs:433-436)
-LOG_N = 15                 # degree of the step circuit at N = 1024 (ivc_based_vpbs.rs:57)
+# Degree of the step circuit at N = 1024.  /root/reference/src/vtfhe/ivc_based_vpbs.rs:54-61 pads the common-data circuit with NoopGates
+# until it HAS 2^15 gates and only then calls build(), which appends the public-input hash rows, the PublicInputGate and the constant
+# gates and pads to the next power of two: 2^16 rows (plonky2's cyclic-recursion test uses the same idiom).  Independent check: the
+# step logic without the recursive verifier, described gate by gate in tests/step_circuit.py, already needs 38 312 rows at the paper's
+# parameters (tests/test_gpu_step_circuit.py proves that circuit).  SURVEY.md 8d quotes 2^15; that size is kept as a secondary figure
+# (`survey_degree_2pow15` in the JSON line, `--log-n 15`).
+LOG_N = 16
+SURVEY_LOG_N = 15
 # the gate set of a recursive plonky2 circuit under standard_recursion_config (ivc_based_vpbs.rs:80-157 builds the step circuit from
 # arithmetic / base-sum / Poseidon gadgets and a recursive verifier); selector_polynomials gives it 4 selector columns
 GATES = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "poseidon_mds", "arithmetic_ext", "mul_ext", "reducing",
@@ -51,15 +58,15 @@ LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (t
 INT_CYCLES_PER_INSTR, SCLK_HZ = 0.5 * 4.61 + 0.5 * 4.35, 2.39e9
 
 
-def leaf_hash_bytes_per_step():
+def leaf_hash_bytes_per_step(log_n=LOG_N):
     """Algorithmic bytes of the dominant kernel (Poseidon leaf hashing) per step: every LDE element read once,
     one 32-byte digest written per leaf; three launches (wires, Z/pp, quotient)."""
-    lde = 1 << (LOG_N + 3)
+    lde = 1 << (log_n + 3)
     return sum(lde * (COLS[k] * 8 + 32) for k in ("wires", "zs_partial_products", "quotient"))
 
 
-def leaf_hash_perms_per_step():
-    lde = 1 << (LOG_N + 3)
+def leaf_hash_perms_per_step(log_n=LOG_N):
+    lde = 1 << (log_n + 3)
     return sum(lde * ((COLS[k] + 7) // 8) for k in ("wires", "zs_partial_products", "quotient"))
 
 
@@ -82,9 +89,9 @@ def cpu_baseline():
     dt = time.time() - t0
     return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": orc.effective_cpus(), "kind": "port",
-            "sample": "1 complete step proof (2^15 rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
+            "sample": "1 complete step proof (2^%d rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
                       "and quotient included) with the C oracle, OpenMP on every CPU the container may use "
-                      "(cgroup CPU quota; os.cpu_count() = %d)" % (os.cpu_count() or 0),
+                      "(cgroup CPU quota; os.cpu_count() = %d)" % (LOG_N, os.cpu_count() or 0),
             "note": "scalar restatement (naive Poseidon, ~8 us per permutation per core; PoW and Merkle top levels serial); "
                     "plonky2's own AVX2 Poseidon is roughly an order of magnitude faster per core -- a reported baseline, "
                     "not a tuned CPU prover"}
@@ -96,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-survey-size", action="store_true", help="skip the secondary degree-2^15 measurement (profiling runs)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
                     help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
                          "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
@@ -247,13 +255,13 @@ def main():
     if rank == 0:
         steps_total = args.steps * (1 if sharded else world) * n_chains
         step_rate = steps_total / elapsed
-        scale = (1 << log_n) / float(1 << LOG_N)
+        scale = 1.0
         per_step_ms = dominant["ms"] / max(1, args.steps * n_chains)  # three leaf_hash launches per step proof
         if sharded:
             scale /= world   # rank 0 hashed 1/world of the leaves
-        bytes_step = leaf_hash_bytes_per_step() * scale
+        bytes_step = leaf_hash_bytes_per_step(log_n) * scale
         achieved = bytes_step / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
-        perms = leaf_hash_perms_per_step() * scale
+        perms = leaf_hash_perms_per_step(log_n) * scale
         valu_rate = perms * LEAF_HASH_INSTR_PER_PERM / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_leaf_hash.json")
@@ -267,10 +275,13 @@ def main():
             "data": "synthetic", "step_proofs_per_s": step_rate, "steps_per_vpbs_proof": STEPS_PER_VPBS,
             "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
                                    "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, %d constant/sigma "
-                                   "columns precommitted; inputs resident in HBM" % (log_n, log_n + 3, COLS["constants_sigmas"]),
+                                   "columns precommitted; inputs resident in HBM.  2^16 is the degree the reference builds at N=1024 "
+                                   "(ivc_based_vpbs.rs:54-61 pads to 2^15 gates BEFORE build(); the step logic alone is 38312 rows, "
+                                   "tests/step_circuit.py); SURVEY.md's 2^15 is reported as survey_degree_2pow15"
+                                   % (log_n, log_n + 3, COLS["constants_sigmas"]),
                        "stages": "wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> permutation Z + partial "
                                  "products (GPU) -> commit -> alphas -> quotient polynomials (GPU: constraints of %d gate types with "
-                                 "their selector filters + the permutation argument over the 2^18 coset, / Z_H, coset iNTT, 16 "
+                                 "their selector filters + the permutation argument over the LDE coset, / Z_H, coset iNTT, 16 "
                                  "chunks) -> commit -> zeta -> openings at zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit "
                                  "PoW, 28 queries), Fiat-Shamir transcript included.  NOT in the timed region (host stage of "
                                  "plonky2's prove(), SURVEY.md 8f-2): witness generation" % gates.n,
@@ -296,6 +307,28 @@ def main():
         if world == 1 and n_chains == 1 and args.batch_chains > 1:
             # BASELINE config 3 flavour on the same GPU: several independent chains in flight (extra contexts/streams)
             out["batch"] = batch_result
+        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_survey_size:
+            # the size SURVEY.md 8d quotes for N = 1024 (degree 2^15), same columns and gates, single chain: a secondary figure
+            c15 = vpbs_amd.Context(local_rank, log_n_max=16)
+            i15 = synth.step_inputs(SURVEY_LOG_N, cols=COLS)
+            d15 = {k: torch.from_numpy(i15[k].view(np.int64)).cuda() for k in ("wires", "constants_sigmas")}
+            cs15 = c15.commit_values(i15["constants_sigmas"])
+            si15 = c15.make_step_inputs(SURVEY_LOG_N, d15["wires"].data_ptr(), None, None, cs15, digest, keep[0][2], on_device=True,
+                                        shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
+                                        sigmas=d15["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << SURVEY_LOG_N),
+                                        n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates)
+            for _ in range(max(1, args.warmup)):
+                c15.prove_step(si15)
+            torch.cuda.synchronize()
+            t15 = time.perf_counter()
+            for _ in range(args.steps):
+                c15.prove_step(si15)
+            c15.synchronize()
+            e15 = (time.perf_counter() - t15) / args.steps
+            out["survey_degree_2pow15"] = {"ms_per_step_proof": e15 * 1e3, "step_proofs_per_s": 1.0 / e15,
+                                           "vpbs_proofs_per_s": 1.0 / e15 / STEPS_PER_VPBS, "chains": 1}
+            cs15.free()
+            c15.close()
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -72,7 +72,7 @@ def main():
     write = [float(r["Counter_Value"]) for r in counter_rows(write_dir, "WRITE_SIZE") if short(r["Kernel_Name"]) == dominant]
     kinds_p = ["constants_sigmas"] + ["wires", "zs_partial_products", "quotient"] * ((len(fetch) - 1) // 3)
     cols = {"constants_sigmas": 86, "wires": 135, "zs_partial_products": 20, "quotient": 16}
-    lde = 1 << 18
+    lde = 1 << 19   # bench.py default: degree 2^16, LDE 2^19
     per_kind = {}
     for kind in cols:
         fv = [v for k, v in zip(kinds_p, fetch) if k == kind]
