@@ -288,6 +288,8 @@ typedef struct {
     const vpbs_gate* gates;           /* laid out by vpbs_gates_layout */
     unsigned n_gates;
     unsigned num_selectors;           /* leading constants columns that are selector polynomials */
+    int sigmas_on_device;             /* 1: sigmas_values is a device pointer even when inputs_on_device == 0 -- the sigma values are
+                                         circuit data, uploaded once, while the wires of each proof arrive from the host */
 } vpbs_step_inputs;
 
 /* Collectives for a step proof sharded over the GPUs of one node: supplied by the host, so the library

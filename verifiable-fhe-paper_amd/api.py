@@ -72,7 +72,8 @@ class StepInputsC(C.Structure):
                 ("constants_sigmas", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64),
                 ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint),
-                ("n_constants", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
+                ("n_constants", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint),
+                ("sigmas_on_device", C.c_int)]
 
 
 class VerifyInputsC(C.Structure):
@@ -663,7 +664,9 @@ class Context:
             else:
                 nz = n_zs_auto
                 si.zs_pp_values = None
-            if sigmas is not None:
+            if sigmas is not None and isinstance(sigmas, int):   # a device pointer: circuit data uploaded once
+                si.sigmas_values, si.sigmas_on_device = sigmas, 1
+            elif sigmas is not None:
                 sigmas = _u64(sigmas)
                 keep.append(sigmas)
                 si.sigmas_values = sigmas.ctypes.data

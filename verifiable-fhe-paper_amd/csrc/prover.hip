@@ -718,7 +718,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
                          "zs_pp_values == NULL needs sigmas_values, n_routed and quotient_degree_factor");
             const unsigned chunks = (in->n_routed + in->quotient_degree_factor - 1) / in->quotient_degree_factor;
             VPBS_REQUIRE(in->n_zs_partial_products == nc * chunks, "n_zs_partial_products != num_challenges * (num_partial_products + 1)");
-            d_sigmas = on_device(in->sigmas_values, (size_t)in->n_routed * n);
+            d_sigmas = in->sigmas_on_device ? in->sigmas_values : on_device(in->sigmas_values, (size_t)in->n_routed * n);
         }
 
         // prove(): public_inputs_hash, wires commitment, transcript
