@@ -430,6 +430,18 @@ def test_step_properties_2pow16(ctx):
     cs.free()
 
 
+def test_step_properties_2pow17():
+    """one size above the N = 1024 step circuit (the N = 2048 ring would land here if its step circuit is padded like the N = 1024 one:
+    degree 2^17, LDE 2^20): the proof verifies under the restated plonky2 verifier and under the product's own."""
+    log_n = 17
+    c = vpbs_amd.Context(0, log_n_max=17)
+    inputs, pis, cs, si, got = _step(c, log_n)
+    assert step_oracle.verify_step(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
+    assert api.verify_step(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
+    cs.free()
+    c.close()
+
+
 def test_full_size_step_properties(ctx):
     """BASELINE config 2 (N = 1024: degree 2^15, LDE 2^18, 135/20/16/85 columns).  The oracle prover would take
     minutes here, so parity is carried by size-independent properties: the proof verifies under the restated
