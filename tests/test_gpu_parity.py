@@ -95,7 +95,8 @@ def test_negacyclic_golden(ctx, path):
 
 
 # ---------- PolynomialBatch ----------
-@pytest.mark.parametrize("log_n,ncols,from_values", [(5, 3, True), (6, 4, True), (10, 9, True), (12, 5, False), (13, 135, True)])
+@pytest.mark.parametrize("log_n,ncols,from_values", [(5, 3, True), (6, 4, True), (10, 9, True), (12, 5, False), (13, 135, True),
+                                                     (16, 3, True), (16, 2, False)])
 def test_commit_matches_oracle(ctx, log_n, ncols, from_values):
     data = rand_field(ncols, 1 << log_n)
     want = orc.Batch(data, 3, 4, from_values=from_values)
@@ -207,7 +208,7 @@ def _fri_case(ctx, log_n, cols, **over):
 
 
 @pytest.mark.parametrize("log_n,over", [(5, {}), (6, {}), (9, {}), (12, {}), (8, {"mul_final_by_x": 1}), (7, {"pow_bits": 5, "num_query_rounds": 3}),
-                                        (10, {"pow_bits": 0})])
+                                        (10, {"pow_bits": 0}), (14, {}), (16, {})])
 def test_fri_prove_bit_exact(ctx, log_n, over):
     """log_n = 5: ConstantArityBits(4,5) gives zero folding rounds (the final polynomial is the whole polynomial)."""
     ob, gb, ch, gch, batches, openings, op, gp = _fri_case(ctx, log_n, (4, 6, 3, 2), **over)
@@ -242,7 +243,7 @@ def _pow_valid(ch, gb, batches, gp, ctx, w):
 
 
 # ---------- permutation argument (a12) ----------
-@pytest.mark.parametrize("log_n,n_routed,deg,nc", [(3, 10, 4, 2), (8, 80, 8, 2), (11, 80, 8, 2), (9, 17, 8, 1), (10, 8, 8, 3)])
+@pytest.mark.parametrize("log_n,n_routed,deg,nc", [(3, 10, 4, 2), (8, 80, 8, 2), (11, 80, 8, 2), (9, 17, 8, 1), (10, 8, 8, 3), (16, 80, 8, 2)])
 def test_partial_products_match_oracle(ctx, log_n, n_routed, deg, nc):
     wires, sig = rand_field(n_routed + 3, 1 << log_n), rand_field(n_routed, 1 << log_n)
     betas, gammas = [int(x) for x in rand_field(nc)], [int(x) for x in rand_field(nc)]
@@ -349,9 +350,12 @@ def test_copy_constraint_proof_end_to_end(ctx, log_n):
     assert not prove_and_check(bad)
 
 
-def test_step_proof_with_device_quotient_bit_exact(ctx):
-    log_n, n_constants, n_routed = 8, 5, 80
-    inputs = synth.step_inputs(log_n)
+@pytest.mark.parametrize("log_n,cols", [(8, None), (16, {"constants_sigmas": 12, "wires": 12, "zs_partial_products": 4, "quotient": 16})])
+def test_step_proof_with_device_quotient_bit_exact(ctx, log_n, cols):
+    """log_n = 16: the degree of the N = 1024 step circuit, with fewer columns so that the oracle prover finishes in seconds --
+    the 2^19-point inverse transform of the quotient stage included"""
+    n_constants, n_routed = (5, 80) if cols is None else (2, 10)
+    inputs = synth.step_inputs(log_n, cols=cols)
     inputs["quotient"] = None
     pis = synth.field_elements(0xD00D, 20)
     sig = np.ascontiguousarray(inputs["constants_sigmas"][n_constants:n_constants + n_routed])
@@ -376,7 +380,8 @@ def _step(ctx, log_n, cols=None, instance=0):
 
 
 @pytest.mark.parametrize("log_n,cols", [(6, {"constants_sigmas": 5, "wires": 9, "zs_partial_products": 4, "quotient": 3}),
-                                        (9, None), (12, None)])
+                                        (9, None), (12, None),
+                                        (16, {"constants_sigmas": 5, "wires": 9, "zs_partial_products": 4, "quotient": 3})])
 def test_step_proof_bit_exact(ctx, log_n, cols):
     """BASELINE config 1 sizes at log_n = 12 (N = 8 ring: degree 2^12, 135/20/16/85 columns)."""
     inputs, pis, cs, si, got = _step(ctx, log_n, cols)
