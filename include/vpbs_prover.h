@@ -203,8 +203,14 @@ int vpbs_gate_fill_row(const vpbs_gate* gate, const uint64_t* constants, uint64_
 typedef enum {
     VPBS_GEN_EQUALITY = 0, /* gadgets/arithmetic.rs EqualityGenerator: in = [x, y]; out = [equal, inv]: equal = (x == y), inv = (x - y)^-1 or 0 */
     VPBS_GEN_BASE_SUM,     /* gates/base_sum.rs BaseSumGenerator (le_sum): p0 = base B; in = limbs (little endian); out = [sum] */
-    VPBS_GEN_WIRE_SPLIT    /* gadgets/split_join.rs WireSplitGenerator (split_le): p0 = limbs per gate; in = [integer]; out = the BaseSumGate sum wire of
-                              every gate: chunk k = bits [k p0, (k+1) p0) of the canonical integer; error if bits remain */
+    VPBS_GEN_WIRE_SPLIT,   /* gadgets/split_join.rs WireSplitGenerator (split_le): p0 = limbs per gate; in = [integer]; out = the BaseSumGate sum wire of
+                              every gate: chunk k = bits [k p0, (k+1) p0) of the canonical integer; error if bits remain.  With p0 = 1 this is
+                              SplitGenerator (one bit per output) */
+    /* the remaining generators of plonky2's recursive verifier gadgets (FRI verifier: div_extension / inverse_extension; range checks): */
+    VPBS_GEN_QUOTIENT_EXT, /* gadgets/arithmetic_extension.rs QuotientGeneratorExtension: in = [num0, num1, den0, den1]; out = [q0, q1] = num / den
+                              in GF(p^2); error on a zero denominator */
+    VPBS_GEN_COPY,         /* iop/generator.rs CopyGenerator: in = [src]; out = [dst] */
+    VPBS_GEN_LOW_HIGH      /* gadgets/range_check.rs LowHighGenerator: p0 = n_log; in = [integer]; out = [low, high]: low = the n_log low bits */
 } vpbs_generator_kind;
 typedef struct {
     unsigned kind, p0;

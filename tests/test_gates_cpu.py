@@ -456,6 +456,63 @@ def test_gadget_level_generators_is_equal_split_le_le_sum():
         circ.generate_witness({(10, 5): 1 << 63})
 
 
+def test_gadget_level_generators_of_the_recursive_verifier():
+    """QuotientGeneratorExtension (div_extension: the quotient is a fresh target, an ArithmeticExtensionGate op checks den * q = num),
+    LowHighGenerator (split_low_high: x = low + 2^n_log * high checked by an ArithmeticGate op) and CopyGenerator, scheduled with the
+    gate generators; the checks close through copy constraints, so a wrong generator would set a class twice with different values."""
+    rng = random.Random(99)
+    spec = ["noop", "arithmetic", "arithmetic_ext"]
+    ps = api.GateSet(spec)
+    ar, ax, noop = ps.by_kind("arithmetic"), ps.by_kind("arithmetic_ext"), ps.by_kind("noop")
+    log_n, n_log = 3, 20
+    n = 1 << log_n
+    for trial in range(4):
+        num, den = [rng.randrange(P) for _ in range(2)], [rng.randrange(P), rng.randrange(P) if trial else 0]
+        x = rng.randrange(P)
+        row_gate = np.full(n, noop.index, np.uint32)
+        row_gate[0], row_gate[1] = ax.index, ar.index
+        constants = np.zeros((ps.num_selectors + 2, n), np.uint64)
+        constants[ps.num_selectors, 0], constants[ps.num_selectors + 1, 0] = 1, 0            # row 0: x * y
+        constants[ps.num_selectors, 1], constants[ps.num_selectors + 1, 1] = 1 << n_log, 1   # row 1: 2^20 * m0 * m1 + addend
+        copies, presets, gens = [], {}, []
+        cp = lambda a, b: copies.append((a[0] * n + a[1], b[0] * n + b[1]))
+        # numerator and denominator live on a noop row (virtual targets of the gadget)
+        for i in range(2):
+            presets[(i, 5)], presets[(2 + i, 5)] = num[i], den[i]
+            cp((2 + i, 5), (i, 0))                       # op 0 of row 0: x = den
+            presets[(4 + i, 0)] = 0                      # addend
+            cp((6 + i, 0), (i, 5))                       # ... and its output is the numerator
+        gens.append(("quotient_ext", 0, [(0, 5), (1, 5), (2, 5), (3, 5)], [(2, 0), (3, 0)]))
+        for op in range(1, ax.p0):                       # unused operations
+            for k in range(6):
+                presets[(8 * op + k, 0)] = 0
+        # split_low_high(x, 20): low / high are fresh targets; row 1 op 0 recomposes them
+        presets[(10, 6)] = x
+        gens.append(("low_high", n_log, [(10, 6)], [(2, 1), (0, 1)]))     # low -> addend, high -> m0
+        presets[(1, 1)] = 1
+        cp((3, 1), (10, 6))
+        gens.append(("copy", 0, [(0, 1)], [(20, 6)]))                     # a copy of `high` on the noop row
+        for op in range(1, ar.p0):
+            for k in range(3):
+                presets[(4 * op + k, 1)] = 0
+        circ = api.Circuit(ps, log_n, row_gate, constants, copies, generators=gens)
+        constants[:ps.num_selectors] = circ.selector_columns()
+        circ = api.Circuit(ps, log_n, row_gate, constants, copies, generators=gens)
+        w = circ.generate_witness(presets)
+        ok, msg = circ.check_witness(w, [0, 0, 0, 0])
+        assert ok, msg
+        q = (int(w[2, 0]), int(w[3, 0]))
+        want = ((den[0] * q[0] + 7 * den[1] * q[1]) % P, (den[0] * q[1] + den[1] * q[0]) % P)
+        assert want == tuple(num)
+        assert int(w[2, 1]) == x & ((1 << n_log) - 1) and int(w[0, 1]) == x >> n_log and int(w[20, 6]) == x >> n_log
+        plan = circ.witness_plan(list(presets))
+        assert (plan.run(list(presets.values())) == w).all()
+    # division by zero is an error of the run, not of the plan
+    presets[(2, 5)] = presets[(3, 5)] = 0
+    with pytest.raises(api.VpbsError, match="division by zero"):
+        circ.generate_witness(presets)
+
+
 def test_malformed_circuit_descriptions_are_errors():
     ps = api.GateSet(["noop", "arithmetic"])
     n = 8
@@ -465,6 +522,8 @@ def test_malformed_circuit_descriptions_are_errors():
                 dict(copies=[(80 * n, 0)]),                                    # copy constraint on a non-routed wire
                 dict(generators=[("equality", 0, [(0, 0)], [(1, 0), (2, 0)])]),  # EqualityGenerator needs two inputs
                 dict(generators=[("wire_split", 64, [(0, 0)], [(1, 0)])]),     # more than 63 bits per BaseSumGate
+                dict(generators=[("quotient_ext", 0, [(0, 0), (1, 0)], [(2, 0), (3, 0)])]),   # needs numerator and denominator
+                dict(generators=[("low_high", 64, [(0, 0)], [(1, 0), (2, 0)])]),               # n_log out of range
                 dict(generators=[("base_sum", 2, [(200, 0)], [(1, 0)])])):     # position beyond the trace
         kw = dict(row_gate=ok_rows, copies=[], generators=())
         kw.update(bad)

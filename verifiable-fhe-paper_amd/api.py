@@ -50,7 +50,7 @@ class GeneratorC(C.Structure):
     _fields_ = [("kind", C.c_uint), ("p0", C.c_uint), ("inp", U32P), ("n_in", C.c_uint), ("out", U32P), ("n_out", C.c_uint)]
 
 
-GENERATOR_KINDS = ["equality", "base_sum", "wire_split"]
+GENERATOR_KINDS = ["equality", "base_sum", "wire_split", "quotient_ext", "copy", "low_high"]
 
 
 class CircuitC(C.Structure):

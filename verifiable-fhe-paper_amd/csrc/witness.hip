@@ -270,7 +270,10 @@ bool check_circuit(const vpbs_circuit* c) {
         if (g.kind == VPBS_GEN_EQUALITY && (g.n_in != 2 || g.n_out != 2)) return false;
         if (g.kind == VPBS_GEN_BASE_SUM && (g.p0 < 2 || g.n_out != 1)) return false;
         if (g.kind == VPBS_GEN_WIRE_SPLIT && (g.p0 < 1 || g.p0 > 63 || g.n_in != 1 || g.n_out < 1)) return false;
-        if (g.kind > VPBS_GEN_WIRE_SPLIT) return false;
+        if (g.kind == VPBS_GEN_QUOTIENT_EXT && (g.n_in != 4 || g.n_out != 2)) return false;
+        if (g.kind == VPBS_GEN_COPY && (g.n_in != 1 || g.n_out != 1)) return false;
+        if (g.kind == VPBS_GEN_LOW_HIGH && (g.p0 < 1 || g.p0 > 63 || g.n_in != 1 || g.n_out != 2)) return false;
+        if (g.kind > VPBS_GEN_LOW_HIGH) return false;
     }
     return true;
 }
@@ -506,6 +509,23 @@ void run_gadget(const vpbs_witness_plan& p, const vpbs_witness_plan::Gadget& g, 
             if (x != 0) throw GenError{"WireSplitGenerator: integer too large to fit in the given number of limbs"};
             break;
         }
+        case VPBS_GEN_QUOTIENT_EXT: {
+            const A num{s.val[in[0]], s.val[in[1]]}, den{s.val[in[2]], s.val[in[3]]};
+            if (den.a == 0 && den.b == 0) throw GenError{"QuotientGeneratorExtension: division by zero"};
+            // 1 / (a + b X) = (a - b X) / (a^2 - 7 b^2)   (X^2 = 7)
+            const u64 norm = gl::sub(gl::mul(den.a, den.a), gl::mul(7, gl::mul(den.b, den.b)));
+            const A q = gates::scale(num * A{den.a, gl::neg(den.b)}, gl::inv(norm));
+            s.set(out[0], q.a, out_pos[0]);
+            s.set(out[1], q.b, out_pos[1]);
+            break;
+        }
+        case VPBS_GEN_COPY: s.set(out[0], s.val[in[0]], out_pos[0]); break;
+        case VPBS_GEN_LOW_HIGH: {
+            const u64 x = s.val[in[0]];
+            s.set(out[0], x & (((u64)1 << g.p0) - 1), out_pos[0]);
+            s.set(out[1], x >> g.p0, out_pos[1]);
+            break;
+        }
         default: break;
     }
 }
@@ -531,13 +551,7 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
     }
     lap("presets");
     const unsigned mc = std::max(1u, p.max_consts);
-    double kind_ms[32] = {0};
     for (const auto& st : p.schedule) {
-        const auto k0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        struct Tick {
-            bool on; decltype(k0) a; double* acc;
-            ~Tick() { if (on) *acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); }
-        } tick{trace, k0, &kind_ms[st.row == NO_ROW ? 31 : p.gates[p.row_gate[st.row]].kind]};
         try {
             if (st.row == NO_ROW) {
                 run_gadget(p, p.gadgets[st.sub], s);
@@ -555,9 +569,6 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
         }
     }
     lap("generators");
-    if (trace)
-        for (int k = 0; k < 32; ++k)
-            if (kind_ms[k] > 0) std::fprintf(stderr, "[witness]   kind %d: %.2f ms\n", k, kind_ms[k]);
     // full_witness: every wire takes its class's value (unset -> 0), position ranges in parallel
     if (threads == 0) threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     auto fill = [&](unsigned t) {
