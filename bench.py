@@ -460,7 +460,10 @@ def main():
             cs15.free()
             c15.close()
         if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_step_circuit:
-            out["step_circuit_pipeline"] = step_circuit_pipeline(local_rank)
+            try:
+                out["step_circuit_pipeline"] = step_circuit_pipeline(local_rank)
+            except Exception as e:   # a secondary figure must not take the headline line down with it
+                out["step_circuit_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -141,6 +141,14 @@ def test_step_circuit_at_the_papers_parameters(ctx):
         wrong = list(pis)
         wrong[-1] ^= 1
         assert not pr.verify(proof, wrong)
+        if counter == 5:                                 # one wrong advice wire of a BaseSumGate row: not a witness of the circuit
+            row = circ.built.row_kinds.index("base_sum")
+            bad = wires.copy()
+            bad[7, row] ^= np.uint64(1)
+            ok_bad, msg_bad = circ.built.circuit.check_witness(bad, api.hash_no_pad(np.array(pis, np.uint64)))
+            assert not ok_bad and "row %d" % row in msg_bad
+            proof_bad, _ = pr.prove(bad)
+            assert not pr.verify(proof_bad, pis)
         report.append((counter, t_wit, t_prove))
     print("\nstep circuit N=1024: %d rows, builder %.1f s, setup (sigma, commit, plan) %.2f s; " % (circ.built.used_rows, t_build, t_setup) +
           "; ".join("counter %d: witness %.0f ms, proof (incl. H2D of the wires) %.1f ms" % (c, 1e3 * a, 1e3 * b) for c, a, b in report))
