@@ -172,7 +172,7 @@ def test_invalid_arguments_are_errors(ctx):
     b.free()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 10), (4, 12), (8, 9)])
+@pytest.mark.parametrize("world,log_n", [(2, 10), (4, 12), (8, 9), (2, 16), (8, 16)])   # 16: the degree of the N = 1024 step circuit
 def test_sharded_step_proof_multi_rank(world, log_n):
     """SURVEY.md 8e / BASELINE config 4: one step proof sharded over `world` ranks (gloo collectives, all ranks on this
     box's single GPU) == the single-GPU proof, bit for bit, on every rank."""
