@@ -153,3 +153,22 @@ def test_step_circuit_at_the_papers_parameters(ctx):
     print("\nstep circuit N=1024: %d rows, builder %.1f s, setup (sigma, commit, plan) %.2f s; " % (circ.built.used_rows, t_build, t_setup) +
           "; ".join("counter %d: witness %.0f ms, proof (incl. H2D of the wires) %.1f ms" % (c, 1e3 * a, 1e3 * b) for c, a, b in report))
     pr.close()
+
+
+@pytest.mark.parametrize("N", [8, 64])
+def test_cxx_host_proves_an_exported_step_circuit(N, tmp_path):
+    """examples/prove_step_circuit.cpp: the step circuit handed over as data (tools/export_step_circuit.py: what the Rust side would
+    export after builder.build()) to a plain C++ host of the C ABI -- layout, sigma, witness plan, check, commit, proof, verification;
+    its witness reproduces the exported public inputs."""
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    sys.path.insert(0, entry.ROOT + "/tools")
+    import export_step_circuit as ex
+    path = str(tmp_path / "step.bin")
+    circ, pis = ex.export(path, N=N)
+    exe = entry.build_example("prove_step_circuit")
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "proof verified: 1; with a wrong public input: 0" in r.stdout
+    assert "degree 2^%d" % circ.built.log_n in r.stdout and "%d public inputs" % len(pis) in r.stdout

@@ -183,3 +183,27 @@ def test_pbs_chain_of_step_witnesses():
             acc_in = acc_out
         m_bar = tf.glwe_decrypt(ring, s_to, [[int(v) for v in acc_in[q]] for q in range(K)], K)[0]
         assert round(m_bar / delta) % (2 * p) == m
+
+
+def test_cxx_host_generates_the_exported_witness(tmp_path):
+    """examples/prove_step_circuit.cpp up to the device boundary, on a box without a GPU: the C++ host loads the exported circuit,
+    makes the plan, generates the witness, reproduces the exported public inputs and checks every constraint -- then fails loudly
+    (exit code 2) because there is no device to prove on."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by test_gpu_step_circuit on a GPU box")
+    import __graft_entry__ as entry
+    sys.path.insert(0, entry.ROOT + "/tools")
+    import export_step_circuit as ex
+    path = str(tmp_path / "step.bin")
+    ex.export(path, N=8)
+    exe = entry.build_example("prove_step_circuit")
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "context creation failed" in r.stderr, r.stdout + r.stderr
+    with open(path, "r+b") as f:                      # a sample value changed: the witness no longer reproduces the exported public inputs
+        f.seek(-8 * (2 * 41 + 3), 2)
+        f.write((12345).to_bytes(8, "little"))
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "public inputs differ" in r.stderr, r.stdout + r.stderr

@@ -326,6 +326,7 @@ class Circuit:
         c.constants, c.n_constants_cols = _ptr(self.constants), self.constants.shape[0]
         c.copies, c.n_copies = self.copies.ctypes.data_as(U32P), self.copies.shape[0]
         self._gen_keep = []
+        self.generator_list = list(generators)
         if generators:
             arr = (GeneratorC * len(generators))()
             for g, (kind, p0, ins, outs) in zip(arr, generators):
