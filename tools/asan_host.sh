@@ -14,4 +14,4 @@ cp "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so" $OUT/real.so
 cp $OUT/libvpbs_hip.so "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so"
 trap 'cp $OUT/real.so "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so"' EXIT
 cd "$ROOT"
-ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$RT python -m pytest tests/test_gates_cpu.py tests/test_host_cpu.py tests/test_golden_plonky2.py -x -q -m "not gpu" -p no:cacheprovider
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$RT python -m pytest tests/test_gates_cpu.py tests/test_host_cpu.py tests/test_golden_plonky2.py tests/test_step_circuit_cpu.py -k "not cxx" -x -q -m "not gpu" -p no:cacheprovider
