@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
                     help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
                          "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
-    ap.add_argument("--batch-chains", type=int, default=3,
+    ap.add_argument("--batch-chains", type=int, default=4,
                     help="after the headline single-chain measurement, also time this many concurrent chains (1 GPU only)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N > 1: 'replicas' = independent chains per GPU (weak scaling, default, no data-path collective); "
