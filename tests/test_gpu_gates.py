@@ -135,10 +135,10 @@ def test_gate_circuit_proof_end_to_end(ctx, log_n):
                                gates=ps)
 
 
-def test_gate_terms_full_size_spot_check(ctx):
-    """BASELINE config 2 shape (degree 2^15, LDE 2^18): all 14 gate types over random columns; the device value at sampled leaves
-    equals the oracle's evaluation of the same gates on the LDE rows read back from the committed batches."""
-    log_n = 15
+@pytest.mark.parametrize("log_n", [15, 16])
+def test_gate_terms_full_size_spot_check(ctx, log_n):
+    """BASELINE config 2 shape (degree 2^15 / 2^16, LDE 2^18 / 2^19): all 14 gate types over random columns; the device value at
+    sampled leaves equals the oracle's evaluation of the same gates on the LDE rows read back from the committed batches."""
     n = 1 << log_n
     gs, ps = go.GateSet(ALL), api.GateSet(ALL)
     n_const = gs.num_selectors + gs.num_constants
@@ -147,7 +147,7 @@ def test_gate_terms_full_size_spot_check(ctx):
     pi_hash, alphas = [int(x) for x in rand_field(4)], [int(x) for x in rand_field(2)]
     cs, wb = ctx.commit_values(consts), ctx.commit_values(wires)
     got = _device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas)   # leaf order
-    for leaf in (0, 1, 77777, (1 << 18) - 1, 131072):
+    for leaf in (0, 1, 77777, 8 * n - 1, 4 * n, 4 * n + 1, 8 * n - 77):
         c_row, w_row = cs.open(leaf)[0], wb.open(leaf)[0]   # MerkleTree::get: the LDE row at this leaf index
         cz = np.stack([c_row, np.zeros_like(c_row)], axis=1)
         wz = np.stack([w_row, np.zeros_like(w_row)], axis=1)
@@ -170,14 +170,15 @@ def test_gate_argument_errors_device(ctx):
         ctx.gate_terms(cs2, small, ps, [0] * 4, [1, 2], out.data_ptr())
 
 
-def test_full_size_gate_circuit_proof_verifies(ctx):
-    """BASELINE config 2 size (degree 2^15, LDE 2^18) with a satisfiable circuit: public-input hash, Poseidon chain, arithmetic
+@pytest.mark.parametrize("log_n", [15, 16])
+def test_full_size_gate_circuit_proof_verifies(ctx, log_n):
+    """BASELINE config 2 size (degree 2^15 and 2^16, LDE 2^18 / 2^19) with a satisfiable circuit: public-input hash, Poseidon chain, arithmetic
     chain, rows of every gate type, copy constraints, 2^15 - 33 NoopGate rows.  The oracle prover would take minutes, so parity is
     carried by the identity itself: the GPU proof is accepted by the oracle's FRI verifier, the vanishing identity holds at zeta with
     the gate terms re-evaluated from the openings by the ORACLE (and by the product's host verifier); one wrong witness value
     anywhere breaks it."""
     r = random.Random(2024)
-    log_n, n_routed = 15, 80
+    n_routed = 80
     gs, ps = go.GateSet(ALL), api.GateSet(ALL)
     pis = [r.randrange(P) for _ in range(4)]
     constants, wires, sigma, pi_hash = go.demo_circuit(r, gs, log_n, pis)
