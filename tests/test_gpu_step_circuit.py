@@ -172,3 +172,26 @@ def test_cxx_host_proves_an_exported_step_circuit(N, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "proof verified: 1; with a wrong public input: 0" in r.stdout
     assert "degree 2^%d" % circ.built.log_n in r.stdout and "%d public inputs" % len(pis) in r.stdout
+
+
+def test_step_circuit_n2048():
+    """BASELINE config 5's ring (N = 2048, the reference's params_2048 tables): 78 555 gate rows -> degree 2^17, 8 201 public inputs.
+    One CMUX step: witness by the compiled plan, accumulator equal to the device's native step, proof on the device, verified."""
+    rng = np.random.default_rng(2048)
+    N, K, ELL, LOGB, n = 2048, 2, 4, 5, 728
+    c17 = vpbs_amd.Context(0, log_n_max=17)
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n, api.ntt_params(11))
+    assert circ.built.log_n == 17 and circ.built.used_rows == 78555
+    pr = Prover(c17, circ)
+    f = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)
+    acc_init, acc_in, ggsw, mask, h1, h2 = f(K, N), f(K, N), f(K * ELL * K * N), int(f(1)[0]), f(4), f(4)
+    wires = pr.witness(acc_init, acc_in, ggsw, 9, mask, h1, h2)
+    proof, pis = pr.prove(wires)
+    want = c17.blind_rotate_step(acc_in[None], [mask], ggsw, K, ELL, LOGB)[0]
+    assert pis[K * N + 1:2 * K * N + 1] == [int(v) for v in want.reshape(-1)]
+    assert pr.verify(proof, pis)
+    wrong = list(pis)
+    wrong[3] ^= 1
+    assert not pr.verify(proof, wrong)
+    pr.close()
+    c17.close()
