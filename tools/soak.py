@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, vpbs_amd
 from vpbs_amd import api, synth
 import bench
-log_n, N = 15, int(sys.argv[1]) if len(sys.argv) > 1 else 300
+log_n, N = bench.LOG_N, int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ctx = vpbs_amd.Context(0, log_n_max=16)
 gates = api.GateSet(bench.GATES)
 inputs = synth.step_inputs(log_n, cols=bench.COLS)
