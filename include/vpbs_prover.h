@@ -258,6 +258,23 @@ int vpbs_witness_plan_create(const vpbs_circuit* circuit, const uint32_t* preset
 int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out /* [n_wires][n] */,
                           char* err, size_t err_len);
 void vpbs_witness_plan_free(vpbs_witness_plan* plan);
+/* The same schedule on the device, for a batch of PartialWitnesses of one circuit (the n + 2 step witnesses of a PBS are independent
+ * once vpbs_pbs_accumulator_chain has produced the accumulators): the plan's generators are grouped by dependency level and replayed
+ * for `batch` instances at once, values in HBM as [slot][batch]; the level launches are captured in a hipGraph per batch size.  The
+ * wires of an instance are then gathered into a device [n_wires][n] matrix that vpbs_prove_step takes with inputs_on_device = 1 --
+ * they never cross PCIe.  Supported generators: ConstantGate, ArithmeticGate, BaseSumGate<2>, PoseidonGate and every gadget generator
+ * kind above (the step circuit's set); creation fails (VPBS_ERR_INVALID, vpbs_last_error names the gate) for a plan that needs others.
+ * preset_val: host [n_preset][batch] (order of preset_pos at plan creation, instances innermost).  Value errors of any instance (a
+ * class set twice with different values, an integer that does not fit, a non-boolean swap) fail the run.  The plan must outlive the
+ * device object; one run at a time per object. */
+typedef struct vpbs_witness_device vpbs_witness_device;
+int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out);
+int vpbs_witness_device_run(vpbs_witness_device* dev, const uint64_t* preset_val, unsigned batch);
+/* gathers instance `instance` of the last run into d_wires (device, [n_wires][n], fully written) */
+int vpbs_witness_device_wires(vpbs_witness_device* dev, unsigned instance, uint64_t* d_wires);
+/* values of `count` wire positions (column * n + row) of one instance -> host (e.g. the public inputs) */
+int vpbs_witness_device_read(vpbs_witness_device* dev, unsigned instance, const uint32_t* positions, size_t count, uint64_t* out);
+void vpbs_witness_device_free(vpbs_witness_device* dev);
 /* Checks a complete witness against the circuit on the host: every row satisfies the constraints of its gate (evaluated on the
  * trace values themselves, i.e. on the subgroup) and every copy constraint holds.  Returns 1 = satisfied, 0 = violated (err names the
  * first violation: row, gate, constraint index or the two wire positions), < 0 = malformed arguments.  This is the integration aid

@@ -153,6 +153,11 @@ SIGNATURES = {
     "vpbs_witness_plan_create": (_i, [C.POINTER(CircuitC), U32P, _sz, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
     "vpbs_witness_plan_run": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_free": (None, [C.c_void_p]),
+    "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
+    "vpbs_witness_device_run": (_i, [C.c_void_p, U64P, C.c_uint]),
+    "vpbs_witness_device_wires": (_i, [C.c_void_p, C.c_uint, C.c_void_p]),
+    "vpbs_witness_device_read": (_i, [C.c_void_p, C.c_uint, U32P, _sz, U64P]),
+    "vpbs_witness_device_free": (None, [C.c_void_p]),
     "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
@@ -384,7 +389,7 @@ class WitnessPlan:
     def __init__(self, circuit, positions):
         self.circuit = circuit
         pos = np.array([c * circuit.n + r for (c, r) in positions], dtype=np.uint32)
-        self.n_preset = pos.size
+        self.n_preset, self.positions = pos.size, pos
         h, err = C.c_void_p(), C.create_string_buffer(512)
         rc = lib().vpbs_witness_plan_create(C.byref(circuit.c), pos.ctypes.data_as(U32P), pos.size, C.byref(h), err, 512)
         if rc:
@@ -406,6 +411,46 @@ class WitnessPlan:
     def free(self):
         if self.h:
             lib().vpbs_witness_plan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class WitnessDevice:
+    """vpbs_witness_device: the plan's schedule replayed on the device for a batch of PartialWitnesses (create once per circuit)."""
+
+    def __init__(self, ctx, plan, max_batch):
+        self.ctx, self.plan, self.max_batch = ctx, plan, max_batch
+        h = C.c_void_p()
+        ctx._check(lib().vpbs_witness_device_create(ctx.h, plan.h, max_batch, C.byref(h)))
+        self.h = h
+
+    def run(self, values):
+        """values: [n_preset][batch] (rows in the order of the plan's positions)"""
+        v = _u64(values)
+        assert v.ndim == 2 and v.shape[0] == self.plan.n_preset and 1 <= v.shape[1] <= self.max_batch
+        self.batch = v.shape[1]
+        self.ctx._check(lib().vpbs_witness_device_run(self.h, _ptr(v), v.shape[1]))
+
+    def wires(self, instance, d_wires_ptr):
+        """gather one instance into a device [n_wires][n] matrix (pointer as int)"""
+        self.ctx._check(lib().vpbs_witness_device_wires(self.h, instance, d_wires_ptr))
+
+    def read(self, instance, positions):
+        """values at wire positions [(column, row), ...] of one instance -> numpy uint64"""
+        n = self.plan.circuit.n
+        pos = np.array([c * n + r for (c, r) in positions], dtype=np.uint32)
+        out = np.zeros(pos.size, np.uint64)
+        self.ctx._check(lib().vpbs_witness_device_read(self.h, instance, pos.ctypes.data_as(U32P), pos.size, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().vpbs_witness_device_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,4 +1,5 @@
-// Witness generation for circuits made of the supported gates (host only; no device code in this file).
+// Witness generation for circuits made of the supported gates: on the host (vpbs_generate_witness, vpbs_witness_plan_*) and, for a
+// batch of PartialWitnesses of one circuit, on the device (vpbs_witness_device_*, at the end of the file).
 // Replaces plonky2 0.2.0 iop/generator.rs `generate_partial_witness` (run every generator whose watched targets are set,
 // propagate through the copy-constraint partition, repeat), iop/witness.rs `PartitionWitness::full_witness`, the gates' own
 // `SimpleGenerator::run_once` implementations (gates/*.rs), plonk/permutation_argument.rs `WirePartition::get_sigma_polys` and
@@ -18,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#include "context.h"
 #include "gates.h"
 #include "../../include/vpbs_prover.h"
 
@@ -83,9 +85,13 @@ template <class R> void walg(R& r, unsigned i, A x) {
     r.set(i + 1, x.b);
 }
 
-template <class R> void poseidon_generate(R& r) {
+// host and device (the device witness generator runs it once per PoseidonGate row and instance); failures go through the accessor
+template <class R> GL_HD void poseidon_generate(R& r) {
     const u64 swap = r.get(24);
-    if (swap > 1) throw GenError{"PoseidonGate: swap wire is not boolean"};
+    if (swap > 1) {
+        r.fail("PoseidonGate: swap wire is not boolean");
+        return;
+    }
     u64 st[12];
     for (int i = 0; i < 4; ++i) {
         const u64 lhs = r.get(i), rhs = r.get(i + 4);
@@ -228,6 +234,7 @@ struct PlainRow {
     u64* w;
     u64 get(unsigned i) const { return w[i]; }
     void set(unsigned i, u64 v) { w[i] = v; }
+    void fail(const char* m) { throw GenError{m}; }
 };
 
 // ---- the copy-constraint partition (plonk/copy_constraint.rs + permutation_argument.rs Forest) ----
@@ -306,6 +313,40 @@ struct vpbs_witness_plan {
     std::vector<Step> schedule;
     std::vector<u32> preset_slot, preset_pos;
     std::vector<u32> out_pos, out_slot;         // every position that carries a slot, ascending (full_witness)
+
+    // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
+    // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
+    // writer earlier in the schedule (a preset, or a generator whose output is copy-constrained to this one), so the operation
+    // compares instead of writing ("set twice with different values") -- the order is static, so no per-slot flag is needed at run time.
+    static constexpr u32 CHECK = 0x80000000u;
+    struct ArithOp {
+        u32 x, y, z, out;
+        u64 c0, c1;
+    };
+    struct ConstOp {
+        u32 out, pad;
+        u64 value;
+    };
+    struct BitsOp {                             // out[k] = (in >> (k * bits)) & mask, k < n_out; the rest must be zero
+        u32 in, out_at, n_out, bits;            // BaseSumGate<2> generator, WireSplitGenerator
+    };
+    struct MiscOp {                             // gadget generators that are not bit splits
+        u32 kind, p0, at, n_in, n_out, pad;
+    };
+    struct DeviceSchedule {
+        bool supported = false;
+        std::string unsupported;                // why not (a gate or generator kind without a device form)
+        u32 n_levels = 0;
+        std::vector<ArithOp> arith;
+        std::vector<ConstOp> consts;            // no inputs: written before level 1
+        std::vector<BitsOp> bits;
+        std::vector<u32> poseidon;              // offsets into row_slots (135 slots per PoseidonGate row)
+        std::vector<MiscOp> misc;
+        std::vector<u32> arith_off, bits_off, poseidon_off, misc_off;   // [n_levels + 2]: operations of level L = [off[L], off[L + 1])
+        std::vector<u32> aux;                   // slot lists of BitsOp outputs and MiscOp inputs / outputs
+        std::vector<u32> row_slots;             // copy of row_slots with CHECK marks on outputs that compare
+        std::vector<u32> preset_slot;           // with CHECK marks (a target preset twice)
+    } dev;
 };
 
 namespace vpbs {
@@ -323,8 +364,13 @@ void report(char* err, size_t err_len, const std::string& m) {
 struct FlagRow {
     std::vector<uint8_t>& ready;
     const u32* rs;
+    std::vector<u32>& written;  // the slots this generator sets, in order
     u64 get(unsigned) { return 1; }
-    void set(unsigned w, u64) { ready[rs[w]] = 1; }
+    void set(unsigned w, u64) {
+        ready[rs[w]] = 1;
+        written.push_back(rs[w]);
+    }
+    void fail(const char* m) { throw GenError{m}; }
 };
 
 struct SlotState {
@@ -348,7 +394,142 @@ struct SlotRow {
     u32 row;
     u64 get(unsigned w) { return s.val[rs[w]]; }
     void set(unsigned w, u64 v) { s.set(rs[w], v, (u32)(w * s.n + row)); }
+    void fail(const char* m) { throw GenError{m}; }
 };
+
+// Levels and typed operation lists for the device (see vpbs_witness_plan::DeviceSchedule).  step_out: the slots every step of the
+// schedule writes, in the order the generator sets them.
+void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_out, const std::vector<u32>& step_out_off) {
+    using Plan = vpbs_witness_plan;
+    Plan::DeviceSchedule& d = p.dev;
+    constexpr u32 CHECK = Plan::CHECK, UNSET = 0xFFFFFFFFu;
+    if (p.n_slots >= CHECK) {
+        d.unsupported = "too many value slots";
+        return;
+    }
+    std::vector<u32> level(p.n_slots, UNSET);  // the level at which a slot gets its value
+    d.preset_slot = p.preset_slot;
+    for (u32& s : d.preset_slot) {
+        if (level[s] != UNSET) s |= CHECK;
+        else level[s] = 0;
+    }
+    d.row_slots = p.row_slots;
+    const unsigned mc = std::max(1u, p.max_consts);
+    struct Tagged {
+        u32 level, kind, index;
+    };
+    std::vector<Plan::ArithOp> arith;
+    std::vector<Plan::BitsOp> bits;
+    std::vector<u32> poseidon;
+    std::vector<Plan::MiscOp> misc;
+    std::vector<u32> l_arith, l_bits, l_pos, l_misc;
+    std::vector<unsigned> deps;
+    u32 max_level = 0;
+    for (size_t i = 0; i < p.schedule.size(); ++i) {
+        const auto& st = p.schedule[i];
+        const u32* outs = step_out.data() + step_out_off[i];
+        const u32 n_outs = step_out_off[i + 1] - step_out_off[i];
+        u32 lvl = 1;
+        auto need = [&](u32 slot) {
+            if (level[slot] != UNSET) lvl = std::max(lvl, level[slot] + 1);
+        };
+        // an output that already has a writer is compared, after that writer
+        auto mark = [&](u32 slot) -> u32 {
+            if (level[slot] != UNSET) return slot | CHECK;
+            level[slot] = lvl;
+            return slot;
+        };
+        if (st.row == NO_ROW) {
+            const auto& gg = p.gadgets[st.sub];
+            const u32* gs = p.gadget_slots.data() + gg.at;
+            for (unsigned k = 0; k < gg.n_in; ++k) need(gs[k]);
+            for (unsigned k = 0; k < gg.n_out; ++k) need(gs[gg.n_in + k]);
+            if (gg.kind == VPBS_GEN_WIRE_SPLIT) {
+                Plan::BitsOp op{gs[0], (u32)d.aux.size(), gg.n_out, gg.p0};
+                for (unsigned k = 0; k < gg.n_out; ++k) d.aux.push_back(mark(gs[gg.n_in + k]));
+                bits.push_back(op);
+                l_bits.push_back(lvl);
+            } else {
+                Plan::MiscOp op{gg.kind, gg.p0, (u32)d.aux.size(), gg.n_in, gg.n_out, 0};
+                for (unsigned k = 0; k < gg.n_in; ++k) d.aux.push_back(gs[k]);
+                for (unsigned k = 0; k < gg.n_out; ++k) d.aux.push_back(mark(gs[gg.n_in + k]));
+                misc.push_back(op);
+                l_misc.push_back(lvl);
+            }
+        } else {
+            const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+            const u32 off = p.row_off[st.row];
+            const u32* rs = p.row_slots.data() + off;
+            const u64* c = p.consts.data() + (size_t)st.row * mc;
+            gen_deps(g, st.sub, deps);
+            for (unsigned w : deps) need(rs[w]);
+            for (u32 k = 0; k < n_outs; ++k) need(outs[k]);
+            switch (g.kind) {
+                case VPBS_GATE_CONSTANT:
+                    if (level[rs[st.sub]] != UNSET) {  // a constant wire that is also preset: compare at level 1
+                        misc.push_back(Plan::MiscOp{0xC0u, 0, (u32)d.aux.size(), 0, 1, 0});
+                        d.aux.push_back(rs[st.sub] | CHECK);
+                        d.aux.push_back((u32)c[st.sub]);
+                        d.aux.push_back((u32)(c[st.sub] >> 32));
+                        l_misc.push_back(lvl);
+                    } else {
+                        level[rs[st.sub]] = 0;
+                        d.consts.push_back(Plan::ConstOp{rs[st.sub], 0, c[st.sub]});
+                    }
+                    break;
+                case VPBS_GATE_ARITHMETIC:
+                    arith.push_back(Plan::ArithOp{rs[4 * st.sub], rs[4 * st.sub + 1], rs[4 * st.sub + 2], mark(rs[4 * st.sub + 3]), c[0], c[1]});
+                    l_arith.push_back(lvl);
+                    break;
+                case VPBS_GATE_BASE_SUM: {
+                    if (g.p1 != 2) {
+                        d.unsupported = "BaseSumGate with a base other than 2";
+                        return;
+                    }
+                    Plan::BitsOp op{rs[0], (u32)d.aux.size(), g.p0, 1};
+                    for (unsigned k = 0; k < g.p0; ++k) d.aux.push_back(mark(rs[1 + k]));
+                    bits.push_back(op);
+                    l_bits.push_back(lvl);
+                    break;
+                }
+                case VPBS_GATE_POSEIDON: {
+                    for (u32 k = 0; k < n_outs; ++k) {   // outputs in generator order; mark the ones that compare in the row's slot table
+                        const u32 m = mark(outs[k]);
+                        if (m & CHECK)
+                            for (unsigned w = 0; w < g.num_wires; ++w)
+                                if (p.row_slots[off + w] == outs[k] && !(w < 12 || w == 24)) d.row_slots[off + w] = m;
+                    }
+                    poseidon.push_back(off);
+                    l_pos.push_back(lvl);
+                    break;
+                }
+                default: {
+                    char id[128] = "gate";
+                    (void)vpbs_gate_id(&g, id, sizeof id);
+                    id[40] = 0;
+                    d.unsupported = std::string("no device generator for ") + id;
+                    return;
+                }
+            }
+        }
+        max_level = std::max(max_level, lvl);
+    }
+    d.n_levels = max_level;
+    // counting sort of every kind by level
+    auto by_level = [&](auto& ops, const std::vector<u32>& lv, auto& sorted, std::vector<u32>& off) {
+        off.assign(max_level + 2, 0);
+        for (u32 l : lv) ++off[l + 1];
+        for (u32 l = 0; l <= max_level; ++l) off[l + 1] += off[l];
+        sorted.resize(ops.size());
+        std::vector<u32> at(off.begin(), off.end() - 1);
+        for (size_t i = 0; i < ops.size(); ++i) sorted[at[lv[i]]++] = ops[i];
+    };
+    by_level(arith, l_arith, d.arith, d.arith_off);
+    by_level(bits, l_bits, d.bits, d.bits_off);
+    by_level(poseidon, l_pos, d.poseidon, d.poseidon_off);
+    by_level(misc, l_misc, d.misc, d.misc_off);
+    d.supported = true;
+}
 
 int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, vpbs_witness_plan** out, std::string& err) {
     auto fail = [&](const std::string& m) {
@@ -422,6 +603,7 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
         for (unsigned sub = 0; sub < gen_count(p.gates[p.row_gate[r]]); ++sub) pending.push_back({(u32)r, sub});
     for (size_t i = 0; i < p.gadgets.size(); ++i) pending.push_back({NO_ROW, (u32)i});
     std::vector<unsigned> deps;
+    std::vector<u32> step_out, step_out_off{0};  // the slots every scheduled step writes (old numbering; renumbered below)
     while (!pending.empty()) {
         later.clear();
         for (const auto& st : pending) {
@@ -430,7 +612,10 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
                 const auto& gg = p.gadgets[st.sub];
                 for (unsigned k = 0; k < gg.n_in && ok; ++k) ok = ready[p.gadget_slots[gg.at + k]];
                 if (ok)
-                    for (unsigned k = 0; k < gg.n_out; ++k) ready[p.gadget_slots[gg.at + gg.n_in + k]] = 1;
+                    for (unsigned k = 0; k < gg.n_out; ++k) {
+                        ready[p.gadget_slots[gg.at + gg.n_in + k]] = 1;
+                        step_out.push_back(p.gadget_slots[gg.at + gg.n_in + k]);
+                    }
             } else {
                 const vpbs_gate& g = p.gates[p.row_gate[st.row]];
                 const u32* rs = p.row_slots.data() + p.row_off[st.row];
@@ -441,7 +626,7 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
                         break;
                     }
                 if (ok) {
-                    FlagRow fr{ready, rs};
+                    FlagRow fr{ready, rs, step_out};
                     try {
                         gen_run(g, st.sub, p.consts.data() + (size_t)st.row * std::max(1u, max_consts), fr);
                     } catch (const GenError& e) {
@@ -449,8 +634,12 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
                     }
                 }
             }
-            if (ok) p.schedule.push_back(st);
-            else later.push_back(st);
+            if (ok) {
+                p.schedule.push_back(st);
+                step_out_off.push_back((u32)step_out.size());
+            } else {
+                later.push_back(st);
+            }
         }
         if (later.size() == pending.size())  // generate_partial_witness: assert_eq!(remaining_generators, 0, "{} generators weren't run")
             return fail(std::to_string(later.size()) + " generators weren't run (first: " +
@@ -478,9 +667,10 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
             }
         }
         for (u32 s = 0; s < n_slots; ++s) visit(s);
-        for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot})
+        for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot, &step_out})
             for (u32& s : *v) s = renum[s];
     }
+    build_device_schedule(p, step_out, step_out_off);
     *out = plan.release();
     return VPBS_OK;
 }
@@ -740,6 +930,342 @@ int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint6
     }
     if (err && err_len) err[0] = 0;
     return 1;
+}
+
+}  // extern "C"
+
+// ---- device witness generation: one circuit, a batch of PartialWitnesses -----------------------------------------------------------
+// The n + 2 step witnesses of a PBS are independent once the accumulator chain is known (vpbs_pbs_accumulator_chain), and they share
+// one circuit: the plan's level schedule is replayed for all of them at once.  Values live in HBM as val[slot][batch] (instances
+// innermost: every access of an operation is one coalesced run over the batch); an operation is a thread per instance.  The
+// sequential spine of the step circuit is its hash chain (2 049 + 514 PoseidonGate rows, one level each), so a run is ~2 600 levels
+// of small launches -- latency-bound, amortised over the batch; the wires of one instance are then gathered straight into the
+// [n_wires][n] matrix vpbs_prove_step takes as a device input: they never cross PCIe.
+namespace vpbs {
+namespace {
+using Plan = vpbs_witness_plan;
+constexpr unsigned WT = 256;
+enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8 };
+
+struct Vals {
+    u64* v;
+    unsigned* err;
+    u32 batch, b;
+    __device__ u64 get(u32 slot) const { return v[(size_t)(slot & ~Plan::CHECK) * batch + b]; }
+    __device__ void set(u32 slot, u64 x) const {
+        if (x >= gl::P) x -= gl::P;
+        u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
+        if (slot & Plan::CHECK) {
+            if (*p != x) atomicOr(err, DE_SET_TWICE);
+        } else {
+            *p = x;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_preset * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    a.set(slots[gid / batch], values[gid]);
+}
+
+__global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    a.set(ops[gid / batch].out, ops[gid / batch].value);
+}
+
+__global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::ArithOp op = ops[gid / batch];
+    a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
+}
+
+__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::BitsOp op = ops[gid / batch];
+    u64 x = a.get(op.in);
+    const u64 mask = ((u64)1 << op.bits) - 1;
+    for (u32 k = 0; k < op.n_out; ++k) {
+        a.set(aux[op.out_at + k], x & mask);
+        x >>= op.bits;
+    }
+    if (x != 0) atomicOr(err, DE_TOO_LARGE);
+}
+
+struct DevRow {
+    Vals a;
+    const u32* rs;
+    __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
+    __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
+    __device__ void fail(const char*) const { atomicOr(a.err, DE_NOT_BOOLEAN); }
+};
+
+__global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + rows[gid / batch]};
+    poseidon_generate(r);
+}
+
+__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::MiscOp op = ops[gid / batch];
+    const u32 *in = aux + op.at, *out = in + op.n_in;
+    switch (op.kind) {
+        case VPBS_GEN_EQUALITY: {
+            const u64 x = a.get(in[0]), y = a.get(in[1]);
+            a.set(out[0], x == y ? 1 : 0);
+            a.set(out[1], x == y ? 0 : gl::inv(gl::sub(x, y)));
+            break;
+        }
+        case VPBS_GEN_BASE_SUM: {
+            u64 sum = 0;
+            for (u32 k = op.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, op.p0), a.get(in[k]));
+            a.set(out[0], sum);
+            break;
+        }
+        case VPBS_GEN_QUOTIENT_EXT: {
+            const A num{a.get(in[0]), a.get(in[1])}, den{a.get(in[2]), a.get(in[3])};
+            if (den.a == 0 && den.b == 0) {
+                atomicOr(err, DE_DIV_ZERO);
+                break;
+            }
+            const u64 norm = gl::sub(gl::mul(den.a, den.a), gl::mul(7, gl::mul(den.b, den.b)));
+            const A q = gates::scale(num * A{den.a, gl::neg(den.b)}, gl::inv(norm));
+            a.set(out[0], q.a);
+            a.set(out[1], q.b);
+            break;
+        }
+        case VPBS_GEN_COPY: a.set(out[0], a.get(in[0])); break;
+        case VPBS_GEN_LOW_HIGH: {
+            const u64 x = a.get(in[0]);
+            a.set(out[0], x & (((u64)1 << op.p0) - 1));
+            a.set(out[1], x >> op.p0);
+            break;
+        }
+        case 0xC0u: a.set(out[0], (u64)out[1] | ((u64)out[2] << 32)); break;  // a ConstantGate wire that is also set elsewhere
+        default: break;
+    }
+}
+
+// wires[pos] = val[slot][b] for every position that carries a slot (the matrix is zeroed first)
+__global__ void __launch_bounds__(WT) wd_gather_kernel(const u64* v, const u32* pos, const u32* slot, size_t count, u32 batch, u32 b, u64* wires) {
+    const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (i < count) wires[pos[i]] = v[(size_t)slot[i] * batch + b];
+}
+
+__global__ void __launch_bounds__(WT) wd_read_kernel(const u64* v, const u32* slots, u32 count, u32 batch, u32 b, u64* out) {
+    const u32 i = blockIdx.x * WT + threadIdx.x;
+    if (i < count) out[i] = v[(size_t)slots[i] * batch + b];
+}
+
+template <class T> T* upload(vpbs_ctx* c, const std::vector<T>& h, std::vector<void*>& owned) {
+    if (h.empty()) return nullptr;
+    void* d = c->alloc_bytes(h.size() * sizeof(T));
+    owned.push_back(d);
+    VPBS_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return static_cast<T*>(d);
+}
+}  // namespace
+}  // namespace vpbs
+
+struct vpbs_witness_device {
+    vpbs_ctx* ctx = nullptr;
+    const vpbs_witness_plan* plan = nullptr;
+    unsigned max_batch = 0, batch = 0;
+    std::vector<void*> owned;
+    vpbs::u64* val = nullptr;
+    unsigned* err = nullptr;
+    const vpbs_witness_plan::ArithOp* arith = nullptr;
+    const vpbs_witness_plan::ConstOp* consts = nullptr;
+    const vpbs_witness_plan::BitsOp* bits = nullptr;
+    const vpbs_witness_plan::MiscOp* misc = nullptr;
+    const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
+    hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
+    unsigned graph_batch = 0;
+};
+
+namespace vpbs {
+namespace {
+void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
+    const Plan::DeviceSchedule& ds = d->plan->dev;
+    auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
+    if (!ds.consts.empty())
+        hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
+    for (u32 l = 1; l <= ds.n_levels; ++l) {
+        if (const u32 k = ds.arith_off[l + 1] - ds.arith_off[l])
+            hipLaunchKernelGGL(wd_arith_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->arith + ds.arith_off[l], k, batch);
+        if (const u32 k = ds.bits_off[l + 1] - ds.bits_off[l])
+            hipLaunchKernelGGL(wd_bits_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->bits + ds.bits_off[l], d->aux, k, batch);
+        if (const u32 k = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
+            hipLaunchKernelGGL(wd_poseidon_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l], d->row_slots, k,
+                               batch);
+        if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
+            hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
+    }
+}
+}  // namespace
+}  // namespace vpbs
+
+extern "C" {
+
+int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
+    if (!ctx || !plan || !out || max_batch == 0) return VPBS_ERR_INVALID;
+    try {
+        VPBS_HIP(hipSetDevice(ctx->device));
+        VPBS_REQUIRE(plan->dev.supported, ("this circuit has no device witness generator: " + plan->dev.unsupported).c_str());
+        auto d = std::make_unique<vpbs_witness_device>();
+        d->ctx = ctx;
+        d->plan = plan;
+        d->max_batch = max_batch;
+        const auto& ds = plan->dev;
+        using namespace vpbs;
+        d->arith = upload(ctx, ds.arith, d->owned);
+        d->consts = upload(ctx, ds.consts, d->owned);
+        d->bits = upload(ctx, ds.bits, d->owned);
+        d->misc = upload(ctx, ds.misc, d->owned);
+        d->poseidon = upload(ctx, ds.poseidon, d->owned);
+        d->aux = upload(ctx, ds.aux, d->owned);
+        d->row_slots = upload(ctx, ds.row_slots, d->owned);
+        d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
+        d->out_pos = upload(ctx, plan->out_pos, d->owned);
+        d->out_slot = upload(ctx, plan->out_slot, d->owned);
+        d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
+        d->owned.push_back(d->val);
+        d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
+        d->owned.push_back(d->err);
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        *out = d.release();
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+void vpbs_witness_device_free(vpbs_witness_device* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->graph) (void)hipGraphExecDestroy(d->graph);
+    for (void* p : d->owned) d->ctx->release(p);
+    delete d;
+}
+
+int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, unsigned batch) {
+    if (!d || batch == 0 || batch > d->max_batch || (!d->plan->preset_slot.empty() && !preset_val)) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const size_t n_preset = d->plan->preset_slot.size();
+        d->batch = batch;
+        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * d->plan->n_slots * batch, s));
+        VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
+        u64* d_vals = nullptr;
+        if (n_preset) {
+            d_vals = ctx->alloc_words(n_preset * batch);
+            VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
+                               d_vals, (u32)n_preset, batch);
+        }
+        // the level launches are a static sequence: captured once per batch size, replayed afterwards
+        if (!d->graph || d->graph_batch != batch) {
+            if (d->graph) {
+                VPBS_HIP(hipGraphExecDestroy(d->graph));
+                d->graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            launch_levels(d, s, batch);
+            VPBS_HIP(hipStreamEndCapture(s, &g));
+            const hipError_t e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            VPBS_HIP(e);
+            d->graph_batch = batch;
+        }
+        VPBS_HIP(hipGraphLaunch(d->graph, s));
+        unsigned flags = 0;
+        VPBS_HIP(hipMemcpyAsync(&flags, d->err, sizeof flags, hipMemcpyDeviceToHost, s));
+        VPBS_HIP(hipStreamSynchronize(s));
+        if (d_vals) ctx->release(d_vals);
+        if (flags) {
+            std::string m;
+            if (flags & DE_SET_TWICE) m += "a partition was set twice with different values; ";
+            if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
+            if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
+            if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
+            throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
+        }
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_t* d_wires) {
+    if (!d || !d_wires || instance >= d->batch) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        const size_t count = d->plan->out_pos.size();
+        VPBS_HIP(hipMemsetAsync(d_wires, 0, sizeof(u64) * d->plan->total, ctx->stream));
+        hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
+                           d->batch, instance, d_wires);
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const uint32_t* positions, size_t count, uint64_t* out) {
+    if (!d || instance >= d->batch || (count && (!positions || !out))) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        // positions -> slots through the plan's ascending (position, slot) list; a position without a slot reads 0
+        const auto& pos = d->plan->out_pos;
+        std::vector<u32> slots(count);
+        std::vector<size_t> missing;
+        for (size_t i = 0; i < count; ++i) {
+            const auto it = std::lower_bound(pos.begin(), pos.end(), positions[i]);
+            if (it != pos.end() && *it == positions[i]) slots[i] = d->plan->out_slot[it - pos.begin()];
+            else {
+                slots[i] = 0;
+                missing.push_back(i);
+            }
+        }
+        if (count == 0) return VPBS_OK;
+        u32* d_slots = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32) * count));
+        u64* d_out = ctx->alloc_words(count);
+        VPBS_HIP(hipMemcpyAsync(d_slots, slots.data(), sizeof(u32) * count, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d_slots, (u32)count, d->batch,
+                           instance, d_out);
+        VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(d_slots);
+        ctx->release(d_out);
+        for (size_t i : missing) out[i] = 0;
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
 }
 
 }  // extern "C"
