@@ -199,6 +199,125 @@ def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
             "setup_s": {"circuit_description_python": t_build, "sigma_and_witness_plan": t_plan}}
 
 
+def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
+    batch = int(os.environ.get("VPBS_PIPE_BATCH", batch))
+    provers = int(os.environ.get("VPBS_PIPE_PROVERS", provers))
+    """The same circuit with the witnesses generated ON THE DEVICE (vpbs_witness_device_*): `batch` PartialWitnesses per run of the level
+    schedule (two device objects on their own contexts, double-buffered), each instance gathered into a device wire matrix and proven
+    by one of `provers` prover contexts.  Nothing but the PartialWitness values (20 490 field elements per step) crosses PCIe."""
+    import queue
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import step_circuit as sc
+    from vpbs_amd import api
+    N, K, ELL, LOGB, n_lwe = 1024, 2, 4, 5, 728
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
+    b = circ.built
+    sigma = b.circuit.sigma_values()
+    targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat + [circ.counter, circ.mask] +
+               circ.bsk_hash_in + circ.lwe_hash_in)
+    plan = b.circuit.witness_plan([b.pos(t) for t in targets])
+    pi_pos = [b.pos(t) for t in b.public_inputs]
+    n_constants = b.constants.shape[0]
+    cs_values = np.concatenate([b.constants, sigma])
+    d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda(device)
+    digest = np.array([11, 22, 33, 44], np.uint64)
+    wctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(2)]
+    wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
+    pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
+    css = [c.commit_values(cs_values) for c in pctx]
+    for c in pctx:
+        c.set_gate_lanes(1 if provers > 1 else 3)
+    d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda:%d" % device) for _ in range(provers)]
+    rng = np.random.default_rng(4048)
+    base = rng.integers(0, synth.P, size=len(targets), dtype=np.uint64)
+
+    def values(batch_index):
+        v = np.repeat(base[:, None], batch, axis=1)
+        v[:2 * K * N] = rng.integers(0, synth.P, size=(2 * K * N, batch), dtype=np.uint64)          # accumulators of every instance
+        v[len(targets) - 10] = 2 + (batch_index * batch + np.arange(batch)) % n_lwe                # counters: CMUX steps
+        return np.ascontiguousarray(v)
+
+    free_obj, ready, errs, done, wit_s, primed = queue.Queue(), queue.Queue(), [], [], [], []
+    for k in range(2):
+        free_obj.put(k)
+    outstanding = [0, 0]
+    lock = threading.Lock()
+
+    def witness_thread(n_batches):
+        try:
+            for bi in range(n_batches):
+                k = free_obj.get()
+                t = time.perf_counter()
+                wdev[k].run(values(bi))
+                wit_s.append(time.perf_counter() - t)
+                if bi == 0:
+                    primed.append(time.perf_counter())       # the pipeline is primed: steady state from here
+                with lock:
+                    outstanding[k] = batch
+                for i in range(batch):
+                    ready.put((k, i))
+        except Exception as e:
+            errs.append(e)
+        for _ in range(provers):
+            ready.put(None)
+
+    def prover(j):
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                k, i = item
+                wdev[k].wires(i, d_wires[j].data_ptr())
+                pis = wdev[k].read(i, pi_pos)
+                with lock:
+                    outstanding[k] -= 1
+                    if outstanding[k] == 0:
+                        free_obj.put(k)
+                si = pctx[j].make_step_inputs(b.log_n, d_wires[j].data_ptr(), None, None, css[j], digest, pis, on_device=True,
+                                              shapes=(135, 20, 16), sigmas=int(d_sigma.data_ptr()), n_routed=N_ROUTED, n_constants=n_constants,
+                                              gates=b.gates)
+                done.append((pctx[j].prove_step(si), pis))
+        except Exception as e:
+            errs.append(e)
+
+    def run(n_batches):
+        ts = [threading.Thread(target=witness_thread, args=(n_batches,))] + [threading.Thread(target=prover, args=(j,)) for j in range(provers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run(1)                      # warm-up (graph capture, pools)
+    done.clear()
+    wit_s.clear()
+    primed.clear()
+    run(batches)
+    elapsed = time.perf_counter() - primed[0]   # the first witness batch of a chain overlaps with whatever ran before it
+    proof, pis = done[-1]
+    ok = api.verify_step(proof, css[0].cap(), [n_constants + N_ROUTED, 135, 20, 16], digest, pis, b.log_n, check_permutation=True,
+                         n_constants=n_constants, n_routed=N_ROUTED, gates=b.gates)
+    for w in wdev:
+        w.free()
+    for c, cs in zip(pctx, css):
+        cs.free()
+        c.close()
+    for c in wctx:
+        c.close()
+    plan.free()
+    if not ok:
+        raise RuntimeError("step-circuit proof (device witness) did not verify")
+    proofs = batch * batches
+    return {"step_proofs_per_s": proofs / elapsed, "ms_per_step_proof": 1e3 * elapsed / proofs, "proofs": proofs, "witness_batch": batch,
+            "device_witness_ms_per_batch": 1e3 * sum(wit_s) / max(1, len(wit_s)), "provers": provers,
+            "includes": "witness generation on the device for %d steps at a time (level schedule in a hipGraph, overlapped with the proofs of "
+                        "the previous batch; timed from the moment the first batch is ready), gather of each instance's wires in HBM, the "
+                        "step proof; the last proof is verified" % batch}
+
+
 def cpu_baseline():
     """One full step proof on the host cores with the CPU oracle (kind 'port': restated algorithm, OpenMP)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -464,6 +583,10 @@ def main():
                 out["step_circuit_pipeline"] = step_circuit_pipeline(local_rank)
             except Exception as e:   # a secondary figure must not take the headline line down with it
                 out["step_circuit_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                out["step_circuit_pipeline"]["device_witness"] = step_circuit_device_pipeline(local_rank)
+            except Exception as e:
+                out["step_circuit_pipeline"]["device_witness"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
