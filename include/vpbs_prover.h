@@ -258,6 +258,9 @@ int vpbs_witness_plan_create(const vpbs_circuit* circuit, const uint32_t* preset
 int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out /* [n_wires][n] */,
                           char* err, size_t err_len);
 void vpbs_witness_plan_free(vpbs_witness_plan* plan);
+/* out: {value slots (copy-constraint classes that carry a value), scheduled generators, dependency levels of the device schedule
+ * (0: the plan has no device form, see vpbs_witness_device_create), wire positions written by full_witness} */
+int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
 /* The same schedule on the device, for a batch of PartialWitnesses of one circuit (the n + 2 step witnesses of a PBS are independent
  * once vpbs_pbs_accumulator_chain has produced the accumulators): the plan's generators are grouped by dependency level and replayed
  * for `batch` instances at once, values in HBM as [slot][batch]; the level launches are captured in a hipGraph per batch size.  The

@@ -109,6 +109,8 @@ def test_witness_plan_replays_the_generators(small):
     positions = list(presets[0])
     assert all(list(p) == positions for p in presets)
     plan = small.built.circuit.witness_plan(positions)
+    st = plan.stats()
+    assert st["generators"] > 1000 and 0 < st["levels"] < st["generators"] and st["slots"] < st["positions"]
     expected = [small.built.circuit.generate_witness(p) for p in presets]
     for p, want, (c, x) in zip(presets, expected, cases):
         for threads in (0, 1, 3):

@@ -153,6 +153,7 @@ SIGNATURES = {
     "vpbs_witness_plan_create": (_i, [C.POINTER(CircuitC), U32P, _sz, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
     "vpbs_witness_plan_run": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_free": (None, [C.c_void_p]),
+    "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "vpbs_witness_device_run": (_i, [C.c_void_p, U64P, C.c_uint]),
     "vpbs_witness_device_wires": (_i, [C.c_void_p, C.c_uint, C.c_void_p]),
@@ -407,6 +408,13 @@ class WitnessPlan:
         if rc:
             raise VpbsError("vpbs_witness_plan_run: " + err.value.decode())
         return out
+
+    def stats(self):
+        """-> dict(slots, generators, levels, positions)"""
+        out = np.zeros(4, np.uint64)
+        if lib().vpbs_witness_plan_stats(self.h, _ptr(out)):
+            raise VpbsError("vpbs_witness_plan_stats failed")
+        return dict(zip(("slots", "generators", "levels", "positions"), (int(x) for x in out)))
 
     def free(self):
         if self.h:

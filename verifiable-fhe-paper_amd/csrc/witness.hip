@@ -858,6 +858,15 @@ int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_
 
 void vpbs_witness_plan_free(vpbs_witness_plan* plan) { delete plan; }
 
+int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]) {
+    if (!plan || !out) return VPBS_ERR_INVALID;
+    out[0] = plan->n_slots;
+    out[1] = plan->schedule.size();
+    out[2] = plan->dev.supported ? plan->dev.n_levels : 0;
+    out[3] = plan->out_pos.size();
+    return VPBS_OK;
+}
+
 int vpbs_generate_witness(const vpbs_circuit* c, const uint32_t* preset_pos, const uint64_t* preset_val, size_t n_preset,
                           uint64_t* wires_out, char* err, size_t err_len) {
     std::string msg;
@@ -938,7 +947,7 @@ int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint6
 // The n + 2 step witnesses of a PBS are independent once the accumulator chain is known (vpbs_pbs_accumulator_chain), and they share
 // one circuit: the plan's level schedule is replayed for all of them at once.  Values live in HBM as val[slot][batch] (instances
 // innermost: every access of an operation is one coalesced run over the batch); an operation is a thread per instance.  The
-// sequential spine of the step circuit is its hash chain (2 049 + 514 PoseidonGate rows, one level each), so a run is ~2 600 levels
+// sequential spine of the step circuit is its bootstrapping-key hash chain (2 049 PoseidonGate rows, one level each), so a run is ~2 050 levels
 // of small launches -- latency-bound, amortised over the batch; the wires of one instance are then gathered straight into the
 // [n_wires][n] matrix vpbs_prove_step takes as a device input: they never cross PCIe.
 namespace vpbs {
