@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""One whole verifiable PBS at the paper's parameters on one MI355X, measured end to end instead of extrapolated from the step rate:
+n + 2 = 730 chained steps of the reference's step circuit WITHOUT its recursive verifier (tests/step_circuit.py; the hand-over of
+accumulator, counter and hash chains between steps is done by this driver, which is what the in-circuit verifier enforces in the
+reference).  Pipeline: native accumulator chain on the device (vpbs_pbs_accumulator_chain) and native hash chains on the host -> the
+PartialWitness values of every step -> device witness generation in batches (vpbs_witness_device_*) -> gather -> step proofs on
+`provers` contexts -> every `verify_every`-th proof verified on the host.  Random bootstrapping keys (no decryption check here: the
+noise-free end-to-end PBS is tests/test_gpu_step_circuit.py at N = 8).
+usage: tools/prove_pbs.py [n_lwe=728] [batch=146] [provers=4]  ->  one JSON line"""
+import json
+import os
+import queue
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import step_circuit as sc  # noqa: E402
+import vpbs_amd  # noqa: E402
+from vpbs_amd import api, synth  # noqa: E402
+
+N, K, ELL, LOGB = 1024, 2, 4, 5
+P = api.P
+
+
+def main():
+    n_lwe = int(sys.argv[1]) if len(sys.argv) > 1 else 728
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 146
+    provers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    verify_every = 73
+    steps = n_lwe + 2
+    t_all = time.perf_counter()
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
+    b = circ.built
+    sigma = b.circuit.sigma_values()
+    targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat + [circ.counter, circ.mask] +
+               circ.bsk_hash_in + circ.lwe_hash_in)
+    plan = b.circuit.witness_plan([b.pos(t) for t in targets])
+    pi_pos = [b.pos(t) for t in b.public_inputs]
+    n_constants = b.constants.shape[0]
+    cs_values = np.concatenate([b.constants, sigma])
+    t_setup = time.perf_counter() - t_all
+
+    rng = np.random.default_rng(728)
+    f = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)
+    ggsw_len = K * ELL * K * N
+    bsk, ksk, ct = f(n_lwe, ggsw_len), f(ggsw_len), f(n_lwe + 1)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), f(1, N)])
+    main_ctx = vpbs_amd.Context(0, log_n_max=16)
+    t0 = time.perf_counter()
+    accs = main_ctx.pbs_accumulator_chain(acc_init, ct, bsk, ksk, K, ELL, LOGB)            # [steps][K][N]
+    t_chain = time.perf_counter() - t0
+    ggsws = lambda s: np.zeros(ggsw_len, np.uint64) if s == 0 else (bsk[s - 1] if s <= n_lwe else ksk)
+    masks = [int(ct[n_lwe])] + [int(v) for v in ct[:n_lwe]] + [0]
+    t0 = time.perf_counter()
+    bsk_h, lwe_h = [np.zeros(4, np.uint64)], [np.zeros(4, np.uint64)]
+    for s in range(steps):
+        bsk_h.append(api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)])))
+        lwe_h.append(api.hash_no_pad(np.concatenate([lwe_h[-1], np.array([masks[s]], np.uint64)])))
+    t_hash = time.perf_counter() - t0
+
+    def values(first, count):
+        v = np.zeros((len(targets), count), np.uint64)
+        for j in range(count):
+            s = first + j
+            acc_in = acc_init if s == 0 else accs[s - 1]
+            v[:, j] = np.concatenate([acc_init.reshape(-1), acc_in.reshape(-1), ggsws(s), np.array([s + 1, masks[s]], np.uint64), bsk_h[s], lwe_h[s]])
+        return v
+
+    wctx = [vpbs_amd.Context(0, log_n_max=16) for _ in range(2)]
+    wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
+    pctx = [vpbs_amd.Context(0, log_n_max=16) for _ in range(provers)]
+    css = [c.commit_values(cs_values) for c in pctx]
+    for c in pctx:
+        c.set_gate_lanes(1 if provers > 1 else 3)
+    d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda()
+    d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda") for _ in range(provers)]
+    digest = np.array([11, 22, 33, 44], np.uint64)
+    free_obj, ready, errs = queue.Queue(), queue.Queue(), []
+    results = [None] * steps
+    for k in range(2):
+        free_obj.put(k)
+    outstanding, lock = [0, 0], threading.Lock()
+    wit_s = []
+
+    def witness_thread():
+        try:
+            for first in range(0, steps, batch):
+                count = min(batch, steps - first)
+                vals = values(first, count)
+                k = free_obj.get()
+                t = time.perf_counter()
+                wdev[k].run(vals)
+                wit_s.append(time.perf_counter() - t)
+                with lock:
+                    outstanding[k] = count
+                for i in range(count):
+                    ready.put((k, i, first + i))
+        except Exception as e:
+            errs.append(e)
+        for _ in range(provers):
+            ready.put(None)
+
+    def prover(j):
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                k, i, s = item
+                wdev[k].wires(i, d_wires[j].data_ptr())
+                pis = wdev[k].read(i, pi_pos)
+                with lock:
+                    outstanding[k] -= 1
+                    if outstanding[k] == 0:
+                        free_obj.put(k)
+                si = pctx[j].make_step_inputs(b.log_n, d_wires[j].data_ptr(), None, None, css[j], digest, pis, on_device=True, shapes=(135, 20, 16),
+                                              sigmas=int(d_sigma.data_ptr()), n_routed=80, n_constants=n_constants, gates=b.gates)
+                results[s] = (pctx[j].prove_step(si), pis)
+        except Exception as e:
+            errs.append(e)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=witness_thread)] + [threading.Thread(target=prover, args=(j,)) for j in range(provers)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    t_prove = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    # the chain the proofs expose is the native one
+    for s in range(steps):
+        pis = results[s][1]
+        assert int(pis[K * N]) == s + 1
+        assert (pis[K * N + 1:2 * K * N + 1] == accs[s].reshape(-1)).all(), s
+        assert (pis[-8:-4] == bsk_h[s + 1]).all() and (pis[-4:] == lwe_h[s + 1]).all(), s
+    t0 = time.perf_counter()
+    checked = 0
+    for s in list(range(0, steps, verify_every)) + [steps - 1]:
+        proof, pis = results[s]
+        assert api.verify_step(proof, css[0].cap(), [n_constants + 80, 135, 20, 16], digest, pis, b.log_n, check_permutation=True,
+                               n_constants=n_constants, n_routed=80, gates=b.gates), s
+        checked += 1
+    t_verify = time.perf_counter() - t0
+    proof_bytes = sum(results[0][0][k].nbytes for k in ("caps", "openings", "fri"))
+    print(json.dumps({
+        "what": "one whole vPBS at N=1024, k=1, ELL=4, LOGB=5, n=%d: %d chained step proofs of build_step_circuit (no recursive verifier; "
+                "%d gate rows, degree 2^%d) on 1 x MI355X" % (n_lwe, steps, b.used_rows, b.log_n),
+        "step_proofs": steps, "seconds_witness_plus_proofs": t_prove, "vpbs_proofs_per_s": 1.0 / t_prove, "step_proofs_per_s": steps / t_prove,
+        "ms_per_step_proof": 1e3 * t_prove / steps, "witness_batch": batch, "provers": provers,
+        "device_witness_s_per_batch": sum(wit_s) / len(wit_s),
+        "before_the_clock": {"accumulator_chain_on_device_s": t_chain, "native_hash_chains_on_host_s": t_hash,
+                             "circuit_description_sigma_plan_s": t_setup},
+        "checks": "accumulator / counter / hash public inputs of all %d proofs equal the native chains; %d proofs verified by vpbs_verify_step "
+                  "(%.1f ms each)" % (steps, checked, 1e3 * t_verify / checked),
+        "proof_words_kB": proof_bytes / 1e3}))
+
+
+if __name__ == "__main__":
+    main()
