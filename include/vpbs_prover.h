@@ -288,7 +288,7 @@ int vpbs_check_witness(const vpbs_circuit* circuit, const uint64_t* wires /* [n_
 
 /* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
 typedef struct {
-    unsigned log_n;                   /* degree_bits: 15 for N=1024, 12 for N=8 */
+    unsigned log_n;                   /* degree_bits: 16 for N=1024, 13 for N=8 (ivc_based_vpbs.rs:54-61 pads to 2^15 / 2^12 gates BEFORE build()) */
     unsigned n_wires;                 /* 135 */
     unsigned n_zs_partial_products;   /* 20: [Z_0, Z_1, pp...] */
     unsigned n_quotient;              /* 16 */
