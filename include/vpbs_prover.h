@@ -269,7 +269,9 @@ int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
  * kind above (the step circuit's set); creation fails (VPBS_ERR_INVALID, vpbs_last_error names the gate) for a plan that needs others.
  * preset_val: host [n_preset][batch] (order of preset_pos at plan creation, instances innermost).  Value errors of any instance (a
  * class set twice with different values, an integer that does not fit, a non-boolean swap) fail the run.  The plan must outlive the
- * device object; one run at a time per object. */
+ * device object.  run / wires / read of one object are serialised internally (they share the context's stream and memory pool), so
+ * several prover threads may gather their instances from the same object; give every object its own context if its runs should
+ * overlap with other work of the same process. */
 typedef struct vpbs_witness_device vpbs_witness_device;
 int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out);
 int vpbs_witness_device_run(vpbs_witness_device* dev, const uint64_t* preset_val, unsigned batch);

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <numeric>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1101,6 +1102,7 @@ struct vpbs_witness_device {
     const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
     hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
     unsigned graph_batch = 0;
+    std::mutex mu;                    // run / wires / read share the context's stream and memory pool: one at a time per object
 };
 
 namespace vpbs {
@@ -1173,6 +1175,8 @@ void vpbs_witness_device_free(vpbs_witness_device* d) {
 int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, unsigned batch) {
     if (!d || batch == 0 || batch > d->max_batch || (!d->plan->preset_slot.empty() && !preset_val)) return VPBS_ERR_INVALID;
     vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    vpbs::u64* d_vals = nullptr;
     try {
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
@@ -1181,7 +1185,6 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         d->batch = batch;
         VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * d->plan->n_slots * batch, s));
         VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
-        u64* d_vals = nullptr;
         if (n_preset) {
             d_vals = ctx->alloc_words(n_preset * batch);
             VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
@@ -1197,9 +1200,12 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
             hipGraph_t g = nullptr;
             VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             launch_levels(d, s, batch);
-            VPBS_HIP(hipStreamEndCapture(s, &g));
-            const hipError_t e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
+            const hipError_t launched = hipGetLastError();
+            const hipError_t ended = hipStreamEndCapture(s, &g);   // always leave capture mode
+            hipError_t e = launched != hipSuccess ? launched : ended;
+            if (e == hipSuccess) e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) d->graph = nullptr;
             VPBS_HIP(e);
             d->graph_batch = batch;
         }
@@ -1208,6 +1214,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         VPBS_HIP(hipMemcpyAsync(&flags, d->err, sizeof flags, hipMemcpyDeviceToHost, s));
         VPBS_HIP(hipStreamSynchronize(s));
         if (d_vals) ctx->release(d_vals);
+        d_vals = nullptr;
         if (flags) {
             std::string m;
             if (flags & DE_SET_TWICE) m += "a partition was set twice with different values; ";
@@ -1218,14 +1225,20 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         }
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
+        if (d_vals) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->release(d_vals);
+        }
         ctx->err = e.what;
         return e.status;
     }
 }
 
 int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_t* d_wires) {
-    if (!d || !d_wires || instance >= d->batch) return VPBS_ERR_INVALID;
+    if (!d || !d_wires) return VPBS_ERR_INVALID;
     vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
     try {
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
@@ -1242,8 +1255,10 @@ int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_
 }
 
 int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const uint32_t* positions, size_t count, uint64_t* out) {
-    if (!d || instance >= d->batch || (count && (!positions || !out))) return VPBS_ERR_INVALID;
+    if (!d || (count && (!positions || !out))) return VPBS_ERR_INVALID;
     vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
     try {
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
