@@ -195,3 +195,21 @@ def test_hash_chain_matches_oracle_and_reference_semantics():
         assert ok and (got == want).all() and (h == want).all()
         bad = want.copy(); bad[0] ^= np.uint64(1)
         assert not api.hash_chain(items, claimed=bad)[1]
+
+
+def test_recorded_bench_line_keeps_the_contract():
+    """profiles/r01_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_latest.json")
+    d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"] / 730) / d["value"] < 1e-6      # vPBS proofs/s = step proofs/s / 730
