@@ -293,3 +293,32 @@ def test_random_builder_programs(seed):
     assert checked > len(pool) // 2
     plan = built.circuit.witness_plan(list(presets))
     assert (plan.run(list(presets.values())) == wires).all()
+
+
+@pytest.mark.parametrize("N", [8, 64, 1024])
+def test_in_circuit_ntt_reproduces_the_references_vectors(N):
+    """The reference's own tests of its NTT gadget (ntt/mod.rs test_ntt_forward / test_ntt_backward: TESTG <-> TESTGHAT of
+    params_{N}.rs, held in tests/golden/ntt_params_{N}.json) on the builder's restatement of that gadget, with the witness generated
+    by the product: forward(TESTG) = TESTGHAT and backward(TESTGHAT) = TESTG as public inputs, every constraint satisfied."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ntt_params_%d.json" % N)))
+    if len(gold["TESTG"]) != N:
+        pytest.skip("the fixture holds hashes only for this N")
+    if "ROOTS" in gold:
+        ring = (np.array(gold["ROOTS"], np.uint64), np.array(gold["INVROOTS"], np.uint64), int(gold["NINV"]))
+    else:                                           # large N: the fixture pins the oracle's tables by their SHA-256 (test_oracle_cpu)
+        ring = _ring(N.bit_length() - 1)
+        assert ring[2] == int(gold["NINV"])
+    cb = sc.Builder()
+    x, y = cb.virtuals(N), cb.virtuals(N)
+    cb.register_public_inputs(sc.ntt_forward(cb, x, ring[0]))
+    cb.register_public_inputs(sc.ntt_backward(cb, y, ring[1], ring[2]))
+    built = cb.build(api)
+    a = dict(zip(x, gold["TESTG"]))
+    a.update(zip(y, gold["TESTGHAT"]))
+    wires = built.circuit.generate_witness(built.presets(a))
+    pis = built.values(wires, built.public_inputs)
+    assert pis[:N] == [int(v) for v in gold["TESTGHAT"]] and pis[N:] == [int(v) for v in gold["TESTG"]]
+    ok, msg = built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+    assert ok, msg
