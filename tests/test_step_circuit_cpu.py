@@ -322,3 +322,57 @@ def test_in_circuit_ntt_reproduces_the_references_vectors(N):
     assert pis[:N] == [int(v) for v in gold["TESTGHAT"]] and pis[N:] == [int(v) for v in gold["TESTG"]]
     ok, msg = built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
     assert ok, msg
+
+
+def test_in_circuit_decompose_like_the_references_test():
+    """glwe_poly.rs test_decompose / test_vec_decompose: the LOGB = 8 digits of x recombine to x (sum of out[i] * B^i); inputs as in the
+    reference's test (2^63 + a random u32) plus edge values"""
+    import random
+    r = random.Random(5)
+    logb, limbs = 8, 8
+    xs = [(1 << 63) + r.randrange(1 << 32) for _ in range(3)] + [0, 1, P - 1, (1 << 63) - 1, 1 << 63, r.randrange(P)]
+    cb = sc.Builder()
+    targets = cb.virtuals(len(xs))
+    digits = [sc.decompose(cb, t, limbs, logb) for t in targets]
+    cb.register_public_inputs([d for ds in digits for d in ds])
+    built = cb.build(api)
+    wires = built.circuit.generate_witness(built.presets(dict(zip(targets, xs))))
+    pis = built.values(wires, built.public_inputs)
+    ok, msg = built.circuit.check_witness(wires, api.hash_no_pad(np.array(pis, np.uint64)))
+    assert ok, msg
+    for k, x in enumerate(xs):
+        out = pis[limbs * k:limbs * (k + 1)]
+        assert sum(o * pow(1 << logb, i, P) for i, o in enumerate(out)) % P == x % P
+        assert out == tf.decompose(x, logb)
+        assert all(min(o, P - o) <= (1 << (logb - 1)) for o in out)          # centred digits
+
+
+def test_in_circuit_rotation_like_the_references_test():
+    """mod.rs test_poly_rotate + check_rotation: rotate_poly by a mask element = multiplication by X^shift with shift the rounded top
+    log2(2N) bits of the mask, negacyclic (out[i + shift] = in[i], wrapped coefficients negated, shift > N: the negated polynomial)"""
+    import random
+    r = random.Random(6)
+    N = 16
+    for mask in [r.randrange(P) for _ in range(4)] + [0, P - 1, 1 << 58, (1 << 59) - 1]:
+        poly = [r.randrange(P) for _ in range(N)]
+        cb = sc.Builder()
+        pt, mt = cb.virtuals(N), cb.virtual()
+        cb.register_public_inputs(sc.rotate_poly(cb, pt, mt))
+        built = cb.build(api)
+        a = dict(zip(pt, poly))
+        a[mt] = mask
+        wires = built.circuit.generate_witness(built.presets(a))
+        out = built.values(wires, built.public_inputs)
+        assert out == tf.rotate(poly, tf.mod_switch(mask, 4))
+        shift = mask >> (64 - 4 - 2)                                          # check_rotation (mod.rs:154-183)
+        carry = shift % 2
+        shift = (shift >> 1) + carry
+        src = poly
+        if shift == 2 * N:
+            continue      # X^(2N) = 1: the reference's check_rotation would negate here (its random test hits this with probability 1/64)
+        if shift > N:
+            shift, src = shift % N, [(P - c) % P for c in poly]
+        for i in range(N - shift):
+            assert src[i] == out[i + shift]
+        for i in range(shift):
+            assert src[N - shift + i] == (P - out[i]) % P
