@@ -961,7 +961,8 @@ struct Vals {
     u64* v;
     unsigned* err;
     u32 batch, b;
-    __device__ u64 get(u32 slot) const { return v[(size_t)(slot & ~Plan::CHECK) * batch + b]; }
+    // volatile: inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line)
+    __device__ u64 get(u32 slot) const { return *(volatile const u64*)(v + (size_t)(slot & ~Plan::CHECK) * batch + b); }
     __device__ void set(u32 slot, u64 x) const {
         if (x >= gl::P) x -= gl::P;
         u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
@@ -1009,19 +1010,81 @@ __global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, cons
     if (x != 0) atomicOr(err, DE_TOO_LARGE);
 }
 
-struct DevRow {
-    Vals a;
-    const u32* rs;
-    __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
-    __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
-    __device__ void fail(const char*) const { atomicOr(a.err, DE_NOT_BOOLEAN); }
-};
+// PoseidonGate generator, 16 lanes per row and instance: lane l < 12 owns state element l (the latency form of the prover's tree
+// kernels: a row is ~13 us of dependent instructions instead of ~65 us with one lane per row -- the step circuit's witness is a chain
+// of 2 049 such rows).  Every lane of the group runs the shuffles; lanes 12..15 carry zeros.
+__device__ __forceinline__ u64 shfl64(u64 x, unsigned src_lane) {
+    const u32 lo = (u32)__shfl((int)(u32)x, (int)src_lane, 64), hi = (u32)__shfl((int)(u32)(x >> 32), (int)src_lane, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ void poseidon_generate_wide(const Vals& a, const u32* rs) {
+    const unsigned lane = threadIdx.x & 63u, l = lane & 15u, base = lane & ~15u;
+    const bool own = l < 12;
+    const unsigned lm = own ? l : 0;
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const u64 swap = a.get(rs[24]);
+    if (swap > 1) {  // the same for every lane of the group
+        if (l == 0) atomicOr(a.err, DE_NOT_BOOLEAN);
+        return;
+    }
+    u64 s = own ? a.get(rs[l]) : 0;
+    const u64 rhs = shfl64(s, base + ((l + 4) & 15u));
+    const u64 delta = l < 4 ? gl::mul(swap, gl::sub(rhs, s)) : 0;   // swap * (rhs - lhs): lanes 0..3
+    const u64 delta_lo = shfl64(delta, base + ((l + 12) & 15u));     // lanes 4..7 see the delta of lane l - 4
+    if (l < 4) {
+        a.set(rs[25 + l], delta);
+        s = gl::add(s, delta);
+    } else if (l < 8) {
+        s = gl::sub(s, delta_lo);
+    }
+    if (own) s = gl::add_nc(s, poseidon::rc((int)l));
+    for (int round = 0; round < 30; ++round) {
+        const bool full = round < 4 || round >= 26;
+        if (own) {
+            if (round >= 1 && round < 4) a.set(rs[29 + 12 * (round - 1) + l], gl::canon(s));
+            else if (round >= 26) a.set(rs[87 + 12 * (round - 26) + l], gl::canon(s));
+            else if (!full && l == 0) a.set(rs[65 + (round - 4)], gl::canon(s));
+        }
+        if (full || l == 0) s = poseidon::sbox(s);
+        u64 acc_lo = 0, acc_hi = 0;  // row lm of the MDS matrix in 32-bit halves
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            unsigned src = lm + i;
+            if (src >= 12) src -= 12;
+            const u64 x = shfl64(s, base + src);
+            acc_lo += (u64)(u32)x * C[i];
+            acc_hi += (x >> 32) * C[i];
+        }
+        if (l == 0) {  // MDS_MATRIX_DIAG[0] = 8
+            acc_lo += (u64)(u32)s * 8;
+            acc_hi += (s >> 32) * 8;
+        }
+        const u64 k = round + 1 < 30 ? poseidon::rc(12 * (round + 1) + (int)lm) : 0;
+        acc_lo += (u32)k;
+        acc_hi += k >> 32;
+        s = own ? poseidon::fold96(acc_lo, acc_hi) : 0;
+    }
+    if (own) a.set(rs[12 + l], gl::canon(s));
+}
 
 __global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + rows[gid / batch]};
-    poseidon_generate(r);
+    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
+    if (group >= (size_t)n_ops * batch) return;
+    poseidon_generate_wide(Vals{v, err, batch, (u32)(group % batch)}, row_slots + rows[group / batch]);
+}
+
+// The tail of the schedule where every level holds PoseidonGate rows only (the hash chain): instances are independent of each other,
+// so one group per instance walks the levels by itself -- one launch instead of one per level.
+__global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned* err, const u32* rows, const u32* level_off, u32 first_level,
+                                                                u32 last_level, const u32* row_slots, u32 batch) {
+    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
+    if (group >= batch) return;
+    const Vals a{v, err, batch, (u32)group};
+    for (u32 level = first_level; level <= last_level; ++level) {
+        for (u32 op = level_off[level]; op < level_off[level + 1]; ++op) poseidon_generate_wide(a, row_slots + rows[op]);
+        __threadfence_block();  // the next level reads what this one stored
+    }
 }
 
 __global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, u32 batch) {
@@ -1100,6 +1163,8 @@ struct vpbs_witness_device {
     const vpbs_witness_plan::BitsOp* bits = nullptr;
     const vpbs_witness_plan::MiscOp* misc = nullptr;
     const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
+    const vpbs::u32* poseidon_off = nullptr;
+    unsigned tail_first = 0;          // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
     hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
     unsigned graph_batch = 0;
     std::mutex mu;                    // run / wires / read share the context's stream and memory pool: one at a time per object
@@ -1112,17 +1177,21 @@ void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
     auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
     if (!ds.consts.empty())
         hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
-    for (u32 l = 1; l <= ds.n_levels; ++l) {
+    const u32 last_stepwise = d->tail_first ? d->tail_first - 1 : ds.n_levels;
+    for (u32 l = 1; l <= last_stepwise; ++l) {
         if (const u32 k = ds.arith_off[l + 1] - ds.arith_off[l])
             hipLaunchKernelGGL(wd_arith_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->arith + ds.arith_off[l], k, batch);
         if (const u32 k = ds.bits_off[l + 1] - ds.bits_off[l])
             hipLaunchKernelGGL(wd_bits_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->bits + ds.bits_off[l], d->aux, k, batch);
         if (const u32 k = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
-            hipLaunchKernelGGL(wd_poseidon_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l], d->row_slots, k,
-                               batch);
+            hipLaunchKernelGGL(wd_poseidon_kernel, blocks((size_t)k * 16, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l],
+                               d->row_slots, k, batch);
         if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
             hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
     }
+    if (d->tail_first)
+        hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((batch * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, d->poseidon, d->poseidon_off,
+                           d->tail_first, ds.n_levels, d->row_slots, batch);
 }
 }  // namespace
 }  // namespace vpbs
@@ -1150,6 +1219,12 @@ int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, uns
         d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
         d->out_pos = upload(ctx, plan->out_pos, d->owned);
         d->out_slot = upload(ctx, plan->out_slot, d->owned);
+        d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
+        {
+            u32 l = ds.n_levels;
+            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l]) --l;
+            d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
+        }
         d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
         d->owned.push_back(d->val);
         d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
