@@ -263,7 +263,8 @@ void vpbs_witness_plan_free(vpbs_witness_plan* plan);
 int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
 /* The same schedule on the device, for a batch of PartialWitnesses of one circuit (the n + 2 step witnesses of a PBS are independent
  * once vpbs_pbs_accumulator_chain has produced the accumulators): the plan's generators are grouped by dependency level and replayed
- * for `batch` instances at once, values in HBM as [slot][batch]; the level launches are captured in a hipGraph per batch size.  The
+ * for `batch` instances at once, values in HBM as [slot][batch]; the level launches are captured in a hipGraph per batch size (the
+ * Poseidon-only tail of the schedule is one launch; ~60 ms per run for the step circuit at the paper's parameters, any batch up to 730).  The
  * wires of an instance are then gathered into a device [n_wires][n] matrix that vpbs_prove_step takes with inputs_on_device = 1 --
  * they never cross PCIe.  Supported generators: ConstantGate, ArithmeticGate, BaseSumGate<2>, PoseidonGate and every gadget generator
  * kind above (the step circuit's set); creation fails (VPBS_ERR_INVALID, vpbs_last_error names the gate) for a plan that needs others.
