@@ -266,8 +266,8 @@ int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
  * for `batch` instances at once, values in HBM as [slot][batch]; the level launches are captured in a hipGraph per batch size (the
  * Poseidon-only tail of the schedule is one launch; ~60 ms per run for the step circuit at the paper's parameters, any batch up to 730).  The
  * wires of an instance are then gathered into a device [n_wires][n] matrix that vpbs_prove_step takes with inputs_on_device = 1 --
- * they never cross PCIe.  Supported generators: ConstantGate, ArithmeticGate, BaseSumGate<2>, PoseidonGate and every gadget generator
- * kind above (the step circuit's set); creation fails (VPBS_ERR_INVALID, vpbs_last_error names the gate) for a plan that needs others.
+ * they never cross PCIe.  Every supported gate and gadget generator has a device form (ArithmeticGate operations, bit splits and
+ * PoseidonGate rows -- the step circuit's bulk -- have dedicated kernels, the rest run the host's generator code per row).
  * preset_val: host [n_preset][batch] (order of preset_pos at plan creation, instances innermost).  Value errors of any instance (a
  * class set twice with different values, an integer that does not fit, a non-boolean swap) fail the run.  The plan must outlive the
  * device object.  run / wires / read of one object are serialised internally (they share the context's stream and memory pool), so

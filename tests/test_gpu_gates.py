@@ -365,3 +365,55 @@ def test_gate_lanes_setting_does_not_change_the_proof(ctx):
     with pytest.raises(api.VpbsError):
         ctx.set_gate_lanes(2)
     cs.free()
+
+
+def test_device_witness_for_every_gate_type(ctx):
+    """vpbs_witness_device_* on the demo circuit with rows of all 14 gate types (in-circuit public-input hash, Poseidon and arithmetic
+    chains through copy constraints, interpolation / random-access / exponentiation / reducing rows): two instances with different
+    PartialWitnesses in one batch, each identical to the host plan's witness and satisfying every constraint."""
+    import torch
+    import test_gates_cpu as tg
+    log_n = 7
+    n = 1 << log_n
+    gs, ps = go.GateSet(ALL), api.GateSet(ALL)
+    columns, witnesses, circ, positions = [], [], None, None
+    for seed in (404, 405):
+        r = random.Random(404)                      # the same circuit ...
+        pis = [random.Random(seed).randrange(P) for _ in range(4)]   # ... proving other public inputs
+        constants, wires, _, pi_hash, desc = go.demo_circuit(r, gs, log_n, pis, describe=True)
+        if circ is None:
+            circ = api.Circuit(ps, log_n, desc["row_gate"], constants, desc["copies"])
+            base_constants = constants
+        assert (constants == base_constants).all() and (desc["row_gate"] == circ.row_gate).all()   # same circuit, other values
+        generated = set()
+        for row in range(n):
+            generated |= {(w, row) for w in tg._owned_wires(gs.gates[int(desc["row_gate"][row])])}
+        fed = set()
+        for cl in desc["classes"]:
+            if any(tuple(x) in generated for x in cl):
+                fed |= {tuple(x) for x in cl}
+        presets = {}
+        for row in range(n):
+            g = gs.gates[int(desc["row_gate"][row])]
+            if g.kind != "public_input":
+                presets.update({(w, row): int(wires[w, row]) for w in tg._free_inputs(g) if (w, row) not in fed})
+        if positions is None:
+            positions = list(presets)
+        assert list(presets) == positions
+        columns.append([presets[p] for p in positions])
+        witnesses.append((wires, pi_hash))
+    plan = circ.witness_plan(positions)
+    st = plan.stats()
+    assert st["levels"] > 0
+    dev = api.WitnessDevice(ctx, plan, max_batch=2)
+    dev.run(np.ascontiguousarray(np.array(columns, dtype=np.uint64).T))
+    d_w = torch.zeros((135, n), dtype=torch.int64, device="cuda")
+    for i in range(2):
+        dev.wires(i, d_w.data_ptr())
+        got = d_w.cpu().numpy().view(np.uint64)
+        want = plan.run(columns[i])
+        assert (got == want).all(), np.argwhere(got != want)[:5]
+        ok, msg = circ.check_witness(got, witnesses[i][1])
+        assert ok, msg
+    assert not (np.array(columns[0]) == np.array(columns[1])).all()
+    dev.free(); plan.free()

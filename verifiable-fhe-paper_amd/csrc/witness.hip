@@ -80,8 +80,8 @@ void gen_deps(const vpbs_gate& g, unsigned sub, std::vector<unsigned>& d) {
 }
 
 // R: get(wire) -> u64, set(wire, value)
-template <class R> A ralg(R& r, unsigned i) { return A{r.get(i), r.get(i + 1)}; }
-template <class R> void walg(R& r, unsigned i, A x) {
+template <class R> GL_HD A ralg(R& r, unsigned i) { return A{r.get(i), r.get(i + 1)}; }
+template <class R> GL_HD void walg(R& r, unsigned i, A x) {
     r.set(i, x.a);
     r.set(i + 1, x.b);
 }
@@ -123,7 +123,8 @@ template <class R> GL_HD void poseidon_generate(R& r) {
     for (int i = 0; i < 12; ++i) r.set(12 + i, gl::canon(st[i]));
 }
 
-template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, R& r) {
+// host and device; `t`: the interpolation tables of a CosetInterpolationGate (gates::coset_tables(g.p0)), unused otherwise
+template <class R> GL_HD void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, R& r, const gates::CosetTables* t = nullptr) {
     switch (g.kind) {
         case VPBS_GATE_CONSTANT: r.set(sub, c[sub]); break;
         case VPBS_GATE_ARITHMETIC:
@@ -139,7 +140,7 @@ template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, 
                     x /= g.p1;
                 }
             }
-            if (x != 0) throw GenError{"BaseSumGate: integer too large to fit in the given number of limbs"};
+            if (x != 0) r.fail("BaseSumGate: integer too large to fit in the given number of limbs");
             break;
         }
         case VPBS_GATE_POSEIDON: poseidon_generate(r); break;
@@ -181,7 +182,10 @@ template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, 
             }
             const unsigned base = (2 + vec) * sub;
             const u64 idx = r.get(base);
-            if (idx >= vec) throw GenError{"RandomAccessGate: access index out of range"};
+            if (idx >= vec) {
+                r.fail("RandomAccessGate: access index out of range");
+                break;
+            }
             r.set(base + 1, r.get(base + 2 + (unsigned)idx));
             for (unsigned b = 0; b < bits; ++b) r.set(routed + sub * bits + b, (idx >> b) & 1);
             break;
@@ -193,7 +197,10 @@ template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, 
             for (unsigned i = 0; i < n; ++i) {
                 const u64 sq = i == 0 ? 1 : gl::mul(prev, prev);
                 const u64 bit = r.get(1 + (n - 1 - i));
-                if (bit > 1) throw GenError{"ExponentiationGate: power bit is not boolean"};
+                if (bit > 1) {
+                    r.fail("ExponentiationGate: power bit is not boolean");
+                    return;
+                }
                 prev = bit ? gl::mul(sq, base) : sq;
                 r.set(2 + n + i, prev);
             }
@@ -205,30 +212,36 @@ template <class R> void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, 
             const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
             const unsigned start_shifted = start_inter + 4 * ni;
             const u64 shift = r.get(0);
-            if (shift == 0) throw GenError{"CosetInterpolationGate: zero shift"};
-            const gates::CosetTables t = gates::coset_tables(g.p0);
+            if (shift == 0 || !t) {
+                r.fail("CosetInterpolationGate: zero shift");
+                break;
+            }
             const A shifted = gates::scale(ralg(r, start_point), gl::inv(shift));
             walg(r, start_shifted, shifted);
             A eval{0, 0}, prod{1, 0};
             auto run = [&](unsigned from, unsigned to) {
                 for (unsigned i = from; i < to; ++i) {
-                    const A term = gates::sub_base(shifted, t.domain[i]);
-                    eval = eval * term + gates::scalec(ralg(r, 1 + 2 * i), t.weights[i]) * prod;
+                    const A term = gates::sub_base(shifted, t->domain[i]);
+                    eval = eval * term + gates::scalec(ralg(r, 1 + 2 * i), t->weights[i]) * prod;
                     prod = prod * term;
                 }
             };
-            run(0, std::min(degree, points));
+            run(0, degree < points ? degree : points);
             for (unsigned i = 0; i < ni; ++i) {
                 walg(r, start_inter + 2 * i, eval);
                 walg(r, start_inter + 2 * (ni + i), prod);
                 const unsigned from = 1 + (degree - 1) * (i + 1);
-                run(from, std::min(from + degree - 1, points));
+                run(from, from + degree - 1 < points ? from + degree - 1 : points);
             }
             walg(r, start_value, eval);
             break;
         }
         default: break;
     }
+}
+
+inline const gates::CosetTables* tables_of(const vpbs_gate& g) {
+    return g.kind == VPBS_GATE_COSET_INTERPOLATION ? &gates::coset_tables(g.p0) : nullptr;
 }
 
 struct PlainRow {
@@ -334,6 +347,9 @@ struct vpbs_witness_plan {
     struct MiscOp {                             // gadget generators that are not bit splits
         u32 kind, p0, at, n_in, n_out, pad;
     };
+    struct RowOp {                              // any other gate generator: gen_run on the row's slot table
+        u32 row, sub;
+    };
     struct DeviceSchedule {
         bool supported = false;
         std::string unsupported;                // why not (a gate or generator kind without a device form)
@@ -343,7 +359,8 @@ struct vpbs_witness_plan {
         std::vector<BitsOp> bits;
         std::vector<u32> poseidon;              // offsets into row_slots (135 slots per PoseidonGate row)
         std::vector<MiscOp> misc;
-        std::vector<u32> arith_off, bits_off, poseidon_off, misc_off;   // [n_levels + 2]: operations of level L = [off[L], off[L + 1])
+        std::vector<RowOp> rowops;
+        std::vector<u32> arith_off, bits_off, poseidon_off, misc_off, rowops_off;   // [n_levels + 2]: operations of level L = [off[L], off[L + 1])
         std::vector<u32> aux;                   // slot lists of BitsOp outputs and MiscOp inputs / outputs
         std::vector<u32> row_slots;             // copy of row_slots with CHECK marks on outputs that compare
         std::vector<u32> preset_slot;           // with CHECK marks (a target preset twice)
@@ -365,11 +382,13 @@ void report(char* err, size_t err_len, const std::string& m) {
 struct FlagRow {
     std::vector<uint8_t>& ready;
     const u32* rs;
-    std::vector<u32>& written;  // the slots this generator sets, in order
+    std::vector<u32>& written;    // the slots this generator sets, in order
+    std::vector<u32>& written_w;  // ... and their wire indices
     u64 get(unsigned) { return 1; }
     void set(unsigned w, u64) {
         ready[rs[w]] = 1;
         written.push_back(rs[w]);
+        written_w.push_back(w);
     }
     void fail(const char* m) { throw GenError{m}; }
 };
@@ -400,7 +419,8 @@ struct SlotRow {
 
 // Levels and typed operation lists for the device (see vpbs_witness_plan::DeviceSchedule).  step_out: the slots every step of the
 // schedule writes, in the order the generator sets them.
-void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_out, const std::vector<u32>& step_out_off) {
+void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_out, const std::vector<u32>& step_out_w,
+                           const std::vector<u32>& step_out_off) {
     using Plan = vpbs_witness_plan;
     Plan::DeviceSchedule& d = p.dev;
     constexpr u32 CHECK = Plan::CHECK, UNSET = 0xFFFFFFFFu;
@@ -423,7 +443,8 @@ void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_ou
     std::vector<Plan::BitsOp> bits;
     std::vector<u32> poseidon;
     std::vector<Plan::MiscOp> misc;
-    std::vector<u32> l_arith, l_bits, l_pos, l_misc;
+    std::vector<Plan::RowOp> rowops;
+    std::vector<u32> l_arith, l_bits, l_pos, l_misc, l_row;
     std::vector<unsigned> deps;
     u32 max_level = 0;
     for (size_t i = 0; i < p.schedule.size(); ++i) {
@@ -483,9 +504,12 @@ void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_ou
                     l_arith.push_back(lvl);
                     break;
                 case VPBS_GATE_BASE_SUM: {
-                    if (g.p1 != 2) {
-                        d.unsupported = "BaseSumGate with a base other than 2";
-                        return;
+                    if (g.p1 != 2) {  // other bases: the generic row operation
+                        const u32* outs_w = step_out_w.data() + step_out_off[i];
+                        for (u32 k = 0; k < n_outs; ++k) d.row_slots[off + outs_w[k]] = mark(outs[k]);
+                        rowops.push_back(Plan::RowOp{st.row, st.sub});
+                        l_row.push_back(lvl);
+                        break;
                     }
                     Plan::BitsOp op{rs[0], (u32)d.aux.size(), g.p0, 1};
                     for (unsigned k = 0; k < g.p0; ++k) d.aux.push_back(mark(rs[1 + k]));
@@ -493,23 +517,19 @@ void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_ou
                     l_bits.push_back(lvl);
                     break;
                 }
-                case VPBS_GATE_POSEIDON: {
-                    for (u32 k = 0; k < n_outs; ++k) {   // outputs in generator order; mark the ones that compare in the row's slot table
-                        const u32 m = mark(outs[k]);
-                        if (m & CHECK)
-                            for (unsigned w = 0; w < g.num_wires; ++w)
-                                if (p.row_slots[off + w] == outs[k] && !(w < 12 || w == 24)) d.row_slots[off + w] = m;
-                    }
-                    poseidon.push_back(off);
-                    l_pos.push_back(lvl);
-                    break;
-                }
+                case VPBS_GATE_POSEIDON:
                 default: {
-                    char id[128] = "gate";
-                    (void)vpbs_gate_id(&g, id, sizeof id);
-                    id[40] = 0;
-                    d.unsupported = std::string("no device generator for ") + id;
-                    return;
+                    // the generator reads and writes through the row's slot table; outputs that compare carry the mark there
+                    const u32* outs_w = step_out_w.data() + step_out_off[i];
+                    for (u32 k = 0; k < n_outs; ++k) d.row_slots[off + outs_w[k]] = mark(outs[k]);
+                    if (g.kind == VPBS_GATE_POSEIDON) {
+                        poseidon.push_back(off);
+                        l_pos.push_back(lvl);
+                    } else {
+                        rowops.push_back(Plan::RowOp{st.row, st.sub});
+                        l_row.push_back(lvl);
+                    }
+                    break;
                 }
             }
         }
@@ -529,6 +549,7 @@ void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_ou
     by_level(bits, l_bits, d.bits, d.bits_off);
     by_level(poseidon, l_pos, d.poseidon, d.poseidon_off);
     by_level(misc, l_misc, d.misc, d.misc_off);
+    by_level(rowops, l_row, d.rowops, d.rowops_off);
     d.supported = true;
 }
 
@@ -605,6 +626,7 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
     for (size_t i = 0; i < p.gadgets.size(); ++i) pending.push_back({NO_ROW, (u32)i});
     std::vector<unsigned> deps;
     std::vector<u32> step_out, step_out_off{0};  // the slots every scheduled step writes (old numbering; renumbered below)
+    std::vector<u32> step_out_w;                 // the wire index of each (row steps; NONE for gadget outputs)
     while (!pending.empty()) {
         later.clear();
         for (const auto& st : pending) {
@@ -616,6 +638,7 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
                     for (unsigned k = 0; k < gg.n_out; ++k) {
                         ready[p.gadget_slots[gg.at + gg.n_in + k]] = 1;
                         step_out.push_back(p.gadget_slots[gg.at + gg.n_in + k]);
+                        step_out_w.push_back(NONE);
                     }
             } else {
                 const vpbs_gate& g = p.gates[p.row_gate[st.row]];
@@ -627,9 +650,9 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
                         break;
                     }
                 if (ok) {
-                    FlagRow fr{ready, rs, step_out};
+                    FlagRow fr{ready, rs, step_out, step_out_w};
                     try {
-                        gen_run(g, st.sub, p.consts.data() + (size_t)st.row * std::max(1u, max_consts), fr);
+                        gen_run(g, st.sub, p.consts.data() + (size_t)st.row * std::max(1u, max_consts), fr, tables_of(g));
                     } catch (const GenError& e) {
                         return fail(e.what + " (row " + std::to_string(st.row) + ")");
                     }
@@ -671,7 +694,7 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
         for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot, &step_out})
             for (u32& s : *v) s = renum[s];
     }
-    build_device_schedule(p, step_out, step_out_off);
+    build_device_schedule(p, step_out, step_out_w, step_out_off);
     *out = plan.release();
     return VPBS_OK;
 }
@@ -748,7 +771,8 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
                 run_gadget(p, p.gadgets[st.sub], s);
             } else {
                 SlotRow r{s, p.row_slots.data() + p.row_off[st.row], st.row};
-                gen_run(p.gates[p.row_gate[st.row]], st.sub, p.consts.data() + (size_t)st.row * mc, r);
+                const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+                gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, r, tables_of(g));
             }
         } catch (const GenError& e) {
             err = e.what + (st.row == NO_ROW ? " (generator " + std::to_string(st.sub) + ")" : " (row " + std::to_string(st.row) + ")");
@@ -787,7 +811,7 @@ int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t*
     if (g.num_constants && !constants) return VPBS_ERR_INVALID;
     vpbs::PlainRow r{row};
     try {
-        for (unsigned sub = 0; sub < vpbs::gen_count(g); ++sub) vpbs::gen_run(g, sub, constants, r);
+        for (unsigned sub = 0; sub < vpbs::gen_count(g); ++sub) vpbs::gen_run(g, sub, constants, r, vpbs::tables_of(g));
     } catch (const vpbs::GenError&) {
         return VPBS_ERR_INVALID;
     }
@@ -955,7 +979,7 @@ namespace vpbs {
 namespace {
 using Plan = vpbs_witness_plan;
 constexpr unsigned WT = 256;
-enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8 };
+enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8, DE_GATE = 16 };
 
 struct Vals {
     u64* v;
@@ -1008,6 +1032,34 @@ __global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, cons
         x >>= op.bits;
     }
     if (x != 0) atomicOr(err, DE_TOO_LARGE);
+}
+
+// every gate generator without a special form: gen_run (the host's code) through the row's slot table, one thread per instance
+struct DevRow {
+    Vals a;
+    const u32* rs;
+    __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
+    __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
+    __device__ void fail(const char*) const { atomicOr(a.err, DE_GATE); }
+};
+
+struct RowTables {
+    const vpbs_gate* gates;
+    const u32 *row_gate, *row_off;
+    const u64* consts;
+    const gates::CosetTables* coset;  // [n_gates]
+    u32 max_consts;
+};
+
+__global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
+                                                       u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Plan::RowOp op = ops[gid / batch];
+    const u32 gi = t.row_gate[op.row];
+    const vpbs_gate g = t.gates[gi];
+    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + t.row_off[op.row]};
+    gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
 }
 
 // PoseidonGate generator, 16 lanes per row and instance: lane l < 12 owns state element l (the latency form of the prover's tree
@@ -1164,6 +1216,8 @@ struct vpbs_witness_device {
     const vpbs_witness_plan::MiscOp* misc = nullptr;
     const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
     const vpbs::u32* poseidon_off = nullptr;
+    const vpbs_witness_plan::RowOp* rowops = nullptr;
+    vpbs::RowTables tables{};
     unsigned tail_first = 0;          // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
     hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
     unsigned graph_batch = 0;
@@ -1188,6 +1242,9 @@ void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
                                d->row_slots, k, batch);
         if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
             hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
+        if (const u32 k = ds.rowops_off[l + 1] - ds.rowops_off[l])
+            hipLaunchKernelGGL(wd_rowop_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->rowops + ds.rowops_off[l], d->tables, d->row_slots, k,
+                               batch);
     }
     if (d->tail_first)
         hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((batch * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, d->poseidon, d->poseidon_off,
@@ -1220,9 +1277,19 @@ int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, uns
         d->out_pos = upload(ctx, plan->out_pos, d->owned);
         d->out_slot = upload(ctx, plan->out_slot, d->owned);
         d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
+        d->rowops = upload(ctx, ds.rowops, d->owned);
+        if (!ds.rowops.empty()) {
+            std::vector<gates::CosetTables> coset(plan->gates.size());
+            for (size_t i = 0; i < plan->gates.size(); ++i)
+                if (plan->gates[i].kind == VPBS_GATE_COSET_INTERPOLATION) coset[i] = gates::coset_tables(plan->gates[i].p0);
+            d->tables = RowTables{upload(ctx, plan->gates, d->owned), upload(ctx, plan->row_gate, d->owned), upload(ctx, plan->row_off, d->owned),
+                                  upload(ctx, plan->consts, d->owned), upload(ctx, coset, d->owned), std::max(1u, plan->max_consts)};
+        }
         {
             u32 l = ds.n_levels;
-            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l]) --l;
+            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
+                   ds.rowops_off[l + 1] == ds.rowops_off[l])
+                --l;
             d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
         }
         d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
@@ -1296,6 +1363,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
             if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
             if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
             if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
+            if (flags & DE_GATE) m += "a gate generator rejected its inputs (limbs that do not fit, an access index out of range, a non-boolean bit, a zero shift); ";
             throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
         }
         return VPBS_OK;
