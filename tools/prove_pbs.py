@@ -6,7 +6,7 @@ reference).  Pipeline: native accumulator chain on the device (vpbs_pbs_accumula
 PartialWitness values of every step (the hash chains computed by a host thread beside the device) -> device witness generation in batches (vpbs_witness_device_*) -> gather -> step proofs on
 `provers` contexts -> every `verify_every`-th proof verified on the host.  Random bootstrapping keys (no decryption check here: the
 noise-free end-to-end PBS is tests/test_gpu_step_circuit.py at N = 8).
-usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=4]  ->  one JSON line"""
+usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=5]  ->  one JSON line"""
 import json
 import os
 import queue
@@ -30,7 +30,7 @@ P = api.P
 def main():
     n_lwe = int(sys.argv[1]) if len(sys.argv) > 1 else 728
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 73
-    provers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    provers = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     verify_every = 73
     steps = n_lwe + 2
     t_all = time.perf_counter()
