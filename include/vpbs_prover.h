@@ -416,6 +416,12 @@ typedef struct {
     const vpbs_gate* gates;                 /* the circuit's gates: their constraints are evaluated at zeta from the openings */
     unsigned n_gates, num_selectors;
 } vpbs_verify_inputs;
+/* The inverse of vpbs_step_proof_to_bytes: ProofWithPublicInputs bytes -> caps [3][cap], openings, fri (the arrays vpbs_verify_step
+ * takes; sizes as vpbs_step_sizes_get reports) and the public inputs.  The shape is taken from `in` (log_n, rate_bits, cap_height, column
+ * counts, num_challenges, n_constants); returns the number of public inputs, or < 0 for bytes of another shape (wrong length, wrong
+ * Merkle-path lengths, a non-canonical field element, more public inputs than public_inputs_capacity). */
+long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const uint8_t* bytes, size_t len, uint64_t* caps, uint64_t* openings,
+                                uint64_t* fri, uint64_t* public_inputs_out, size_t public_inputs_capacity);
 /* returns 1 = proof accepted, 0 = rejected, < 0 = malformed arguments */
 int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][cap] */, const uint64_t* openings,
                      const uint64_t* fri);

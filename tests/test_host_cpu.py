@@ -213,3 +213,32 @@ def test_recorded_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"] / 730) / d["value"] < 1e-6      # vPBS proofs/s = step proofs/s / 730
+
+
+def test_proof_bytes_round_trip_and_verify():
+    """data format behind the path: an (oracle) step proof serialised with the restated ProofWithPublicInputs::to_bytes layout is parsed
+    back by the product (vpbs_step_proof_from_bytes) into the very arrays it came from, public inputs included, and the parsed proof
+    is accepted by vpbs_verify_step; truncated / padded / foreign-shape / non-canonical byte strings are rejected."""
+    import regression_cases as rc
+    import step_oracle
+    case = next(c for c in rc.cases() if rc.build(c)["gates"] is None)
+    b = rc.build(case)
+    p = step_oracle.prove_step(b["inputs"], rc.DIGEST, b["pis"], b["log_n"])
+    ncols, n_constants = p["ncols"], 3
+    blob = step_oracle.to_bytes(p, ncols, n_constants, b["pis"], b["log_n"])
+    proof, pis = api.step_proof_from_bytes(blob, ncols, b["log_n"], n_constants)
+    for key in ("caps", "openings", "fri"):
+        assert (proof[key].reshape(-1) == np.asarray(p[key], np.uint64).reshape(-1)).all(), key
+    assert (pis == np.asarray(b["pis"], np.uint64)).all()
+    assert api.verify_step(proof, p["cs_cap"], ncols, rc.DIGEST, pis, b["log_n"])
+    for bad in (blob[:-8], blob + b"\\0" * 8, blob[:len(blob) // 2]):
+        with pytest.raises(api.VpbsError):
+            api.step_proof_from_bytes(bad, ncols, b["log_n"], n_constants)
+    with pytest.raises(api.VpbsError):
+        api.step_proof_from_bytes(blob, [ncols[0], ncols[1] + 1, ncols[2], ncols[3]], b["log_n"], n_constants)
+    with pytest.raises(api.VpbsError):
+        api.step_proof_from_bytes(blob, ncols, b["log_n"] + 1, n_constants)
+    tampered = bytearray(blob)
+    tampered[8:16] = (0xFFFFFFFFFFFFFFFF).to_bytes(8, "little")          # a cap element >= p
+    with pytest.raises(api.VpbsError):
+        api.step_proof_from_bytes(bytes(tampered), ncols, b["log_n"], n_constants)

@@ -152,6 +152,7 @@ SIGNATURES = {
     "vpbs_generate_witness": (_i, [C.POINTER(CircuitC), U32P, U64P, _sz, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_create": (_i, [C.POINTER(CircuitC), U32P, _sz, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
     "vpbs_witness_plan_run": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.c_char_p, _sz]),
+    "vpbs_step_proof_from_bytes": (C.c_long, [C.POINTER(VerifyInputsC), C.POINTER(C.c_uint8), _sz, U64P, U64P, U64P, U64P, _sz]),
     "vpbs_witness_plan_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
@@ -504,6 +505,26 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     if rc < 0:
         raise VpbsError("vpbs_verify_step: malformed arguments (%d)" % rc)
     return rc == 1
+
+
+def step_proof_from_bytes(blob, ncols, log_n, n_constants, num_challenges=2, rate_bits=3, cap_height=4, max_public_inputs=1 << 16):
+    """vpbs_step_proof_from_bytes: ProofWithPublicInputs bytes -> ({"caps", "openings", "fri"}, public inputs)"""
+    v = VerifyInputsC()
+    v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
+    v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
+    v.num_challenges, v.n_constants = num_challenges, n_constants
+    p = fri_params(log_n)
+    sizes = (C.c_size_t * 4)(*ncols)
+    fri_words = lib().vpbs_fri_proof_words(C.byref(p), log_n, sizes, 4)
+    caps = np.zeros((3, 1 << cap_height, 4), np.uint64)
+    openings = np.zeros((sum(ncols) + num_challenges, 2), np.uint64)
+    fri = np.zeros(fri_words, np.uint64)
+    pis = np.zeros(max_public_inputs, np.uint64)
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+    n = lib().vpbs_step_proof_from_bytes(C.byref(v), buf, len(blob), _ptr(caps), _ptr(openings), _ptr(fri), _ptr(pis), pis.size)
+    if n < 0:
+        raise VpbsError("vpbs_step_proof_from_bytes: not a step proof of this shape")
+    return {"caps": caps, "openings": openings, "fri": fri}, pis[:n].copy()
 
 
 def fri_params(degree_bits, **over):

@@ -253,3 +253,92 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     }
     return 1;
 }
+
+// The inverse of vpbs_step_proof_to_bytes (prover.hip): ProofWithPublicInputs bytes -> the flat arrays vpbs_verify_step takes.  The
+// shape comes from `in` (column counts, n_constants, degree); a byte string of another shape is rejected, not guessed at.
+extern "C" long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const uint8_t* bytes, size_t len, uint64_t* caps, uint64_t* openings, uint64_t* fri,
+                                uint64_t* public_inputs_out, size_t public_inputs_capacity) {
+    if (!in || !bytes || !caps || !openings || !fri || in->n_constants > in->n_constants_sigmas || in->num_challenges > in->n_zs_partial_products)
+        return VPBS_ERR_INVALID;
+    using namespace plonky2;
+    FriParams fp = FriParams::standard(in->log_n);
+    fp.config.rate_bits = in->rate_bits;
+    fp.config.cap_height = in->cap_height;
+    size_t pos = 0;
+    bool bad = false;
+    auto get_words = [&](uint64_t* w, size_t cnt) {
+        if (bad || pos + 8 * cnt > len) {
+            bad = true;
+            return;
+        }
+        std::memcpy(w, bytes + pos, 8 * cnt);
+        for (size_t i = 0; i < cnt; ++i)
+            if (w[i] >= gl::P) bad = true;  // non-canonical field element
+        pos += 8 * cnt;
+    };
+    auto expect_u8 = [&](unsigned v) {
+        if (bad || pos + 1 > len || bytes[pos] != (uint8_t)v) bad = true;
+        ++pos;
+    };
+    const size_t cap_words = (size_t)4 << in->cap_height;
+    const size_t n_cs = in->n_constants_sigmas, nc = in->num_challenges;
+    get_words(caps, 3 * cap_words);
+    uint64_t* cs = openings;
+    uint64_t* wires = cs + 2 * n_cs;
+    uint64_t* zs_pp = wires + 2 * (size_t)in->n_wires;
+    uint64_t* quot = zs_pp + 2 * (size_t)in->n_zs_partial_products;
+    uint64_t* zs_next = quot + 2 * (size_t)in->n_quotient;
+    get_words(cs, 2 * (size_t)in->n_constants);
+    get_words(cs + 2 * (size_t)in->n_constants, 2 * (n_cs - in->n_constants));
+    get_words(wires, 2 * (size_t)in->n_wires);
+    get_words(zs_pp, 2 * nc);
+    get_words(zs_next, 2 * nc);
+    get_words(zs_pp + 2 * nc, 2 * (size_t)(in->n_zs_partial_products - nc));
+    get_words(quot, 2 * (size_t)in->n_quotient);
+    uint64_t* w = fri;
+    const size_t n_rounds = fp.reduction_arity_bits.size();
+    get_words(w, n_rounds * cap_words);
+    w += n_rounds * cap_words;
+    const unsigned log_lde = fp.lde_bits();
+    const size_t oracle_cols[4] = {n_cs, in->n_wires, in->n_zs_partial_products, in->n_quotient};
+    for (unsigned q = 0; q < fp.config.num_query_rounds && !bad; ++q) {
+        for (size_t o = 0; o < 4; ++o) {
+            const unsigned nsib = log_lde - fp.config.cap_height;
+            get_words(w, oracle_cols[o]);
+            w += oracle_cols[o];
+            expect_u8(nsib);
+            get_words(w, 4 * (size_t)nsib);
+            w += 4 * (size_t)nsib;
+        }
+        unsigned lg = log_lde;
+        for (unsigned ab : fp.reduction_arity_bits) {
+            lg -= ab;
+            const unsigned nsib = lg - fp.config.cap_height;
+            get_words(w, (size_t)2 << ab);
+            w += (size_t)2 << ab;
+            expect_u8(nsib);
+            get_words(w, 4 * (size_t)nsib);
+            w += 4 * (size_t)nsib;
+        }
+    }
+    const size_t final_words = (size_t)2 << fp.final_poly_bits();
+    get_words(w, final_words);
+    if (!bad && pos + 8 <= len) {  // pow_witness: a plain u64, not a field element
+        std::memcpy(w + final_words, bytes + pos, 8);
+        pos += 8;
+    } else {
+        bad = true;
+    }
+    uint64_t n_pi = 0;
+    if (!bad && pos + 8 <= len) {
+        std::memcpy(&n_pi, bytes + pos, 8);
+        pos += 8;
+    } else {
+        bad = true;
+    }
+    if (bad || n_pi > public_inputs_capacity || (n_pi && !public_inputs_out)) return VPBS_ERR_INVALID;
+    get_words(public_inputs_out, (size_t)n_pi);
+    if (bad || pos != len) return VPBS_ERR_INVALID;
+    return (long)n_pi;
+}
+
