@@ -4,7 +4,7 @@ n + 2 = 730 chained steps of the reference's step circuit WITHOUT its recursive 
 accumulator, counter and hash chains between steps is done by this driver, which is what the in-circuit verifier enforces in the
 reference).  Pipeline: native accumulator chain on the device (vpbs_pbs_accumulator_chain) and native hash chains on the host -> the
 PartialWitness values of every step (the hash chains computed by a host thread beside the device) -> device witness generation in batches (vpbs_witness_device_*) -> gather -> step proofs on
-`provers` contexts -> every `verify_every`-th proof verified on the host.  Random bootstrapping keys (no decryption check here: the
+`provers` contexts -> every proof verified on the host (after the clock).  Random bootstrapping keys (no decryption check here: the
 noise-free end-to-end PBS is tests/test_gpu_step_circuit.py at N = 8).
 usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=5]  ->  one JSON line"""
 import json
@@ -31,7 +31,6 @@ def main():
     n_lwe = int(sys.argv[1]) if len(sys.argv) > 1 else 728
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 73
     provers = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    verify_every = 73
     steps = n_lwe + 2
     t_all = time.perf_counter()
     circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
@@ -155,12 +154,18 @@ def main():
         assert (pis[K * N + 1:2 * K * N + 1] == accs[s].reshape(-1)).all(), s
         assert (pis[-8:-4] == bsk_h[s + 1]).all() and (pis[-4:] == lwe_h[s + 1]).all(), s
     t0 = time.perf_counter()
-    checked = 0
-    for s in list(range(0, steps, verify_every)) + [steps - 1]:
+    from concurrent.futures import ThreadPoolExecutor
+    cs_cap = css[0].cap()
+
+    def verify(s):
         proof, pis = results[s]
-        assert api.verify_step(proof, css[0].cap(), [n_constants + 80, 135, 20, 16], digest, pis, b.log_n, check_permutation=True,
-                               n_constants=n_constants, n_routed=80, gates=b.gates), s
-        checked += 1
+        return api.verify_step(proof, cs_cap, [n_constants + 80, 135, 20, 16], digest, pis, b.log_n, check_permutation=True,
+                               n_constants=n_constants, n_routed=80, gates=b.gates)
+
+    with ThreadPoolExecutor(max_workers=8) as pool:      # the host verifier releases the GIL: every proof of the chain is checked
+        verdicts = list(pool.map(verify, range(steps)))
+    assert all(verdicts), [s for s, v in enumerate(verdicts) if not v][:5]
+    checked = steps
     t_verify = time.perf_counter() - t0
     proof_bytes = sum(results[0][0][k].nbytes for k in ("caps", "openings", "fri"))
     print(json.dumps({
@@ -172,8 +177,8 @@ def main():
         "inside_the_clock": {"accumulator_chain_on_device_s": t_chain, "native_hash_chains_on_one_host_core_s": t_hash,
                              "note": "the hash chains run beside the device; every witness batch waits for the prefix it needs"},
         "before_the_clock": {"circuit_description_sigma_plan_s": t_setup, "note": "once per circuit, not per PBS"},
-        "checks": "accumulator / counter / hash public inputs of all %d proofs equal the native chains; %d proofs verified by vpbs_verify_step "
-                  "(%.1f ms each)" % (steps, checked, 1e3 * t_verify / checked),
+        "checks": "accumulator / counter / hash public inputs of all %d proofs equal the native chains; all %d proofs verified by "
+                  "vpbs_verify_step on 8 host threads in %.2f s (after the clock)" % (steps, checked, t_verify),
         "proof_words_kB": proof_bytes / 1e3}))
 
 
