@@ -70,6 +70,21 @@ def leaf_hash_perms_per_step(log_n=LOG_N):
     return sum(lde * ((COLS[k] + 7) // 8) for k in ("wires", "zs_partial_products", "quotient"))
 
 
+_STEP_CIRCUIT = {}
+
+
+def step_circuit():
+    """the step circuit at the paper's parameters, described once per process (tests/step_circuit.py; ~2-5 s of Python)"""
+    if "circ" not in _STEP_CIRCUIT:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import step_circuit as sc
+        from vpbs_amd import api
+        t0 = time.perf_counter()
+        _STEP_CIRCUIT["circ"] = sc.StepCircuit(api, 1024, 2, 4, 5, 728, api.ntt_params(10))
+        _STEP_CIRCUIT["seconds"] = time.perf_counter() - t0
+    return _STEP_CIRCUIT["circ"], _STEP_CIRCUIT["seconds"]
+
+
 def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     """The reference's step circuit without its recursive verifier (build_step_circuit, ivc_based_vpbs.rs:80-155, described by
     tests/step_circuit.py at the paper's parameters: 38 312 gate rows, degree 2^16, 4 105 public inputs) through the whole product
@@ -80,14 +95,10 @@ def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     import threading
     witness_threads = int(os.environ.get("VPBS_PIPE_WITNESS", witness_threads))
     provers = int(os.environ.get("VPBS_PIPE_PROVERS", provers))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import step_circuit as sc
     from vpbs_amd import api
     N, K, ELL, LOGB, n_lwe = 1024, 2, 4, 5, 728
-    t0 = time.perf_counter()
-    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
+    circ, t_build = step_circuit()
     b = circ.built
-    t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     sigma = b.circuit.sigma_values()
     targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat + [circ.counter, circ.mask] +
@@ -207,11 +218,9 @@ def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
     by one of `provers` prover contexts.  Nothing but the PartialWitness values (20 490 field elements per step) crosses PCIe."""
     import queue
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import step_circuit as sc
     from vpbs_amd import api
     N, K, ELL, LOGB, n_lwe = 1024, 2, 4, 5, 728
-    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
+    circ, _ = step_circuit()
     b = circ.built
     sigma = b.circuit.sigma_values()
     targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat + [circ.counter, circ.mask] +
