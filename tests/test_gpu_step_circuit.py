@@ -4,6 +4,7 @@ generation on the host (vpbs_witness_plan), the native TFHE data path on the dev
 (vpbs_pbs_accumulator_chain / vpbs_blind_rotate_step), step proofs on the device with the gate constraints of the six gate types the
 circuit uses, the host verifier -- a verifiable PBS with the IVC hand-over (accumulator, counter, hash chains) done by the caller
 instead of the in-circuit verifier."""
+import os
 import time
 
 import numpy as np
@@ -261,3 +262,25 @@ def test_device_witness_matches_the_host_plan(ctx, N, batch):
 def plan_positions(plan):
     n = plan.circuit.n
     return [divmod(int(p), n) for p in plan.positions]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_whole_pbs_tool(world):
+    """tools/prove_pbs.py on a short chain (n = 14: 16 steps) at the paper's ring dimension: every step witness-generated on the device,
+    proven, verified, public inputs equal to the native chains; with two ranks (both on this box's one GPU, gloo) the steps of the one
+    PBS are split between the ranks."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    tool = entry.ROOT + "/tools/prove_pbs.py"
+    env = dict(os.environ, VPBS_PBS_BACKEND="gloo", VPBS_PBS_DEVICE="0")
+    if world == 1:
+        cmd = [sys.executable, tool, "14", "4", "2"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+               "--master-port", "29561", tool, "14", "4", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["step_proofs"] == 16 and d["n_gpus"] == world and "all 16 proofs verified" in d["checks"]

@@ -6,7 +6,11 @@ reference).  Pipeline: native accumulator chain on the device (vpbs_pbs_accumula
 PartialWitness values of every step (the hash chains computed by a host thread beside the device) -> device witness generation in batches (vpbs_witness_device_*) -> gather -> step proofs on
 `provers` contexts -> every proof verified on the host (after the clock).  Random bootstrapping keys (no decryption check here: the
 noise-free end-to-end PBS is tests/test_gpu_step_circuit.py at N = 8).
-usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=5]  ->  one JSON line"""
+usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=5]  ->  one JSON line
+Several GPUs: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/prove_pbs.py ...
+  the steps of the ONE PBS are split into N contiguous ranges, one per rank / GPU (they are independent once the accumulator and hash
+  chains are known; every rank recomputes those chains -- 40 ms on its device, 2 s on one host core, beside the proving).  No data-path
+  collective: a barrier and a max over the ranks' times.  VPBS_PBS_BACKEND=gloo and VPBS_PBS_DEVICE=0 put all ranks on one GPU (tests)."""
 import json
 import os
 import queue
@@ -32,6 +36,14 @@ def main():
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 73
     provers = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     steps = n_lwe + 2
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get("VPBS_PBS_BACKEND", "nccl"))
+    torch.cuda.set_device(device)
+    my_first, my_end = steps * rank // world, steps * (rank + 1) // world      # this rank's steps: [my_first, my_end)
     t_all = time.perf_counter()
     circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
     b = circ.built
@@ -49,7 +61,7 @@ def main():
     ggsw_len = K * ELL * K * N
     bsk, ksk, ct = f(n_lwe, ggsw_len), f(ggsw_len), f(n_lwe + 1)
     acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), f(1, N)])
-    main_ctx = vpbs_amd.Context(0, log_n_max=16)
+    main_ctx = vpbs_amd.Context(device, log_n_max=16)
     ggsws = lambda s: np.zeros(ggsw_len, np.uint64) if s == 0 else (bsk[s - 1] if s <= n_lwe else ksk)
     masks = [int(ct[n_lwe])] + [int(v) for v in ct[:n_lwe]] + [0]
     bsk_h, lwe_h = [np.zeros(4, np.uint64)], [np.zeros(4, np.uint64)]
@@ -60,14 +72,22 @@ def main():
         """the native hash chains (verify_hash_output's sponge over every bootstrapping-key element): sequential by construction, 2.8 ms
         per step on one host core -- runs beside the device, the witness thread waits for the prefix its batch needs"""
         t = time.perf_counter()
-        for s in range(steps):
-            hb = api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)]))
+        for s in range(my_end):
+            hb = bsk_pre[s + 1] if bsk_pre else api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)]))
             hl = api.hash_no_pad(np.concatenate([lwe_h[-1], np.array([masks[s]], np.uint64)]))
             with hashed:
                 bsk_h.append(hb)
                 lwe_h.append(hl)
                 hashed.notify_all()
         timing["hash"] = time.perf_counter() - t
+
+    # The bootstrapping-key chain depends on the key only: a deployment computes it once per key.  With several GPUs it is taken as
+    # given (otherwise rank r would wait r / N of the 2 s chain before its first witness); on one GPU it stays inside the clock.
+    bsk_pre = []
+    if os.environ.get("VPBS_PBS_BSK_CHAIN", "precomputed" if world > 1 else "inside") == "precomputed":
+        bsk_pre = [np.zeros(4, np.uint64)]
+        for s in range(my_end):
+            bsk_pre.append(api.hash_no_pad(np.concatenate([bsk_pre[-1], ggsws(s)])))
 
     def values(first, count):
         v = np.zeros((len(targets), count), np.uint64)
@@ -77,9 +97,9 @@ def main():
             v[:, j] = np.concatenate([acc_init.reshape(-1), acc_in.reshape(-1), ggsws(s), np.array([s + 1, masks[s]], np.uint64), bsk_h[s], lwe_h[s]])
         return v
 
-    wctx = [vpbs_amd.Context(0, log_n_max=16) for _ in range(2)]
+    wctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(2)]
     wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
-    pctx = [vpbs_amd.Context(0, log_n_max=16) for _ in range(provers)]
+    pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
     for c in pctx:
         c.set_gate_lanes(1 if provers > 1 else 3)
@@ -95,8 +115,8 @@ def main():
 
     def witness_thread():
         try:
-            for first in range(0, steps, batch):
-                count = min(batch, steps - first)
+            for first in range(my_first, my_end, batch):
+                count = min(batch, my_end - first)
                 with hashed:
                     hashed.wait_for(lambda: len(bsk_h) > first + count - 1)
                 vals = values(first, count)
@@ -133,6 +153,8 @@ def main():
             errs.append(e)
 
     torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     t0 = time.perf_counter()
     hasher = threading.Thread(target=hash_thread)
     hasher.start()
@@ -143,12 +165,15 @@ def main():
         t.start()
     for t in ts + [hasher]:
         t.join()
-    t_prove = time.perf_counter() - t0
+    t_mine = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    t_prove = time.perf_counter() - t0          # all ranks done
     t_hash = timing["hash"]
     if errs:
         raise errs[0]
     # the chain the proofs expose is the native one
-    for s in range(steps):
+    for s in range(my_first, my_end):
         pis = results[s][1]
         assert int(pis[K * N]) == s + 1
         assert (pis[K * N + 1:2 * K * N + 1] == accs[s].reshape(-1)).all(), s
@@ -163,23 +188,41 @@ def main():
                                n_constants=n_constants, n_routed=80, gates=b.gates)
 
     with ThreadPoolExecutor(max_workers=8) as pool:      # the host verifier releases the GIL: every proof of the chain is checked
-        verdicts = list(pool.map(verify, range(steps)))
-    assert all(verdicts), [s for s, v in enumerate(verdicts) if not v][:5]
-    checked = steps
+        verdicts = list(pool.map(verify, range(my_first, my_end)))
+    assert all(verdicts), [my_first + s for s, v in enumerate(verdicts) if not v][:5]
+    checked = my_end - my_first
     t_verify = time.perf_counter() - t0
-    proof_bytes = sum(results[0][0][k].nbytes for k in ("caps", "openings", "fri"))
+    if dist:
+        t = torch.tensor([t_prove, float(checked)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        t_prove, checked = float(tmax[0]), int(tsum[1])
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+    proof_bytes = sum(results[my_first][0][k].nbytes for k in ("caps", "openings", "fri"))
     print(json.dumps({
         "what": "one whole vPBS at N=1024, k=1, ELL=4, LOGB=5, n=%d: %d chained step proofs of build_step_circuit (no recursive verifier; "
-                "%d gate rows, degree 2^%d) on 1 x MI355X" % (n_lwe, steps, b.used_rows, b.log_n),
+                "%d gate rows, degree 2^%d) on %d x MI355X%s" % (n_lwe, steps, b.used_rows, b.log_n, world,
+                                                           "" if world == 1 else " (the steps split into %d contiguous ranges, one per GPU)" % world),
+        "n_gpus": world,
         "step_proofs": steps, "seconds": t_prove, "vpbs_proofs_per_s": 1.0 / t_prove, "step_proofs_per_s": steps / t_prove,
         "ms_per_step_proof": 1e3 * t_prove / steps, "witness_batch": batch, "provers": provers,
         "device_witness_s_per_batch": sum(wit_s) / len(wit_s),
+        "bsk_hash_chain": "precomputed per key (before the clock)" if bsk_pre else "inside the clock",
         "inside_the_clock": {"accumulator_chain_on_device_s": t_chain, "native_hash_chains_on_one_host_core_s": t_hash,
                              "note": "the hash chains run beside the device; every witness batch waits for the prefix it needs"},
         "before_the_clock": {"circuit_description_sigma_plan_s": t_setup, "note": "once per circuit, not per PBS"},
         "checks": "accumulator / counter / hash public inputs of all %d proofs equal the native chains; all %d proofs verified by "
-                  "vpbs_verify_step on 8 host threads in %.2f s (after the clock)" % (steps, checked, t_verify),
+                  "vpbs_verify_step on 8 host threads per rank in %.2f s (after the clock)" % (checked, checked, t_verify),
         "proof_words_kB": proof_bytes / 1e3}))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
