@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-circuit", action="store_true", help="skip the witness -> proof pipeline on the real step circuit")
+    ap.add_argument("--no-whole-pbs", action="store_true", help="skip tools/prove_pbs.py (one whole vPBS, 730 step proofs, end to end)")
     ap.add_argument("--no-survey-size", action="store_true", help="skip the secondary degree-2^15 measurement (profiling runs)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
                     help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
@@ -596,6 +597,19 @@ def main():
                 out["step_circuit_pipeline"]["device_witness"] = step_circuit_device_pipeline(local_rank)
             except Exception as e:
                 out["step_circuit_pipeline"]["device_witness"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_whole_pbs:
+            # one whole vPBS end to end (tools/prove_pbs.py) in its own process, after this one has released the device
+            for ctx in ctxs:
+                ctx.close()
+            ctxs = []
+            torch.cuda.empty_cache()
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_pbs.py")], capture_output=True, text=True, timeout=600,
+                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank), WORLD_SIZE="1", RANK="0"))
+                out["whole_pbs"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
+            except Exception as e:
+                out["whole_pbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
