@@ -365,7 +365,7 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
  * redundantly on every rank (cheaper than exchanging them), and the query openings of the sharded oracles are answered
  * by the owning rank and merged with comm->allreduce_sum.  With quotient_coeffs == NULL every rank evaluates the quotient
  * values of its own cosets (the next-row access stays inside a coset), the values are all-gathered on the device
- * (comm->allgather_dev, 2^18 * 16 B per step) and the cheap size-8n iNTT is replicated.  in->constants_sigmas must be a batch committed with
+ * (comm->allgather_dev, 8n * 16 B per step: 8 MiB at degree 2^16) and the cheap size-8n iNTT is replicated.  in->constants_sigmas must be a batch committed with
  * vpbs_commit_sharded_dev(.., comm->rank, comm->world, ..) (or an unsharded one).  Every rank returns the complete,
  * identical proof -- bit-identical to vpbs_prove_step on one GPU. */
 int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out,
