@@ -327,8 +327,9 @@ def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
                         "step proof; the last proof is verified" % batch}
 
 
-def cpu_baseline():
-    """One full step proof on the host cores with the CPU oracle (kind 'port': restated algorithm, OpenMP)."""
+def cpu_baseline(gpu_proof=None):
+    """One full step proof on the host cores with the CPU oracle (kind 'port': restated algorithm, OpenMP).  gpu_proof = (proof, bytes,
+    constants/sigmas cap) of the GPU for the same instance: compared word for word (the bench fails if they differ)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gates_oracle
     import oracle as orc
@@ -341,10 +342,24 @@ def cpu_baseline():
     t0 = time.time()
     sig = np.ascontiguousarray(inputs["constants_sigmas"][N_CONSTANTS:N_CONSTANTS + N_ROUTED])
     inputs["quotient"] = None   # quotient chunks evaluated (permutation-argument constraints), like the GPU step
-    step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS,
-                           gates=gates_oracle.GateSet(GATES))
+    want = step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS,
+                                  gates=gates_oracle.GateSet(GATES))
     dt = time.time() - t0
-    return {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
+    parity = None
+    if gpu_proof is not None:
+        # the oracle proved the very instance chain 0 of the GPU proved (same seeded columns, gates, public inputs, digest): every
+        # word of the proof must agree -- caps, Fiat-Shamir challenges, openings, FRI proof (PoW nonce, query paths), serialised bytes
+        got, got_bytes, got_cs_cap = gpu_proof
+        bad = [k for k in ("caps", "challenges", "openings", "fri") if not (np.asarray(got[k]).reshape(-1) == np.asarray(want[k]).reshape(-1)).all()]
+        if not (np.asarray(got_cs_cap) == want["cs_cap"]).all():
+            bad.append("cs_cap")
+        if got_bytes != step_oracle.to_bytes(want, want["ncols"], N_CONSTANTS, pis, LOG_N):
+            bad.append("bytes")
+        if bad:
+            raise RuntimeError("full-size GPU step proof differs from the CPU oracle's in: " + ", ".join(bad))
+        parity = {"compared": ["cs_cap", "caps", "challenges", "openings", "fri", "bytes"], "proof_bytes": len(got_bytes),
+                  "fri_words": int(np.asarray(want["fri"]).size)}
+    return parity, {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
             "cores": orc.effective_cpus(), "kind": "port",
             "sample": "1 complete step proof (2^%d rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
                       "and quotient included) with the C oracle, OpenMP on every CPU the container may use "
@@ -507,8 +522,11 @@ def main():
     # per-kernel breakdown of one extra (untimed) step proof on chain 0 alone, for the record
     ctx = ctxs[0]
     ctx.timing_enable(1)
-    ctx.prove_step(sis[0], comm)
+    proof0 = ctx.prove_step(sis[0], comm)
     breakdown = {k: round(v["ms"], 4) for k, v in ctx.timing_report().items()}
+    gpu_proof = None
+    if rank == 0 and not sharded and world == 1:   # kept for the word-for-word comparison with the oracle's proof (cpu_baseline leg)
+        gpu_proof = (proof0, ctx.step_proof_to_bytes(sis[0], N_CONSTANTS, proof0), keep[0][1].cap().copy())
     ctx.timing_enable(0)
 
     if rank == 0:
@@ -611,7 +629,9 @@ def main():
             except Exception as e:
                 out["whole_pbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
-            out["cpu_baseline"] = cpu_baseline()
+            parity, out["cpu_baseline"] = cpu_baseline(gpu_proof)
+            out["parity_checked_full_size"] = parity is not None
+            out["parity_full_size"] = parity
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     for ctx in ctxs:

@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
     v.constants_sigmas_cap = cs_cap.data();
     for (int i = 0; i < 4; ++i) v.circuit_digest[i] = in.circuit_digest[i];
     v.public_inputs = pis; v.n_public_inputs = 4;
-    v.check_permutation = 1;
+    v.fri_only = 0;   // full verification: vanishing identity at zeta with the gate constraints
     v.n_constants = n_constants; v.n_routed = n_routed; v.quotient_degree_factor = 8;
     v.gates = gates; v.n_gates = 3; v.num_selectors = num_selectors;
     const int ok = vpbs_verify_step(&v, caps.data(), openings.data(), fri.data());

@@ -401,8 +401,11 @@ int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* constants_sigmas, unsig
 /* ---- verifier (host only; plonky2 plonk/verifier.rs `verify` -> fri/verifier.rs `verify_fri_proof`; the reference calls it
  *      as cd.verify(proof) at /root/reference/src/vtfhe/ivc_based_vpbs.rs:443-447).  Replays the transcript of
  *      vpbs_prove_step, checks proof-of-work, every Merkle path, the alpha-combination, the arity-16 folds and the final
- *      polynomial; with check_permutation it also checks vanishing(zeta) == Z_H(zeta) * t(zeta) for the permutation-
- *      argument constraints (+ gate_terms_zeta, the alpha-folded gate constraints at zeta, when the circuit has gates). */
+ *      polynomial, and vanishing(zeta) == Z_H(zeta) * t(zeta): the permutation-argument constraints + the circuit's gate
+ *      constraints (and with them the PublicInputGate binding) evaluated at zeta from the openings.  That full check is the DEFAULT
+ *      (a zero-initialised struct): it needs n_constants, n_routed, quotient_degree_factor and the gates.  fri_only = 1 skips the
+ *      vanishing identity -- then "accepted" only says that the openings belong to committed low-degree polynomials, NOT that any
+ *      constraint holds (that mode is for proofs over synthetic columns, e.g. bench.py's random traces). */
 typedef struct {
     unsigned log_n, rate_bits, cap_height;
     unsigned n_constants_sigmas, n_wires, n_zs_partial_products, n_quotient, num_challenges;
@@ -410,7 +413,7 @@ typedef struct {
     uint64_t circuit_digest[4];
     const uint64_t* public_inputs;
     size_t n_public_inputs;
-    int check_permutation;                  /* 0: FRI / transcript only */
+    int fri_only;                           /* 0 (default): full verification; 1: transcript + PoW + Merkle paths + FRI only (unsound as a verdict on the circuit) */
     unsigned n_constants, n_routed, quotient_degree_factor;
     const uint64_t* gate_terms_zeta;        /* [num_challenges][2] or NULL (ignored when gates != NULL) */
     const vpbs_gate* gates;                 /* the circuit's gates: their constraints are evaluated at zeta from the openings */

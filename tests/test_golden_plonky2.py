@@ -89,7 +89,7 @@ def check_with_product(ctx, fx):
     if fx["proof_bytes"] is not None:
         assert ctx.step_proof_to_bytes(si, m["n_constants"], p) == fx["proof_bytes"], "proof bytes"
     ncols = [cs.ncols, m["n_wires"], fx["zs_partial_products_values"].shape[0], fx["quotient_coeffs"].shape[0]]
-    assert api.verify_step(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
+    assert api.verify_step_fri_only(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
     # device partial products / quotient from the wires alone
     sig = np.ascontiguousarray(fx["constants_sigmas_values"][m["n_constants"]:])
     ch = [int(x) for x in fx["challenges"]]

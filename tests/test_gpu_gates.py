@@ -331,19 +331,51 @@ def test_cxx_circuit_example(ctx):
 
 
 def test_product_reproduces_frozen_step_proofs(ctx):
-    """the same regression vectors through the HIP path (C ABI): bit-identical caps, challenges, openings and FRI proofs"""
+    """the same regression vectors through the HIP path (C ABI): bit-identical caps, challenges, openings and FRI proofs -- including the
+    instance bench.py times (degree 2^16, 135/20/16/86 columns, all 14 gate types, 4173 public inputs: caps, challenges, openings, FRI
+    words and the serialised bytes frozen from the oracle's proof)"""
     import regression_cases as rc
-    for case in rc.cases():
+    for case in rc.cases(full_size=True):
         b = rc.build(case)
+        digest = b.get("digest", rc.DIGEST)
         cs = ctx.commit_values(b["inputs"]["constants_sigmas"])
         if b["gates"] is None:
-            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], b["inputs"]["zs_partial_products"], b["inputs"]["quotient"], cs, rc.DIGEST,
+            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], b["inputs"]["zs_partial_products"], b["inputs"]["quotient"], cs, digest,
                                       b["pis"])
         else:
-            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], None, None, cs, rc.DIGEST, b["pis"], sigmas=b["sigma"], n_routed=80,
+            si = ctx.make_step_inputs(b["log_n"], b["inputs"]["wires"], None, None, cs, digest, b["pis"], sigmas=b["sigma"], n_routed=80,
                                       n_constants=b["n_constants"], gates=api.GateSet(b["gates"]))
-        rc.check(case, ctx.prove_step(si))
+        proof = ctx.prove_step(si)
+        rc.check(case, proof)
+        if "cs_cap_sha256" in case:
+            assert rc.sha(cs.cap()) == case["cs_cap_sha256"]
+        rc.check_bytes(case, ctx.step_proof_to_bytes(si, b["n_constants"], proof))
         cs.free()
+
+
+def test_full_size_step_proof_bit_exact_against_the_oracle(ctx):
+    """BASELINE config 2 at the benchmarked shape -- degree 2^16, LDE 2^19, 135 wire / 20 Z+pp / 16 quotient / 86 constant+sigma
+    columns, the constraints of all 14 gate types, partial products and quotient computed by the prover, 4173 public inputs -- proven by
+    the HIP path and by the C oracle (run here, ~10-40 s of the host's cores) on the same seeded inputs: every word must agree, and the
+    serialised bytes (ivc_based_vpbs.rs:488 to_bytes) too.  A second instance (other seeds) so that this is not the frozen one."""
+    import regression_cases as rc
+    import step_oracle
+    B = rc.BENCH
+    log_n, nc, nr = B["log_n"], B["n_constants"], B["n_routed"]
+    inputs = synth.step_inputs(log_n, instance=3, cols=B["cols"])
+    inputs["quotient"] = None
+    pis = synth.field_elements(0xABCD + 3, B["n_public_inputs"])
+    sig = np.ascontiguousarray(inputs["constants_sigmas"][nc:nc + nr])
+    cs = ctx.commit_values(inputs["constants_sigmas"])
+    si = ctx.make_step_inputs(log_n, inputs["wires"], None, None, cs, B["digest"], pis, sigmas=sig, n_routed=nr, n_constants=nc,
+                              gates=api.GateSet(rc.GATES))
+    got = ctx.prove_step(si)
+    want = step_oracle.prove_step(inputs, B["digest"], pis, log_n, sigmas=sig, n_routed=nr, n_constants=nc, gates=go.GateSet(rc.GATES))
+    assert (cs.cap() == want["cs_cap"]).all()
+    for key in ("caps", "challenges", "openings", "fri"):
+        assert (np.asarray(got[key]).reshape(-1) == np.asarray(want[key]).reshape(-1)).all(), key
+    assert ctx.step_proof_to_bytes(si, nc, got) == step_oracle.to_bytes(want, want["ncols"], nc, pis, log_n)
+    cs.free()
 
 
 def test_gate_lanes_setting_does_not_change_the_proof(ctx):

@@ -339,7 +339,7 @@ def test_copy_constraint_proof_end_to_end(ctx, log_n):
         ok = orc.check_vanishing_at_zeta(w_z[:n_routed], cs_z[n_constants:], zs_all[:2], zs_next, zs_all[2:], q_z, log_n,
                                          [int(b) for b in betas], [int(g) for g in gammas], [int(a) for a in alphas], zeta)
         # the product's own host verifier must reach the same verdict (FRI alone is fine either way)
-        assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n)
+        assert api.verify_step_fri_only(proof, cs.cap(), ncols, DIGEST, pis, log_n)
         assert api.verify_step(proof, cs.cap(), ncols, DIGEST, pis, log_n, check_permutation=True, n_constants=n_constants,
                                n_routed=n_routed) == ok
         cs.free()
@@ -397,7 +397,7 @@ def test_step_proof_bit_exact(ctx, log_n, cols):
     if cols is None:   # standard column counts: the bytes parse back into the same proof, which the host verifier accepts
         back, back_pis = api.step_proof_from_bytes(blob, want["ncols"], log_n, n_constants)
         assert all((back[k].reshape(-1) == got[k].reshape(-1)).all() for k in ("caps", "openings", "fri")) and (back_pis == pis).all()
-        assert api.verify_step(back, want["cs_cap"], want["ncols"], DIGEST, back_pis, log_n)
+        assert api.verify_step_fri_only(back, want["cs_cap"], want["ncols"], DIGEST, back_pis, log_n)
 
 
 @pytest.mark.parametrize("log_n", [7, 12])
@@ -447,7 +447,7 @@ def test_step_properties_2pow17():
     c = vpbs_amd.Context(0, log_n_max=17)
     inputs, pis, cs, si, got = _step(c, log_n)
     assert step_oracle.verify_step(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
-    assert api.verify_step(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
+    assert api.verify_step_fri_only(got, cs.cap(), [85, 135, 20, 16], DIGEST, pis, log_n)
     cs.free()
     c.close()
 
@@ -460,7 +460,7 @@ def test_full_size_step_properties(ctx):
     inputs, pis, cs, si, got = _step(ctx, log_n)
     ncols = [85, 135, 20, 16]
     assert step_oracle.verify_step(got, cs.cap(), ncols, DIGEST, pis, log_n)
-    assert api.verify_step(got, cs.cap(), ncols, DIGEST, pis, log_n)     # the product's own verifier agrees
+    assert api.verify_step_fri_only(got, cs.cap(), ncols, DIGEST, pis, log_n)     # the product's own verifier agrees
     # determinism
     again = ctx.prove_step(si)
     assert (again["fri"] == got["fri"]).all() and (again["caps"] == got["caps"]).all()

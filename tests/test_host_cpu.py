@@ -169,7 +169,7 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
     ncols = proof["ncols"]
     assert ncols == [9, 12, 2, 16]
     assert step_oracle.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n)
-    assert api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n)
+    assert api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis, log_n)
     # random sigmas are not a permutation of the wires: the FRI part verifies, the vanishing identity does not
     assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n, check_permutation=True, n_constants=n_constants,
                                n_routed=n_routed)
@@ -177,8 +177,31 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
         bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in proof.items()}
         flat = bad[key].reshape(-1)
         flat[pos] = (int(flat[pos]) + 1) % P
-        assert not api.verify_step(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
-    assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs
+        assert not api.verify_step_fri_only(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
+    assert not api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs
+    # the default is the full check: without the circuit's shape it refuses instead of quietly running the FRI part alone
+    with pytest.raises(ValueError):
+        api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n)
+    # FRI configurations whose caps are taller than a tree of the proof are rejected as malformed (they used to underflow the path lengths)
+    for log_bad, cap_bad, rate_bad in ((3, 8, 3), (6, 8, 0), (4, 8, 3), (1, 5, 3)):
+        with pytest.raises(api.VpbsError):
+            api.verify_step_fri_only(proof, np.zeros((1 << cap_bad, 4), np.uint64), ncols, digest, pis, log_bad, rate_bits=rate_bad,
+                                     cap_height=cap_bad)
+        with pytest.raises(api.VpbsError):
+            api.step_proof_from_bytes(b"\0" * 64, ncols, log_bad, 1, rate_bits=rate_bad, cap_height=cap_bad)
+
+
+def test_fri_arities_follow_the_supplied_config():
+    """ConstantArityBits(4, 5) depends on rate_bits and cap_height: reduce while degree_bits > 5 and degree_bits + rate_bits - 4 >= cap_height"""
+    import oracle as orc
+    for log_n in range(1, 18):
+        p = api.fri_params(log_n)
+        assert [p.arity_bits[i] for i in range(p.n_rounds)] == list(orc.fri_params(log_n).arity_bits)[:p.n_rounds]
+        d, rounds = log_n, 0
+        while d > 5 and d + 3 - 4 >= 4:
+            d -= 4
+            rounds += 1
+        assert p.n_rounds == rounds
 
 
 def test_hash_chain_matches_oracle_and_reference_semantics():
@@ -230,7 +253,7 @@ def test_proof_bytes_round_trip_and_verify():
     for key in ("caps", "openings", "fri"):
         assert (proof[key].reshape(-1) == np.asarray(p[key], np.uint64).reshape(-1)).all(), key
     assert (pis == np.asarray(b["pis"], np.uint64)).all()
-    assert api.verify_step(proof, p["cs_cap"], ncols, rc.DIGEST, pis, b["log_n"])
+    assert api.verify_step_fri_only(proof, p["cs_cap"], ncols, rc.DIGEST, pis, b["log_n"])
     for bad in (blob[:-8], blob + b"\\0" * 8, blob[:len(blob) // 2]):
         with pytest.raises(api.VpbsError):
             api.step_proof_from_bytes(bad, ncols, b["log_n"], n_constants)

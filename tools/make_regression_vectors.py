@@ -46,9 +46,21 @@ def case_circuit(log_n, seed):
     return {"kind": "circuit", "log_n": log_n, "seed": seed}, p
 
 
+def case_bench():
+    """the instance bench.py times (tests/regression_cases.py BENCH): degree 2^16, 135/20/16/86 columns, 14 gate types, 4173 public inputs"""
+    import hashlib
+    import regression_cases as rc
+    b = rc.build({"kind": "bench", "log_n": rc.BENCH["log_n"]})
+    p = step_oracle.prove_step(b["inputs"], b["digest"], b["pis"], b["log_n"], sigmas=b["sigma"], n_routed=80, n_constants=b["n_constants"],
+                               gates=go.GateSet(GATES))
+    blob = step_oracle.to_bytes(p, p["ncols"], b["n_constants"], b["pis"], b["log_n"])
+    return {"kind": "bench", "log_n": b["log_n"], "cs_cap_sha256": sha(p["cs_cap"]), "bytes_sha256": hashlib.sha256(blob).hexdigest(),
+            "bytes_len": len(blob)}, p
+
+
 def main():
     out = []
-    for meta, p in [case_synthetic(5), case_synthetic(8), case_circuit(6, 4242), case_circuit(7, 777)]:
+    for meta, p in [case_synthetic(5), case_synthetic(8), case_circuit(6, 4242), case_circuit(7, 777), case_bench()]:
         meta.update({"caps_sha256": sha(p["caps"]), "openings_sha256": sha(p["openings"]), "fri_sha256": sha(p["fri"]),
                      "challenges": [int(x) for x in p["challenges"]], "pow_witness": int(p["fri"][-1]), "fri_words": int(p["fri"].size)})
         out.append(meta)

@@ -67,19 +67,42 @@ def main():
     bsk_h, lwe_h = [np.zeros(4, np.uint64)], [np.zeros(4, np.uint64)]
     hashed = threading.Condition()
     timing = {}
+    stop = threading.Event()      # set by the first worker that fails: every wait below polls it, so an error ends the run instead of hanging it
+
+    def fail(e):
+        errs.append(e)
+        stop.set()
+        with hashed:
+            hashed.notify_all()
+
+    def q_get(q):
+        while not stop.is_set():
+            try:
+                return q.get(timeout=0.2)
+            except queue.Empty:
+                continue
+        return None
 
     def hash_thread():
         """the native hash chains (verify_hash_output's sponge over every bootstrapping-key element): sequential by construction, 2.8 ms
         per step on one host core -- runs beside the device, the witness thread waits for the prefix its batch needs"""
         t = time.perf_counter()
-        for s in range(my_end):
-            hb = bsk_pre[s + 1] if bsk_pre else api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)]))
-            hl = api.hash_no_pad(np.concatenate([lwe_h[-1], np.array([masks[s]], np.uint64)]))
-            with hashed:
-                bsk_h.append(hb)
-                lwe_h.append(hl)
-                hashed.notify_all()
+        try:
+            for s in range(my_end):
+                if stop.is_set():
+                    return
+                hash_one(s)
+        except Exception as e:
+            fail(e)
         timing["hash"] = time.perf_counter() - t
+
+    def hash_one(s):
+        hb = bsk_pre[s + 1] if bsk_pre else api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)]))
+        hl = api.hash_no_pad(np.concatenate([lwe_h[-1], np.array([masks[s]], np.uint64)]))
+        with hashed:
+            bsk_h.append(hb)
+            lwe_h.append(hl)
+            hashed.notify_all()
 
     # The bootstrapping-key chain depends on the key only: a deployment computes it once per key.  With several GPUs it is taken as
     # given (otherwise rank r would wait r / N of the 2 s chain before its first witness); on one GPU it stays inside the clock.
@@ -118,9 +141,14 @@ def main():
             for first in range(my_first, my_end, batch):
                 count = min(batch, my_end - first)
                 with hashed:
-                    hashed.wait_for(lambda: len(bsk_h) > first + count - 1)
+                    while not hashed.wait_for(lambda: stop.is_set() or len(bsk_h) > first + count - 1, timeout=0.5):
+                        pass
+                if stop.is_set():
+                    break
                 vals = values(first, count)
-                k = free_obj.get()
+                k = q_get(free_obj)
+                if k is None:
+                    break
                 t = time.perf_counter()
                 wdev[k].run(vals)
                 wit_s.append(time.perf_counter() - t)
@@ -129,28 +157,30 @@ def main():
                 for i in range(count):
                     ready.put((k, i, first + i))
         except Exception as e:
-            errs.append(e)
+            fail(e)
         for _ in range(provers):
             ready.put(None)
 
     def prover(j):
         try:
             while True:
-                item = ready.get()
+                item = q_get(ready)
                 if item is None:
                     return
                 k, i, s = item
-                wdev[k].wires(i, d_wires[j].data_ptr())
-                pis = wdev[k].read(i, pi_pos)
-                with lock:
-                    outstanding[k] -= 1
-                    if outstanding[k] == 0:
-                        free_obj.put(k)
+                try:
+                    wdev[k].wires(i, d_wires[j].data_ptr())
+                    pis = wdev[k].read(i, pi_pos)
+                finally:      # the witness object goes back whether or not this instance could be read
+                    with lock:
+                        outstanding[k] -= 1
+                        if outstanding[k] == 0:
+                            free_obj.put(k)
                 si = pctx[j].make_step_inputs(b.log_n, d_wires[j].data_ptr(), None, None, css[j], digest, pis, on_device=True, shapes=(135, 20, 16),
                                               sigmas=int(d_sigma.data_ptr()), n_routed=80, n_constants=n_constants, gates=b.gates)
                 results[s] = (pctx[j].prove_step(si), pis)
         except Exception as e:
-            errs.append(e)
+            fail(e)
 
     torch.cuda.synchronize()
     if dist:
@@ -166,12 +196,12 @@ def main():
     for t in ts + [hasher]:
         t.join()
     t_mine = time.perf_counter() - t0
+    if errs:        # before any collective and before the chain-equality assertions
+        raise errs[0]
     if dist:
         dist.barrier()
     t_prove = time.perf_counter() - t0          # all ranks done
     t_hash = timing["hash"]
-    if errs:
-        raise errs[0]
     # the chain the proofs expose is the native one
     for s in range(my_first, my_end):
         pis = results[s][1]

@@ -80,7 +80,7 @@ class VerifyInputsC(C.Structure):
     _fields_ = [("log_n", C.c_uint), ("rate_bits", C.c_uint), ("cap_height", C.c_uint),
                 ("n_constants_sigmas", C.c_uint), ("n_wires", C.c_uint), ("n_zs_partial_products", C.c_uint), ("n_quotient", C.c_uint),
                 ("num_challenges", C.c_uint), ("constants_sigmas_cap", U64P), ("circuit_digest", C.c_uint64 * 4),
-                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("check_permutation", C.c_int),
+                ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("fri_only", C.c_int),
                 ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P),
                 ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
 
@@ -480,9 +480,16 @@ def hash_chain(items, claimed=None):
     return out, rc == 1
 
 
-def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=False, n_constants=0,
+def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=True, n_constants=0,
                 n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4, gates=None):
-    """Host-side verifier of the product library (plonky2 verify / verify_fri_proof).  True = accepted."""
+    """Host-side verifier of the product library (plonky2 `verify`: transcript, vanishing identity at zeta -- permutation argument and the
+    gate constraints, the PublicInputGate binding among them -- then verify_fri_proof).  True = accepted.  The full check is the default and
+    needs the circuit's shape: n_constants, n_routed and its gates (or gate_terms_zeta, or neither for a circuit of NoopGates only).
+    check_permutation=False (= verify_step_fri_only) checks the transcript, PoW, Merkle paths and the low-degree test ONLY: it accepts a
+    proof over unsatisfied wires, so it is a statement about the commitments, never about the circuit."""
+    if check_permutation and n_routed == 0:
+        raise ValueError("verify_step: the full check needs n_constants / n_routed (and the gates); for transcript + FRI only call "
+                         "verify_step_fri_only explicitly")
     v = VerifyInputsC()
     v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
     v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
@@ -494,7 +501,7 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     pi = _u64(public_inputs).reshape(-1)
     v.public_inputs = _ptr(pi)
     v.n_public_inputs = pi.size
-    v.check_permutation = 1 if check_permutation else 0
+    v.fri_only = 0 if check_permutation else 1
     v.n_constants, v.n_routed, v.quotient_degree_factor = n_constants, n_routed, quotient_degree_factor
     gt = _u64(gate_terms_zeta) if gate_terms_zeta is not None else None
     v.gate_terms_zeta = _ptr(gt) if gt is not None else None
@@ -505,6 +512,13 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     if rc < 0:
         raise VpbsError("vpbs_verify_step: malformed arguments (%d)" % rc)
     return rc == 1
+
+
+def verify_step_fri_only(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, rate_bits=3, cap_height=4):
+    """Transcript + PoW + Merkle paths + FRI low-degree test only (vpbs_verify_inputs.fri_only = 1): for proofs over synthetic columns
+    whose constraints are not meant to hold.  NOT a sound accept of a circuit."""
+    return verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=num_challenges, check_permutation=False,
+                       rate_bits=rate_bits, cap_height=cap_height)
 
 
 def step_proof_from_bytes(blob, ncols, log_n, n_constants, num_challenges=2, rate_bits=3, cap_height=4, max_public_inputs=1 << 16):

@@ -63,16 +63,30 @@ struct FriParams {
         for (unsigned a : reduction_arity_bits) d -= a;
         return d;
     }
-    // FriReductionStrategy::ConstantArityBits(4, 5) of standard_recursion_config
-    static FriParams standard(unsigned degree_bits) {
+    // FriReductionStrategy::ConstantArityBits(4, 5) of standard_recursion_config (fri/reduction_strategies.rs), evaluated with the
+    // rate_bits / cap_height the caller's FriConfig carries (the arities depend on both)
+    static FriParams standard(unsigned degree_bits, unsigned rate_bits = 3, unsigned cap_height = 4) {
         FriParams p;
+        p.config.rate_bits = rate_bits;
+        p.config.cap_height = cap_height;
         p.degree_bits = degree_bits;
         unsigned d = degree_bits;
-        while (d > 5 && d + p.config.rate_bits - 4 >= p.config.cap_height) {
+        while (d > 5 && d + rate_bits >= cap_height + 4) {
             p.reduction_arity_bits.push_back(4);
             d -= 4;
         }
         return p;
+    }
+    // every Merkle tree of the proof (initial trees over the LDE, one per reduction round) must be at least as tall as its cap
+    bool caps_fit() const {
+        unsigned lg = degree_bits + config.rate_bits;
+        if (config.cap_height > lg) return false;
+        for (unsigned a : reduction_arity_bits) {
+            if (a > lg) return false;
+            lg -= a;
+            if (config.cap_height > lg) return false;
+        }
+        return true;
     }
     static FriParams from_c(const vpbs_fri_params& c, unsigned degree_bits) {
         FriParams p;

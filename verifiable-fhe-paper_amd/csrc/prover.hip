@@ -664,7 +664,7 @@ int vpbs_gate_terms(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const vpbs
 
 int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_step_sizes* out) {
     if (!ctx || !in || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
-    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
+    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n, ctx->rate_bits, ctx->cap_height);
     const size_t n_cs = in->constants_sigmas->ncols;
     out->cap_words = (size_t)4 << ctx->cap_height;
     out->openings_words = 2 * (n_cs + in->n_wires + in->n_zs_partial_products + in->n_quotient + in->num_challenges);
@@ -794,9 +794,9 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         const Ext zeta_next = instance.batches[1].point;
         const unsigned chunks = (unsigned)((n + 4095) / 4096);
         u64* zpow = ctx->alloc_words(4 * n);
+        staged.push_back(zpow);   // on the cleanup list before the next allocation can throw
         u64* znpow = zpow + 2 * n;
         u64* d_open = ctx->alloc_words(2 * (total_cols + nc) * (size_t)(1 + chunks) + 64);
-        staged.push_back(zpow);
         staged.push_back(d_open);
         {
             Timed t(ctx, "openings_eval");
@@ -812,7 +812,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         // challenger.observe_openings(&openings.to_fri_openings()): zeta batch then zeta_next batch
         challenger.observe_elements(openings_out, 2 * (total_cols + nc));
 
-        FriParams fp = FriParams::standard(log_n);
+        FriParams fp = FriParams::standard(log_n, ctx->rate_bits, ctx->cap_height);
         PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out, comm);
         if (challenger_out) *challenger_out = challenger.st;
     });
@@ -832,7 +832,7 @@ int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpb
 long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants, const uint64_t* caps,
                               const uint64_t* openings, const uint64_t* fri, uint8_t* out, size_t cap_bytes) {
     if (!ctx || !in || !caps || !openings || !fri || !out || !in->constants_sigmas) return VPBS_ERR_INVALID;
-    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n);
+    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n, ctx->rate_bits, ctx->cap_height);
     const size_t n_cs = in->constants_sigmas->ncols;
     if (n_constants > n_cs) return VPBS_ERR_INVALID;
     size_t pos = 0;

@@ -115,16 +115,15 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     if (in->rate_bits > 3 || in->cap_height > 8 || in->log_n == 0 || in->log_n + in->rate_bits > 24 || in->num_challenges == 0 ||
         in->num_challenges > in->n_zs_partial_products)
         return VPBS_ERR_INVALID;
-    if (in->check_permutation) {
+    if (!in->fri_only) {
         const unsigned deg = in->quotient_degree_factor;
         if (deg == 0 || in->n_routed == 0 || in->n_routed > in->n_wires || in->n_constants + in->n_routed > in->n_constants_sigmas ||
             in->n_zs_partial_products != in->num_challenges * ((in->n_routed + deg - 1) / deg) ||
             in->n_quotient != (in->num_challenges << in->rate_bits))
             return VPBS_ERR_INVALID;
     }
-    FriParams fp = FriParams::standard(in->log_n);
-    fp.config.rate_bits = in->rate_bits;
-    fp.config.cap_height = in->cap_height;
+    const FriParams fp = FriParams::standard(in->log_n, in->rate_bits, in->cap_height);
+    if (!fp.caps_fit()) return VPBS_ERR_INVALID;
     const unsigned nc = in->num_challenges, log_n = in->log_n;
     const unsigned log_lde = log_n + in->rate_bits;
     const size_t lde = (size_t)1 << log_lde, cap_words = (size_t)4 << in->cap_height;
@@ -145,7 +144,7 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     ch.observe_cap(caps + 2 * cap_words, cap_words / 4);
     const Ext zeta = ch.get_extension_challenge();
     ch.observe_elements(openings, 2 * (total_cols + nc));
-    if (in->check_permutation) {
+    if (!in->fri_only) {
         // eval_vanishing_poly: the gate constraints at zeta come from the openings of the constants and the wires
         const u64* gate_terms = in->gate_terms_zeta;
         std::vector<u64> gt(2 * (size_t)nc);
@@ -261,9 +260,9 @@ extern "C" long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const u
     if (!in || !bytes || !caps || !openings || !fri || in->n_constants > in->n_constants_sigmas || in->num_challenges > in->n_zs_partial_products)
         return VPBS_ERR_INVALID;
     using namespace plonky2;
-    FriParams fp = FriParams::standard(in->log_n);
-    fp.config.rate_bits = in->rate_bits;
-    fp.config.cap_height = in->cap_height;
+    if (in->rate_bits > 3 || in->cap_height > 8 || in->log_n == 0 || in->log_n + in->rate_bits > 24) return VPBS_ERR_INVALID;
+    const FriParams fp = FriParams::standard(in->log_n, in->rate_bits, in->cap_height);
+    if (!fp.caps_fit()) return VPBS_ERR_INVALID;
     size_t pos = 0;
     bool bad = false;
     auto get_words = [&](uint64_t* w, size_t cnt) {

@@ -1402,6 +1402,8 @@ int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const ui
     vpbs_ctx* ctx = d->ctx;
     std::lock_guard<std::mutex> lock(d->mu);
     if (instance >= d->batch) return VPBS_ERR_INVALID;
+    vpbs::u32* d_slots = nullptr;
+    vpbs::u64* d_out = nullptr;
     try {
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
@@ -1418,8 +1420,8 @@ int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const ui
             }
         }
         if (count == 0) return VPBS_OK;
-        u32* d_slots = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32) * count));
-        u64* d_out = ctx->alloc_words(count);
+        d_slots = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32) * count));
+        d_out = ctx->alloc_words(count);
         VPBS_HIP(hipMemcpyAsync(d_slots, slots.data(), sizeof(u32) * count, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d_slots, (u32)count, d->batch,
                            instance, d_out);
@@ -1430,6 +1432,9 @@ int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const ui
         for (size_t i : missing) out[i] = 0;
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
+        hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
+        if (d_slots) ctx->release(d_slots);
+        if (d_out) ctx->release(d_out);
         ctx->err = e.what;
         return e.status;
     }
