@@ -47,15 +47,19 @@ N_CONSTANTS, N_ROUTED = 6, 80   # constants_sigmas = 4 selectors + 2 gate consta
 N_PUBLIC_INPUTS = 4173
 COLS = dict(synth.STEP_COLS, constants_sigmas=N_CONSTANTS + N_ROUTED)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# VALU issue ceiling: a wave64 instruction occupies a 16-lane SIMD for 4 cycles (measured 4.1-4.2 for integer multiply / VOP3 / carry
-# ops AND for v_fma_f32 / v_fma_f64, profiles/r01_microbench_valu.txt; only trivial VOP2 integer ops and packed fp32 go faster):
-# 256 CUs x 4 SIMD x 16 lanes/clk x 2.4 GHz
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py)
-# measured issue cost of the kernel's instruction mix on gfx950 (profiles/r01_microbench_valu.txt): half v_mad_u64_u32 at 4.61 cycles
-# per wave64, half other integer VALU (carry adds 4.56, cndmask / 64-bit shifts 4.2); shader clock under this load 2.39 GHz
-# (tools/sample_clocks.sh)
-INT_CYCLES_PER_INSTR, SCLK_HZ = 0.5 * 4.61 + 0.5 * 4.35, 2.39e9
+# VALU ceilings, measured on gfx950 with tools/microbench_valu2.hip (profiles/r02_microbench_valu2.txt: distinct source registers per
+# chain, in-kernel s_memtime / s_memrealtime, exact waves per SIMD, per-SIMD spans):
+#  * v_fma_f32, v_add_u32, v_xor_b32: 2.24-2.27 cycles per wave64 instruction at 8 waves per SIMD -- the SIMD-32 rate of
+#    MI355X_MICROARCH.md (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s).  (Round 1's harness read one VGPR for two operands
+#    and reported 4.13 for v_fma_f32: wrong.)
+#  * every instruction the Poseidon / NTT arithmetic is made of -- v_mad_u64_u32, v_mul_lo/hi_u32, carry adds (v_add_co / v_addc_co),
+#    v_cndmask_b32_e64, 64-bit shifts, three-operand integer VOP3 -- runs at HALF that rate: 4.15-4.26 cycles at 8 waves per SIMD,
+#    4.3-4.5 at 4 waves per SIMD (the occupancy of the leaf-hash kernel), 4.6-5.1 at 2, 5.5-6.75 for a lone wave.
+# valu_frac prices the kernel against the fp32 rate (what the guide calls the vector peak); int_issue_frac against the best rate the
+# integer multiply-add path was seen to sustain (4.2 cycles, 8 waves per SIMD), so it cannot exceed 1 by construction of the ceiling.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py; SQ_INSTS_VALU: 15358)
+INT_CYCLES_PER_INSTR, SCLK_HZ = 4.2, 2.39e9   # shader clock under this load: rocm-smi 2.39 GHz; the microbenchmark's waves measured 2.33-2.41
 
 
 def leaf_hash_bytes_per_step(log_n=LOG_N):
@@ -541,9 +545,11 @@ def main():
         perms = leaf_hash_perms_per_step(log_n) * scale
         valu_rate = perms * LEAF_HASH_INSTR_PER_PERM / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_leaf_hash.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
+        for tname in ("r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
+                break
         out = {
             "metric": "vPBS proofs/sec at N=1024", "value": step_rate / STEPS_PER_VPBS, "unit": "vPBS proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -570,13 +576,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms_per_step": per_step_ms, "launches": dominant["count"],
-                         "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation; valu_* = achieved "
-                                 "lane-ops/s vs 256CU*4SIMD*16 lanes*2.4GHz" % LEAF_HASH_INSTR_PER_PERM,
+                         "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation, half of them v_mad_u64_u32.  valu_frac = "
+                                 "achieved lane-ops/s vs the fp32-FMA rate 256CU*4SIMD*32 lanes*2.4GHz (MI355X_MICROARCH.md); the "
+                                 "integer multiply-add / carry / VOP3 instructions of this kernel issue at half that rate on gfx950 "
+                                 "(profiles/r02_microbench_valu2.txt), int_issue_frac = against that measured rate" % LEAF_HASH_INSTR_PER_PERM,
+                         "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections "
+                                           "applied); not re-measured inside this run",
                          "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
                          "valu_achieved_tlaneops": valu_rate, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS,
                          "valu_frac": valu_rate / VALU_PEAK_TLANEOPS,
-                         # the same instruction stream priced at the MEASURED per-instruction issue costs of integer VALU on gfx950
-                         # (the fp32-FMA rate above is not reachable by integer VOP3 / v_mad_u64_u32): ~1.0 = no issue slack left
+                         # the same instruction stream priced at the best MEASURED issue rate of integer multiply-add / carry / VOP3
+                         # instructions on gfx950 (4.2 cycles per wave64 instruction at 8 waves per SIMD)
                          "int_issue_frac": (perms * LEAF_HASH_INSTR_PER_PERM / (256 * 4 * 64) * INT_CYCLES_PER_INSTR / SCLK_HZ)
                                            / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0},
             "kernel_ms_one_step": breakdown,

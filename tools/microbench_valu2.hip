@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <array>
+#include <map>
 #include <vector>
 
 #define CHECK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); return 1; } } while (0)
@@ -23,6 +25,7 @@ constexpr int REPS = 4;        // each chain advanced REPS times per loop iterat
 
 struct Stamp {
     uint64_t c0, c1, r0, r1;
+    uint32_t hw_id, xcc_id;   // HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE) and HW_REG_XCC_ID: which SIMD of the chip ran the wave
 };
 
 extern __shared__ uint32_t lds_pin[];
@@ -44,7 +47,7 @@ extern __shared__ uint32_t lds_pin[];
     uint32_t acc = 0; \
     for (int i = 0; i < CHAINS; ++i) acc ^= a[i] ^ b[i] ^ c[i] ^ d[i] ^ (uint32_t)q[i] ^ (uint32_t)(q[i] >> 32) ^ (uint32_t)q2[i] ^ (uint32_t)q3[i]; \
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc; \
-    if ((threadIdx.x & 63) == 0) stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{c0, c1, r0, r1};
+    if ((threadIdx.x & 63) == 0) stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{c0, c1, r0, r1, __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11))};
 
 #define EACH(...) _Pragma("unroll") for (int r = 0; r < REPS; ++r) { _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) { __VA_ARGS__; } }
 
@@ -113,8 +116,12 @@ int main() {
     CHECK(hipMalloc(&d_out, max_threads * 4));
     CHECK(hipMalloc(&d_st, max_threads / 64 * sizeof(Stamp)));
     std::vector<Stamp> st(max_threads / 64);
-    printf("%-30s", "cycles per wave64 instr per SIMD");
-    for (int w : ws) printf("  w=%d/SIMD", w);
+    hipEvent_t ev0, ev1;
+    CHECK(hipEventCreate(&ev0));
+    CHECK(hipEventCreate(&ev1));
+    printf("cycles of one SIMD per wave64 instruction: in-kernel span of the SIMD's waves / from the HIP-event time of the launch\n");
+    printf("%-30s", "");
+    for (int w : ws) printf("  w=%d per SIMD", w);
     printf("   sclk(GHz)\n");
     for (const Entry& e : es) {
         printf("%-30s", e.name);
@@ -126,27 +133,53 @@ int main() {
             const size_t lds = w <= 4 ? 96 * 1024 : 64 * 1024;
             CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int blocks = cus * per_cu;
-            double best = 1e30;
+            double best = 1e30, evt = 0;
             for (int rep = 0; rep < 4; ++rep) {
+                CHECK(hipEventRecord(ev0));
                 hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), lds, 0, d_out, d_st, 7u + rep);
+                CHECK(hipEventRecord(ev1));
                 CHECK(hipDeviceSynchronize());
+                float ms = 0;
+                CHECK(hipEventElapsedTime(&ms, ev0, ev1));
                 const size_t waves = (size_t)blocks * threads / 64;
                 CHECK(hipMemcpy(st.data(), d_st, waves * sizeof(Stamp), hipMemcpyDeviceToHost));
-                // median over waves of the wave's own cycle count
-                std::vector<double> cyc(waves), clk(waves);
+                // group the waves by the SIMD that ran them (XCC, SE, SH, CU, SIMD): one SIMD's throughput = the instructions of all its
+                // waves / the span from its first start to its last end (s_memtime of one SIMD's waves is one clock domain); waves of a
+                // SIMD need not run in lock-step (issue arbitration prefers the older wave), so a per-wave time would mislead
+                std::map<uint64_t, std::array<double, 4>> simd;   // key -> {min c0, max c1, waves, sum of per-wave clock}
                 for (size_t i = 0; i < waves; ++i) {
-                    cyc[i] = (double)(st[i].c1 - st[i].c0);
-                    clk[i] = cyc[i] / ((double)(st[i].r1 - st[i].r0) * 10.0);   // s_memrealtime ticks at 100 MHz = 10 ns
+                    const uint32_t h = st[i].hw_id;
+                    const uint64_t key = ((uint64_t)(st[i].xcc_id & 0xF) << 32) | (h & 0xFF30);   // se_id[15:13] sh_id[12] cu_id[11:8] simd_id[5:4]
+                    auto it = simd.find(key);
+                    const double clk = (double)(st[i].c1 - st[i].c0) / ((double)(st[i].r1 - st[i].r0) * 10.0);   // s_memrealtime: 100 MHz
+                    if (it == simd.end()) simd[key] = {(double)st[i].c0, (double)st[i].c1, 1.0, clk};
+                    else {
+                        it->second[0] = std::min(it->second[0], (double)st[i].c0);
+                        it->second[1] = std::max(it->second[1], (double)st[i].c1);
+                        it->second[2] += 1.0;
+                        it->second[3] += clk;
+                    }
                 }
-                std::nth_element(cyc.begin(), cyc.begin() + waves / 2, cyc.end());
-                std::nth_element(clk.begin(), clk.begin() + waves / 2, clk.end());
-                const double per_instr = cyc[waves / 2] / ((double)ITERS * CHAINS * REPS * e.instr_per_body * w);
+                std::vector<double> per, clks;
+                size_t uneven = 0;
+                for (auto& kv : simd) {
+                    if ((int)kv.second[2] != w) ++uneven;
+                    per.push_back((kv.second[1] - kv.second[0]) / ((double)ITERS * CHAINS * REPS * e.instr_per_body * kv.second[2]));
+                    clks.push_back(kv.second[3] / kv.second[2]);
+                }
+                std::nth_element(per.begin(), per.begin() + per.size() / 2, per.end());
+                std::nth_element(clks.begin(), clks.begin() + clks.size() / 2, clks.end());
+                const double per_instr = per[per.size() / 2];
+                if (rep == 1 && (simd.size() != (size_t)cus * 4 || uneven)) printf("[%zu SIMDs seen, %zu without exactly %d waves] ", simd.size(), uneven, w);
                 if (rep > 0 && per_instr < best) {
                     best = per_instr;
-                    ghz = clk[waves / 2];
+                    ghz = clks[clks.size() / 2];
+                    // cross-check from outside the kernel: HIP-event time of the whole launch (launch overhead and tail included) at the
+                    // clock the waves measured
+                    evt = ms * 1e-3 * ghz * 1e9 / ((double)ITERS * CHAINS * REPS * e.instr_per_body * w);
                 }
             }
-            printf("  %8.2f", best);
+            printf("  %5.2f/%5.2f", best, evt);
         }
         printf("   %8.3f\n", ghz);
     }

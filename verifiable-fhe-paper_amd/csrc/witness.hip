@@ -1432,7 +1432,7 @@ int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const ui
         for (size_t i : missing) out[i] = 0;
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
-        hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
+        (void)hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
         if (d_slots) ctx->release(d_slots);
         if (d_out) ctx->release(d_out);
         ctx->err = e.what;
