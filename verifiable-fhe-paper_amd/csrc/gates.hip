@@ -222,6 +222,82 @@ void launch_one(hipStream_t s, const u64* wires, const u64* consts, size_t len, 
                            pih, out, accumulate);
 }
 
+// ---- all gates in ONE launch (the default path) ----
+// The per-gate launches above make every gate re-read its wires from HBM (the 135 wire columns are touched 7.6 times between them, and each
+// launch read-modify-writes the output).  Here a launch covers (point tile x work item): an item is a group of gates evaluated one after the
+// other by the same thread, and the blocks of one tile are numbered so that they are dispatched back to back to the SAME XCD (workgroups go
+// round-robin over the 8 XCDs): the tile's columns are fetched into that XCD's L2 once and the other items of the tile hit there (or in the
+// memory-side cache) instead of HBM.  Every item writes its own output plane [nc][len] exactly once (no read-modify-write); the caller sums
+// the planes (quotient_combine_kernel / sum_planes_kernel).
+constexpr unsigned FUSED_MAX_GATES = 20, FUSED_MAX_ITEMS = 8, FUSED_TILE = THREADS;
+struct FusedPlan {
+    vpbs_gate gates[FUSED_MAX_GATES];  // ordered by item
+    gates::CosetTables tables;         // the CosetInterpolationGate's domain / weights (at most one such gate per plan)
+    unsigned item_first[FUSED_MAX_ITEMS + 1];
+    unsigned n_items;
+};
+template <int NC>
+__global__ void __launch_bounds__(THREADS, 4)   // 4 waves per SIMD: at most 128 VGPRs
+gate_fused_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, FusedPlan plan, unsigned num_selectors,
+                  const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out, int xcd_map) {
+    unsigned tile, item;
+    if (xcd_map) {  // block b runs on XCD b % 8: consecutive blocks OF ONE XCD are the items of one tile
+        const unsigned xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        item = i % plan.n_items;
+        tile = (i / plan.n_items) * 8 + xcd;
+    } else {
+        tile = blockIdx.x / plan.n_items;
+        item = blockIdx.x % plan.n_items;
+    }
+    const size_t j = (size_t)tile * FUSED_TILE + threadIdx.x;
+    if (j >= len) return;
+    u64 total[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) total[a] = 0;
+    for (unsigned gi = plan.item_first[item]; gi < plan.item_first[item + 1]; ++gi) {
+        const vpbs_gate& g = plan.gates[gi];
+        // the point index is made opaque per gate: otherwise the column addresses (the same for every gate) are hoisted out of the loop
+        // as loop invariants and live across all the cases (235 VGPRs instead of ~100)
+        size_t jj = j;
+        asm volatile("" : "+v"(jj));
+        DevVars v{wires, consts + (size_t)num_selectors * len, len, jj, pih};
+        DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
+        switch (g.kind) {  // wave-uniform
+#define VPBS_FUSED_CASE(K) case K: eval_kind<K>(g, plan.tables, v, s); break;
+            VPBS_FUSED_CASE(VPBS_GATE_CONSTANT)
+            VPBS_FUSED_CASE(VPBS_GATE_PUBLIC_INPUT)
+            VPBS_FUSED_CASE(VPBS_GATE_ARITHMETIC)
+            VPBS_FUSED_CASE(VPBS_GATE_BASE_SUM)
+            VPBS_FUSED_CASE(VPBS_GATE_POSEIDON)
+            VPBS_FUSED_CASE(VPBS_GATE_POSEIDON_MDS)
+            VPBS_FUSED_CASE(VPBS_GATE_ARITHMETIC_EXT)
+            VPBS_FUSED_CASE(VPBS_GATE_MUL_EXT)
+            VPBS_FUSED_CASE(VPBS_GATE_REDUCING)
+            VPBS_FUSED_CASE(VPBS_GATE_REDUCING_EXT)
+            VPBS_FUSED_CASE(VPBS_GATE_RANDOM_ACCESS)
+            VPBS_FUSED_CASE(VPBS_GATE_EXPONENTIATION)
+            VPBS_FUSED_CASE(VPBS_GATE_COSET_INTERPOLATION)
+#undef VPBS_FUSED_CASE
+            default: break;
+        }
+        const u64 filter = gates::compute_filter<u64>(g, consts[(size_t)g.selector_index * len + jj], num_selectors > 1);
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if ((unsigned)a < nc) total[a] = gl::add(total[a], gl::mul(filter, s.acc[a].reduce()));
+    }
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+        if ((unsigned)a < nc) out[((size_t)item * nc + a) * len + j] = total[a];
+}
+
+__global__ void sum_planes_kernel(const u64* __restrict__ planes, unsigned n_planes, size_t words, u64* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    u64 r = planes[i];
+    for (unsigned p = 1; p < n_planes; ++p) r = gl::add(r, planes[(size_t)p * words + i]);
+    out[i] = r;
+}
+
 // ---- host: Gate::id() strings, derived parameters, sorting ----
 const char* const FIELD = "plonky2_field::goldilocks_field::GoldilocksField";
 std::string gate_id(const vpbs_gate& g) {
@@ -406,6 +482,70 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
                                used[2] ? out[2] : (const u64*)nullptr, words);
         }
     }
+}
+
+// Work items of the one-launch path: the gates with constraints, heaviest first, packed into n_items groups of about equal weight (the
+// PoseidonGate is an item by itself).  Fewer items = fewer output planes; more items = more blocks sharing one tile's columns in L2.
+// Returns false when the gate set does not fit the plan (more gates than FUSED_MAX_GATES, or two CosetInterpolationGates).
+static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, FusedPlan& plan) {
+    std::vector<unsigned> order;
+    unsigned n_coset = 0, total = 0, heaviest = 1;
+    for (unsigned i = 0; i < n_gates; ++i) {
+        if (!gs[i].num_constraints) continue;
+        order.push_back(i);
+        total += gate_weight(gs[i]);
+        heaviest = std::max(heaviest, gate_weight(gs[i]));
+        if (gs[i].kind == VPBS_GATE_COSET_INTERPOLATION) {
+            if (n_coset++) return false;
+            plan.tables = gates::coset_tables(gs[i].p0);
+        }
+    }
+    if (order.empty() || order.size() > FUSED_MAX_GATES) return false;
+    static const unsigned max_items = [] { const char* e = getenv("VPBS_GATE_ITEMS"); return e ? (unsigned)atoi(e) : 5u; }();
+    const unsigned n_items = std::max(1u, std::min({(unsigned)order.size(), (total + heaviest - 1) / heaviest, max_items, FUSED_MAX_ITEMS}));
+    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return gate_weight(gs[a]) > gate_weight(gs[b]); });
+    std::vector<std::vector<unsigned>> bins(n_items);
+    std::vector<unsigned> load(n_items, 0);
+    for (unsigned i : order) {
+        const unsigned b = (unsigned)(std::min_element(load.begin(), load.end()) - load.begin());
+        bins[b].push_back(i);
+        load[b] += gate_weight(gs[i]);
+    }
+    unsigned k = 0;
+    for (unsigned b = 0; b < n_items; ++b) {
+        plan.item_first[b] = k;
+        for (unsigned i : bins[b]) plan.gates[k++] = gs[i];
+    }
+    plan.item_first[n_items] = k;
+    plan.n_items = n_items;
+    return true;
+}
+
+unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates) {
+    FusedPlan plan{};
+    return make_fused_plan(gs, n_gates, plan) ? plan.n_items : 0;
+}
+
+// d_planes: [n_items][nc][len]; returns the number of planes written (0: the gate set does not fit the one-launch path, nothing launched)
+unsigned launch_gate_terms_fused(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
+                                 unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes) {
+    FusedPlan plan{};
+    if (!make_fused_plan(gs, n_gates, plan)) return 0;
+    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+    const unsigned n_tiles = (unsigned)((len + FUSED_TILE - 1) / FUSED_TILE);
+    const int xcd_map = n_tiles % 8 == 0;
+    const dim3 grid(n_tiles * plan.n_items);
+    if (nc <= 2)
+        hipLaunchKernelGGL((gate_fused_kernel<2>), grid, dim3(THREADS), 0, s, wires_lde, consts_lde, len, plan, num_selectors, d_apow, pow_stride, nc, pih,
+                           d_planes, xcd_map);
+    else
+        hipLaunchKernelGGL((gate_fused_kernel<4>), grid, dim3(THREADS), 0, s, wires_lde, consts_lde, len, plan, num_selectors, d_apow, pow_stride, nc, pih,
+                           d_planes, xcd_map);
+    return plan.n_items;
+}
+
+void launch_sum_planes(hipStream_t s, const u64* d_planes, unsigned n_planes, size_t words, u64* d_out) {
+    hipLaunchKernelGGL(sum_planes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, d_planes, n_planes, words, d_out);
 }
 
 // checks a laid-out gate list against the batches it will be evaluated on

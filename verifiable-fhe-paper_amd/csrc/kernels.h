@@ -52,6 +52,8 @@ void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigm
                             size_t local_len, u64* q_leaf_local, bool raw = false);
 // raw = true leaves out the gate terms and the division by Z_H; this joins them in afterwards:
 // q <- (q + alpha_a^(n_terms) (g0 + g1 + g2)) / Z_H   (g*: [nc][local_len] gate-term lanes, null = unused; apow_last: host [nc])
+void launch_quotient_combine_planes(hipStream_t s, u64* q_local, const u64* planes, unsigned n_planes, const u64* apow_last, unsigned log_n,
+                                    unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len);
 void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u64* g1, const u64* g2, const u64* apow_last, unsigned log_n,
                              unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len);
 // phase 2: q_gathered is rank-major [world][nc][local_len] (world * local_len = 8n); q_nat, scratch: [nc][8n]
@@ -78,6 +80,13 @@ struct GateLanes {
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                        unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
                        GateLanes* lanes = nullptr);
+// The same sum in ONE launch over (point tile x work item) with an XCD-aware block numbering (gates.hip): every item writes its own plane
+// d_planes[item][nc][len]; the sum over the planes is the value launch_gate_terms would produce.  gate_terms_planes: how many planes the gate
+// set needs (0 = not supported by this path, use launch_gate_terms).
+unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates);
+unsigned launch_gate_terms_fused(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
+                                 unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes);
+void launch_sum_planes(hipStream_t s, const u64* d_planes, unsigned n_planes, size_t words, u64* d_out);
 // throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
 void validate_gates(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned n_constants_cols, unsigned n_wires);
 // host, GF(p^2): the same folded sum at one point from openings ([..][2] arrays); out [nc][2]

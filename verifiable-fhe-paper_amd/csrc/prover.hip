@@ -333,6 +333,12 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
     VPBS_REQUIRE(flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
 }
 
+// the one-launch gate kernel (gates.hip) is the default; VPBS_GATES_FUSED=0 selects the per-gate launches (kept for comparison)
+static bool gates_fused_enabled() {
+    static const bool on = [] { const char* e = getenv("VPBS_GATES_FUSED"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 // evaluate_gate_constraints_base_batch folded with the alphas, on the device; d_out: [nc][local LDE length]
 void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors,
                        const u64 pi_hash[4], const u64* alphas, unsigned nc, u64* d_out) {
@@ -357,6 +363,26 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
     const bool multi = !env_single && ctx->gate_lanes == 3;
     const size_t len = wires->lde_len();
     u64* lane_buf = nullptr;
+    const unsigned n_planes = gates_fused_enabled() ? vpbs::gate_terms_planes(gs, n_gates) : 0;
+    if (n_planes) {  // one launch over (tile x item), then the sum of the items' planes
+        u64* planes = nullptr;
+        try {
+            planes = ctx->alloc_words((size_t)n_planes * nc * len);
+            VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
+            Timed t(ctx, "gate_constraints");
+            vpbs::launch_gate_terms_fused(ctx->stream, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, planes);
+            vpbs::launch_sum_planes(ctx->stream, planes, n_planes, (size_t)nc * len, d_out);
+            VPBS_HIP(hipGetLastError());
+        } catch (...) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->release(d_apow);
+            if (planes) ctx->release(planes);
+            throw;
+        }
+        ctx->release(d_apow);
+        ctx->release(planes);
+        return;
+    }
     try {
         VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
         vpbs::GateLanes lanes{};
@@ -459,9 +485,27 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                 }
             }
             d_gpow = ctx->alloc_words(h_gpow.size());
-            lane_buf = ctx->alloc_words(3 * (size_t)nc * local_len);
+            const unsigned n_planes = gates_fused_enabled() ? vpbs::gate_terms_planes(gw->gates, gw->n_gates) : 0;
+            lane_buf = ctx->alloc_words(std::max(3u, n_planes) * (size_t)nc * local_len);
             VPBS_HIP(hipMemcpyAsync(d_gpow, h_gpow.data(), sizeof(u64) * h_gpow.size(), hipMemcpyHostToDevice, s));
             ctx->ensure_gate_lanes();
+            u64 apow_last[4] = {0, 0, 0, 0};
+            for (unsigned a = 0; a < nc; ++a) apow_last[a] = h_apow[(size_t)a * (n_terms + 1) + n_terms];
+            if (n_planes) {
+                // every gate in ONE launch on the context's stream; the permutation part (reads the sigma and Z columns, few
+                // instructions) runs beside it on a helper stream; quotient_combine joins the two
+                Timed t(ctx, "gate_constraints");
+                VPBS_HIP(hipEventRecord(ctx->gate_fork, s));
+                VPBS_HIP(hipStreamWaitEvent(ctx->gate_streams[0], ctx->gate_fork, 0));
+                vpbs::launch_quotient_values(ctx->gate_streams[0], wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde,
+                                             ctx->roots(log_big, false), l0, nullptr, d_apow, betas, gammas, n_routed, log_n, rate_bits, max_degree, nc,
+                                             leaf_offset, local_len, q_local, true);
+                VPBS_HIP(hipEventRecord(ctx->gate_join[0], ctx->gate_streams[0]));
+                vpbs::launch_gate_terms_fused(s, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride,
+                                              nc, lane_buf);
+                VPBS_HIP(hipStreamWaitEvent(s, ctx->gate_join[0], 0));
+                vpbs::launch_quotient_combine_planes(s, q_local, lane_buf, n_planes, apow_last, log_n, rate_bits, nc, leaf_offset, local_len);
+            } else {
             QuotientValuesCall call{wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde, ctx->roots(log_big, false), l0, d_apow,
                                     betas, gammas, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_local};
             vpbs::GateLanes lanes{};
@@ -476,13 +520,12 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
             lanes.extra_arg = &call;
             lanes.extra_weight = 165;
             lanes.skip_sum = true;
-            u64 apow_last[4] = {0, 0, 0, 0};
-            for (unsigned a = 0; a < nc; ++a) apow_last[a] = h_apow[(size_t)a * (n_terms + 1) + n_terms];
             Timed t(ctx, "gate_constraints");  // gates + permutation part, overlapped
             vpbs::launch_gate_terms(s, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride, nc,
                                     lane_buf, &lanes);
             vpbs::launch_quotient_combine(s, q_local, lanes.used[0] ? lane_buf : nullptr, lanes.used[1] ? lanes.out[0] : nullptr,
                                           lanes.used[2] ? lanes.out[1] : nullptr, apow_last, log_n, rate_bits, nc, leaf_offset, local_len);
+            }
         } else {
             Timed t(ctx, "quotient_permutation");
             vpbs::launch_quotient_values(s, wires->d_lde, cs->d_lde + (size_t)n_constants * local_len, zs_pp->d_lde, ctx->roots(log_big, false), l0,

@@ -143,6 +143,20 @@ quotient_combine_kernel(u64* __restrict__ q, const u64* __restrict__ g0, const u
     q[i] = gl::mul(gl::add(q[i], gl::mul(g, k.apow_last[a])), k.zh_inv[t & ((1u << rate_bits) - 1)]);
 }
 
+// the same with the gate terms as n_planes planes [plane][nc][local_len] (the one-launch gate kernel's items)
+__global__ void __launch_bounds__(THREADS)
+quotient_combine_planes_kernel(u64* __restrict__ q, const u64* __restrict__ planes, unsigned n_planes, CombineConsts k, unsigned log_big,
+                               unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len) {
+    const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    if (j >= local_len) return;
+    const unsigned a = blockIdx.y;
+    const unsigned t = gl::bitrev32((u32)(leaf_offset + j), log_big);
+    const size_t i = (size_t)a * local_len + j, plane = (size_t)nc * local_len;
+    u64 g = planes[i];
+    for (unsigned p = 1; p < n_planes; ++p) g = gl::add(g, planes[p * plane + i]);
+    q[i] = gl::mul(gl::add(q[i], gl::mul(g, k.apow_last[a])), k.zh_inv[t & ((1u << rate_bits) - 1)]);
+}
+
 // out[a][t] = value of challenge a at leaf bitrev(t)  (leaf order -> natural order).  `in` is rank-major
 // [world][nc][local_len] (the layout an all-gather of per-rank [nc][local_len] buffers produces; world = 1: [nc][len]).
 __global__ void bitrev_copy_kernel(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_len, size_t local_len, unsigned nc) {
@@ -203,6 +217,16 @@ void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u
     for (unsigned a = 0; a < nc; ++a) k.apow_last[a] = apow_last[a];
     hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((local_len + THREADS - 1) / THREADS), nc), dim3(THREADS), 0, s, q_local, g0, g1, g2, k,
                        log_n + rate_bits, rate_bits, leaf_offset, local_len);
+}
+
+void launch_quotient_combine_planes(hipStream_t s, u64* q_local, const u64* planes, unsigned n_planes, const u64* apow_last, unsigned log_n,
+                                    unsigned rate_bits, unsigned nc, size_t leaf_offset, size_t local_len) {
+    const QuotientConsts qc = make_consts(log_n, rate_bits);
+    CombineConsts k{};
+    for (unsigned r = 0; r < 8; ++r) k.zh_inv[r] = qc.zh_inv[r];
+    for (unsigned a = 0; a < nc; ++a) k.apow_last[a] = apow_last[a];
+    hipLaunchKernelGGL(quotient_combine_planes_kernel, dim3((unsigned)((local_len + THREADS - 1) / THREADS), nc), dim3(THREADS), 0, s, q_local, planes,
+                       n_planes, k, log_n + rate_bits, rate_bits, nc, leaf_offset, local_len);
 }
 
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
