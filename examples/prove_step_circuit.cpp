@@ -9,7 +9,8 @@
 //   vpbs_verify_step                                                       (host)
 // File format (little-endian u64 words): header {magic, log_n, n_wires, n_routed, n_gates, n_constants_cols, n_copies, n_generators,
 // generator_words, n_preset, n_public_inputs}; gates [n_gates][kind, p0, p1, p2]; row_gate [n]; constants [cols][n]; copies [n_copies][2];
-// generators {kind, p0, n_in, n_out, in.., out..}*; preset positions; public-input positions; sample preset values; expected public inputs.
+// generators {kind, p0, n_in, n_out, in.., out..}*; preset positions; public-input positions; sample preset values; expected public inputs;
+// optional trailer {N, K, ELL, LOGB, n_lwe, used_rows}.
 //   build: g++ -O2 -std=c++17 -I include examples/prove_step_circuit.cpp -L verifiable-fhe-paper_amd -lvpbs_hip \
 //              -Wl,-rpath,$PWD/verifiable-fhe-paper_amd -o examples/prove_step_circuit
 //   run  : python tools/export_step_circuit.py /tmp/step.bin 8 2 4 5 6 && examples/prove_step_circuit /tmp/step.bin
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
     };
     const uint64_t *f_gates = take(4 * n_gates), *f_rows = take(n), *f_consts = take((size_t)n_const_cols * n), *f_copies = take(2 * n_copies),
                    *f_gens = take(gen_words), *f_preset = take(n_preset), *f_pi = take(n_pi), *f_values = take(n_preset), *f_expect = take(n_pi);
+    if ((size_t)(p - file.data()) + 6 == file.size()) p += 6;   // optional trailer {N, K, ELL, LOGB, n_lwe, used_rows}
     if ((size_t)(p - file.data()) != file.size()) {
         std::fprintf(stderr, "truncated file\n");
         return 2;

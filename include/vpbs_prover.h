@@ -472,6 +472,34 @@ int vpbs_blind_rotate_step(vpbs_ctx* ctx, const vpbs_tfhe_params* params, unsign
 int vpbs_pbs_accumulator_chain(vpbs_ctx* ctx, const vpbs_tfhe_params* params, unsigned n, const uint64_t* acc_init,
                                const uint64_t* lwe_ct, const uint64_t* bsk, const uint64_t* ksk, uint64_t* accs_out);
 
+/* ---- seeded key / ciphertext generation (the reference draws all of it from unseeded RNGs,
+ *      /root/reference/src/main.rs:40-52, crypto/poly.rs:72-88, crypto/lwe.rs:12,43,55) ----
+ * Everything is a function of ONE seed (generator: csrc/keygen.hip header; restated by tests/tfhe_oracle.py):
+ *   s_to   [K][N]      Glwe::partial_key(n_lwe)   (crypto/glwe.rs:19-40): binary, only the leading n_lwe coefficients non-zero
+ *   s_lwe  [n_lwe]     flatten_partial_key        = those coefficients
+ *   s_glwe [K-1][N]    Glwe::key_gen              (crypto/glwe.rs:15-17)
+ *   bsk    [n_lwe][K][ELL][K][N]   compute_bsk(s_lwe, s_glwe, sigma_glwe) (crypto/mod.rs:29-45): Ggsw::encrypt(s_glwe, constant(s_i)).ntt_forward(),
+ *                                  NTT domain, Ggsw::flatten order -- what vpbs_pbs_accumulator_chain / the step circuit's GGSW targets take
+ *   ksk    [K][ELL][K][N]          Ggsw::compute_ksk(s_to, s_glwe, sigma_lwe) (crypto/ggsw.rs:38-48)
+ * Noise: a rounded Gaussian stand-in with standard deviation floor(sigma q + 1/2) in integer arithmetic (Irwin-Hall of twelve 32-bit
+ * uniforms), so that host, device and oracle agree bit for bit.  The GGSWs are generated on the device (728 x 16 GLWE encryptions at the
+ * paper's parameters); bsk / ksk are host pointers, or device pointers when keys_on_device != 0; the three key outputs are host arrays.
+ * Any output may be NULL. */
+typedef struct {
+    unsigned log_N, K, ELL, LOGB; /* as vpbs_tfhe_params */
+    unsigned n_lwe;               /* LWE dimension (728 in /root/reference/src/main.rs:27) */
+    uint64_t seed;
+    double sigma_glwe, sigma_lwe; /* relative to q, as main.rs:29-30 (4.99027217501041e-8, 1.17021618159313e-5) */
+} vpbs_keygen_params;
+int vpbs_keygen(vpbs_ctx* ctx, const vpbs_keygen_params* params, uint64_t* s_lwe, uint64_t* s_glwe, uint64_t* s_to, uint64_t* bsk,
+                uint64_t* ksk, int keys_on_device);
+/* lwe::encrypt(s_lwe, message, sigma_lwe) (crypto/lwe.rs:55-64) with the mask / noise streams of `nonce` (< 2^24); host only; ct: [n_lwe + 1] */
+int vpbs_lwe_encrypt(const vpbs_keygen_params* params, const uint64_t* s_lwe, uint64_t message, uint64_t nonce, uint64_t* ct);
+/* get_testv(p, get_delta(2 p)) (crypto/mod.rs:17-27, crypto/lwe.rs:50-52; main.rs:47-48): testv [N] (may be NULL), *delta */
+int vpbs_testv(unsigned log_N, unsigned p, uint64_t* testv, uint64_t* delta);
+/* Glwe::decrypt (crypto/glwe.rs:60-63): m = body - sum_j a_j s_j over X^N + 1; s: [K-1][N], ct: [K][N] coefficient domain, host arrays */
+int vpbs_glwe_decrypt(vpbs_ctx* ctx, unsigned log_N, unsigned K, const uint64_t* s, const uint64_t* ct, uint64_t* m_out);
+
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */
 /* on: 0 off, 1 every kernel group, 2 only the dominant kernel (leaf_hash) */
 int vpbs_timing_enable(vpbs_ctx* ctx, int on);

@@ -603,3 +603,116 @@ def test_step_proof_degenerate_inputs(ctx, kind):
     for key in ("caps", "challenges", "openings", "fri"):
         assert (got[key] == want[key]).all(), key
     cs.free()
+
+
+def test_batch_of_128_independent_proofs():
+    """BASELINE config 3: 128 independent step proofs of one circuit at the N = 1024 shape (degree 2^16, 135/20/16/86 columns, all 14 gate
+    types) on one GPU through a bounded pool of prover contexts.  Every proof verifies (transcript, PoW, Merkle paths, FRI), all 128 are
+    distinct, a proof does not depend on which context of the pool produced it, and two sampled instances are bit-identical to the CPU
+    oracle's proofs of the same wires."""
+    import queue
+    import threading
+    import torch
+    import gates_oracle as go
+    import regression_cases as rc
+    B = rc.BENCH
+    log_n, nc, nr, n = B["log_n"], B["n_constants"], B["n_routed"], 1 << B["log_n"]
+    proofs, pool = 128, 4
+    gates = api.GateSet(rc.GATES)
+    cs_values = synth.step_inputs(log_n, cols=B["cols"])["constants_sigmas"]
+    d_cs = torch.from_numpy(cs_values.view(np.int64)).cuda()
+    sig_ptr = d_cs.data_ptr() + 8 * nc * n
+    gen = torch.Generator(device="cuda")
+    wires, pis = [], []
+    for i in range(proofs):
+        gen.manual_seed(0x5EED0000 + 16 * i)
+        wires.append(torch.randint(0, P >> 1, (135, n), dtype=torch.int64, device="cuda", generator=gen))
+        pis.append(synth.field_elements(0xABCD + i, 64))
+    torch.cuda.synchronize()
+    ctxs = [vpbs_amd.Context(0, log_n_max=16) for _ in range(pool)]
+    css = [c.commit_values(cs_values) for c in ctxs]
+    todo, out, errs = queue.Queue(), [None] * proofs, []
+    for i in range(proofs):
+        todo.put(i)
+
+    def prove(k, i):
+        si = ctxs[k].make_step_inputs(log_n, wires[i].data_ptr(), None, None, css[k], B["digest"], pis[i], on_device=True, shapes=(135, 20, 16),
+                                      sigmas=sig_ptr, n_routed=nr, n_constants=nc, gates=gates)
+        return ctxs[k].prove_step(si)
+
+    def work(k):
+        try:
+            while True:
+                try:
+                    i = todo.get_nowait()
+                except queue.Empty:
+                    return
+                out[i] = prove(k, i)
+        except Exception as e:
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(pool)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    cap = css[0].cap()
+    assert len({p["caps"].tobytes() for p in out}) == proofs
+    for i in range(0, proofs, 9):
+        assert api.verify_step_fri_only(out[i], cap, [nc + nr, 135, 20, 16], B["digest"], pis[i], log_n), i
+    # another context of the pool, alone on the device, reproduces the proof of a concurrently proven instance
+    for i, k in ((5, 3), (77, 0)):
+        again = prove(k, i)
+        assert all((again[key] == out[i][key]).all() for key in ("caps", "openings", "fri")), i
+    # sampled subset against the oracle
+    sig = np.ascontiguousarray(cs_values[nc:nc + nr])
+    for i in (17, 101):
+        w = wires[i].cpu().numpy().view(np.uint64)
+        want = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": w, "quotient": None}, B["digest"], pis[i], log_n, sigmas=sig,
+                                      n_routed=nr, n_constants=nc, gates=go.GateSet(rc.GATES))
+        for key in ("caps", "challenges", "openings", "fri"):
+            assert (np.asarray(out[i][key]).reshape(-1) == np.asarray(want[key]).reshape(-1)).all(), (i, key)
+    for cs, c in zip(css, ctxs):
+        cs.free()
+        c.close()
+
+
+# ---------- seeded key generation (SURVEY.md 8f-4) ----------
+@pytest.mark.parametrize("log_ring,n_lwe,K,ELL,LOGB", [(3, 6, 2, 4, 5), (6, 40, 3, 3, 7), (10, 728, 2, 4, 5)])
+def test_keygen_matches_oracle(ctx, log_ring, n_lwe, K, ELL, LOGB):
+    """vpbs_keygen (GGSW encryptions generated on the device, directly in the NTT domain) against the oracle's literal restatement of
+    Glwe::encrypt -> Glev / Ggsw::encrypt -> ntt_forward (crypto/glwe.rs:49-57, glev.rs:26-38, ggsw.rs:26-48, mod.rs:29-45) on the same
+    seeded streams, with the paper's noise levels: bit-exact.  At N = 1024 / n = 728 a sample of the 728 GGSWs is compared."""
+    import tfhe_oracle as T
+    N, seed = 1 << log_ring, 0xC0FFEE + log_ring
+    sg, sl = 4.99027217501041e-8, 1.17021618159313e-5       # main.rs:29-30
+    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, seed, sg, sl)
+    ring = T.Ring(log_ring)
+    sample = list(range(n_lwe)) if n_lwe <= 40 else [0, 1, 357, 727]
+    s_to, s_lwe, s_glwe, bsk, ksk = T.seeded_pbs_keys(ring, seed, n_lwe, K, ELL, LOGB, sg, sl, bsk_indices=sample)
+    assert (keys["s_to"] == np.array(s_to, np.uint64)).all() and (keys["s_lwe"] == np.array(s_lwe, np.uint64)).all()
+    assert (keys["s_glwe"] == np.array(s_glwe, np.uint64)).all()
+    assert (keys["ksk"] == ksk).all()
+    for i in sample:
+        assert (keys["bsk"][i] == bsk[i]).all(), i
+    # the noise is there and small: decrypting GLWE (p = K-1, l = ELL-1) of a GGSW gives s_i * B^(first + ELL - 1) up to ~6 sigma q
+    i = sample[-1]
+    g = keys["bsk"][i].reshape(K, ELL, K, N)
+    ct = np.stack([np.array(ring.bw([int(v) for v in g[K - 1, ELL - 1, r]]), np.uint64) for r in range(K)])
+    m = ctx.glwe_decrypt(keys["s_glwe"], ct)
+    want = int(keys["s_lwe"][i]) * pow(2, LOGB * (T.num_limbs(LOGB) - 1), P) % P
+    err = [min((int(v) - (want if j == 0 else 0)) % P, (-(int(v) - (want if j == 0 else 0))) % P) for j, v in enumerate(m)]
+    assert 0 < max(err) < 7 * T.sigma_to_int(sg)
+
+
+def test_seeded_pbs_decrypts_to_the_message(ctx):
+    """main.rs:40-65 end to end at the paper's parameters (N = 1024, K = 2, ELL = 4, LOGB = 5, n = 728, p = 2, the paper's noise): seeded keys
+    from vpbs_keygen, an LWE encryption of delta * m, the accumulator chain of the 730 steps on the device, Glwe::decrypt under the partial
+    key: the bootstrapped message is m, for both messages."""
+    N, K, ELL, LOGB, n, p = 1024, 2, 4, 5, 728, 2
+    keys = ctx.keygen(N, K, ELL, LOGB, n, 0x5EED, 4.99027217501041e-8, 1.17021618159313e-5)
+    testv, delta = api.testv(N, p)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), testv.reshape(1, N)])
+    for m in (0, 1):
+        ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * m % P, nonce=m)
+        accs = ctx.pbs_accumulator_chain(acc_init, ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
+        m_bar = ctx.glwe_decrypt(keys["s_to"], accs[-1])
+        assert round(int(m_bar[0]) / delta) % (2 * p) == m, (m, int(m_bar[0]) / delta)

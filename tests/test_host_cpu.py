@@ -265,3 +265,56 @@ def test_proof_bytes_round_trip_and_verify():
     tampered[8:16] = (0xFFFFFFFFFFFFFFFF).to_bytes(8, "little")          # a cap element >= p
     with pytest.raises(api.VpbsError):
         api.step_proof_from_bytes(bytes(tampered), ncols, b["log_n"], n_constants)
+
+
+def test_seeded_lwe_encrypt_and_testv_match_the_oracle():
+    """the host-only members of the seeded generator (vpbs_lwe_encrypt, vpbs_testv) against tests/tfhe_oracle.py; the noise stand-in has
+    the requested standard deviation"""
+    import tfhe_oracle as T
+    seed, n = 0xC0FFEE, 40
+    ring = T.Ring(6)
+    s_to, s_lwe, s_glwe = T.seeded_keys(ring, seed, n, 3)
+    assert set(s_lwe) <= {0, 1} and 8 < sum(s_lwe) < 32 and all(v == 0 for poly in s_to[1:] for v in poly) and s_to[0][n:] == [0] * (64 - n)
+    prm = api.KeygenParamsC(6, 3, 3, 7, n, seed, 1e-8, 1.17021618159313e-5)
+    for p, nonce in ((2, 0), (4, 9)):
+        t, delta = api.testv(64, p)
+        assert delta == T.get_delta(2 * p) and (t == np.array(T.get_testv(ring, p, delta), np.uint64)).all()
+        ct = api.lwe_encrypt(prm, s_lwe, delta % P, nonce)
+        assert (ct == np.array(T.seeded_lwe_encrypt(seed, s_lwe, delta % P, 1.17021618159313e-5, nonce), np.uint64)).all()
+    g = T.Seeded(seed)
+    m_sigma = T.sigma_to_int(4.99027217501041e-8)
+    xs = [g.noise(g.stream(T.BSK_NOISE, 1, 2), i, m_sigma) for i in range(4000)]
+    xs = [x - P if x > P // 2 else x for x in xs]
+    mean, std = sum(xs) / len(xs), (sum(x * x for x in xs) / len(xs)) ** 0.5
+    assert abs(mean) < 0.1 * m_sigma and 0.9 * m_sigma < std < 1.1 * m_sigma and max(abs(x) for x in xs) <= 6 * m_sigma
+
+
+def test_prover_tools_load_the_circuit_as_data():
+    """bench.py and tools/prove_pbs.py get the step circuit from the exported file through the product package; neither imports the
+    test-side circuit builder (bench.py touches tests/ only inside its cpu_baseline leg, for the oracle)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pbs = open(os.path.join(root, "tools", "prove_pbs.py")).read()
+    assert "import step_circuit" not in pbs and '"tests"' not in pbs
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert "import step_circuit" not in bench
+    legs = re.findall(r'sys\.path\.insert\(0, os\.path\.join\(ROOT, "tests"\)\)', bench)
+    assert len(legs) == 1 and bench.index('def cpu_baseline') < bench.index(legs[0])
+
+
+def test_circuit_file_round_trip(tmp_path):
+    """exporter -> file -> circuit_file.load: the loaded description generates the sample witness and its public inputs"""
+    import subprocess
+    import sys
+    from vpbs_amd import circuit_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "step8.bin")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "export_step_circuit.py"), path, "8", "2", "4", "5", "6"], stdout=subprocess.DEVNULL)
+    d = circuit_file.load(path)
+    assert d.meta == {"N": 8, "K": 2, "ELL": 4, "LOGB": 5, "n_lwe": 6, "used_rows": d.used_rows} and d.n == 1 << d.log_n
+    plan = d.circuit.witness_plan(d.preset_pos)
+    w = plan.run(d.sample_values)
+    assert (np.array([w[c][r] for c, r in d.pi_pos], np.uint64) == d.sample_public_inputs).all()
+    ok, msg = d.circuit.check_witness(w, api.hash_no_pad(d.sample_public_inputs))
+    assert ok, msg
+    plan.free()

@@ -180,3 +180,107 @@ def pbs_chain(ring, acc_init, ct, bsk, ksk, K, ELL, logb):
         accs.append(step(ring, accs[-1], ct[x], bsk[x], K, ELL, logb))
     accs.append(step(ring, accs[-1], 0, ksk, K, ELL, logb, last_step=True))
     return accs
+
+
+# ---- seeded keys / ciphertexts (the checker of vpbs_keygen, vpbs_lwe_encrypt, vpbs_testv; generator spec: csrc/keygen.hip header) ----
+# The encryptions follow the reference literally -- Glwe::encrypt in the coefficient domain (crypto/glwe.rs:49-57: mask, error,
+# body = <s, mask> + error + m through Poly::mul), Glev / Ggsw::encrypt (crypto/glev.rs:26-38, crypto/ggsw.rs:26-36), then ntt_forward --
+# while the product generates the NTT-domain form directly; both must give the same field elements.
+_G = 0x9E3779B97F4A7C15
+_M64 = (1 << 64) - 1
+S_TO, S_GLWE, BSK_MASK, BSK_NOISE, KSK_MASK, KSK_NOISE, LWE_MASK, LWE_NOISE = range(1, 9)
+
+
+def _mix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+class Seeded:
+    def __init__(self, seed):
+        self.seed = seed
+
+    def stream(self, kind, a=0, b=0, c=0):
+        tag = (kind << 56) | (a << 32) | (b << 16) | c
+        return _mix64((self.seed + _G * (tag + 1)) & _M64)
+
+    @staticmethod
+    def draw(key, i):
+        return _mix64((key + _G * (i + 1)) & _M64)
+
+    def field(self, key, i):
+        u = self.draw(key, i)
+        return u - P if u >= P else u
+
+    def bit(self, key, i):
+        return self.draw(key, i) & 1
+
+    def noise(self, key, i, m_sigma):
+        s = 0
+        for k in range(6):
+            d = self.draw(key, 6 * i + k)
+            s += (d & 0xFFFFFFFF) + (d >> 32)
+        t = s - (6 << 32)
+        return ((t * m_sigma) >> 32) % P          # Python's >> floors, % maps negatives into the field
+
+
+def sigma_to_int(sigma):
+    import math
+    return int(math.floor(sigma * float(P) + 0.5))
+
+
+def seeded_keys(ring, seed, n_lwe, K):
+    """partial_key / flatten_partial_key / key_gen (crypto/glwe.rs:15-40)"""
+    g = Seeded(seed)
+    s_to = [[0] * ring.n for _ in range(K)]
+    for x in range(n_lwe):
+        s_to[x // ring.n][x % ring.n] = g.bit(g.stream(S_TO, x // ring.n), x % ring.n)
+    s_lwe = [s_to[x // ring.n][x % ring.n] for x in range(n_lwe)]
+    s_glwe = [[g.bit(g.stream(S_GLWE, j), i) for i in range(ring.n)] for j in range(K - 1)]
+    return s_to, s_lwe, s_glwe
+
+
+def seeded_glwe_encrypt(ring, g, s, m, K, kind_mask, kind_noise, gi, pl, m_sigma):
+    """Glwe::encrypt with the mask / error streams of GLWE (gi, pl)"""
+    mask = [[g.field(g.stream(kind_mask, gi, pl, r), i) for i in range(ring.n)] for r in range(K - 1)]
+    ke = g.stream(kind_noise, gi, pl, 0)
+    body = [g.noise(ke, i, m_sigma) for i in range(ring.n)]
+    for a, sk in zip(mask, s):
+        body = [(x + y) % P for x, y in zip(body, ring.mul(a, sk))]
+    return mask + [[(b + int(mi)) % P for b, mi in zip(body, m)]]
+
+
+def seeded_ggsw_hat(ring, g, s, glev_msgs, bit, K, ELL, logb, kind_mask, kind_noise, gi, m_sigma):
+    """Ggsw::encrypt(s, .).ntt_forward() where GLEV p encrypts bit * glev_msgs[p]; flattened in Ggsw::flatten order"""
+    first = num_limbs(logb) - ELL
+    out = []
+    for p in range(K):
+        for l in range(ELL):
+            scale = pow(2, logb * (first + l), P) * bit
+            ct = seeded_glwe_encrypt(ring, g, s, [x * scale % P for x in glev_msgs[p]], K, kind_mask, kind_noise, gi, p * ELL + l, m_sigma)
+            out += [c for poly in ct for c in ring.fw(poly)]
+    return np.array(out, dtype=np.uint64)
+
+
+def seeded_pbs_keys(ring, seed, n_lwe, K, ELL, logb, sigma_glwe=0.0, sigma_lwe=0.0, bsk_indices=None):
+    """main.rs:40-46 with seeded RNGs -> s_to, s_lwe, s_glwe, {i: bsk[i]} for the requested indices (all when None), ksk"""
+    g = Seeded(seed)
+    s_to, s_lwe, s_glwe = seeded_keys(ring, seed, n_lwe, K)
+    one = [1] + [0] * (ring.n - 1)
+    # compute_bsk: Ggsw::encrypt(s_glwe, constant(s_i)): GLEV p < K-1 encrypts s_i * s_glwe[p], the last one s_i
+    msgs = [list(s_glwe[p]) for p in range(K - 1)] + [one]
+    idx = range(n_lwe) if bsk_indices is None else bsk_indices
+    bsk = {i: seeded_ggsw_hat(ring, g, s_glwe, msgs, s_lwe[i], K, ELL, logb, BSK_MASK, BSK_NOISE, i, sigma_to_int(sigma_glwe)) for i in idx}
+    # compute_ksk(s_to, s_from = s_glwe): GLEV i < K-1 encrypts s_glwe[i], the last one the constant 1, under s_to
+    ksk = seeded_ggsw_hat(ring, g, s_to, msgs, 1, K, ELL, logb, KSK_MASK, KSK_NOISE, 0, sigma_to_int(sigma_lwe))
+    return s_to, s_lwe, s_glwe, bsk, ksk
+
+
+def seeded_lwe_encrypt(seed, s_lwe, message, sigma_lwe, nonce=0):
+    """lwe::encrypt (crypto/lwe.rs:55-64)"""
+    g = Seeded(seed)
+    km, ke = g.stream(LWE_MASK, nonce), g.stream(LWE_NOISE, nonce)
+    mask = [g.field(km, i) for i in range(len(s_lwe))]
+    body = (sum(a * b for a, b in zip(mask, s_lwe)) + message + g.noise(ke, 0, sigma_to_int(sigma_lwe))) % P
+    return mask + [body]

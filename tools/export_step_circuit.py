@@ -40,7 +40,7 @@ def export(path, N=8, K=2, ELL=4, LOGB=5, n_lwe=6, seed=1):
                        len(gens), preset_pos.size, pi_pos.size], np.uint64),
              np.array([[g.kind, g.p0, g.p1, g.p2] for g in b.gates], np.uint64).reshape(-1),
              c.row_gate.astype(np.uint64), c.constants.reshape(-1), c.copies.astype(np.uint64).reshape(-1), np.array(gens, np.uint64),
-             preset_pos, pi_pos, values, pis]
+             preset_pos, pi_pos, values, pis, np.array([N, K, ELL, LOGB, n_lwe, b.used_rows], np.uint64)]
     with open(path, "wb") as f:
         for w in words:
             f.write(np.ascontiguousarray(w, dtype="<u8").tobytes())

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """One whole verifiable PBS at the paper's parameters on one MI355X, measured end to end instead of extrapolated from the step rate:
-n + 2 = 730 chained steps of the reference's step circuit WITHOUT its recursive verifier (tests/step_circuit.py; the hand-over of
+n + 2 = 730 chained steps of the reference's step circuit WITHOUT its recursive verifier (the exported circuit description,
+verifiable-fhe-paper_amd/circuit_file.py: this tool imports no circuit builder; the hand-over of
 accumulator, counter and hash chains between steps is done by this driver, which is what the in-circuit verifier enforces in the
 reference).  Pipeline: native accumulator chain on the device (vpbs_pbs_accumulator_chain) and native hash chains on the host -> the
 PartialWitness values of every step (the hash chains computed by a host thread beside the device) -> device witness generation in batches (vpbs_witness_device_*) -> gather -> step proofs on
-`provers` contexts -> every proof verified on the host (after the clock).  Random bootstrapping keys (no decryption check here: the
-noise-free end-to-end PBS is tests/test_gpu_step_circuit.py at N = 8).
+`provers` contexts -> every proof verified on the host (after the clock).  Keys, test vector and the LWE input are the seeded ones of
+vpbs_keygen / vpbs_lwe_encrypt / vpbs_testv at the paper's noise levels (main.rs:40-52); the final accumulator -- a public input of the last
+proof -- decrypts to the encrypted message under the partial key (main.rs:58-64).
 usage: tools/prove_pbs.py [n_lwe=728] [batch=73] [provers=5]  ->  one JSON line
 Several GPUs: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/prove_pbs.py ...
   the steps of the ONE PBS are split into N contiguous ranges, one per rank / GPU (they are independent once the accumulator and hash
@@ -19,13 +21,12 @@ import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-import step_circuit as sc  # noqa: E402
 import vpbs_amd  # noqa: E402
-from vpbs_amd import api, synth  # noqa: E402
+from vpbs_amd import api, circuit_file  # noqa: E402
 
 N, K, ELL, LOGB = 1024, 2, 4, 5
 P = api.P
@@ -45,23 +46,27 @@ def main():
     torch.cuda.set_device(device)
     my_first, my_end = steps * rank // world, steps * (rank + 1) // world      # this rank's steps: [my_first, my_end)
     t_all = time.perf_counter()
-    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(10))
-    b = circ.built
+    b = circuit_file.load(circuit_file.ensure_step_circuit(N, K, ELL, LOGB, n_lwe))
     sigma = b.circuit.sigma_values()
-    targets = ([t for p in circ.acc_init for t in p] + [t for p in circ.acc_in for t in p] + circ.ggsw_flat + [circ.counter, circ.mask] +
-               circ.bsk_hash_in + circ.lwe_hash_in)
-    plan = b.circuit.witness_plan([b.pos(t) for t in targets])
-    pi_pos = [b.pos(t) for t in b.public_inputs]
+    targets = b.preset_pos      # acc_init, acc_in, GGSW, counter, mask, the two chain hashes (the exporter's order, ivc_based_vpbs.rs:325-330)
+    plan = b.circuit.witness_plan(targets)
+    pi_pos = b.pi_pos
     n_constants = b.constants.shape[0]
     cs_values = np.concatenate([b.constants, sigma])
     t_setup = time.perf_counter() - t_all
 
-    rng = np.random.default_rng(728)
-    f = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)
     ggsw_len = K * ELL * K * N
-    bsk, ksk, ct = f(n_lwe, ggsw_len), f(ggsw_len), f(n_lwe + 1)
-    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), f(1, N)])
     main_ctx = vpbs_amd.Context(device, log_n_max=16)
+    # main.rs:40-52 with seeded generators: partial key / LWE key, GLWE key, bootstrapping and key-switching keys (on the device), test
+    # vector, an LWE encryption of delta * message -- before the clock: key material exists once per key, not per PBS
+    t_keys = time.perf_counter()
+    message = int(os.environ.get("VPBS_PBS_MESSAGE", "1"))
+    keys = main_ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728, 4.99027217501041e-8, 1.17021618159313e-5)
+    bsk, ksk = keys["bsk"], keys["ksk"]
+    testv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * message % P)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), testv.reshape(1, N)])
+    t_keys = time.perf_counter() - t_keys
     ggsws = lambda s: np.zeros(ggsw_len, np.uint64) if s == 0 else (bsk[s - 1] if s <= n_lwe else ksk)
     masks = [int(ct[n_lwe])] + [int(v) for v in ct[:n_lwe]] + [0]
     bsk_h, lwe_h = [np.zeros(4, np.uint64)], [np.zeros(4, np.uint64)]
@@ -208,6 +213,10 @@ def main():
         assert int(pis[K * N]) == s + 1
         assert (pis[K * N + 1:2 * K * N + 1] == accs[s].reshape(-1)).all(), s
         assert (pis[-8:-4] == bsk_h[s + 1]).all() and (pis[-4:] == lwe_h[s + 1]).all(), s
+    # ... and the PBS did its job: the last accumulator decrypts to the message under the partial key (main.rs:58-64)
+    m_bar = main_ctx.glwe_decrypt(keys["s_to"], accs[-1])
+    decrypted = round(int(m_bar[0]) / delta) % 4
+    assert decrypted == message, (decrypted, message)
     t0 = time.perf_counter()
     from concurrent.futures import ThreadPoolExecutor
     cs_cap = css[0].cap()
@@ -246,8 +255,11 @@ def main():
         "bsk_hash_chain": "precomputed per key (before the clock)" if bsk_pre else "inside the clock",
         "inside_the_clock": {"accumulator_chain_on_device_s": t_chain, "native_hash_chains_on_one_host_core_s": t_hash,
                              "note": "the hash chains run beside the device; every witness batch waits for the prefix it needs"},
-        "before_the_clock": {"circuit_description_sigma_plan_s": t_setup, "note": "once per circuit, not per PBS"},
-        "checks": "accumulator / counter / hash public inputs of all %d proofs equal the native chains; all %d proofs verified by "
+        "before_the_clock": {"circuit_file_sigma_plan_s": t_setup, "seeded_keygen_on_device_s": t_keys,
+                             "note": "once per circuit / once per key, not per PBS"},
+        "message": message, "decrypted": decrypted,
+        "checks": "the bootstrapped ciphertext decrypts to the message; accumulator / counter / hash public inputs of all %d proofs equal "
+                  "the native chains; all %d proofs verified by "
                   "vpbs_verify_step on 8 host threads per rank in %.2f s (after the clock)" % (checked, checked, t_verify),
         "proof_words_kB": proof_bytes / 1e3}))
     if dist:

@@ -6,5 +6,5 @@ entry point raises if the library is missing or no device is present.
 
 The directory name is not a valid Python identifier; import it through the root-level `vpbs_amd` loader.
 """
-from . import api, synth, sharding  # noqa: F401
+from . import api, synth, sharding, circuit_file  # noqa: F401
 from .api import Context, Batch, ChallengerState, FriParams, VpbsError, lib, build_library  # noqa: F401

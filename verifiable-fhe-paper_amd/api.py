@@ -89,6 +89,11 @@ class TfheParamsC(C.Structure):
     _fields_ = [("log_N", C.c_uint), ("K", C.c_uint), ("ELL", C.c_uint), ("LOGB", C.c_uint)]
 
 
+class KeygenParamsC(C.Structure):
+    _fields_ = [("log_N", C.c_uint), ("K", C.c_uint), ("ELL", C.c_uint), ("LOGB", C.c_uint), ("n_lwe", C.c_uint), ("seed", C.c_uint64),
+                ("sigma_glwe", C.c_double), ("sigma_lwe", C.c_double)]
+
+
 class StepSizesC(C.Structure):
     _fields_ = [("cap_words", C.c_size_t), ("openings_words", C.c_size_t), ("fri_words", C.c_size_t)]
 
@@ -164,6 +169,10 @@ SIGNATURES = {
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
+    "vpbs_keygen": (_i, [_vp, C.POINTER(KeygenParamsC), U64P, U64P, U64P, _vp, _vp, _i]),
+    "vpbs_lwe_encrypt": (_i, [C.POINTER(KeygenParamsC), U64P, _u64, _u64, U64P]),
+    "vpbs_testv": (_i, [_ui, _ui, U64P, U64P]),
+    "vpbs_glwe_decrypt": (_i, [_vp, _ui, _ui, U64P, U64P, U64P]),
     "vpbs_k_poseidon_batch": (_i, [_vp, U64P, _sz]),
     "vpbs_k_hash_rows": (_i, [_vp, U64P, _sz, _ui, U64P]),
     "vpbs_k_intt": (_i, [_vp, U64P, _ui, _ui, U64P]),
@@ -541,6 +550,23 @@ def step_proof_from_bytes(blob, ncols, log_n, n_constants, num_challenges=2, rat
     return {"caps": caps, "openings": openings, "fri": fri}, pis[:n].copy()
 
 
+def lwe_encrypt(params, s_lwe, message, nonce=0):
+    """vpbs_lwe_encrypt (host): lwe::encrypt(s_lwe, message, sigma_lwe) with the seeded mask / noise streams of `nonce` -> ct [n + 1]"""
+    s = _u64(s_lwe).reshape(-1)
+    ct = np.zeros(s.size + 1, np.uint64)
+    if lib().vpbs_lwe_encrypt(C.byref(params), _ptr(s), int(message), int(nonce), _ptr(ct)) != 0:
+        raise VpbsError("vpbs_lwe_encrypt: bad arguments")
+    return ct
+
+
+def testv(N, p=2):
+    """get_testv(p, get_delta(2 p)) -> (testv [N], delta)"""
+    t, d = np.zeros(N, np.uint64), np.zeros(1, np.uint64)
+    if lib().vpbs_testv(N.bit_length() - 1, p, _ptr(t), _ptr(d)) != 0:
+        raise VpbsError("vpbs_testv: bad arguments")
+    return t, int(d[0])
+
+
 def fri_params(degree_bits, **over):
     p = FriParams()
     lib().vpbs_fri_params_standard(degree_bits, C.byref(p))
@@ -859,6 +885,27 @@ class Context:
         prm = TfheParamsC(N.bit_length() - 1, K, ELL, LOGB)
         out = np.zeros((n + 2, K, N), np.uint64)
         self._check(lib().vpbs_pbs_accumulator_chain(self.h, C.byref(prm), n, _ptr(acc), _ptr(ct), _ptr(b), _ptr(k), _ptr(out)))
+        return out
+
+    def keygen(self, N, K, ELL, LOGB, n_lwe, seed, sigma_glwe=0.0, sigma_lwe=0.0, want_bsk=True, want_ksk=True):
+        """vpbs_keygen: every key of one PBS from one seed (main.rs:40-46 with the RNGs seeded) -> dict(params, s_lwe [n], s_glwe [K-1][N],
+        s_to [K][N], bsk [n][K*ELL*K*N], ksk [K*ELL*K*N]); bsk / ksk in the NTT domain, Ggsw::flatten order."""
+        prm = KeygenParamsC(N.bit_length() - 1, K, ELL, LOGB, n_lwe, seed, sigma_glwe, sigma_lwe)
+        s_lwe, s_glwe, s_to = np.zeros(n_lwe, np.uint64), np.zeros((K - 1, N), np.uint64), np.zeros((K, N), np.uint64)
+        g = K * ELL * K * N
+        bsk = np.zeros((n_lwe, g), np.uint64) if want_bsk else None
+        ksk = np.zeros(g, np.uint64) if want_ksk else None
+        self._check(lib().vpbs_keygen(self.h, C.byref(prm), _ptr(s_lwe), _ptr(s_glwe), _ptr(s_to), bsk.ctypes.data if want_bsk else None,
+                                      ksk.ctypes.data if want_ksk else None, 0))
+        return {"params": prm, "s_lwe": s_lwe, "s_glwe": s_glwe, "s_to": s_to, "bsk": bsk, "ksk": ksk}
+
+    def glwe_decrypt(self, s, ct):
+        """Glwe::decrypt: s [K-1][N] (or [K][N]: the leading K-1 polynomials are used), ct [K][N] -> m [N]"""
+        ct = _u64(ct)
+        K, N = ct.shape
+        s = np.ascontiguousarray(_u64(s)[:K - 1])
+        out = np.zeros(N, np.uint64)
+        self._check(lib().vpbs_glwe_decrypt(self.h, N.bit_length() - 1, K, _ptr(s), _ptr(ct), _ptr(out)))
         return out
 
     # ---- kernel-level hooks ----
