@@ -488,10 +488,9 @@ def main():
     log_n = args.log_n
     sharded = distributed and args.mode == "sharded"
     comm = None
+    native_comm = False
     if sharded:
         from vpbs_amd import sharding
-        comm = sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None,
-                                  stage_words=(2 << (args.log_n + 3)) // world, stage_device=torch.device("cuda", local_rank))
     n_chains = 1 if sharded else max(1, args.chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
     gates = vpbs_amd.api.GateSet(GATES)
@@ -501,6 +500,16 @@ def main():
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)
         if n_chains > 1:
             ctx.set_gate_lanes(1)   # several chains keep the device busy by themselves: one stream per context is the better setting
+        if sharded:
+            # the collectives of the sharded step: the library's own RCCL path on GPUs (ncclAllGather / ncclAllReduce between device
+            # buffers on the prover's stream; torch.distributed only carries the ncclUniqueId), host callbacks over torch.distributed for gloo
+            stage_words = (2 << (args.log_n + 3)) // world
+            native_comm = args.dist_backend == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
+            if native_comm:
+                comm = sharding.make_comm_rccl(ctx, stage_words=stage_words)
+            else:
+                comm = sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None,
+                                          stage_words=stage_words, stage_device=torch.device("cuda", local_rank))
         # chain c of rank r proves its own seeded instance
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst, cols=COLS)
@@ -643,7 +652,7 @@ def main():
                                  "plonky2's prove(), SURVEY.md 8f-2): witness generation" % gates.n,
                        "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
                                        "hashes, 1 device all-gather of quotient values (4 MiB) + 1 all-reduce of query records (%s)"
-                                       % (world, args.dist_backend)) if sharded else
+                                       % (world, "native RCCL (dlopen) on the prover's stream" if native_comm else args.dist_backend)) if sharded else
                                       "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",
@@ -722,6 +731,8 @@ def main():
             out["parity_full_size"] = parity
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    if native_comm and comm is not None and ctxs:
+        sharding.free_comm_rccl(comm)
     for ctx in ctxs:
         ctx.close()
     if distributed:

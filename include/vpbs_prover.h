@@ -342,6 +342,16 @@ typedef struct {
     size_t stage_capacity_words;
 } vpbs_comm;
 
+/* The same collectives natively: RCCL over xGMI, bound with dlopen at the first call (no link-time dependency; 0 from
+ * vpbs_rccl_available when no librccl.so can be loaded).  Cap hashes, query records and the quotient values move between device buffers
+ * with ncclAllGather / ncclAllReduce on the context's stream.  Rank 0 makes the 128-byte id (ncclGetUniqueId) and the host hands it to
+ * the other ranks (torch.distributed broadcast in bench.py, the launcher's channel in a C++ / Rust host); every rank of the node then
+ * creates its communicator.  stage_words > 0: device staging for the on-device quotient (nc * local LDE length words per rank). */
+int vpbs_rccl_available(void);
+int vpbs_rccl_unique_id(uint8_t id_out[128]);
+int vpbs_comm_rccl_create(vpbs_ctx* ctx, const uint8_t unique_id[128], unsigned rank, unsigned world, size_t stage_words, vpbs_comm* out);
+void vpbs_comm_rccl_destroy(vpbs_comm* comm);
+
 /* sizes of the outputs of vpbs_prove_step, in u64 words */
 typedef struct {
     size_t cap_words;       /* per cap: 4 << cap_height */

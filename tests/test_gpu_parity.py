@@ -716,3 +716,34 @@ def test_seeded_pbs_decrypts_to_the_message(ctx):
         accs = ctx.pbs_accumulator_chain(acc_init, ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
         m_bar = ctx.glwe_decrypt(keys["s_to"], accs[-1])
         assert round(int(m_bar[0]) / delta) % (2 * p) == m, (m, int(m_bar[0]) / delta)
+
+
+def test_native_rccl_collectives_single_rank(ctx):
+    """vpbs_comm_rccl_create (RCCL bound with dlopen): with one rank -- all a one-GPU box allows -- the three collectives of the sharded
+    step run through ncclAllGather / ncclAllReduce on the context's stream and return their input; a step proof handed that communicator
+    equals the plain one.  (The multi-rank behaviour of the same vpbs_comm contract is covered with the callback communicator over gloo.)"""
+    import torch
+    from vpbs_amd import sharding
+    assert api.lib().vpbs_rccl_available() == 1
+    stage = 4096
+    comm = sharding.make_comm_rccl(ctx, stage_words=stage)
+    assert comm.rank == 0 and comm.world == 1 and comm.stage_capacity_words == stage
+    local = synth.field_elements(7, 64)
+    full = np.zeros(64, np.uint64)
+    assert comm.allgather(comm.user, api._ptr(local), 64, api._ptr(full)) == 0 and (full == local).all()
+    rec = synth.field_elements(8, 40000)          # more than one staging block
+    want = rec.copy()
+    assert comm.allreduce_sum(comm.user, api._ptr(rec), rec.size) == 0 and (rec == want).all()
+    src = torch.from_numpy(synth.field_elements(9, stage).view(np.int64))
+    ctypes.cdll.LoadLibrary("libamdhip64.so")
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(comm.d_stage_local), ctypes.c_void_p(src.data_ptr()), stage * 8, 1) == 0
+    assert comm.allgather_dev(comm.user, stage) == 0
+    back = torch.zeros(stage, dtype=torch.int64)
+    assert hip.hipMemcpy(ctypes.c_void_p(back.data_ptr()), ctypes.c_void_p(comm.d_stage_full), stage * 8, 2) == 0
+    assert (back == src).all()
+    inputs, pis, cs, si, want_proof = _step(ctx, 8)
+    got = ctx.prove_step(si, comm)
+    assert all((got[k] == want_proof[k]).all() for k in ("caps", "openings", "fri"))
+    cs.free()
+    sharding.free_comm_rccl(comm)

@@ -284,3 +284,60 @@ def test_whole_pbs_tool(world):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["step_proofs"] == 16 and d["n_gpus"] == world and "all 16 proofs verified" in d["checks"]
+
+
+def test_device_witness_at_paper_parameters_against_independent_evaluations(ctx):
+    """Row a14 at full size: the device witness generator on a batch of 73 consecutive steps of a REAL PBS at the paper's parameters
+    (N = 1024, K = 2, ELL = 4, LOGB = 5, n = 728; seeded keys with the paper's noise, vpbs_keygen) -- checked against evaluations that
+    share no code with it:
+      * every gathered wire matrix of a sample satisfies all gate constraints and all copy constraints (vpbs_check_witness: host
+        re-evaluation of the 38 312 gate rows from the wires alone);
+      * the accumulator public inputs equal the Python big-int restatement of the step (tests/tfhe_oracle.py, reference semantics
+        ivc_based_vpbs.rs:99-125) applied to the previous accumulator;
+      * counter and chain-hash public inputs equal the native sponge (hash_no_pad of previous hash || key material, :126-143);
+      * and the wires equal the host plan's."""
+    import torch
+    import tfhe_oracle as T
+    from vpbs_amd import circuit_file
+    N, K, ELL, LOGB, n_lwe, batch = 1024, 2, 4, 5, 728, 73
+    d = circuit_file.load(circuit_file.ensure_step_circuit(N, K, ELL, LOGB, n_lwe))
+    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0xA14, 4.99027217501041e-8, 1.17021618159313e-5)
+    testv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), testv.reshape(1, N)])
+    accs = ctx.pbs_accumulator_chain(acc_init, ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
+    ggsw_len = K * ELL * K * N
+    ggsws = lambda s: np.zeros(ggsw_len, np.uint64) if s == 0 else keys["bsk"][s - 1]
+    masks = [int(ct[n_lwe])] + [int(v) for v in ct[:n_lwe]]
+    bsk_h, lwe_h = [np.zeros(4, np.uint64)], [np.zeros(4, np.uint64)]
+    for s in range(batch):
+        bsk_h.append(api.hash_no_pad(np.concatenate([bsk_h[-1], ggsws(s)])))
+        lwe_h.append(api.hash_no_pad(np.concatenate([lwe_h[-1], np.array([masks[s]], np.uint64)])))
+    vals = np.zeros((len(d.preset_pos), batch), np.uint64)
+    for s in range(batch):
+        acc_in = acc_init if s == 0 else accs[s - 1]
+        vals[:, s] = np.concatenate([acc_init.reshape(-1), acc_in.reshape(-1), ggsws(s), np.array([s + 1, masks[s]], np.uint64), bsk_h[s], lwe_h[s]])
+    plan = d.circuit.witness_plan(d.preset_pos)
+    dev = api.WitnessDevice(ctx, plan, max_batch=batch)
+    dev.run(vals)
+    d_wires = torch.zeros((135, d.n), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ring = T.Ring(10)
+    for s in (0, 1, 36, 72):
+        dev.wires(s, d_wires.data_ptr())
+        w = d_wires.cpu().numpy().view(np.uint64)
+        pis = np.array([w[c][r] for c, r in d.pi_pos], np.uint64)
+        assert (dev.read(s, d.pi_pos) == pis).all()
+        ok, msg = d.circuit.check_witness(w, api.hash_no_pad(pis))
+        assert ok, (s, msg)
+        # public inputs in the reference's order (ivc_based_vpbs.rs:196-207): acc_init, counter, accumulator, the two chain hashes
+        assert (pis[:K * N] == acc_init.reshape(-1)).all() and int(pis[K * N]) == s + 1
+        acc_in = acc_init if s == 0 else accs[s - 1]
+        ggsw_hat = [[[[int(v) for v in ggsws(s).reshape(K, ELL, K, N)[p, l, r]] for r in range(K)] for l in range(ELL)] for p in range(K)]
+        want = T.step(ring, [[int(v) for v in poly] for poly in acc_in], masks[s], ggsw_hat, K, ELL, LOGB, first_step=(s == 0))
+        assert [int(v) for v in pis[K * N + 1:2 * K * N + 1]] == [c for poly in want for c in poly], s
+        assert (pis[-8:-4] == bsk_h[s + 1]).all() and (pis[-4:] == lwe_h[s + 1]).all()
+        if s in (1, 72):
+            assert (plan.run(vals[:, s]) == w).all()
+    dev.free()
+    plan.free()

@@ -143,6 +143,10 @@ SIGNATURES = {
     "vpbs_step_sizes_get": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(StepSizesC)]),
     "vpbs_prove_step": (_i, [_vp, C.POINTER(StepInputsC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
     "vpbs_prove_step_sharded": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(CommC), U64P, U64P, U64P, C.POINTER(ChallengerStateC), U64P]),
+    "vpbs_rccl_available": (_i, []),
+    "vpbs_rccl_unique_id": (_i, [C.POINTER(C.c_uint8)]),
+    "vpbs_comm_rccl_create": (_i, [_vp, C.POINTER(C.c_uint8), _ui, _ui, _sz, C.POINTER(CommC)]),
+    "vpbs_comm_rccl_destroy": (None, [C.POINTER(CommC)]),
     "vpbs_step_proof_to_bytes": (C.c_long, [_vp, C.POINTER(StepInputsC), _ui, U64P, U64P, U64P, C.POINTER(C.c_uint8), _sz]),
     "vpbs_partial_products": (_i, [_vp, _vp, _vp, _i, _ui, _ui, U64P, U64P, _ui, _ui, _vp]),
     "vpbs_quotient_permutation": (_i, [_vp, _vp, _ui, _vp, _vp, _ui, U64P, U64P, U64P, _ui, _ui, _vp, _vp, _i]),

@@ -157,3 +157,36 @@ def make_comm(group=None, device=None, stage_words=0, stage_device=None):
         keep += [cb, _allgather_dev, local_t, full_t]
     comm._keep = tuple(keep)
     return comm
+
+
+def make_comm_rccl(ctx, group=None, stage_words=0):
+    """vpbs_comm with the library's NATIVE collectives (vpbs_comm_rccl_create: RCCL bound with dlopen, ncclAllGather / ncclAllReduce between
+    device buffers on the context's stream).  torch.distributed is used once, to hand rank 0's ncclUniqueId to the other ranks; with a
+    single rank (group is None and torch.distributed not initialised) nothing is exchanged.  Call free_comm_rccl(comm) before ctx.close()."""
+    import ctypes as C
+    import torch
+    from . import api
+    rank, world = 0, 1
+    dist = None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lib = api.lib()
+    if not lib.vpbs_rccl_available():
+        raise api.VpbsError("librccl.so is not loadable")
+    uid = (C.c_uint8 * 128)()
+    if rank == 0 and lib.vpbs_rccl_unique_id(uid):
+        raise api.VpbsError("ncclGetUniqueId failed")
+    if world > 1:
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    comm = api.CommC()
+    ctx._check(lib.vpbs_comm_rccl_create(ctx.h, uid, rank, world, stage_words, C.byref(comm)))
+    return comm
+
+
+def free_comm_rccl(comm):
+    import ctypes as C
+    from . import api
+    api.lib().vpbs_comm_rccl_destroy(C.byref(comm))
