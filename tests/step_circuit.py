@@ -24,6 +24,8 @@ GATE_SPEC = ["noop", "constant", "public_input", "arithmetic", "base_sum", "pose
 
 
 class Builder:
+    gate_spec = GATE_SPEC          # the circuit's gate set (tests/cyclic_circuit.py widens it to the 14 standard gates)
+
     def __init__(self):
         self.parent, self.t_row, self.t_col = [], [], []      # targets: ids; wire targets carry (row, column), virtual ones (-1, -1)
         self.rows, self.row_consts = [], []                    # gate kind and gate constants per row
@@ -195,6 +197,9 @@ class Builder:
     def register_public_inputs(self, targets):
         self.public_inputs += list(targets)
 
+    def fill_unused_slots(self):
+        """hook: gates with several operations per row give their unused operations defined inputs before build()"""
+
     # ---- CircuitBuilder::build ----
     def build(self, api, min_log_n=5):
         """-> Built (circuit description for the product; target -> wire position map)"""
@@ -208,10 +213,12 @@ class Builder:
                 for w in range(3):
                     self._wire(row, 4 * j + w, zero)
         self.arith_free.clear()
+        self.fill_unused_slots()
         log_n = max(min_log_n, (len(self.rows) - 1).bit_length())
         n = 1 << log_n
-        gates = api.GateSet(GATE_SPEC)
-        index = {kind: gates.by_kind(kind).index for kind in GATE_SPEC}
+        gates = api.GateSet(self.gate_spec)
+        names = [k if isinstance(k, str) else k[0] for k in self.gate_spec]
+        index = {kind: gates.by_kind(kind).index for kind in names}
         row_gate = np.full(n, index["noop"], np.uint32)
         row_gate[:len(self.rows)] = [index[k] for k in self.rows]
         constants = np.zeros((gates.num_selectors + NUM_CONSTS, n), np.uint64)
@@ -384,6 +391,11 @@ class StepCircuit:
 
     def __init__(self, api, N, K, ELL, LOGB, n_lwe, ring):
         cb = Builder()
+        self.logic(cb, N, K, ELL, LOGB, n_lwe, ring)
+        self.built = cb.build(api)
+
+    def logic(self, cb, N, K, ELL, LOGB, n_lwe, ring):
+        """build_step_circuit on the builder cb (ivc_based_vpbs.rs:80-155); registers the step's public inputs in the reference's order"""
         self.shape = (N, K, ELL, LOGB, n_lwe)
         self.acc_init = [cb.virtuals(N) for _ in range(K)]
         self.ggsw = [[[cb.virtuals(N) for _ in range(K)] for _ in range(ELL)] for _ in range(K)]   # [glev][glwe][poly][N]
@@ -410,7 +422,6 @@ class StepCircuit:
         self.lwe_hash_out = cb.hash_no_pad(self.lwe_hash_in + [self.mask])
         cb.register_public_inputs(self.bsk_hash_out)
         cb.register_public_inputs(self.lwe_hash_out)
-        self.built = cb.build(api)
 
     def witness(self, acc_init, ggsw_flat, acc_in, counter, mask, bsk_hash_in, lwe_hash_in):
         """PartialWitness of one step (ivc_based_vpbs.rs:283-299, 314-330, 345-361) -> wires via the PRODUCT's generators"""

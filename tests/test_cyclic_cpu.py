@@ -1,0 +1,149 @@
+"""The reference's CYCLIC step circuit (ivc_based_vpbs.rs:159-386: each step proof verifies the previous one in circuit) on the CPU: the
+circuit description of tests/cyclic_circuit.py, witnesses by the PRODUCT's generators (host), proofs by the CPU oracle's prover, every
+proof accepted by the product's host verifier.  The GPU twin is tests/test_gpu_step_circuit.py::test_ivc_chain_*."""
+import random
+
+import numpy as np
+import pytest
+
+import cyclic_circuit as cc
+import gates_oracle as go
+import oracle as orc
+import step_oracle
+import tfhe_oracle as T
+from cyclic_circuit import P
+from vpbs_amd import api
+
+
+def test_gate_constraints_model_matches_the_product():
+    """the gate-constraint restatement the in-circuit verifier is generated from (cyclic_circuit.gate_constraints, all 14 gates) equals the
+    product's evaluation at a GF(p^2) point (vpbs_gate_terms_at)"""
+    rnd = random.Random(9)
+    gs = api.GateSet(cc.GATE_SPEC)
+    consts = [(rnd.randrange(P), rnd.randrange(P)) for _ in range(gs.num_selectors + gs.num_constants)]
+    wires = [(rnd.randrange(P), rnd.randrange(P)) for _ in range(135)]
+    pih = [rnd.randrange(P) for _ in range(4)]
+    alphas = [rnd.randrange(P) for _ in range(2)]
+    B = cc.NumBackend()
+    total = cc.gate_terms(B, gs, api, consts, wires, [(h, 0) for h in pih])
+    want = gs.terms_at(np.array(consts, np.uint64), np.array(wires, np.uint64), pih, alphas)
+    for a in range(2):
+        acc = (0, 0)
+        for t in reversed(total):
+            acc = B.add(B.mul(acc, (alphas[a], 0)), t)
+        assert acc == tuple(int(x) for x in want[a])
+
+
+class OracleProver:
+    """prove / verify of one circuit with the CPU oracle (the GPU tests use the product's prover here)"""
+
+    def __init__(self, built):
+        self.built = built
+        self.sigma = built.circuit.sigma_values()
+        self.cs_values = np.concatenate([built.constants, self.sigma])
+        self.cs = orc.Batch(self.cs_values, 3, 4, True)
+        self.cap = self.cs.cap()
+        self.vk = cc.vk_words(self.cap, built.log_n)
+        self.nconst = built.constants.shape[0]
+        self.gs, self.ps = go.GateSet(cc.GATE_SPEC), api.GateSet(cc.GATE_SPEC)
+
+    def prove(self, wires, pis):
+        p = step_oracle.prove_step({"constants_sigmas": self.cs_values, "wires": wires, "quotient": None}, self.vk[:4], pis, self.built.log_n,
+                                   cs_batch=self.cs, sigmas=self.sigma, n_routed=80, n_constants=self.nconst, gates=self.gs)
+        assert self.verify(p, pis)
+        return p
+
+    def verify(self, p, pis):
+        return api.verify_step(p, self.cap, p["ncols"], self.vk[:4], pis, self.built.log_n, n_constants=self.nconst, n_routed=80, gates=self.ps)
+
+
+def test_in_circuit_verifier_accepts_a_proof_and_rejects_a_tampered_one():
+    """verify_proof (recursive_verifier.rs) as a circuit: the witness generated from a real proof satisfies every gate and copy constraint,
+    the in-circuit transcript reproduces the prover's challenges; one flipped opening makes the circuit unsatisfiable"""
+    rnd = random.Random(3)
+    log_c = 6
+    gs = go.GateSet(cc.GATE_SPEC)
+    cpis = [rnd.randrange(P) for _ in range(4)]
+    constants, wires, sigma, _ = go.demo_circuit(rnd, gs, log_c, cpis)
+    cs_values = np.concatenate([constants, sigma])
+    cs = orc.Batch(cs_values, 3, 4, True)
+    digest = cc.circuit_digest(cs.cap(), log_c)
+    proof = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, digest, cpis, log_c, cs_batch=cs, sigmas=sigma,
+                                   n_routed=80, n_constants=constants.shape[0], gates=gs)
+    shape = cc.Shape(api, log_c, 4)
+    assert shape.ncols == proof["ncols"] and shape.fri_words == proof["fri"].size
+    vc = cc.VerifierOnlyCircuit(api, shape)
+    w = vc.built.circuit.generate_witness(vc.presets(shape.flat_proof(proof), cpis, digest, proof["cs_cap"]))
+    ok, msg = vc.built.circuit.check_witness(w, api.hash_no_pad(np.array(vc.built.values(w, vc.built.public_inputs), np.uint64)))
+    assert ok, msg
+    ch = vc.challenges
+    assert vc.built.values(w, ch["betas"] + ch["gammas"] + ch["alphas"] + list(ch["zeta"])) == [int(x) for x in proof["challenges"]]
+    for at in (shape.caps_words + 10, 3, shape.proof_words - 1, shape.caps_words + shape.openings_words + 200):
+        bad = shape.flat_proof(proof).copy()
+        bad[at] ^= np.uint64(1)
+        with pytest.raises(api.VpbsError, match="set twice|too large"):     # a connect that cannot hold, or the proof-of-work range check
+            vc.built.circuit.generate_witness(vc.presets(bad, cpis, digest, proof["cs_cap"]))
+
+
+def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
+    """verified_pbs (ivc_based_vpbs.rs:277-371): base proof of the dummy circuit, then the n + 2 steps, each taking the previous proof"""
+    N, K, ELL, LOGB, n_lwe = cy.params
+    s_to, s_lwe, s_glwe, bsk, ksk = keys
+    flat = lambda acc: [int(v) for p in acc for v in p]
+    base_pis = np.array(flat(acc_init) + [0] + [0] * (K * N) + [0] * 8 + [int(v) for v in C.vk], np.uint64)
+    proof, pis = prove_d(dm.witness(base_pis), base_pis), base_pis
+    plan = cy.built.circuit.witness_plan(cy.positions)
+    zero_ggsw = np.zeros(K * ELL * K * N, np.uint64)
+    steps = [(0, zero_ggsw, ct[n_lwe])] + [(1, bsk[x], ct[x]) for x in range(n_lwe)] + [(1, ksk, 0)]
+    proofs = []
+    for cond, ggsw, mask in steps:
+        wires = plan.run(cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk))
+        pis = np.array(cy.public_inputs(wires), np.uint64)
+        if check:
+            ok, msg = cy.built.circuit.check_witness(wires, api.hash_no_pad(pis))
+            assert ok, msg
+        proof = prove_c(wires, pis)
+        proofs.append((proof, pis))
+    plan.free()
+    return proofs
+
+
+def test_ivc_chain_on_the_cpu():
+    """BASELINE config 1 (N = 8 ring, one blind-rotation step, CPU prover): the cyclic circuit fits degree 2^13; base proof + first step +
+    CMUX + key switch, every proof verifying its predecessor in circuit; the last proof alone carries the statement (verify_pbs, :388-489):
+    test vector, counter n + 2, accumulator = the native chain's, chain hashes = the native sponge, verifier data = the circuit's own."""
+    N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
+    cy = cc.CyclicStepCircuit(api, N, K, ELL, LOGB, n_lwe, orc.negacyclic_params(3), log_n)
+    assert cy.built.log_n == 13 and cy.shape.n_pi == 109
+    with pytest.raises(ValueError, match="does not fit"):
+        cc.CyclicStepCircuit(api, N, K, ELL, LOGB, n_lwe, orc.negacyclic_params(3), 12)
+    dm = cc.DummyCircuit(api, log_n, cy.shape.n_pi)
+    C, D = OracleProver(cy.built), OracleProver(dm.built)
+    rng = np.random.default_rng(5)
+    ring = T.Ring(3)
+    s_to, s_lwe, s_glwe, bsk, ksk = T.pbs_setup(ring, rng, n_lwe, K, ELL, LOGB)
+    delta = T.get_delta(4)
+    testv = T.get_testv(ring, 2, delta)
+    ct = T.lwe_encrypt(rng, s_lwe, delta % P)
+    acc_init = [[0] * N for _ in range(K - 1)] + [testv]
+    keys = (s_to, s_lwe, s_glwe, [T.flatten_ggsw(g) for g in bsk], T.flatten_ggsw(ksk))
+    proofs = run_chain(cy, dm, C, D, C.prove, D.prove, keys, ct, acc_init)
+    accs = T.pbs_chain(ring, acc_init, ct, bsk, ksk, K, ELL, LOGB)
+    kn = K * N
+    for s, (proof, pis) in enumerate(proofs):
+        assert int(pis[kn]) == s + 1 and [int(v) for v in pis[kn + 1:2 * kn + 1]] == [int(v) for p in accs[s] for v in p]
+    proof, pis = proofs[-1]
+    # verify_pbs on the LAST proof only
+    assert C.verify(proof, pis)
+    assert [int(v) for v in pis[:kn]] == [0] * (kn - N) + [int(v) for v in testv] and int(pis[kn]) == n_lwe + 2
+    assert (pis[-68:] == C.vk).all()                                                      # check_cyclic_proof_verifier_data
+    zero_ggsw = np.zeros(K * ELL * K * N, np.uint64)
+    bsk_items = np.stack([zero_ggsw] + keys[3] + [keys[4]])
+    lwe_items = np.array([[ct[n_lwe]]] + [[ct[x]] for x in range(n_lwe)] + [[0]], np.uint64)
+    assert api.hash_chain(bsk_items, pis[2 * kn + 1:2 * kn + 5])[1] and api.hash_chain(lwe_items, pis[2 * kn + 5:2 * kn + 9])[1]
+    m_bar = T.glwe_decrypt(ring, s_to, [[int(v) for v in pis[kn + 1 + p * N:kn + 1 + (p + 1) * N]] for p in range(K)], K)
+    assert round(m_bar[0] / delta) % 4 == 1
+    # a proof of another statement is not accepted in its place
+    wrong = pis.copy()
+    wrong[kn + 2] ^= np.uint64(1)
+    assert not C.verify(proof, wrong)
