@@ -454,6 +454,7 @@ def main():
     ap.add_argument("--no-step-circuit", action="store_true", help="skip the witness -> proof pipeline on the real step circuit")
     ap.add_argument("--no-whole-pbs", action="store_true", help="skip tools/prove_pbs.py (one whole vPBS, 730 step proofs, end to end)")
     ap.add_argument("--no-survey-size", action="store_true", help="skip the secondary degree-2^15 measurement (profiling runs)")
+    ap.add_argument("--no-ivc", action="store_true", help="skip tools/prove_ivc.py (one vPBS as the reference's IVC chain: 730 proofs of the cyclic circuit)")
     ap.add_argument("--no-batch128", action="store_true", help="skip the BASELINE config 3 leg (128 independent proofs through a pool of contexts)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
                     help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
@@ -725,6 +726,20 @@ def main():
                 out["whole_pbs"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
             except Exception as e:
                 out["whole_pbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_ivc:
+            # the reference's actual object: ONE vPBS proof = an IVC chain of 730 step proofs of the CYCLIC circuit (each verifies its
+            # predecessor in circuit), measured end to end in its own process (tools/prove_ivc.py)
+            for ctx in ctxs:
+                ctx.close()
+            ctxs = []
+            torch.cuda.empty_cache()
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], capture_output=True, text=True, timeout=900,
+                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank)))
+                out["ivc_chain"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
+            except Exception as e:
+                out["ivc_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             parity, out["cpu_baseline"] = cpu_baseline(gpu_proof)
             out["parity_checked_full_size"] = parity is not None

@@ -57,6 +57,10 @@ int main(int argc, char** argv) {
     const uint64_t *f_gates = take(4 * n_gates), *f_rows = take(n), *f_consts = take((size_t)n_const_cols * n), *f_copies = take(2 * n_copies),
                    *f_gens = take(gen_words), *f_preset = take(n_preset), *f_pi = take(n_pi), *f_values = take(n_preset), *f_expect = take(n_pi);
     if ((size_t)(p - file.data()) + 6 == file.size()) p += 6;   // optional trailer {N, K, ELL, LOGB, n_lwe, used_rows}
+    if ((size_t)(p - file.data()) + 8 == file.size()) {
+        std::fprintf(stderr, "a cyclic / dummy circuit file carries no sample witness (it needs a proof): see tools/prove_ivc.py\n");
+        return 2;
+    }
     if ((size_t)(p - file.data()) != file.size()) {
         std::fprintf(stderr, "truncated file\n");
         return 2;

@@ -258,6 +258,20 @@ int vpbs_witness_plan_create(const vpbs_circuit* circuit, const uint32_t* preset
 int vpbs_witness_plan_run(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out /* [n_wires][n] */,
                           char* err, size_t err_len);
 void vpbs_witness_plan_free(vpbs_witness_plan* plan);
+/* Two-phase runs, for a chain in which part of the PartialWitness arrives late -- the previous proof of an IVC step
+ * (/root/reference/src/vtfhe/ivc_based_vpbs.rs:314-330: set_proof_with_pis_target(&inner_cyclic_proof_with_pis, &proof)): everything that does
+ * not depend on the late targets is generated while the previous proof is still being computed.
+ *   split     : late[i] != 0 marks preset i (plan order) as late; every generator that reads a late value, directly or not, becomes late
+ *   run_early : the early presets (the late entries of preset_val are ignored), the early generators, the whole wire matrix (late wires 0)
+ *   run_late  : the late presets, the late generators, the late wires written into the same matrix; consumes the state
+ * run_early + run_late produce exactly the matrix of vpbs_witness_plan_run. */
+typedef struct vpbs_witness_state vpbs_witness_state;
+int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
+int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
+                                vpbs_witness_state** state_out, char* err, size_t err_len);
+int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
+                               char* err, size_t err_len);
+void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that run_late did not consume */
 /* out: {value slots (copy-constraint classes that carry a value), scheduled generators, dependency levels of the device schedule
  * (0: the plan has no device form, see vpbs_witness_device_create), wire positions written by full_witness} */
 int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);

@@ -96,8 +96,19 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     zero_ggsw = np.zeros(K * ELL * K * N, np.uint64)
     steps = [(0, zero_ggsw, ct[n_lwe])] + [(1, bsk[x], ct[x]) for x in range(n_lwe)] + [(1, ksk, 0)]
     proofs = []
+    # two-phase plan: the proof words are the late part of the PartialWitness (vpbs_witness_plan_split); both forms give the same wires
+    split = cy.built.circuit.witness_plan(cy.positions)
+    late = np.zeros(len(cy.positions), np.uint8)
+    late[:cy.shape.proof_words] = 1
+    split.split(late)
     for cond, ggsw, mask in steps:
-        wires = plan.run(cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk))
+        values = cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk)
+        wires = plan.run(values)
+        early_values = values.copy()
+        early_values[:cy.shape.proof_words] = 0xDEAD                  # the late entries are not read by the early phase
+        two = np.empty_like(wires)
+        state = split.run_early(early_values, two)
+        assert (split.run_late(state, values, two) == wires).all()
         pis = np.array(cy.public_inputs(wires), np.uint64)
         if check:
             ok, msg = cy.built.circuit.check_witness(wires, api.hash_no_pad(pis))
@@ -105,6 +116,7 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
         proof = prove_c(wires, pis)
         proofs.append((proof, pis))
     plan.free()
+    split.free()
     return proofs
 
 

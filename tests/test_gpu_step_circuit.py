@@ -341,3 +341,24 @@ def test_device_witness_at_paper_parameters_against_independent_evaluations(ctx)
             assert (plan.run(vals[:, s]) == w).all()
     dev.free()
     plan.free()
+
+
+@pytest.mark.parametrize("args,expect_steps", [(["8", "6", "13"], 8), (["1024", "728", "16", "5"], 5)])
+def test_ivc_chain_tool(args, expect_steps):
+    """tools/prove_ivc.py: the reference's IVC (ivc_based_vpbs.rs:159-386) on the GPU -- every step proof of the CYCLIC circuit verifies its
+    predecessor in circuit; the last proof alone is verified (after a byte round trip) and carries test vector, counter, verifier data, the
+    native accumulator and both native chain hashes.  N = 8: the whole chain of a PBS with n = 6 (BASELINE config 1's ring), decrypting to
+    the message; N = 1024: the first five steps of the paper-parameter chain (degree 2^16, 4173 public inputs; BASELINE config 4's circuit)."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, entry.ROOT + "/tools/prove_ivc.py"] + args, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["step_proofs"] == expect_steps
+    if args[0] == "8":
+        assert d["decrypted"] == d["message"] == 1
+    else:
+        assert 150_000 < d["proof_bytes"] < 210_000                 # the paper's "~200 kB" (ivc_based_vpbs.rs:488)
+    print(d["ms_per_step_split"], d["seconds"])

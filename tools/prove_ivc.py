@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""One verifiable PBS as the reference produces it: an IVC chain (/root/reference/src/vtfhe/ivc_based_vpbs.rs:159-386 `verified_pbs`) --
+n + 2 step proofs of the CYCLIC step circuit, each verifying its predecessor in circuit, so that the LAST proof alone (~190 kB) attests to the
+whole bootstrap -- followed by `verify_pbs` (:388-489) on that one proof.
+
+The circuit arrives as data (verifiable-fhe-paper_amd/circuit_file.py: the exported cyclic circuit and its dummy circuit; this tool imports
+no circuit builder).  Per step: the PartialWitness (previous proof's words and public inputs, condition bit, GGSW, mask, verifier data) ->
+compiled witness generation on the host in two phases (what does not depend on the previous proof is generated ahead on a second thread;
+the recursive-verifier rows wait for the proof, so the chain itself is sequential by construction) -> wires to the device -> vpbs_prove_step -> the proof's words feed the next step.  Keys, test vector and the LWE input are the
+seeded ones of vpbs_keygen / vpbs_testv / vpbs_lwe_encrypt at the paper's noise.
+
+usage: tools/prove_ivc.py [N=1024] [n_lwe=728] [log_n=16] [steps=all]   ->  one JSON line
+  steps < n + 2 proves only a prefix of the chain (tests); verify_pbs's counter / hash checks are then made against that prefix."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import vpbs_amd  # noqa: E402
+from vpbs_amd import api, circuit_file  # noqa: E402
+
+K, ELL, LOGB = 2, 4, 5
+P = api.P
+
+
+class Circuit:
+    """one exported circuit on one context: constants/sigmas commitment, verifier data, witness plan, prove / verify"""
+
+    def __init__(self, ctx, path):
+        self.ctx = ctx
+        self.d = d = circuit_file.load(path)
+        self.sigma = d.circuit.sigma_values()
+        self.cs_values = np.concatenate([d.constants, self.sigma])
+        self.cs = ctx.commit_values(self.cs_values)
+        self.cap = self.cs.cap()
+        self.vk = circuit_file.verifier_data_words(self.cap, d.log_n)
+        self.d_sigma = torch.from_numpy(self.sigma.view(np.int64)).cuda()
+        self.plan = d.circuit.witness_plan(d.preset_pos)
+        pi = np.array(d.pi_pos)
+        self.pi_cols, self.pi_rows = pi[:, 0], pi[:, 1]
+        self.ncols = [d.n_constants + 80, 135, 20, 16]
+
+    def prove(self, d_wires_ptr, pis):
+        si = self.ctx.make_step_inputs(self.d.log_n, d_wires_ptr, None, None, self.cs, self.vk[:4], pis, on_device=True, shapes=(135, 20, 16),
+                                       sigmas=int(self.d_sigma.data_ptr()), n_routed=80, n_constants=self.d.n_constants, gates=self.d.gates)
+        return self.ctx.prove_step(si), si
+
+    def verify(self, proof, pis):
+        return api.verify_step(proof, self.cap, self.ncols, self.vk[:4], pis, self.d.log_n, n_constants=self.d.n_constants, n_routed=80,
+                               gates=self.d.gates)
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    n_lwe = int(sys.argv[2]) if len(sys.argv) > 2 else 728
+    log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    total = n_lwe + 2
+    steps = min(total, int(sys.argv[4])) if len(sys.argv) > 4 else total
+    device = int(os.environ.get("VPBS_PBS_DEVICE", "0"))
+    torch.cuda.set_device(device)
+    t_setup = time.perf_counter()
+    cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
+    cyc, dum = Circuit(ctx, cyc_path), Circuit(ctx, dummy_path)
+    shape_words = cyc.d.meta["proof_words"]
+    n_pi, kn = len(cyc.d.pi_pos), K * N
+    assert n_pi == 2 * kn + 9 + 68 and len(dum.d.preset_pos) == n_pi
+    t_setup = time.perf_counter() - t_setup
+
+    # main.rs:40-52 with seeded generators (before the clock: key material exists once per key)
+    t_keys = time.perf_counter()
+    message = int(os.environ.get("VPBS_PBS_MESSAGE", "1"))
+    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728, 4.99027217501041e-8, 1.17021618159313e-5)
+    testv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * message % P)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), testv.reshape(1, N)])
+    t_keys = time.perf_counter() - t_keys
+    ggsw_len = K * ELL * K * N
+    zero_ggsw = np.zeros(ggsw_len, np.uint64)
+    plan_steps = [(0, zero_ggsw, int(ct[n_lwe]))] + [(1, keys["bsk"][x], int(ct[x])) for x in range(n_lwe)] + [(1, keys["ksk"], 0)]
+
+    n_buf = 3
+    bufs = [torch.empty((135, cyc.d.n), dtype=torch.int64).pin_memory() for _ in range(n_buf)]
+    views = [b.numpy().view(np.uint64) for b in bufs]
+    d_wires = torch.empty((135, cyc.d.n), dtype=torch.int64, device="cuda")
+    flat = lambda p: np.concatenate([np.asarray(p[k], np.uint64).reshape(-1) for k in ("caps", "openings", "fri")])
+    # The previous proof is the LATE part of a step's PartialWitness: everything that does not depend on it -- the step logic, both chain
+    # hashes, the public-input hashes, i.e. three quarters of the generator work -- is generated ahead by a second host thread
+    # (vpbs_witness_plan_split / run_early), which also yields the step's public inputs, the only thing the next early phase needs.
+    late_mask = np.zeros(len(cyc.d.preset_pos), np.uint8)
+    late_mask[:shape_words] = 1
+    cyc.plan.split(late_mask)
+    import queue
+    import threading
+    free_bufs, ready, errs = queue.Queue(), queue.Queue(), []
+    for i in range(n_buf):
+        free_bufs.put(i)
+    base_pis = np.concatenate([acc_init.reshape(-1), np.zeros(1 + kn + 8, np.uint64), cyc.vk])
+    t_early = [0.0]
+
+    def early_thread():
+        try:
+            pis_prev = base_pis
+            zeros = np.zeros(shape_words, np.uint64)
+            for s in range(steps):
+                cond, ggsw, mask = plan_steps[s]
+                b = free_bufs.get()
+                t = time.perf_counter()
+                values = np.concatenate([zeros, pis_prev, np.array([cond], np.uint64), ggsw, np.array([mask], np.uint64), cyc.vk, dum.vk])
+                state = cyc.plan.run_early(values, views[b])
+                pis_prev = views[b][cyc.pi_cols, cyc.pi_rows].copy()     # public inputs never depend on the inner proof's words
+                t_early[0] += time.perf_counter() - t
+                ready.put((b, state, values, pis_prev))
+        except Exception as e:
+            errs.append(e)
+            ready.put(None)
+
+    t_wit = t_copy = t_prove = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    worker = threading.Thread(target=early_thread)
+    worker.start()
+    # cyclic_base_proof (ivc_based_vpbs.rs:292-299): a proof of the dummy circuit whose public inputs carry the initial accumulator and the
+    # cyclic circuit's verifier data
+    base_host = torch.empty((135, dum.d.n), dtype=torch.int64).pin_memory()
+    dum.plan.run(base_pis, out=base_host.numpy().view(np.uint64))
+    d_wires.copy_(base_host, non_blocking=True)
+    torch.cuda.synchronize()
+    proof, _ = dum.prove(d_wires.data_ptr(), base_pis)
+    t_base = time.perf_counter() - t0
+    last = None
+    for s in range(steps):
+        item = ready.get()
+        if item is None:
+            raise errs[0]
+        b, state, values, pis = item
+        t = time.perf_counter()
+        values[:shape_words] = flat(proof)
+        cyc.plan.run_late(state, values, views[b])
+        t_wit += time.perf_counter() - t
+        t = time.perf_counter()
+        d_wires.copy_(bufs[b], non_blocking=True)
+        torch.cuda.synchronize()
+        free_bufs.put(b)
+        t_copy += time.perf_counter() - t
+        t = time.perf_counter()
+        proof, last = cyc.prove(d_wires.data_ptr(), pis)
+        t_prove += time.perf_counter() - t
+    worker.join()
+    seconds = time.perf_counter() - t0
+
+    # verify_pbs (:388-489) on the LAST proof only
+    t = time.perf_counter()
+    blob = ctx.step_proof_to_bytes(last, cyc.d.n_constants, proof)
+    back, back_pis = api.step_proof_from_bytes(blob, cyc.ncols, log_n, cyc.d.n_constants)
+    assert cyc.verify(back, back_pis), "the final proof does not verify"
+    t_verify = time.perf_counter() - t
+    assert (back_pis[:kn] == acc_init.reshape(-1)).all() and int(back_pis[kn]) == steps          # test vector, number of steps
+    assert (back_pis[-68:] == cyc.vk).all()                                                      # check_cyclic_proof_verifier_data
+    bsk_items = np.stack([zero_ggsw] + [keys["bsk"][x] for x in range(min(steps - 1, n_lwe))] + ([keys["ksk"]] if steps == total else []))
+    lwe_items = np.array([[plan_steps[s][2]] for s in range(steps)], np.uint64)
+    assert api.hash_chain(bsk_items, back_pis[2 * kn + 1:2 * kn + 5])[1] and api.hash_chain(lwe_items, back_pis[2 * kn + 5:2 * kn + 9])[1]
+    accs = ctx.pbs_accumulator_chain(acc_init, ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
+    assert (back_pis[kn + 1:2 * kn + 1] == accs[steps - 1].reshape(-1)).all()                    # the accumulator the native chain reaches
+    decrypted = None
+    if steps == total:
+        m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
+        decrypted = round(int(m_bar[0]) / delta) % 4
+        assert decrypted == message, (decrypted, message)
+    print(json.dumps({
+        "what": "one vPBS as an IVC chain (ivc_based_vpbs.rs verified_pbs): %d of the %d step proofs of the CYCLIC step circuit (step logic + "
+                "in-circuit verifier of the previous proof: %d gate rows, degree 2^%d, %d public inputs) at N=%d, k=1, ELL=4, LOGB=5, n=%d on "
+                "1 x MI355X; the last proof alone is the vPBS proof" % (steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe),
+        "step_proofs": steps, "seconds": seconds, "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
+        "vpbs_proofs_per_s": (1.0 / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
+        "ms_per_step_split": {"witness_late_phase_host": 1e3 * t_wit / steps, "wires_to_device": 1e3 * t_copy / steps,
+                              "prove_step": 1e3 * t_prove / steps, "base_proof_once": 1e3 * t_base,
+                              "witness_early_phase_on_a_second_thread": 1e3 * t_early[0] / steps},
+        "proof_bytes": len(blob), "verify_last_proof_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted,
+        "before_the_clock": {"circuit_files_commit_plan_s": t_setup, "seeded_keygen_s": t_keys},
+        "checks": "final proof serialised, parsed back and verified by vpbs_verify_step (full check); its public inputs carry the test vector, "
+                  "counter = number of steps, the circuit's own verifier data, the native accumulator and both native chain hashes"
+                  + ("; the bootstrapped ciphertext decrypts to the message" if steps == total else "")}))
+    cyc.plan.free()
+    dum.plan.free()
+    cyc.cs.free()
+    dum.cs.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

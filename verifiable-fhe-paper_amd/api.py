@@ -163,6 +163,10 @@ SIGNATURES = {
     "vpbs_witness_plan_run": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.c_char_p, _sz]),
     "vpbs_step_proof_from_bytes": (C.c_long, [C.POINTER(VerifyInputsC), C.POINTER(C.c_uint8), _sz, U64P, U64P, U64P, U64P, _sz]),
     "vpbs_witness_plan_free": (None, [C.c_void_p]),
+    "vpbs_witness_plan_split": (_i, [C.c_void_p, C.POINTER(C.c_uint8), C.c_char_p, _sz]),
+    "vpbs_witness_plan_run_early": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
+    "vpbs_witness_plan_run_late": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
+    "vpbs_witness_state_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "vpbs_witness_device_run": (_i, [C.c_void_p, U64P, C.c_uint]),
@@ -421,6 +425,32 @@ class WitnessPlan:
         rc = lib().vpbs_witness_plan_run(self.h, _ptr(val) if val.size else None, threads, _ptr(out), err, 512)
         if rc:
             raise VpbsError("vpbs_witness_plan_run: " + err.value.decode())
+        return out
+
+    def split(self, late):
+        """vpbs_witness_plan_split: late[i] marks preset i (creation order) as arriving late -> run_early / run_late"""
+        m = np.ascontiguousarray(np.asarray(late, dtype=np.uint8))
+        assert m.size == self.n_preset
+        err = C.create_string_buffer(512)
+        if lib().vpbs_witness_plan_split(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), err, 512):
+            raise VpbsError("vpbs_witness_plan_split: " + err.value.decode())
+
+    def run_early(self, values, out, threads=0):
+        """everything that does not depend on the late presets -> opaque state for run_late (out: the [n_wires][n] matrix, filled)"""
+        val = _u64(values)
+        assert val.size == self.n_preset and out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
+        st, err = C.c_void_p(), C.create_string_buffer(512)
+        if lib().vpbs_witness_plan_run_early(self.h, _ptr(val), threads, _ptr(out), C.byref(st), err, 512):
+            raise VpbsError("vpbs_witness_plan_run_early: " + err.value.decode())
+        return st
+
+    def run_late(self, state, values, out):
+        """the late presets and what depends on them, into the same matrix; consumes the state"""
+        val = _u64(values)
+        assert val.size == self.n_preset
+        err = C.create_string_buffer(512)
+        if lib().vpbs_witness_plan_run_late(self.h, state, _ptr(val), _ptr(out), err, 512):
+            raise VpbsError("vpbs_witness_plan_run_late: " + err.value.decode())
         return out
 
     def stats(self):

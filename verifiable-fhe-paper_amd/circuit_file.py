@@ -6,7 +6,8 @@ side, /root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155 `build_step_circuit` ->
 
 File: header {magic, log_n, n_wires, n_routed, n_gates, n_constants_cols, n_copies, n_generators, generator_words, n_preset, n_public_inputs};
 gates [n_gates][kind, p0, p1, p2]; row_gate [n]; constants [cols][n]; copies [n_copies][2]; generators {kind, p0, n_in, n_out, in.., out..}*;
-preset positions; public-input positions; sample preset values; expected public inputs; optional trailer {N, K, ELL, LOGB, n_lwe, used_rows}.
+preset positions; public-input positions; sample preset values; expected public inputs; optional trailer {N, K, ELL, LOGB, n_lwe, used_rows
+[, kind, proof_words]} (kind 1: the cyclic step circuit, 2: its dummy circuit -- no sample witness in those files).
 Positions are column * n + row."""
 import os
 import subprocess
@@ -58,6 +59,8 @@ class CircuitDescription:
         self.meta = {}
         if words.size - pos >= 6:
             self.meta = dict(zip(("N", "K", "ELL", "LOGB", "n_lwe", "used_rows"), (int(x) for x in take(6))))
+        if words.size - pos >= 2:       # cyclic / dummy circuits: kind (1 / 2) and the number of proof words among the presets
+            self.meta.update(zip(("kind", "proof_words"), (int(x) for x in take(2))))
         self.preset_pos = [(int(x) // n, int(x) % n) for x in self.preset_flat]
         self.pi_pos = [(int(x) // n, int(x) % n) for x in self.pi_flat]
         self.circuit = api.Circuit(self.gates, self.log_n, row_gate, self.constants, copies, self.n_wires, self.n_routed, gens)
@@ -85,3 +88,32 @@ def ensure_step_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728):
                                str(n_lwe)], stdout=subprocess.DEVNULL)
         os.replace(tmp, path)
     return path
+
+
+def circuit_digest(cs_cap, log_n):
+    """verifier_only.circuit_digest as this stack defines it: hash_no_pad(constants/sigmas cap || degree bits).  (plonky2 hashes the cap with
+    a domain separator and the degree; the value only has to be fixed per circuit -- it is the first thing the transcript absorbs.)"""
+    return api.hash_no_pad(np.concatenate([np.asarray(cs_cap, np.uint64).reshape(-1), np.array([log_n], np.uint64)]))
+
+
+def verifier_data_words(cs_cap, log_n):
+    """the 68 public-input words of add_verifier_data_public_inputs: circuit digest [4], then the cap [16][4]"""
+    return np.concatenate([circuit_digest(cs_cap, log_n), np.asarray(cs_cap, np.uint64).reshape(-1)])
+
+
+def cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n):
+    stem = "N%d_K%d_ELL%d_LOGB%d_n%d_deg%d.bin" % (N, K, ELL, LOGB, n_lwe, log_n)
+    return os.path.join(DIR, "cyclic_" + stem), os.path.join(DIR, "dummy_" + stem)
+
+
+def ensure_cyclic_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728, log_n=16):
+    """(cyclic circuit file, dummy circuit file) of the IVC chain at these parameters; exported on first use by the exporter process"""
+    path, dummy = cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n)
+    if not (os.path.exists(path) and os.path.exists(dummy)):
+        os.makedirs(DIR, exist_ok=True)
+        tmp, tmpd = path + ".tmp%d" % os.getpid(), dummy + ".tmp%d" % os.getpid()
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_step_circuit.py"), "--cyclic", tmp, tmpd] +
+                              [str(x) for x in (N, K, ELL, LOGB, n_lwe, log_n)], stdout=subprocess.DEVNULL)
+        os.replace(tmpd, dummy)
+        os.replace(tmp, path)
+    return path, dummy

@@ -327,6 +327,11 @@ struct vpbs_witness_plan {
     std::vector<Step> schedule;
     std::vector<u32> preset_slot, preset_pos;
     std::vector<u32> out_pos, out_slot;         // every position that carries a slot, ascending (full_witness)
+    // ---- two-phase runs (vpbs_witness_plan_split): some presets arrive late (the previous proof of an IVC step); a generator is LATE when
+    // anything it reads is, everything else can run before the late values exist
+    bool is_split = false;
+    std::vector<uint8_t> preset_late, step_late;
+    std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late
 
     // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
     // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
@@ -799,10 +804,179 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
     lap("full_witness");
     return VPBS_OK;
 }
+// ---- two-phase runs ----
+// Taint propagation along the schedule: the late presets taint their slots, a step that reads a tainted slot is late and taints what it
+// writes.  Reads / writes of a gate generator are found the way plan creation finds them (gen_run on flags).
+int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
+    if (!pp || !late) {
+        err = "malformed arguments";
+        return VPBS_ERR_INVALID;
+    }
+    vpbs_witness_plan& p = *pp;
+    std::vector<uint8_t> taint(p.n_slots, 0), ready(p.n_slots, 1);
+    p.preset_late.assign(late, late + p.preset_slot.size());
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (late[i]) taint[p.preset_slot[i]] = 1;
+    p.step_late.assign(p.schedule.size(), 0);
+    const unsigned mc = std::max(1u, p.max_consts);
+    std::vector<unsigned> deps;
+    std::vector<u32> written, written_w;
+    for (size_t i = 0; i < p.schedule.size(); ++i) {
+        const auto& st = p.schedule[i];
+        bool is_late = false;
+        if (st.row == NO_ROW) {
+            const auto& gg = p.gadgets[st.sub];
+            const u32* gs = p.gadget_slots.data() + gg.at;
+            for (unsigned k = 0; k < gg.n_in; ++k) is_late |= taint[gs[k]] != 0;
+            if (is_late)
+                for (unsigned k = 0; k < gg.n_out; ++k) taint[gs[gg.n_in + k]] = 1;
+        } else {
+            const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+            const u32* rs = p.row_slots.data() + p.row_off[st.row];
+            gen_deps(g, st.sub, deps);
+            for (unsigned w : deps) is_late |= taint[rs[w]] != 0;
+            if (is_late) {
+                written.clear();
+                written_w.clear();
+                FlagRow fr{ready, rs, written, written_w};
+                try {
+                    gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, fr, tables_of(g));
+                } catch (const GenError& e) {
+                    err = e.what;
+                    return VPBS_ERR_INVALID;
+                }
+                for (u32 slot : written) taint[slot] = 1;
+            }
+        }
+        p.step_late[i] = is_late ? 1 : 0;
+    }
+    p.late_out.clear();
+    for (size_t i = 0; i < p.out_slot.size(); ++i)
+        if (taint[p.out_slot[i]]) p.late_out.push_back((u32)i);
+    p.is_split = true;
+    return VPBS_OK;
+}
+}  // namespace
+}  // namespace vpbs
+
+struct vpbs_witness_state {
+    vpbs::SlotState s;
+};
+
+namespace vpbs {
+namespace {
+int run_steps(const vpbs_witness_plan& p, SlotState& s, int want_late, std::string& err) {
+    const unsigned mc = std::max(1u, p.max_consts);
+    for (size_t i = 0; i < p.schedule.size(); ++i) {
+        if (p.step_late[i] != want_late) continue;
+        const auto& st = p.schedule[i];
+        try {
+            if (st.row == NO_ROW) {
+                run_gadget(p, p.gadgets[st.sub], s);
+            } else {
+                SlotRow r{s, p.row_slots.data() + p.row_off[st.row], st.row};
+                const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+                gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, r, tables_of(g));
+            }
+        } catch (const GenError& e) {
+            err = e.what + (st.row == NO_ROW ? " (generator " + std::to_string(st.sub) + ")" : " (row " + std::to_string(st.row) + ")");
+            return VPBS_ERR_INVALID;
+        }
+        if (!s.error.empty()) {
+            err = s.error;
+            return VPBS_ERR_INVALID;
+        }
+    }
+    return VPBS_OK;
+}
 }  // namespace
 }  // namespace vpbs
 
 extern "C" {
+
+int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late, char* err, size_t err_len) {
+    std::string msg;
+    const int rc = vpbs::plan_split(plan, late, msg);
+    vpbs::report(err, err_len, msg);
+    return rc;
+}
+
+int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
+                                vpbs_witness_state** state_out, char* err, size_t err_len) {
+    using namespace vpbs;
+    if (!plan || !plan->is_split || !preset_val || !wires_out || !state_out) {
+        report(err, err_len, "malformed arguments (is the plan split?)");
+        return VPBS_ERR_INVALID;
+    }
+    const vpbs_witness_plan& p = *plan;
+    auto* st = new vpbs_witness_state{SlotState{std::vector<u64>(p.n_slots, 0), std::vector<uint8_t>(p.n_slots, 0), p.n, {}}};
+    SlotState& s = st->s;
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (!p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+    std::string msg = s.error;
+    int rc = msg.empty() ? run_steps(p, s, 0, msg) : VPBS_ERR_INVALID;
+    if (rc != VPBS_OK) {
+        report(err, err_len, msg);
+        delete st;
+        return rc;
+    }
+    // every wire takes its class's value: the late classes are still zero and are overwritten by run_late
+    if (threads == 0) threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    auto fill = [&](unsigned t) {
+        const size_t lo = p.total * t / threads, hi = p.total * (t + 1) / threads;
+        std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
+        const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
+        for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fill, t);
+    fill(0);
+    for (auto& th : pool) th.join();
+    *state_out = st;
+    return VPBS_OK;
+}
+
+int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
+                               char* err, size_t err_len) {
+    using namespace vpbs;
+    if (!plan || !plan->is_split || !state || !preset_val || !wires_out) {
+        report(err, err_len, "malformed arguments");
+        return VPBS_ERR_INVALID;
+    }
+    const vpbs_witness_plan& p = *plan;
+    SlotState& s = state->s;
+    const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t1 = std::chrono::steady_clock::now();
+        if (trace) std::fprintf(stderr, "[witness late] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+    lap("presets");
+    std::string msg = s.error;
+    const int rc = msg.empty() ? run_steps(p, s, 1, msg) : VPBS_ERR_INVALID;
+    lap("generators");
+    if (rc == VPBS_OK)
+        for (u32 i : p.late_out) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
+    lap("late wires");
+    if (trace) {
+        size_t n_late = 0, n_pos = 0;
+        for (size_t i = 0; i < p.schedule.size(); ++i)
+            if (p.step_late[i]) {
+                ++n_late;
+                if (p.schedule[i].row != NO_ROW && p.gates[p.row_gate[p.schedule[i].row]].kind == VPBS_GATE_POSEIDON) ++n_pos;
+            }
+        std::fprintf(stderr, "[witness late] %zu late generators (%zu PoseidonGate rows) of %zu, %zu late wire positions\n", n_late, n_pos,
+                     p.schedule.size(), p.late_out.size());
+    }
+    report(err, err_len, msg);
+    delete state;
+    return rc;
+}
+
+void vpbs_witness_state_free(vpbs_witness_state* state) { delete state; }
 
 int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t* row) {
     if (!gp || !row) return VPBS_ERR_INVALID;
