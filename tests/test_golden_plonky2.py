@@ -26,15 +26,21 @@ def load_fixture(path):
         a = np.fromfile(os.path.join(path, name + ".u64"), dtype="<u8")
         return a.reshape(shape) if shape else a
     n_cs = meta["n_constants"] + meta["n_routed"]
+
+    def opt(name, *shape):
+        return arr(name, *shape) if os.path.exists(os.path.join(path, name + ".u64")) else None
     fx = {"meta": meta, "n": n,
           "constants_sigmas_values": arr("constants_sigmas_values", n_cs, n), "circuit_digest": arr("circuit_digest"),
           "public_inputs": arr("public_inputs"), "witness_wires": arr("witness_wires", meta["n_wires"], n),
-          "zs_partial_products_values": arr("zs_partial_products_values", -1, n), "quotient_coeffs": arr("quotient_coeffs", -1, n),
-          "caps": arr("caps", 3, -1, 4), "constants_sigmas_cap": arr("constants_sigmas_cap", -1, 4), "challenges": arr("challenges"),
+          # only a plonky2 patched inside prove() can dump these two; a capture through the public API (tools/plonky2_capture) omits them
+          # and both are then recomputed from the wires (which needs the gates in meta.json)
+          "zs_partial_products_values": opt("zs_partial_products_values", -1, n), "quotient_coeffs": opt("quotient_coeffs", -1, n),
+          "caps": arr("caps", 3, -1, 4), "constants_sigmas_cap": arr("constants_sigmas_cap", -1, 4), "challenges": opt("challenges"),
           "openings": arr("openings", -1, 2), "fri": arr("fri")}
     pb = os.path.join(path, "proof_bytes.bin")
     fx["proof_bytes"] = open(pb, "rb").read() if os.path.exists(pb) else None
-    assert fx["challenges"].size == 3 * nc + 2
+    assert fx["challenges"] is None or fx["challenges"].size == 3 * nc + 2
+    assert fx["zs_partial_products_values"] is not None or meta.get("gates"), "a fixture without the Z / quotient data needs the gate list"
     return fx
 
 
@@ -49,27 +55,40 @@ def write_fixture(path, fx):
         open(os.path.join(path, "proof_bytes.bin"), "wb").write(fx["proof_bytes"])
 
 
+def _gate_spec(meta):
+    return [(api.GATE_KINDS[k] if isinstance(k, int) else k, p0, p1, p2) for k, p0, p1, p2 in meta["gates"]]
+
+
 def check_with_oracle(fx):
     """the CPU oracle against the fixture"""
+    import gates_oracle as go
     m = fx["meta"]
-    inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"],
-              "zs_partial_products": fx["zs_partial_products_values"], "quotient": fx["quotient_coeffs"]}
-    p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=m["num_challenges"],
-                               forced_pow=int(fx["fri"][-1]))
+    nc = m["num_challenges"]
+    supplied = fx["zs_partial_products_values"] is not None
+    sig = np.ascontiguousarray(fx["constants_sigmas_values"][m["n_constants"]:])
+    if supplied:
+        inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"],
+                  "zs_partial_products": fx["zs_partial_products_values"], "quotient": fx["quotient_coeffs"]}
+        p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=nc, forced_pow=int(fx["fri"][-1]))
+    else:   # Z / partial products and the quotient (gate constraints + permutation argument) recomputed from the wires
+        inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"], "quotient": None}
+        p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=nc, forced_pow=int(fx["fri"][-1]),
+                                   sigmas=sig, n_routed=m["n_routed"], n_constants=m["n_constants"], gates=go.GateSet(_gate_spec(m)))
     assert (p["cs_cap"] == fx["constants_sigmas_cap"]).all(), "constants_sigmas cap"
     for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
         assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
-    assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
+    if fx["challenges"] is not None:
+        assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
     assert (p["openings"] == fx["openings"]).all(), "openings"
     assert (p["fri"] == fx["fri"]).all(), "FRI proof"
     if fx["proof_bytes"] is not None:
-        got = step_oracle.to_bytes(p, p["ncols"], m["n_constants"], fx["public_inputs"], m["log_n"], num_challenges=m["num_challenges"])
+        got = step_oracle.to_bytes(p, p["ncols"], m["n_constants"], fx["public_inputs"], m["log_n"], num_challenges=nc)
         assert got == fx["proof_bytes"], "proof bytes"
-    # the permutation argument's partial products are recomputable from the wires and the transcript
-    nc = m["num_challenges"]
-    ch = [int(x) for x in fx["challenges"]]
-    zs = orc.partial_products(fx["witness_wires"][:m["n_routed"]], fx["constants_sigmas_values"][m["n_constants"]:], ch[:nc], ch[nc:2 * nc])
-    assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
+    if supplied:
+        # the permutation argument's partial products are recomputable from the wires and the transcript
+        ch = [int(x) for x in p["challenges"]]
+        zs = orc.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
+        assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
 
 
 def check_with_product(ctx, fx):
@@ -78,30 +97,38 @@ def check_with_product(ctx, fx):
     log_n, nc = m["log_n"], m["num_challenges"]
     cs = ctx.commit_values(fx["constants_sigmas_values"])
     assert (cs.cap() == fx["constants_sigmas_cap"]).all(), "constants_sigmas cap"
-    si = ctx.make_step_inputs(log_n, fx["witness_wires"], fx["zs_partial_products_values"], fx["quotient_coeffs"], cs, fx["circuit_digest"],
-                              fx["public_inputs"], num_challenges=nc, forced_pow=int(fx["fri"][-1]))
-    p = ctx.prove_step(si)
-    for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
-        assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
-    assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
-    assert (p["openings"] == fx["openings"]).all(), "openings"
-    assert (p["fri"] == fx["fri"]).all(), "FRI proof"
-    if fx["proof_bytes"] is not None:
-        assert ctx.step_proof_to_bytes(si, m["n_constants"], p) == fx["proof_bytes"], "proof bytes"
-    ncols = [cs.ncols, m["n_wires"], fx["zs_partial_products_values"].shape[0], fx["quotient_coeffs"].shape[0]]
-    assert api.verify_step_fri_only(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
-    # device partial products / quotient from the wires alone
     sig = np.ascontiguousarray(fx["constants_sigmas_values"][m["n_constants"]:])
-    ch = [int(x) for x in fx["challenges"]]
-    zs = ctx.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
-    assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
+    supplied = fx["zs_partial_products_values"] is not None
+    if supplied:
+        si = ctx.make_step_inputs(log_n, fx["witness_wires"], fx["zs_partial_products_values"], fx["quotient_coeffs"], cs, fx["circuit_digest"],
+                                  fx["public_inputs"], num_challenges=nc, forced_pow=int(fx["fri"][-1]))
+        p = ctx.prove_step(si)
+        for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
+            assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
+        if fx["challenges"] is not None:
+            assert [int(x) for x in p["challenges"]] == [int(x) for x in fx["challenges"]], "challenges (Fiat-Shamir transcript)"
+        assert (p["openings"] == fx["openings"]).all(), "openings"
+        assert (p["fri"] == fx["fri"]).all(), "FRI proof"
+        if fx["proof_bytes"] is not None:
+            assert ctx.step_proof_to_bytes(si, m["n_constants"], p) == fx["proof_bytes"], "proof bytes"
+        ncols = [cs.ncols, m["n_wires"], fx["zs_partial_products_values"].shape[0], fx["quotient_coeffs"].shape[0]]
+        assert api.verify_step_fri_only(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
+        ch = [int(x) for x in p["challenges"]]
+        zs = ctx.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
+        assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
     if m.get("gates"):
-        gates = api.GateSet([(api.GATE_KINDS[k] if isinstance(k, int) else k, p0, p1, p2) for k, p0, p1, p2 in m["gates"]])
+        # everything after the witness on the device: partial products, gate constraints, quotient -- from the wires alone
+        gates = api.GateSet(_gate_spec(m))
         si2 = ctx.make_step_inputs(log_n, fx["witness_wires"], None, None, cs, fx["circuit_digest"], fx["public_inputs"], num_challenges=nc,
                                    forced_pow=int(fx["fri"][-1]), sigmas=sig, n_routed=m["n_routed"], n_constants=m["n_constants"], gates=gates)
         p2 = ctx.prove_step(si2)
         assert (p2["caps"] == fx["caps"]).all(), "caps with the quotient evaluated on the device (gate constraints + permutation argument)"
+        assert (p2["openings"] == fx["openings"]).all(), "openings"
         assert (p2["fri"] == fx["fri"]).all(), "FRI proof with the quotient evaluated on the device"
+        if fx["proof_bytes"] is not None:
+            assert ctx.step_proof_to_bytes(si2, m["n_constants"], p2) == fx["proof_bytes"], "proof bytes"
+        assert api.verify_step(p2, cs.cap(), [cs.ncols, m["n_wires"], 20, 16], fx["circuit_digest"], fx["public_inputs"], log_n,
+                               num_challenges=nc, n_constants=m["n_constants"], n_routed=m["n_routed"], gates=gates)
     cs.free()
 
 
@@ -163,6 +190,43 @@ def test_fixture_roundtrip_with_an_oracle_made_fixture(tmp_path):
     fx["openings"][3][0] ^= np.uint64(1)
     with pytest.raises(AssertionError, match="openings"):
         check_with_oracle(fx)
+
+
+def test_public_api_capture_layout_converts_and_checks(tmp_path):
+    """what tools/plonky2_capture/capture.rs writes (a capture through plonky2's PUBLIC API: no Z / quotient / challenges files, gate ids
+    instead of a gate list, the copy-constraint forest) -> tools/plonky2_capture/to_fixture.py -> the fixture the golden tests consume and
+    the STEPCIRC circuit file; exercised on a capture simulated from this repository's own stack."""
+    import subprocess
+    import sys
+    import random
+    import gates_oracle as go
+    import regression_cases as rc
+    from vpbs_amd import circuit_file
+    sys.path.insert(0, os.path.join(ROOT, "tools", "plonky2_capture"))
+    import to_fixture
+    log_n = 6
+    rnd = random.Random(77)
+    gs, ps = go.GateSet(rc.GATES), api.GateSet(rc.GATES)
+    pis = [rnd.randrange(go.P) for _ in range(4)]
+    constants, wires, sigma, _, desc = go.demo_circuit(rnd, gs, log_n, pis, describe=True)
+    cs_values = np.concatenate([constants, sigma])
+    digest = np.array([9, 8, 7, 6], np.uint64)
+    p = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, digest, pis, log_n, sigmas=sigma, n_routed=80,
+                               n_constants=constants.shape[0], gates=gs)
+    cap_dir = str(tmp_path / "capture")
+    to_fixture.simulate_capture(cap_dir, ps, log_n, cs_values, constants.shape[0], wires, desc, digest, pis, p,
+                                step_oracle.to_bytes(p, p["ncols"], constants.shape[0], pis, log_n))
+    out, circ = str(tmp_path / "fixture"), str(tmp_path / "circuit.bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plonky2_capture", "to_fixture.py"), cap_dir, out, "--step", "0", "--circuit", circ],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fx = load_fixture(out)
+    assert fx["zs_partial_products_values"] is None and fx["meta"]["gates"]
+    check_with_oracle(fx)
+    d = circuit_file.load(circ)
+    assert (d.circuit.sigma_values() == sigma).all()                       # the forest -> copy constraints -> the captured sigma columns
+    ok, msg = d.circuit.check_witness(fx["witness_wires"], api.hash_no_pad(fx["public_inputs"]))
+    assert ok, msg
 
 
 @pytest.mark.gpu

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Turns what capture.rs wrote (a capture of the reference through plonky2's public API) into
+  * the golden fixture tests/test_golden_plonky2.py consumes (tests/golden/PLONKY2_FIXTURE_FORMAT.md): the gate ids become a gate list
+    after they have been checked, string by string and in order, against the prover's own `Gate::id()` restatement (vpbs_gate_id) and
+    selector layout (vpbs_gates_layout);
+  * optionally the circuit as a STEPCIRC file (verifiable-fhe-paper_amd/circuit_file.py): gate per row from the selector columns, constants,
+    copy constraints from the representative_map forest, public-input positions.  No generators: the witness of such a circuit comes from
+    the Rust side (`generate_partial_witness`), the captured `witness_wires` being the first examples.
+usage: to_fixture.py CAPTURE_DIR OUT_FIXTURE_DIR [--step K] [--circuit OUT.bin]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from vpbs_amd import api  # noqa: E402
+
+MAGIC = 0x5354455043495243
+UNUSED = 0xFFFFFFFF
+
+
+def parse_gate_id(gid):
+    """Gate::id() (a Debug string) -> (kind name, p0, p1, p2)"""
+    ints = lambda s: [int(x) for x in re.findall(r"(?<![\w.])\d+(?![\w.])", s)]
+    head = gid.split("{")[0].split("(")[0].strip()
+    if head == "NoopGate":
+        return ("noop", 0, 0, 0)
+    if head == "PublicInputGate":
+        return ("public_input", 0, 0, 0)
+    if head == "PoseidonGate":
+        return ("poseidon", 0, 0, 0)
+    if head == "PoseidonMdsGate":
+        return ("poseidon_mds", 0, 0, 0)
+    m = re.search(r"\{([^}]*)\}", gid)
+    fields = dict((k.strip(), v.strip()) for k, v in (f.split(":", 1) for f in m.group(1).split(",") if ":" in f and "[" not in f and "PhantomData" not in f)) if m else {}
+    if head == "ConstantGate":
+        return ("constant", int(fields["num_consts"]), 0, 0)
+    if head == "ArithmeticGate":
+        return ("arithmetic", int(fields["num_ops"]), 0, 0)
+    if head == "ArithmeticExtensionGate":
+        return ("arithmetic_ext", int(fields["num_ops"]), 0, 0)
+    if head == "MulExtensionGate":
+        return ("mul_ext", int(fields["num_ops"]), 0, 0)
+    if head == "BaseSumGate":
+        return ("base_sum", int(fields["num_limbs"]), int(re.search(r"Base:\s*(\d+)", gid).group(1)), 0)
+    if head == "ReducingGate":
+        return ("reducing", int(fields["num_coeffs"]), 0, 0)
+    if head == "ReducingExtensionGate":
+        return ("reducing_ext", int(fields["num_coeffs"]), 0, 0)
+    if head == "RandomAccessGate":
+        return ("random_access", int(fields["bits"]), int(fields["num_copies"]), int(fields["num_extra_constants"]))
+    if head == "ExponentiationGate":
+        return ("exponentiation", int(fields["num_power_bits"]), 0, 0)
+    if head == "CosetInterpolationGate":
+        return ("coset_interpolation", int(re.search(r"subgroup_bits:\s*(\d+)", gid).group(1)), int(re.search(r"degree:\s*(\d+)", gid).group(1)), 0)
+    raise ValueError("a gate this prover does not know: " + gid)
+
+
+def gate_set_from_ids(meta):
+    """the product's GateSet for the captured circuit, after checking ids / order / selector layout against the capture"""
+    spec = [parse_gate_id(g) for g in meta["gate_ids"]]
+    gs = api.GateSet(spec, max_degree=meta.get("quotient_degree_factor", 8) + 1)
+    ids = gs.ids()
+    for mine, theirs in zip(ids, meta["gate_ids"]):
+        if mine != theirs:
+            raise ValueError("Gate::id() differs:\n  prover   : %s\n  plonky2  : %s" % (mine, theirs))
+    if "selector_indices" in meta:
+        mine = [g.selector_index for g in gs]
+        if mine != list(meta["selector_indices"]):
+            raise ValueError("selector_indices differ: %r vs %r" % (mine, meta["selector_indices"]))
+        groups = sorted({(g.group_start, g.group_end) for g in gs})
+        if [list(g) for g in groups] != [list(g) for g in meta["selector_groups"]]:
+            raise ValueError("selector groups differ: %r vs %r" % (groups, meta["selector_groups"]))
+    return spec, gs
+
+
+def convert_step(cap_dir, step, out_dir):
+    src = os.path.join(cap_dir, "step_%03d" % step)
+    meta = json.load(open(os.path.join(src, "meta.json")))
+    spec, gs = gate_set_from_ids(meta)
+    os.makedirs(out_dir, exist_ok=True)
+    for f in os.listdir(src):
+        if f != "meta.json":
+            shutil.copy(os.path.join(src, f), os.path.join(out_dir, f))
+    meta["gates"] = [[g.kind, g.p0, g.p1, g.p2] for g in gs]
+    json.dump(meta, open(os.path.join(out_dir, "meta.json"), "w"))
+    return meta, gs
+
+
+def convert_circuit(cap_dir, out_path):
+    src = os.path.join(cap_dir, "circuit")
+    meta = json.load(open(os.path.join(src, "meta.json")))
+    spec, gs = gate_set_from_ids(meta)
+    log_n, nw, nr, nconst = meta["log_n"], meta["n_wires"], meta["n_routed"], meta["n_constants"]
+    n = 1 << log_n
+    cs = np.fromfile(os.path.join(src, "constants_sigmas_values.u64"), dtype="<u8").reshape(nconst + nr, n)
+    constants = cs[:nconst]
+    # gate per row: the one selector column that does not hold UNUSED_SELECTOR carries the gate's index
+    sel = constants[:gs.num_selectors]
+    row_gate = np.zeros(n, np.uint64)
+    for r in range(n):
+        vals = [int(v) for v in sel[:, r] if int(v) != UNUSED] if gs.num_selectors > 1 else [int(sel[0, r])]
+        assert len(vals) == 1, "row %d: selector columns %r" % (r, [int(v) for v in sel[:, r]])
+        row_gate[r] = vals[0]
+    # copy constraints: wire targets of one forest class, chained
+    rep = np.fromfile(os.path.join(src, "representative_map.u64"), dtype="<u8")
+    wire_count = n * nw
+    classes = {}
+    for t in range(wire_count):
+        row, col = divmod(t, nw)
+        if col < nr:
+            classes.setdefault(int(rep[t]), []).append(col * n + row)
+    copies = [(a, b) for cl in classes.values() if len(cl) > 1 for a, b in zip(cl, cl[1:])]
+    # public inputs: a wire of each target's class
+    pi_t = np.fromfile(os.path.join(src, "public_input_targets.u64"), dtype="<u8")
+    pi_pos = []
+    for t in pi_t:
+        cl = classes.get(int(rep[int(t)]))
+        assert cl, "public input target %d has no routed wire in its class" % int(t)
+        pi_pos.append(cl[0])
+    words = [np.array([MAGIC, log_n, nw, nr, gs.n, nconst, len(copies), 0, 0, 0, len(pi_pos)], np.uint64),
+             np.array([[g.kind, g.p0, g.p1, g.p2] for g in gs], np.uint64).reshape(-1), row_gate, constants.reshape(-1),
+             np.array(copies, np.uint64).reshape(-1), np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.array(pi_pos, np.uint64),
+             np.zeros(0, np.uint64), np.zeros(len(pi_pos), np.uint64)]
+    with open(out_path, "wb") as f:
+        for w in words:
+            f.write(np.ascontiguousarray(w, dtype="<u8").tobytes())
+    return len(copies)
+
+
+def simulate_capture(cap_dir, gs, log_n, cs_values, n_constants, wires, desc, digest, pis, proof, proof_bytes):
+    """TEST HELPER: the files capture.rs would write, produced from this repository's own stack (no Rust here) -- so that the converter and
+    the consumer of a public-API capture are exercised end to end.  desc: gates_oracle.demo_circuit(.., describe=True)[-1]."""
+    n, nw, nr = 1 << log_n, wires.shape[0], cs_values.shape[0] - n_constants
+    step, circ = os.path.join(cap_dir, "step_000"), os.path.join(cap_dir, "circuit")
+    os.makedirs(step, exist_ok=True)
+    os.makedirs(circ, exist_ok=True)
+    groups = sorted({(g.group_start, g.group_end) for g in gs})
+    meta = {"log_n": log_n, "n_wires": nw, "n_routed": nr, "num_challenges": 2, "n_constants": n_constants, "n_public_inputs": len(pis),
+            "quotient_degree_factor": 8, "gate_ids": gs.ids(), "selector_indices": [g.selector_index for g in gs],
+            "selector_groups": [list(g) for g in groups], "step": 0}
+    for d in (step, circ):
+        json.dump(meta, open(os.path.join(d, "meta.json"), "w"))
+    put = lambda d, name, a: np.ascontiguousarray(a, dtype="<u8").tofile(os.path.join(d, name + ".u64"))
+    put(step, "witness_wires", wires)
+    put(step, "constants_sigmas_values", cs_values)
+    put(step, "constants_sigmas_cap", proof["cs_cap"])
+    put(step, "circuit_digest", digest)
+    put(step, "public_inputs", np.array(pis, np.uint64))
+    put(step, "caps", proof["caps"])
+    put(step, "openings", proof["openings"])
+    put(step, "fri", proof["fri"])
+    open(os.path.join(step, "proof_bytes.bin"), "wb").write(proof_bytes)
+    put(circ, "constants_sigmas_values", cs_values)
+    rep = np.arange(n * nw, dtype=np.uint64)                    # target index of wire (row, col) = row * num_wires + col
+    for cl in desc["classes"]:
+        idx = [r * nw + c for c, r in cl]
+        rep[idx] = min(idx)
+    put(circ, "representative_map", rep)
+    # the public inputs of demo_circuit are the inputs of its first PoseidonGate row (row 1, wires 0..3)
+    put(circ, "public_input_targets", np.array([1 * nw + i for i in range(len(pis))], np.uint64))
+
+
+def main():
+    args = sys.argv[1:]
+    cap_dir, out_dir = args[0], args[1]
+    step = int(args[args.index("--step") + 1]) if "--step" in args else 1
+    meta, gs = convert_step(cap_dir, step, out_dir)
+    print("fixture: step %d, degree 2^%d, %d gates (ids and selector layout agree with the prover's), %d public inputs -> %s" %
+          (step, meta["log_n"], gs.n, meta["n_public_inputs"], out_dir))
+    if "--circuit" in args:
+        path = args[args.index("--circuit") + 1]
+        n_copies = convert_circuit(cap_dir, path)
+        print("circuit: %d copy constraints -> %s" % (n_copies, path))
+
+
+if __name__ == "__main__":
+    main()
