@@ -362,3 +362,19 @@ def test_ivc_chain_tool(args, expect_steps):
     else:
         assert 150_000 < d["proof_bytes"] < 210_000                 # the paper's "~200 kB" (ivc_based_vpbs.rs:488)
     print(d["ms_per_step_split"], d["seconds"])
+
+
+def test_ivc_chain_tool_sharded_over_two_ranks():
+    """BASELINE config 4's mechanism on the one GPU of the test box: the IVC chain with every step proof coset-sharded over two ranks (gloo,
+    callback communicator; both ranks on device 0) -- same final proof checks as the single-rank chain, decrypting to the message"""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    env = dict(os.environ, VPBS_PBS_BACKEND="gloo", VPBS_PBS_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+           entry.ROOT + "/tools/prove_ivc.py", "8", "6", "13"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1

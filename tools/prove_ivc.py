@@ -10,7 +10,12 @@ the recursive-verifier rows wait for the proof, so the chain itself is sequentia
 seeded ones of vpbs_keygen / vpbs_testv / vpbs_lwe_encrypt at the paper's noise.
 
 usage: tools/prove_ivc.py [N=1024] [n_lwe=728] [log_n=16] [steps=all]   ->  one JSON line
-  steps < n + 2 proves only a prefix of the chain (tests); verify_pbs's counter / hash checks are then made against that prefix."""
+  steps < n + 2 proves only a prefix of the chain (tests); verify_pbs's counter / hash checks are then made against that prefix.
+Several GPUs (BASELINE config 4): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/prove_ivc.py ...
+  the chain is sequential, so the GPUs share every STEP: each step proof is coset-sharded over the ranks (vpbs_prove_step_sharded: a rank
+  computes the LDEs, leaf hashes and Merkle subtrees of its cosets; cap hashes, quotient values and query records travel over the library's
+  RCCL collectives), every rank generates the (identical) witness on its host and ends with the identical proof.  VPBS_PBS_BACKEND=gloo and
+  VPBS_PBS_DEVICE=0 put all ranks on one GPU with the callback communicator (tests)."""
 import json
 import os
 import sys
@@ -31,13 +36,20 @@ P = api.P
 class Circuit:
     """one exported circuit on one context: constants/sigmas commitment, verifier data, witness plan, prove / verify"""
 
-    def __init__(self, ctx, path):
-        self.ctx = ctx
+    def __init__(self, ctx, path, comm=None, dist_device=None):
+        self.ctx, self.comm = ctx, comm
         self.d = d = circuit_file.load(path)
         self.sigma = d.circuit.sigma_values()
         self.cs_values = np.concatenate([d.constants, self.sigma])
-        self.cs = ctx.commit_values(self.cs_values)
-        self.cap = self.cs.cap()
+        if comm is None:
+            self.cs = ctx.commit_values(self.cs_values)
+            self.cap = self.cs.cap()
+        else:   # this rank's cosets of the constants/sigmas commitment; the cap is assembled from all ranks
+            from vpbs_amd import sharding
+            self.d_cs = torch.from_numpy(self.cs_values.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            self.cs, self.cap = sharding.sharded_commit(ctx, self.d_cs.data_ptr(), self.cs_values.shape[0], d.log_n, device=dist_device)
+            self.cap = self.cap.reshape(-1, 4)
         self.vk = circuit_file.verifier_data_words(self.cap, d.log_n)
         self.d_sigma = torch.from_numpy(self.sigma.view(np.int64)).cuda()
         self.plan = d.circuit.witness_plan(d.preset_pos)
@@ -48,7 +60,7 @@ class Circuit:
     def prove(self, d_wires_ptr, pis):
         si = self.ctx.make_step_inputs(self.d.log_n, d_wires_ptr, None, None, self.cs, self.vk[:4], pis, on_device=True, shapes=(135, 20, 16),
                                        sigmas=int(self.d_sigma.data_ptr()), n_routed=80, n_constants=self.d.n_constants, gates=self.d.gates)
-        return self.ctx.prove_step(si), si
+        return self.ctx.prove_step(si, self.comm), si
 
     def verify(self, proof, pis):
         return api.verify_step(proof, self.cap, self.ncols, self.vk[:4], pis, self.d.log_n, n_constants=self.d.n_constants, n_routed=80,
@@ -61,12 +73,32 @@ def main():
     log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
     total = n_lwe + 2
     steps = min(total, int(sys.argv[4])) if len(sys.argv) > 4 else total
-    device = int(os.environ.get("VPBS_PBS_DEVICE", "0"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
+    dist, comm, native, dist_device = None, None, False, None
     t_setup = time.perf_counter()
+    if rank == 0:
+        circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("VPBS_PBS_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist_device = torch.device("cuda", device)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
     cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
     ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
-    cyc, dum = Circuit(ctx, cyc_path), Circuit(ctx, dummy_path)
+    if world > 1:
+        from vpbs_amd import sharding
+        stage_words = (2 << (log_n + 3)) // world
+        native = dist.get_backend() == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
+        comm = sharding.make_comm_rccl(ctx, stage_words=stage_words) if native else \
+            sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
+    cyc, dum = Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)
     shape_words = cyc.d.meta["proof_words"]
     n_pi, kn = len(cyc.d.pi_pos), K * N
     assert n_pi == 2 * kn + 9 + 68 and len(dum.d.preset_pos) == n_pi
@@ -152,6 +184,8 @@ def main():
         proof, last = cyc.prove(d_wires.data_ptr(), pis)
         t_prove += time.perf_counter() - t
     worker.join()
+    if dist:
+        dist.barrier()
     seconds = time.perf_counter() - t0
 
     # verify_pbs (:388-489) on the LAST proof only
@@ -172,10 +206,18 @@ def main():
         m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
         decrypted = round(int(m_bar[0]) / delta) % 4
         assert decrypted == message, (decrypted, message)
+    if rank != 0:
+        if native:
+            sharding.free_comm_rccl(comm)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     print(json.dumps({
+        "n_gpus": world, "step_proofs_sharded": ("every step proof coset-sharded over %d GPUs (%s)" % (world, "native RCCL" if native else
+                                                 dist.get_backend())) if world > 1 else None,
         "what": "one vPBS as an IVC chain (ivc_based_vpbs.rs verified_pbs): %d of the %d step proofs of the CYCLIC step circuit (step logic + "
                 "in-circuit verifier of the previous proof: %d gate rows, degree 2^%d, %d public inputs) at N=%d, k=1, ELL=4, LOGB=5, n=%d on "
-                "1 x MI355X; the last proof alone is the vPBS proof" % (steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe),
+                "%d x MI355X; the last proof alone is the vPBS proof" % (steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe, world),
         "step_proofs": steps, "seconds": seconds, "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
         "vpbs_proofs_per_s": (1.0 / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
         "ms_per_step_split": {"witness_late_phase_host": 1e3 * t_wit / steps, "wires_to_device": 1e3 * t_copy / steps,
@@ -190,7 +232,12 @@ def main():
     dum.plan.free()
     cyc.cs.free()
     dum.cs.free()
+    if native:
+        sharding.free_comm_rccl(comm)
     ctx.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

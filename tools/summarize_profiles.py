@@ -96,6 +96,29 @@ def main():
     with open(os.path.join(out_dir, "%s_pmc_leaf_hash.json" % tag), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
+    # 3. the gate-constraint stage: HBM traffic of the one-launch kernel (or of the per-gate launches) against its algorithmic bytes
+    def traffic(pred):
+        fv = [float(r["Counter_Value"]) for r in counter_rows(fetch_dir, "FETCH_SIZE") if pred(short(r["Kernel_Name"]))]
+        wv = [float(r["Counter_Value"]) for r in counter_rows(write_dir, "WRITE_SIZE") if pred(short(r["Kernel_Name"]))]
+        tr = [r for r in trace if pred(short(r["Kernel_Name"]))]
+        return fv, wv, [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+    fused = traffic(lambda k: k == "gate_fused_kernel")
+    per_gate = traffic(lambda k: k.startswith("gate_kernel<"))
+    steps = len(by_kind["wires"])
+    gates = {"algorithmic_bytes_per_step": lde * (135 + 6) * 8,
+             "note": "algorithmic = every column a gate can read, once: 135 wire + 6 selector / gate-constant columns x 2^19 x 8 B (the sigma and Z "
+                     "columns belong to the permutation part, quotient_perm_kernel, which runs beside it; the items' output planes -- "
+                     "n_items x 2 x 2^19 x 8 B written once -- and the alpha powers are not counted); measured = FETCH_SIZE x 2 + WRITE_SIZE "
+                     "per step (FETCH_SIZE counts what leaves the XCD's L2, whether the memory-side cache or HBM serves it)"}
+    for name, (fv, wv, du) in (("gate_fused_kernel", fused), ("per_gate_kernels", per_gate)):
+        if fv:
+            hbm = (2 * sum(fv) + sum(wv)) * 1024 / max(1, steps)
+            gates[name] = {"launches": len(fv), "hbm_bytes_per_step": hbm, "ratio_to_algorithmic": hbm / gates["algorithmic_bytes_per_step"],
+                           "fetch_bytes_per_step": 2 * sum(fv) * 1024 / max(1, steps), "write_bytes_per_step": sum(wv) * 1024 / max(1, steps),
+                           "duration_us_per_step": sum(du) / max(1, steps)}
+    with open(os.path.join(out_dir, "%s_pmc_gates.json" % tag), "w") as f:
+        json.dump(gates, f, indent=1)
+    print(json.dumps(gates, indent=1))
 
 
 if __name__ == "__main__":
