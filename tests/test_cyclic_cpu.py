@@ -109,6 +109,12 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
         two = np.empty_like(wires)
         state = split.run_early(early_values, two)
         assert (split.run_late(state, values, two) == wires).all()
+        if cond:   # a proof with one flipped word makes the late phase fail (its generators run on several threads), whatever the word
+            bad = values.copy()
+            bad[(7919 * len(proofs) + 13) % cy.shape.proof_words] ^= np.uint64(1)
+            state = split.run_early(early_values, two)
+            with pytest.raises(api.VpbsError):
+                split.run_late(state, bad, two)
         pis = np.array(cy.public_inputs(wires), np.uint64)
         if check:
             ok, msg = cy.built.circuit.check_witness(wires, api.hash_no_pad(pis))

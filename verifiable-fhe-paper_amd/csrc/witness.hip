@@ -9,6 +9,7 @@
 // Restated from the published crate: parity unpinned; checked against an independent Python restatement and against the
 // gate constraints (every generated row must satisfy them).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -332,6 +333,10 @@ struct vpbs_witness_plan {
     bool is_split = false;
     std::vector<uint8_t> preset_late, step_late;
     std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late
+    // the late generators by dependency level (a generator of level L reads only what levels < L wrote, and two generators of one level
+    // never write the same slot: a second writer of a slot is placed above the first and compares): the wide levels -- the 28 FRI queries
+    // of an in-circuit verifier are independent of each other -- are run by several host threads
+    std::vector<u32> late_order, late_level_off;
 
     // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
     // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
@@ -405,9 +410,13 @@ struct SlotState {
     std::string error;
     void set(u32 slot, u64 v, u32 pos) {
         if (v >= gl::P) v -= gl::P;
-        if (is_set[slot] && val[slot] != v && error.empty())
-            error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
-                    ") was set twice with different values";
+        if (is_set[slot] && val[slot] != v) {
+            static std::mutex report_mutex;   // the late phase of a split plan runs generators on several threads
+            std::lock_guard<std::mutex> lock(report_mutex);
+            if (error.empty())
+                error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
+                        ") was set twice with different values";
+        }
         val[slot] = v;
         is_set[slot] = 1;
     }
@@ -821,6 +830,9 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     const unsigned mc = std::max(1u, p.max_consts);
     std::vector<unsigned> deps;
     std::vector<u32> written, written_w;
+    // level bookkeeping of the late part: slot -> level of its (first) late writer, 0 = early or a preset
+    std::vector<u32> slot_level(p.n_slots, 0), step_level(p.schedule.size(), 0);
+    u32 max_level = 0;
     for (size_t i = 0; i < p.schedule.size(); ++i) {
         const auto& st = p.schedule[i];
         bool is_late = false;
@@ -828,8 +840,16 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             const auto& gg = p.gadgets[st.sub];
             const u32* gs = p.gadget_slots.data() + gg.at;
             for (unsigned k = 0; k < gg.n_in; ++k) is_late |= taint[gs[k]] != 0;
-            if (is_late)
-                for (unsigned k = 0; k < gg.n_out; ++k) taint[gs[gg.n_in + k]] = 1;
+            if (is_late) {
+                u32 lvl = 1;
+                for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, slot_level[gs[k]] + 1);
+                for (unsigned k = 0; k < gg.n_out; ++k) {
+                    taint[gs[gg.n_in + k]] = 1;
+                    if (slot_level[gs[gg.n_in + k]] == 0) slot_level[gs[gg.n_in + k]] = lvl;
+                }
+                step_level[i] = lvl;
+                max_level = std::max(max_level, lvl);
+            }
         } else {
             const vpbs_gate& g = p.gates[p.row_gate[st.row]];
             const u32* rs = p.row_slots.data() + p.row_off[st.row];
@@ -845,10 +865,29 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
                     err = e.what;
                     return VPBS_ERR_INVALID;
                 }
-                for (u32 slot : written) taint[slot] = 1;
+                u32 lvl = 1;
+                for (unsigned w : deps) lvl = std::max(lvl, slot_level[rs[w]] + 1);
+                for (u32 slot : written) lvl = std::max(lvl, slot_level[slot] + 1);   // an earlier late writer: this one compares, after it
+                for (u32 slot : written) {
+                    taint[slot] = 1;
+                    if (slot_level[slot] == 0) slot_level[slot] = lvl;
+                }
+                step_level[i] = lvl;
+                max_level = std::max(max_level, lvl);
             }
         }
         p.step_late[i] = is_late ? 1 : 0;
+    }
+    // counting sort of the late steps by level (schedule order kept inside a level)
+    p.late_level_off.assign(max_level + 2, 0);
+    for (size_t i = 0; i < p.schedule.size(); ++i)
+        if (p.step_late[i]) ++p.late_level_off[step_level[i] + 1];
+    for (u32 l = 1; l <= max_level + 1; ++l) p.late_level_off[l] += p.late_level_off[l - 1];
+    p.late_order.assign(p.late_level_off[max_level + 1], 0);
+    {
+        std::vector<u32> at(p.late_level_off.begin(), p.late_level_off.end() - 1);
+        for (size_t i = 0; i < p.schedule.size(); ++i)
+            if (p.step_late[i]) p.late_order[at[step_level[i]]++] = (u32)i;
     }
     p.late_out.clear();
     for (size_t i = 0; i < p.out_slot.size(); ++i)
@@ -865,29 +904,129 @@ struct vpbs_witness_state {
 
 namespace vpbs {
 namespace {
+// one step of the schedule on the slot state; returns false (message in err) when a generator rejects its inputs
+bool run_one(const vpbs_witness_plan& p, SlotState& s, size_t i, unsigned mc, std::string& err) {
+    const auto& st = p.schedule[i];
+    try {
+        if (st.row == NO_ROW) {
+            run_gadget(p, p.gadgets[st.sub], s);
+        } else {
+            SlotRow r{s, p.row_slots.data() + p.row_off[st.row], st.row};
+            const vpbs_gate& g = p.gates[p.row_gate[st.row]];
+            gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, r, tables_of(g));
+        }
+    } catch (const GenError& e) {
+        err = e.what + (st.row == NO_ROW ? " (generator " + std::to_string(st.sub) + ")" : " (row " + std::to_string(st.row) + ")");
+        return false;
+    }
+    return true;
+}
+
 int run_steps(const vpbs_witness_plan& p, SlotState& s, int want_late, std::string& err) {
     const unsigned mc = std::max(1u, p.max_consts);
     for (size_t i = 0; i < p.schedule.size(); ++i) {
         if (p.step_late[i] != want_late) continue;
-        const auto& st = p.schedule[i];
-        try {
-            if (st.row == NO_ROW) {
-                run_gadget(p, p.gadgets[st.sub], s);
-            } else {
-                SlotRow r{s, p.row_slots.data() + p.row_off[st.row], st.row};
-                const vpbs_gate& g = p.gates[p.row_gate[st.row]];
-                gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, r, tables_of(g));
-            }
-        } catch (const GenError& e) {
-            err = e.what + (st.row == NO_ROW ? " (generator " + std::to_string(st.sub) + ")" : " (row " + std::to_string(st.row) + ")");
-            return VPBS_ERR_INVALID;
-        }
+        if (!run_one(p, s, i, mc, err)) return VPBS_ERR_INVALID;
         if (!s.error.empty()) {
             err = s.error;
             return VPBS_ERR_INVALID;
         }
     }
     return VPBS_OK;
+}
+
+// The late generators level by level; a level with at least PAR_MIN generators is shared by `threads` host threads (workers spin on a
+// phase counter between the wide levels: there are a few hundred levels and the whole phase lasts milliseconds).  Generators of one level
+// touch disjoint slots (plan_split), so the slot state needs no locking; a "set twice with different values" report goes through a
+// per-thread state whose error is merged at the end of the level.
+// spin briefly (the other side answers within microseconds), then give the core away
+template <class Pred> void spin_until(Pred ready) {
+    for (unsigned i = 0; !ready(); ++i) {
+        if (i < 2000) __builtin_ia32_pause();
+        else std::this_thread::yield();
+    }
+}
+
+int run_late_levels(const vpbs_witness_plan& p, SlotState& s, unsigned threads, u64* wires_out, std::string& err) {
+    constexpr u32 PAR_MIN = 24;
+    const unsigned mc = std::max(1u, p.max_consts);
+    const u32 n_levels = (u32)p.late_level_off.size() - 1;
+    if (threads <= 1) {
+        for (u32 k = 0; k < p.late_order.size(); ++k) {
+            if (!run_one(p, s, p.late_order[k], mc, err)) return VPBS_ERR_INVALID;
+            if (!s.error.empty()) {
+                err = s.error;
+                return VPBS_ERR_INVALID;
+            }
+        }
+        for (u32 i : p.late_out) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
+        return VPBS_OK;
+    }
+    std::atomic<u32> phase{0}, done{0};
+    std::atomic<bool> quit{false}, failed{false};
+    std::vector<std::string> errs(threads);
+    u32 cur_lo = 0, cur_hi = 0;   // the level being shared; written by the main thread before it bumps `phase`
+    bool scatter = false;         // the last shared job: the late wires into the matrix
+    auto chunk = [&](unsigned t) {
+        const u32 cnt = cur_hi - cur_lo, lo = cur_lo + (u32)((u64)cnt * t / threads), hi = cur_lo + (u32)((u64)cnt * (t + 1) / threads);
+        if (scatter) {
+            for (u32 k = lo; k < hi; ++k) wires_out[p.out_pos[p.late_out[k]]] = s.val[p.out_slot[p.late_out[k]]];
+            return;
+        }
+        for (u32 k = lo; k < hi && !failed.load(std::memory_order_relaxed); ++k)
+            if (!run_one(p, s, p.late_order[k], mc, errs[t])) failed.store(true);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            u32 seen = 0;
+            for (;;) {
+                spin_until([&] { return phase.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
+                if (phase.load(std::memory_order_acquire) == seen) return;   // quit
+                ++seen;
+                chunk(t);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    int rc = VPBS_OK;
+    for (u32 l = 0; l < n_levels && rc == VPBS_OK; ++l) {
+        const u32 lo = p.late_level_off[l], hi = p.late_level_off[l + 1];
+        if (hi - lo < PAR_MIN) {
+            for (u32 k = lo; k < hi && rc == VPBS_OK; ++k)
+                if (!run_one(p, s, p.late_order[k], mc, errs[0])) rc = VPBS_ERR_INVALID;
+        } else {
+            cur_lo = lo;
+            cur_hi = hi;
+            done.store(0, std::memory_order_relaxed);
+            phase.fetch_add(1, std::memory_order_release);
+            chunk(0);
+            spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+            if (failed.load()) rc = VPBS_ERR_INVALID;
+        }
+        if (rc == VPBS_OK && !s.error.empty()) {
+            errs[0] = s.error;
+            rc = VPBS_ERR_INVALID;
+        }
+    }
+    if (rc == VPBS_OK) {   // the late wires, shared the same way
+        scatter = true;
+        cur_lo = 0;
+        cur_hi = (u32)p.late_out.size();
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+        chunk(0);
+        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+    }
+    quit.store(true, std::memory_order_release);
+    for (auto& th : pool) th.join();
+    if (rc != VPBS_OK)
+        for (const auto& e : errs)
+            if (!e.empty()) {
+                err = e;
+                break;
+            }
+    if (rc != VPBS_OK && err.empty()) err = s.error.empty() ? "a late generator failed" : s.error;
+    return rc;
 }
 }  // namespace
 }  // namespace vpbs
@@ -956,11 +1095,12 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
         if (p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
     lap("presets");
     std::string msg = s.error;
-    const int rc = msg.empty() ? run_steps(p, s, 1, msg) : VPBS_ERR_INVALID;
-    lap("generators");
-    if (rc == VPBS_OK)
-        for (u32 i : p.late_out) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
-    lap("late wires");
+    static const unsigned late_threads = [] {
+        const char* e = std::getenv("VPBS_LATE_THREADS");
+        return e ? (unsigned)std::max(1, atoi(e)) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    }();
+    const int rc = msg.empty() ? run_late_levels(p, s, late_threads, wires_out, msg) : VPBS_ERR_INVALID;
+    lap("generators + late wires");
     if (trace) {
         size_t n_late = 0, n_pos = 0;
         for (size_t i = 0; i < p.schedule.size(); ++i)
@@ -968,8 +1108,25 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
                 ++n_late;
                 if (p.schedule[i].row != NO_ROW && p.gates[p.row_gate[p.schedule[i].row]].kind == VPBS_GATE_POSEIDON) ++n_pos;
             }
-        std::fprintf(stderr, "[witness late] %zu late generators (%zu PoseidonGate rows) of %zu, %zu late wire positions\n", n_late, n_pos,
-                     p.schedule.size(), p.late_out.size());
+        size_t wide = 0, wide_steps = 0, wide_pos = 0, narrow_pos = 0;
+        for (size_t l = 0; l + 1 < p.late_level_off.size(); ++l) {
+            const u32 cnt = p.late_level_off[l + 1] - p.late_level_off[l];
+            size_t pos_rows = 0;
+            for (u32 k = p.late_level_off[l]; k < p.late_level_off[l + 1]; ++k) {
+                const auto& st = p.schedule[p.late_order[k]];
+                if (st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) ++pos_rows;
+            }
+            if (cnt >= 24) {
+                ++wide;
+                wide_steps += cnt;
+                wide_pos += pos_rows;
+            } else {
+                narrow_pos += pos_rows;
+            }
+        }
+        std::fprintf(stderr, "[witness late] %zu late generators (%zu PoseidonGate rows) of %zu, %zu late wire positions; %zu levels, %zu of them "
+                     "wide with %zu generators (%zu PoseidonGate rows; %zu PoseidonGate rows sit in narrow levels)\n", n_late, n_pos,
+                     p.schedule.size(), p.late_out.size(), p.late_level_off.size() - 1, wide, wide_steps, wide_pos, narrow_pos);
     }
     report(err, err_len, msg);
     delete state;
