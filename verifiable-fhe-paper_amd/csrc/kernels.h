@@ -11,6 +11,9 @@ using gl::u64;
 
 // ---------- ntt.hip ----------
 // roots[j] = w^j, j < n, w = primitive n-th root (or its inverse for the inverse transform)
+// roots: root_table_words(log_n) words -- the n powers of w (w^-1 for inverse) followed by the transform kernels' round tables (twiddles in
+// the order the threads consume them, ntt.hip); every NTT launch below takes a table made here
+size_t root_table_words(unsigned log_n);
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse);
 // prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n
 void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift);

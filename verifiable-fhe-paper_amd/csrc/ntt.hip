@@ -54,8 +54,32 @@ __device__ __forceinline__ unsigned insert_zero_bit(unsigned x, unsigned pos) {
 // 8th roots are applied inside (w_8 = -2^24, w_4 = 2^48, w_8^3 = -2^72: shifts, gl::mul_2e*), and each output gets ONE table
 // twiddle w^(j e1), j = 1..7: 7 modular multiplications + 5 shifts per 8 elements instead of 12 multiplications.
 // `inverse`: the table holds powers of w^-1, whose 8th roots are the conjugates (w_8^-1 = 2^72, w_4^-1 = -2^48, w_8^-3 = 2^24).
-template <typename TwIndex>
-__device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigned first_bit, const u64* __restrict__ roots, bool inverse,
+// Where a round's twiddles come from.  Gathering w^(j e1) from the table of all n powers costs a 64-line memory instruction per twiddle in
+// the rounds whose exponents differ from lane to lane (the SQ counters of round 1 showed these kernels waiting, not computing: VALU issue
+// share 0.12).  Which twiddles a thread needs depends only on (transform size, pass, tile, round, thread) -- not on the column or the
+// coset -- so they are laid out once per transform size in exactly the order the threads consume them: rt[(round slot)][thread], a
+// coalesced 512-byte load per wave and twiddle, shared by every column and coset through L2.  RECORD: the pass that writes that layout
+// (run once per transform size on a dummy tile, by the same code that later reads it).
+template <bool RECORD> struct TwSource {
+    const u64* roots;   // w^i, i < n
+    u64* rt;            // this block's round table (slots x THREADS)
+    unsigned slot;
+    __device__ __forceinline__ u64 get(unsigned exponent) {
+        u64* p = rt + (size_t)slot * THREADS + threadIdx.x;
+        ++slot;
+        if (RECORD) {
+            const u64 v = roots[exponent];
+            *p = v;
+            return v;
+        }
+        return *p;
+    }
+};
+// twiddle slots a pass of n_stages stages uses per thread: 7 per full round, 4 per stage of a partial one
+__host__ __device__ inline unsigned round_slots(unsigned n_stages) { return 7 * (n_stages / 3) + 4 * (n_stages % 3); }
+
+template <bool RECORD, typename TwIndex>
+__device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigned first_bit, TwSource<RECORD> tw, bool inverse,
                                            TwIndex tw_index) {
     // stage j (0-based inside this pass) has distance bit first_bit - j
     for (unsigned j0 = 0; j0 < n_stages; j0 += 3) {
@@ -101,14 +125,17 @@ __device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigne
                 bq[h + 3] = gl::mul_2e48(inverse ? gl::sub(a[h + 3], a[h + 1]) : gl::sub(a[h + 1], a[h + 3]));  // times w_4
             }
             // outputs: element k carries W_j with j = bit-reversal of k over 3 bits
+            // the seven twiddles are requested together, ahead of the butterfly arithmetic that precedes their use
+            const u64 t4 = tw.get(4 * e1), t2 = tw.get(2 * e1), t6 = tw.get(6 * e1), t1 = tw.get(e1), t5 = tw.get(5 * e1), t3 = tw.get(3 * e1),
+                      t7 = tw.get(7 * e1);
             x[0] = gl::add(bq[0], bq[1]);
-            x[1] = gl::mul(gl::sub(bq[0], bq[1]), roots[4 * e1]);
-            x[2] = gl::mul(gl::add(bq[2], bq[3]), roots[2 * e1]);
-            x[3] = gl::mul(gl::sub(bq[2], bq[3]), roots[6 * e1]);
-            x[4] = gl::mul(gl::add(bq[4], bq[5]), roots[e1]);
-            x[5] = gl::mul(gl::sub(bq[4], bq[5]), roots[5 * e1]);
-            x[6] = gl::mul(gl::add(bq[6], bq[7]), roots[3 * e1]);
-            x[7] = gl::mul(gl::sub(bq[6], bq[7]), roots[7 * e1]);
+            x[1] = gl::mul(gl::sub(bq[0], bq[1]), t4);
+            x[2] = gl::mul(gl::add(bq[2], bq[3]), t2);
+            x[3] = gl::mul(gl::sub(bq[2], bq[3]), t6);
+            x[4] = gl::mul(gl::add(bq[4], bq[5]), t1);
+            x[5] = gl::mul(gl::sub(bq[4], bq[5]), t5);
+            x[6] = gl::mul(gl::add(bq[6], bq[7]), t3);
+            x[7] = gl::mul(gl::sub(bq[6], bq[7]), t7);
         } else {
         // stage A: pairs (k, k+4)
         {
@@ -117,7 +144,7 @@ __device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigne
                 const unsigned lo = base | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]);
                 const u64 u = x[k], v = x[k + 4];
                 x[k] = gl::add(u, v);
-                x[k + 4] = gl::mul(gl::sub(u, v), roots[tw_index(lo, j0)]);
+                x[k + 4] = gl::mul(gl::sub(u, v), tw.get(tw_index(lo, j0)));
             }
         }
         if (ns > 1) {
@@ -127,7 +154,7 @@ __device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigne
                 const unsigned lo = base | (((k >> 2) & 1u) << b[0]) | ((k & 1u) << b[2]);
                 const u64 u = x[k], v = x[k + 2];
                 x[k] = gl::add(u, v);
-                x[k + 2] = gl::mul(gl::sub(u, v), roots[tw_index(lo, j0 + 1)]);
+                x[k + 2] = gl::mul(gl::sub(u, v), tw.get(tw_index(lo, j0 + 1)));
             }
         }
         }
@@ -138,11 +165,14 @@ __device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigne
 }
 
 // Strided pass: stages [0, log_r).  Tile = R rows x C cols, element (rho, gamma) <-> index rho*(n/R) + c0 + gamma.
+template <bool RECORD>
 __global__ void __launch_bounds__(THREADS)
 ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
-                   const u64* __restrict__ roots, unsigned log_n, unsigned log_r, size_t in_col_stride,
+                   const u64* __restrict__ roots, u64* __restrict__ round_tables, unsigned log_n, unsigned log_r, size_t in_col_stride,
                    size_t out_col_stride, unsigned rate_bits, unsigned block_first, int inverse) {
     __shared__ u64 tile[TILE];
+    // this tile's table: the strided pass's exponents depend on the tile's columns
+    TwSource<RECORD> tw{roots, round_tables + (size_t)blockIdx.x * round_slots(log_r) * THREADS, 0};
     const unsigned log_c = TILE_LOG - log_r;
     const unsigned C = 1u << log_c, R = 1u << log_r;
     const unsigned row_stride = 1u << (log_n - log_r);  // n / R
@@ -154,17 +184,18 @@ ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64*
     for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
         const unsigned rho = t >> log_c, gamma = t & (C - 1);
         const unsigned idx = rho * row_stride + c0 + gamma;
-        u64 x = src[idx];
-        if (ps) x = gl::mul(x, ps[idx]);
+        u64 x = RECORD ? 0 : src[idx];
+        if (!RECORD && ps) x = gl::mul(x, ps[idx]);
         tile[sw(t)] = x;
     }
     __syncthreads();
     // stage s: butterfly distance (R >> (s+1)) rows = tile bit log_c + log_r - 1 - s
-    dif_rounds(tile, log_r, log_c + log_r - 1, roots, inverse != 0, [=](unsigned lo, unsigned s) {
+    dif_rounds(tile, log_r, log_c + log_r - 1, tw, inverse != 0, [=](unsigned lo, unsigned s) {
         const unsigned half_rows = R >> (s + 1);
         const unsigned rho = lo >> log_c, gamma = lo & (C - 1);
         return ((rho & (half_rows - 1)) * row_stride + c0 + gamma) << s;
     });
+    if (RECORD) return;
     u64* dst = out + blockIdx.y * out_col_stride + ((size_t)blockIdx.z << log_n);
     for (unsigned t = threadIdx.x; t < TILE; t += THREADS) {
         const unsigned rho = t >> log_c, gamma = t & (C - 1);
@@ -175,18 +206,23 @@ ntt_strided_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64*
 // Contiguous pass: stages [s_begin, log_n) on blocks of B = n >> s_begin elements; one workgroup owns
 // min(TILE, n) consecutive elements.  If s_begin == 0 the input is read from `in` (with optional prescale), else the
 // transform continues in place in `out`.  bitrev_out: scatter to natural order and scale (inverse transform).
+template <bool RECORD>
 __global__ void __launch_bounds__(THREADS)
 ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
-                  const u64* __restrict__ roots, unsigned log_n, unsigned s_begin, size_t in_col_stride,
+                  const u64* __restrict__ roots, u64* __restrict__ round_tables, unsigned log_n, unsigned s_begin, size_t in_col_stride,
                   size_t out_col_stride, unsigned rate_bits, int bitrev_out, u64 scale, unsigned block_first) {
     __shared__ u64 tile[TILE];
+    // one table for every tile: ((base + lo) & (half - 1)) << s does not depend on the tile (base is a multiple of 2 half)
+    TwSource<RECORD> tw{roots, round_tables, 0};
     const unsigned n = 1u << log_n;
     const unsigned tile_elems = n < TILE ? n : TILE;
     const unsigned base = blockIdx.x * tile_elems;
     const unsigned coset = gl::bitrev32(block_first + blockIdx.z, rate_bits);
     const size_t coset_off = (size_t)blockIdx.z << log_n;
     u64* dst_col = out + blockIdx.y * out_col_stride;
-    if (s_begin == 0) {
+    if (RECORD) {
+        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[sw(t)] = 0;
+    } else if (s_begin == 0) {
         const u64* src = in + blockIdx.y * in_col_stride;
         const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
         for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) {
@@ -202,7 +238,7 @@ ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* 
     __syncthreads();
     if (tile_elems == TILE) {
         // stage s: distance n >> (s+1) = tile bit log_n - 1 - s
-        dif_rounds(tile, log_n - s_begin, log_n - 1 - s_begin, roots, bitrev_out != 0, [=](unsigned lo, unsigned j) {
+        dif_rounds(tile, log_n - s_begin, log_n - 1 - s_begin, tw, bitrev_out != 0, [=](unsigned lo, unsigned j) {
             const unsigned s = s_begin + j;
             const unsigned half = n >> (s + 1);
             return ((base + lo) & (half - 1)) << s;
@@ -220,6 +256,7 @@ ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* 
             __syncthreads();
         }
     }
+    if (RECORD) return;
     if (bitrev_out) {
         for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS)
             dst_col[gl::bitrev32(base + t, log_n)] = gl::mul(tile[sw(t)], scale);
@@ -273,13 +310,44 @@ unsigned split_log_r(unsigned log_n) {
     const unsigned want = log_n - 9 > 7 ? 7 : log_n - 9, need = log_n - TILE_LOG;
     return want > need ? want : need;
 }
+// round tables of a transform size, stored behind the n powers of the root table: [contiguous pass | strided pass, tile by tile]
+struct RoundLayout {
+    unsigned log_r, tiles;
+    size_t contig_words, strided_words;
+    bool tables;   // the tile-sized passes use them (transforms of at least one tile)
+};
+RoundLayout round_layout(unsigned log_n) {
+    RoundLayout l{};
+    l.log_r = split_log_r(log_n);
+    const size_t n = (size_t)1 << log_n;
+    l.tiles = n <= TILE ? 1 : (unsigned)(n / TILE);
+    l.tables = n >= TILE;
+    l.contig_words = l.tables ? (size_t)round_slots(log_n - l.log_r) * THREADS : 0;
+    l.strided_words = l.log_r ? (size_t)l.tiles * round_slots(l.log_r) * THREADS : 0;
+    return l;
+}
 }  // namespace
+
+size_t root_table_words(unsigned log_n) {
+    const RoundLayout l = round_layout(log_n);
+    return ((size_t)1 << log_n) + l.contig_words + l.strided_words;
+}
 
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse) {
     u64 w = gl::root_of_unity(log_n);
     if (inverse) w = gl::inv(w);
     const size_t cnt = (size_t)1 << log_n;
     hipLaunchKernelGGL(root_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, roots, log_n, w);
+    // the round tables: the transform kernels themselves in RECORD mode, one column, one coset, on a dummy tile
+    const RoundLayout l = round_layout(log_n);
+    if (!l.tables) return;
+    u64* contig = roots + cnt;
+    u64* strided = contig + l.contig_words;
+    if (l.log_r)
+        hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3(l.tiles, 1, 1), dim3(THREADS), 0, s, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr,
+                           (const u64*)roots, strided, log_n, l.log_r, (size_t)0, (size_t)0, 0u, 0u, inverse ? 1 : 0);
+    hipLaunchKernelGGL(ntt_contig_kernel<true>, dim3(1, 1, 1), dim3(THREADS), 0, s, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr,
+                       (const u64*)roots, contig, log_n, l.log_r, (size_t)0, (size_t)0, 0u, inverse ? 1 : 0, (u64)1, 0u);
 }
 
 void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift) {
@@ -294,25 +362,29 @@ static void run_transform(hipStream_t s, const u64* in, u64* out, u64* scratch, 
     const unsigned n = 1u << log_n;
     const unsigned cosets = n_blocks;
     if (log_n > 2 * TILE_LOG) throw DeviceError{VPBS_ERR_INVALID, "transform larger than 2^22 points"};
-    const unsigned log_r = split_log_r(log_n);
+    const RoundLayout l = round_layout(log_n);
+    const unsigned log_r = l.log_r;
     const u64 scale = inverse ? gl::inv((u64)n) : 1;
-    const unsigned tiles = n <= TILE ? 1 : n / TILE;
+    const unsigned tiles = l.tiles;
+    // the round tables sit behind the powers (root_table_words); the table of an inverse transform was recorded with the inverse roots
+    u64* contig_rt = const_cast<u64*>(roots) + n;
+    u64* strided_rt = contig_rt + l.contig_words;
     if (log_r == 0) {
-        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n, 0u,
+        hipLaunchKernelGGL(ntt_contig_kernel<false>, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, contig_rt, log_n, 0u,
                            in_stride, out_stride, rate_bits, inverse ? 1 : 0, scale, block_first);
         return;
     }
     if (inverse) {
         // strided pass into scratch (layout [ncols][n]), contiguous pass scatters into `out`
-        hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, in, scratch, (const u64*)nullptr, roots,
+        hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, in, scratch, (const u64*)nullptr, roots, strided_rt,
                            log_n, log_r, in_stride, (size_t)n, 0u, 0u, 1);
-        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, (const u64*)scratch, out,
-                           (const u64*)nullptr, roots, log_n, log_r, (size_t)n, out_stride, 0u, 1, scale, 0u);
+        hipLaunchKernelGGL(ntt_contig_kernel<false>, dim3(tiles, ncols, 1), dim3(THREADS), 0, s, (const u64*)scratch, out,
+                           (const u64*)nullptr, roots, contig_rt, log_n, log_r, (size_t)n, out_stride, 0u, 1, scale, 0u);
     } else {
-        hipLaunchKernelGGL(ntt_strided_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, log_n,
+        hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, in, out, prescale, roots, strided_rt, log_n,
                            log_r, in_stride, out_stride, rate_bits, block_first, 0);
-        hipLaunchKernelGGL(ntt_contig_kernel, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, (const u64*)nullptr, out,
-                           (const u64*)nullptr, roots, log_n, log_r, (size_t)0, out_stride, rate_bits, 0, scale, block_first);
+        hipLaunchKernelGGL(ntt_contig_kernel<false>, dim3(tiles, ncols, cosets), dim3(THREADS), 0, s, (const u64*)nullptr, out,
+                           (const u64*)nullptr, roots, contig_rt, log_n, log_r, (size_t)0, out_stride, rate_bits, 0, scale, block_first);
     }
 }
 
