@@ -155,7 +155,7 @@ def main():
     t_wit = t_copy = t_prove = 0.0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    worker = threading.Thread(target=early_thread)
+    worker = threading.Thread(target=early_thread, daemon=True)   # a failure of the main loop must not leave the process waiting on it
     worker.start()
     # cyclic_base_proof (ivc_based_vpbs.rs:292-299): a proof of the dummy circuit whose public inputs carry the initial accumulator and the
     # cyclic circuit's verifier data
