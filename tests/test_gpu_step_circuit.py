@@ -365,6 +365,24 @@ def test_ivc_chain_tool(args, expect_steps):
     print(d["ms_per_step_split"], d["seconds"])
 
 
+@pytest.mark.parametrize("N,n_lwe,log_n,steps", [(8, 6, 13, 8), (1024, 728, 16, 4)])
+def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
+    """examples/prove_ivc.cpp: the IVC chain driven by a plain C++ host of the C ABI (no Python, no torch in the process) from the exported
+    cyclic + dummy circuit files: split witness plan with the early phase on its own thread, pinned wires, the final proof alone verified
+    after a byte round trip, chain hashes, and -- for the whole chain at N = 8 -- decryption to the message."""
+    import subprocess
+    import __graft_entry__ as entry
+    from vpbs_amd import circuit_file
+    cyc, dum = circuit_file.ensure_cyclic_circuit(N, 2, 4, 5, n_lwe, log_n)
+    exe = entry.build_example("prove_ivc")
+    r = subprocess.run([exe, cyc, dum, str(steps)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "IVC chain: %d of %d step proofs" % (steps, n_lwe + 2) in r.stdout and "verified: 1" in r.stdout
+    if steps == n_lwe + 2:
+        assert "decrypted 1 (message 1)" in r.stdout
+    print(r.stdout.strip())
+
+
 def test_ivc_chain_tool_sharded_over_two_ranks():
     """BASELINE config 4's mechanism on the one GPU of the test box: the IVC chain with every step proof coset-sharded over two ranks (gloo,
     callback communicator; both ranks on device 0) -- same final proof checks as the single-rank chain, decrypting to the message"""

@@ -211,6 +211,25 @@ def test_cxx_host_generates_the_exported_witness(tmp_path):
     assert r.returncode == 1 and "public inputs differ" in r.stderr, r.stdout + r.stderr
 
 
+def test_cxx_ivc_host_builds_and_fails_loudly_without_a_device(tmp_path):
+    """examples/prove_ivc.cpp (the IVC chain from a plain C++ host) compiles against include/vpbs_prover.h with g++ alone, rejects a file
+    that is not a circuit, and without a GPU stops at context creation instead of computing anything on the CPU."""
+    import subprocess
+    import torch
+    import __graft_entry__ as entry
+    exe = entry.build_example("prove_ivc")
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"\0" * 256)
+    r = subprocess.run([exe, str(junk), str(junk)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "not a circuit file" in r.stderr
+    if torch.cuda.is_available():
+        return
+    head = tmp_path / "head.bin"
+    head.write_bytes(b"".join(int(v).to_bytes(8, "little") for v in [0x5354455043495243, 13] + [0] * 14))
+    r = subprocess.run([exe, str(head), str(head)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "context creation failed" in r.stderr, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_builder_programs(seed):
     """Random straight-line programs over the builder's gadgets (arithmetic in every form, select, is_equal, split_le / le_sum,

@@ -177,6 +177,11 @@ SIGNATURES = {
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
+    "vpbs_host_alloc": (_vp, [_sz]),
+    "vpbs_host_free": (None, [_vp]),
+    "vpbs_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "vpbs_device_upload": (_i, [_vp, _vp, U64P, _sz]),
+    "vpbs_device_free": (None, [_vp, _vp]),
     "vpbs_keygen": (_i, [_vp, C.POINTER(KeygenParamsC), U64P, U64P, U64P, _vp, _vp, _i]),
     "vpbs_lwe_encrypt": (_i, [C.POINTER(KeygenParamsC), U64P, _u64, _u64, U64P]),
     "vpbs_testv": (_i, [_ui, _ui, U64P, U64P]),

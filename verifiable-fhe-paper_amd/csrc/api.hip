@@ -655,6 +655,32 @@ int vpbs_pbs_accumulator_chain(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigne
     });
 }
 
+// ---------------- memory helpers for hosts without the HIP runtime ----------------
+void* vpbs_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void vpbs_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+int vpbs_device_alloc(vpbs_ctx* c, size_t words, uint64_t** out) {
+    if (!c || !out || !words) return VPBS_ERR_INVALID;
+    return guarded(c, [&] { *out = c->alloc_words(words); });
+}
+int vpbs_device_upload(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, size_t words) {
+    if (!c || !d_dst || !host_src) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        VPBS_HIP(hipMemcpyAsync(d_dst, host_src, sizeof(u64) * words, hipMemcpyHostToDevice, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+void vpbs_device_free(vpbs_ctx* c, uint64_t* d_ptr) {
+    if (c && d_ptr) {
+        (void)hipStreamSynchronize(c->stream);
+        c->release(d_ptr);
+    }
+}
+
 // ---------------- timing ----------------
 int vpbs_timing_enable(vpbs_ctx* c, int on) {
     if (!c) return VPBS_ERR_INVALID;
