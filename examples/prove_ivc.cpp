@@ -4,8 +4,9 @@
 // step circuit and its dummy circuit, tools/export_step_circuit.py --cyclic), and per step
 //     PartialWitness = previous proof's words | its public inputs | condition | GGSW | mask | own verifier data | dummy verifier data
 //     -> vpbs_witness_plan_run_early (everything that does not need the previous proof, on a second thread, ahead)
-//     -> vpbs_witness_plan_run_late  (the in-circuit verifier's rows, when the proof exists)
-//     -> vpbs_prove_step (wires in pinned host memory) -> the proof feeds the next step.
+//     -> vpbs_device_upload_bg       (that matrix to the device, on a third thread, while the previous step is being proven)
+//     -> vpbs_witness_plan_run_late  (the in-circuit verifier's rows, when the proof exists) -> vpbs_device_upload_rows (those rows only)
+//     -> vpbs_prove_step (wires on the device) -> the proof feeds the next step.
 // At the end: verify_pbs on the LAST proof only (byte round trip, vpbs_verify_step, test vector, counter, verifier data, chain hashes,
 // decryption).  Keys, test vector and the LWE input: vpbs_keygen / vpbs_testv / vpbs_lwe_encrypt (seeded, the paper's noise).
 //   build: g++ -O2 -std=c++17 -pthread -I include examples/prove_ivc.cpp -L verifiable-fhe-paper_amd -lvpbs_hip
@@ -180,15 +181,18 @@ int main(int argc, char** argv) {
     auto ggsw_of = [&](unsigned s) { return s == 0 ? zero_ggsw.data() : (s <= n_lwe ? bsk.data() + (size_t)(s - 1) * ggsw_len : ksk.data()); };
     auto mask_of = [&](unsigned s) { return s == 0 ? ct[n_lwe] : (s <= n_lwe ? ct[s - 1] : (u64)0); };
 
-    // ---- buffers: three pinned wire matrices cycle between the early thread and the prover ----
+    // ---- buffers: three pinned wire matrices and their device twins cycle through early thread -> uploader -> prover ----
     constexpr int NBUF = 3;
     const size_t wire_words = (size_t)cyc.n_wires * cyc.n;
-    u64* bufs[NBUF];
+    u64 *bufs[NBUF], *d_bufs[NBUF];
     for (auto& b : bufs) REQUIRE((b = static_cast<u64*>(vpbs_host_alloc(8 * wire_words))) != nullptr, "pinned allocation failed");
+    for (auto& d : d_bufs) REQUIRE(vpbs_device_alloc(ctx, wire_words, &d) == 0, "device allocation: %s", vpbs_last_error(ctx));
     std::vector<uint8_t> late(cyc.n_preset, 0);
     std::fill(late.begin(), late.begin() + proof_words, 1);   // the previous proof's words arrive late
     char err[256];
     REQUIRE(vpbs_witness_plan_split(cyc.plan, late.data(), err, sizeof err) == 0, "split: %s", err);
+    size_t late_rows[2];
+    REQUIRE(vpbs_witness_plan_late_rows(cyc.plan, late_rows) == 0, "late rows");
     std::vector<u64> base_pis(acc_init);
     base_pis.resize(kn + 1 + kn + 8, 0);
     base_pis.insert(base_pis.end(), cyc.vk.begin(), cyc.vk.end());
@@ -201,7 +205,7 @@ int main(int argc, char** argv) {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> free_bufs{0, 1, 2};
-    std::deque<Ready> ready;
+    std::deque<Ready> generated, ready;   // early thread -> uploader -> main
     std::atomic<bool> failed{false};
     double t_early = 0;
     auto values_of = [&](unsigned s, const std::vector<u64>& inner_pis) {
@@ -240,6 +244,29 @@ int main(int argc, char** argv) {
             t_early += now() - t;
             {
                 std::lock_guard<std::mutex> lk(mu);
+                generated.push_back(std::move(r));
+            }
+            cv.notify_all();
+        }
+    });
+    std::thread uploader([&] {
+        for (unsigned s = 0; s < steps; ++s) {
+            Ready r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !generated.empty() || failed; });
+                if (failed) return;
+                r = std::move(generated.front());
+                generated.pop_front();
+            }
+            if (vpbs_device_upload_bg(ctx, d_bufs[r.buf], bufs[r.buf], wire_words) != 0) {
+                std::fprintf(stderr, "upload of the early wires of step %u failed\n", s);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
                 ready.push_back(std::move(r));
             }
             cv.notify_all();
@@ -260,6 +287,8 @@ int main(int argc, char** argv) {
     REQUIRE(vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr) == 0, "base proof: %s", vpbs_last_error(ctx));
     double t_late = 0, t_prove = 0;
     std::vector<u64> pis;
+    const bool timing = std::getenv("VPBS_TIMING") != nullptr;   // HIP events around every kernel group of the step proofs
+    if (timing) vpbs_timing_enable(ctx, 1);
     for (unsigned s = 0; s < steps; ++s) {
         Ready r;
         {
@@ -276,7 +305,10 @@ int main(int argc, char** argv) {
         t_late += now() - t;
         t = now();
         pis = r.pis;
-        cyc.step_inputs(in, bufs[r.buf], pis.data());
+        REQUIRE(vpbs_device_upload_rows(ctx, d_bufs[r.buf], bufs[r.buf], cyc.n_wires, cyc.n, late_rows[0], late_rows[1]) == 0, "upload: %s",
+                vpbs_last_error(ctx));
+        cyc.step_inputs(in, d_bufs[r.buf], pis.data());
+        in.inputs_on_device = 1;
         REQUIRE(vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr) == 0, "step %u: %s", s, vpbs_last_error(ctx));
         t_prove += now() - t;
         {
@@ -287,6 +319,13 @@ int main(int argc, char** argv) {
     }
     const double seconds = now() - t0;
     early.join();
+    uploader.join();
+    if (timing) {
+        std::vector<char> report(1 << 14);
+        vpbs_timing_report(ctx, report.data(), report.size());
+        std::printf("device time of %u step proofs by kernel group: %s\n", steps, report.data());
+        vpbs_timing_enable(ctx, 0);
+    }
 
     // ---- verify_pbs (:388-489) on the LAST proof only ----
     std::vector<uint8_t> bytes(8 * (proof_words + n_pi) + 8192);
@@ -325,7 +364,7 @@ int main(int argc, char** argv) {
         REQUIRE(decrypted == (long)message, "the bootstrapped ciphertext decrypts to %ld, not %llu", decrypted, (unsigned long long)message);
     }
     std::printf("IVC chain: %u of %u step proofs of the cyclic circuit (%llu gate rows, degree 2^%u, %zu public inputs) in %.3f s "
-                "(%.2f ms per step: late witness %.2f, prove incl. upload %.2f; early phase on its thread %.2f); final proof %ld bytes, "
+                "(%.2f ms per step: late witness %.2f, late rows upload + prove %.2f; early phase on its thread %.2f); final proof %ld bytes, "
                 "verified: %d in %.1f ms; decrypted %ld (message %llu)\n",
                 steps, total, (unsigned long long)cyc.meta[5], cyc.log_n, n_pi, seconds, 1e3 * seconds / steps, 1e3 * t_late / steps,
                 1e3 * t_prove / steps, 1e3 * t_early / steps, n_bytes, ok, verify_ms, decrypted, (unsigned long long)message);

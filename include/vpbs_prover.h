@@ -272,6 +272,9 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
                                char* err, size_t err_len);
 void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that run_late did not consume */
+/* out = {row_lo, row_hi}: every wire position run_late writes lies in rows [row_lo, row_hi) -- what has to be uploaded again when the
+ * matrix run_early produced is already on the device.  (0, 0) for a plan without late wires. */
+int vpbs_witness_plan_late_rows(const vpbs_witness_plan* plan, size_t out[2]);
 /* out: {value slots (copy-constraint classes that carry a value), scheduled generators, dependency levels of the device schedule
  * (0: the plan has no device form, see vpbs_witness_device_create), wire positions written by full_witness} */
 int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
@@ -532,6 +535,13 @@ void* vpbs_host_alloc(size_t bytes);
 void vpbs_host_free(void* p);
 int vpbs_device_alloc(vpbs_ctx* ctx, size_t words, uint64_t** out);
 int vpbs_device_upload(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* host_src, size_t words); /* returns after the copy has completed */
+/* The same copy on the context's upload stream, for a second host thread: it may run while another call (vpbs_prove_step ...) is in
+ * progress on the context, touches none of the context's state and reports failures by return code only (vpbs_last_error is not set).
+ * An IVC host uploads the early-phase wires of the NEXT step with it while the current step is being proven. */
+int vpbs_device_upload_bg(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* host_src, size_t words);
+/* Rows [row_lo, row_hi) of every column of a column-major [n_cols][n] matrix (one strided copy; the late phase of a split witness plan
+ * only changes the rows vpbs_witness_plan_late_rows reports).  Returns after the copy has completed. */
+int vpbs_device_upload_rows(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* host_src, unsigned n_cols, size_t n, size_t row_lo, size_t row_hi);
 void vpbs_device_free(vpbs_ctx* ctx, uint64_t* d_ptr);
 
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */

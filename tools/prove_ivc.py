@@ -119,17 +119,20 @@ def main():
     n_buf = 3
     bufs = [torch.empty((135, cyc.d.n), dtype=torch.int64).pin_memory() for _ in range(n_buf)]
     views = [b.numpy().view(np.uint64) for b in bufs]
-    d_wires = torch.empty((135, cyc.d.n), dtype=torch.int64, device="cuda")
+    d_bufs = [torch.empty((135, cyc.d.n), dtype=torch.int64, device="cuda") for _ in range(n_buf)]
     flat = lambda p: np.concatenate([np.asarray(p[k], np.uint64).reshape(-1) for k in ("caps", "openings", "fri")])
     # The previous proof is the LATE part of a step's PartialWitness: everything that does not depend on it -- the step logic, both chain
     # hashes, the public-input hashes, i.e. three quarters of the generator work -- is generated ahead by a second host thread
-    # (vpbs_witness_plan_split / run_early), which also yields the step's public inputs, the only thing the next early phase needs.
+    # (vpbs_witness_plan_split / run_early), which also yields the step's public inputs, the only thing the next early phase needs.  A third
+    # thread moves that matrix to the device while the current step is being proven (vpbs_device_upload_bg); once the proof exists, the late
+    # phase fills the in-circuit verifier's rows and only those rows are uploaded again (vpbs_device_upload_rows).
     late_mask = np.zeros(len(cyc.d.preset_pos), np.uint8)
     late_mask[:shape_words] = 1
     cyc.plan.split(late_mask)
     import queue
     import threading
-    free_bufs, ready, errs = queue.Queue(), queue.Queue(), []
+    free_bufs, generated, ready, errs = queue.Queue(), queue.Queue(), queue.Queue(), []
+    late_rows = cyc.plan.late_rows()
     for i in range(n_buf):
         free_bufs.put(i)
     base_pis = np.concatenate([acc_init.reshape(-1), np.zeros(1 + kn + 8, np.uint64), cyc.vk])
@@ -147,9 +150,22 @@ def main():
                 state = cyc.plan.run_early(values, views[b])
                 pis_prev = views[b][cyc.pi_cols, cyc.pi_rows].copy()     # public inputs never depend on the inner proof's words
                 t_early[0] += time.perf_counter() - t
-                ready.put((b, state, values, pis_prev))
+                generated.put((b, state, values, pis_prev))
         except Exception as e:
             errs.append(e)
+            generated.put(None)
+
+    def upload_thread():
+        try:
+            for s in range(steps):
+                item = generated.get()
+                if item is None:
+                    break
+                ctx.upload_bg(d_bufs[item[0]].data_ptr(), bufs[item[0]].data_ptr(), 135 * cyc.d.n)
+                ready.put(item)
+        except Exception as e:
+            errs.append(e)
+        if errs:
             ready.put(None)
 
     t_wit = t_copy = t_prove = 0.0
@@ -157,13 +173,15 @@ def main():
     t0 = time.perf_counter()
     worker = threading.Thread(target=early_thread, daemon=True)   # a failure of the main loop must not leave the process waiting on it
     worker.start()
+    uploader = threading.Thread(target=upload_thread, daemon=True)
+    uploader.start()
     # cyclic_base_proof (ivc_based_vpbs.rs:292-299): a proof of the dummy circuit whose public inputs carry the initial accumulator and the
     # cyclic circuit's verifier data
     base_host = torch.empty((135, dum.d.n), dtype=torch.int64).pin_memory()
     dum.plan.run(base_pis, out=base_host.numpy().view(np.uint64))
-    d_wires.copy_(base_host, non_blocking=True)
+    d_base = base_host.cuda()
     torch.cuda.synchronize()
-    proof, _ = dum.prove(d_wires.data_ptr(), base_pis)
+    proof, _ = dum.prove(d_base.data_ptr(), base_pis)
     t_base = time.perf_counter() - t0
     last = None
     for s in range(steps):
@@ -176,14 +194,14 @@ def main():
         cyc.plan.run_late(state, values, views[b])
         t_wit += time.perf_counter() - t
         t = time.perf_counter()
-        d_wires.copy_(bufs[b], non_blocking=True)
-        torch.cuda.synchronize()
-        free_bufs.put(b)
+        ctx.upload_rows(d_bufs[b].data_ptr(), bufs[b].data_ptr(), 135, cyc.d.n, *late_rows)
         t_copy += time.perf_counter() - t
         t = time.perf_counter()
-        proof, last = cyc.prove(d_wires.data_ptr(), pis)
+        proof, last = cyc.prove(d_bufs[b].data_ptr(), pis)
         t_prove += time.perf_counter() - t
+        free_bufs.put(b)
     worker.join()
+    uploader.join()
     if dist:
         dist.barrier()
     seconds = time.perf_counter() - t0
@@ -220,7 +238,7 @@ def main():
                 "%d x MI355X; the last proof alone is the vPBS proof" % (steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe, world),
         "step_proofs": steps, "seconds": seconds, "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
         "vpbs_proofs_per_s": (1.0 / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
-        "ms_per_step_split": {"witness_late_phase_host": 1e3 * t_wit / steps, "wires_to_device": 1e3 * t_copy / steps,
+        "ms_per_step_split": {"witness_late_phase_host": 1e3 * t_wit / steps, "late_rows_to_device": 1e3 * t_copy / steps,
                               "prove_step": 1e3 * t_prove / steps, "base_proof_once": 1e3 * t_base,
                               "witness_early_phase_on_a_second_thread": 1e3 * t_early[0] / steps},
         "proof_bytes": len(blob), "verify_last_proof_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted,

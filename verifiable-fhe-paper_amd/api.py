@@ -181,6 +181,9 @@ SIGNATURES = {
     "vpbs_host_free": (None, [_vp]),
     "vpbs_device_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vpbs_device_upload": (_i, [_vp, _vp, U64P, _sz]),
+    "vpbs_device_upload_bg": (_i, [_vp, _vp, _vp, _sz]),
+    "vpbs_device_upload_rows": (_i, [_vp, _vp, _vp, _ui, _sz, _sz, _sz]),
+    "vpbs_witness_plan_late_rows": (_i, [_vp, C.POINTER(_sz)]),
     "vpbs_device_free": (None, [_vp, _vp]),
     "vpbs_keygen": (_i, [_vp, C.POINTER(KeygenParamsC), U64P, U64P, U64P, _vp, _vp, _i]),
     "vpbs_lwe_encrypt": (_i, [C.POINTER(KeygenParamsC), U64P, _u64, _u64, U64P]),
@@ -457,6 +460,13 @@ class WitnessPlan:
         if lib().vpbs_witness_plan_run_late(self.h, state, _ptr(val), _ptr(out), err, 512):
             raise VpbsError("vpbs_witness_plan_run_late: " + err.value.decode())
         return out
+
+    def late_rows(self):
+        """-> (row_lo, row_hi): the rows run_late writes (vpbs_witness_plan_late_rows)"""
+        out = (C.c_size_t * 2)()
+        if lib().vpbs_witness_plan_late_rows(self.h, out):
+            raise VpbsError("vpbs_witness_plan_late_rows: the plan is not split")
+        return int(out[0]), int(out[1])
 
     def stats(self):
         """-> dict(slots, generators, levels, positions)"""
@@ -937,6 +947,16 @@ class Context:
         self._check(lib().vpbs_keygen(self.h, C.byref(prm), _ptr(s_lwe), _ptr(s_glwe), _ptr(s_to), bsk.ctypes.data if want_bsk else None,
                                       ksk.ctypes.data if want_ksk else None, 0))
         return {"params": prm, "s_lwe": s_lwe, "s_glwe": s_glwe, "s_to": s_to, "bsk": bsk, "ksk": ksk}
+
+    def upload_bg(self, d_dst, host, words):
+        """vpbs_device_upload_bg: host (pinned) -> device pointer on the context's upload stream; callable from a second thread while a
+        prover call runs on the context"""
+        if lib().vpbs_device_upload_bg(self.h, C.c_void_p(int(d_dst)), C.c_void_p(int(host)), int(words)):
+            raise VpbsError("vpbs_device_upload_bg failed")
+
+    def upload_rows(self, d_dst, host, n_cols, n, row_lo, row_hi):
+        """vpbs_device_upload_rows: rows [row_lo, row_hi) of every column of a column-major [n_cols][n] matrix"""
+        self._check(lib().vpbs_device_upload_rows(self.h, C.c_void_p(int(d_dst)), C.c_void_p(int(host)), n_cols, n, row_lo, row_hi))
 
     def glwe_decrypt(self, s, ct):
         """Glwe::decrypt: s [K-1][N] (or [K][N]: the leading K-1 polynomials are used), ct [K][N] -> m [N]"""

@@ -271,7 +271,9 @@ int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, 
     c->log_n_max = log_n_max;
     c->rate_bits = rate_bits;
     c->cap_height = cap_height;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return VPBS_ERR_DEVICE;
     }
@@ -296,6 +298,8 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     if (c->gate_fork) (void)hipEventDestroy(c->gate_fork);
     for (auto e : c->gate_join)
         if (e) (void)hipEventDestroy(e);
+    (void)hipStreamSynchronize(c->upload_stream);
+    (void)hipStreamDestroy(c->upload_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -671,6 +675,22 @@ int vpbs_device_upload(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, s
     if (!c || !d_dst || !host_src) return VPBS_ERR_INVALID;
     return guarded(c, [&] {
         VPBS_HIP(hipMemcpyAsync(d_dst, host_src, sizeof(u64) * words, hipMemcpyHostToDevice, c->stream));
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int vpbs_device_upload_bg(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, size_t words) {
+    // nothing of the context is touched except its (immutable) device ordinal and upload stream: safe beside a running prover call
+    if (!c || !d_dst || !host_src) return VPBS_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return VPBS_ERR_DEVICE;
+    if (hipMemcpyAsync(d_dst, host_src, sizeof(u64) * words, hipMemcpyHostToDevice, c->upload_stream) != hipSuccess) return VPBS_ERR_DEVICE;
+    return hipStreamSynchronize(c->upload_stream) == hipSuccess ? VPBS_OK : VPBS_ERR_DEVICE;
+}
+int vpbs_device_upload_rows(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, unsigned n_cols, size_t n, size_t row_lo, size_t row_hi) {
+    if (!c || !d_dst || !host_src || row_lo > row_hi || row_hi > n) return VPBS_ERR_INVALID;
+    if (row_lo == row_hi || n_cols == 0) return VPBS_OK;
+    return guarded(c, [&] {
+        VPBS_HIP(hipMemcpy2DAsync(d_dst + row_lo, n * sizeof(u64), host_src + row_lo, n * sizeof(u64), (row_hi - row_lo) * sizeof(u64), n_cols,
+                                  hipMemcpyHostToDevice, c->stream));
         VPBS_HIP(hipStreamSynchronize(c->stream));
     });
 }

@@ -35,6 +35,7 @@ struct DeviceError {
 struct vpbs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t upload_stream = nullptr;   // vpbs_device_upload_bg: host->device copies next to the work on `stream`
     unsigned log_n_max = 0, rate_bits = 3, cap_height = 4;
     std::string err;
 

@@ -150,7 +150,8 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
 // inner S-box corrections) multiply-adds and 14 folds.  s: x1 on entry (round constants included), x1' on exit.
 // GATE = true is the PoseidonGate form of the same three rounds (gates.hip): the S-box inputs are the gate's partial_sbox wires
 // w[0..3) instead of the computed values, and the computed inputs of rounds 2 and 3 are returned (canonical) in x_out[0..2)
-// for the constraints "computed - wire" (round 1's input is s[0] on entry).
+// for the constraints "computed - wire" (round 1's input is s[0] on entry).  GATE = false with x_out != nullptr is the witness
+// generator's form: the plain permutation that also reports those two S-box inputs (the gate's wires).
 template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w, u64* x_out) {
     const PartialGroup& G = partial_group(g);
     // request the group's constants before the first S-box (scalar-load latency hidden under it)
@@ -173,7 +174,7 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
         a_hi += (u64)hi[j] * MDS1[0][j];
     }
     const u64 x2 = gl::canon(fold96(a_lo, a_hi));
-    if (GATE) x_out[0] = x2;
+    if (GATE || x_out) x_out[0] = x2;
     const u64 d2 = gl::sub(gl::canon(sbox(GATE ? w[1] : x2)), x2);
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
     // x3_0 = (M^2 y)[0] + M[0][0] d2 + (M c2)[0] + c3[0]
@@ -186,7 +187,7 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
     b_lo += (u64)d2l * MDS1[0][0];
     b_hi += (u64)d2h * MDS1[0][0];
     const u64 x3 = gl::canon(fold96(b_lo, b_hi));
-    if (GATE) x_out[1] = x3;
+    if (GATE || x_out) x_out[1] = x3;
     const u64 d3 = gl::sub(gl::canon(sbox(GATE ? w[2] : x3)), x3);
     const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
     // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec

@@ -8,12 +8,17 @@
 // reference's own circuit builder (vec_arithmetic, the recursive verifier) are outside: the caller presets their targets.
 // Restated from the published crate: parity unpinned; checked against an independent Python restatement and against the
 // gate constraints (every generated row must satisfy them).
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <memory>
 #include <mutex>
@@ -103,24 +108,36 @@ template <class R> GL_HD void poseidon_generate(R& r) {
         st[i + 4] = gl::sub(rhs, delta);
     }
     for (int i = 8; i < 12; ++i) st[i] = r.get(i);
-    // st holds the S-box inputs of the current round as arbitrary u64 residues; the MDS layer adds the next round's constants
+    // st holds the S-box inputs of the current round as arbitrary u64 residues; the MDS layer adds the next round's constants.  Same
+    // schedule as poseidon::permute (the 22 partial rounds as 7 fused groups of three + one), with every S-box input the gate carries
+    // as a wire written on the way.
     for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], poseidon::rc(i));
-    for (int round = 0; round < 30; ++round) {
-        if (round < 4 || round >= 26) {
-            for (int i = 0; i < 12; ++i) {
-                if (round >= 1 && round < 4) r.set(29 + 12 * (round - 1) + i, gl::canon(st[i]));
-                if (round >= 26) r.set(87 + 12 * (round - 26) + i, gl::canon(st[i]));
-                st[i] = poseidon::sbox(st[i]);
-            }
-        } else {
-            r.set(65 + (round - 4), gl::canon(st[0]));
-            st[0] = poseidon::sbox(st[0]);
-        }
+    auto full_round = [&](int round, int wire0) {
         u64 kc[12];
         if (round + 1 < 30)
             for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * (round + 1) + i);
+        for (int i = 0; i < 12; ++i) {
+            if (wire0 >= 0) r.set(wire0 + i, gl::canon(st[i]));
+            st[i] = poseidon::sbox(st[i]);
+        }
         poseidon::mds_add_const(st, round + 1 < 30 ? kc : nullptr);
+    };
+    for (int round = 0; round < 4; ++round) full_round(round, round ? 29 + 12 * (round - 1) : -1);
+    for (int g = 0; g < 7; ++g) {
+        u64 x[2];
+        r.set(65 + 3 * g, gl::canon(st[0]));
+        poseidon::partial_group3_core<false>(st, g, nullptr, x);
+        r.set(65 + 3 * g + 1, x[0]);
+        r.set(65 + 3 * g + 2, x[1]);
     }
+    {
+        u64 kc[12];
+        for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * 26 + i);
+        r.set(65 + 21, gl::canon(st[0]));
+        st[0] = poseidon::sbox(st[0]);
+        poseidon::mds_add_const(st, kc);
+    }
+    for (int round = 26; round < 30; ++round) full_round(round, 87 + 12 * (round - 26));
     for (int i = 0; i < 12; ++i) r.set(12 + i, gl::canon(st[i]));
 }
 
@@ -305,6 +322,112 @@ bool check_circuit(const vpbs_circuit* c) {
 // value slots (one slot per copy-constraint class).  A run is then: presets -> slots, the schedule in order (no readiness checks, no
 // union-find), slots -> wires (full_witness) in parallel.  The step circuit is proven n + 2 times per PBS with the same plan.
 }  // namespace
+
+// spin briefly (the other side answers within microseconds), then give the core away
+template <class Pred> void spin_until(Pred ready) {
+    for (unsigned i = 0; !ready(); ++i) {
+        if (i < 2000) __builtin_ia32_pause();
+        else std::this_thread::yield();
+    }
+}
+
+// The host threads that share the wide dependency levels of a split plan's phase.  They belong to the plan and live as long as it does:
+// asleep on a condition variable between runs, spinning on a phase counter while a run is active (a run is hundreds of levels within a
+// few milliseconds; waking a sleeping thread per level would cost more than the level).  One run at a time per pool (`busy`); a second
+// concurrent run of the same phase finds the pool taken and proceeds on its own thread alone.
+struct LevelPool {
+    const unsigned threads;                       // including the calling thread (number 0)
+    std::mutex busy;
+    explicit LevelPool(unsigned n) : threads(std::max(1u, n)) {
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([this, t] { work(t); });
+        place_near_caller();
+    }
+    ~LevelPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    void begin() {   // wake the workers for a run
+        {
+            std::lock_guard<std::mutex> lk(m);
+            active.store(true, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    void end() {
+        std::lock_guard<std::mutex> lk(m);
+        active.store(false, std::memory_order_release);
+    }
+    // every thread of the pool (the caller as number 0) runs job(t); returns when all have finished
+    template <class Job> void share(Job&& j) {
+        job = std::ref(j);
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+        j(0u);
+        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+    }
+
+  private:
+    // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs that share
+    // the caller's last-level cache (Linux: cache/index3/shared_cpu_list of the CPU the caller runs on) when that set can hold them.  The
+    // caller's own affinity is left alone.  VPBS_POOL_PIN=0 turns it off.
+    void place_near_caller() {
+        const char* e = std::getenv("VPBS_POOL_PIN");
+        if ((e && std::atoi(e) == 0) || workers.empty()) return;
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return;
+        char path[128];
+        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        FILE* f = std::fopen(path, "r");
+        if (!f) return;
+        char line[512] = {0};
+        const bool got = std::fgets(line, sizeof line, f) != nullptr;
+        std::fclose(f);
+        if (!got) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        unsigned count = 0;
+        for (const char* q = line; *q;) {   // "0-7,128-135"
+            char* end = nullptr;
+            const long a = std::strtol(q, &end, 10);
+            if (end == q) break;
+            long b = a;
+            if (*end == '-') b = std::strtol(end + 1, &end, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &set), ++count;
+            q = *end == ',' ? end + 1 : end;
+            if (*end != ',') break;
+        }
+        if (count < threads) return;   // the cache domain cannot hold the pool: leave the placement to the scheduler
+        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof set, &set);
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<u32> phase{0}, done{0};
+    std::atomic<bool> active{false};
+    bool quit = false;
+    std::function<void(unsigned)> job;
+    void work(unsigned t) {
+        u32 seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || active.load(std::memory_order_acquire); });
+                if (quit) return;
+            }
+            for (;;) {
+                spin_until([&] { return phase.load(std::memory_order_acquire) != seen || !active.load(std::memory_order_acquire); });
+                if (phase.load(std::memory_order_acquire) == seen) break;   // the run is over: back to sleep
+                ++seen;
+                job(t);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        }
+    }
+};
 }  // namespace vpbs
 
 struct vpbs_witness_plan {
@@ -336,7 +459,15 @@ struct vpbs_witness_plan {
     // the late generators by dependency level (a generator of level L reads only what levels < L wrote, and two generators of one level
     // never write the same slot: a second writer of a slot is placed above the first and compares): the wide levels -- the 28 FRI queries
     // of an in-circuit verifier are independent of each other -- are run by several host threads
-    std::vector<u32> late_order, late_level_off;
+    // Both phases hold their generators by dependency level like that (the early phase of the step circuit: the NTT / external-product
+    // arithmetic is wide, the hash chains are one PoseidonGate row per level).
+    struct Phase {
+        std::vector<u32> order, level_off;      // schedule indices sorted by level; level l = order[level_off[l], level_off[l + 1])
+        std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
+    };
+    Phase phase[2];                             // [0] early, [1] late
+    mutable std::unique_ptr<vpbs::LevelPool> pool[2];
+    mutable std::mutex pool_mutex;              // creation of the pools (first run of a phase)
 
     // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
     // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
@@ -830,68 +961,105 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     const unsigned mc = std::max(1u, p.max_consts);
     std::vector<unsigned> deps;
     std::vector<u32> written, written_w;
-    // level bookkeeping of the late part: slot -> level of its (first) late writer, 0 = early or a preset
-    std::vector<u32> slot_level(p.n_slots, 0), step_level(p.schedule.size(), 0);
-    u32 max_level = 0;
+    // level bookkeeping, per phase: slot -> level of its (first) writer in that phase, 0 = a preset or a value of the other phase
+    std::vector<u32> slot_level[2] = {std::vector<u32>(p.n_slots, 0), std::vector<u32>(p.n_slots, 0)};
+    std::vector<u32> step_level(p.schedule.size(), 0);
+    u32 max_level[2] = {0, 0};
     for (size_t i = 0; i < p.schedule.size(); ++i) {
         const auto& st = p.schedule[i];
         bool is_late = false;
+        u32 lvl = 1;
         if (st.row == NO_ROW) {
             const auto& gg = p.gadgets[st.sub];
             const u32* gs = p.gadget_slots.data() + gg.at;
             for (unsigned k = 0; k < gg.n_in; ++k) is_late |= taint[gs[k]] != 0;
-            if (is_late) {
-                u32 lvl = 1;
-                for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, slot_level[gs[k]] + 1);
-                for (unsigned k = 0; k < gg.n_out; ++k) {
-                    taint[gs[gg.n_in + k]] = 1;
-                    if (slot_level[gs[gg.n_in + k]] == 0) slot_level[gs[gg.n_in + k]] = lvl;
-                }
-                step_level[i] = lvl;
-                max_level = std::max(max_level, lvl);
+            std::vector<u32>& sl = slot_level[is_late];
+            for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, sl[gs[k]] + 1);
+            for (unsigned k = 0; k < gg.n_out; ++k) {
+                if (is_late) taint[gs[gg.n_in + k]] = 1;
+                if (sl[gs[gg.n_in + k]] == 0) sl[gs[gg.n_in + k]] = lvl;
             }
         } else {
             const vpbs_gate& g = p.gates[p.row_gate[st.row]];
             const u32* rs = p.row_slots.data() + p.row_off[st.row];
             gen_deps(g, st.sub, deps);
             for (unsigned w : deps) is_late |= taint[rs[w]] != 0;
-            if (is_late) {
-                written.clear();
-                written_w.clear();
-                FlagRow fr{ready, rs, written, written_w};
-                try {
-                    gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, fr, tables_of(g));
-                } catch (const GenError& e) {
-                    err = e.what;
-                    return VPBS_ERR_INVALID;
-                }
-                u32 lvl = 1;
-                for (unsigned w : deps) lvl = std::max(lvl, slot_level[rs[w]] + 1);
-                for (u32 slot : written) lvl = std::max(lvl, slot_level[slot] + 1);   // an earlier late writer: this one compares, after it
-                for (u32 slot : written) {
-                    taint[slot] = 1;
-                    if (slot_level[slot] == 0) slot_level[slot] = lvl;
-                }
-                step_level[i] = lvl;
-                max_level = std::max(max_level, lvl);
+            written.clear();
+            written_w.clear();
+            FlagRow fr{ready, rs, written, written_w};
+            try {
+                gen_run(g, st.sub, p.consts.data() + (size_t)st.row * mc, fr, tables_of(g));
+            } catch (const GenError& e) {
+                err = e.what;
+                return VPBS_ERR_INVALID;
+            }
+            std::vector<u32>& sl = slot_level[is_late];
+            for (unsigned w : deps) lvl = std::max(lvl, sl[rs[w]] + 1);
+            for (u32 slot : written) lvl = std::max(lvl, sl[slot] + 1);   // an earlier writer of the phase: this one compares, after it
+            for (u32 slot : written) {
+                if (is_late) taint[slot] = 1;
+                if (sl[slot] == 0) sl[slot] = lvl;
             }
         }
+        step_level[i] = lvl;
+        max_level[is_late] = std::max(max_level[is_late], lvl);
         p.step_late[i] = is_late ? 1 : 0;
     }
-    // counting sort of the late steps by level (schedule order kept inside a level)
-    p.late_level_off.assign(max_level + 2, 0);
-    for (size_t i = 0; i < p.schedule.size(); ++i)
-        if (p.step_late[i]) ++p.late_level_off[step_level[i] + 1];
-    for (u32 l = 1; l <= max_level + 1; ++l) p.late_level_off[l] += p.late_level_off[l - 1];
-    p.late_order.assign(p.late_level_off[max_level + 1], 0);
-    {
-        std::vector<u32> at(p.late_level_off.begin(), p.late_level_off.end() - 1);
+    for (int ph = 0; ph < 2; ++ph) {
+        vpbs_witness_plan::Phase& P = p.phase[ph];
+        // counting sort of the phase's steps by level (schedule order kept inside a level)
+        P.level_off.assign(max_level[ph] + 2, 0);
         for (size_t i = 0; i < p.schedule.size(); ++i)
-            if (p.step_late[i]) p.late_order[at[step_level[i]]++] = (u32)i;
+            if (p.step_late[i] == ph) ++P.level_off[step_level[i] + 1];
+        for (u32 l = 1; l <= max_level[ph] + 1; ++l) P.level_off[l] += P.level_off[l - 1];
+        P.order.assign(P.level_off[max_level[ph] + 1], 0);
+        {
+            std::vector<u32> at(P.level_off.begin(), P.level_off.end() - 1);
+            for (size_t i = 0; i < p.schedule.size(); ++i)
+                if (p.step_late[i] == ph) P.order[at[step_level[i]]++] = (u32)i;
+        }
+        // Estimated cost per generator (measured, VPBS_TRACE_WITNESS with one thread, EPYC 9575F): a PoseidonGate row is a whole
+        // permutation (1.4 us), most others a handful of field operations (30 ns).  The threads of a wide level take equal COST, not
+        // equal counts.
+        P.cost.assign(P.order.size() + 1, 0);
+        for (size_t k = 0; k < P.order.size(); ++k) {
+            const auto& st = p.schedule[P.order[k]];
+            u32 cost = 3;
+            if (st.row == NO_ROW) {
+                if (p.gadgets[st.sub].kind == VPBS_GEN_QUOTIENT_EXT) cost = 40;
+            } else {
+                switch (p.gates[p.row_gate[st.row]].kind) {
+                    case VPBS_GATE_POSEIDON: cost = 140; break;
+                    case VPBS_GATE_POSEIDON_MDS:
+                    case VPBS_GATE_REDUCING:
+                    case VPBS_GATE_REDUCING_EXT:
+                    case VPBS_GATE_COSET_INTERPOLATION:
+                    case VPBS_GATE_EXPONENTIATION: cost = 60; break;
+                    case VPBS_GATE_BASE_SUM: cost = 20; break;
+                    default: break;
+                }
+            }
+            P.cost[k + 1] = P.cost[k] + cost;
+        }
+        p.pool[ph].reset();
     }
     p.late_out.clear();
     for (size_t i = 0; i < p.out_slot.size(); ++i)
         if (taint[p.out_slot[i]]) p.late_out.push_back((u32)i);
+    if (std::getenv("VPBS_TRACE_WITNESS")) {
+        std::vector<uint8_t> row_late(p.n, 0);
+        for (u32 i : p.late_out) row_late[p.out_pos[i] % p.n] = 1;
+        size_t rows = 0, lo = p.n, hi = 0, runs = 0;
+        for (size_t r = 0; r < p.n; ++r)
+            if (row_late[r]) {
+                ++rows;
+                lo = std::min(lo, r);
+                hi = r;
+                if (r == 0 || !row_late[r - 1]) ++runs;
+            }
+        std::fprintf(stderr, "[witness split] %zu late wire positions on %zu rows in [%zu, %zu], %zu runs of consecutive rows\n", p.late_out.size(), rows,
+                     lo, hi, runs);
+    }
     p.is_split = true;
     return VPBS_OK;
 }
@@ -922,111 +1090,125 @@ bool run_one(const vpbs_witness_plan& p, SlotState& s, size_t i, unsigned mc, st
     return true;
 }
 
-int run_steps(const vpbs_witness_plan& p, SlotState& s, int want_late, std::string& err) {
+// VPBS_TRACE_WITNESS: where a sequential run spends its time, per gate kind (0..31) / gadget generator kind (32..)
+struct KindProfile {
+    const bool on = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
+    double us[64] = {0};
+    unsigned count[64] = {0};
+    std::chrono::steady_clock::time_point t;
+    void start() {
+        if (on) t = std::chrono::steady_clock::now();
+    }
+    void stop(const vpbs_witness_plan& p, size_t i) {
+        if (!on) return;
+        const auto& st = p.schedule[i];
+        const unsigned kind = st.row == NO_ROW ? 32 + (p.gadgets[st.sub].kind & 31) : (p.gates[p.row_gate[st.row]].kind & 31);
+        us[kind] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count();
+        ++count[kind];
+    }
+    void report(const char* phase) const {
+        if (!on) return;
+        for (unsigned q = 0; q < 64; ++q)
+            if (count[q])
+                std::fprintf(stderr, "[witness %s] %s kind %2u: %6u generators, %8.1f us (%.2f us each)\n", phase, q < 32 ? "gate  " : "gadget", q & 31,
+                             count[q], us[q], us[q] / count[q]);
+    }
+};
+
+// The generators of one phase of a split plan, level by level.  A level worth at least PAR_MIN_COST is shared by the threads of the
+// phase's pool, each taking an equal share of the level's estimated cost; cheaper levels (a single PoseidonGate row of a hash chain, a
+// few field operations) stay on the calling thread.  Generators of one level touch disjoint slots (plan_split), so the slot state needs no
+// locking; a "set twice with different values" report goes through SlotState's mutex.  `after` (may be empty) is one more shared job at
+// the end -- the wires of the phase written into the matrix.
+int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned threads, const std::function<void(unsigned, unsigned)>& after,
+               std::string& err) {
+    constexpr u32 PAR_MIN_COST = 600;   // ~6 us of work: four PoseidonGate rows
+    const vpbs_witness_plan::Phase& P = p.phase[ph];
     const unsigned mc = std::max(1u, p.max_consts);
-    for (size_t i = 0; i < p.schedule.size(); ++i) {
-        if (p.step_late[i] != want_late) continue;
-        if (!run_one(p, s, i, mc, err)) return VPBS_ERR_INVALID;
-        if (!s.error.empty()) {
-            err = s.error;
-            return VPBS_ERR_INVALID;
+    const u32 n_levels = (u32)P.level_off.size() - 1;
+    static const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
+    const char* name = ph ? "late" : "early";
+    LevelPool* pool = nullptr;
+    std::unique_lock<std::mutex> busy;
+    if (threads > 1) {
+        {
+            std::lock_guard<std::mutex> lk(p.pool_mutex);
+            if (!p.pool[ph] || p.pool[ph]->threads != threads) {
+                if (!p.pool[ph] || std::unique_lock<std::mutex>(p.pool[ph]->busy, std::try_to_lock).owns_lock()) p.pool[ph].reset(new LevelPool(threads));
+            }
+            pool = p.pool[ph].get();
         }
+        busy = std::unique_lock<std::mutex>(pool->busy, std::try_to_lock);
+        if (!busy.owns_lock()) pool = nullptr;   // another run of this phase has the threads: this one goes alone
     }
-    return VPBS_OK;
-}
-
-// The late generators level by level; a level with at least PAR_MIN generators is shared by `threads` host threads (workers spin on a
-// phase counter between the wide levels: there are a few hundred levels and the whole phase lasts milliseconds).  Generators of one level
-// touch disjoint slots (plan_split), so the slot state needs no locking; a "set twice with different values" report goes through a
-// per-thread state whose error is merged at the end of the level.
-// spin briefly (the other side answers within microseconds), then give the core away
-template <class Pred> void spin_until(Pred ready) {
-    for (unsigned i = 0; !ready(); ++i) {
-        if (i < 2000) __builtin_ia32_pause();
-        else std::this_thread::yield();
-    }
-}
-
-int run_late_levels(const vpbs_witness_plan& p, SlotState& s, unsigned threads, u64* wires_out, std::string& err) {
-    constexpr u32 PAR_MIN = 24;
-    const unsigned mc = std::max(1u, p.max_consts);
-    const u32 n_levels = (u32)p.late_level_off.size() - 1;
-    if (threads <= 1) {
-        for (u32 k = 0; k < p.late_order.size(); ++k) {
-            if (!run_one(p, s, p.late_order[k], mc, err)) return VPBS_ERR_INVALID;
+    if (!pool) {   // alone: the plan's own schedule order (generators of a row's neighbourhood together: far fewer cache misses than level order)
+        KindProfile prof;
+        for (size_t i = 0; i < p.schedule.size(); ++i) {
+            if (p.step_late[i] != ph) continue;
+            prof.start();
+            const bool ok = run_one(p, s, i, mc, err);
+            prof.stop(p, i);
+            if (!ok) return VPBS_ERR_INVALID;
             if (!s.error.empty()) {
                 err = s.error;
                 return VPBS_ERR_INVALID;
             }
         }
-        for (u32 i : p.late_out) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
+        prof.report(name);
+        if (after) after(0, 1);
         return VPBS_OK;
     }
-    std::atomic<u32> phase{0}, done{0};
-    std::atomic<bool> quit{false}, failed{false};
+    threads = pool->threads;
+    std::atomic<bool> failed{false};
     std::vector<std::string> errs(threads);
-    u32 cur_lo = 0, cur_hi = 0;   // the level being shared; written by the main thread before it bumps `phase`
-    bool scatter = false;         // the last shared job: the late wires into the matrix
-    auto chunk = [&](unsigned t) {
-        const u32 cnt = cur_hi - cur_lo, lo = cur_lo + (u32)((u64)cnt * t / threads), hi = cur_lo + (u32)((u64)cnt * (t + 1) / threads);
-        if (scatter) {
-            for (u32 k = lo; k < hi; ++k) wires_out[p.out_pos[p.late_out[k]]] = s.val[p.out_slot[p.late_out[k]]];
-            return;
-        }
-        for (u32 k = lo; k < hi && !failed.load(std::memory_order_relaxed); ++k)
-            if (!run_one(p, s, p.late_order[k], mc, errs[t])) failed.store(true);
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t)
-        pool.emplace_back([&, t] {
-            u32 seen = 0;
-            for (;;) {
-                spin_until([&] { return phase.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
-                if (phase.load(std::memory_order_acquire) == seen) return;   // quit
-                ++seen;
-                chunk(t);
-                done.fetch_add(1, std::memory_order_release);
-            }
-        });
+    double t_narrow = 0, t_wide = 0;
+    u32 n_wide = 0;
+    auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    pool->begin();
     int rc = VPBS_OK;
     for (u32 l = 0; l < n_levels && rc == VPBS_OK; ++l) {
-        const u32 lo = p.late_level_off[l], hi = p.late_level_off[l + 1];
-        if (hi - lo < PAR_MIN) {
+        const u32 lo = P.level_off[l], hi = P.level_off[l + 1];
+        const double t_level = trace ? clock() : 0;
+        if (P.cost[hi] - P.cost[lo] < PAR_MIN_COST) {
             for (u32 k = lo; k < hi && rc == VPBS_OK; ++k)
-                if (!run_one(p, s, p.late_order[k], mc, errs[0])) rc = VPBS_ERR_INVALID;
+                if (!run_one(p, s, P.order[k], mc, errs[0])) rc = VPBS_ERR_INVALID;
+            if (trace) t_narrow += clock() - t_level;
         } else {
-            cur_lo = lo;
-            cur_hi = hi;
-            done.store(0, std::memory_order_relaxed);
-            phase.fetch_add(1, std::memory_order_release);
-            chunk(0);
-            spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+            // equal shares of the level's estimated cost
+            const u32 *c0 = P.cost.data() + lo, *c1 = P.cost.data() + hi;
+            const u64 total = *c1 - *c0;
+            auto bound = [&](unsigned t) { return t >= threads ? hi : (u32)(std::lower_bound(c0, c1, (u32)(*c0 + total * t / threads)) - P.cost.data()); };
+            pool->share([&](unsigned t) {
+                for (u32 k = bound(t), end = bound(t + 1); k < end && !failed.load(std::memory_order_relaxed); ++k)
+                    if (!run_one(p, s, P.order[k], mc, errs[t])) failed.store(true);
+            });
             if (failed.load()) rc = VPBS_ERR_INVALID;
+            if (trace) t_wide += clock() - t_level, ++n_wide;
         }
         if (rc == VPBS_OK && !s.error.empty()) {
             errs[0] = s.error;
             rc = VPBS_ERR_INVALID;
         }
     }
-    if (rc == VPBS_OK) {   // the late wires, shared the same way
-        scatter = true;
-        cur_lo = 0;
-        cur_hi = (u32)p.late_out.size();
-        done.store(0, std::memory_order_relaxed);
-        phase.fetch_add(1, std::memory_order_release);
-        chunk(0);
-        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
-    }
-    quit.store(true, std::memory_order_release);
-    for (auto& th : pool) th.join();
+    const double t_after = trace ? clock() : 0;
+    if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
+    pool->end();
+    if (trace)
+        std::fprintf(stderr, "[witness %s] %u threads: %u narrow levels %.2f ms, %u wide levels %.2f ms, wires %.2f ms\n", name, threads,
+                     n_levels - n_wide, t_narrow, n_wide, t_wide, clock() - t_after);
     if (rc != VPBS_OK)
         for (const auto& e : errs)
             if (!e.empty()) {
                 err = e;
                 break;
             }
-    if (rc != VPBS_OK && err.empty()) err = s.error.empty() ? "a late generator failed" : s.error;
+    if (rc != VPBS_OK && err.empty()) err = s.error.empty() ? "a generator failed" : s.error;
     return rc;
+}
+
+unsigned default_phase_threads() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return std::max(1u, std::max(std::min(8u, hw / 2), std::min(12u, hw / 8)));   // 4 of 8, 8 of 16..64, 12 of 96 and more
 }
 }  // namespace
 }  // namespace vpbs
@@ -1048,29 +1230,41 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
         return VPBS_ERR_INVALID;
     }
     const vpbs_witness_plan& p = *plan;
+    const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t1 = std::chrono::steady_clock::now();
+        if (trace) std::fprintf(stderr, "[witness early] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     auto* st = new vpbs_witness_state{SlotState{std::vector<u64>(p.n_slots, 0), std::vector<uint8_t>(p.n_slots, 0), p.n, {}}};
     SlotState& s = st->s;
+    lap("state");
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
         if (!p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+    lap("presets");
     std::string msg = s.error;
-    int rc = msg.empty() ? run_steps(p, s, 0, msg) : VPBS_ERR_INVALID;
+    if (threads == 0) {
+        static const unsigned early_threads = [] {
+            const char* e = std::getenv("VPBS_EARLY_THREADS");
+            return e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
+        }();
+        threads = early_threads;
+    }
+    // the generators, then every wire takes its class's value: the late classes are still zero and are overwritten by run_late
+    auto fill = [&](unsigned t, unsigned of) {
+        const size_t lo = p.total * t / of, hi = p.total * (t + 1) / of;
+        std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
+        const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
+        for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.is_set[p.out_slot[i]] ? s.val[p.out_slot[i]] : 0;
+    };
+    const int rc = msg.empty() ? run_levels(p, 0, s, threads, fill, msg) : VPBS_ERR_INVALID;
     if (rc != VPBS_OK) {
         report(err, err_len, msg);
         delete st;
         return rc;
     }
-    // every wire takes its class's value: the late classes are still zero and are overwritten by run_late
-    if (threads == 0) threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    auto fill = [&](unsigned t) {
-        const size_t lo = p.total * t / threads, hi = p.total * (t + 1) / threads;
-        std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
-        const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
-        for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.val[p.out_slot[i]];
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fill, t);
-    fill(0);
-    for (auto& th : pool) th.join();
+    lap("generators + wires");
     *state_out = st;
     return VPBS_OK;
 }
@@ -1097,36 +1291,41 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
     std::string msg = s.error;
     static const unsigned late_threads = [] {
         const char* e = std::getenv("VPBS_LATE_THREADS");
-        return e ? (unsigned)std::max(1, atoi(e)) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        return e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
     }();
-    const int rc = msg.empty() ? run_late_levels(p, s, late_threads, wires_out, msg) : VPBS_ERR_INVALID;
+    auto scatter = [&](unsigned t, unsigned of) {
+        const size_t cnt = p.late_out.size();
+        for (size_t k = cnt * t / of, hi = cnt * (t + 1) / of; k < hi; ++k) {
+            const u32 slot = p.out_slot[p.late_out[k]];
+            wires_out[p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
+        }
+    };
+    const int rc = msg.empty() ? run_levels(p, 1, s, late_threads, scatter, msg) : VPBS_ERR_INVALID;
     lap("generators + late wires");
     if (trace) {
-        size_t n_late = 0, n_pos = 0;
-        for (size_t i = 0; i < p.schedule.size(); ++i)
-            if (p.step_late[i]) {
-                ++n_late;
-                if (p.schedule[i].row != NO_ROW && p.gates[p.row_gate[p.schedule[i].row]].kind == VPBS_GATE_POSEIDON) ++n_pos;
+        for (int ph = 0; ph < 2; ++ph) {
+            const vpbs_witness_plan::Phase& P = p.phase[ph];
+            size_t n_pos = 0, wide = 0, wide_steps = 0, wide_pos = 0, narrow_pos = 0;
+            for (size_t l = 0; l + 1 < P.level_off.size(); ++l) {
+                size_t pos_rows = 0;
+                for (u32 k = P.level_off[l]; k < P.level_off[l + 1]; ++k) {
+                    const auto& st = p.schedule[P.order[k]];
+                    if (st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) ++pos_rows;
+                }
+                n_pos += pos_rows;
+                if (P.cost[P.level_off[l + 1]] - P.cost[P.level_off[l]] >= 600) {
+                    ++wide;
+                    wide_steps += P.level_off[l + 1] - P.level_off[l];
+                    wide_pos += pos_rows;
+                } else {
+                    narrow_pos += pos_rows;
+                }
             }
-        size_t wide = 0, wide_steps = 0, wide_pos = 0, narrow_pos = 0;
-        for (size_t l = 0; l + 1 < p.late_level_off.size(); ++l) {
-            const u32 cnt = p.late_level_off[l + 1] - p.late_level_off[l];
-            size_t pos_rows = 0;
-            for (u32 k = p.late_level_off[l]; k < p.late_level_off[l + 1]; ++k) {
-                const auto& st = p.schedule[p.late_order[k]];
-                if (st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) ++pos_rows;
-            }
-            if (cnt >= 24) {
-                ++wide;
-                wide_steps += cnt;
-                wide_pos += pos_rows;
-            } else {
-                narrow_pos += pos_rows;
-            }
+            std::fprintf(stderr, "[witness %s] %zu generators (%zu PoseidonGate rows) of %zu; %zu levels, %zu of them wide with %zu generators "
+                         "(%zu PoseidonGate rows; %zu PoseidonGate rows sit in narrow levels)\n", ph ? "late" : "early", P.order.size(), n_pos,
+                         p.schedule.size(), P.level_off.size() - 1, wide, wide_steps, wide_pos, narrow_pos);
         }
-        std::fprintf(stderr, "[witness late] %zu late generators (%zu PoseidonGate rows) of %zu, %zu late wire positions; %zu levels, %zu of them "
-                     "wide with %zu generators (%zu PoseidonGate rows; %zu PoseidonGate rows sit in narrow levels)\n", n_late, n_pos,
-                     p.schedule.size(), p.late_out.size(), p.late_level_off.size() - 1, wide, wide_steps, wide_pos, narrow_pos);
+        std::fprintf(stderr, "[witness late] %zu late wire positions\n", p.late_out.size());
     }
     report(err, err_len, msg);
     delete state;
@@ -1134,6 +1333,19 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
 }
 
 void vpbs_witness_state_free(vpbs_witness_state* state) { delete state; }
+
+int vpbs_witness_plan_late_rows(const vpbs_witness_plan* plan, size_t out[2]) {
+    if (!plan || !plan->is_split || !out) return VPBS_ERR_INVALID;
+    size_t lo = plan->n, hi = 0;
+    for (vpbs::u32 i : plan->late_out) {
+        const size_t r = plan->out_pos[i] % plan->n;
+        lo = std::min(lo, r);
+        hi = std::max(hi, r + 1);
+    }
+    out[0] = hi ? lo : 0;
+    out[1] = hi;
+    return VPBS_OK;
+}
 
 int vpbs_gate_fill_row(const vpbs_gate* gp, const uint64_t* constants, uint64_t* row) {
     if (!gp || !row) return VPBS_ERR_INVALID;
