@@ -211,6 +211,83 @@ def test_cxx_host_generates_the_exported_witness(tmp_path):
     assert r.returncode == 1 and "public inputs differ" in r.stderr, r.stdout + r.stderr
 
 
+def test_split_plan_levels_threads_and_concurrent_runs():
+    """vpbs_witness_plan_split on the step circuit with the GGSW (the key material) arriving late: the early phase alone, on 2 and on 5
+    threads, gives the matrix of the one-shot plan once the late phase has run; the late phase only writes the rows
+    vpbs_witness_plan_late_rows reports; four host threads running the same plan at once (one gets the plan's thread pool, the others go
+    alone) each get their own correct matrix."""
+    import threading
+    N, K, ELL, LOGB, n_lwe = 64, 2, 4, 5, 6
+    circ = sc.StepCircuit(api, N, K, ELL, LOGB, n_lwe, _ring(6))
+    b = circ.built
+
+    def presets(seed, counter):
+        x = _inputs(seed, N, K, ELL)
+        a = {}
+        for targets, values in ((circ.acc_init, x["acc_init"]), (circ.acc_in, x["acc_in"])):
+            for tp, vp in zip(targets, values):
+                a.update(zip(tp, vp))
+        a.update(zip(circ.ggsw_flat, x["ggsw"].reshape(-1)))
+        a[circ.counter], a[circ.mask] = counter, x["mask"]
+        a.update(zip(circ.bsk_hash_in, x["bsk_hash_in"]))
+        a.update(zip(circ.lwe_hash_in, x["lwe_hash_in"]))
+        return b.presets(a)
+
+    first = presets(1, 3)
+    positions = list(first)
+    late_pos = {b.pos(t) for t in circ.ggsw_flat}
+    late = np.array([1 if q in late_pos else 0 for q in positions], np.uint8)
+    plan, whole = b.circuit.witness_plan(positions), b.circuit.witness_plan(positions)
+    with pytest.raises(api.VpbsError):
+        plan.late_rows()                                   # not split yet
+    plan.split(late)
+    lo, hi = plan.late_rows()
+    assert 0 <= lo < hi <= b.circuit.n
+    vals = lambda pre: np.array([pre[q] for q in positions], np.uint64)
+    for threads in (1, 2, 5):
+        v = vals(presets(10 + threads, 2 + threads % 3))
+        want = whole.run(v)
+        out = np.full_like(want, 0xABCD)
+        early_only = v.copy()
+        early_only[late == 1] = 0xDEAD                      # the late entries are not read by the early phase
+        st = plan.run_early(early_only, out, threads=threads)
+        before = out.copy()
+        plan.run_late(st, v, out)
+        assert (out == want).all()
+        changed = np.nonzero((before != out).any(axis=0))[0]
+        assert changed.size and lo <= changed.min() and changed.max() < hi
+    results, errors = {}, []
+
+    def worker(i):
+        try:
+            v = vals(presets(50 + i, 1 + i % 4))
+            out = np.empty((b.circuit.n_wires, b.circuit.n), np.uint64)
+            for _ in range(3):
+                plan.run_late(plan.run_early(v, out), v, out)
+            results[i] = (out, v)
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    pool = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
+    assert not errors, errors
+    for out, v in results.values():
+        assert (out == whole.run(v)).all()
+    # a late word changed after the early phase: the late phase follows the values it is given
+    v = vals(first)
+    out = np.empty((b.circuit.n_wires, b.circuit.n), np.uint64)
+    st = plan.run_early(v, out)
+    v2 = v.copy()
+    v2[np.nonzero(late)[0][5]] ^= np.uint64(1)
+    plan.run_late(st, v2, out)
+    assert (out == whole.run(v2)).all()
+    plan.free()
+    whole.free()
+
+
 def test_cxx_ivc_host_builds_and_fails_loudly_without_a_device(tmp_path):
     """examples/prove_ivc.cpp (the IVC chain from a plain C++ host) compiles against include/vpbs_prover.h with g++ alone, rejects a file
     that is not a circuit, and without a GPU stops at context creation instead of computing anything on the CPU."""
