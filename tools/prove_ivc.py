@@ -11,6 +11,8 @@ seeded ones of vpbs_keygen / vpbs_testv / vpbs_lwe_encrypt at the paper's noise.
 
 usage: tools/prove_ivc.py [N=1024] [n_lwe=728] [log_n=16] [steps=all]   ->  one JSON line
   steps < n + 2 proves only a prefix of the chain (tests); verify_pbs's counter / hash checks are then made against that prefix.
+  VPBS_IVC_CHAINS=c: c independent PBS (own keys, message, context, plans) side by side on the one GPU: a chain leaves the GPU idle while its
+  host phases run, a second chain fills those gaps -- throughput, not latency.
 Several GPUs (BASELINE config 4): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/prove_ivc.py ...
   the chain is sequential, so the GPUs share every STEP: each step proof is coset-sharded over the ranks (vpbs_prove_step_sharded: a rank
   computes the LDEs, leaf hashes and Merkle subtrees of its cosets; cap hashes, quotient values and query records travel over the library's
@@ -67,47 +69,18 @@ class Circuit:
                                gates=self.d.gates)
 
 
-def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    n_lwe = int(sys.argv[2]) if len(sys.argv) > 2 else 728
-    log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=None):
+    """one vPBS: keys from `seed`, base proof, `steps` chained proofs, verify_pbs on the last -> result dict.  `start`: a threading.Barrier
+    shared by the chains of this process (several independent PBS chains keep one GPU busy while each waits for its host phases)."""
+    import queue
+    import threading
     total = n_lwe + 2
-    steps = min(total, int(sys.argv[4])) if len(sys.argv) > 4 else total
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
-    dist, comm, native, dist_device = None, None, False, None
-    t_setup = time.perf_counter()
-    if rank == 0:
-        circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("VPBS_PBS_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-            dist_device = torch.device("cuda", device)
-        else:
-            dist.init_process_group(backend)
-        dist.barrier()
-    cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
-    ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
-    if world > 1:
-        from vpbs_amd import sharding
-        stage_words = (2 << (log_n + 3)) // world
-        native = dist.get_backend() == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
-        comm = sharding.make_comm_rccl(ctx, stage_words=stage_words) if native else \
-            sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
-    cyc, dum = Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)
     shape_words = cyc.d.meta["proof_words"]
     n_pi, kn = len(cyc.d.pi_pos), K * N
     assert n_pi == 2 * kn + 9 + 68 and len(dum.d.preset_pos) == n_pi
-    t_setup = time.perf_counter() - t_setup
-
     # main.rs:40-52 with seeded generators (before the clock: key material exists once per key)
     t_keys = time.perf_counter()
-    message = int(os.environ.get("VPBS_PBS_MESSAGE", "1"))
-    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728, 4.99027217501041e-8, 1.17021618159313e-5)
+    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, seed, 4.99027217501041e-8, 1.17021618159313e-5)
     testv, delta = api.testv(N, 2)
     ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * message % P)
     acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), testv.reshape(1, N)])
@@ -129,8 +102,6 @@ def main():
     late_mask = np.zeros(len(cyc.d.preset_pos), np.uint8)
     late_mask[:shape_words] = 1
     cyc.plan.split(late_mask)
-    import queue
-    import threading
     free_bufs, generated, ready, errs = queue.Queue(), queue.Queue(), queue.Queue(), []
     late_rows = cyc.plan.late_rows()
     for i in range(n_buf):
@@ -170,6 +141,7 @@ def main():
 
     t_wit = t_copy = t_prove = 0.0
     torch.cuda.synchronize()
+    start.wait()
     t0 = time.perf_counter()
     worker = threading.Thread(target=early_thread, daemon=True)   # a failure of the main loop must not leave the process waiting on it
     worker.start()
@@ -224,6 +196,79 @@ def main():
         m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
         decrypted = round(int(m_bar[0]) / delta) % 4
         assert decrypted == message, (decrypted, message)
+    return {"seconds": seconds, "split": {"witness_late_phase_host": 1e3 * t_wit / steps, "late_rows_to_device": 1e3 * t_copy / steps,
+                                          "prove_step": 1e3 * t_prove / steps, "base_proof_once": 1e3 * t_base,
+                                          "witness_early_phase_on_a_second_thread": 1e3 * t_early[0] / steps},
+            "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
+
+
+def main():
+    import threading
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    n_lwe = int(sys.argv[2]) if len(sys.argv) > 2 else 728
+    log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    total = n_lwe + 2
+    steps = min(total, int(sys.argv[4])) if len(sys.argv) > 4 else total
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    n_chains = int(os.environ.get("VPBS_IVC_CHAINS", "1")) if world == 1 else 1
+    if n_chains > 1:   # measured: with several chains' pools side by side, 8 threads per witness phase beat the single-chain default of 12
+        os.environ.setdefault("VPBS_LATE_THREADS", "8")
+        os.environ.setdefault("VPBS_EARLY_THREADS", "8")
+    torch.cuda.set_device(device)
+    dist, comm, native, dist_device = None, None, False, None
+    t_setup = time.perf_counter()
+    if rank == 0:
+        circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("VPBS_PBS_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist_device = torch.device("cuda", device)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+    cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    chains = []
+    for ci in range(n_chains):   # every chain has its own context (stream, device memory), circuit commitments and witness plans
+        ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
+        if world > 1:
+            from vpbs_amd import sharding
+            stage_words = (2 << (log_n + 3)) // world
+            native = dist.get_backend() == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
+            comm = sharding.make_comm_rccl(ctx, stage_words=stage_words) if native else \
+                sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
+        chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))
+    t_setup = time.perf_counter() - t_setup
+    message = int(os.environ.get("VPBS_PBS_MESSAGE", "1"))
+    start = threading.Barrier(n_chains)
+    results, errors = [None] * n_chains, []
+
+    def chain_thread(ci):
+        try:
+            torch.cuda.set_device(device)
+            ctx, cyc, dum = chains[ci]
+            results[ci] = run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start, dist)
+        except BaseException as e:                           # noqa: BLE001
+            errors.append(e)
+            start.abort()
+
+    t_all = time.perf_counter()
+    threads = [threading.Thread(target=chain_thread, args=(ci,)) for ci in range(1, n_chains)]
+    for th in threads:
+        th.start()
+    chain_thread(0)
+    for th in threads:
+        th.join()
+    t_all = time.perf_counter() - t_all
+    if errors:
+        raise errors[0]
+    ctx, cyc, dum = chains[0]
+    r0 = results[0]
+    seconds = max(r["seconds"] for r in results)
+    n_pi = len(cyc.d.pi_pos)
     if rank != 0:
         if native:
             sharding.free_comm_rccl(comm)
@@ -233,26 +278,29 @@ def main():
     print(json.dumps({
         "n_gpus": world, "step_proofs_sharded": ("every step proof coset-sharded over %d GPUs (%s)" % (world, "native RCCL" if native else
                                                  dist.get_backend())) if world > 1 else None,
-        "what": "one vPBS as an IVC chain (ivc_based_vpbs.rs verified_pbs): %d of the %d step proofs of the CYCLIC step circuit (step logic + "
+        "what": "%s as an IVC chain (ivc_based_vpbs.rs verified_pbs): %d of the %d step proofs of the CYCLIC step circuit (step logic + "
                 "in-circuit verifier of the previous proof: %d gate rows, degree 2^%d, %d public inputs) at N=%d, k=1, ELL=4, LOGB=5, n=%d on "
-                "%d x MI355X; the last proof alone is the vPBS proof" % (steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe, world),
-        "step_proofs": steps, "seconds": seconds, "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
-        "vpbs_proofs_per_s": (1.0 / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
-        "ms_per_step_split": {"witness_late_phase_host": 1e3 * t_wit / steps, "late_rows_to_device": 1e3 * t_copy / steps,
-                              "prove_step": 1e3 * t_prove / steps, "base_proof_once": 1e3 * t_base,
-                              "witness_early_phase_on_a_second_thread": 1e3 * t_early[0] / steps},
-        "proof_bytes": len(blob), "verify_last_proof_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted,
-        "before_the_clock": {"circuit_files_commit_plan_s": t_setup, "seeded_keygen_s": t_keys},
+                "%d x MI355X; the last proof alone is the vPBS proof" % ("one vPBS" if n_chains == 1 else "%d independent vPBS side by side, each" %
+                                                                         n_chains, steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe, world),
+        "chains": n_chains, "step_proofs": steps, "seconds": seconds,
+        "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
+        "vpbs_proofs_per_s": (n_chains / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
+        "ms_per_step_split": r0["split"], "ms_per_step_split_other_chains": [r["split"] for r in results[1:]],
+        "proof_bytes": r0["proof_bytes"], "verify_last_proof_ms": r0["verify_ms"], "message": r0["message"], "decrypted": r0["decrypted"],
+        "other_chains": [{k: r[k] for k in ("seconds", "message", "decrypted")} for r in results[1:]],
+        "before_the_clock": {"circuit_files_commit_plan_s": t_setup, "seeded_keygen_s": r0["keygen_s"]},
         "checks": "final proof serialised, parsed back and verified by vpbs_verify_step (full check); its public inputs carry the test vector, "
                   "counter = number of steps, the circuit's own verifier data, the native accumulator and both native chain hashes"
                   + ("; the bootstrapped ciphertext decrypts to the message" if steps == total else "")}))
-    cyc.plan.free()
-    dum.plan.free()
-    cyc.cs.free()
-    dum.cs.free()
+    for ctx, cyc, dum in chains:
+        cyc.plan.free()
+        dum.plan.free()
+        cyc.cs.free()
+        dum.cs.free()
     if native:
         sharding.free_comm_rccl(comm)
-    ctx.close()
+    for ctx, _, _ in chains:
+        ctx.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -10,6 +10,7 @@
 // gate constraints (every generated row must satisfy them).
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -349,6 +350,7 @@ struct LevelPool {
         }
         cv.notify_all();
         for (auto& w : workers) w.join();
+        if (domain >= 0) domains().give_back(domain, threads);
     }
     void begin() {   // wake the workers for a run
         {
@@ -371,37 +373,89 @@ struct LevelPool {
     }
 
   private:
-    // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs that share
-    // the caller's last-level cache (Linux: cache/index3/shared_cpu_list of the CPU the caller runs on) when that set can hold them.  The
-    // caller's own affinity is left alone.  VPBS_POOL_PIN=0 turns it off.
+    // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs of ONE
+    // last-level-cache domain (Linux: cache/index3/shared_cpu_list) -- the caller's when it still has room for them, otherwise the least
+    // taken domain of the same package (a process runs several pools: two phases per plan, one plan per concurrent chain; two pools spinning
+    // on the same sixteen hardware threads cost more than the placement gains).  The caller's own affinity is left alone.
+    // VPBS_POOL_PIN=0 turns the placement off.
+    struct Domains {
+        struct D {
+            cpu_set_t set;
+            unsigned cpus = 0, taken = 0;
+            int package = -1;
+        };
+        std::mutex m;
+        std::vector<D> all;
+        std::vector<int> of_cpu;   // cpu -> index into all, -1 unknown
+        static bool read_line(const char* fmt, int cpu, char* line, size_t len) {
+            char path[160];
+            std::snprintf(path, sizeof path, fmt, cpu);
+            FILE* f = std::fopen(path, "r");
+            if (!f) return false;
+            const bool got = std::fgets(line, (int)len, f) != nullptr;
+            std::fclose(f);
+            return got;
+        }
+        Domains() {
+            const long n = std::min<long>(sysconf(_SC_NPROCESSORS_CONF), CPU_SETSIZE);
+            of_cpu.assign(n > 0 ? (size_t)n : 0, -1);
+            for (int cpu = 0; cpu < (int)of_cpu.size(); ++cpu) {
+                if (of_cpu[cpu] >= 0) continue;
+                char line[512] = {0};
+                if (!read_line("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, line, sizeof line)) continue;
+                D d;
+                CPU_ZERO(&d.set);
+                for (const char* q = line; *q;) {   // "0-7,128-135"
+                    char* end = nullptr;
+                    const long a = std::strtol(q, &end, 10);
+                    if (end == q) break;
+                    long b = a;
+                    if (*end == '-') b = std::strtol(end + 1, &end, 10);
+                    for (long c = a; c <= b && c < (long)of_cpu.size(); ++c) {
+                        CPU_SET((int)c, &d.set);
+                        ++d.cpus;
+                        of_cpu[c] = (int)all.size();
+                    }
+                    if (*end != ',') break;
+                    q = end + 1;
+                }
+                char pk[64] = {0};
+                if (read_line("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu, pk, sizeof pk)) d.package = std::atoi(pk);
+                if (d.cpus) all.push_back(d);
+            }
+        }
+        // -> index of the domain that takes `n` more threads, or -1
+        int take(unsigned n) {
+            std::lock_guard<std::mutex> lk(m);
+            const int cpu = sched_getcpu();
+            const int home = cpu >= 0 && cpu < (int)of_cpu.size() ? of_cpu[cpu] : -1;
+            if (home < 0) return -1;
+            int best = -1;
+            if (all[home].taken + n <= all[home].cpus) best = home;
+            for (int pass = 0; pass < 2 && best < 0; ++pass)   // same package first
+                for (int i = 0; i < (int)all.size(); ++i) {
+                    if (all[i].cpus < n || (pass == 0 && all[i].package != all[home].package)) continue;
+                    if (best < 0 || all[i].taken < all[best].taken) best = i;
+                }
+            if (best >= 0) all[best].taken += n;
+            return best;
+        }
+        void give_back(int i, unsigned n) {
+            std::lock_guard<std::mutex> lk(m);
+            if (i >= 0) all[i].taken -= std::min(n, all[i].taken);
+        }
+    };
+    static Domains& domains() {
+        static Domains d;
+        return d;
+    }
+    int domain = -1;
     void place_near_caller() {
         const char* e = std::getenv("VPBS_POOL_PIN");
         if ((e && std::atoi(e) == 0) || workers.empty()) return;
-        const int cpu = sched_getcpu();
-        if (cpu < 0) return;
-        char path[128];
-        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-        FILE* f = std::fopen(path, "r");
-        if (!f) return;
-        char line[512] = {0};
-        const bool got = std::fgets(line, sizeof line, f) != nullptr;
-        std::fclose(f);
-        if (!got) return;
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        unsigned count = 0;
-        for (const char* q = line; *q;) {   // "0-7,128-135"
-            char* end = nullptr;
-            const long a = std::strtol(q, &end, 10);
-            if (end == q) break;
-            long b = a;
-            if (*end == '-') b = std::strtol(end + 1, &end, 10);
-            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &set), ++count;
-            q = *end == ',' ? end + 1 : end;
-            if (*end != ',') break;
-        }
-        if (count < threads) return;   // the cache domain cannot hold the pool: leave the placement to the scheduler
-        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof set, &set);
+        domain = domains().take(threads);
+        if (domain < 0) return;   // no cache topology to read, or no domain can hold the pool: the scheduler places the threads
+        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof(cpu_set_t), &domains().all[domain].set);
     }
     std::vector<std::thread> workers;
     std::mutex m;
