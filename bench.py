@@ -741,6 +741,15 @@ def main():
                 out["ivc_chain"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
             except Exception as e:
                 out["ivc_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # ... and three independent PBS side by side on the same GPU (throughput: one chain leaves the GPU idle during its host phases)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], capture_output=True, text=True, timeout=900,
+                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank), VPBS_IVC_CHAINS="3"))
+                d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
+                out["ivc_three_chains"] = {k: d[k] for k in ("what", "chains", "seconds", "vpbs_proofs_per_s", "ms_per_step", "ms_per_step_split",
+                                                              "decrypted", "other_chains") if k in d} if "error" not in d else d
+            except Exception as e:
+                out["ivc_three_chains"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             parity, out["cpu_baseline"] = cpu_baseline(gpu_proof)
             out["parity_checked_full_size"] = parity is not None

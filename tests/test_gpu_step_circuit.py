@@ -383,6 +383,21 @@ def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
     print(r.stdout.strip())
 
 
+def test_ivc_chain_tool_two_chains_side_by_side():
+    """VPBS_IVC_CHAINS=2: two independent PBS (own seed, message, context and witness plans) chained concurrently on the one GPU; each
+    final proof passes verify_pbs and decrypts to its own message"""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, entry.ROOT + "/tools/prove_ivc.py", "8", "6", "13"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, VPBS_IVC_CHAINS="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["chains"] == 2 and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1
+    assert [c["decrypted"] for c in d["other_chains"]] == [c["message"] for c in d["other_chains"]] == [0]
+
+
 def test_ivc_chain_tool_sharded_over_two_ranks():
     """BASELINE config 4's mechanism on the one GPU of the test box: the IVC chain with every step proof coset-sharded over two ranks (gloo,
     callback communicator; both ranks on device 0) -- same final proof checks as the single-rank chain, decrypting to the message"""
