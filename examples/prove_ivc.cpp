@@ -232,7 +232,9 @@ int main(int argc, char** argv) {
             }
             const double t = now();
             Ready r{b, nullptr, values_of(s, pis_prev), {}};
-            if (vpbs_witness_plan_run_early(cyc.plan, r.values.data(), 0, bufs[b], &r.state, e2, sizeof e2) != 0) {
+            // the first pass through the three matrices fills them completely, later passes only rewrite the positions that carry values
+            const auto run_early = s < NBUF ? vpbs_witness_plan_run_early : vpbs_witness_plan_run_early_recycled;
+            if (run_early(cyc.plan, r.values.data(), 0, bufs[b], &r.state, e2, sizeof e2) != 0) {
                 std::fprintf(stderr, "early witness phase of step %u: %s\n", s, e2);
                 failed = true;
                 cv.notify_all();

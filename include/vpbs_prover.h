@@ -269,6 +269,12 @@ typedef struct vpbs_witness_state vpbs_witness_state;
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
                                 vpbs_witness_state** state_out, char* err, size_t err_len);
+/* run_early into a matrix that still holds what an earlier run_early (+ run_late) of THIS plan left there -- an IVC host cycles a few pinned
+ * matrices: only the wire positions that carry values are rewritten; the others, zero since that earlier run, are left alone (zeroing the
+ * matrix is a third of the early phase at the paper's parameters).  Anything else in wires_out gives a wrong witness (which the prover's
+ * output then fails to verify); the first use of a buffer must go through vpbs_witness_plan_run_early. */
+int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
+                                         vpbs_witness_state** state_out, char* err, size_t err_len);
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
                                char* err, size_t err_len);
 void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that run_late did not consume */

@@ -214,7 +214,7 @@ def test_cxx_host_generates_the_exported_witness(tmp_path):
 def test_split_plan_levels_threads_and_concurrent_runs():
     """vpbs_witness_plan_split on the step circuit with the GGSW (the key material) arriving late: the early phase alone, on 2 and on 5
     threads, gives the matrix of the one-shot plan once the late phase has run; the late phase only writes the rows
-    vpbs_witness_plan_late_rows reports; four host threads running the same plan at once (one gets the plan's thread pool, the others go
+    vpbs_witness_plan_late_rows reports; a recycled matrix gives the same result; four host threads running the same plan at once (one gets the plan's thread pool, the others go
     alone) each get their own correct matrix."""
     import threading
     N, K, ELL, LOGB, n_lwe = 64, 2, 4, 5, 6
@@ -256,6 +256,10 @@ def test_split_plan_levels_threads_and_concurrent_runs():
         assert (out == want).all()
         changed = np.nonzero((before != out).any(axis=0))[0]
         assert changed.size and lo <= changed.min() and changed.max() < hi
+    # a recycled matrix (it holds the previous run's result): only the positions that carry values are rewritten
+    v = vals(presets(77, 4))
+    plan.run_late(plan.run_early(v, out, recycled=True), v, out)
+    assert (out == whole.run(v)).all()
     results, errors = {}, []
 
     def worker(i):

@@ -113,12 +113,14 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
         try:
             pis_prev = base_pis
             zeros = np.zeros(shape_words, np.uint64)
+            filled = set()
             for s in range(steps):
                 cond, ggsw, mask = plan_steps[s]
                 b = free_bufs.get()
                 t = time.perf_counter()
                 values = np.concatenate([zeros, pis_prev, np.array([cond], np.uint64), ggsw, np.array([mask], np.uint64), cyc.vk, dum.vk])
-                state = cyc.plan.run_early(values, views[b])
+                state = cyc.plan.run_early(values, views[b], recycled=b in filled)   # a matrix this plan filled before: values only
+                filled.add(b)
                 pis_prev = views[b][cyc.pi_cols, cyc.pi_rows].copy()     # public inputs never depend on the inner proof's words
                 t_early[0] += time.perf_counter() - t
                 generated.put((b, state, values, pis_prev))

@@ -165,6 +165,7 @@ SIGNATURES = {
     "vpbs_witness_plan_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_split": (_i, [C.c_void_p, C.POINTER(C.c_uint8), C.c_char_p, _sz]),
     "vpbs_witness_plan_run_early": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
+    "vpbs_witness_plan_run_early_recycled": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
     "vpbs_witness_plan_run_late": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_state_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
@@ -443,12 +444,14 @@ class WitnessPlan:
         if lib().vpbs_witness_plan_split(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), err, 512):
             raise VpbsError("vpbs_witness_plan_split: " + err.value.decode())
 
-    def run_early(self, values, out, threads=0):
-        """everything that does not depend on the late presets -> opaque state for run_late (out: the [n_wires][n] matrix, filled)"""
+    def run_early(self, values, out, threads=0, recycled=False):
+        """everything that does not depend on the late presets -> opaque state for run_late (out: the [n_wires][n] matrix, filled).
+        recycled: `out` still holds the result of an earlier run of this plan -- only the positions that carry values are rewritten"""
         val = _u64(values)
         assert val.size == self.n_preset and out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
         st, err = C.c_void_p(), C.create_string_buffer(512)
-        if lib().vpbs_witness_plan_run_early(self.h, _ptr(val), threads, _ptr(out), C.byref(st), err, 512):
+        fn = lib().vpbs_witness_plan_run_early_recycled if recycled else lib().vpbs_witness_plan_run_early
+        if fn(self.h, _ptr(val), threads, _ptr(out), C.byref(st), err, 512):
             raise VpbsError("vpbs_witness_plan_run_early: " + err.value.decode())
         return st
 

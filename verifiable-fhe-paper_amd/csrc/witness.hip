@@ -372,6 +372,16 @@ struct LevelPool {
         spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
     }
 
+    // the same without the caller: the workers run job(t), t = 1 .. threads - 1, while the caller does something else; finish() waits for them
+    template <class Job> void start(Job&& j) {
+        job = std::ref(j);
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+    }
+    void finish() {
+        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+    }
+
   private:
     // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs of ONE
     // last-level-cache domain (Linux: cache/index3/shared_cpu_list) -- the caller's when it still has room for them, otherwise the least
@@ -520,7 +530,16 @@ struct vpbs_witness_plan {
         std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
     };
     Phase phase[2];                             // [0] early, [1] late
-    mutable std::unique_ptr<vpbs::LevelPool> pool[2];
+    // Chain lanes: PoseidonGate rows whose results nothing but other such rows reads inside the phase (the hash chains over the GGSW and
+    // over the public inputs: thousands of permutations, each needing the one before).  They are taken out of the levels and run on
+    // threads of their own next to them, in schedule order, waiting on the set flag of a value another lane or a level still has to produce.
+    struct Lane {
+        std::vector<u32> steps;                 // schedule indices, ascending
+        std::vector<u32> wait_off, wait;        // step k waits for slots wait[wait_off[k], wait_off[k + 1])
+    };
+    std::vector<Lane> lanes[2];
+    std::vector<u32> lane_steps_sorted[2];      // all lane steps of a phase, ascending (a run without threads for the lanes)
+    mutable std::unique_ptr<vpbs::LevelPool> pool[2], lane_pool[2];
     mutable std::mutex pool_mutex;              // creation of the pools (first run of a phase)
 
     // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
@@ -588,9 +607,20 @@ struct FlagRow {
     void fail(const char* m) { throw GenError{m}; }
 };
 
+// a plain array that is not zeroed unless asked: a slot state is tens of MB, and nothing reads a value whose set flag is clear
+template <class T> struct Buf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    Buf(size_t count, bool zero) : p(zero ? new T[count]() : new T[count]), n(count) {}
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* data() { return p.get(); }
+    size_t size() const { return n; }
+};
+
 struct SlotState {
-    std::vector<u64> val;
-    std::vector<uint8_t> is_set;
+    Buf<u64> val;
+    Buf<uint8_t> is_set;
     size_t n;
     std::string error;
     void set(u32 slot, u64 v, u32 pos) {
@@ -603,8 +633,9 @@ struct SlotState {
                         ") was set twice with different values";
         }
         val[slot] = v;
-        is_set[slot] = 1;
+        __atomic_store_n(&is_set[slot], (uint8_t)1, __ATOMIC_RELEASE);   // a chain lane of a split plan may be waiting for this slot
     }
+    bool ready(u32 slot) const { return __atomic_load_n(&is_set[slot], __ATOMIC_ACQUIRE) != 0; }
 };
 
 struct SlotRow {
@@ -956,7 +987,7 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
         if (trace) std::fprintf(stderr, "[witness] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    SlotState s{std::vector<u64>(p.n_slots, 0), std::vector<uint8_t>(p.n_slots, 0), p.n, {}};
+    SlotState s{Buf<u64>(p.n_slots, true), Buf<uint8_t>(p.n_slots, true), p.n, {}};
     for (size_t i = 0; i < p.preset_slot.size(); ++i) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
     if (!s.error.empty()) {
         err = s.error;
@@ -1019,6 +1050,8 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     std::vector<u32> slot_level[2] = {std::vector<u32>(p.n_slots, 0), std::vector<u32>(p.n_slots, 0)};
     std::vector<u32> step_level(p.schedule.size(), 0);
     u32 max_level[2] = {0, 0};
+    // what every step reads and writes (slots): [step_io_off[i], + step_n_in[i]) inputs, then outputs up to step_io_off[i + 1]
+    std::vector<u32> step_io, step_io_off(p.schedule.size() + 1, 0), step_n_in(p.schedule.size(), 0);
     for (size_t i = 0; i < p.schedule.size(); ++i) {
         const auto& st = p.schedule[i];
         bool is_late = false;
@@ -1027,6 +1060,8 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             const auto& gg = p.gadgets[st.sub];
             const u32* gs = p.gadget_slots.data() + gg.at;
             for (unsigned k = 0; k < gg.n_in; ++k) is_late |= taint[gs[k]] != 0;
+            step_io.insert(step_io.end(), gs, gs + gg.n_in + gg.n_out);
+            step_n_in[i] = gg.n_in;
             std::vector<u32>& sl = slot_level[is_late];
             for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, sl[gs[k]] + 1);
             for (unsigned k = 0; k < gg.n_out; ++k) {
@@ -1047,6 +1082,9 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
                 err = e.what;
                 return VPBS_ERR_INVALID;
             }
+            for (unsigned w : deps) step_io.push_back(rs[w]);
+            step_io.insert(step_io.end(), written.begin(), written.end());
+            step_n_in[i] = (u32)deps.size();
             std::vector<u32>& sl = slot_level[is_late];
             for (unsigned w : deps) lvl = std::max(lvl, sl[rs[w]] + 1);
             for (u32 slot : written) lvl = std::max(lvl, sl[slot] + 1);   // an earlier writer of the phase: this one compares, after it
@@ -1058,19 +1096,106 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
         step_level[i] = lvl;
         max_level[is_late] = std::max(max_level[is_late], lvl);
         p.step_late[i] = is_late ? 1 : 0;
+        step_io_off[i + 1] = (u32)step_io.size();
+    }
+    // ---- chain lanes (see vpbs_witness_plan::Lane) ----
+    constexpr u32 NONE = 0xFFFFFFFFu, MAX_LANES = 4;
+    const u32 LANE_MIN_ROWS = std::getenv("VPBS_LANE_MIN_ROWS") ? (u32)std::atoi(std::getenv("VPBS_LANE_MIN_ROWS")) : 150;   // 0x7fffffff: no lanes
+    std::vector<int> lane_of(p.schedule.size(), -1);
+    for (int ph = 0; ph < 2; ++ph) {
+        p.lanes[ph].clear();
+        p.lane_steps_sorted[ph].clear();
+        p.lane_pool[ph].reset();
+        auto ins = [&](size_t i) { return std::make_pair(step_io.data() + step_io_off[i], step_io.data() + step_io_off[i] + step_n_in[i]); };
+        auto outs = [&](size_t i) { return std::make_pair(step_io.data() + step_io_off[i] + step_n_in[i], step_io.data() + step_io_off[i + 1]); };
+        // the first writer of every slot inside the phase; candidates = PoseidonGate rows that are the only writers of what they write
+        std::vector<u32> writer(p.n_slots, NONE);
+        std::vector<uint8_t> cand(p.schedule.size(), 0);
+        for (size_t i = 0; i < p.schedule.size(); ++i) {
+            if (p.step_late[i] != ph) continue;
+            const auto& st = p.schedule[i];
+            cand[i] = st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON;
+            for (auto o = outs(i); o.first != o.second; ++o.first) {
+                if (writer[*o.first] == NONE) {
+                    writer[*o.first] = (u32)i;
+                } else {   // a second writer compares with the first: both stay in the levels, where that order is kept
+                    cand[i] = 0;
+                    cand[writer[*o.first]] = 0;
+                }
+            }
+        }
+        // a candidate whose result anything else of the phase reads is not one (and then neither are the rows it reads from): fixpoint
+        std::vector<u32> work;
+        for (size_t i = 0; i < p.schedule.size(); ++i)
+            if (p.step_late[i] == ph && !cand[i]) work.push_back((u32)i);
+        while (!work.empty()) {
+            const u32 i = work.back();
+            work.pop_back();
+            for (auto d = ins(i); d.first != d.second; ++d.first) {
+                const u32 w = writer[*d.first];
+                if (w != NONE && w != i && cand[w]) {
+                    cand[w] = 0;
+                    work.push_back(w);
+                }
+            }
+        }
+        // chains of what is left: a row continues the chain of the row that produced its incoming capacity (wire 8 -- the sponge state a
+        // hash carries from one permutation to the next); a row that starts from constants starts a chain.  Rows that merely READ another
+        // chain's digest (the public-input hash absorbs the key hash) stay in their own chain and wait for it.
+        std::vector<u32> chain_of(p.schedule.size(), NONE), chain_rows;
+        size_t n_cand = 0;
+        for (size_t i = 0; i < p.schedule.size(); ++i) {
+            if (!cand[i]) continue;
+            ++n_cand;
+            const u32 w = step_n_in[i] > 8 ? writer[step_io[step_io_off[i] + 8]] : NONE;
+            if (w != NONE && w != i && cand[w] && chain_of[w] != NONE) {
+                chain_of[i] = chain_of[w];
+            } else {
+                chain_of[i] = (u32)chain_rows.size();
+                chain_rows.push_back(0);
+            }
+            ++chain_rows[chain_of[i]];
+        }
+        if (n_cand < LANE_MIN_ROWS) continue;
+        std::vector<std::pair<u32, u32>> comps;   // (rows, chain)
+        for (u32 c = 0; c < chain_rows.size(); ++c) comps.push_back({chain_rows[c], c});
+        std::sort(comps.begin(), comps.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        const size_t n_lanes = std::min<size_t>(MAX_LANES, comps.size());
+        std::vector<u32> load(n_lanes, 0), lane_of_chain(chain_rows.size(), 0);
+        for (const auto& c : comps) {   // longest chain first, each to the lane with the least work so far
+            const size_t l = std::min_element(load.begin(), load.end()) - load.begin();
+            load[l] += c.first;
+            lane_of_chain[c.second] = (u32)l;
+        }
+        p.lanes[ph].resize(n_lanes);
+        for (size_t i = 0; i < p.schedule.size(); ++i) {
+            if (!cand[i]) continue;
+            lane_of[i] = (int)lane_of_chain[chain_of[i]];
+            p.lane_steps_sorted[ph].push_back((u32)i);
+        }
+        for (u32 i : p.lane_steps_sorted[ph]) {
+            vpbs_witness_plan::Lane& L = p.lanes[ph][lane_of[i]];
+            if (L.wait_off.empty()) L.wait_off.push_back(0);
+            L.steps.push_back(i);
+            for (auto d = ins(i); d.first != d.second; ++d.first) {
+                const u32 w = writer[*d.first];
+                if (w != NONE && lane_of[w] != lane_of[i]) L.wait.push_back(*d.first);   // produced by a level or by another lane
+            }
+            L.wait_off.push_back((u32)L.wait.size());
+        }
     }
     for (int ph = 0; ph < 2; ++ph) {
         vpbs_witness_plan::Phase& P = p.phase[ph];
         // counting sort of the phase's steps by level (schedule order kept inside a level)
         P.level_off.assign(max_level[ph] + 2, 0);
         for (size_t i = 0; i < p.schedule.size(); ++i)
-            if (p.step_late[i] == ph) ++P.level_off[step_level[i] + 1];
+            if (p.step_late[i] == ph && lane_of[i] < 0) ++P.level_off[step_level[i] + 1];
         for (u32 l = 1; l <= max_level[ph] + 1; ++l) P.level_off[l] += P.level_off[l - 1];
         P.order.assign(P.level_off[max_level[ph] + 1], 0);
         {
             std::vector<u32> at(P.level_off.begin(), P.level_off.end() - 1);
             for (size_t i = 0; i < p.schedule.size(); ++i)
-                if (p.step_late[i] == ph) P.order[at[step_level[i]]++] = (u32)i;
+                if (p.step_late[i] == ph && lane_of[i] < 0) P.order[at[step_level[i]]++] = (u32)i;
         }
         // Estimated cost per generator (measured, VPBS_TRACE_WITNESS with one thread, EPYC 9575F): a PoseidonGate row is a whole
         // permutation (1.4 us), most others a handful of field operations (30 ns).  The threads of a wide level take equal COST, not
@@ -1215,6 +1340,36 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     threads = pool->threads;
     std::atomic<bool> failed{false};
     std::vector<std::string> errs(threads);
+    // the chain lanes start now, on threads of their own, and run next to the levels
+    const std::vector<vpbs_witness_plan::Lane>& lanes = p.lanes[ph];
+    LevelPool* lane_pool = nullptr;
+    std::unique_lock<std::mutex> lane_busy;
+    std::vector<std::string> lane_errs(lanes.size() + 1);
+    if (!lanes.empty()) {
+        {
+            std::lock_guard<std::mutex> lk(p.pool_mutex);
+            if (!p.lane_pool[ph]) p.lane_pool[ph].reset(new LevelPool((unsigned)lanes.size() + 1));
+            lane_pool = p.lane_pool[ph].get();
+        }
+        lane_busy = std::unique_lock<std::mutex>(lane_pool->busy, std::try_to_lock);
+        if (!lane_busy.owns_lock()) lane_pool = nullptr;
+    }
+    auto run_lane = [&](unsigned t) {
+        const vpbs_witness_plan::Lane& L = lanes[t - 1];
+        for (size_t k = 0; k < L.steps.size(); ++k) {
+            for (u32 w = L.wait_off[k]; w < L.wait_off[k + 1]; ++w)
+                spin_until([&] { return s.ready(L.wait[w]) || failed.load(std::memory_order_relaxed); });
+            if (failed.load(std::memory_order_relaxed)) return;
+            if (!run_one(p, s, L.steps[k], mc, lane_errs[t])) {
+                failed.store(true);
+                return;
+            }
+        }
+    };
+    if (lane_pool) {
+        lane_pool->begin();
+        lane_pool->start(run_lane);
+    }
     double t_narrow = 0, t_wide = 0;
     u32 n_wide = 0;
     auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1244,18 +1399,37 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
             rc = VPBS_ERR_INVALID;
         }
     }
+    if (rc != VPBS_OK) failed.store(true);   // lets waiting lanes go
+    const double t_lanes = trace ? clock() : 0;
+    if (lane_pool) {
+        lane_pool->finish();
+        lane_pool->end();
+    } else if (rc == VPBS_OK) {   // no threads for the lanes (another run has them): their steps here, in schedule order
+        for (u32 i : p.lane_steps_sorted[ph])
+            if (!run_one(p, s, i, mc, errs[0])) {
+                rc = VPBS_ERR_INVALID;
+                break;
+            }
+    }
+    if (failed.load()) rc = VPBS_ERR_INVALID;
+    if (rc == VPBS_OK && !s.error.empty()) {
+        errs[0] = s.error;
+        rc = VPBS_ERR_INVALID;
+    }
+    if (trace && !lanes.empty()) std::fprintf(stderr, "[witness %s] %zu chain lanes (%zu PoseidonGate rows): %.2f ms after the levels\n", name, lanes.size(),
+                                              p.lane_steps_sorted[ph].size(), clock() - t_lanes);
     const double t_after = trace ? clock() : 0;
     if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
     pool->end();
     if (trace)
         std::fprintf(stderr, "[witness %s] %u threads: %u narrow levels %.2f ms, %u wide levels %.2f ms, wires %.2f ms\n", name, threads,
                      n_levels - n_wide, t_narrow, n_wide, t_wide, clock() - t_after);
-    if (rc != VPBS_OK)
+    if (rc != VPBS_OK) {
         for (const auto& e : errs)
-            if (!e.empty()) {
-                err = e;
-                break;
-            }
+            if (err.empty() && !e.empty()) err = e;
+        for (const auto& e : lane_errs)
+            if (err.empty() && !e.empty()) err = e;
+    }
     if (rc != VPBS_OK && err.empty()) err = s.error.empty() ? "a generator failed" : s.error;
     return rc;
 }
@@ -1276,8 +1450,8 @@ int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late, char* 
     return rc;
 }
 
-int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
-                                vpbs_witness_state** state_out, char* err, size_t err_len) {
+static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out, bool recycled,
+                          vpbs_witness_state** state_out, char* err, size_t err_len) {
     using namespace vpbs;
     if (!plan || !plan->is_split || !preset_val || !wires_out || !state_out) {
         report(err, err_len, "malformed arguments (is the plan split?)");
@@ -1291,7 +1465,8 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
         if (trace) std::fprintf(stderr, "[witness early] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    auto* st = new vpbs_witness_state{SlotState{std::vector<u64>(p.n_slots, 0), std::vector<uint8_t>(p.n_slots, 0), p.n, {}}};
+    // values stay unwritten until a generator sets them (the pages are then first touched by the pool's threads, not zeroed here by one)
+    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
     SlotState& s = st->s;
     lap("state");
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
@@ -1308,7 +1483,7 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
     // the generators, then every wire takes its class's value: the late classes are still zero and are overwritten by run_late
     auto fill = [&](unsigned t, unsigned of) {
         const size_t lo = p.total * t / of, hi = p.total * (t + 1) / of;
-        std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
+        if (!recycled) std::memset(wires_out + lo, 0, (hi - lo) * sizeof(u64));
         const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
         for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.is_set[p.out_slot[i]] ? s.val[p.out_slot[i]] : 0;
     };
@@ -1321,6 +1496,15 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
     lap("generators + wires");
     *state_out = st;
     return VPBS_OK;
+}
+
+int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
+                                vpbs_witness_state** state_out, char* err, size_t err_len) {
+    return run_early_impl(plan, preset_val, threads, wires_out, false, state_out, err, err_len);
+}
+int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
+                                         vpbs_witness_state** state_out, char* err, size_t err_len) {
+    return run_early_impl(plan, preset_val, threads, wires_out, true, state_out, err, err_len);
 }
 
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
