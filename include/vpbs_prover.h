@@ -475,6 +475,8 @@ int vpbs_k_merkle_cap(vpbs_ctx* ctx, const uint64_t* leaves, size_t n_leaves, un
 /* reference negacyclic NTT (/root/reference/src/vtfhe/crypto/poly.rs:27-64), batched, in place on [batch][1<<log_n] */
 int vpbs_k_negacyclic_ntt(vpbs_ctx* ctx, uint64_t* data, unsigned batch, unsigned log_n, int inverse);
 /* the params_{N}.rs tables (ROOTS, INVROOTS, NINV) regenerated per /root/reference/src/ntt/gen_param_file.sage */
+/* shader clock (MHz) of one CU measured over 20 us on the context's stream, after everything queued before it (s_memtime / s_memrealtime) */
+int vpbs_k_clock_probe(vpbs_ctx* ctx, double* mhz_out);
 int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv);
 
 /* ---- native TFHE data path of a step (witness-generation core) ----

@@ -116,6 +116,7 @@ SIGNATURES = {
     "vpbs_ctx_destroy": (None, [_vp]),
     "vpbs_last_error": (C.c_char_p, [_vp]),
     "vpbs_ctx_synchronize": (_i, [_vp]),
+    "vpbs_k_clock_probe": (_i, [_vp, C.POINTER(C.c_double)]),
     "vpbs_ctx_set_gate_lanes": (_i, [_vp, _ui]),
     "vpbs_ctx_stream": (_vp, [_vp]),
     "vpbs_commit_values": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
@@ -950,6 +951,12 @@ class Context:
         self._check(lib().vpbs_keygen(self.h, C.byref(prm), _ptr(s_lwe), _ptr(s_glwe), _ptr(s_to), bsk.ctypes.data if want_bsk else None,
                                       ksk.ctypes.data if want_ksk else None, 0))
         return {"params": prm, "s_lwe": s_lwe, "s_glwe": s_glwe, "s_to": s_to, "bsk": bsk, "ksk": ksk}
+
+    def clock_probe(self):
+        """shader clock in MHz, measured on the context's stream after the work queued so far"""
+        out = C.c_double()
+        self._check(lib().vpbs_k_clock_probe(self.h, C.byref(out)))
+        return out.value
 
     def upload_bg(self, d_dst, host, words):
         """vpbs_device_upload_bg: host (pinned) -> device pointer on the context's upload stream; callable from a second thread while a

@@ -315,6 +315,34 @@ int vpbs_ctx_synchronize(vpbs_ctx* c) {
 }
 void* vpbs_ctx_stream(vpbs_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+// shader clock of one CU over ~20 us: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned x = threadIdx.x + 1;
+    unsigned long long r1 = r0;
+    while (r1 - r0 < 2000) {   // 20 us
+        for (int k = 0; k < 64; ++k) x = x * 2654435761u + 12345u;
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+        out[2] = x;
+    }
+}
+int vpbs_k_clock_probe(vpbs_ctx* c, double* mhz_out) {
+    if (!c || !mhz_out) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        u64* d = c->alloc_words(4);
+        clock_probe_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<unsigned long long*>(d));
+        u64 h[3] = {0, 0, 0};
+        c->d2h_sync(h, d, sizeof h);
+        c->release(d);
+        *mhz_out = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    });
+}
+
 static int commit_any(vpbs_ctx* c, const u64* data, bool on_device, bool is_values, unsigned ncols, unsigned log_n, vpbs_batch** out,
                       u64* cap_out) {
     if (!c || !data || !out) return VPBS_ERR_INVALID;

@@ -1705,7 +1705,6 @@ int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint6
         return VPBS_ERR_INVALID;
     }
     struct RowVars {
-        using F = u64;
         const u64* wires;
         const u64* constants;
         size_t n, row;
