@@ -55,11 +55,18 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #  * every instruction the Poseidon / NTT arithmetic is made of -- v_mad_u64_u32, v_mul_lo/hi_u32, carry adds (v_add_co / v_addc_co),
 #    v_cndmask_b32_e64, 64-bit shifts, three-operand integer VOP3 -- runs at HALF that rate: 4.15-4.26 cycles at 8 waves per SIMD,
 #    4.3-4.5 at 4 waves per SIMD (the occupancy of the leaf-hash kernel), 4.6-5.1 at 2, 5.5-6.75 for a lone wave.
-# valu_frac prices the kernel against the fp32 rate (what the guide calls the vector peak); int_issue_frac against the best rate the
-# integer multiply-add path was seen to sustain (4.2 cycles, 8 waves per SIMD), so it cannot exceed 1 by construction of the ceiling.
+# valu_frac prices the kernel against the fp32 rate at the nominal clock (what the guide calls the vector peak).  int_issue_frac prices it
+# against what the SIMD can issue AT THE CLOCK THE KERNEL REALLY RAN AT: 97 % of the permutation's VALU instructions (v_mad_u64_u32 54 %,
+# v_cndmask_b32_e64 14 %, carry adds / subtracts 27 %: tools/count_poseidon_isa.py) are of the half-rate class -- 16 lanes per cycle, 4
+# cycles per wave64 instruction, of which the microbenchmark reaches 4.15 -- the other 3 % (v_mov) full rate, 2 cycles.  The clock is
+# measured by one wave of every timed launch over its own lifetime (s_memtime / s_memrealtime: vpbs_timing_shader_clock): a loaded MI355X
+# sustains ~2.25 GHz under this kernel, not the 2.4 GHz an idle probe or rocm-smi shows (round 2's first figures assumed 2.39 GHz and a
+# 4.2-cycle ceiling, two errors that cancelled), and ~2.0 GHz for several milliseconds after a pause (tools/experiments/idle_gap.py).
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 LEAF_HASH_INSTR_PER_PERM = 15260  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py; SQ_INSTS_VALU: 15358)
-INT_CYCLES_PER_INSTR, SCLK_HZ = 4.2, 2.39e9   # shader clock under this load: rocm-smi 2.39 GHz; the microbenchmark's waves measured 2.33-2.41
+HALF_RATE_SHARE = 0.97            # of those, the share that issues at 4 cycles per wave64 instruction; the rest at 2
+CEILING_CYCLES_PER_INSTR = HALF_RATE_SHARE * 4.0 + (1 - HALF_RATE_SHARE) * 2.0
+SCLK_FALLBACK_HZ = 2.25e9         # only if the in-kernel measurement is unavailable
 
 
 def leaf_hash_bytes_per_step(log_n=LOG_N):
@@ -568,6 +575,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dominant = {"ms": 0.0, "count": 0}
+    sclk_mhz, sclk_samples = ctxs[0].timing_shader_clock()   # measured by one wave of every leaf-hash launch of the timed region
     for ctx in ctxs:
         d = ctx.timing_report().get("leaf_hash", {"ms": 0.0, "count": 0})
         dominant["ms"] += d["ms"]; dominant["count"] += d["count"]
@@ -663,7 +671,9 @@ def main():
                          "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation, half of them v_mad_u64_u32.  valu_frac = "
                                  "achieved lane-ops/s vs the fp32-FMA rate 256CU*4SIMD*32 lanes*2.4GHz (MI355X_MICROARCH.md); the "
                                  "integer multiply-add / carry / VOP3 instructions of this kernel issue at half that rate on gfx950 "
-                                 "(profiles/r02_microbench_valu2.txt), int_issue_frac = against that measured rate" % LEAF_HASH_INSTR_PER_PERM,
+                                 "(profiles/r02_microbench_valu2.txt): int_issue_frac = the instruction stream at 4 cycles per wave64 "
+                                 "instruction for that class (97 %% of it) and 2 for the rest, at the shader clock measured inside the "
+                                 "kernel, over the measured time" % LEAF_HASH_INSTR_PER_PERM,
                          "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections "
                                            "applied); not re-measured inside this run",
                          "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
@@ -671,8 +681,13 @@ def main():
                          "valu_frac": valu_rate / VALU_PEAK_TLANEOPS,
                          # the same instruction stream priced at the best MEASURED issue rate of integer multiply-add / carry / VOP3
                          # instructions on gfx950 (4.2 cycles per wave64 instruction at 8 waves per SIMD)
-                         "int_issue_frac": (perms * LEAF_HASH_INSTR_PER_PERM / (256 * 4 * 64) * INT_CYCLES_PER_INSTR / SCLK_HZ)
-                                           / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0},
+                         "int_issue_frac": (perms * LEAF_HASH_INSTR_PER_PERM / (256 * 4 * 64) * CEILING_CYCLES_PER_INSTR
+                                            / (sclk_mhz * 1e6 if sclk_mhz > 0 else SCLK_FALLBACK_HZ)) / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
+                         # the shader clock one wave of every timed leaf-hash launch saw over its own lifetime, and what the kernel then
+                         # spends per wave64 VALU instruction and SIMD (ceiling: 3.94)
+                         "shader_clock_mhz_in_kernel": sclk_mhz, "shader_clock_samples": sclk_samples,
+                         "cycles_per_valu_instr_per_simd": (per_step_ms * 1e-3 * sclk_mhz * 1e6 * 256 * 4)
+                                                           / (perms * LEAF_HASH_INSTR_PER_PERM / 64) if sclk_mhz > 0 else None},
             "kernel_ms_one_step": breakdown,
         }
         if world == 1 and n_chains == 1 and args.batch_chains > 1:

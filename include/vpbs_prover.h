@@ -557,6 +557,10 @@ void vpbs_device_free(vpbs_ctx* ctx, uint64_t* d_ptr);
 int vpbs_timing_enable(vpbs_ctx* ctx, int on);
 /* writes a JSON object {"kernel": {"ms": total, "count": launches}, ...} and resets the accumulators */
 int vpbs_timing_report(vpbs_ctx* ctx, char* buf, size_t len);
+/* The shader clock the chip sustained UNDER the dominant kernel while timing was on: one wave of every leaf-hash launch measures its own
+ * lifetime in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime); average over the launches since the last call (at most 1024).
+ * A loaded MI355X runs well below the boost clock an idle probe reads, and the issue-rate figures of bench.py are priced at THIS clock. */
+int vpbs_timing_shader_clock(vpbs_ctx* ctx, double* mhz_out, unsigned* samples_out);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ for gap_ms in (0.0, 1.0, 2.5, 5.0, 10.0, 0.0):
         t_prove += time.perf_counter() - t
         after.append(ctx.clock_probe())
     rep = ctx.timing_report()
+    under_load = ctx.timing_shader_clock()[0]
     ctx.timing_enable(0)
-    print("gap %.1f ms: prove %.3f ms; leaf_hash %.3f coset_lde %.3f merkle_levels %.3f fri_tree %.3f (ms per step); shader clock before / after a proof %.0f / %.0f MHz" % (
-        gap_ms, 1e3 * t_prove / n, *(rep[k]["ms"] / n for k in ("leaf_hash", "coset_lde", "merkle_levels", "fri_tree")), sum(before) / n, sum(after) / n))
+    print("gap %.1f ms: prove %.3f ms; leaf_hash %.3f coset_lde %.3f merkle_levels %.3f fri_tree %.3f (ms per step); shader clock before / after a proof %.0f / %.0f MHz, inside the leaf-hash kernel %.0f MHz" % (
+        gap_ms, 1e3 * t_prove / n, *(rep[k]["ms"] / n for k in ("leaf_hash", "coset_lde", "merkle_levels", "fri_tree")), sum(before) / n, sum(after) / n, under_load))

@@ -200,6 +200,7 @@ SIGNATURES = {
     "vpbs_ntt_params": (_i, [_ui, U64P, U64P, U64P]),
     "vpbs_timing_enable": (_i, [_vp, _i]),
     "vpbs_timing_report": (_i, [_vp, C.c_char_p, _sz]),
+    "vpbs_timing_shader_clock": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_ui)]),
 }
 
 _lib = None
@@ -951,6 +952,12 @@ class Context:
         self._check(lib().vpbs_keygen(self.h, C.byref(prm), _ptr(s_lwe), _ptr(s_glwe), _ptr(s_to), bsk.ctypes.data if want_bsk else None,
                                       ksk.ctypes.data if want_ksk else None, 0))
         return {"params": prm, "s_lwe": s_lwe, "s_glwe": s_glwe, "s_to": s_to, "bsk": bsk, "ksk": ksk}
+
+    def timing_shader_clock(self):
+        """-> (MHz sustained under the leaf-hash kernel while timing was on, launches sampled)"""
+        mhz, n = C.c_double(), C.c_uint()
+        self._check(lib().vpbs_timing_shader_clock(self.h, C.byref(mhz), C.byref(n)))
+        return mhz.value, n.value
 
     def clock_probe(self):
         """shader clock in MHz, measured on the context's stream after the work queued so far"""

@@ -203,7 +203,7 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
         // with 2 / 4 ranges against 10.01 ms with one launch.)
         {
             Timed t(ctx, "leaf_hash");
-            launch_leaf_hash(ctx->stream, b->d_lde, ncols, L, L, b->d_digests);
+            launch_leaf_hash(ctx->stream, b->d_lde, ncols, L, L, b->d_digests, ctx->next_clock_sample());
         }
         {
             Timed t(ctx, "merkle_levels");
@@ -285,6 +285,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->d_clock_samples) c->release(c->d_clock_samples);
     for (auto& kv : c->root_tables) c->release(kv.second);
     for (auto& kv : c->prescale_tables) c->release(kv.second);
     for (auto& kv : c->l0_tables) c->release(kv.second);
@@ -736,6 +737,32 @@ int vpbs_timing_enable(vpbs_ctx* c, int on) {
     c->timing = on != 0;
     c->timing_only = on == 2 ? "leaf_hash" : "";  // 2: dominant kernel only (bench.py timed region)
     return VPBS_OK;
+}
+vpbs::u64* vpbs_ctx::next_clock_sample() {
+    if (!timing) return nullptr;
+    if (!d_clock_samples) {
+        d_clock_samples = alloc_words(2 * CLOCK_SAMPLES);
+        VPBS_HIP(hipMemsetAsync(d_clock_samples, 0, 2 * CLOCK_SAMPLES * sizeof(vpbs::u64), stream));
+    }
+    return d_clock_samples + 2 * (clock_samples++ % CLOCK_SAMPLES);
+}
+int vpbs_timing_shader_clock(vpbs_ctx* c, double* mhz_out, unsigned* samples_out) {
+    if (!c || !mhz_out) return VPBS_ERR_INVALID;
+    return guarded(c, [&] {
+        *mhz_out = 0.0;
+        const unsigned n = std::min(c->clock_samples, vpbs_ctx::CLOCK_SAMPLES);
+        if (samples_out) *samples_out = n;
+        if (!n || !c->d_clock_samples) return;
+        std::vector<u64> h(2 * n);
+        c->d2h_sync(h.data(), c->d_clock_samples, h.size() * sizeof(u64));
+        double cycles = 0, ticks = 0;
+        for (unsigned i = 0; i < n; ++i) {
+            cycles += (double)h[2 * i];
+            ticks += (double)h[2 * i + 1];
+        }
+        if (ticks > 0) *mhz_out = 100.0 * cycles / ticks;
+        c->clock_samples = 0;
+    });
 }
 int vpbs_timing_report(vpbs_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len < 4) return VPBS_ERR_INVALID;

@@ -71,6 +71,10 @@ struct vpbs_ctx {
     unsigned gate_lanes = 3;
 
     // ---- timing ----
+    vpbs::u64* d_clock_samples = nullptr;   // [CLOCK_SAMPLES][2], one pair per leaf-hash launch while timing is on (ring)
+    static constexpr unsigned CLOCK_SAMPLES = 1024;
+    unsigned clock_samples = 0;
+    vpbs::u64* next_clock_sample();         // nullptr unless timing is on
     bool timing = false;
     std::string timing_only;  // when non-empty, only this timer is recorded
     struct Pending {

@@ -15,9 +15,18 @@ namespace {
 constexpr unsigned THREADS = 256;
 
 __global__ void __launch_bounds__(THREADS)
-leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* __restrict__ digests) {
+leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* __restrict__ digests,
+                 u64* __restrict__ clock_sample) {
     const size_t j = blockIdx.x * (size_t)THREADS + threadIdx.x;
     if (j >= n_leaves) return;
+    // timing runs only: one wave in the middle of the grid reports the shader cycles and the 100 MHz ticks of its own lifetime -- the clock the
+    // chip really sustains under this kernel (a light probe kernel reads the boost clock instead)
+    const bool sample = clock_sample != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    u64 c0 = 0, r0 = 0;
+    if (sample) {
+        r0 = __builtin_amdgcn_s_memrealtime();
+        c0 = __builtin_amdgcn_s_memtime();
+    }
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = 0;
@@ -46,6 +55,10 @@ leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, s
     ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * j);
     d[0] = make_ulonglong2(s[0], s[1]);
     d[1] = make_ulonglong2(s[2], s[3]);
+    if (sample) {
+        clock_sample[0] = __builtin_amdgcn_s_memtime() - c0;
+        clock_sample[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -202,9 +215,9 @@ pow_search_kernel(PowState st, unsigned pos, unsigned pow_bits, u64 start, u64 c
 }
 }  // namespace
 
-void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests) {
+void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests, u64* clock_sample) {
     hipLaunchKernelGGL(leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
-                       col_stride, digests);
+                       col_stride, digests, clock_sample);
 }
 // below this many independent permutations a launch is latency-bound and the 16-lane form wins (measured)
 static size_t wide_threshold() {

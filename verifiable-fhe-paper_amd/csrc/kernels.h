@@ -106,7 +106,8 @@ void launch_blind_rotate_step(hipStream_t s, const u64* acc_in, const u64* masks
 
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
-void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests);
+// clock_sample: nullptr, or two device words that receive {shader cycles, 100 MHz ticks} over the lifetime of one wave of the launch
+void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests, u64* clock_sample = nullptr);
 // FRI round leaves: leaf l = flatten(values[arity*l .. arity*(l+1))) of ext values stored SoA [2][m]
 void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests);
 // parents[i] = two_to_one(children[2i], children[2i+1])
