@@ -1,0 +1,35 @@
+#!/bin/bash
+# ThreadSanitizer run of the library's HOST code that runs on several threads: the split witness plans (level pools, chain lanes, concurrent
+# runs of one plan) through the CPU tests that exercise them.  Only witness.hip is instrumented (the rest of the host code is single-threaded
+# per context); device code is compiled without sanitizer.
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT=/tmp/vpbs_tsan; mkdir -p $OUT
+cd "$ROOT/verifiable-fhe-paper_amd/csrc"
+for f in ntt hash fri permutation quotient gates tfhe keygen comm_rccl api prover verifier; do
+  /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
+done
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=thread -Wno-unused-function -Wno-pass-failed -c witness.hip -o $OUT/witness.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -o $OUT/libvpbs_hip.so $OUT/*.o
+RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.tsan-x86_64.so" | head -1)
+cp "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so" $OUT/real.so
+cp $OUT/libvpbs_hip.so "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so"
+trap 'cp $OUT/real.so "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so"' EXIT
+cd "$ROOT"
+# lanes forced on for every circuit size; the reports of the uninstrumented interpreter are not ours
+VPBS_LANE_MIN_ROWS=1 TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path=$OUT/report" LD_PRELOAD=$RT \
+  python -m pytest tests/test_step_circuit_cpu.py tests/test_cyclic_cpu.py -k "split_plan or ivc_chain or tampered" -x -q -m "not gpu" -p no:cacheprovider
+python3 - "$OUT" <<'PY'
+import glob, sys
+n = ours = 0
+for f in glob.glob(sys.argv[1] + "/report.*"):
+    for block in open(f, errors="replace").read().split("=================="):
+        if "WARNING: ThreadSanitizer" in block:
+            n += 1
+            if "libvpbs_hip" in block:
+                ours += 1
+                print(block[:3000])
+print("%d reports, %d with frames in libvpbs_hip.so (the others: the uninstrumented oracle's OpenMP loops)" % (n, ours))
+sys.exit(1 if ours else 0)
+PY

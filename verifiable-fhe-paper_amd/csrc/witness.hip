@@ -625,12 +625,17 @@ struct SlotState {
     std::string error;
     void set(u32 slot, u64 v, u32 pos) {
         if (v >= gl::P) v -= gl::P;
-        if (is_set[slot] && val[slot] != v) {
-            static std::mutex report_mutex;   // the late phase of a split plan runs generators on several threads
-            std::lock_guard<std::mutex> lock(report_mutex);
-            if (error.empty())
-                error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
-                        ") was set twice with different values";
+        if (is_set[slot]) {
+            // a second writer only compares: in a split plan another thread may be reading this value right now (a generator of the same
+            // level, a chain lane), so it is not stored again
+            if (val[slot] != v) {
+                static std::mutex report_mutex;   // the phases of a split plan run generators on several threads
+                std::lock_guard<std::mutex> lock(report_mutex);
+                if (error.empty())
+                    error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
+                            ") was set twice with different values";
+            }
+            return;
         }
         val[slot] = v;
         __atomic_store_n(&is_set[slot], (uint8_t)1, __ATOMIC_RELEASE);   // a chain lane of a split plan may be waiting for this slot
