@@ -358,6 +358,14 @@ int main(int argc, char** argv) {
     }
     REQUIRE(vpbs_hash_chain(items.data(), steps, ggsw_len, b_pis.data() + 2 * kn + 1, nullptr) == 1, "bootstrapping-key hash chain");
     REQUIRE(vpbs_hash_chain(masks.data(), steps, 1, b_pis.data() + 2 * kn + 5, nullptr) == 1, "LWE hash chain");
+    if (steps == total) {   // the whole of verify_pbs in one call of the library
+        vpbs_verify_pbs_inputs vp{};
+        vp.circuit = &v;
+        vp.N = N; vp.K = K; vp.n_lwe = n_lwe; vp.ggsw_len = ggsw_len;
+        vp.testv = testv.data(); vp.out_ct = b_pis.data() + kn + 1; vp.ct = ct.data(); vp.bsk = bsk.data(); vp.ksk = ksk.data();
+        char why[256];
+        REQUIRE(vpbs_verify_pbs(&vp, bytes.data(), (size_t)n_bytes, why, sizeof why) == 1, "verify_pbs: %s", why);
+    }
     long decrypted = -1;
     if (steps == total) {
         std::vector<u64> m_bar(N);

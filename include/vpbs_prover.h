@@ -462,6 +462,25 @@ long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const uint8_t* byt
 int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][cap] */, const uint64_t* openings,
                      const uint64_t* fri);
 
+/* = verify_pbs (/root/reference/src/vtfhe/ivc_based_vpbs.rs:388-489): the statement of ONE verifiable PBS checked on the last proof of its IVC
+ * chain, in the reference's order -- claimed test vector, counter = n + 2, output ciphertext = the proof's accumulator, cd.verify(proof)
+ * (full vpbs_verify_step), check_cyclic_proof_verifier_data (the trailing public inputs are this circuit's digest and cap), the hash chain
+ * over [dummy GGSW, bsk_0 .. bsk_{n-1}, ksk] and the one over [ct[n], ct[0] .. ct[n-1], 0].  Host only.
+ * circuit: shape, cap, digest and gates of the cyclic step circuit as for vpbs_verify_step (its public_inputs fields are ignored; the
+ * public inputs come out of the proof bytes: acc_init [K N] | counter | accumulator [K N] | key hash [4] | LWE hash [4] | digest [4] | cap).
+ * Returns 1 = accepted, 0 = rejected (why: the first failing check), < 0 = malformed arguments. */
+typedef struct {
+    const vpbs_verify_inputs* circuit;
+    unsigned N, K, n_lwe;
+    size_t ggsw_len;          /* K ELL K N: words of one flattened GGSW */
+    const uint64_t* testv;    /* [N] */
+    const uint64_t* out_ct;   /* [K][N] the bootstrapped ciphertext the caller holds, or NULL to skip that comparison */
+    const uint64_t* ct;       /* [n_lwe + 1] the LWE input */
+    const uint64_t* bsk;      /* [n_lwe][ggsw_len] NTT domain, Ggsw::flatten order */
+    const uint64_t* ksk;      /* [ggsw_len] */
+} vpbs_verify_pbs_inputs;
+int vpbs_verify_pbs(const vpbs_verify_pbs_inputs* in, const uint8_t* proof_bytes, size_t len, char* why, size_t why_len);
+
 /* ---- kernel-level entry points (host buffers; used by parity tests and by callers outside the prover) ---- */
 int vpbs_k_poseidon_batch(vpbs_ctx* ctx, uint64_t* states /* [n][12] in place */, size_t n);
 int vpbs_k_hash_rows(vpbs_ctx* ctx, const uint64_t* rows /* [n][len] */, size_t n, unsigned len, uint64_t* out /* [n][4] */);

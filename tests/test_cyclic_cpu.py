@@ -165,3 +165,28 @@ def test_ivc_chain_on_the_cpu():
     wrong = pis.copy()
     wrong[kn + 2] ^= np.uint64(1)
     assert not C.verify(proof, wrong)
+    # the same statement through the product's one-call verify_pbs (vpbs_verify_pbs) on the serialised proof, and each of its checks failing
+    blob = step_oracle.to_bytes(proof, proof["ncols"], C.nconst, pis, log_n)
+    out_ct = pis[kn + 1:2 * kn + 1]
+    bsk_flat = np.stack(keys[3])
+
+    def vp(blob=blob, testv=testv, ct=ct, bsk=bsk_flat, ksk=keys[4], out_ct=out_ct, cap=C.cap, digest=C.vk[:4]):
+        return api.verify_pbs(blob, cap, proof["ncols"], digest, log_n, C.nconst, 80, C.ps, N, K, testv, ct, bsk, ksk, out_ct=out_ct)
+
+    assert vp() == (True, "")
+    assert vp(out_ct=None)[0]
+    other = lambda a, i=0: np.concatenate([np.asarray(a, np.uint64).reshape(-1)[:i], [np.uint64(int(np.asarray(a, np.uint64).reshape(-1)[i]) ^ 1)],
+                                           np.asarray(a, np.uint64).reshape(-1)[i + 1:]]).astype(np.uint64)
+    assert vp(testv=other(testv, 3)) == (False, "claimed test vector differs from testv")
+    assert vp(out_ct=other(out_ct, 5)) == (False, "the output ciphertext is not the proof's accumulator")
+    assert vp(ksk=other(keys[4], 7)) == (False, "the key hash chain does not match")
+    assert vp(bsk=other(bsk_flat, 9).reshape(bsk_flat.shape)) == (False, "the key hash chain does not match")
+    assert vp(ct=other(ct, 1)) == (False, "the LWE hash chain does not match")
+    bad = bytearray(blob)
+    bad[8 * 200] ^= 1                                                  # a word of the wires cap / openings
+    assert vp(blob=bytes(bad))[0] is False
+    assert vp(blob=blob[:-8])[1].startswith("the bytes are not a proof")
+    assert vp(cap=D.cap, digest=D.vk[:4])[0] is False                  # the dummy circuit's verifier data: the proof does not verify there
+    # an earlier proof of the chain: valid, but its counter is not n + 2
+    p1, pis1 = proofs[1]
+    assert vp(blob=step_oracle.to_bytes(p1, p1["ncols"], C.nconst, pis1, log_n), out_ct=None) == (False, "the counter is not n + 2")

@@ -186,6 +186,10 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
     back, back_pis = api.step_proof_from_bytes(blob, cyc.ncols, log_n, cyc.d.n_constants)
     assert cyc.verify(back, back_pis), "the final proof does not verify"
     t_verify = time.perf_counter() - t
+    if steps == total:   # ... the same through the one-call form of the library (vpbs_verify_pbs), which insists on counter = n + 2
+        ok, why = api.verify_pbs(blob, cyc.cap, cyc.ncols, cyc.vk[:4], log_n, cyc.d.n_constants, 80, cyc.d.gates, N, K, testv, ct, keys["bsk"],
+                                 keys["ksk"], out_ct=back_pis[kn + 1:2 * kn + 1])
+        assert ok, why
     assert (back_pis[:kn] == acc_init.reshape(-1)).all() and int(back_pis[kn]) == steps          # test vector, number of steps
     assert (back_pis[-68:] == cyc.vk).all()                                                      # check_cyclic_proof_verifier_data
     bsk_items = np.stack([zero_ggsw] + [keys["bsk"][x] for x in range(min(steps - 1, n_lwe))] + ([keys["ksk"]] if steps == total else []))

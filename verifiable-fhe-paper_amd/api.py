@@ -85,6 +85,11 @@ class VerifyInputsC(C.Structure):
                 ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
 
 
+class VerifyPbsInputsC(C.Structure):
+    _fields_ = [("circuit", C.POINTER(VerifyInputsC)), ("N", C.c_uint), ("K", C.c_uint), ("n_lwe", C.c_uint), ("ggsw_len", C.c_size_t),
+                ("testv", U64P), ("out_ct", U64P), ("ct", U64P), ("bsk", U64P), ("ksk", U64P)]
+
+
 class TfheParamsC(C.Structure):
     _fields_ = [("log_N", C.c_uint), ("K", C.c_uint), ("ELL", C.c_uint), ("LOGB", C.c_uint)]
 
@@ -177,6 +182,7 @@ SIGNATURES = {
     "vpbs_witness_device_free": (None, [C.c_void_p]),
     "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
+    "vpbs_verify_pbs": (_i, [C.POINTER(VerifyPbsInputsC), C.POINTER(C.c_uint8), _sz, C.c_char_p, _sz]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
     "vpbs_host_alloc": (_vp, [_sz]),
@@ -575,6 +581,37 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     if rc < 0:
         raise VpbsError("vpbs_verify_step: malformed arguments (%d)" % rc)
     return rc == 1
+
+
+def verify_pbs(blob, cs_cap, ncols, circuit_digest, log_n, n_constants, n_routed, gates, N, K, testv, ct, bsk, ksk, out_ct=None, num_challenges=2,
+               quotient_degree_factor=8, rate_bits=3, cap_height=4):
+    """vpbs_verify_pbs = the reference's verify_pbs (ivc_based_vpbs.rs:388-489) on the serialised LAST proof of an IVC chain:
+    -> (accepted, reason of the first failing check).  bsk: [n][ggsw_len] (NTT domain, flattened), ksk: [ggsw_len], ct: [n + 1]."""
+    v = VerifyInputsC()
+    v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
+    v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
+    v.num_challenges = num_challenges
+    cap = _u64(cs_cap)
+    v.constants_sigmas_cap = _ptr(cap)
+    for i in range(4):
+        v.circuit_digest[i] = int(circuit_digest[i])
+    v.n_constants, v.n_routed, v.quotient_degree_factor = n_constants, n_routed, quotient_degree_factor
+    v.gates, v.n_gates, v.num_selectors = gates.arr, gates.n, gates.num_selectors
+    p = VerifyPbsInputsC()
+    p.circuit = C.pointer(v)
+    ct_a, tv, ks = _u64(ct).reshape(-1), _u64(testv).reshape(-1), _u64(ksk).reshape(-1)
+    bs = _u64(bsk).reshape(-1) if bsk is not None and len(bsk) else None
+    oc = _u64(out_ct).reshape(-1) if out_ct is not None else None
+    p.N, p.K, p.n_lwe, p.ggsw_len = N, K, ct_a.size - 1, ks.size
+    p.testv, p.ct, p.ksk = _ptr(tv), _ptr(ct_a), _ptr(ks)
+    p.bsk = _ptr(bs) if bs is not None else None
+    p.out_ct = _ptr(oc) if oc is not None else None
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+    why = C.create_string_buffer(256)
+    rc = lib().vpbs_verify_pbs(C.byref(p), buf, len(blob), why, 256)
+    if rc < 0:
+        raise VpbsError("vpbs_verify_pbs: " + why.value.decode())
+    return rc == 1, why.value.decode()
 
 
 def verify_step_fri_only(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, rate_bits=3, cap_height=4):

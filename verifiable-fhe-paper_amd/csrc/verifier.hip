@@ -341,3 +341,86 @@ extern "C" long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const u
     return (long)n_pi;
 }
 
+
+// verify_pbs of the reference (/root/reference/src/vtfhe/ivc_based_vpbs.rs:388-489), check for check and in its order: the claimed test
+// vector, the step counter, the output ciphertext, cd.verify(proof) (vpbs_verify_step, full check), check_cyclic_proof_verifier_data (the
+// proof's last public inputs are the circuit's own digest and constants/sigmas cap), verify_hash_output over the bootstrapping / key
+// switching keys and over the LWE masks.  The reference panics at the first failing check; here the verdict is returned and `why` names it.
+extern "C" int vpbs_verify_pbs(const vpbs_verify_pbs_inputs* in, const uint8_t* proof_bytes, size_t len, char* why, size_t why_len) {
+    auto say = [&](const char* m) {
+        if (why && why_len) {
+            std::strncpy(why, m, why_len - 1);
+            why[why_len - 1] = 0;
+        }
+    };
+    say("");
+    if (!in || !in->circuit || !proof_bytes || !in->testv || !in->ct || !in->ksk || (in->n_lwe && !in->bsk) || in->N == 0 || in->K == 0) {
+        say("malformed arguments");
+        return VPBS_ERR_INVALID;
+    }
+    const vpbs_verify_inputs& c = *in->circuit;
+    const size_t kn = (size_t)in->K * in->N, cap_words = (size_t)4 << c.cap_height;
+    const size_t n_pi = 2 * kn + 1 + 8 + 4 + cap_words;   // acc_init | counter | acc | two hashes | verifier data (digest, cap)
+    std::vector<uint64_t> caps(3 * cap_words),
+        openings(2 * ((size_t)c.n_constants_sigmas + c.n_wires + c.n_zs_partial_products + c.n_quotient + c.num_challenges)), fri(len / 8 + 8), pis(n_pi);
+    if (vpbs_step_proof_from_bytes(&c, proof_bytes, len, caps.data(), openings.data(), fri.data(), pis.data(), n_pi) != (long)n_pi) {
+        say("the bytes are not a proof of this circuit (shape, canonical field elements, number of public inputs)");
+        return 0;
+    }
+    // claimed test vector: K - 1 zero polynomials, then testv (:422-433)
+    for (size_t i = 0; i < kn - in->N; ++i)
+        if (pis[i] != 0) {
+            say("claimed test vector: the mask polynomials are not zero");
+            return 0;
+        }
+    if (std::memcmp(pis.data() + kn - in->N, in->testv, 8 * (size_t)in->N) != 0) {
+        say("claimed test vector differs from testv");
+        return 0;
+    }
+    if (pis[kn] != (uint64_t)in->n_lwe + 2) {   // :435-438
+        say("the counter is not n + 2");
+        return 0;
+    }
+    if (in->out_ct && std::memcmp(pis.data() + kn + 1, in->out_ct, 8 * kn) != 0) {   // :440-442
+        say("the output ciphertext is not the proof's accumulator");
+        return 0;
+    }
+    vpbs_verify_inputs v = c;   // cd.verify (:444-448)
+    v.public_inputs = pis.data();
+    v.n_public_inputs = n_pi;
+    v.fri_only = 0;
+    const int ok = vpbs_verify_step(&v, caps.data(), openings.data(), fri.data());
+    if (ok < 0) {
+        say("malformed circuit description");
+        return ok;
+    }
+    if (ok != 1) {
+        say("the proof does not verify");
+        return 0;
+    }
+    // check_cyclic_proof_verifier_data (:449-453): the verifier data the chain was run with is this circuit's
+    const uint64_t* vk = pis.data() + n_pi - 4 - cap_words;
+    if (std::memcmp(vk, c.circuit_digest, 32) != 0 || !c.constants_sigmas_cap || std::memcmp(vk + 4, c.constants_sigmas_cap, 8 * cap_words) != 0) {
+        say("the proof carries another circuit's verifier data");
+        return 0;
+    }
+    // verify_hash_output (:454-481): dummy GGSW, the n bootstrapping keys, the key-switching key / ct[n], the n masks, zero
+    const size_t steps = (size_t)in->n_lwe + 2, g = in->ggsw_len;
+    {
+        std::vector<uint64_t> items(steps * g, 0);
+        if (in->n_lwe) std::memcpy(items.data() + g, in->bsk, 8 * (size_t)in->n_lwe * g);
+        std::memcpy(items.data() + (steps - 1) * g, in->ksk, 8 * g);
+        if (vpbs_hash_chain(items.data(), steps, g, pis.data() + 2 * kn + 1, nullptr) != 1) {
+            say("the key hash chain does not match");
+            return 0;
+        }
+    }
+    std::vector<uint64_t> masks(steps, 0);
+    masks[0] = in->ct[in->n_lwe];
+    for (unsigned i = 0; i < in->n_lwe; ++i) masks[i + 1] = in->ct[i];
+    if (vpbs_hash_chain(masks.data(), steps, 1, pis.data() + 2 * kn + 5, nullptr) != 1) {
+        say("the LWE hash chain does not match");
+        return 0;
+    }
+    return 1;
+}
