@@ -462,6 +462,42 @@ long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const uint8_t* byt
 int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][cap] */, const uint64_t* openings,
                      const uint64_t* fri);
 
+/* ---- one verifiable PBS as one call: the IVC chain of verified_pbs (/root/reference/src/vtfhe/ivc_based_vpbs.rs:159-386) ----
+ * The cyclic step circuit and its dummy circuit arrive as data (what CircuitBuilder::build leaves behind: vpbs_circuit + the PartialWitness
+ * targets in the order verified_pbs sets them + the public-input targets).  vpbs_ivc_create commits their constants / sigmas, derives the
+ * verifier data, compiles and splits the witness plans and allocates the wire matrices; vpbs_ivc_prove_pbs then runs
+ *     base proof of the dummy circuit -> n + 2 step proofs of the cyclic circuit, each taking the previous proof as a witness
+ * with the early witness phase of the next step and its upload running on two host threads beside the proof of the current one, and
+ * returns the LAST proof serialised (ProofWithPublicInputs bytes): the input of vpbs_verify_pbs.  One chain at a time per vpbs_ivc; several
+ * vpbs_ivc objects (one context each) run side by side.
+ *   preset_pos of the cyclic circuit: previous proof's words [proof_words] | its public inputs [n_pi] | condition | GGSW [ggsw_len] | mask |
+ *                                     own verifier data [4 + cap] | dummy verifier data [4 + cap]      (wire positions column * n + row)
+ *   preset_pos of the dummy circuit : its public inputs [n_pi];  n_pi = 2 K N + 9 + 4 + cap words
+ *   bsk [n_lwe][ggsw_len] NTT domain (vpbs_keygen's layout), ksk [ggsw_len], ct [n_lwe + 1], testv [N]: host arrays
+ *   steps: 0 or n_lwe + 2 = the whole chain; fewer = a prefix (tests)
+ * vpbs_ivc_prove_pbs returns the number of proof bytes, or < 0 (err: which step failed and why). */
+typedef struct {
+    const vpbs_circuit* circuit;
+    const uint32_t* preset_pos;
+    size_t n_preset;
+    const uint32_t* pi_pos;     /* public-input targets (cyclic circuit; ignored for the dummy circuit may be NULL there) */
+    size_t n_pi;
+    size_t proof_words;         /* cyclic circuit: words of one proof in target order (caps, openings, FRI); 0 for the dummy circuit */
+} vpbs_ivc_circuit;
+typedef struct vpbs_ivc vpbs_ivc;
+typedef struct {
+    double seconds;             /* base proof + steps, wall clock */
+    unsigned steps;
+    double base_proof_ms, late_witness_ms, late_rows_upload_ms, prove_step_ms, early_witness_ms;   /* per step, except the base proof */
+} vpbs_ivc_timing;
+int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_ivc_circuit* dummy, unsigned N, unsigned K, size_t ggsw_len,
+                    vpbs_ivc** out, char* err, size_t err_len);
+void vpbs_ivc_free(vpbs_ivc* ivc);
+/* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */
+int vpbs_ivc_verifier_data(const vpbs_ivc* ivc, uint64_t* cyclic_vk, uint64_t* dummy_vk);
+long vpbs_ivc_prove_pbs(vpbs_ivc* ivc, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,
+                        unsigned steps, uint8_t* proof_out, size_t capacity, vpbs_ivc_timing* timing, char* err, size_t err_len);
+
 /* = verify_pbs (/root/reference/src/vtfhe/ivc_based_vpbs.rs:388-489): the statement of ONE verifiable PBS checked on the last proof of its IVC
  * chain, in the reference's order -- claimed test vector, counter = n + 2, output ciphertext = the proof's accumulator, cd.verify(proof)
  * (full vpbs_verify_step), check_cyclic_proof_verifier_data (the trailing public inputs are this circuit's digest and cap), the hash chain

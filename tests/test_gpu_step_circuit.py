@@ -383,6 +383,37 @@ def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
     print(r.stdout.strip())
 
 
+def test_ivc_driver_through_the_python_binding():
+    """vpbs_ivc_create checks the PartialWitness / public-input layout against the parameters; vpbs_ivc_prove_pbs twice on one object (two
+    PBS with the same keys, different ciphertexts), each proof accepted by vpbs_verify_pbs for its own ciphertext only"""
+    from vpbs_amd import circuit_file
+    N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 6, 13
+    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    c = vpbs_amd.Context(0, log_n_max=16)
+    g = K * ELL * K * N
+    with pytest.raises(api.VpbsError, match="not a cyclic step circuit"):
+        api.Ivc(c, cyc, dum, N, K, g + 1)
+    with pytest.raises(api.VpbsError, match="not a cyclic step circuit"):
+        api.Ivc(c, dum, cyc, N, K, g)
+    ivc = api.Ivc(c, cyc, dum, N, K, g)
+    keys = c.keygen(N, K, ELL, LOGB, n_lwe, 77, 4.99027217501041e-8, 1.17021618159313e-5)
+    testv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
+    blob, t = ivc.prove_pbs(testv, ct, keys["bsk"], keys["ksk"])
+    vk, _ = ivc.verifier_data()
+    ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates, N, K,
+                             testv, ct, keys["bsk"], keys["ksk"])
+    assert ok, why
+    assert t["steps"] == n_lwe + 2
+    ct2 = api.lwe_encrypt(keys["params"], keys["s_lwe"], 0, nonce=1)
+    blob2, _ = ivc.prove_pbs(testv, ct2, keys["bsk"], keys["ksk"])
+    vp = lambda b, c_: api.verify_pbs(b, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates,
+                                      N, K, testv, c_, keys["bsk"], keys["ksk"])
+    assert vp(blob2, ct2)[0] and vp(blob2, ct) == (False, "the LWE hash chain does not match") and not vp(blob, ct2)[0]
+    ivc.free()
+    c.close()
+
+
 def test_ivc_chain_tool_two_chains_side_by_side():
     """VPBS_IVC_CHAINS=2: two independent PBS (own seed, message, context and witness plans) chained concurrently on the one GPU; each
     final proof passes verify_pbs and decrypts to its own message"""

@@ -208,6 +208,48 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
             "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
 
 
+def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start):
+    """the same PBS through the library's own driver (vpbs_ivc_prove_pbs: the loop of run_chain in C++, csrc/ivc.hip) -> result dict"""
+    total, kn = n_lwe + 2, K * N
+    t_keys = time.perf_counter()
+    keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, seed, 4.99027217501041e-8, 1.17021618159313e-5)
+    testv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * message % P)
+    t_keys = time.perf_counter() - t_keys
+    vk, _ = ivc.verifier_data()
+    ncols = [d.n_constants + 80, 135, 20, 16]
+    torch.cuda.synchronize()
+    start.wait()
+    blob, t = ivc.prove_pbs(testv, ct, keys["bsk"], keys["ksk"], steps)
+    # verify_pbs (:388-489) on the LAST proof only
+    tv = time.perf_counter()
+    back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, d.n_constants)
+    assert api.verify_step(back, vk[4:].reshape(-1, 4), ncols, vk[:4], back_pis, log_n, n_constants=d.n_constants, n_routed=80, gates=d.gates), \
+        "the final proof does not verify"
+    t_verify = time.perf_counter() - tv
+    acc_init = np.concatenate([np.zeros((K - 1) * N, np.uint64), testv])
+    assert (back_pis[:kn] == acc_init).all() and int(back_pis[kn]) == steps and (back_pis[-68:] == vk).all()
+    accs = ctx.pbs_accumulator_chain(acc_init.reshape(K, N), ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
+    assert (back_pis[kn + 1:2 * kn + 1] == accs[steps - 1].reshape(-1)).all()                    # the accumulator the native chain reaches
+    decrypted = None
+    if steps == total:
+        ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), ncols, vk[:4], log_n, d.n_constants, 80, d.gates, N, K, testv, ct, keys["bsk"],
+                                 keys["ksk"], out_ct=back_pis[kn + 1:2 * kn + 1])
+        assert ok, why
+        m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
+        decrypted = round(int(m_bar[0]) / delta) % 4
+        assert decrypted == message, (decrypted, message)
+    else:   # a prefix of the chain: the hash chains against the prefix of the keys
+        zero = np.zeros(K * ELL * K * N, np.uint64)
+        bsk_items = np.stack([zero] + [keys["bsk"][x] for x in range(min(steps - 1, n_lwe))])
+        lwe_items = np.array([[int(ct[n_lwe])]] + [[int(ct[x])] for x in range(min(steps - 1, n_lwe))], np.uint64)
+        assert api.hash_chain(bsk_items, back_pis[2 * kn + 1:2 * kn + 5])[1] and api.hash_chain(lwe_items, back_pis[2 * kn + 5:2 * kn + 9])[1]
+    return {"seconds": t["seconds"], "split": {"witness_late_phase_host": t["late_witness_ms"], "late_rows_to_device": t["late_rows_upload_ms"],
+                                               "prove_step": t["prove_step_ms"], "base_proof_once": t["base_proof_ms"],
+                                               "witness_early_phase_on_a_second_thread": t["early_witness_ms"]},
+            "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
+
+
 def main():
     import threading
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -237,6 +279,8 @@ def main():
             dist.init_process_group(backend)
         dist.barrier()
     cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    # one GPU: the chain runs inside the library (vpbs_ivc_prove_pbs); several GPUs, or VPBS_IVC_DRIVER=python: the same loop spelled out here
+    native_driver = world == 1 and os.environ.get("VPBS_IVC_DRIVER", "library") != "python"
     chains = []
     for ci in range(n_chains):   # every chain has its own context (stream, device memory), circuit commitments and witness plans
         ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
@@ -246,7 +290,11 @@ def main():
             native = dist.get_backend() == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
             comm = sharding.make_comm_rccl(ctx, stage_words=stage_words) if native else \
                 sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
-        chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))
+        if native_driver:
+            cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
+            chains.append((ctx, api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N), cd))
+        else:
+            chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))
     t_setup = time.perf_counter() - t_setup
     message = int(os.environ.get("VPBS_PBS_MESSAGE", "1"))
     start = threading.Barrier(n_chains)
@@ -256,7 +304,10 @@ def main():
         try:
             torch.cuda.set_device(device)
             ctx, cyc, dum = chains[ci]
-            results[ci] = run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start, dist)
+            if native_driver:
+                results[ci] = run_chain_native(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start)
+            else:
+                results[ci] = run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start, dist)
         except BaseException as e:                           # noqa: BLE001
             errors.append(e)
             start.abort()
@@ -274,7 +325,8 @@ def main():
     ctx, cyc, dum = chains[0]
     r0 = results[0]
     seconds = max(r["seconds"] for r in results)
-    n_pi = len(cyc.d.pi_pos)
+    desc = dum if native_driver else cyc.d
+    n_pi = len(desc.pi_pos)
     if rank != 0:
         if native:
             sharding.free_comm_rccl(comm)
@@ -287,8 +339,9 @@ def main():
         "what": "%s as an IVC chain (ivc_based_vpbs.rs verified_pbs): %d of the %d step proofs of the CYCLIC step circuit (step logic + "
                 "in-circuit verifier of the previous proof: %d gate rows, degree 2^%d, %d public inputs) at N=%d, k=1, ELL=4, LOGB=5, n=%d on "
                 "%d x MI355X; the last proof alone is the vPBS proof" % ("one vPBS" if n_chains == 1 else "%d independent vPBS side by side, each" %
-                                                                         n_chains, steps, total, cyc.d.used_rows, log_n, n_pi, N, n_lwe, world),
-        "chains": n_chains, "step_proofs": steps, "seconds": seconds,
+                                                                         n_chains, steps, total, desc.meta.get("used_rows", 0), log_n, n_pi, N, n_lwe, world),
+        "chains": n_chains, "driver": "vpbs_ivc_prove_pbs (csrc/ivc.hip)" if native_driver else "the loop of tools/prove_ivc.py over the C ABI",
+        "step_proofs": steps, "seconds": seconds,
         "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
         "vpbs_proofs_per_s": (n_chains / seconds) if steps == total else None, "ms_per_step": 1e3 * seconds / steps,
         "ms_per_step_split": r0["split"], "ms_per_step_split_other_chains": [r["split"] for r in results[1:]],
@@ -299,6 +352,9 @@ def main():
                   "counter = number of steps, the circuit's own verifier data, the native accumulator and both native chain hashes"
                   + ("; the bootstrapped ciphertext decrypts to the message" if steps == total else "")}))
     for ctx, cyc, dum in chains:
+        if native_driver:
+            cyc.free()
+            continue
         cyc.plan.free()
         dum.plan.free()
         cyc.cs.free()

@@ -90,6 +90,16 @@ class VerifyPbsInputsC(C.Structure):
                 ("testv", U64P), ("out_ct", U64P), ("ct", U64P), ("bsk", U64P), ("ksk", U64P)]
 
 
+class IvcCircuitC(C.Structure):
+    _fields_ = [("circuit", C.POINTER(CircuitC)), ("preset_pos", U32P), ("n_preset", C.c_size_t), ("pi_pos", U32P), ("n_pi", C.c_size_t),
+                ("proof_words", C.c_size_t)]
+
+
+class IvcTimingC(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("steps", C.c_uint), ("base_proof_ms", C.c_double), ("late_witness_ms", C.c_double),
+                ("late_rows_upload_ms", C.c_double), ("prove_step_ms", C.c_double), ("early_witness_ms", C.c_double)]
+
+
 class TfheParamsC(C.Structure):
     _fields_ = [("log_N", C.c_uint), ("K", C.c_uint), ("ELL", C.c_uint), ("LOGB", C.c_uint)]
 
@@ -182,6 +192,10 @@ SIGNATURES = {
     "vpbs_witness_device_free": (None, [C.c_void_p]),
     "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
+    "vpbs_ivc_create": (_i, [_vp, C.POINTER(IvcCircuitC), C.POINTER(IvcCircuitC), _ui, _ui, _sz, C.POINTER(_vp), C.c_char_p, _sz]),
+    "vpbs_ivc_free": (None, [_vp]),
+    "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
+    "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
     "vpbs_verify_pbs": (_i, [C.POINTER(VerifyPbsInputsC), C.POINTER(C.c_uint8), _sz, C.c_char_p, _sz]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "vpbs_pbs_accumulator_chain": (_i, [_vp, C.POINTER(TfheParamsC), _ui, U64P, U64P, U64P, U64P, U64P]),
@@ -581,6 +595,53 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     if rc < 0:
         raise VpbsError("vpbs_verify_step: malformed arguments (%d)" % rc)
     return rc == 1
+
+
+class Ivc:
+    """vpbs_ivc: one verifiable PBS as one call -- the IVC chain of verified_pbs (ivc_based_vpbs.rs:159-386) driven inside the library.
+    cyclic / dummy: circuit_file.CircuitDescription of the exported cyclic step circuit and its dummy circuit."""
+
+    def __init__(self, ctx, cyclic, dummy, N, K, ggsw_len):
+        self.ctx, self._keep = ctx, []
+
+        def side(d, proof_words):
+            c = IvcCircuitC()
+            pre = np.ascontiguousarray(d.preset_flat, dtype=np.uint32)
+            pi = np.ascontiguousarray(d.pi_flat, dtype=np.uint32)
+            self._keep += [pre, pi, d]
+            c.circuit = C.pointer(d.circuit.c)
+            c.preset_pos, c.n_preset = pre.ctypes.data_as(U32P), pre.size
+            c.pi_pos, c.n_pi = pi.ctypes.data_as(U32P), pi.size
+            c.proof_words = proof_words
+            return c
+        cy, du = side(cyclic, cyclic.meta["proof_words"]), side(dummy, 0)
+        self.h, err = C.c_void_p(), C.create_string_buffer(512)
+        if lib().vpbs_ivc_create(ctx.h, C.byref(cy), C.byref(du), N, K, ggsw_len, C.byref(self.h), err, 512):
+            raise VpbsError("vpbs_ivc_create: " + err.value.decode())
+        self.vk_words = 4 + (4 << 4)
+        self.max_bytes = 8 * (cyclic.meta["proof_words"] + len(cyclic.pi_pos)) + (1 << 16)
+
+    def verifier_data(self):
+        """-> (cyclic circuit: digest [4] + cap, dummy circuit: the same)"""
+        a, b = np.zeros(self.vk_words, np.uint64), np.zeros(self.vk_words, np.uint64)
+        lib().vpbs_ivc_verifier_data(self.h, _ptr(a), _ptr(b))
+        return a, b
+
+    def prove_pbs(self, testv, ct, bsk, ksk, steps=0):
+        """-> (ProofWithPublicInputs bytes of the LAST proof of the chain, timing dict)"""
+        tv, c, ks = _u64(testv).reshape(-1), _u64(ct).reshape(-1), _u64(ksk).reshape(-1)
+        bs = _u64(bsk).reshape(-1) if c.size > 1 else None
+        buf, t, err = (C.c_uint8 * self.max_bytes)(), IvcTimingC(), C.create_string_buffer(512)
+        n = lib().vpbs_ivc_prove_pbs(self.h, _ptr(tv), _ptr(c), _ptr(bs) if bs is not None else None, _ptr(ks), c.size - 1, steps, buf,
+                                     self.max_bytes, C.byref(t), err, 512)
+        if n < 0:
+            raise VpbsError("vpbs_ivc_prove_pbs: " + err.value.decode())
+        return bytes(buf[:n]), {f: getattr(t, f) for f, _ in IvcTimingC._fields_}
+
+    def free(self):
+        if self.h:
+            lib().vpbs_ivc_free(self.h)
+            self.h = None
 
 
 def verify_pbs(blob, cs_cap, ncols, circuit_digest, log_n, n_constants, n_routed, gates, N, K, testv, ct, bsk, ksk, out_ct=None, num_challenges=2,

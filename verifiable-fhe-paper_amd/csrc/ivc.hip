@@ -1,0 +1,362 @@
+// One verifiable PBS as the reference produces it, as ONE call: the IVC chain of `verified_pbs`
+// (/root/reference/src/vtfhe/ivc_based_vpbs.rs:159-386: build the cyclic step circuit, prove the base case, then n + 2 steps each verifying its
+// predecessor in circuit) driven inside the library.  Host code only, written against the library's own C ABI (include/vpbs_prover.h) -- what
+// examples/prove_ivc.cpp did by hand: nothing here reaches below that boundary.
+//   create : constants/sigmas commitments and verifier data of the cyclic and the dummy circuit (CircuitBuilder::build's prover data),
+//            compiled witness plans, the split of the cyclic plan (the previous proof's words are the late part), three pinned + three
+//            device wire matrices
+//   prove  : base proof of the dummy circuit (cyclic_base_proof, :292-299), then per step
+//              thread E  vpbs_witness_plan_run_early   everything that does not need the previous proof; yields the step's public inputs
+//              thread U  vpbs_device_upload_bg         that matrix to the device while the previous step is being proven
+//              caller    vpbs_witness_plan_run_late -> vpbs_device_upload_rows -> vpbs_prove_step
+//            and the last proof serialised (ProofWithPublicInputs::to_bytes)
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vpbs_prover.h"
+
+namespace {
+using u64 = uint64_t;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Side {   // one circuit on the context
+    vpbs_ctx* ctx = nullptr;
+    unsigned log_n = 0, n_wires = 0, n_routed = 0, n_const_cols = 0, num_selectors = 0;
+    size_t n = 0;
+    std::vector<vpbs_gate> gates;
+    std::vector<uint32_t> pi_pos;
+    size_t n_preset = 0;
+    std::vector<u64> cs_cap, vk;   // vk: circuit digest [4] then the constants/sigmas cap
+    u64* d_sigma = nullptr;
+    vpbs_batch* cs = nullptr;
+    vpbs_witness_plan* plan = nullptr;
+
+    int init(vpbs_ctx* c, const vpbs_ivc_circuit& d, unsigned cap_height, std::string& err) {
+        ctx = c;
+        const vpbs_circuit& k = *d.circuit;
+        log_n = k.log_n; n_wires = k.n_wires; n_routed = k.n_routed; n_const_cols = k.n_constants_cols; num_selectors = k.num_selectors;
+        n = (size_t)1 << log_n;
+        gates.assign(k.gates, k.gates + k.n_gates);
+        pi_pos.assign(d.pi_pos, d.pi_pos + d.n_pi);
+        n_preset = d.n_preset;
+        std::vector<u64> csv((size_t)(n_const_cols + n_routed) * n);
+        std::memcpy(csv.data(), k.constants, 8 * (size_t)n_const_cols * n);
+        u64* sigma = csv.data() + (size_t)n_const_cols * n;
+        if (vpbs_sigma_values(&k, sigma) != 0) return err = "sigma polynomials: malformed copy constraints", VPBS_ERR_INVALID;
+        const size_t cap_words = (size_t)4 << cap_height;
+        cs_cap.resize(cap_words);
+        int rc = vpbs_commit_values(ctx, csv.data(), n_const_cols + n_routed, log_n, &cs, cs_cap.data());
+        if (rc != 0) return err = std::string("constants / sigmas commitment: ") + vpbs_last_error(ctx), rc;
+        std::vector<u64> dig_in(cs_cap);
+        dig_in.push_back(log_n);
+        vk.assign(4, 0);
+        vpbs_hash_no_pad(dig_in.data(), dig_in.size(), vk.data());   // circuit digest: hash_no_pad(cap || degree bits)
+        vk.insert(vk.end(), cs_cap.begin(), cs_cap.end());
+        rc = vpbs_device_alloc(ctx, (size_t)n_routed * n, &d_sigma);
+        if (rc == 0) rc = vpbs_device_upload(ctx, d_sigma, sigma, (size_t)n_routed * n);
+        if (rc != 0) return err = std::string("sigma values to the device: ") + vpbs_last_error(ctx), rc;
+        char e[256] = {0};
+        rc = vpbs_witness_plan_create(&k, d.preset_pos, d.n_preset, &plan, e, sizeof e);
+        if (rc != 0) return err = std::string("witness plan: ") + e, rc;
+        return VPBS_OK;
+    }
+    void step_inputs(vpbs_step_inputs& in, const u64* wires, bool on_device, const u64* pis) const {
+        in = vpbs_step_inputs{};
+        in.log_n = log_n; in.n_wires = n_wires; in.n_zs_partial_products = 20; in.n_quotient = 16; in.num_challenges = 2;
+        in.inputs_on_device = on_device ? 1 : 0;
+        in.wires_values = wires;
+        in.constants_sigmas = cs;
+        for (int i = 0; i < 4; ++i) in.circuit_digest[i] = vk[i];
+        in.public_inputs = pis; in.n_public_inputs = pi_pos.size();
+        in.forced_pow = VPBS_POW_ANY;
+        in.sigmas_values = d_sigma; in.sigmas_on_device = 1;
+        in.n_routed = n_routed; in.quotient_degree_factor = 8; in.n_constants = n_const_cols;
+        in.gates = gates.data(); in.n_gates = (unsigned)gates.size(); in.num_selectors = num_selectors;
+    }
+    void release() {
+        if (plan) vpbs_witness_plan_free(plan);
+        if (cs) vpbs_batch_free(cs);
+        if (d_sigma) vpbs_device_free(ctx, d_sigma);
+        plan = nullptr; cs = nullptr; d_sigma = nullptr;
+    }
+};
+}  // namespace
+
+struct vpbs_ivc {
+    vpbs_ctx* ctx = nullptr;
+    Side cyc, dum;
+    unsigned N = 0, K = 0;
+    size_t proof_words = 0, ggsw_len = 0, kn = 0, n_pi = 0, wire_words = 0;
+    size_t late_rows[2] = {0, 0};
+    static constexpr int NBUF = 3;
+    u64 *bufs[NBUF] = {nullptr, nullptr, nullptr}, *d_bufs[NBUF] = {nullptr, nullptr, nullptr}, *base_wires = nullptr;
+    bool filled[NBUF] = {false, false, false};
+    std::string err;
+    ~vpbs_ivc() {
+        for (auto b : bufs)
+            if (b) vpbs_host_free(b);
+        for (auto d : d_bufs)
+            if (d) vpbs_device_free(ctx, d);
+        if (base_wires) vpbs_host_free(base_wires);
+        cyc.release();
+        dum.release();
+    }
+};
+
+extern "C" {
+
+int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_ivc_circuit* dummy, unsigned N, unsigned K, size_t ggsw_len,
+                    vpbs_ivc** out, char* err, size_t err_len) {
+    auto say = [&](const std::string& m) {
+        if (err && err_len) {
+            std::strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+    };
+    say("");
+    if (!ctx || !cyclic || !dummy || !out || !cyclic->circuit || !dummy->circuit || !cyclic->preset_pos || !dummy->preset_pos || !cyclic->pi_pos ||
+        N == 0 || K == 0) {
+        say("malformed arguments");
+        return VPBS_ERR_INVALID;
+    }
+    const size_t kn = (size_t)K * N, cap_words = (size_t)4 << 4, n_pi = 2 * kn + 9 + 4 + cap_words;
+    // the PartialWitness of a step, in the order the reference sets it (:314-330): previous proof | its public inputs | condition | GGSW |
+    // mask | own verifier data | dummy verifier data; the dummy circuit's PartialWitness is its public inputs
+    if (cyclic->n_pi != n_pi || dummy->n_preset != n_pi || cyclic->n_preset != cyclic->proof_words + n_pi + 1 + ggsw_len + 1 + 2 * (4 + cap_words)) {
+        say("the circuits are not a cyclic step circuit and its dummy circuit for these parameters (public inputs / PartialWitness layout)");
+        return VPBS_ERR_INVALID;
+    }
+    auto* v = new vpbs_ivc();
+    v->ctx = ctx; v->N = N; v->K = K; v->ggsw_len = ggsw_len; v->kn = kn; v->n_pi = n_pi; v->proof_words = cyclic->proof_words;
+    int rc = v->cyc.init(ctx, *cyclic, 4, v->err);
+    if (rc == 0) rc = v->dum.init(ctx, *dummy, 4, v->err);
+    if (rc == 0) {
+        std::vector<uint8_t> late(cyclic->n_preset, 0);
+        std::fill(late.begin(), late.begin() + cyclic->proof_words, 1);
+        char e[256] = {0};
+        rc = vpbs_witness_plan_split(v->cyc.plan, late.data(), e, sizeof e);
+        if (rc != 0) v->err = std::string("split: ") + e;
+        if (rc == 0) rc = vpbs_witness_plan_late_rows(v->cyc.plan, v->late_rows);
+    }
+    if (rc == 0) {
+        v->wire_words = (size_t)v->cyc.n_wires * v->cyc.n;
+        for (auto& b : v->bufs)
+            if (!(b = static_cast<u64*>(vpbs_host_alloc(8 * v->wire_words)))) rc = VPBS_ERR_OOM;
+        for (auto& d : v->d_bufs)
+            if (rc == 0) rc = vpbs_device_alloc(ctx, v->wire_words, &d);
+        if (!(v->base_wires = static_cast<u64*>(vpbs_host_alloc(8 * (size_t)v->dum.n_wires * v->dum.n)))) rc = VPBS_ERR_OOM;
+        if (rc != 0) v->err = "wire matrices: out of (pinned or device) memory";
+    }
+    if (rc != 0) {
+        say(v->err);
+        delete v;
+        return rc;
+    }
+    *out = v;
+    return VPBS_OK;
+}
+
+void vpbs_ivc_free(vpbs_ivc* v) { delete v; }
+
+int vpbs_ivc_verifier_data(const vpbs_ivc* v, uint64_t* cyclic_vk, uint64_t* dummy_vk) {
+    if (!v) return VPBS_ERR_INVALID;
+    if (cyclic_vk) std::memcpy(cyclic_vk, v->cyc.vk.data(), 8 * v->cyc.vk.size());
+    if (dummy_vk) std::memcpy(dummy_vk, v->dum.vk.data(), 8 * v->dum.vk.size());
+    return VPBS_OK;
+}
+
+long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,
+                        unsigned steps, uint8_t* proof_out, size_t capacity, vpbs_ivc_timing* timing, char* err, size_t err_len) {
+    auto say = [&](const std::string& m) {
+        if (err && err_len) {
+            std::strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+    };
+    say("");
+    if (!v || !testv || !ct || !ksk || (n_lwe && !bsk) || !proof_out) {
+        say("malformed arguments");
+        return VPBS_ERR_INVALID;
+    }
+    const unsigned total = n_lwe + 2;
+    if (steps == 0 || steps > total) steps = total;
+    Side &cyc = v->cyc, &dum = v->dum;
+    vpbs_ctx* ctx = v->ctx;
+    const size_t kn = v->kn, n_pi = v->n_pi, proof_words = v->proof_words, ggsw_len = v->ggsw_len;
+    const std::vector<u64> zero_ggsw(ggsw_len, 0);
+    auto ggsw_of = [&](unsigned s) { return s == 0 ? zero_ggsw.data() : (s <= n_lwe ? bsk + (size_t)(s - 1) * ggsw_len : ksk); };
+    auto mask_of = [&](unsigned s) { return s == 0 ? ct[n_lwe] : (s <= n_lwe ? ct[s - 1] : (u64)0); };
+    // public inputs of the base proof: acc_init = (0, .., 0, testv) | counter 0 | accumulator 0 | hashes 0 | the cyclic circuit's verifier data
+    std::vector<u64> base_pis(n_pi, 0);
+    std::memcpy(base_pis.data() + kn - v->N, testv, 8 * (size_t)v->N);
+    std::memcpy(base_pis.data() + n_pi - cyc.vk.size(), cyc.vk.data(), 8 * cyc.vk.size());
+
+    struct Ready {
+        int buf;
+        vpbs_witness_state* state;
+        std::vector<u64> values, pis;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> free_bufs{0, 1, 2};
+    std::deque<Ready> generated, ready;   // early thread -> uploader -> caller
+    std::atomic<bool> failed{false};
+    std::string thread_err;
+    double t_early = 0;
+    auto fail = [&](const std::string& m) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (thread_err.empty()) thread_err = m;
+        }
+        failed = true;
+        cv.notify_all();
+    };
+    std::thread early([&] {
+        std::vector<u64> pis_prev(base_pis);
+        char e2[256];
+        for (unsigned s = 0; s < steps && !failed; ++s) {
+            int b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !free_bufs.empty() || failed; });
+                if (failed) return;
+                b = free_bufs.front();
+                free_bufs.pop_front();
+            }
+            const double t = now();
+            Ready r{b, nullptr, std::vector<u64>(proof_words, 0), {}};
+            r.values.reserve(cyc.n_preset);
+            r.values.insert(r.values.end(), pis_prev.begin(), pis_prev.end());
+            r.values.push_back(s == 0 ? 0 : 1);   // condition: false only in the base step
+            r.values.insert(r.values.end(), ggsw_of(s), ggsw_of(s) + ggsw_len);
+            r.values.push_back(mask_of(s));
+            r.values.insert(r.values.end(), cyc.vk.begin(), cyc.vk.end());
+            r.values.insert(r.values.end(), dum.vk.begin(), dum.vk.end());
+            // a matrix this plan has filled before only gets its value-carrying positions rewritten
+            const auto run_early = v->filled[b] ? vpbs_witness_plan_run_early_recycled : vpbs_witness_plan_run_early;
+            if (run_early(cyc.plan, r.values.data(), 0, v->bufs[b], &r.state, e2, sizeof e2) != 0)
+                return fail("early witness phase of step " + std::to_string(s) + ": " + e2);
+            v->filled[b] = true;
+            r.pis.resize(n_pi);
+            for (size_t i = 0; i < n_pi; ++i) r.pis[i] = v->bufs[b][cyc.pi_pos[i]];   // public inputs never depend on the inner proof's words
+            pis_prev = r.pis;
+            t_early += now() - t;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                generated.push_back(std::move(r));
+            }
+            cv.notify_all();
+        }
+    });
+    std::thread uploader([&] {
+        for (unsigned s = 0; s < steps; ++s) {
+            Ready r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !generated.empty() || failed; });
+                if (failed) return;
+                r = std::move(generated.front());
+                generated.pop_front();
+            }
+            if (vpbs_device_upload_bg(ctx, v->d_bufs[r.buf], v->bufs[r.buf], v->wire_words) != 0)
+                return fail("upload of the early wires of step " + std::to_string(s));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready.push_back(std::move(r));
+            }
+            cv.notify_all();
+        }
+    });
+    auto stop = [&](const std::string& m, int rc) {
+        fail(m);
+        early.join();
+        uploader.join();
+        for (auto& r : generated)
+            if (r.state) vpbs_witness_state_free(r.state);
+        for (auto& r : ready)
+            if (r.state) vpbs_witness_state_free(r.state);
+        std::string first;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            first = thread_err;
+        }
+        say(first);
+        return (long)rc;
+    };
+
+    // cyclic_base_proof (:292-299): a proof of the dummy circuit carrying the initial accumulator and the cyclic verifier data
+    const double t0 = now();
+    char e[256] = {0};
+    vpbs_step_inputs in;
+    vpbs_step_sizes sz{};
+    if (vpbs_witness_plan_run(dum.plan, base_pis.data(), 0, v->base_wires, e, sizeof e) != 0) return stop(std::string("dummy witness: ") + e, VPBS_ERR_INVALID);
+    dum.step_inputs(in, v->base_wires, false, base_pis.data());
+    if (vpbs_step_sizes_get(ctx, &in, &sz) != 0 || 3 * sz.cap_words + sz.openings_words + sz.fri_words != proof_words)
+        return stop("the proof of this shape does not have the number of words the cyclic circuit expects", VPBS_ERR_INVALID);
+    std::vector<u64> proof(proof_words), pis;
+    u64 *caps = proof.data(), *openings = caps + 3 * sz.cap_words, *fri = openings + sz.openings_words;   // the flat order of the proof targets
+    int rc = vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr);
+    if (rc != 0) return stop(std::string("base proof: ") + vpbs_last_error(ctx), rc);
+    const double t_base = now() - t0;
+    double t_late = 0, t_rows = 0, t_prove = 0;
+    for (unsigned s = 0; s < steps; ++s) {
+        Ready r;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || failed; });
+            if (failed) {
+                lk.unlock();
+                return stop("", VPBS_ERR_INVALID);
+            }
+            r = std::move(ready.front());
+            ready.pop_front();
+        }
+        double t = now();
+        std::copy(proof.begin(), proof.end(), r.values.begin());
+        rc = vpbs_witness_plan_run_late(cyc.plan, r.state, r.values.data(), v->bufs[r.buf], e, sizeof e);   // consumes the state
+        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+        t_late += now() - t;
+        t = now();
+        rc = vpbs_device_upload_rows(ctx, v->d_bufs[r.buf], v->bufs[r.buf], cyc.n_wires, cyc.n, v->late_rows[0], v->late_rows[1]);
+        if (rc != 0) return stop(std::string("upload of the late rows: ") + vpbs_last_error(ctx), rc);
+        t_rows += now() - t;
+        t = now();
+        pis = std::move(r.pis);
+        cyc.step_inputs(in, v->d_bufs[r.buf], true, pis.data());
+        rc = vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr);
+        if (rc != 0) return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        t_prove += now() - t;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_bufs.push_back(r.buf);
+        }
+        cv.notify_all();
+    }
+    early.join();
+    uploader.join();
+    const double seconds = now() - t0;
+    const long n_bytes = vpbs_step_proof_to_bytes(ctx, &in, cyc.n_const_cols, caps, openings, fri, proof_out, capacity);
+    if (n_bytes <= 0) {
+        say("the output buffer is too small for the proof");
+        return VPBS_ERR_INVALID;
+    }
+    if (timing) {
+        timing->seconds = seconds;
+        timing->steps = steps;
+        timing->base_proof_ms = 1e3 * t_base;
+        timing->late_witness_ms = 1e3 * t_late / steps;
+        timing->late_rows_upload_ms = 1e3 * t_rows / steps;
+        timing->prove_step_ms = 1e3 * t_prove / steps;
+        timing->early_witness_ms = 1e3 * t_early / steps;
+    }
+    return n_bytes;
+}
+}  // extern "C"
