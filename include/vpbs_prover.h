@@ -264,7 +264,11 @@ void vpbs_witness_plan_free(vpbs_witness_plan* plan);
  *   split     : late[i] != 0 marks preset i (plan order) as late; every generator that reads a late value, directly or not, becomes late
  *   run_early : the early presets (the late entries of preset_val are ignored), the early generators, the whole wire matrix (late wires 0)
  *   run_late  : the late presets, the late generators, the late wires written into the same matrix; consumes the state
- * run_early + run_late produce exactly the matrix of vpbs_witness_plan_run. */
+ * run_early + run_late produce exactly the matrix of vpbs_witness_plan_run.
+ * Threads: each phase runs on a pool of host threads that belongs to the plan (created at the phase's first run -- `threads`, 0 = default
+ * by host size, or VPBS_EARLY_THREADS / VPBS_LATE_THREADS -- and kept until the plan is freed): generators are grouped by dependency level,
+ * wide levels are shared, long hash chains run as lanes beside them.  run_early and run_late of one plan may run concurrently with each
+ * other; a second concurrent run of the SAME phase finds the pool taken and runs on its calling thread alone. */
 typedef struct vpbs_witness_state vpbs_witness_state;
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,

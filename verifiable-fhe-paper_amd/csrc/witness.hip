@@ -1317,9 +1317,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     if (threads > 1) {
         {
             std::lock_guard<std::mutex> lk(p.pool_mutex);
-            if (!p.pool[ph] || p.pool[ph]->threads != threads) {
-                if (!p.pool[ph] || std::unique_lock<std::mutex>(p.pool[ph]->busy, std::try_to_lock).owns_lock()) p.pool[ph].reset(new LevelPool(threads));
-            }
+            if (!p.pool[ph]) p.pool[ph].reset(new LevelPool(threads));   // the phase's pool keeps the size of its first run
             pool = p.pool[ph].get();
         }
         busy = std::unique_lock<std::mutex>(pool->busy, std::try_to_lock);
