@@ -324,11 +324,17 @@ bool check_circuit(const vpbs_circuit* c) {
 // union-find), slots -> wires (full_witness) in parallel.  The step circuit is proven n + 2 times per PBS with the same plan.
 }  // namespace
 
-// spin briefly (the other side answers within microseconds), then give the core away
+// spin for up to 150 us (the other side usually answers within microseconds), then sleep in short naps: a pool's workers wait
+// through the stretches of a phase that only the calling thread or the chain lanes work on, and a container's CPU quota is spent by
+// spinning threads as by working ones
 template <class Pred> void spin_until(Pred ready) {
+    std::chrono::steady_clock::time_point t0;
     for (unsigned i = 0; !ready(); ++i) {
-        if (i < 2000) __builtin_ia32_pause();
-        else std::this_thread::yield();
+        __builtin_ia32_pause();
+        if ((i & 63) != 63) continue;
+        const auto t = std::chrono::steady_clock::now();
+        if (i == 63) t0 = t;
+        else if (t - t0 > std::chrono::microseconds(150)) std::this_thread::sleep_for(std::chrono::microseconds(20));   // a long wait: nap
     }
 }
 
@@ -1437,9 +1443,24 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     return rc;
 }
 
+// CPUs this process may really use: the hardware threads, capped by the scheduler affinity and by the cgroup's CPU quota (a container on a
+// 256-thread host is often given 16)
+unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64] = {0};
+        unsigned long period = 0;
+        if (std::fscanf(f, "%63s %lu", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+            n = std::min(n, (unsigned)std::max(1ul, std::strtoul(q, nullptr, 10) / period));
+        std::fclose(f);
+    }
+    return n;
+}
+
 unsigned default_phase_threads() {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return std::max(1u, std::max(std::min(8u, hw / 2), std::min(12u, hw / 8)));   // 4 of 8, 8 of 16..64, 12 of 96 and more
+    return std::max(1u, std::min(12u, usable_cpus() * 3 / 4));   // 12 on the GPU box (256 hardware threads, 16 by its cgroup), 6 of 8
 }
 }  // namespace
 }  // namespace vpbs
