@@ -1,6 +1,7 @@
 """The reference's CYCLIC step circuit (ivc_based_vpbs.rs:159-386: each step proof verifies the previous one in circuit) on the CPU: the
 circuit description of tests/cyclic_circuit.py, witnesses by the PRODUCT's generators (host), proofs by the CPU oracle's prover, every
 proof accepted by the product's host verifier.  The GPU twin is tests/test_gpu_step_circuit.py::test_ivc_chain_*."""
+import os
 import random
 
 import numpy as np
@@ -126,6 +127,21 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     return proofs
 
 
+GOLDEN_CHAIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ivc_chain_n8.json")
+
+
+def n8_chain_inputs():
+    """keys, ciphertext and test vector of the N = 8, n = 1 chain both the CPU test (oracle prover) and the GPU test (vpbs_ivc_prove_pbs) run"""
+    N, K, ELL, LOGB, n_lwe = 8, 2, 4, 5, 1
+    rng = np.random.default_rng(5)
+    ring = T.Ring(3)
+    s_to, s_lwe, s_glwe, bsk, ksk = T.pbs_setup(ring, rng, n_lwe, K, ELL, LOGB)
+    delta = T.get_delta(4)
+    testv = T.get_testv(ring, 2, delta)
+    ct = T.lwe_encrypt(rng, s_lwe, delta % P)
+    return ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct
+
+
 def test_ivc_chain_on_the_cpu():
     """BASELINE config 1 (N = 8 ring, one blind-rotation step, CPU prover): the cyclic circuit fits degree 2^13; base proof + first step +
     CMUX + key switch, every proof verifying its predecessor in circuit; the last proof alone carries the statement (verify_pbs, :388-489):
@@ -137,12 +153,7 @@ def test_ivc_chain_on_the_cpu():
         cc.CyclicStepCircuit(api, N, K, ELL, LOGB, n_lwe, orc.negacyclic_params(3), 12)
     dm = cc.DummyCircuit(api, log_n, cy.shape.n_pi)
     C, D = OracleProver(cy.built), OracleProver(dm.built)
-    rng = np.random.default_rng(5)
-    ring = T.Ring(3)
-    s_to, s_lwe, s_glwe, bsk, ksk = T.pbs_setup(ring, rng, n_lwe, K, ELL, LOGB)
-    delta = T.get_delta(4)
-    testv = T.get_testv(ring, 2, delta)
-    ct = T.lwe_encrypt(rng, s_lwe, delta % P)
+    ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
     acc_init = [[0] * N for _ in range(K - 1)] + [testv]
     keys = (s_to, s_lwe, s_glwe, [T.flatten_ggsw(g) for g in bsk], T.flatten_ggsw(ksk))
     proofs = run_chain(cy, dm, C, D, C.prove, D.prove, keys, ct, acc_init)
@@ -175,6 +186,17 @@ def test_ivc_chain_on_the_cpu():
 
     assert vp() == (True, "")
     assert vp(out_ct=None)[0]
+    # the chain is deterministic (smallest proof-of-work nonce): its last proof is frozen, and the GPU chain of the same inputs
+    # (test_gpu_step_circuit.py::test_ivc_chain_bit_identical_to_the_cpu_oracle_chain) must produce the same bytes
+    import hashlib
+    import json
+    digest = hashlib.sha256(blob).hexdigest()
+    if os.environ.get("VPBS_RECORD_GOLDEN"):
+        json.dump({"what": "sha256 of ProofWithPublicInputs::to_bytes of the LAST proof of the N = 8, n = 1 IVC chain (3 step proofs of the cyclic "
+                           "circuit after the base proof; inputs: tests/test_cyclic_cpu.py::n8_chain_inputs), proven by the CPU oracle",
+                   "bytes": len(blob), "sha256": digest}, open(GOLDEN_CHAIN, "w"), indent=1)
+    frozen = json.load(open(GOLDEN_CHAIN))
+    assert (len(blob), digest) == (frozen["bytes"], frozen["sha256"])
     other = lambda a, i=0: np.concatenate([np.asarray(a, np.uint64).reshape(-1)[:i], [np.uint64(int(np.asarray(a, np.uint64).reshape(-1)[i]) ^ 1)],
                                            np.asarray(a, np.uint64).reshape(-1)[i + 1:]]).astype(np.uint64)
     assert vp(testv=other(testv, 3)) == (False, "claimed test vector differs from testv")

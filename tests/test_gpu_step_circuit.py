@@ -383,6 +383,31 @@ def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
     print(r.stdout.strip())
 
 
+def test_ivc_chain_bit_identical_to_the_cpu_oracle_chain():
+    """The N = 8, n = 1 chain of tests/test_cyclic_cpu.py (same keys, ciphertext, test vector) through vpbs_ivc_prove_pbs on the GPU: the
+    serialised last proof has the bytes the CPU oracle's chain froze in tests/golden/ivc_chain_n8.json -- three chained proofs of the cyclic
+    circuit, witness generation by the split plans, every prover stage and the transcript, bit for bit."""
+    import hashlib
+    import json
+    from test_cyclic_cpu import GOLDEN_CHAIN, n8_chain_inputs
+    from vpbs_amd import circuit_file
+    N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
+    ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
+    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    c = vpbs_amd.Context(0, log_n_max=16)
+    ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
+    bsk_flat, ksk_flat = np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk)
+    blob, _ = ivc.prove_pbs(testv, ct, bsk_flat, ksk_flat)
+    frozen = json.load(open(GOLDEN_CHAIN))
+    assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"])
+    vk, _ = ivc.verifier_data()
+    ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates, N, K,
+                             testv, ct, bsk_flat, ksk_flat)
+    assert ok, why
+    ivc.free()
+    c.close()
+
+
 def test_ivc_driver_through_the_python_binding():
     """vpbs_ivc_create checks the PartialWitness / public-input layout against the parameters; vpbs_ivc_prove_pbs twice on one object (two
     PBS with the same keys, different ciphertexts), each proof accepted by vpbs_verify_pbs for its own ciphertext only"""
