@@ -747,3 +747,47 @@ def test_native_rccl_collectives_single_rank(ctx):
     assert all((got[k] == want_proof[k]).all() for k in ("caps", "openings", "fri"))
     cs.free()
     sharding.free_comm_rccl(comm)
+
+
+@pytest.mark.gpu
+def test_host_to_device_helpers():
+    """vpbs_device_upload_bg (the context's upload stream, callable beside a running proof) and vpbs_device_upload_rows (a row range of every
+    column of a column-major matrix): the device ends up with exactly the bytes asked for, nothing else touched"""
+    import threading
+    import torch
+    c = vpbs_amd.Context(0, log_n_max=12)
+    cols, n = 7, 1 << 10
+    rng = np.random.default_rng(3)
+    host = torch.from_numpy(rng.integers(0, 1 << 62, size=(cols, n), dtype=np.int64)).pin_memory()
+    dev = torch.full((cols, n), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    c.upload_rows(dev.data_ptr(), host.data_ptr(), cols, n, 100, 357)
+    got = dev.cpu()
+    assert (got[:, 100:357] == host[:, 100:357]).all() and (got[:, :100] == -1).all() and (got[:, 357:] == -1).all()
+    c.upload_rows(dev.data_ptr(), host.data_ptr(), cols, n, 5, 5)                      # empty range: nothing moves
+    assert (dev.cpu() == got).all()
+    with pytest.raises(api.VpbsError):
+        c.upload_rows(dev.data_ptr(), host.data_ptr(), cols, n, 10, n + 1)
+    # the background upload from a second host thread while the context proves
+    inputs = synth.step_inputs(10)
+    cs = c.commit_values(inputs["constants_sigmas"])
+    si = c.make_step_inputs(10, inputs["wires"], inputs["zs_partial_products"], inputs["quotient"], cs, np.array([1, 2, 3, 4], np.uint64),
+                            synth.field_elements(9, 8))
+    want = c.prove_step(si)
+    errors = []
+
+    def uploader():
+        try:
+            for _ in range(20):
+                c.upload_bg(dev.data_ptr(), host.data_ptr(), cols * n)
+        except Exception as e:                                                        # noqa: BLE001
+            errors.append(e)
+    t = threading.Thread(target=uploader)
+    t.start()
+    for _ in range(5):
+        p = c.prove_step(si)
+        assert all((p[k] == want[k]).all() for k in ("caps", "openings", "fri"))
+    t.join()
+    assert not errors and (dev.cpu() == host).all()
+    cs.free()
+    c.close()
