@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     char err[256];
     vpbs_ivc* ivc = nullptr;
     const vpbs_ivc_circuit c_desc = cyc.describe(proof_words), d_desc = dum.describe(0);
-    REQUIRE(vpbs_ivc_create(ctx, &c_desc, &d_desc, N, K, ggsw_len, &ivc, err, sizeof err) == 0, "vpbs_ivc_create: %s", err);
+    REQUIRE(vpbs_ivc_create(ctx, &c_desc, &d_desc, N, K, ggsw_len, /* comm: one GPU */ nullptr, &ivc, err, sizeof err) == 0, "vpbs_ivc_create: %s", err);
     std::vector<u64> vk(68);
     vpbs_ivc_verifier_data(ivc, vk.data(), nullptr);
 

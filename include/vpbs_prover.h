@@ -494,8 +494,12 @@ typedef struct {
     unsigned steps;
     double base_proof_ms, late_witness_ms, late_rows_upload_ms, prove_step_ms, early_witness_ms;   /* per step, except the base proof */
 } vpbs_ivc_timing;
+/* comm: NULL = one GPU.  Otherwise (BASELINE config 4) every rank of the node calls with its own context and its vpbs_comm (callbacks or
+ * vpbs_comm_rccl_create): the chain is sequential, so the GPUs share every STEP -- constants / sigmas committed with
+ * vpbs_commit_sharded_dev, every step proven with vpbs_prove_step_sharded -- while every rank generates the (identical) witnesses on its
+ * host and ends with the identical proof.  The communicator must outlive the vpbs_ivc. */
 int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_ivc_circuit* dummy, unsigned N, unsigned K, size_t ggsw_len,
-                    vpbs_ivc** out, char* err, size_t err_len);
+                    const vpbs_comm* comm, vpbs_ivc** out, char* err, size_t err_len);
 void vpbs_ivc_free(vpbs_ivc* ivc);
 /* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */
 int vpbs_ivc_verifier_data(const vpbs_ivc* ivc, uint64_t* cyclic_vk, uint64_t* dummy_vk);

@@ -439,6 +439,20 @@ def test_ivc_driver_through_the_python_binding():
     c.close()
 
 
+def test_ivc_chain_tool_with_the_loop_spelled_out_in_python():
+    """VPBS_IVC_DRIVER=python: the same chain driven call by call over the C ABI (run_early / upload_bg / run_late / upload_rows / prove_step)
+    instead of vpbs_ivc_prove_pbs -- the form a host that wants its own pipeline would write"""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, entry.ROOT + "/tools/prove_ivc.py", "8", "6", "13"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, VPBS_IVC_DRIVER="python"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["driver"].startswith("the loop of tools/prove_ivc.py") and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1
+
+
 def test_ivc_chain_tool_two_chains_side_by_side():
     """VPBS_IVC_CHAINS=2: two independent PBS (own seed, message, context and witness plans) chained concurrently on the one GPU; each
     final proof passes verify_pbs and decrypts to its own message"""

@@ -208,7 +208,7 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
             "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
 
 
-def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start):
+def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start, dist=None):
     """the same PBS through the library's own driver (vpbs_ivc_prove_pbs: the loop of run_chain in C++, csrc/ivc.hip) -> result dict"""
     total, kn = n_lwe + 2, K * N
     t_keys = time.perf_counter()
@@ -221,6 +221,8 @@ def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start):
     torch.cuda.synchronize()
     start.wait()
     blob, t = ivc.prove_pbs(testv, ct, keys["bsk"], keys["ksk"], steps)
+    if dist:
+        dist.barrier()
     # verify_pbs (:388-489) on the LAST proof only
     tv = time.perf_counter()
     back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, d.n_constants)
@@ -279,8 +281,9 @@ def main():
             dist.init_process_group(backend)
         dist.barrier()
     cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
-    # one GPU: the chain runs inside the library (vpbs_ivc_prove_pbs); several GPUs, or VPBS_IVC_DRIVER=python: the same loop spelled out here
-    native_driver = world == 1 and os.environ.get("VPBS_IVC_DRIVER", "library") != "python"
+    # the chain runs inside the library (vpbs_ivc_prove_pbs; with several GPUs every rank calls it with its communicator);
+    # VPBS_IVC_DRIVER=python: the same loop spelled out here over the C ABI
+    native_driver = os.environ.get("VPBS_IVC_DRIVER", "library") != "python"
     chains = []
     for ci in range(n_chains):   # every chain has its own context (stream, device memory), circuit commitments and witness plans
         ctx = vpbs_amd.Context(device, log_n_max=max(16, log_n))
@@ -292,7 +295,7 @@ def main():
                 sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
         if native_driver:
             cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
-            chains.append((ctx, api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N), cd))
+            chains.append((ctx, api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm), cd))
         else:
             chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))
     t_setup = time.perf_counter() - t_setup
@@ -305,7 +308,7 @@ def main():
             torch.cuda.set_device(device)
             ctx, cyc, dum = chains[ci]
             if native_driver:
-                results[ci] = run_chain_native(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start)
+                results[ci] = run_chain_native(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start, dist)
             else:
                 results[ci] = run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, 0x5EED0728 + ci, (message + ci) % 2, start, dist)
         except BaseException as e:                           # noqa: BLE001
@@ -328,6 +331,8 @@ def main():
     desc = dum if native_driver else cyc.d
     n_pi = len(desc.pi_pos)
     if rank != 0:
+        if native_driver:
+            cyc.free()               # the communicator must outlive the vpbs_ivc
         if native:
             sharding.free_comm_rccl(comm)
         dist.barrier()

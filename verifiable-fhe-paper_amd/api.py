@@ -192,7 +192,7 @@ SIGNATURES = {
     "vpbs_witness_device_free": (None, [C.c_void_p]),
     "vpbs_check_witness": (_i, [C.POINTER(CircuitC), U64P, U64P, C.c_char_p, _sz]),
     "vpbs_verify_step": (_i, [C.POINTER(VerifyInputsC), U64P, U64P, U64P]),
-    "vpbs_ivc_create": (_i, [_vp, C.POINTER(IvcCircuitC), C.POINTER(IvcCircuitC), _ui, _ui, _sz, C.POINTER(_vp), C.c_char_p, _sz]),
+    "vpbs_ivc_create": (_i, [_vp, C.POINTER(IvcCircuitC), C.POINTER(IvcCircuitC), _ui, _ui, _sz, C.POINTER(CommC), C.POINTER(_vp), C.c_char_p, _sz]),
     "vpbs_ivc_free": (None, [_vp]),
     "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
     "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
@@ -601,8 +601,9 @@ class Ivc:
     """vpbs_ivc: one verifiable PBS as one call -- the IVC chain of verified_pbs (ivc_based_vpbs.rs:159-386) driven inside the library.
     cyclic / dummy: circuit_file.CircuitDescription of the exported cyclic step circuit and its dummy circuit."""
 
-    def __init__(self, ctx, cyclic, dummy, N, K, ggsw_len):
-        self.ctx, self._keep = ctx, []
+    def __init__(self, ctx, cyclic, dummy, N, K, ggsw_len, comm=None):
+        """comm: a CommC (sharding.make_comm / make_comm_rccl) -> every step proof coset-sharded over the ranks; every rank builds its own Ivc"""
+        self.ctx, self._keep = ctx, [comm]
 
         def side(d, proof_words):
             c = IvcCircuitC()
@@ -616,7 +617,8 @@ class Ivc:
             return c
         cy, du = side(cyclic, cyclic.meta["proof_words"]), side(dummy, 0)
         self.h, err = C.c_void_p(), C.create_string_buffer(512)
-        if lib().vpbs_ivc_create(ctx.h, C.byref(cy), C.byref(du), N, K, ggsw_len, C.byref(self.h), err, 512):
+        if lib().vpbs_ivc_create(ctx.h, C.byref(cy), C.byref(du), N, K, ggsw_len, C.byref(comm) if comm is not None else None, C.byref(self.h),
+                                 err, 512):
             raise VpbsError("vpbs_ivc_create: " + err.value.decode())
         self.vk_words = 4 + (4 << 4)
         self.max_bytes = 8 * (cyclic.meta["proof_words"] + len(cyclic.pi_pos)) + (1 << 16)

@@ -2,7 +2,9 @@
 // (/root/reference/src/vtfhe/ivc_based_vpbs.rs:159-386: build the cyclic step circuit, prove the base case, then n + 2 steps each verifying its
 // predecessor in circuit) driven inside the library.  Host code only, written against the library's own C ABI (include/vpbs_prover.h) -- what
 // examples/prove_ivc.cpp did by hand: nothing here reaches below that boundary.
-//   create : constants/sigmas commitments and verifier data of the cyclic and the dummy circuit (CircuitBuilder::build's prover data),
+//   create : (comm != NULL: coset-sharded over the GPUs of a node -- every rank calls with its own context and communicator, generates the
+//            same witnesses, proves its cosets of every step and ends with the same proof)
+//            constants/sigmas commitments and verifier data of the cyclic and the dummy circuit (CircuitBuilder::build's prover data),
 //            compiled witness plans, the split of the cyclic plan (the previous proof's words are the late part), three pinned + three
 //            device wire matrices
 //   prove  : base proof of the dummy circuit (cyclic_base_proof, :292-299), then per step
@@ -36,11 +38,14 @@ struct Side {   // one circuit on the context
     size_t n_preset = 0;
     std::vector<u64> cs_cap, vk;   // vk: circuit digest [4] then the constants/sigmas cap
     u64* d_sigma = nullptr;
+    u64* d_csv = nullptr;          // sharded commitment only: the constants / sigmas matrix on the device
     vpbs_batch* cs = nullptr;
     vpbs_witness_plan* plan = nullptr;
+    const vpbs_comm* comm = nullptr;   // not null: every commitment and proof of this circuit is coset-sharded over comm->world GPUs
 
-    int init(vpbs_ctx* c, const vpbs_ivc_circuit& d, unsigned cap_height, std::string& err) {
+    int init(vpbs_ctx* c, const vpbs_ivc_circuit& d, unsigned cap_height, const vpbs_comm* cm, std::string& err) {
         ctx = c;
+        comm = cm;
         const vpbs_circuit& k = *d.circuit;
         log_n = k.log_n; n_wires = k.n_wires; n_routed = k.n_routed; n_const_cols = k.n_constants_cols; num_selectors = k.num_selectors;
         n = (size_t)1 << log_n;
@@ -53,7 +58,17 @@ struct Side {   // one circuit on the context
         if (vpbs_sigma_values(&k, sigma) != 0) return err = "sigma polynomials: malformed copy constraints", VPBS_ERR_INVALID;
         const size_t cap_words = (size_t)4 << cap_height;
         cs_cap.resize(cap_words);
-        int rc = vpbs_commit_values(ctx, csv.data(), n_const_cols + n_routed, log_n, &cs, cs_cap.data());
+        int rc;
+        if (!comm) {
+            rc = vpbs_commit_values(ctx, csv.data(), n_const_cols + n_routed, log_n, &cs, cs_cap.data());
+        } else {   // this rank's cosets; the cap is the concatenation of every rank's part (one all-gather of 32-byte hashes)
+            if (comm->world == 0 || cap_words % comm->world != 0 || !comm->allgather) return err = "malformed communicator", VPBS_ERR_INVALID;
+            rc = vpbs_device_alloc(ctx, csv.size(), &d_csv);
+            if (rc == 0) rc = vpbs_device_upload(ctx, d_csv, csv.data(), csv.size());
+            std::vector<u64> local(cap_words / comm->world);
+            if (rc == 0) rc = vpbs_commit_sharded_dev(ctx, d_csv, 1, n_const_cols + n_routed, log_n, comm->rank, comm->world, &cs, local.data());
+            if (rc == 0 && comm->allgather(comm->user, local.data(), local.size(), cs_cap.data()) != 0) return err = "all-gather of the cap failed", VPBS_ERR_DEVICE;
+        }
         if (rc != 0) return err = std::string("constants / sigmas commitment: ") + vpbs_last_error(ctx), rc;
         std::vector<u64> dig_in(cs_cap);
         dig_in.push_back(log_n);
@@ -81,11 +96,16 @@ struct Side {   // one circuit on the context
         in.n_routed = n_routed; in.quotient_degree_factor = 8; in.n_constants = n_const_cols;
         in.gates = gates.data(); in.n_gates = (unsigned)gates.size(); in.num_selectors = num_selectors;
     }
+    int prove(const vpbs_step_inputs& in, u64* caps, u64* openings, u64* fri) const {
+        return comm ? vpbs_prove_step_sharded(ctx, &in, comm, caps, openings, fri, nullptr, nullptr)
+                    : vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr);
+    }
     void release() {
         if (plan) vpbs_witness_plan_free(plan);
         if (cs) vpbs_batch_free(cs);
         if (d_sigma) vpbs_device_free(ctx, d_sigma);
-        plan = nullptr; cs = nullptr; d_sigma = nullptr;
+        if (d_csv) vpbs_device_free(ctx, d_csv);
+        plan = nullptr; cs = nullptr; d_sigma = nullptr; d_csv = nullptr;
     }
 };
 }  // namespace
@@ -100,6 +120,7 @@ struct vpbs_ivc {
     u64 *bufs[NBUF] = {nullptr, nullptr, nullptr}, *d_bufs[NBUF] = {nullptr, nullptr, nullptr}, *base_wires = nullptr;
     bool filled[NBUF] = {false, false, false};
     std::string err;
+    vpbs_comm comm{};
     ~vpbs_ivc() {
         for (auto b : bufs)
             if (b) vpbs_host_free(b);
@@ -114,7 +135,7 @@ struct vpbs_ivc {
 extern "C" {
 
 int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_ivc_circuit* dummy, unsigned N, unsigned K, size_t ggsw_len,
-                    vpbs_ivc** out, char* err, size_t err_len) {
+                    const vpbs_comm* comm, vpbs_ivc** out, char* err, size_t err_len) {
     auto say = [&](const std::string& m) {
         if (err && err_len) {
             std::strncpy(err, m.c_str(), err_len - 1);
@@ -136,8 +157,9 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
     }
     auto* v = new vpbs_ivc();
     v->ctx = ctx; v->N = N; v->K = K; v->ggsw_len = ggsw_len; v->kn = kn; v->n_pi = n_pi; v->proof_words = cyclic->proof_words;
-    int rc = v->cyc.init(ctx, *cyclic, 4, v->err);
-    if (rc == 0) rc = v->dum.init(ctx, *dummy, 4, v->err);
+    if (comm) v->comm = *comm;   // the callbacks and staging buffers stay the caller's; the struct itself is copied
+    int rc = v->cyc.init(ctx, *cyclic, 4, comm ? &v->comm : nullptr, v->err);
+    if (rc == 0) rc = v->dum.init(ctx, *dummy, 4, nullptr, v->err);   // the base proof is small: every rank proves it whole
     if (rc == 0) {
         std::vector<uint8_t> late(cyclic->n_preset, 0);
         std::fill(late.begin(), late.begin() + cyclic->proof_words, 1);
@@ -303,7 +325,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         return stop("the proof of this shape does not have the number of words the cyclic circuit expects", VPBS_ERR_INVALID);
     std::vector<u64> proof(proof_words), pis;
     u64 *caps = proof.data(), *openings = caps + 3 * sz.cap_words, *fri = openings + sz.openings_words;   // the flat order of the proof targets
-    int rc = vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr);
+    int rc = dum.prove(in, caps, openings, fri);
     if (rc != 0) return stop(std::string("base proof: ") + vpbs_last_error(ctx), rc);
     const double t_base = now() - t0;
     double t_late = 0, t_rows = 0, t_prove = 0;
@@ -331,7 +353,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         t = now();
         pis = std::move(r.pis);
         cyc.step_inputs(in, v->d_bufs[r.buf], true, pis.data());
-        rc = vpbs_prove_step(ctx, &in, caps, openings, fri, nullptr, nullptr);
+        rc = cyc.prove(in, caps, openings, fri);
         if (rc != 0) return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
         t_prove += now() - t;
         {
