@@ -79,11 +79,19 @@ def test_in_circuit_verifier_accepts_a_proof_and_rejects_a_tampered_one():
     assert ok, msg
     ch = vc.challenges
     assert vc.built.values(w, ch["betas"] + ch["gammas"] + ch["alphas"] + list(ch["zeta"])) == [int(x) for x in proof["challenges"]]
-    for at in (shape.caps_words + 10, 3, shape.proof_words - 1, shape.caps_words + shape.openings_words + 200):
+    # EVERY word of the proof is bound: a few chosen positions, then a random sweep over caps, openings, query leaves and paths, fold
+    # evaluations, final polynomial and proof-of-work witness (a word the in-circuit verifier did not constrain would pass here)
+    plan = vc.built.circuit.witness_plan(list(vc.presets(shape.flat_proof(proof), cpis, digest, proof["cs_cap"])))
+    vals = lambda flat: np.array(list(vc.presets(flat, cpis, digest, proof["cs_cap"]).values()), np.uint64)
+    assert (plan.run(vals(shape.flat_proof(proof))) == w).all()
+    sweep = [shape.caps_words + 10, 3, shape.proof_words - 1, shape.caps_words + shape.openings_words + 200] + \
+            [rnd.randrange(shape.proof_words) for _ in range(400)]
+    for at in sweep:
         bad = shape.flat_proof(proof).copy()
-        bad[at] ^= np.uint64(1)
+        bad[at] ^= np.uint64(1 << rnd.randrange(0, 40)) if at != sweep[0] else np.uint64(1)
         with pytest.raises(api.VpbsError, match="set twice|too large"):     # a connect that cannot hold, or the proof-of-work range check
-            vc.built.circuit.generate_witness(vc.presets(bad, cpis, digest, proof["cs_cap"]))
+            plan.run(vals(bad))
+    plan.free()
 
 
 def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
