@@ -538,6 +538,10 @@ int vpbs_k_merkle_cap(vpbs_ctx* ctx, const uint64_t* leaves, size_t n_leaves, un
 /* reference negacyclic NTT (/root/reference/src/vtfhe/crypto/poly.rs:27-64), batched, in place on [batch][1<<log_n] */
 int vpbs_k_negacyclic_ntt(vpbs_ctx* ctx, uint64_t* data, unsigned batch, unsigned log_n, int inverse);
 /* the params_{N}.rs tables (ROOTS, INVROOTS, NINV) regenerated per /root/reference/src/ntt/gen_param_file.sage */
+/* n Poseidon permutations on the HOST, in place ([n][12], canonical in and out): eight at a time on AVX-512 lanes where the CPU has them
+ * (returns 1), one after the other otherwise (returns 0).  The batched form is what the witness generator and the verifier use for
+ * independent permutations; exported for parity tests. */
+int vpbs_k_poseidon_host(uint64_t* states, size_t n);
 /* shader clock (MHz) of one CU measured over 20 us on the context's stream, after everything queued before it (s_memtime / s_memrealtime) */
 int vpbs_k_clock_probe(vpbs_ctx* ctx, double* mhz_out);
 int vpbs_ntt_params(unsigned log_n, uint64_t* roots, uint64_t* invroots, uint64_t* ninv);

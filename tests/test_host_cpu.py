@@ -318,3 +318,17 @@ def test_circuit_file_round_trip(tmp_path):
     ok, msg = d.circuit.check_witness(w, api.hash_no_pad(d.sample_public_inputs))
     assert ok, msg
     plan.free()
+
+
+def test_host_poseidon_batches_match_the_oracle():
+    """vpbs_k_poseidon_host: n independent permutations on the host -- eight per AVX-512 register where the CPU has it (csrc/host/poseidon_x8.h),
+    one by one otherwise -- against the oracle's permutation, edge values and a ragged tail (n not a multiple of eight) included"""
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 7, 8, 9, 203):
+        st = rng.integers(0, P, size=(n, 12), dtype=np.uint64)
+        if n > 2:
+            st[0], st[1], st[2] = 0, P - 1, np.arange(12)
+        got = st.copy()
+        rc = api.lib().vpbs_k_poseidon_host(api._ptr(got) if n else None, n)
+        assert rc in (0, 1)
+        assert all((got[i] == orc.poseidon(st[i])).all() for i in range(n))

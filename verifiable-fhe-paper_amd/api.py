@@ -131,6 +131,7 @@ SIGNATURES = {
     "vpbs_ctx_destroy": (None, [_vp]),
     "vpbs_last_error": (C.c_char_p, [_vp]),
     "vpbs_ctx_synchronize": (_i, [_vp]),
+    "vpbs_k_poseidon_host": (_i, [U64P, _sz]),
     "vpbs_k_clock_probe": (_i, [_vp, C.POINTER(C.c_double)]),
     "vpbs_ctx_set_gate_lanes": (_i, [_vp, _ui]),
     "vpbs_ctx_stream": (_vp, [_vp]),

@@ -6,6 +6,7 @@
 
 #include "context.h"
 #include "poseidon.h"
+#include "host/poseidon_x8.h"
 
 using vpbs::DeviceError;
 using vpbs::u64;
@@ -804,6 +805,18 @@ uint64_t vpbs_challenger_get(vpbs_challenger_state* ch) {
     return ch->output[--ch->output_len];
 }
 void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) { poseidon::hash_no_pad_host(in, n, out); }
+
+int vpbs_k_poseidon_host(uint64_t* states, size_t n) {
+    if (!states && n) return VPBS_ERR_INVALID;
+#if defined(VPBS_HAVE_POSEIDON_X8)
+    if (poseidon_x8::available()) {
+        poseidon_x8::permute_many(states, n);
+        return 1;
+    }
+#endif
+    for (size_t i = 0; i < n; ++i) poseidon::permute_host(states + 12 * i);
+    return 0;
+}
 
 int vpbs_hash_chain(const uint64_t* items, size_t n_items, size_t item_len, const uint64_t claimed[4], uint64_t out[4]) {
     if (n_items && !items) return VPBS_ERR_INVALID;

@@ -29,6 +29,7 @@
 
 #include "context.h"
 #include "gates.h"
+#include "host/poseidon_x8.h"
 #include "../../include/vpbs_prover.h"
 
 namespace vpbs {
@@ -1280,6 +1281,57 @@ bool run_one(const vpbs_witness_plan& p, SlotState& s, size_t i, unsigned mc, st
     return true;
 }
 
+#if defined(VPBS_HAVE_POSEIDON_X8)
+// Up to eight PoseidonGate rows of one dependency level at once (they are independent: plan_split), one permutation per AVX-512 lane:
+// poseidon_generate for `cnt` schedule steps.  The wires written are the scalar generator's, bit for bit (canonical values).
+__attribute__((target("avx512f,avx512dq")))
+bool poseidon_rows_x8(const vpbs_witness_plan& p, SlotState& s, const u32* steps, unsigned cnt, std::string& err) {
+    using poseidon_x8::V;
+    alignas(64) u64 in[12][8];
+    const u32* rs[8];
+    u32 row[8];
+    for (unsigned l = 0; l < 8; ++l) {
+        const unsigned q = l < cnt ? l : 0;   // spare lanes repeat the first row
+        const u32 r = p.schedule[steps[q]].row;
+        row[l] = r;
+        rs[l] = p.row_slots.data() + p.row_off[r];
+        if (l >= cnt) {
+            for (int i = 0; i < 12; ++i) in[i][l] = in[i][0];
+            continue;
+        }
+        SlotRow sr{s, rs[l], r};
+        const u64 swap = sr.get(24);
+        if (swap > 1) {
+            err = "PoseidonGate: swap wire is not boolean (row " + std::to_string(r) + ")";
+            return false;
+        }
+        for (int i = 0; i < 4; ++i) {
+            const u64 lhs = sr.get(i), rhs = sr.get(i + 4);
+            const u64 delta = gl::mul(swap, gl::sub(rhs, lhs));
+            sr.set(25 + i, delta);
+            in[i][l] = gl::add(lhs, delta);
+            in[i + 4][l] = gl::sub(rhs, delta);
+        }
+        for (int i = 8; i < 12; ++i) in[i][l] = sr.get(i);
+    }
+    V st[12], gate[106];
+    for (int i = 0; i < 12; ++i) st[i] = _mm512_load_si512(in[i]);
+    poseidon_x8::permute(st, gate);
+    alignas(64) u64 out[8];
+    auto scatter = [&](V v, unsigned wire) __attribute__((target("avx512f,avx512dq"))) {
+        _mm512_store_si512(out, v);
+        for (unsigned l = 0; l < cnt; ++l) s.set(rs[l][wire], out[l], (u32)(wire * s.n + row[l]));
+    };
+    for (int round = 1; round < 4; ++round)
+        for (int i = 0; i < 12; ++i) scatter(gate[12 * (round - 1) + i], 29 + 12 * (round - 1) + i);
+    for (int q = 0; q < 22; ++q) scatter(gate[36 + q], 65 + q);
+    for (int round = 26; round < 30; ++round)
+        for (int i = 0; i < 12; ++i) scatter(gate[58 + 12 * (round - 26) + i], 87 + 12 * (round - 26) + i);
+    for (int i = 0; i < 12; ++i) scatter(st[i], 12 + i);
+    return true;
+}
+#endif
+
 // VPBS_TRACE_WITNESS: where a sequential run spends its time, per gate kind (0..31) / gadget generator kind (32..)
 struct KindProfile {
     const bool on = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
@@ -1347,6 +1399,9 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
         return VPBS_OK;
     }
     threads = pool->threads;
+#if defined(VPBS_HAVE_POSEIDON_X8)
+    static const bool x8 = poseidon_x8::available() && !(std::getenv("VPBS_POSEIDON_X8") && std::atoi(std::getenv("VPBS_POSEIDON_X8")) == 0);
+#endif
     std::atomic<bool> failed{false};
     std::vector<std::string> errs(threads);
     // the chain lanes start now, on threads of their own, and run next to the levels
@@ -1397,8 +1452,33 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
             const u64 total = *c1 - *c0;
             auto bound = [&](unsigned t) { return t >= threads ? hi : (u32)(std::lower_bound(c0, c1, (u32)(*c0 + total * t / threads)) - P.cost.data()); };
             pool->share([&](unsigned t) {
+#if defined(VPBS_HAVE_POSEIDON_X8)
+                // the PoseidonGate rows of this thread's share eight at a time (batches of three or more; the rest one by one)
+                u32 pending[8];
+                unsigned np = 0;
+                auto flush = [&] {
+                    if (np >= 3) {
+                        if (!poseidon_rows_x8(p, s, pending, np, errs[t])) failed.store(true);
+                    } else {
+                        for (unsigned q = 0; q < np; ++q)
+                            if (!run_one(p, s, pending[q], mc, errs[t])) failed.store(true);
+                    }
+                    np = 0;
+                };
+                for (u32 k = bound(t), end = bound(t + 1); k < end && !failed.load(std::memory_order_relaxed); ++k) {
+                    const auto& st = p.schedule[P.order[k]];
+                    if (x8 && st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) {
+                        pending[np++] = P.order[k];
+                        if (np == 8) flush();
+                    } else if (!run_one(p, s, P.order[k], mc, errs[t])) {
+                        failed.store(true);
+                    }
+                }
+                flush();
+#else
                 for (u32 k = bound(t), end = bound(t + 1); k < end && !failed.load(std::memory_order_relaxed); ++k)
                     if (!run_one(p, s, P.order[k], mc, errs[t])) failed.store(true);
+#endif
             });
             if (failed.load()) rc = VPBS_ERR_INVALID;
             if (trace) t_wide += clock() - t_level, ++n_wide;
