@@ -4,12 +4,14 @@
 // `eval_vanishing_poly` (permutation part).  The reference calls it as `cd.verify(proof)` at
 // /root/reference/src/vtfhe/ivc_based_vpbs.rs:443-447.  Product code: written against gl.h /
 // poseidon.h, independent of the test oracle.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "host/plonky2_mirror.h"
 #include "kernels.h"
 #include "poseidon.h"
+#include "host/poseidon_x8.h"
 
 using gl::Ext;
 using gl::u64;
@@ -39,6 +41,89 @@ bool merkle_verify(const u64* leaf, size_t leaf_len, size_t idx, const u64* cap,
         idx >>= 1;
     }
     return std::memcmp(cur, cap + 4 * idx, sizeof cur) == 0;
+}
+// The Merkle checks of a proof are independent of each other and of the arithmetic checks: they are collected while the query rounds are
+// replayed and verified together at the end -- eight paths of one shape (leaf length, path length) side by side, one per AVX-512 lane
+// (host/poseidon_x8.h), where the CPU has them; one after the other otherwise.  4 oracles + 3 FRI rounds x 28 queries = 196 paths,
+// ~3 200 permutations: two thirds of the verifier's time when done one by one.
+struct MerkleJob {
+    const u64* leaf;
+    size_t leaf_len, idx;
+    const u64* cap;
+    const u64* siblings;
+    size_t n_sib;
+};
+#if defined(VPBS_HAVE_POSEIDON_X8)
+__attribute__((target("avx512f,avx512dq")))
+bool merkle_verify_x8(const MerkleJob* jobs, unsigned cnt) {   // cnt <= 8 jobs of one shape
+    using poseidon_x8::V;
+    const size_t leaf_len = jobs[0].leaf_len, n_sib = jobs[0].n_sib;
+    alignas(64) u64 lane[12][8];
+    u64 cur[8][4];
+    auto job = [&](unsigned l) -> const MerkleJob& { return jobs[l < cnt ? l : 0]; };   // spare lanes repeat the first job
+    if (leaf_len <= 4) {   // hash_or_noop: padded, not hashed
+        for (unsigned l = 0; l < 8; ++l)
+            for (int i = 0; i < 4; ++i) cur[l][i] = (size_t)i < leaf_len ? job(l).leaf[i] : 0;
+    } else {
+        V st[12];
+        for (int i = 0; i < 12; ++i) st[i] = _mm512_setzero_si512();
+        for (size_t off = 0; off < leaf_len; off += 8) {   // overwrite-mode sponge, rate 8
+            const size_t len = leaf_len - off < 8 ? leaf_len - off : 8;
+            for (size_t i = 0; i < len; ++i) {
+                for (unsigned l = 0; l < 8; ++l) lane[i][l] = job(l).leaf[off + i];
+                st[i] = _mm512_load_si512(lane[i]);
+            }
+            poseidon_x8::permute(st, nullptr);
+        }
+        for (int i = 0; i < 4; ++i) {
+            _mm512_store_si512(lane[i], st[i]);
+            for (unsigned l = 0; l < 8; ++l) cur[l][i] = lane[i][l];
+        }
+    }
+    size_t idx[8];
+    for (unsigned l = 0; l < 8; ++l) idx[l] = job(l).idx;
+    for (size_t k = 0; k < n_sib; ++k) {
+        for (unsigned l = 0; l < 8; ++l) {
+            const u64* sib = job(l).siblings + 4 * k;
+            const bool right = idx[l] & 1;   // this node is the right child: two_to_one(sibling, node)
+            for (int i = 0; i < 4; ++i) {
+                lane[i][l] = right ? sib[i] : cur[l][i];
+                lane[i + 4][l] = right ? cur[l][i] : sib[i];
+            }
+            idx[l] >>= 1;
+        }
+        V st[12];
+        for (int i = 0; i < 8; ++i) st[i] = _mm512_load_si512(lane[i]);
+        for (int i = 8; i < 12; ++i) st[i] = _mm512_setzero_si512();
+        poseidon_x8::permute(st, nullptr);
+        for (int i = 0; i < 4; ++i) {
+            _mm512_store_si512(lane[i], st[i]);
+            for (unsigned l = 0; l < 8; ++l) cur[l][i] = lane[i][l];
+        }
+    }
+    for (unsigned l = 0; l < cnt; ++l)
+        if (std::memcmp(cur[l], jobs[l].cap + 4 * idx[l], sizeof cur[l]) != 0) return false;
+    return true;
+}
+#endif
+bool merkle_verify_all(std::vector<MerkleJob>& jobs) {
+#if defined(VPBS_HAVE_POSEIDON_X8)
+    if (poseidon_x8::available()) {
+        std::stable_sort(jobs.begin(), jobs.end(), [](const MerkleJob& a, const MerkleJob& b) {
+            return a.leaf_len != b.leaf_len ? a.leaf_len < b.leaf_len : a.n_sib < b.n_sib;
+        });
+        for (size_t at = 0; at < jobs.size();) {
+            size_t end = at + 1;
+            while (end < jobs.size() && end - at < 8 && jobs[end].leaf_len == jobs[at].leaf_len && jobs[end].n_sib == jobs[at].n_sib) ++end;
+            if (!merkle_verify_x8(jobs.data() + at, (unsigned)(end - at))) return false;
+            at = end;
+        }
+        return true;
+    }
+#endif
+    for (const MerkleJob& j : jobs)
+        if (!merkle_verify(j.leaf, j.leaf_len, j.idx, j.cap, j.siblings, j.n_sib)) return false;
+    return true;
 }
 Ext ext_at(const u64* p, size_t i) { return Ext{p[2 * i], p[2 * i + 1]}; }
 size_t bitrev(size_t x, unsigned bits) {
@@ -191,13 +276,15 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     for (size_t j = nc; j-- > 0;) reduced1 = gl::add(gl::mul(reduced1, fri_alpha), ext_at(openings, total_cols + j));
     const u64* oracle_caps[4] = {in->constants_sigmas_cap, caps, caps + cap_words, caps + 2 * cap_words};
 
+    std::vector<MerkleJob> merkle_jobs;
+    merkle_jobs.reserve((size_t)fp.config.num_query_rounds * (4 + n_rounds));
     for (unsigned q = 0; q < fp.config.num_query_rounds; ++q) {
         size_t x_index = (size_t)(ch.get_challenge() % lde);
         const u64* leaf[4];
         const size_t nsib0 = log_lde - in->cap_height;
         for (size_t o = 0; o < 4; ++o) {  // fri_verify_initial_proof
             leaf[o] = w;
-            if (!merkle_verify(w, ncols[o], x_index, oracle_caps[o], w + ncols[o], nsib0)) return 0;
+            merkle_jobs.push_back({w, ncols[o], x_index, oracle_caps[o], w + ncols[o], nsib0});
             w += ncols[o] + 4 * nsib0;
         }
         u64 subgroup_x = gl::mul(gl::GENERATOR, gl::pow(gl::root_of_unity(log_lde), bitrev(x_index, log_lde)));
@@ -241,7 +328,7 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
             old_eval = interpolate(xs, ys, arity, fri_betas[r]);
             lg -= ab;
             const size_t nsib = lg - in->cap_height;
-            if (!merkle_verify(evals, 2 * arity, coset_index, fri_caps[r], evals + 2 * arity, nsib)) return 0;
+            merkle_jobs.push_back({evals, 2 * arity, coset_index, fri_caps[r], evals + 2 * arity, nsib});
             w += 2 * arity + 4 * nsib;
             for (unsigned k = 0; k < ab; ++k) subgroup_x = gl::mul(subgroup_x, subgroup_x);
             x_index = coset_index;
@@ -250,7 +337,7 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
         for (size_t i = final_len; i-- > 0;) acc = gl::add(gl::mul(acc, subgroup_x), ext_at(final_words, i));
         if (!gl::eq(acc, old_eval)) return 0;
     }
-    return 1;
+    return merkle_verify_all(merkle_jobs) ? 1 : 0;
 }
 
 // The inverse of vpbs_step_proof_to_bytes (prover.hip): ProofWithPublicInputs bytes -> the flat arrays vpbs_verify_step takes.  The
