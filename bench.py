@@ -689,6 +689,11 @@ def main():
                          "cycles_per_valu_instr_per_simd": (per_step_ms * 1e-3 * sclk_mhz * 1e6 * 256 * 4)
                                                            / (perms * LEAF_HASH_INSTR_PER_PERM / 64) if sclk_mhz > 0 else None},
             "kernel_ms_one_step": breakdown,
+            # the host side of the secondary legs (witness generation, the IVC chain's host phases) runs on a SHARED machine: what this
+            # process may use, and how busy the machine was when the line was written
+            "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
+                                                                             if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+                     "loadavg_1min": os.getloadavg()[0]},
         }
         if world == 1 and n_chains == 1 and args.batch_chains > 1:
             # BASELINE config 3 flavour on the same GPU: several independent chains in flight (extra contexts/streams)

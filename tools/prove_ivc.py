@@ -345,6 +345,9 @@ def main():
                 "in-circuit verifier of the previous proof: %d gate rows, degree 2^%d, %d public inputs) at N=%d, k=1, ELL=4, LOGB=5, n=%d on "
                 "%d x MI355X; the last proof alone is the vPBS proof" % ("one vPBS" if n_chains == 1 else "%d independent vPBS side by side, each" %
                                                                          n_chains, steps, total, desc.meta.get("used_rows", 0), log_n, n_pi, N, n_lwe, world),
+        "host": {"cpus_in_affinity_mask": len(os.sched_getaffinity(0)), "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
+                                                                                              if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+                 "loadavg": os.getloadavg()[0]},
         "chains": n_chains, "driver": "vpbs_ivc_prove_pbs (csrc/ivc.hip)" if native_driver else "the loop of tools/prove_ivc.py over the C ABI",
         "step_proofs": steps, "seconds": seconds,
         "seconds_full_chain_extrapolated": None if steps == total else seconds / steps * total,
