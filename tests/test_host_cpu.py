@@ -173,11 +173,24 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
     # random sigmas are not a permutation of the wires: the FRI part verifies, the vanishing identity does not
     assert not api.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n, check_permutation=True, n_constants=n_constants,
                                n_routed=n_routed)
-    for key, pos in (("fri", 0), ("fri", proof["fri"].size // 2), ("fri", proof["fri"].size - 1), ("openings", 3), ("caps", 5)):
-        bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in proof.items()}
-        flat = bad[key].reshape(-1)
-        flat[pos] = (int(flat[pos]) + 1) % P
-        assert not api.verify_step_fri_only(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
+    # every word of the FRI part (query leaves, Merkle siblings, fold evaluations, final polynomial, proof-of-work witness), a random sweep:
+    # with the Merkle checks batched eight paths per AVX-512 register (where the CPU has it) and one after the other (VPBS_POSEIDON_X8=0)
+    rnd = np.random.default_rng(17)
+    sweep = [("fri", 0), ("fri", proof["fri"].size // 2), ("fri", proof["fri"].size - 1), ("openings", 3), ("caps", 5)] + \
+            [("fri", int(q)) for q in rnd.integers(0, proof["fri"].size, 120)]
+    for form in ("", "0"):
+        os.environ["VPBS_POSEIDON_X8"] = form
+        try:
+            if not form:
+                del os.environ["VPBS_POSEIDON_X8"]
+            assert api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis, log_n)
+            for key, pos in sweep:
+                bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in proof.items()}
+                flat = bad[key].reshape(-1)
+                flat[pos] = (int(flat[pos]) + 1) % P
+                assert not api.verify_step_fri_only(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
+        finally:
+            os.environ.pop("VPBS_POSEIDON_X8", None)
     assert not api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs
     # the default is the full check: without the circuit's shape it refuses instead of quietly running the FRI part alone
     with pytest.raises(ValueError):

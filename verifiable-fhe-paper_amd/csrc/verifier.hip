@@ -5,6 +5,7 @@
 // /root/reference/src/vtfhe/ivc_based_vpbs.rs:443-447.  Product code: written against gl.h /
 // poseidon.h, independent of the test oracle.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -108,7 +109,8 @@ bool merkle_verify_x8(const MerkleJob* jobs, unsigned cnt) {   // cnt <= 8 jobs 
 #endif
 bool merkle_verify_all(std::vector<MerkleJob>& jobs) {
 #if defined(VPBS_HAVE_POSEIDON_X8)
-    if (poseidon_x8::available()) {
+    const char* sw = std::getenv("VPBS_POSEIDON_X8");   // "0": one path after the other (A/B measurements, tests of that form)
+    if (poseidon_x8::available() && !(sw && std::atoi(sw) == 0)) {
         std::stable_sort(jobs.begin(), jobs.end(), [](const MerkleJob& a, const MerkleJob& b) {
             return a.leaf_len != b.leaf_len ? a.leaf_len < b.leaf_len : a.n_sib < b.n_sib;
         });
