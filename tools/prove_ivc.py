@@ -262,9 +262,6 @@ def main():
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     n_chains = int(os.environ.get("VPBS_IVC_CHAINS", "1")) if world == 1 else 1
-    if n_chains > 1:   # measured: with several chains' pools side by side, 8 threads per witness phase beat the single-chain default of 12
-        os.environ.setdefault("VPBS_LATE_THREADS", "8")
-        os.environ.setdefault("VPBS_EARLY_THREADS", "8")
     torch.cuda.set_device(device)
     dist, comm, native, dist_device = None, None, False, None
     t_setup = time.perf_counter()

@@ -335,7 +335,8 @@ template <class Pred> void spin_until(Pred ready) {
         if ((i & 63) != 63) continue;
         const auto t = std::chrono::steady_clock::now();
         if (i == 63) t0 = t;
-        else if (t - t0 > std::chrono::microseconds(150)) std::this_thread::sleep_for(std::chrono::microseconds(20));   // a long wait: nap
+        else if (t - t0 > std::chrono::milliseconds(1)) std::this_thread::sleep_for(std::chrono::microseconds(100));   // a very long wait
+        else if (t - t0 > std::chrono::microseconds(150)) std::this_thread::sleep_for(std::chrono::microseconds(20));  // a long wait: nap
     }
 }
 
@@ -1437,9 +1438,18 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     double t_narrow = 0, t_wide = 0;
     u32 n_wide = 0;
     auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    pool->begin();
+    // the workers are only needed up to the last wide level (and again for the wires at the end): in between they sleep
+    u32 last_wide = 0;
+    for (u32 l = 0; l < n_levels; ++l)
+        if (P.cost[P.level_off[l + 1]] - P.cost[P.level_off[l]] >= PAR_MIN_COST) last_wide = l + 1;
+    bool pool_awake = last_wide > 0;
+    if (pool_awake) pool->begin();
     int rc = VPBS_OK;
     for (u32 l = 0; l < n_levels && rc == VPBS_OK; ++l) {
+        if (pool_awake && l >= last_wide) {
+            pool->end();
+            pool_awake = false;
+        }
         const u32 lo = P.level_off[l], hi = P.level_off[l + 1];
         const double t_level = trace ? clock() : 0;
         if (P.cost[hi] - P.cost[lo] < PAR_MIN_COST) {
@@ -1508,8 +1518,12 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     if (trace && !lanes.empty()) std::fprintf(stderr, "[witness %s] %zu chain lanes (%zu PoseidonGate rows): %.2f ms after the levels\n", name, lanes.size(),
                                               p.lane_steps_sorted[ph].size(), clock() - t_lanes);
     const double t_after = trace ? clock() : 0;
-    if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
-    pool->end();
+    if (rc == VPBS_OK && after) {
+        if (!pool_awake) pool->begin();
+        pool_awake = true;
+        pool->share([&](unsigned t) { after(t, threads); });
+    }
+    if (pool_awake) pool->end();
     if (trace)
         std::fprintf(stderr, "[witness %s] %u threads: %u narrow levels %.2f ms, %u wide levels %.2f ms, wires %.2f ms\n", name, threads,
                      n_levels - n_wide, t_narrow, n_wide, t_wide, clock() - t_after);
@@ -1540,7 +1554,10 @@ unsigned usable_cpus() {
 }
 
 unsigned default_phase_threads() {
-    return std::max(1u, std::min(12u, usable_cpus() * 3 / 4));   // 12 on the GPU box (256 hardware threads, 16 by its cgroup), 6 of 8
+    // 8 on the GPU box (256 hardware threads, 16 by its cgroup), 4 of 8.  With the PoseidonGate rows of a level generated eight per AVX-512
+    // register, 6, 8 and 12 threads measure the same for one chain (the 112 rows of a query level are two batches per thread either way);
+    // fewer threads leave more of a CPU quota to the other phases and chains.
+    return std::max(1u, std::min(8u, usable_cpus() / 2));
 }
 }  // namespace
 }  // namespace vpbs
