@@ -1457,13 +1457,17 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
                 if (!run_one(p, s, P.order[k], mc, errs[0])) rc = VPBS_ERR_INVALID;
             if (trace) t_narrow += clock() - t_level;
         } else {
-            // equal shares of the level's estimated cost
+            // The level is handed out in pieces of about equal estimated COST -- a piece is at least eight PoseidonGate rows' worth, and there
+            // are about three pieces per thread -- claimed from a shared cursor: a thread the host has descheduled (the machine is shared)
+            // holds up one piece, not an eighth of the level.
             const u32 *c0 = P.cost.data() + lo, *c1 = P.cost.data() + hi;
             const u64 total = *c1 - *c0;
-            auto bound = [&](unsigned t) { return t >= threads ? hi : (u32)(std::lower_bound(c0, c1, (u32)(*c0 + total * t / threads)) - P.cost.data()); };
+            static const unsigned pieces_per_thread = std::getenv("VPBS_LEVEL_PIECES") ? std::max(1, std::atoi(std::getenv("VPBS_LEVEL_PIECES"))) : 3;
+            const u64 piece = std::max<u64>(8 * 140, total / (pieces_per_thread * threads) + 1);
+            std::atomic<u64> cursor{0};
             pool->share([&](unsigned t) {
 #if defined(VPBS_HAVE_POSEIDON_X8)
-                // the PoseidonGate rows of this thread's share eight at a time (batches of three or more; the rest one by one)
+                // the PoseidonGate rows of a piece eight at a time (batches of three or more; the rest one by one)
                 u32 pending[8];
                 unsigned np = 0;
                 auto flush = [&] {
@@ -1475,20 +1479,27 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
                     }
                     np = 0;
                 };
-                for (u32 k = bound(t), end = bound(t + 1); k < end && !failed.load(std::memory_order_relaxed); ++k) {
-                    const auto& st = p.schedule[P.order[k]];
-                    if (x8 && st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) {
-                        pending[np++] = P.order[k];
-                        if (np == 8) flush();
-                    } else if (!run_one(p, s, P.order[k], mc, errs[t])) {
-                        failed.store(true);
-                    }
-                }
-                flush();
-#else
-                for (u32 k = bound(t), end = bound(t + 1); k < end && !failed.load(std::memory_order_relaxed); ++k)
-                    if (!run_one(p, s, P.order[k], mc, errs[t])) failed.store(true);
 #endif
+                for (;;) {
+                    const u64 at = cursor.fetch_add(piece, std::memory_order_relaxed);
+                    if (at >= total || failed.load(std::memory_order_relaxed)) break;
+                    const u32 k0 = (u32)(std::lower_bound(c0, c1, (u32)(*c0 + at)) - P.cost.data());
+                    const u32 k1 = at + piece >= total ? hi : (u32)(std::lower_bound(c0, c1, (u32)(*c0 + at + piece)) - P.cost.data());
+                    for (u32 k = k0; k < k1 && !failed.load(std::memory_order_relaxed); ++k) {
+#if defined(VPBS_HAVE_POSEIDON_X8)
+                        const auto& st = p.schedule[P.order[k]];
+                        if (x8 && st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) {
+                            pending[np++] = P.order[k];
+                            if (np == 8) flush();
+                            continue;
+                        }
+#endif
+                        if (!run_one(p, s, P.order[k], mc, errs[t])) failed.store(true);
+                    }
+#if defined(VPBS_HAVE_POSEIDON_X8)
+                    flush();
+#endif
+                }
             });
             if (failed.load()) rc = VPBS_ERR_INVALID;
             if (trace) t_wide += clock() - t_level, ++n_wide;
