@@ -439,6 +439,30 @@ def test_ivc_driver_through_the_python_binding():
     c.close()
 
 
+def test_ivc_driver_with_the_native_rccl_communicator_on_one_rank():
+    """vpbs_ivc_create with a communicator made by vpbs_comm_rccl_create (RCCL bound with dlopen; a world of one rank is all a one-GPU box
+    allows): sharded constants / sigmas commitment, every step through vpbs_prove_step_sharded with ncclAllGather / ncclAllReduce on the
+    prover's stream -- and the last proof still has the bytes of the CPU oracle's chain"""
+    import hashlib
+    import json
+    from test_cyclic_cpu import GOLDEN_CHAIN, n8_chain_inputs
+    from vpbs_amd import circuit_file, sharding
+    if not api.lib().vpbs_rccl_available():
+        pytest.skip("librccl.so is not loadable here")
+    N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
+    ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
+    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    c = vpbs_amd.Context(0, log_n_max=16)
+    comm = sharding.make_comm_rccl(c, stage_words=2 << (log_n + 3))
+    ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N, comm)
+    blob, _ = ivc.prove_pbs(testv, ct, np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk))
+    frozen = json.load(open(GOLDEN_CHAIN))
+    assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"])
+    ivc.free()
+    sharding.free_comm_rccl(comm)
+    c.close()
+
+
 def test_ivc_chain_tool_with_the_loop_spelled_out_in_python():
     """VPBS_IVC_DRIVER=python: the same chain driven call by call over the C ABI (run_early / upload_bg / run_late / upload_rows / prove_step)
     instead of vpbs_ivc_prove_pbs -- the form a host that wants its own pipeline would write"""
