@@ -47,6 +47,37 @@ int vpbs_ctx_synchronize(vpbs_ctx* ctx);
  * for throughput when several contexts already keep the device busy (-2 % with three chains otherwise). */
 int vpbs_ctx_set_gate_lanes(vpbs_ctx* ctx, unsigned lanes);
 void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share device buffers with the ctx */
+/* the FriConfig shape the context was created for (vpbs_ctx_create's rate_bits / cap_height); 0 for a null context */
+unsigned vpbs_ctx_rate_bits(const vpbs_ctx* ctx);
+unsigned vpbs_ctx_cap_height(const vpbs_ctx* ctx);
+
+/* ---- compatibility switch table ----
+ * plonky2 0.2.0 is an un-vendored dependency of the reference (/root/reference/Cargo.lock:371-374) and cannot be run in the authoring image,
+ * so a few transcript / layout choices of the crate are restated without a golden proof to pin them.  Every such choice that changes a
+ * proof's words or bytes sits in THIS table, and prover, serialiser, verifier and the test oracle (oracle/vpbs_oracle.h `orc_compat`) all
+ * read it: one capture of a real proof (tools/plonky2_capture) is checked against every position, and to_fixture.py records the one that
+ * reproduces it.  The defaults are plonky2 0.2.0 as restated (vpbs_compat_default); the alternative of each switch is the behaviour of
+ * earlier releases of the crate.  Call sites in the reference: proof.to_bytes() ivc_based_vpbs.rs:488, cd.verify :443-447,
+ * add_verifier_data_public_inputs :209-214 (the circuit digest travels in the public inputs of every step proof). */
+typedef struct {
+    int fri_mul_final_by_x;       /* fri/oracle.rs prove_openings.  0 (default): each batch quotient is padded back to a power of two
+                                     ("quotient.coeffs.push(ZERO)").  1: the final polynomial is multiplied by X before the LDE and
+                                     fri_combine_initial multiplies its sum by subgroup_x (releases before the padding change) */
+    int bytes_pi_len_prefix;      /* util/serialization write_proof_with_public_inputs.  1 (default): write_usize(public_inputs.len()) as a
+                                     little-endian u64 in front of the public inputs.  0: the public inputs run to the end of the buffer
+                                     (the older Buffer reader: remaining / 8 elements) */
+    int digest_domain_separator;  /* plonk/circuit_builder.rs build().  1 (default): circuit_digest = hash_no_pad(constants_sigmas_cap ||
+                                     hash_pad(domain_separator = []) || degree_bits).  0: hash_no_pad(cap || degree_bits) (before the
+                                     domain separator existed; what rounds 1-2 of this library used) */
+    int pow_smallest_nonce;       /* fri/prover.rs fri_proof_of_work.  1 (default): the SMALLEST u64 whose challenger response has the
+                                     required leading zeros -- deterministic.  The crate's rayon find_any may return ANY valid nonce, so a
+                                     captured proof is reproduced by passing its pow_witness as vpbs_step_inputs.forced_pow; 0 is reserved
+                                     for "first found" and is rejected by this build */
+} vpbs_compat;
+void vpbs_compat_default(vpbs_compat* out);
+/* A context proves and serialises under one table (default at creation); VPBS_ERR_INVALID for a position this build does not implement. */
+int vpbs_ctx_set_compat(vpbs_ctx* ctx, const vpbs_compat* compat);
+int vpbs_ctx_get_compat(const vpbs_ctx* ctx, vpbs_compat* out);
 
 /* ---- PolynomialBatch (plonky2 fri/oracle.rs) ---- */
 /* = PolynomialBatch::from_values(values, rate_bits, blinding=false, cap_height, ..): iFFT -> coset LDE -> Merkle */
@@ -95,6 +126,13 @@ void vpbs_challenger_observe(vpbs_challenger_state* ch, const uint64_t* elems, s
 uint64_t vpbs_challenger_get(vpbs_challenger_state* ch);                                 /* get_challenge   */
 /* PoseidonHash::hash_no_pad on the host (public-input hash, small inputs) */
 void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]);
+/* PoseidonHash::hash_pad (plonk/config.rs Hasher::hash_pad): the pad10*1 rule -- push 1, zeros until len + 1 is a multiple of the sponge
+ * rate 8, push 1 -- then hash_no_pad.  CircuitBuilder::build hashes the (empty) domain separator with it. */
+void vpbs_hash_pad(const uint64_t* in, size_t n, uint64_t out[4]);
+/* verifier_only.circuit_digest as CircuitBuilder::build derives it from the constants/sigmas cap and the degree (formula: vpbs_compat.
+ * digest_domain_separator; compat NULL = default).  cap: [cap_words] = 2^cap_height hashes.  The digest is the first thing the transcript
+ * absorbs and, in the IVC chain, part of every step's public inputs (ivc_based_vpbs.rs:209-214, check_cyclic_proof_verifier_data :448-452). */
+int vpbs_circuit_digest(const vpbs_compat* compat, const uint64_t* cap, size_t cap_words, unsigned degree_bits, uint64_t out[4]);
 /* the hash chain of verify_hash_output (/root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78): h_0 = 0^4,
  * h_{k+1} = hash_no_pad(h_k || item_k) over n_items items of item_len elements each (row-major); host only.
  * returns 1 if the chain ends in `claimed` (or claimed == NULL: just computes), 0 otherwise; out may be NULL. */
@@ -108,9 +146,10 @@ typedef struct {
     unsigned num_query_rounds; /* 28 */
     unsigned n_rounds;         /* len(reduction_arity_bits) */
     unsigned arity_bits[16];
-    int mul_final_by_x;        /* 0: plonky2 0.2.0 as restated (lower-confidence item) */
+    int mul_final_by_x;        /* vpbs_compat.fri_mul_final_by_x for a direct vpbs_fri_prove call; vpbs_prove_step and the verifier take
+                                  the switch from their compat table, not from here */
 } vpbs_fri_params;
-/* CircuitConfig::standard_recursion_config().fri_config.fri_params(degree_bits, hiding=false) */
+/* CircuitConfig::standard_recursion_config().fri_config.fri_params(degree_bits, hiding=false); mul_final_by_x = the default (0) */
 void vpbs_fri_params_standard(unsigned degree_bits, vpbs_fri_params* out);
 
 typedef struct { /* FriBatchInfo: opening point + FriPolynomialInfo list */
@@ -280,8 +319,8 @@ int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* p
 int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
                                          vpbs_witness_state** state_out, char* err, size_t err_len);
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
-                               char* err, size_t err_len);
-void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that run_late did not consume */
+                               char* err, size_t err_len);   /* the state is consumed whether the run succeeds or not */
+void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that never reached run_late */
 /* out = {row_lo, row_hi}: every wire position run_late writes lies in rows [row_lo, row_hi) -- what has to be uploaded again when the
  * matrix run_early produced is already on the device.  (0, 0) for a plan without late wires. */
 int vpbs_witness_plan_late_rows(const vpbs_witness_plan* plan, size_t out[2]);
@@ -409,7 +448,8 @@ int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpb
                             uint64_t* openings_out, uint64_t* fri_out, vpbs_challenger_state* challenger_out,
                             uint64_t* challenges_out);
 /* ProofWithPublicInputs::to_bytes layout (util/serialization); returns bytes written or <0.
- * n_constants: how many leading columns of constants_sigmas are `constants` (the rest are plonk_sigmas). */
+ * n_constants: how many leading columns of constants_sigmas are `constants` (the rest are plonk_sigmas).  The public-input prefix follows
+ * the context's compat table. */
 long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned n_constants,
                               const uint64_t* caps, const uint64_t* openings, const uint64_t* fri, uint8_t* out,
                               size_t out_capacity);
@@ -455,6 +495,8 @@ typedef struct {
     const uint64_t* gate_terms_zeta;        /* [num_challenges][2] or NULL (ignored when gates != NULL) */
     const vpbs_gate* gates;                 /* the circuit's gates: their constraints are evaluated at zeta from the openings */
     unsigned n_gates, num_selectors;
+    const vpbs_compat* compat;              /* NULL (zero-initialised struct) = vpbs_compat_default; read by vpbs_verify_step (FRI combination),
+                                               vpbs_step_proof_from_bytes (public-input prefix) and vpbs_verify_pbs */
 } vpbs_verify_inputs;
 /* The inverse of vpbs_step_proof_to_bytes: ProofWithPublicInputs bytes -> caps [3][cap], openings, fri (the arrays vpbs_verify_step
  * takes; sizes as vpbs_step_sizes_get reports) and the public inputs.  The shape is taken from `in` (log_n, rate_bits, cap_height, column
@@ -484,8 +526,8 @@ typedef struct {
     const vpbs_circuit* circuit;
     const uint32_t* preset_pos;
     size_t n_preset;
-    const uint32_t* pi_pos;     /* public-input targets (cyclic circuit; ignored for the dummy circuit may be NULL there) */
-    size_t n_pi;
+    const uint32_t* pi_pos;     /* public-input targets of the cyclic circuit; never read for the dummy circuit (may be NULL there) */
+    size_t n_pi;                /* cyclic circuit: 2 K N + 9 + 4 + cap words; dummy circuit: the same number or 0 (its public inputs are its PartialWitness) */
     size_t proof_words;         /* cyclic circuit: words of one proof in target order (caps, openings, FRI); 0 for the dummy circuit */
 } vpbs_ivc_circuit;
 typedef struct vpbs_ivc vpbs_ivc;
@@ -518,7 +560,7 @@ typedef struct {
     unsigned N, K, n_lwe;
     size_t ggsw_len;          /* K ELL K N: words of one flattened GGSW */
     const uint64_t* testv;    /* [N] */
-    const uint64_t* out_ct;   /* [K][N] the bootstrapped ciphertext the caller holds, or NULL to skip that comparison */
+    const uint64_t* out_ct;   /* [K][N] the bootstrapped ciphertext the caller holds; required (the reference asserts it, :440-442) */
     const uint64_t* ct;       /* [n_lwe + 1] the LWE input */
     const uint64_t* bsk;      /* [n_lwe][ggsw_len] NTT domain, Ggsw::flatten order */
     const uint64_t* ksk;      /* [ggsw_len] */

@@ -6,6 +6,7 @@
  * Pinned by the upstream KATs in tests/golden/poseidon_kat.json. */
 #include "vpbs_oracle.h"
 #include "poseidon_constants.h"
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -48,6 +49,44 @@ void orc_hash_no_pad(const u64* in, size_t n, u64 out[4]) {
         orc_poseidon(s);
     }
     memcpy(out, s, 4 * sizeof(u64));
+}
+
+/* Hasher::hash_pad (plonk/config.rs): padded_input.push(ONE); while (len + 1) % RATE != 0 push(ZERO); push(ONE); hash_no_pad */
+void orc_hash_pad(const u64* in, size_t n, u64 out[4]) {
+    size_t len = n + 1;
+    while ((len + 1) % 8 != 0) ++len;
+    ++len;
+    u64* buf = (u64*)calloc(len, sizeof(u64));
+    if (n) memcpy(buf, in, n * sizeof(u64));
+    buf[n] = 1;
+    buf[len - 1] = 1;
+    orc_hash_no_pad(buf, len, out);
+    free(buf);
+}
+
+void orc_compat_default(orc_compat* out) {
+    out->fri_mul_final_by_x = 0;
+    out->bytes_pi_len_prefix = 1;
+    out->digest_domain_separator = 1;
+    out->pow_smallest_nonce = 1;
+}
+
+/* plonk/circuit_builder.rs build(): circuit_digest_parts = [constants_sigmas_cap.flatten(), hash_pad(domain_separator = []).to_vec(),
+ * [degree_bits]]; circuit_digest = hash_no_pad(concat).  The reference sets no domain separator (ivc_based_vpbs.rs:190-276). */
+void orc_circuit_digest(const orc_compat* compat, const u64* cap, size_t cap_words, unsigned degree_bits, u64 out[4]) {
+    orc_compat k;
+    orc_compat_default(&k);
+    if (compat) k = *compat;
+    u64* buf = (u64*)calloc(cap_words + 5, sizeof(u64));
+    size_t len = cap_words;
+    memcpy(buf, cap, cap_words * sizeof(u64));
+    if (k.digest_domain_separator) {
+        orc_hash_pad(NULL, 0, buf + len);
+        len += 4;
+    }
+    buf[len++] = degree_bits;
+    orc_hash_no_pad(buf, len, out);
+    free(buf);
 }
 
 void orc_hash_or_noop(const u64* in, size_t n, u64 out[4]) {

@@ -44,8 +44,24 @@ void orc_poseidon_batch(u64* states, size_t n);                 /* n independent
 void orc_hash_no_pad(const u64* in, size_t n, u64 out[4]);      /* PoseidonHash::hash_no_pad   */
 void orc_hash_or_noop(const u64* in, size_t n, u64 out[4]);     /* H::hash_or_noop             */
 void orc_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]);/* H::two_to_one               */
+/* Hasher::hash_pad (plonk/config.rs): pad10*1 -- push 1, zeros until len + 1 is a multiple of the rate 8, push 1 -- then hash_no_pad */
+void orc_hash_pad(const u64* in, size_t n, u64 out[4]);
 /* hash chain of verify_hash_output, /root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78 */
 void orc_hash_chain(const u64* data, size_t n_items, size_t item_len, u64 out[4]);
+
+/* ---- compatibility switch table: the oracle's copy of include/vpbs_prover.h `vpbs_compat` (same fields, same order, same defaults).
+ *      Every restated choice of plonky2 0.2.0 that changes proof words or bytes and that no vector in this repository pins:
+ *        fri_mul_final_by_x       fri/oracle.rs prove_openings / fri/verifier.rs fri_combine_initial   (0 = 0.2.0 as restated)
+ *        bytes_pi_len_prefix      util/serialization write_proof_with_public_inputs                    (1)
+ *        digest_domain_separator  plonk/circuit_builder.rs build(): cap || hash_pad([]) || degree_bits (1)
+ *        pow_smallest_nonce       fri/prover.rs fri_proof_of_work: smallest valid nonce (forced_pow reproduces a captured one) (1)
+ *      tests/step_oracle.py applies it to the transcript, the FRI parameters and the byte layout. ---- */
+typedef struct {
+    int fri_mul_final_by_x, bytes_pi_len_prefix, digest_domain_separator, pow_smallest_nonce;
+} orc_compat;
+void orc_compat_default(orc_compat* out);
+/* CircuitBuilder::build's circuit_digest from the constants/sigmas cap and the degree; compat NULL = default */
+void orc_circuit_digest(const orc_compat* compat, const u64* cap, size_t cap_words, unsigned degree_bits, u64 out[4]);
 
 /* ---- FFT for proving (plonky2_field fft.rs / polynomial/mod.rs) ---- */
 void orc_fft(u64* a, unsigned log_n);   /* coeffs -> values on <w_n>, natural order in and out */

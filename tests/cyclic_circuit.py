@@ -13,8 +13,9 @@ verifies the same proofs natively.
 
 Differences from plonky2, stated: row placement and gadget packing are this builder's own; the base case uses ONE proof slot and selects the
 verifier data (the cyclic circuit's own, or the dummy circuit's) instead of selecting between two proof slots -- the proof is prover-supplied
-either way; the circuit digest is a host convention (`circuit_digest` below), carried like plonky2's in the verifier data.  Parity with the
-crate is unpinned; the semantics are those of the reference: ONE proof attests to the whole chain.
+either way.  The circuit digest is CircuitBuilder::build's (`circuit_digest` below: cap, hash_pad of the empty domain separator, degree bits),
+carried in the verifier data.  Parity with the crate is unpinned; the semantics are those of the reference: ONE proof attests to
+the whole chain.
 """
 import numpy as np
 
@@ -591,9 +592,20 @@ class Shape:
         return out
 
 
-def circuit_digest(cs_cap, log_n):
-    """host convention for verifier_only.circuit_digest (plonky2 hashes the constants/sigmas cap with the degree and domain separator)"""
-    return np.array(pymodel.hash_no_pad([int(x) for x in np.asarray(cs_cap).reshape(-1)] + [log_n]), np.uint64)
+def hash_pad(words=()):
+    """Hasher::hash_pad (plonk/config.rs): pad10*1 to a multiple of the rate 8, then hash_no_pad"""
+    padded = [int(x) for x in words] + [1]
+    while (len(padded) + 1) % 8:
+        padded.append(0)
+    return pymodel.hash_no_pad(padded + [1])
+
+
+def circuit_digest(cs_cap, log_n, domain_separator=True):
+    """verifier_only.circuit_digest as CircuitBuilder::build derives it (plonk/circuit_builder.rs): hash_no_pad(constants_sigmas_cap ||
+    hash_pad(domain_separator = []) || degree_bits); domain_separator=False: the formula without the separator (the other position of
+    vpbs_compat.digest_domain_separator)"""
+    sep = [int(x) for x in hash_pad()] if domain_separator else []
+    return np.array(pymodel.hash_no_pad([int(x) for x in np.asarray(cs_cap).reshape(-1)] + sep + [log_n]), np.uint64)
 
 
 class CircuitChallenger:
@@ -885,6 +897,6 @@ class CyclicStepCircuit:
         return self.built.values(wires, self.built.public_inputs)
 
 
-def vk_words(cs_cap, log_n):
+def vk_words(cs_cap, log_n, domain_separator=True):
     """verifier data as the 68 words the public inputs carry: circuit digest, then the constants/sigmas cap"""
-    return np.concatenate([circuit_digest(cs_cap, log_n), np.asarray(cs_cap, np.uint64).reshape(-1)])
+    return np.concatenate([circuit_digest(cs_cap, log_n, domain_separator), np.asarray(cs_cap, np.uint64).reshape(-1)])

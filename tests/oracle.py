@@ -36,6 +36,30 @@ class FriParams(C.Structure):
                 ("mul_final_by_x", C.c_int)]
 
 
+class Compat(C.Structure):
+    """orc_compat = the oracle's copy of include/vpbs_prover.h vpbs_compat (the switch table of the unpinned plonky2 choices)"""
+    _fields_ = [("fri_mul_final_by_x", C.c_int), ("bytes_pi_len_prefix", C.c_int), ("digest_domain_separator", C.c_int),
+                ("pow_smallest_nonce", C.c_int)]
+
+
+COMPAT_FIELDS = ("fri_mul_final_by_x", "bytes_pi_len_prefix", "digest_domain_separator", "pow_smallest_nonce")
+
+
+def compat(**over):
+    """the default table (plonky2 0.2.0 as restated) with the given switches changed"""
+    k = Compat()
+    lib().orc_compat_default(C.byref(k))
+    for name, v in over.items():
+        assert name in COMPAT_FIELDS, name
+        setattr(k, name, int(v))
+    return k
+
+
+def compat_dict(k=None):
+    k = k if k is not None else compat()
+    return {name: int(getattr(k, name)) for name in COMPAT_FIELDS}
+
+
 class FriBatchInfo(C.Structure):
     _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_size_t), ("oracle_index", U32P), ("poly_index", U32P)]
 
@@ -75,6 +99,8 @@ def lib():
             "orc_ext_mul": (None, [U64P, U64P, U64P]), "orc_ext_inv": (None, [U64P, U64P]),
             "orc_poseidon": (None, [U64P]), "orc_poseidon_batch": (None, [U64P, sz]),
             "orc_hash_no_pad": (None, [U64P, sz, U64P]), "orc_hash_or_noop": (None, [U64P, sz, U64P]),
+            "orc_hash_pad": (None, [U64P, sz, U64P]), "orc_compat_default": (None, [C.POINTER(Compat)]),
+            "orc_circuit_digest": (None, [C.POINTER(Compat), U64P, sz, ui, U64P]),
             "orc_two_to_one": (None, [U64P, U64P, U64P]), "orc_hash_chain": (None, [U64P, sz, sz, U64P]),
             "orc_fft": (None, [U64P, ui]), "orc_ifft": (None, [U64P, ui]),
             "orc_coset_lde": (None, [U64P, ui, ui, u64, U64P]),
@@ -132,6 +158,19 @@ def poseidon(state):
 def hash_no_pad(x):
     x = u64arr(x); out = np.zeros(4, np.uint64)
     lib().orc_hash_no_pad(ptr(x), x.size, ptr(out))
+    return out
+
+
+def hash_pad(x):
+    x = u64arr(x).reshape(-1); out = np.zeros(4, np.uint64)
+    lib().orc_hash_pad(ptr(x) if x.size else None, x.size, ptr(out))
+    return out
+
+
+def circuit_digest(cs_cap, log_n, k=None):
+    """CircuitBuilder::build's circuit_digest (formula: compat.digest_domain_separator)"""
+    cap = u64arr(cs_cap).reshape(-1); out = np.zeros(4, np.uint64)
+    lib().orc_circuit_digest(C.byref(k) if k is not None else None, ptr(cap), cap.size, log_n, ptr(out))
     return out
 
 

@@ -27,9 +27,10 @@ def commit_inputs(inputs, rate_bits=3, cap_height=4):
 
 
 def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, forced_pow=orc.POW_ANY, cs_batch=None,
-               sigmas=None, n_routed=0, n_constants=0, gates=None):
+               sigmas=None, n_routed=0, n_constants=0, gates=None, compat=None):
     """sigmas given: the Z / partial-product matrix is computed from the wires and the transcript's betas/gammas
-    (all_wires_permutation_partial_products) instead of being read from inputs["zs_partial_products"]."""
+    (all_wires_permutation_partial_products) instead of being read from inputs["zs_partial_products"].
+    compat: an orc.Compat (the switch table, oracle/vpbs_oracle.h); None = the defaults."""
     rate_bits, cap_height = 3, 4
     cs = cs_batch if cs_batch is not None else orc.Batch(inputs["constants_sigmas"], rate_bits, cap_height, True)
     pi_hash = orc.hash_no_pad(public_inputs)
@@ -61,14 +62,14 @@ def prove_step(inputs, circuit_digest, public_inputs, log_n, num_challenges=2, f
     batches, zeta_next = step_batches(ncols, num_challenges, zeta, log_n)
     openings = np.concatenate([o.eval_ext(zeta) for o in oracles] + [zs.eval_ext(zeta_next)[:num_challenges]])
     ch.observe(openings)
-    params = orc.fri_params(log_n)
+    params = orc.fri_params(log_n, mul_final_by_x=(compat.fri_mul_final_by_x if compat is not None else 0))
     fri = orc.prove_openings(oracles, batches, ch, params, log_n, forced_pow)
     return {"caps": np.stack([wires.cap(), zs.cap(), quot.cap()]), "openings": openings, "fri": fri,
             "challenger": ch, "challenges": np.array(betas + gammas + alphas + [int(zeta[0]), int(zeta[1])], np.uint64),
             "cs_cap": cs.cap(), "ncols": ncols}
 
 
-def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2):
+def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, compat=None):
     """Verifier side of the same transcript + verify_fri_proof (checks a proof without recomputing any commitment)."""
     ch = orc.ChallengerState()
     ch.observe(circuit_digest)
@@ -84,11 +85,11 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     openings = [proof["openings"][:total], proof["openings"][total:]]
     ch.observe(proof["openings"])
     caps = [cs_cap, proof["caps"][0], proof["caps"][1], proof["caps"][2]]
-    params = orc.fri_params(log_n)
+    params = orc.fri_params(log_n, mul_final_by_x=(compat.fri_mul_final_by_x if compat is not None else 0))
     return orc.verify_fri(caps, ncols, batches, openings, ch, params, log_n, proof["fri"])
 
 
-def to_bytes(proof, ncols, n_constants, public_inputs, log_n, num_challenges=2, cap_height=4, rate_bits=3):
+def to_bytes(proof, ncols, n_constants, public_inputs, log_n, num_challenges=2, cap_height=4, rate_bits=3, compat=None):
     """ProofWithPublicInputs::to_bytes restated in Python (SURVEY.md Appendix A.8) from the flat proof pieces."""
     import struct
     out = bytearray()
@@ -125,6 +126,7 @@ def to_bytes(proof, ncols, n_constants, public_inputs, log_n, num_challenges=2, 
             out.append(lg - cap_height)
             put(take(4 * (lg - cap_height)))
     put(take(fri.size - pos))
-    out.extend(struct.pack("<Q", len(public_inputs)))
+    if compat is None or compat.bytes_pi_len_prefix:       # write_usize(public_inputs.len())
+        out.extend(struct.pack("<Q", len(public_inputs)))
     put(np.asarray(public_inputs, dtype=np.uint64))
     return bytes(out)

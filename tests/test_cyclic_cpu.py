@@ -193,7 +193,8 @@ def test_ivc_chain_on_the_cpu():
         return api.verify_pbs(blob, cap, proof["ncols"], digest, log_n, C.nconst, 80, C.ps, N, K, testv, ct, bsk, ksk, out_ct=out_ct)
 
     assert vp() == (True, "")
-    assert vp(out_ct=None)[0]
+    with pytest.raises(api.VpbsError):       # the output ciphertext is part of the statement: no verdict without it
+        vp(out_ct=None)
     # the chain is deterministic (smallest proof-of-work nonce): its last proof is frozen, and the GPU chain of the same inputs
     # (test_gpu_step_circuit.py::test_ivc_chain_bit_identical_to_the_cpu_oracle_chain) must produce the same bytes
     import hashlib
@@ -219,4 +220,4 @@ def test_ivc_chain_on_the_cpu():
     assert vp(cap=D.cap, digest=D.vk[:4])[0] is False                  # the dummy circuit's verifier data: the proof does not verify there
     # an earlier proof of the chain: valid, but its counter is not n + 2
     p1, pis1 = proofs[1]
-    assert vp(blob=step_oracle.to_bytes(p1, p1["ncols"], C.nconst, pis1, log_n), out_ct=None) == (False, "the counter is not n + 2")
+    assert vp(blob=step_oracle.to_bytes(p1, p1["ncols"], C.nconst, pis1, log_n), out_ct=pis1[kn + 1:2 * kn + 1]) == (False, "the counter is not n + 2")

@@ -59,22 +59,31 @@ def _gate_spec(meta):
     return [(api.GATE_KINDS[k] if isinstance(k, int) else k, p0, p1, p2) for k, p0, p1, p2 in meta["gates"]]
 
 
+def _switches(m):
+    """the fixture's position of the switch table (written by tools/plonky2_capture/to_fixture.py; absent = the defaults)"""
+    return {k: v for k, v in m.get("compat", {}).items()}
+
+
 def check_with_oracle(fx):
     """the CPU oracle against the fixture"""
     import gates_oracle as go
     m = fx["meta"]
     nc = m["num_challenges"]
+    ko = orc.compat(**_switches(m))
     supplied = fx["zs_partial_products_values"] is not None
     sig = np.ascontiguousarray(fx["constants_sigmas_values"][m["n_constants"]:])
     if supplied:
         inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"],
                   "zs_partial_products": fx["zs_partial_products_values"], "quotient": fx["quotient_coeffs"]}
-        p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=nc, forced_pow=int(fx["fri"][-1]))
+        p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=nc, forced_pow=int(fx["fri"][-1]),
+                                   compat=ko)
     else:   # Z / partial products and the quotient (gate constraints + permutation argument) recomputed from the wires
         inputs = {"constants_sigmas": fx["constants_sigmas_values"], "wires": fx["witness_wires"], "quotient": None}
         p = step_oracle.prove_step(inputs, fx["circuit_digest"], fx["public_inputs"], m["log_n"], num_challenges=nc, forced_pow=int(fx["fri"][-1]),
-                                   sigmas=sig, n_routed=m["n_routed"], n_constants=m["n_constants"], gates=go.GateSet(_gate_spec(m)))
+                                   sigmas=sig, n_routed=m["n_routed"], n_constants=m["n_constants"], gates=go.GateSet(_gate_spec(m)), compat=ko)
     assert (p["cs_cap"] == fx["constants_sigmas_cap"]).all(), "constants_sigmas cap"
+    if "compat" in m:   # a real capture: the digest is CircuitBuilder::build's, in the formula the converter found
+        assert orc.circuit_digest(p["cs_cap"], m["log_n"], ko).tolist() == fx["circuit_digest"].tolist(), "circuit digest"
     for i, name in enumerate(("wires", "zs_partial_products", "quotient")):
         assert (p["caps"][i] == fx["caps"][i]).all(), name + " cap"
     if fx["challenges"] is not None:
@@ -82,7 +91,7 @@ def check_with_oracle(fx):
     assert (p["openings"] == fx["openings"]).all(), "openings"
     assert (p["fri"] == fx["fri"]).all(), "FRI proof"
     if fx["proof_bytes"] is not None:
-        got = step_oracle.to_bytes(p, p["ncols"], m["n_constants"], fx["public_inputs"], m["log_n"], num_challenges=nc)
+        got = step_oracle.to_bytes(p, p["ncols"], m["n_constants"], fx["public_inputs"], m["log_n"], num_challenges=nc, compat=ko)
         assert got == fx["proof_bytes"], "proof bytes"
     if supplied:
         # the permutation argument's partial products are recomputable from the wires and the transcript
@@ -93,6 +102,16 @@ def check_with_oracle(fx):
 
 def check_with_product(ctx, fx):
     """the HIP path (through the C ABI) against the fixture"""
+    m = fx["meta"]
+    log_n, nc = m["log_n"], m["num_challenges"]
+    kp = ctx.set_compat(**_switches(m))
+    try:
+        _check_with_product(ctx, fx, kp)
+    finally:
+        ctx.set_compat()
+
+
+def _check_with_product(ctx, fx, kp):
     m = fx["meta"]
     log_n, nc = m["log_n"], m["num_challenges"]
     cs = ctx.commit_values(fx["constants_sigmas_values"])
@@ -112,7 +131,7 @@ def check_with_product(ctx, fx):
         if fx["proof_bytes"] is not None:
             assert ctx.step_proof_to_bytes(si, m["n_constants"], p) == fx["proof_bytes"], "proof bytes"
         ncols = [cs.ncols, m["n_wires"], fx["zs_partial_products_values"].shape[0], fx["quotient_coeffs"].shape[0]]
-        assert api.verify_step_fri_only(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc)
+        assert api.verify_step(p, cs.cap(), ncols, fx["circuit_digest"], fx["public_inputs"], log_n, num_challenges=nc, check_permutation=False, compat=kp)
         ch = [int(x) for x in p["challenges"]]
         zs = ctx.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
         assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
@@ -128,7 +147,7 @@ def check_with_product(ctx, fx):
         if fx["proof_bytes"] is not None:
             assert ctx.step_proof_to_bytes(si2, m["n_constants"], p2) == fx["proof_bytes"], "proof bytes"
         assert api.verify_step(p2, cs.cap(), [cs.ncols, m["n_wires"], 20, 16], fx["circuit_digest"], fx["public_inputs"], log_n,
-                               num_challenges=nc, n_constants=m["n_constants"], n_routed=m["n_routed"], gates=gates)
+                               num_challenges=nc, n_constants=m["n_constants"], n_routed=m["n_routed"], gates=gates, compat=kp)
     cs.free()
 
 
@@ -192,8 +211,12 @@ def test_fixture_roundtrip_with_an_oracle_made_fixture(tmp_path):
         check_with_oracle(fx)
 
 
-def test_public_api_capture_layout_converts_and_checks(tmp_path):
-    """what tools/plonky2_capture/capture.rs writes (a capture through plonky2's PUBLIC API: no Z / quotient / challenges files, gate ids
+@pytest.mark.parametrize("position", [{}, dict(fri_mul_final_by_x=1, bytes_pi_len_prefix=0, digest_domain_separator=0),
+                                      dict(bytes_pi_len_prefix=0), dict(fri_mul_final_by_x=1)], ids=["defaults", "all_moved", "no_prefix", "mul_x"])
+def test_public_api_capture_layout_converts_and_checks(tmp_path, position):
+    """(the simulated capture is made under `position` of the switch table: the converter has to FIND that position from the files alone
+    and record it, and the golden checks then run under it)
+    what tools/plonky2_capture/capture.rs writes (a capture through plonky2's PUBLIC API: no Z / quotient / challenges files, gate ids
     instead of a gate list, the copy-constraint forest) -> tools/plonky2_capture/to_fixture.py -> the fixture the golden tests consume and
     the STEPCIRC circuit file; exercised on a capture simulated from this repository's own stack."""
     import subprocess
@@ -210,18 +233,20 @@ def test_public_api_capture_layout_converts_and_checks(tmp_path):
     pis = [rnd.randrange(go.P) for _ in range(4)]
     constants, wires, sigma, _, desc = go.demo_circuit(rnd, gs, log_n, pis, describe=True)
     cs_values = np.concatenate([constants, sigma])
-    digest = np.array([9, 8, 7, 6], np.uint64)
+    ko = orc.compat(**position)
+    digest = orc.circuit_digest(orc.Batch(cs_values, 3, 4, True).cap(), log_n, ko)
     p = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, digest, pis, log_n, sigmas=sigma, n_routed=80,
-                               n_constants=constants.shape[0], gates=gs)
+                               n_constants=constants.shape[0], gates=gs, compat=ko)
     cap_dir = str(tmp_path / "capture")
     to_fixture.simulate_capture(cap_dir, ps, log_n, cs_values, constants.shape[0], wires, desc, digest, pis, p,
-                                step_oracle.to_bytes(p, p["ncols"], constants.shape[0], pis, log_n))
+                                step_oracle.to_bytes(p, p["ncols"], constants.shape[0], pis, log_n, compat=ko))
     out, circ = str(tmp_path / "fixture"), str(tmp_path / "circuit.bin")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plonky2_capture", "to_fixture.py"), cap_dir, out, "--step", "0", "--circuit", circ],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     fx = load_fixture(out)
     assert fx["zs_partial_products_values"] is None and fx["meta"]["gates"]
+    assert fx["meta"]["compat"] == {**orc.compat_dict(), **position} and fx["meta"]["forced_pow"] == int(p["fri"][-1])
     check_with_oracle(fx)
     d = circuit_file.load(circ)
     assert (d.circuit.sigma_values() == sigma).all()                       # the forest -> copy constraints -> the captured sigma columns

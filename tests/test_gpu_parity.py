@@ -400,6 +400,50 @@ def test_step_proof_bit_exact(ctx, log_n, cols):
         assert api.verify_step_fri_only(back, want["cs_cap"], want["ncols"], DIGEST, back_pis, log_n)
 
 
+@pytest.mark.parametrize("pos", [dict(fri_mul_final_by_x=m, bytes_pi_len_prefix=b, digest_domain_separator=d) for m in (0, 1) for b in (0, 1)
+                                 for d in (0, 1)], ids=lambda p: "x%d_pi%d_ds%d" % tuple(p.values()))
+def test_every_compat_position_bit_exact(ctx, pos):
+    """The switch table of include/vpbs_prover.h (vpbs_compat): under every position the device prover, the serialiser, the oracle and the
+    product's host verifier agree word for word -- one capture of a real plonky2 proof then picks the position, nothing else has to move.
+    The whole prover on the device (partial products, gate constraints, quotient) on a satisfiable circuit, so the full verifier runs."""
+    import random
+    import gates_oracle as go
+    gate_spec = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon"]
+    gs, ps = go.GateSet(gate_spec), api.GateSet(gate_spec)
+    rnd = random.Random(11)
+    log_c = 6
+    cpis = [rnd.randrange(api.P) for _ in range(4)]
+    constants, wires, sigma, _ = go.demo_circuit(rnd, gs, log_c, cpis)
+    cs_values = np.concatenate([constants, sigma])
+    nconst = constants.shape[0]
+    ko = orc.compat(**pos)
+    kp = ctx.set_compat(**pos)
+    try:
+        assert api.compat_dict(ctx.get_compat()) == api.compat_dict(kp)
+        cs = ctx.commit_values(cs_values)
+        digest = api.circuit_digest(cs.cap(), log_c, kp)
+        assert digest.tolist() == orc.circuit_digest(cs.cap(), log_c, ko).tolist()
+        si = ctx.make_step_inputs(log_c, wires, None, None, cs, digest, cpis, sigmas=sigma, n_routed=80, n_constants=nconst, gates=ps)
+        got = ctx.prove_step(si)
+        want = step_oracle.prove_step({"constants_sigmas": cs_values, "wires": wires, "quotient": None}, digest, cpis, log_c, sigmas=sigma,
+                                      n_routed=80, n_constants=nconst, gates=gs, compat=ko)
+        for key in ("caps", "challenges", "openings", "fri"):
+            assert (got[key] == want[key]).all(), key
+        blob = ctx.step_proof_to_bytes(si, nconst, got)
+        assert blob == step_oracle.to_bytes(want, want["ncols"], nconst, cpis, log_c, compat=ko)
+        back, back_pis = api.step_proof_from_bytes(blob, want["ncols"], log_c, nconst, compat=kp)
+        assert back_pis.tolist() == cpis
+        full = dict(check_permutation=True, n_constants=nconst, n_routed=80, gates=ps)
+        assert api.verify_step(back, cs.cap(), want["ncols"], digest, back_pis, log_c, compat=kp, **full)
+        assert step_oracle.verify_step(got, want["cs_cap"], want["ncols"], digest, cpis, log_c, compat=ko)
+        assert not api.verify_step(back, cs.cap(), want["ncols"], digest, back_pis, log_c,
+                                   compat=api.compat(**{**pos, "fri_mul_final_by_x": 1 - pos["fri_mul_final_by_x"]}), **full)
+    finally:
+        ctx.set_compat()
+    with pytest.raises(api.VpbsError):     # "first found" nonces are not a position of this build
+        ctx.set_compat(pow_smallest_nonce=0)
+
+
 @pytest.mark.parametrize("log_n", [7, 12])
 def test_step_proof_with_device_partial_products(ctx, log_n):
     """The step with a12 inside: Z / partial products computed on the GPU from the wires, the sigma columns of the

@@ -345,3 +345,68 @@ def test_host_poseidon_batches_match_the_oracle():
         rc = api.lib().vpbs_k_poseidon_host(api._ptr(got) if n else None, n)
         assert rc in (0, 1)
         assert all((got[i] == orc.poseidon(st[i])).all() for i in range(n))
+
+
+COMPAT_POSITIONS = [dict(fri_mul_final_by_x=m, bytes_pi_len_prefix=b, digest_domain_separator=d) for m in (0, 1) for b in (0, 1) for d in (0, 1)]
+
+
+def test_compat_defaults_and_digest_agree_with_the_oracle():
+    """the switch table of include/vpbs_prover.h and its copy in oracle/vpbs_oracle.h: same fields, same defaults; hash_pad and the circuit
+    digest of CircuitBuilder::build agree in both formulas, and with a third restatement in plain Python (tests/cyclic_circuit.py)"""
+    import cyclic_circuit as cc
+    assert api.compat_dict() == orc.compat_dict() == dict(fri_mul_final_by_x=0, bytes_pi_len_prefix=1, digest_domain_separator=1, pow_smallest_nonce=1)
+    for words in ([], [5], list(range(1, 7)), list(range(1, 8)), list(range(1, 9)), list(range(3, 23))):
+        assert api.hash_pad(words).tolist() == orc.hash_pad(words).tolist() == [int(x) for x in cc.hash_pad(words)]
+    # pad10*1: the empty message is the block 1, 0, 0, 0, 0, 0, 0, 1
+    assert api.hash_pad([]).tolist() == api.hash_no_pad([1, 0, 0, 0, 0, 0, 0, 1]).tolist()
+    cap = synth.field_elements(31, 64).reshape(16, 4)
+    sep = api.hash_pad([])
+    for ds in (0, 1):
+        want = api.hash_no_pad(np.concatenate([cap.reshape(-1), sep if ds else sep[:0], np.array([13], np.uint64)]))
+        assert api.circuit_digest(cap, 13, api.compat(digest_domain_separator=ds)).tolist() == want.tolist()
+        assert orc.circuit_digest(cap, 13, orc.compat(digest_domain_separator=ds)).tolist() == want.tolist()
+        assert cc.circuit_digest(cap, 13, bool(ds)).tolist() == want.tolist()
+    assert api.circuit_digest(cap, 13).tolist() == api.circuit_digest(cap, 13, api.compat()).tolist()   # NULL = the defaults
+    with pytest.raises(ValueError):
+        api.compat(no_such_switch=1)
+
+
+@pytest.mark.parametrize("pos", COMPAT_POSITIONS, ids=lambda p: "x%d_pi%d_ds%d" % tuple(p.values()))
+def test_every_compat_position_oracle_prover_vs_product_verifier(pos):
+    """Every position of the switch table, oracle prover against the product's host-side parser and verifier (the device prover against the
+    oracle under every position: test_gpu_parity.py::test_every_compat_position_bit_exact): bytes made under a position parse and verify under
+    the same position, and each switch that changes the proof is noticed when the two sides disagree."""
+    import step_oracle
+    log_n = 6
+    cols = {"constants_sigmas": 9, "wires": 12, "zs_partial_products": 4, "quotient": 16}
+    inputs = synth.step_inputs(log_n, cols=cols)
+    pis = synth.field_elements(5, 9)
+    ko, kp = orc.compat(**pos), api.compat(**pos)
+    cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)
+    digest = orc.circuit_digest(cs.cap(), log_n, ko)
+    assert digest.tolist() == api.circuit_digest(cs.cap(), log_n, kp).tolist()
+    proof = step_oracle.prove_step(inputs, digest, pis, log_n, cs_batch=cs, compat=ko)
+    ncols = proof["ncols"]
+    assert step_oracle.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n, compat=ko)
+    blob = step_oracle.to_bytes(proof, ncols, 1, pis, log_n, compat=ko)
+    back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, 1, compat=kp)
+    assert back_pis.tolist() == pis.tolist()
+    for key in ("caps", "openings", "fri"):
+        assert (back[key].reshape(-1) == proof[key].reshape(-1)).all()
+    assert api.verify_step(back, proof["cs_cap"], ncols, digest, back_pis, log_n, check_permutation=False, compat=kp)
+    # the other position of each switch
+    flipped = lambda name: api.compat(**{**pos, name: 1 - pos[name]})
+    assert not api.verify_step(back, proof["cs_cap"], ncols, digest, back_pis, log_n, check_permutation=False, compat=flipped("fri_mul_final_by_x"))
+    assert not step_oracle.verify_step(proof, proof["cs_cap"], ncols, digest, pis, log_n, compat=orc.compat(**{**pos, "fri_mul_final_by_x": 1 - pos["fri_mul_final_by_x"]}))
+    other_digest = api.circuit_digest(cs.cap(), log_n, flipped("digest_domain_separator"))
+    assert other_digest.tolist() != digest.tolist()
+    assert not api.verify_step(back, proof["cs_cap"], ncols, other_digest, back_pis, log_n, check_permutation=False, compat=kp)
+    if pos["bytes_pi_len_prefix"]:
+        # read without the prefix the length word becomes a tenth public input: another statement, which does not verify
+        b2, p2 = api.step_proof_from_bytes(blob, ncols, log_n, 1, compat=flipped("bytes_pi_len_prefix"))
+        assert p2.tolist() == [len(pis)] + pis.tolist()
+        assert not api.verify_step(b2, proof["cs_cap"], ncols, digest, p2, log_n, check_permutation=False, compat=kp)
+    else:
+        # read with the prefix the first public input is taken for a length that the buffer does not have
+        with pytest.raises(api.VpbsError):
+            api.step_proof_from_bytes(blob, ncols, log_n, 1, compat=flipped("bytes_pi_len_prefix"))

@@ -78,6 +78,51 @@ def gate_set_from_ids(meta):
     return spec, gs
 
 
+def detect_compat(src, meta):
+    """Which position of the switch table (include/vpbs_prover.h `vpbs_compat`) reproduces this capture: every switch is decided from the
+    captured files alone, on the host (no device, no prover):
+      digest_domain_separator  the captured circuit_digest against vpbs_circuit_digest(cap, degree_bits) in both formulas
+      bytes_pi_len_prefix      which reading of proof_bytes.bin gives back the captured proof words and public inputs
+      fri_mul_final_by_x       under which position the product's verifier (transcript + PoW + Merkle paths + FRI) accepts the captured proof
+    A switch that no position satisfies is an error naming it: that is the finding a capture run exists to make.  The captured pow_witness is
+    recorded as forced_pow (the crate's find_any may return any valid nonce)."""
+    rd = lambda name: np.fromfile(os.path.join(src, name + ".u64"), dtype="<u8")
+    log_n, nc = meta["log_n"], meta["num_challenges"]
+    qdf = meta.get("quotient_degree_factor", 8)
+    ncols = [meta["n_constants"] + meta["n_routed"], meta["n_wires"], nc * ((meta["n_routed"] + qdf - 1) // qdf), nc * qdf]
+    cap, digest, pis = rd("constants_sigmas_cap"), rd("circuit_digest"), rd("public_inputs")
+    proof = {"caps": rd("caps"), "openings": rd("openings"), "fri": rd("fri")}
+    found = {}
+    hits = [ds for ds in (1, 0) if api.circuit_digest(cap, log_n, api.compat(digest_domain_separator=ds)).tolist() == digest.tolist()]
+    if not hits:
+        raise ValueError("circuit_digest: neither hash_no_pad(cap || hash_pad([]) || degree_bits) nor hash_no_pad(cap || degree_bits) gives the "
+                         "captured digest -- CircuitBuilder::build's formula is restated wrongly")
+    found["digest_domain_separator"] = hits[0]
+    pb = os.path.join(src, "proof_bytes.bin")
+    if os.path.exists(pb):
+        blob, hits = open(pb, "rb").read(), []
+        for prefix in (1, 0):
+            try:
+                back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, meta["n_constants"], num_challenges=nc,
+                                                           compat=api.compat(bytes_pi_len_prefix=prefix), max_public_inputs=len(pis) + 8)
+            except api.VpbsError:
+                continue
+            if back_pis.tolist() == pis.tolist() and all((back[k].reshape(-1) == proof[k].reshape(-1)).all() for k in proof):
+                hits.append(prefix)
+        if not hits:
+            raise ValueError("proof_bytes.bin: neither byte layout (public inputs with / without a length prefix) parses back into the captured "
+                             "proof words -- the layout of util/serialization is restated wrongly")
+        found["bytes_pi_len_prefix"] = hits[0]
+    hits = [x for x in (0, 1) if api.verify_step(proof, cap, ncols, digest, pis, log_n, num_challenges=nc, check_permutation=False,
+                                                 compat=api.compat(fri_mul_final_by_x=x))]
+    if not hits:
+        raise ValueError("the captured proof is rejected by the product's verifier under both positions of fri_mul_final_by_x: the transcript "
+                         "order, the FRI combination or the Merkle conventions are restated wrongly")
+    found["fri_mul_final_by_x"] = hits[0]
+    k = api.compat_dict(api.compat(**found))
+    return k, int(proof["fri"][-1])
+
+
 def convert_step(cap_dir, step, out_dir):
     src = os.path.join(cap_dir, "step_%03d" % step)
     meta = json.load(open(os.path.join(src, "meta.json")))
@@ -87,6 +132,8 @@ def convert_step(cap_dir, step, out_dir):
         if f != "meta.json":
             shutil.copy(os.path.join(src, f), os.path.join(out_dir, f))
     meta["gates"] = [[g.kind, g.p0, g.p1, g.p2] for g in gs]
+    # the position of the switch table that reproduces the capture: the golden tests prove and serialise under it
+    meta["compat"], meta["forced_pow"] = detect_compat(src, meta)
     json.dump(meta, open(os.path.join(out_dir, "meta.json"), "w"))
     return meta, gs
 
@@ -172,6 +219,10 @@ def main():
     meta, gs = convert_step(cap_dir, step, out_dir)
     print("fixture: step %d, degree 2^%d, %d gates (ids and selector layout agree with the prover's), %d public inputs -> %s" %
           (step, meta["log_n"], gs.n, meta["n_public_inputs"], out_dir))
+    default = api.compat_dict()
+    moved = {k: v for k, v in meta["compat"].items() if default[k] != v}
+    print("switch table: %s%s; pow_witness %d recorded as forced_pow" %
+          (json.dumps(meta["compat"]), " -- DIFFERS from the defaults in " + ", ".join(sorted(moved)) if moved else " (the defaults)", meta["forced_pow"]))
     if "--circuit" in args:
         path = args[args.index("--circuit") + 1]
         n_copies = convert_circuit(cap_dir, path)

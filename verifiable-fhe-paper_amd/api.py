@@ -30,6 +30,31 @@ class FriParams(C.Structure):
                 ("mul_final_by_x", C.c_int)]
 
 
+class CompatC(C.Structure):
+    """vpbs_compat: the switch table of the unpinned plonky2 0.2.0 choices (include/vpbs_prover.h)"""
+    _fields_ = [("fri_mul_final_by_x", C.c_int), ("bytes_pi_len_prefix", C.c_int), ("digest_domain_separator", C.c_int),
+                ("pow_smallest_nonce", C.c_int)]
+
+
+COMPAT_FIELDS = tuple(f[0] for f in CompatC._fields_)
+
+
+def compat(**over):
+    """vpbs_compat_default with the given switches changed, e.g. compat(bytes_pi_len_prefix=0)"""
+    k = CompatC()
+    lib().vpbs_compat_default(C.byref(k))
+    for name, v in over.items():
+        if name not in COMPAT_FIELDS:
+            raise ValueError("no such switch: " + name)
+        setattr(k, name, int(v))
+    return k
+
+
+def compat_dict(k=None):
+    k = k if k is not None else compat()
+    return {name: int(getattr(k, name)) for name in COMPAT_FIELDS}
+
+
 class FriBatchInfoC(C.Structure):
     _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_size_t), ("oracle_index", U32P), ("poly_index", U32P)]
 
@@ -82,7 +107,7 @@ class VerifyInputsC(C.Structure):
                 ("num_challenges", C.c_uint), ("constants_sigmas_cap", U64P), ("circuit_digest", C.c_uint64 * 4),
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("fri_only", C.c_int),
                 ("n_constants", C.c_uint), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint), ("gate_terms_zeta", U64P),
-                ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint)]
+                ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint), ("compat", C.POINTER(CompatC))]
 
 
 class VerifyPbsInputsC(C.Structure):
@@ -135,6 +160,13 @@ SIGNATURES = {
     "vpbs_k_clock_probe": (_i, [_vp, C.POINTER(C.c_double)]),
     "vpbs_ctx_set_gate_lanes": (_i, [_vp, _ui]),
     "vpbs_ctx_stream": (_vp, [_vp]),
+    "vpbs_compat_default": (None, [C.POINTER(CompatC)]),
+    "vpbs_ctx_set_compat": (_i, [_vp, C.POINTER(CompatC)]),
+    "vpbs_ctx_get_compat": (_i, [_vp, C.POINTER(CompatC)]),
+    "vpbs_hash_pad": (None, [U64P, _sz, U64P]),
+    "vpbs_circuit_digest": (_i, [C.POINTER(CompatC), U64P, _sz, _ui, U64P]),
+    "vpbs_ctx_rate_bits": (_ui, [_vp]),
+    "vpbs_ctx_cap_height": (_ui, [_vp]),
     "vpbs_commit_values": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_commit_coeffs": (_i, [_vp, U64P, _ui, _ui, C.POINTER(_vp), U64P]),
     "vpbs_commit_values_dev": (_i, [_vp, _vp, _ui, _ui, C.POINTER(_vp), U64P]),
@@ -302,6 +334,24 @@ def hash_no_pad(x):
     x = _u64(x).reshape(-1)
     out = np.zeros(4, np.uint64)
     lib().vpbs_hash_no_pad(_ptr(x), x.size, _ptr(out))
+    return out
+
+
+def hash_pad(x=()):
+    """PoseidonHash::hash_pad (pad10*1, then hash_no_pad)"""
+    x = _u64(x).reshape(-1)
+    out = np.zeros(4, np.uint64)
+    lib().vpbs_hash_pad(_ptr(x) if x.size else None, x.size, _ptr(out))
+    return out
+
+
+def circuit_digest(cs_cap, log_n, k=None):
+    """vpbs_circuit_digest: verifier_only.circuit_digest as CircuitBuilder::build derives it (formula: compat.digest_domain_separator)"""
+    cap = _u64(cs_cap).reshape(-1)
+    out = np.zeros(4, np.uint64)
+    rc = lib().vpbs_circuit_digest(C.byref(k) if k is not None else None, _ptr(cap), cap.size, log_n, _ptr(out))
+    if rc:
+        raise VpbsError("vpbs_circuit_digest: malformed cap")
     return out
 
 
@@ -565,7 +615,7 @@ def hash_chain(items, claimed=None):
 
 
 def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=True, n_constants=0,
-                n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4, gates=None):
+                n_routed=0, quotient_degree_factor=8, gate_terms_zeta=None, rate_bits=3, cap_height=4, gates=None, compat=None):
     """Host-side verifier of the product library (plonky2 `verify`: transcript, vanishing identity at zeta -- permutation argument and the
     gate constraints, the PublicInputGate binding among them -- then verify_fri_proof).  True = accepted.  The full check is the default and
     needs the circuit's shape: n_constants, n_routed and its gates (or gate_terms_zeta, or neither for a circuit of NoopGates only).
@@ -591,6 +641,8 @@ def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_
     v.gate_terms_zeta = _ptr(gt) if gt is not None else None
     if gates is not None:
         v.gates, v.n_gates, v.num_selectors = gates.arr, gates.n, gates.num_selectors
+    if compat is not None:
+        v.compat = C.pointer(compat)
     caps, openings, fri = _u64(proof["caps"]), _u64(proof["openings"]), _u64(proof["fri"])
     rc = lib().vpbs_verify_step(C.byref(v), _ptr(caps), _ptr(openings), _ptr(fri))
     if rc < 0:
@@ -647,10 +699,11 @@ class Ivc:
             self.h = None
 
 
-def verify_pbs(blob, cs_cap, ncols, circuit_digest, log_n, n_constants, n_routed, gates, N, K, testv, ct, bsk, ksk, out_ct=None, num_challenges=2,
-               quotient_degree_factor=8, rate_bits=3, cap_height=4):
+def verify_pbs(blob, cs_cap, ncols, circuit_digest, log_n, n_constants, n_routed, gates, N, K, testv, ct, bsk, ksk, out_ct, num_challenges=2,
+               quotient_degree_factor=8, rate_bits=3, cap_height=4, compat=None):
     """vpbs_verify_pbs = the reference's verify_pbs (ivc_based_vpbs.rs:388-489) on the serialised LAST proof of an IVC chain:
-    -> (accepted, reason of the first failing check).  bsk: [n][ggsw_len] (NTT domain, flattened), ksk: [ggsw_len], ct: [n + 1]."""
+    -> (accepted, reason of the first failing check).  bsk: [n][ggsw_len] (NTT domain, flattened), ksk: [ggsw_len], ct: [n + 1]; out_ct [K][N]
+    is the bootstrapped ciphertext the caller holds -- required, as in the reference (:440-442); None raises VpbsError."""
     v = VerifyInputsC()
     v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
     v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
@@ -661,6 +714,8 @@ def verify_pbs(blob, cs_cap, ncols, circuit_digest, log_n, n_constants, n_routed
         v.circuit_digest[i] = int(circuit_digest[i])
     v.n_constants, v.n_routed, v.quotient_degree_factor = n_constants, n_routed, quotient_degree_factor
     v.gates, v.n_gates, v.num_selectors = gates.arr, gates.n, gates.num_selectors
+    if compat is not None:
+        v.compat = C.pointer(compat)
     p = VerifyPbsInputsC()
     p.circuit = C.pointer(v)
     ct_a, tv, ks = _u64(ct).reshape(-1), _u64(testv).reshape(-1), _u64(ksk).reshape(-1)
@@ -685,12 +740,14 @@ def verify_step_fri_only(proof, cs_cap, ncols, circuit_digest, public_inputs, lo
                        rate_bits=rate_bits, cap_height=cap_height)
 
 
-def step_proof_from_bytes(blob, ncols, log_n, n_constants, num_challenges=2, rate_bits=3, cap_height=4, max_public_inputs=1 << 16):
+def step_proof_from_bytes(blob, ncols, log_n, n_constants, num_challenges=2, rate_bits=3, cap_height=4, max_public_inputs=1 << 16, compat=None):
     """vpbs_step_proof_from_bytes: ProofWithPublicInputs bytes -> ({"caps", "openings", "fri"}, public inputs)"""
     v = VerifyInputsC()
     v.log_n, v.rate_bits, v.cap_height = log_n, rate_bits, cap_height
     v.n_constants_sigmas, v.n_wires, v.n_zs_partial_products, v.n_quotient = ncols
     v.num_challenges, v.n_constants = num_challenges, n_constants
+    if compat is not None:
+        v.compat = C.pointer(compat)
     p = fri_params(log_n)
     sizes = (C.c_size_t * 4)(*ncols)
     fri_words = lib().vpbs_fri_proof_words(C.byref(p), log_n, sizes, 4)
@@ -826,6 +883,18 @@ class Context:
     def set_gate_lanes(self, lanes):
         """3 (default): gate-constraint kernels over three streams (best single-chain latency); 1: one stream (multi-chain throughput)"""
         self._check(lib().vpbs_ctx_set_gate_lanes(self.h, lanes))
+
+    def set_compat(self, k=None, **over):
+        """the context proves and serialises under this switch table (vpbs_ctx_set_compat); set_compat() restores the defaults"""
+        k = k if k is not None else compat(**over)
+        if lib().vpbs_ctx_set_compat(self.h, C.byref(k)):
+            raise VpbsError("vpbs_ctx_set_compat: a position this build does not implement: %r" % (compat_dict(k),))
+        return k
+
+    def get_compat(self):
+        k = CompatC()
+        self._check(lib().vpbs_ctx_get_compat(self.h, C.byref(k)))
+        return k
 
     @property
     def stream(self):

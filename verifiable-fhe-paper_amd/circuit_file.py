@@ -90,15 +90,15 @@ def ensure_step_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728):
     return path
 
 
-def circuit_digest(cs_cap, log_n):
-    """verifier_only.circuit_digest as this stack defines it: hash_no_pad(constants/sigmas cap || degree bits).  (plonky2 hashes the cap with
-    a domain separator and the degree; the value only has to be fixed per circuit -- it is the first thing the transcript absorbs.)"""
-    return api.hash_no_pad(np.concatenate([np.asarray(cs_cap, np.uint64).reshape(-1), np.array([log_n], np.uint64)]))
+def circuit_digest(cs_cap, log_n, compat=None):
+    """verifier_only.circuit_digest as CircuitBuilder::build derives it: hash_no_pad(constants/sigmas cap || hash_pad(domain separator = [])
+    || degree bits) (vpbs_circuit_digest; compat: an api.CompatC for the older formula without the separator)."""
+    return api.circuit_digest(cs_cap, log_n, compat)
 
 
-def verifier_data_words(cs_cap, log_n):
+def verifier_data_words(cs_cap, log_n, compat=None):
     """the 68 public-input words of add_verifier_data_public_inputs: circuit digest [4], then the cap [16][4]"""
-    return np.concatenate([circuit_digest(cs_cap, log_n), np.asarray(cs_cap, np.uint64).reshape(-1)])
+    return np.concatenate([circuit_digest(cs_cap, log_n, compat), np.asarray(cs_cap, np.uint64).reshape(-1)])
 
 
 def cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n):

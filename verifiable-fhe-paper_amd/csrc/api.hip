@@ -316,6 +316,26 @@ int vpbs_ctx_synchronize(vpbs_ctx* c) {
     return guarded(c, [&] { VPBS_HIP(hipStreamSynchronize(c->stream)); });
 }
 void* vpbs_ctx_stream(vpbs_ctx* c) { return c ? (void*)c->stream : nullptr; }
+// the switch table (include/vpbs_prover.h): defaults = plonky2 0.2.0 as restated
+void vpbs_compat_default(vpbs_compat* out) {
+    if (out) *out = vpbs_compat{0, 1, 1, 1};
+}
+static bool compat_supported(const vpbs_compat& k) {
+    return (k.fri_mul_final_by_x == 0 || k.fri_mul_final_by_x == 1) && (k.bytes_pi_len_prefix == 0 || k.bytes_pi_len_prefix == 1) &&
+           (k.digest_domain_separator == 0 || k.digest_domain_separator == 1) && k.pow_smallest_nonce == 1;
+}
+int vpbs_ctx_set_compat(vpbs_ctx* c, const vpbs_compat* compat) {
+    if (!c || !compat || !compat_supported(*compat)) return VPBS_ERR_INVALID;
+    c->compat = *compat;
+    return VPBS_OK;
+}
+int vpbs_ctx_get_compat(const vpbs_ctx* c, vpbs_compat* out) {
+    if (!c || !out) return VPBS_ERR_INVALID;
+    *out = c->compat;
+    return VPBS_OK;
+}
+unsigned vpbs_ctx_rate_bits(const vpbs_ctx* c) { return c ? c->rate_bits : 0; }
+unsigned vpbs_ctx_cap_height(const vpbs_ctx* c) { return c ? c->cap_height : 0; }
 
 // shader clock of one CU over ~20 us: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
 __global__ void clock_probe_kernel(unsigned long long* out) {
@@ -805,6 +825,32 @@ uint64_t vpbs_challenger_get(vpbs_challenger_state* ch) {
     return ch->output[--ch->output_len];
 }
 void vpbs_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) { poseidon::hash_no_pad_host(in, n, out); }
+// Hasher::hash_pad (plonk/config.rs): pad10*1 -- push 1, zeros until len + 1 is a multiple of the rate, push 1 -- then hash_no_pad
+void vpbs_hash_pad(const uint64_t* in, size_t n, uint64_t out[4]) {
+    std::vector<uint64_t> padded(in, in + (in ? n : 0));
+    padded.push_back(1);
+    while ((padded.size() + 1) % 8 != 0) padded.push_back(0);
+    padded.push_back(1);
+    poseidon::hash_no_pad_host(padded.data(), padded.size(), out);
+}
+// CircuitBuilder::build (plonk/circuit_builder.rs): circuit_digest_parts = [constants_sigmas_cap.flatten(), hash_pad(domain_separator),
+// [degree_bits]] -> hash_no_pad of the concatenation.  The reference never sets a domain separator (ivc_based_vpbs.rs:190-276 build the
+// circuit with CircuitBuilder::new + build), so it is the empty vector.
+int vpbs_circuit_digest(const vpbs_compat* compat, const uint64_t* cap, size_t cap_words, unsigned degree_bits, uint64_t out[4]) {
+    if (!cap || !out || cap_words == 0 || cap_words % 4 != 0) return VPBS_ERR_INVALID;
+    vpbs_compat k;
+    vpbs_compat_default(&k);
+    if (compat) k = *compat;
+    std::vector<uint64_t> parts(cap, cap + cap_words);
+    if (k.digest_domain_separator) {
+        uint64_t sep[4];
+        vpbs_hash_pad(nullptr, 0, sep);
+        parts.insert(parts.end(), sep, sep + 4);
+    }
+    parts.push_back(degree_bits);
+    poseidon::hash_no_pad_host(parts.data(), parts.size(), out);
+    return VPBS_OK;
+}
 
 int vpbs_k_poseidon_host(uint64_t* states, size_t n) {
     if (!states && n) return VPBS_ERR_INVALID;

@@ -37,6 +37,7 @@ struct vpbs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t upload_stream = nullptr;   // vpbs_device_upload_bg: host->device copies next to the work on `stream`
     unsigned log_n_max = 0, rate_bits = 3, cap_height = 4;
+    vpbs_compat compat{0, 1, 1, 1};   // vpbs_compat_default: plonky2 0.2.0 as restated (include/vpbs_prover.h, the switch table)
     std::string err;
 
     // ---- device memory pool ----

@@ -34,8 +34,8 @@ struct Side {   // one circuit on the context
     unsigned log_n = 0, n_wires = 0, n_routed = 0, n_const_cols = 0, num_selectors = 0;
     size_t n = 0;
     std::vector<vpbs_gate> gates;
-    std::vector<uint32_t> pi_pos;
-    size_t n_preset = 0;
+    std::vector<uint32_t> pi_pos;   // cyclic circuit only (the dummy circuit's public inputs are its PartialWitness, never read back)
+    size_t n_pi = 0, n_preset = 0;
     std::vector<u64> cs_cap, vk;   // vk: circuit digest [4] then the constants/sigmas cap
     u64* d_sigma = nullptr;
     u64* d_csv = nullptr;          // sharded commitment only: the constants / sigmas matrix on the device
@@ -50,7 +50,8 @@ struct Side {   // one circuit on the context
         log_n = k.log_n; n_wires = k.n_wires; n_routed = k.n_routed; n_const_cols = k.n_constants_cols; num_selectors = k.num_selectors;
         n = (size_t)1 << log_n;
         gates.assign(k.gates, k.gates + k.n_gates);
-        pi_pos.assign(d.pi_pos, d.pi_pos + d.n_pi);
+        if (d.pi_pos) pi_pos.assign(d.pi_pos, d.pi_pos + d.n_pi);
+        n_pi = d.n_pi;
         n_preset = d.n_preset;
         std::vector<u64> csv((size_t)(n_const_cols + n_routed) * n);
         std::memcpy(csv.data(), k.constants, 8 * (size_t)n_const_cols * n);
@@ -70,10 +71,10 @@ struct Side {   // one circuit on the context
             if (rc == 0 && comm->allgather(comm->user, local.data(), local.size(), cs_cap.data()) != 0) return err = "all-gather of the cap failed", VPBS_ERR_DEVICE;
         }
         if (rc != 0) return err = std::string("constants / sigmas commitment: ") + vpbs_last_error(ctx), rc;
-        std::vector<u64> dig_in(cs_cap);
-        dig_in.push_back(log_n);
         vk.assign(4, 0);
-        vpbs_hash_no_pad(dig_in.data(), dig_in.size(), vk.data());   // circuit digest: hash_no_pad(cap || degree bits)
+        vpbs_compat compat;
+        vpbs_ctx_get_compat(ctx, &compat);
+        vpbs_circuit_digest(&compat, cs_cap.data(), cs_cap.size(), log_n, vk.data());   // CircuitBuilder::build's circuit_digest
         vk.insert(vk.end(), cs_cap.begin(), cs_cap.end());
         rc = vpbs_device_alloc(ctx, (size_t)n_routed * n, &d_sigma);
         if (rc == 0) rc = vpbs_device_upload(ctx, d_sigma, sigma, (size_t)n_routed * n);
@@ -90,7 +91,7 @@ struct Side {   // one circuit on the context
         in.wires_values = wires;
         in.constants_sigmas = cs;
         for (int i = 0; i < 4; ++i) in.circuit_digest[i] = vk[i];
-        in.public_inputs = pis; in.n_public_inputs = pi_pos.size();
+        in.public_inputs = pis; in.n_public_inputs = n_pi;
         in.forced_pow = VPBS_POW_ANY;
         in.sigmas_values = d_sigma; in.sigmas_on_device = 1;
         in.n_routed = n_routed; in.quotient_degree_factor = 8; in.n_constants = n_const_cols;
@@ -148,18 +149,27 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
         say("malformed arguments");
         return VPBS_ERR_INVALID;
     }
-    const size_t kn = (size_t)K * N, cap_words = (size_t)4 << 4, n_pi = 2 * kn + 9 + 4 + cap_words;
+    // the proofs of the chain are proofs under CircuitConfig::standard_recursion_config (ivc_based_vpbs.rs:190): rate 1/8, cap height 4 -- the
+    // in-circuit verifier of the cyclic circuit is built for that shape (16 cap entries in the verifier data and in every proof), so a
+    // context of another shape cannot prove it: its commitments would carry another cap and every vk derived here would be wrong
+    const unsigned cap_height = vpbs_ctx_cap_height(ctx);
+    if (vpbs_ctx_rate_bits(ctx) != 3 || cap_height != 4) {
+        say("the IVC chain needs a context with rate_bits = 3 and cap_height = 4 (standard_recursion_config)");
+        return VPBS_ERR_INVALID;
+    }
+    const size_t kn = (size_t)K * N, cap_words = (size_t)4 << cap_height, n_pi = 2 * kn + 9 + 4 + cap_words;
     // the PartialWitness of a step, in the order the reference sets it (:314-330): previous proof | its public inputs | condition | GGSW |
     // mask | own verifier data | dummy verifier data; the dummy circuit's PartialWitness is its public inputs
-    if (cyclic->n_pi != n_pi || dummy->n_preset != n_pi || cyclic->n_preset != cyclic->proof_words + n_pi + 1 + ggsw_len + 1 + 2 * (4 + cap_words)) {
+    if (cyclic->n_pi != n_pi || dummy->n_preset != n_pi || (dummy->n_pi != 0 && dummy->n_pi != n_pi) || cyclic->n_preset != cyclic->proof_words + n_pi + 1 + ggsw_len + 1 + 2 * (4 + cap_words)) {
         say("the circuits are not a cyclic step circuit and its dummy circuit for these parameters (public inputs / PartialWitness layout)");
         return VPBS_ERR_INVALID;
     }
     auto* v = new vpbs_ivc();
     v->ctx = ctx; v->N = N; v->K = K; v->ggsw_len = ggsw_len; v->kn = kn; v->n_pi = n_pi; v->proof_words = cyclic->proof_words;
     if (comm) v->comm = *comm;   // the callbacks and staging buffers stay the caller's; the struct itself is copied
-    int rc = v->cyc.init(ctx, *cyclic, 4, comm ? &v->comm : nullptr, v->err);
-    if (rc == 0) rc = v->dum.init(ctx, *dummy, 4, nullptr, v->err);   // the base proof is small: every rank proves it whole
+    int rc = v->cyc.init(ctx, *cyclic, cap_height, comm ? &v->comm : nullptr, v->err);
+    if (rc == 0) rc = v->dum.init(ctx, *dummy, cap_height, nullptr, v->err);   // the base proof is small: every rank proves it whole
+    v->dum.n_pi = n_pi;   // the base proof carries the cyclic circuit's public-input layout whatever the caller wrote into dummy->n_pi
     if (rc == 0) {
         std::vector<uint8_t> late(cyclic->n_preset, 0);
         std::fill(late.begin(), late.begin() + cyclic->proof_words, 1);
@@ -221,10 +231,28 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     std::memcpy(base_pis.data() + kn - v->N, testv, 8 * (size_t)v->N);
     std::memcpy(base_pis.data() + n_pi - cyc.vk.size(), cyc.vk.data(), 8 * cyc.vk.size());
 
-    struct Ready {
-        int buf;
-        vpbs_witness_state* state;
+    struct Ready {   // owns the early phase's state until run_late consumes it (a failure on the way must not leak tens of MB of slot values)
+        int buf = -1;
+        vpbs_witness_state* state = nullptr;
         std::vector<u64> values, pis;
+        Ready() = default;
+        Ready(int b, std::vector<u64>&& v) : buf(b), values(std::move(v)) {}
+        Ready(Ready&& o) noexcept : buf(o.buf), state(o.state), values(std::move(o.values)), pis(std::move(o.pis)) { o.state = nullptr; }
+        Ready& operator=(Ready&& o) noexcept {
+            if (this != &o) {
+                drop();
+                buf = o.buf; state = o.state; values = std::move(o.values); pis = std::move(o.pis);
+                o.state = nullptr;
+            }
+            return *this;
+        }
+        Ready(const Ready&) = delete;
+        Ready& operator=(const Ready&) = delete;
+        void drop() {
+            if (state) vpbs_witness_state_free(state);
+            state = nullptr;
+        }
+        ~Ready() { drop(); }
     };
     std::mutex mu;
     std::condition_variable cv;
@@ -254,7 +282,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
                 free_bufs.pop_front();
             }
             const double t = now();
-            Ready r{b, nullptr, std::vector<u64>(proof_words, 0), {}};
+            Ready r(b, std::vector<u64>(proof_words, 0));
             r.values.reserve(cyc.n_preset);
             r.values.insert(r.values.end(), pis_prev.begin(), pis_prev.end());
             r.values.push_back(s == 0 ? 0 : 1);   // condition: false only in the base step
@@ -301,10 +329,8 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         fail(m);
         early.join();
         uploader.join();
-        for (auto& r : generated)
-            if (r.state) vpbs_witness_state_free(r.state);
-        for (auto& r : ready)
-            if (r.state) vpbs_witness_state_free(r.state);
+        generated.clear();   // ~Ready frees the states nobody consumed
+        ready.clear();
         std::string first;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -343,7 +369,9 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         }
         double t = now();
         std::copy(proof.begin(), proof.end(), r.values.begin());
-        rc = vpbs_witness_plan_run_late(cyc.plan, r.state, r.values.data(), v->bufs[r.buf], e, sizeof e);   // consumes the state
+        vpbs_witness_state* st = r.state;
+        r.state = nullptr;
+        rc = vpbs_witness_plan_run_late(cyc.plan, st, r.values.data(), v->bufs[r.buf], e, sizeof e);   // consumes the state, also when it fails
         if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
         t_late += now() - t;
         t = now();

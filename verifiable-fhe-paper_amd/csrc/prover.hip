@@ -856,6 +856,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         challenger.observe_elements(openings_out, 2 * (total_cols + nc));
 
         FriParams fp = FriParams::standard(log_n, ctx->rate_bits, ctx->cap_height);
+        fp.mul_final_by_x = ctx->compat.fri_mul_final_by_x != 0;   // the switch table of include/vpbs_prover.h
         PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out, comm);
         if (challenger_out) *challenger_out = challenger.st;
     });
@@ -935,9 +936,9 @@ long vpbs_step_proof_to_bytes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, u
     }
     const size_t final_words = (size_t)2 << fp.final_poly_bits();
     put_words(w, final_words + 1);  // final_poly, pow_witness
-    // public inputs: length prefix (u64) + elements
+    // public inputs: write_usize(len) (compat.bytes_pi_len_prefix) + elements
     const uint64_t n_pi = in->n_public_inputs;
-    put_words(&n_pi, 1);
+    if (ctx->compat.bytes_pi_len_prefix) put_words(&n_pi, 1);
     put_words(in->public_inputs, in->n_public_inputs);
     return overflow ? (long)VPBS_ERR_INVALID : (long)pos;
 }

@@ -211,6 +211,9 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
     }
     const FriParams fp = FriParams::standard(in->log_n, in->rate_bits, in->cap_height);
     if (!fp.caps_fit()) return VPBS_ERR_INVALID;
+    vpbs_compat compat;   // the switch table of include/vpbs_prover.h (NULL = plonky2 0.2.0 as restated)
+    vpbs_compat_default(&compat);
+    if (in->compat) compat = *in->compat;
     const unsigned nc = in->num_challenges, log_n = in->log_n;
     const unsigned log_lde = log_n + in->rate_bits;
     const size_t lde = (size_t)1 << log_lde, cap_words = (size_t)4 << in->cap_height;
@@ -307,6 +310,8 @@ extern "C" int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* ca
                 apow = gl::mul(apow, fri_alpha);
             }
             sum = gl::add(gl::mul(sum, apow), gl::mul(gl::sub(acc, reduced1), gl::inv(gl::sub(gl::ext(subgroup_x), zeta_next))));
+            // compat.fri_mul_final_by_x: the prover multiplied the final polynomial by X, so the combined value carries a factor subgroup_x
+            if (compat.fri_mul_final_by_x) sum = gl::mul(sum, subgroup_x);
         }
         Ext old_eval = sum;
         unsigned lg = log_lde;
@@ -418,7 +423,11 @@ extern "C" long vpbs_step_proof_from_bytes(const vpbs_verify_inputs* in, const u
         bad = true;
     }
     uint64_t n_pi = 0;
-    if (!bad && pos + 8 <= len) {
+    const bool pi_prefix = in->compat ? in->compat->bytes_pi_len_prefix != 0 : true;   // the switch table of include/vpbs_prover.h
+    if (!pi_prefix) {   // older layout: the public inputs run to the end of the buffer
+        if (!bad && (len - pos) % 8 == 0) n_pi = (len - pos) / 8;
+        else bad = true;
+    } else if (!bad && pos + 8 <= len) {
         std::memcpy(&n_pi, bytes + pos, 8);
         pos += 8;
     } else {
@@ -443,8 +452,11 @@ extern "C" int vpbs_verify_pbs(const vpbs_verify_pbs_inputs* in, const uint8_t* 
         }
     };
     say("");
-    if (!in || !in->circuit || !proof_bytes || !in->testv || !in->ct || !in->ksk || (in->n_lwe && !in->bsk) || in->N == 0 || in->K == 0) {
-        say("malformed arguments");
+    // out_ct is part of the statement (the reference asserts it, :440-442): a verdict without it would not bind the proof to the ciphertext
+    // the caller holds.  ggsw_len strides the caller's bsk / ksk arrays: it must be a whole number of [K][N] GLWE rows (K * ELL * K * N)
+    if (!in || !in->circuit || !proof_bytes || !in->testv || !in->out_ct || !in->ct || !in->ksk || (in->n_lwe && !in->bsk) || in->N == 0 ||
+        in->K == 0 || in->ggsw_len == 0 || in->ggsw_len % ((size_t)in->K * in->K * in->N) != 0) {
+        say("malformed arguments (testv, out_ct, ct, ksk, bsk are all required; ggsw_len = K * ELL * K * N)");
         return VPBS_ERR_INVALID;
     }
     const vpbs_verify_inputs& c = *in->circuit;
@@ -470,7 +482,7 @@ extern "C" int vpbs_verify_pbs(const vpbs_verify_pbs_inputs* in, const uint8_t* 
         say("the counter is not n + 2");
         return 0;
     }
-    if (in->out_ct && std::memcmp(pis.data() + kn + 1, in->out_ct, 8 * kn) != 0) {   // :440-442
+    if (std::memcmp(pis.data() + kn + 1, in->out_ct, 8 * kn) != 0) {   // :440-442
         say("the output ciphertext is not the proof's accumulator");
         return 0;
     }

@@ -630,18 +630,28 @@ struct SlotState {
     Buf<u64> val;
     Buf<uint8_t> is_set;
     size_t n;
-    std::string error;
+    std::string error;        // written under report_mutex(); other threads look at has_error while generators may still be running
+    uint8_t has_error = 0;    // and read the text through error_text(), or directly once every thread of the run has finished
+    static std::mutex& report_mutex() {
+        static std::mutex m;   // the phases of a split plan run generators on several threads
+        return m;
+    }
+    bool failed() const { return __atomic_load_n(&has_error, __ATOMIC_ACQUIRE) != 0; }
+    std::string error_text() const {
+        std::lock_guard<std::mutex> lock(report_mutex());
+        return error;
+    }
     void set(u32 slot, u64 v, u32 pos) {
         if (v >= gl::P) v -= gl::P;
         if (is_set[slot]) {
             // a second writer only compares: in a split plan another thread may be reading this value right now (a generator of the same
             // level, a chain lane), so it is not stored again
             if (val[slot] != v) {
-                static std::mutex report_mutex;   // the phases of a split plan run generators on several threads
-                std::lock_guard<std::mutex> lock(report_mutex);
+                std::lock_guard<std::mutex> lock(report_mutex());
                 if (error.empty())
                     error = "partition containing wire (column " + std::to_string(pos / n) + ", row " + std::to_string(pos % n) +
                             ") was set twice with different values";
+                __atomic_store_n(&has_error, (uint8_t)1, __ATOMIC_RELEASE);
             }
             return;
         }
@@ -1390,8 +1400,8 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
             const bool ok = run_one(p, s, i, mc, err);
             prof.stop(p, i);
             if (!ok) return VPBS_ERR_INVALID;
-            if (!s.error.empty()) {
-                err = s.error;
+            if (s.failed()) {
+                err = s.error_text();
                 return VPBS_ERR_INVALID;
             }
         }
@@ -1504,10 +1514,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
             if (failed.load()) rc = VPBS_ERR_INVALID;
             if (trace) t_wide += clock() - t_level, ++n_wide;
         }
-        if (rc == VPBS_OK && !s.error.empty()) {
-            errs[0] = s.error;
-            rc = VPBS_ERR_INVALID;
-        }
+        if (rc == VPBS_OK && s.failed()) rc = VPBS_ERR_INVALID;   // the text is read further down, when the lanes have stopped too
     }
     if (rc != VPBS_OK) failed.store(true);   // lets waiting lanes go
     const double t_lanes = trace ? clock() : 0;
@@ -1521,11 +1528,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
                 break;
             }
     }
-    if (failed.load()) rc = VPBS_ERR_INVALID;
-    if (rc == VPBS_OK && !s.error.empty()) {
-        errs[0] = s.error;
-        rc = VPBS_ERR_INVALID;
-    }
+    if (failed.load() || s.failed()) rc = VPBS_ERR_INVALID;
     if (trace && !lanes.empty()) std::fprintf(stderr, "[witness %s] %zu chain lanes (%zu PoseidonGate rows): %.2f ms after the levels\n", name, lanes.size(),
                                               p.lane_steps_sorted[ph].size(), clock() - t_lanes);
     const double t_after = trace ? clock() : 0;
@@ -1544,7 +1547,10 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
         for (const auto& e : lane_errs)
             if (err.empty() && !e.empty()) err = e;
     }
-    if (rc != VPBS_OK && err.empty()) err = s.error.empty() ? "a generator failed" : s.error;
+    if (rc != VPBS_OK && err.empty()) {   // every thread of the run has finished: the state's message can be read
+        const std::string set_twice = s.error_text();
+        err = set_twice.empty() ? "a generator failed" : set_twice;
+    }
     return rc;
 }
 
@@ -1644,6 +1650,7 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
     using namespace vpbs;
     if (!plan || !plan->is_split || !state || !preset_val || !wires_out) {
         report(err, err_len, "malformed arguments");
+        delete state;   // consumed whatever happens (header: only a state that never reached run_late is freed by the caller)
         return VPBS_ERR_INVALID;
     }
     const vpbs_witness_plan& p = *plan;
