@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: vPBS proofs/s at N = 1024 on N GPUs (BASELINE.json metric).
 
-A "step" = one step proof of the vPBS IVC chain on the 2^16-row, 135-wire plonky2 circuit (BASELINE config 2 at the degree the
-reference really builds for N = 1024, see LOG_N below: commit wires / Z+partial-products / quotient chunks -> openings -> FRI,
-Fiat-Shamir transcript included) with the inputs resident in HBM; a vPBS proof = 730 chained step proofs (/root/reference/src/main.rs:27, n + 2).  Witness
-generation is a host stage of plonky2's prove() outside this round's hot path and is NOT inside the timed
-region -- `config.stages` says so explicitly.  The permutation-argument partial products (row a12) and the quotient
-polynomials (row a13: permutation argument + the constraints of all 14 gate types of a standard_recursion_config
-circuit, over random columns -- the cost is data-independent) ARE computed inside the step, on the GPU.
+The default workload is the reference's own object: verifiable PBS proofs as IVC chains (`verified_pbs`,
+/root/reference/src/vtfhe/ivc_based_vpbs.rs:159-386) driven by the library's vpbs_ivc_prove_pbs.  A "step" = one CHAINED step proof of
+the cyclic step circuit (step logic + in-circuit verifier of the previous proof; 2^16 rows, 135 wires) of every chain on the GPU, with
+everything a step of the chain costs inside the clock: both witness phases on the host, the uploads, the proof with its Fiat-Shamir
+transcript, and the dependency of each proof on the one before.  A vPBS proof = base proof + 730 chained step proofs
+(/root/reference/src/main.rs:27, n + 2), so value = chained step proofs/s / 730.  --warmup chained steps run untimed, then exactly --steps
+are timed between barrier + synchronise (the clock is placed from the library's progress hook, vpbs_ivc_set_step_callback).
 
-Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode).
+`--workload step` (and the `step_micro` object of the default line) is the synthetic back-to-back step proof over seeded random columns
+resident in HBM that rounds 1-2 reported as the headline: no witness generation, no chain dependency, boost clock -- the device-side
+prover alone; the full-size parity check against the CPU oracle is made on that instance.
+
+Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode); --mode sharded: ONE
+chain whose every step proof is coset-sharded over the GPUs.
 Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: under torch.distributed.run, one rank per GPU)
 """
 import argparse
@@ -453,54 +458,236 @@ def cpu_baseline(gpu_proof=None):
                     "against it says nothing and is not quoted"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-step-circuit", action="store_true", help="skip the witness -> proof pipeline on the real step circuit")
-    ap.add_argument("--no-whole-pbs", action="store_true", help="skip tools/prove_pbs.py (one whole vPBS, 730 step proofs, end to end)")
-    ap.add_argument("--no-survey-size", action="store_true", help="skip the secondary degree-2^15 measurement (profiling runs)")
-    ap.add_argument("--no-ivc", action="store_true", help="skip tools/prove_ivc.py (one vPBS as the reference's IVC chain: 730 proofs of the cyclic circuit)")
-    ap.add_argument("--no-batch128", action="store_true", help="skip the BASELINE config 3 leg (128 independent proofs through a pool of contexts)")
-    ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "1")),
-                    help="independent vPBS chains proven concurrently per GPU (one context + HIP stream + host thread each; "
-                         "BASELINE config 3 style batching).  A step = one step proof of EVERY chain.")
-    ap.add_argument("--batch-chains", type=int, default=4,
-                    help="after the headline single-chain measurement, also time this many concurrent chains (1 GPU only)")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N > 1: 'replicas' = independent chains per GPU (weak scaling, default, no data-path collective); "
-                         "'sharded' = ONE chain whose commitments are coset-sharded over the GPUs (strong scaling: per-step "
-                         "latency; collectives: all-gather of cap hashes + one all-reduce of query records per step)")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
-    ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches, measured_in):
+    """The dominant kernel (Poseidon leaf hashing) against its real bound -- integer VALU issue -- with the HBM fraction beside it.
+    per_step_ms: HIP-event time of its three launches per step proof; bytes_step / perms: algorithmic bytes and permutations per step."""
+    if per_step_ms <= 0:
+        return {"bound": "int-valu-issue", "kernel": "leaf_hash_kernel", "achieved": 0.0, "peak": 0.0, "unit": "T lane-ops/s", "frac": 0.0, "traffic": None}
+    sclk_hz = sclk_mhz * 1e6 if sclk_mhz > 0 else SCLK_FALLBACK_HZ
+    secs = per_step_ms * 1e-3
+    lane_ops = perms * LEAF_HASH_INSTR_PER_PERM                      # one lane executes one permutation
+    achieved = lane_ops / secs / 1e12
+    # what 1024 SIMDs can issue for THIS instruction mix at the clock the kernel ran at: 64 lanes per wave64 instruction every
+    # CEILING_CYCLES_PER_INSTR cycles (97 % of the stream is of the half-rate integer class: 16 lanes per cycle)
+    peak = 256 * 4 * 64 / CEILING_CYCLES_PER_INSTR * sclk_hz / 1e12
+    hbm = bytes_step / secs / 1e9
+    traffic = None
+    for tname in ("r03_pmc_leaf_hash.json", "r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
+            break
+    return {"bound": "int-valu-issue", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches per step proof)",
+            "achieved": achieved, "peak": peak, "unit": "T lane-ops/s", "frac": achieved / peak, "traffic": traffic,
+            "kernel_ms_per_step": per_step_ms, "launches": launches, "measured_in": measured_in,
+            "int_issue_frac": achieved / peak,
+            "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_step": bytes_step,
+                    "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the step workload, gfx950 corrections "
+                                      "applied; per launch on average); not re-measured inside this run"},
+            "note": "the kernel moves exactly its algorithmic bytes (traffic = 1.00 x) and is bound by integer instruction issue: ~%d VALU "
+                    "instructions per permutation, 97 %% of them (v_mad_u64_u32, carry adds, v_cndmask, VOP3 integer) issuing at 4 cycles per "
+                    "wave64 instruction on gfx950 (profiles/r02_microbench_valu2.txt), the rest at 2.  peak = 1024 SIMDs x 64 lanes / %.2f "
+                    "cycles at the shader clock one wave of every timed launch measured over its own lifetime; valu_frac prices the same "
+                    "stream against the guide's fp32 vector peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), which this instruction class "
+                    "cannot reach" % (LEAF_HASH_INSTR_PER_PERM, CEILING_CYCLES_PER_INSTR),
+            "poseidon_permutations_per_s": perms / secs,
+            "valu_achieved_tlaneops": achieved, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS, "valu_frac": achieved / VALU_PEAK_TLANEOPS,
+            "shader_clock_mhz_in_kernel": sclk_mhz, "shader_clock_samples": sclk_samples,
+            "cycles_per_valu_instr_per_simd": (secs * sclk_hz * 256 * 4) / (lane_ops / 64)}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if distributed:
-        assert world == args.gpus, "WORLD_SIZE must equal --gpus"
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.device is not None:
-        local_rank = args.device
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
 
-    log_n = args.log_n
+def host_info():
+    return {"hardware_threads": os.cpu_count(), "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
+                                                                   if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+            "loadavg_1min": os.getloadavg()[0]}
+
+
+IVC_N, IVC_K, IVC_ELL, IVC_LOGB, IVC_NLWE = 1024, 2, 4, 5, 728   # the paper's parameters (/root/reference/src/main.rs:23-30)
+
+
+def measure_ivc(args, rank, local_rank, world, distributed):
+    """The headline: the reference's own object -- vPBS proofs as IVC chains (verified_pbs, ivc_based_vpbs.rs:159-386) through the library's
+    driver vpbs_ivc_prove_pbs.  A step = one CHAINED step proof of the cyclic circuit (step logic + in-circuit verifier of the previous
+    proof, 44 250 gate rows, degree 2^16) of every chain on this GPU: witness generation (host, two phases), upload, proof -- everything a
+    step of the chain costs, the chain dependency included.  --warmup chained steps run untimed (after the base proof), then exactly --steps
+    are timed between barrier + synchronise on both sides; the clock is placed from the library's progress hook."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prove_ivc
+    from vpbs_amd import api, circuit_file
+    N, K, ELL, LOGB, n_lwe, log_n = IVC_N, IVC_K, IVC_ELL, IVC_LOGB, IVC_NLWE, LOG_N
+    total = n_lwe + 2
+    W, Kt = args.warmup, args.steps
+    if W + Kt > total:
+        raise SystemExit("bench.py: --warmup + --steps = %d exceeds the %d steps of one vPBS chain at the paper's parameters" % (W + Kt, total))
+    steps = W + Kt
+    sharded = distributed and args.mode == "sharded"
+    n_chains = 1 if sharded else max(1, args.chains)
+    if rank == 0:
+        circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    if distributed:
+        dist.barrier()
+    cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    t_setup = time.perf_counter()
+    chains, comm, native_comm = [], None, False
+    for ci in range(n_chains):
+        ctx = vpbs_amd.Context(local_rank, log_n_max=16)
+        if n_chains > 1:
+            ctx.set_gate_lanes(1)
+        if sharded:
+            from vpbs_amd import sharding
+            stage_words = (2 << (log_n + 3)) // world
+            native_comm = args.dist_backend == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
+            comm = sharding.make_comm_rccl(ctx, stage_words=stage_words) if native_comm else \
+                sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None, stage_words=stage_words,
+                                   stage_device=torch.device("cuda", local_rank))
+        cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
+        ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
+        inst = 0 if sharded else rank * n_chains + ci        # every chain of every rank is its own PBS: own keys, own message
+        keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728 + inst, 4.99027217501041e-8, 1.17021618159313e-5)
+        testv, delta = api.testv(N, 2)
+        message = (1 + inst) % 2
+        ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta * message % api.P)
+        chains.append({"ctx": ctx, "ivc": ivc, "d": cd, "keys": keys, "testv": testv, "delta": delta, "ct": ct, "message": message})
+    t_setup = time.perf_counter() - t_setup
+    torch.cuda.synchronize()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for c in chains:
+            c["ctx"].synchronize()
+
+    gate = threading.Barrier(n_chains)
+    clock = {}
+    errs = []
+
+    def on_step(ci, done):
+        if done != W:
+            return
+        # the warm-up steps are done on this chain: all chains of this process meet, the ranks meet, the device is drained -- t0
+        gate.wait()
+        if ci == 0:
+            barrier()
+            for c in chains:
+                c["ctx"].timing_enable(2)      # HIP events around the dominant kernel only, on each prover's own stream
+                c["ctx"].timing_report()
+            clock["t0"] = time.perf_counter()
+        gate.wait()
+
+    def chain_thread(ci):
+        try:
+            torch.cuda.set_device(local_rank)
+            c = chains[ci]
+            c["ivc"].on_step(lambda done: on_step(ci, done))
+            c["blob"], c["timing"] = c["ivc"].prove_pbs(c["testv"], c["ct"], c["keys"]["bsk"], c["keys"]["ksk"], steps)
+            c["t_end"] = time.perf_counter()
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    barrier()
+    threads = [threading.Thread(target=chain_thread, args=(ci,)) for ci in range(1, n_chains)]
+    for t in threads:
+        t.start()
+    chain_thread(0)
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    barrier()
+    elapsed = time.perf_counter() - clock["t0"]
+    dominant = {"ms": 0.0, "count": 0}
+    sclk_mhz, sclk_samples = chains[0]["ctx"].timing_shader_clock()
+    for c in chains:
+        d = c["ctx"].timing_report().get("leaf_hash", {"ms": 0.0, "count": 0})
+        dominant["ms"] += d["ms"]; dominant["count"] += d["count"]
+        c["ctx"].timing_enable(0)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # after the clock: the last proof of every chain is the proof of a prefix of a vPBS -- parsed, fully verified (gate constraints at
+    # zeta included), its public inputs checked against the native accumulator chain and both native hash chains
+    verify_ms = []
+    for c in chains:
+        vk, _ = c["ivc"].verifier_data()
+        tv, _ = prove_ivc.check_chain(c["ctx"], c["d"], vk, c["blob"], c["keys"], c["testv"], c["delta"], c["ct"], N, n_lwe, log_n, steps, c["message"])
+        verify_ms.append(1e3 * tv)
+    result = None
+    if rank == 0:
+        d0 = chains[0]["d"]
+        scale = 1.0 / world if sharded else 1.0     # sharded: rank 0 hashed 1/world of the leaves
+        cols = {"wires": 135, "zs_partial_products": 20, "quotient": 16}
+        lde = 1 << (log_n + 3)
+        bytes_step = sum(lde * (cols[k] * 8 + 32) for k in cols) * scale
+        perms = sum(lde * ((cols[k] + 7) // 8) for k in cols) * scale
+        per_step_ms = dominant["ms"] / max(1, Kt * n_chains)
+        steps_total = Kt * (1 if sharded else world) * n_chains
+        t0s = chains[0]["timing"]
+        result = {
+            "metric": "vPBS proofs/sec at N=1024", "value": steps_total / elapsed / STEPS_PER_VPBS, "unit": "vPBS proofs/s",
+            "n_gpus": world, "steps": Kt, "warmup": W, "ms_per_step": elapsed / Kt * 1e3,
+            "ms_per_step_proof": elapsed / (Kt * n_chains) * 1e3,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
+            "data": "synthetic", "step_proofs_per_s": steps_total / elapsed, "steps_per_vpbs_proof": STEPS_PER_VPBS,
+            "config": {"workload": "N=1024 vPBS as the reference produces it (BASELINE config 2; verified_pbs, ivc_based_vpbs.rs:159-386): "
+                                   "CHAINED step proofs of the cyclic step circuit (step logic + in-circuit verifier of the previous proof: "
+                                   "%d gate rows, degree 2^%d, LDE 2^%d, 135 wire + 20 Z/partial-product + 16 quotient columns committed per "
+                                   "step, %d public inputs) at k=1, ELL=4, LOGB=5, n=728, driven by vpbs_ivc_prove_pbs; %d chain(s) per GPU, "
+                                   "each its own PBS (seeded keys, ciphertext); a step = one chained proof of every chain; value = "
+                                   "chained step proofs/s / 730 (one vPBS = base proof + 730 chained proofs)"
+                                   % (d0.meta.get("used_rows", 0), log_n, log_n + 3, len(d0.pi_pos), n_chains),
+                       "stages": "per chained step, all inside the timed region: PartialWitness (previous proof's words + public inputs, GGSW, "
+                                 "mask, verifier data) -> witness generation on the host (early phase ahead on a second thread, late phase "
+                                 "= the in-circuit verifier's rows once the previous proof exists) -> wires to the device (early matrix in "
+                                 "the background, late rows again) -> wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> "
+                                 "permutation Z + partial products -> commit -> alphas -> quotient polynomials (constraints of the "
+                                 "circuit's %d gate types + permutation argument on the LDE coset, / Z_H, coset iNTT, 16 chunks) -> commit -> "
+                                 "zeta -> openings -> FRI (combine, 3 arity-16 folds, 16-bit PoW, 28 queries), Fiat-Shamir transcript "
+                                 "included.  Before the clock: key generation, circuit commitments, witness plans, the base proof and "
+                                 "--warmup chained steps" % d0.gates.n,
+                       "parallelism": ("coset-sharded: ONE chain, every step proof split over %d GPUs (3 all-gathers of cap hashes, 1 device "
+                                       "all-gather of quotient values, 1 all-reduce of query records per step; %s); every rank generates the "
+                                       "identical witness" % (world, "native RCCL (dlopen) on the prover's stream" if native_comm else args.dist_backend))
+                                      if sharded else "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
+                       "chains_per_gpu": n_chains},
+            "roofline": roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, dominant["count"],
+                                    "the timed chained steps of this run (HIP events on each prover's stream)"),
+            "chain_ms_per_step_split": {"witness_late_phase_host": t0s["late_witness_ms"], "late_rows_to_device": t0s["late_rows_upload_ms"],
+                                        "prove_step": t0s["prove_step_ms"], "witness_early_phase_on_a_second_thread": t0s["early_witness_ms"],
+                                        "base_proof_once": t0s["base_proof_ms"], "over": "chain 0, warm-up steps included"},
+            "chain_checks": {"last_proof_verify_ms": verify_ms, "proof_bytes": len(chains[0]["blob"]),
+                             "what": "after the clock, per chain: the last proof serialised by the library, parsed back, fully verified by "
+                                     "vpbs_verify_step (gate constraints at zeta included); test vector, counter = %d, verifier data, the "
+                                     "native accumulator chain and both native hash chains match its public inputs" % steps},
+            "before_the_clock_s": {"circuit_files_commit_plans_keys": t_setup},
+            "host": host_info(),
+        }
+    for c in chains:
+        c["ivc"].free()
+    if native_comm and comm is not None:
+        from vpbs_amd import sharding
+        sharding.free_comm_rccl(comm)
+    for c in chains:
+        c["ctx"].close()
+    chains.clear()
+    torch.cuda.empty_cache()
+    return result
+
+
+def measure_step(args, rank, local_rank, world, distributed, log_n):
+    """The synthetic step (rounds 1-2's headline, now `step_micro`): back-to-back step proofs of BASELINE config 2's shape with the wires
+    resident in HBM -- no witness generation, no chain dependency: what the device-side prover does per step, at boost clock.  --workload
+    step makes it the printed line (profiling scripts, the sharded-step measurements)."""
     sharded = distributed and args.mode == "sharded"
     comm = None
     native_comm = False
     if sharded:
         from vpbs_amd import sharding
-    n_chains = 1 if sharded else max(1, args.chains)
+    n_chains = 1 if sharded else max(1, args.step_chains)
     digest = np.array([11, 22, 33, 44], np.uint64)
     gates = vpbs_amd.api.GateSet(GATES)
     assert gates.num_selectors + gates.num_constants == N_CONSTANTS
@@ -512,7 +699,7 @@ def main():
         if sharded:
             # the collectives of the sharded step: the library's own RCCL path on GPUs (ncclAllGather / ncclAllReduce between device
             # buffers on the prover's stream; torch.distributed only carries the ncclUniqueId), host callbacks over torch.distributed for gloo
-            stage_words = (2 << (args.log_n + 3)) // world
+            stage_words = (2 << (log_n + 3)) // world
             native_comm = args.dist_backend == "nccl" and os.environ.get("VPBS_COMM", "rccl") == "rccl"
             if native_comm:
                 comm = sharding.make_comm_rccl(ctx, stage_words=stage_words)
@@ -523,7 +710,6 @@ def main():
         inst = 0 if sharded else rank * n_chains + c   # sharded: every rank works on the same proof
         inputs = synth.step_inputs(log_n, instance=inst, cols=COLS)
         dev = {k: torch.from_numpy(inputs[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}
-        quot_ptr = None   # quotient chunks are evaluated on the device (sharded: values all-gathered between the GPUs)
         if sharded:
             cs, _ = sharding.sharded_commit(ctx, dev["constants_sigmas"].data_ptr(), COLS["constants_sigmas"], log_n,
                                             device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
@@ -531,7 +717,7 @@ def main():
             cs = ctx.commit_values(inputs["constants_sigmas"])      # once per circuit, untimed
         pis = synth.field_elements(0xABCD + inst, N_PUBLIC_INPUTS)
         sig_ptr = dev["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << log_n)   # sigma value columns
-        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, quot_ptr, cs, digest, pis,
+        si = ctx.make_step_inputs(log_n, dev["wires"].data_ptr(), None, None, cs, digest, pis,
                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
                                   sigmas=sig_ptr, n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates)
         ctxs.append(ctx); sis.append(si); keep.append((dev, cs, pis))
@@ -625,6 +811,7 @@ def main():
         gpu_proof = (proof0, ctx.step_proof_to_bytes(sis[0], N_CONSTANTS, proof0), keep[0][1].cap().copy())
     ctx.timing_enable(0)
 
+    out = None
     if rank == 0:
         steps_total = args.steps * (1 if sharded else world) * n_chains
         step_rate = steps_total / elapsed
@@ -632,100 +819,176 @@ def main():
         per_step_ms = dominant["ms"] / max(1, args.steps * n_chains)  # three leaf_hash launches per step proof
         if sharded:
             scale /= world   # rank 0 hashed 1/world of the leaves
-        bytes_step = leaf_hash_bytes_per_step(log_n) * scale
-        achieved = bytes_step / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
-        perms = leaf_hash_perms_per_step(log_n) * scale
-        valu_rate = perms * LEAF_HASH_INSTR_PER_PERM / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
-        traffic = None
-        for tname in ("r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
-                break
         out = {
             "metric": "vPBS proofs/sec at N=1024", "value": step_rate / STEPS_PER_VPBS, "unit": "vPBS proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_proof": elapsed / (args.steps * n_chains) * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks mod p)",
             "data": "synthetic", "step_proofs_per_s": step_rate, "steps_per_vpbs_proof": STEPS_PER_VPBS,
-            "config": {"workload": "N=1024 vPBS step proof on 1xMI355X per rank (BASELINE config 2): degree 2^%d, LDE 2^%d, "
-                                   "135 wire + 20 Z/partial-product + 16 quotient columns committed per step, %d constant/sigma "
-                                   "columns precommitted; inputs resident in HBM.  2^16 is the degree the reference builds at N=1024 "
-                                   "(ivc_based_vpbs.rs:54-61 pads to 2^15 gates BEFORE build(); the step logic alone is 38312 rows, "
-                                   "tests/step_circuit.py); SURVEY.md's 2^15 is reported as survey_degree_2pow15"
-                                   % (log_n, log_n + 3, COLS["constants_sigmas"]),
+            "config": {"workload": "SYNTHETIC step (not the chain): N=1024 vPBS step proof on 1xMI355X per rank, back to back on seeded random "
+                                   "columns resident in HBM: degree 2^%d, LDE 2^%d, 135 wire + 20 Z/partial-product + 16 quotient columns "
+                                   "committed per step, %d constant/sigma columns precommitted, 14 gate types, %d public inputs; value = "
+                                   "step rate / 730; no witness generation, no chain dependency" % (log_n, log_n + 3, COLS["constants_sigmas"], N_PUBLIC_INPUTS),
                        "stages": "wires commit (iNTT + coset LDE + Poseidon Merkle) -> betas/gammas -> permutation Z + partial "
                                  "products (GPU) -> commit -> alphas -> quotient polynomials (GPU: constraints of %d gate types with "
                                  "their selector filters + the permutation argument over the LDE coset, / Z_H, coset iNTT, 16 "
                                  "chunks) -> commit -> zeta -> openings at zeta/g*zeta -> FRI (combine, 3 arity-16 folds, 16-bit "
-                                 "PoW, 28 queries), Fiat-Shamir transcript included.  NOT in the timed region (host stage of "
-                                 "plonky2's prove(), SURVEY.md 8f-2): witness generation" % gates.n,
+                                 "PoW, 28 queries), Fiat-Shamir transcript included.  NOT in the timed region: witness generation" % gates.n,
                        "parallelism": ("coset-sharded: one chain, every commitment split over %d GPUs; per step 3 all-gathers of cap "
                                        "hashes, 1 device all-gather of quotient values (4 MiB) + 1 all-reduce of query records (%s)"
                                        % (world, "native RCCL (dlopen) on the prover's stream" if native_comm else args.dist_backend)) if sharded else
                                       "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains},
-            "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches/step)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms_per_step": per_step_ms, "launches": dominant["count"],
-                         "note": "integer-VALU bound, not HBM bound: ~%d VALU instr/permutation, half of them v_mad_u64_u32.  valu_frac = "
-                                 "achieved lane-ops/s vs the fp32-FMA rate 256CU*4SIMD*32 lanes*2.4GHz (MI355X_MICROARCH.md); the "
-                                 "integer multiply-add / carry / VOP3 instructions of this kernel issue at half that rate on gfx950 "
-                                 "(profiles/r02_microbench_valu2.txt): int_issue_frac = the instruction stream at 4 cycles per wave64 "
-                                 "instruction for that class (97 %% of it) and 2 for the rest, at the shader clock measured inside the "
-                                 "kernel, over the measured time" % LEAF_HASH_INSTR_PER_PERM,
-                         "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections "
-                                           "applied); not re-measured inside this run",
-                         "poseidon_permutations_per_s": perms / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
-                         "valu_achieved_tlaneops": valu_rate, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS,
-                         "valu_frac": valu_rate / VALU_PEAK_TLANEOPS,
-                         # the same instruction stream priced at the best MEASURED issue rate of integer multiply-add / carry / VOP3
-                         # instructions on gfx950 (4.2 cycles per wave64 instruction at 8 waves per SIMD)
-                         "int_issue_frac": (perms * LEAF_HASH_INSTR_PER_PERM / (256 * 4 * 64) * CEILING_CYCLES_PER_INSTR
-                                            / (sclk_mhz * 1e6 if sclk_mhz > 0 else SCLK_FALLBACK_HZ)) / (per_step_ms * 1e-3) if per_step_ms > 0 else 0.0,
-                         # the shader clock one wave of every timed leaf-hash launch saw over its own lifetime, and what the kernel then
-                         # spends per wave64 VALU instruction and SIMD (ceiling: 3.94)
-                         "shader_clock_mhz_in_kernel": sclk_mhz, "shader_clock_samples": sclk_samples,
-                         "cycles_per_valu_instr_per_simd": (per_step_ms * 1e-3 * sclk_mhz * 1e6 * 256 * 4)
-                                                           / (perms * LEAF_HASH_INSTR_PER_PERM / 64) if sclk_mhz > 0 else None},
+            "roofline": roofline_of(per_step_ms, leaf_hash_bytes_per_step(log_n) * scale, leaf_hash_perms_per_step(log_n) * scale, sclk_mhz,
+                                    sclk_samples, dominant["count"], "the timed back-to-back synthetic steps"),
             "kernel_ms_one_step": breakdown,
-            # the host side of the secondary legs (witness generation, the IVC chain's host phases) runs on a SHARED machine: what this
-            # process may use, and how busy the machine was when the line was written
-            "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip()
-                                                                             if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
-                     "loadavg_1min": os.getloadavg()[0]},
+            "host": host_info(),
         }
-        if world == 1 and n_chains == 1 and args.batch_chains > 1:
-            # BASELINE config 3 flavour on the same GPU: several independent chains in flight (extra contexts/streams)
-            out["batch"] = batch_result
-        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_survey_size:
-            # the size SURVEY.md 8d quotes for N = 1024 (degree 2^15), same columns and gates, single chain: a secondary figure
-            c15 = vpbs_amd.Context(local_rank, log_n_max=16)
-            i15 = synth.step_inputs(SURVEY_LOG_N, cols=COLS)
-            d15 = {k: torch.from_numpy(i15[k].view(np.int64)).cuda() for k in ("wires", "constants_sigmas")}
-            cs15 = c15.commit_values(i15["constants_sigmas"])
-            si15 = c15.make_step_inputs(SURVEY_LOG_N, d15["wires"].data_ptr(), None, None, cs15, digest, keep[0][2], on_device=True,
-                                        shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
-                                        sigmas=d15["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << SURVEY_LOG_N),
-                                        n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates)
-            for _ in range(max(1, args.warmup)):
-                c15.prove_step(si15)
-            torch.cuda.synchronize()
-            t15 = time.perf_counter()
-            for _ in range(args.steps):
-                c15.prove_step(si15)
-            c15.synchronize()
-            e15 = (time.perf_counter() - t15) / args.steps
-            out["survey_degree_2pow15"] = {"ms_per_step_proof": e15 * 1e3, "step_proofs_per_s": 1.0 / e15,
-                                           "vpbs_proofs_per_s": 1.0 / e15 / STEPS_PER_VPBS, "chains": 1}
-            cs15.free()
-            c15.close()
-        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_batch128:
+        if batch_result is not None:
+            out["batch"] = batch_result   # several independent synthetic chains in flight (extra contexts / streams)
+    if native_comm and comm is not None:
+        sharding.free_comm_rccl(comm)
+    state = {"ctxs": ctxs, "keep": keep, "gates": gates, "digest": digest, "gpu_proof": gpu_proof}
+    return out, state
+
+
+def survey_size_leg(local_rank, args, state):
+    """the size SURVEY.md 8d quotes for N = 1024 (degree 2^15), same columns and gates, single chain: a secondary figure"""
+    gates, digest, keep = state["gates"], state["digest"], state["keep"]
+    c15 = vpbs_amd.Context(local_rank, log_n_max=16)
+    i15 = synth.step_inputs(SURVEY_LOG_N, cols=COLS)
+    d15 = {k: torch.from_numpy(i15[k].view(np.int64)).cuda() for k in ("wires", "constants_sigmas")}
+    cs15 = c15.commit_values(i15["constants_sigmas"])
+    si15 = c15.make_step_inputs(SURVEY_LOG_N, d15["wires"].data_ptr(), None, None, cs15, digest, keep[0][2], on_device=True,
+                                shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
+                                sigmas=d15["constants_sigmas"].data_ptr() + 8 * N_CONSTANTS * (1 << SURVEY_LOG_N),
+                                n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates)
+    for _ in range(max(1, args.warmup)):
+        c15.prove_step(si15)
+    torch.cuda.synchronize()
+    t15 = time.perf_counter()
+    for _ in range(args.steps):
+        c15.prove_step(si15)
+    c15.synchronize()
+    e15 = (time.perf_counter() - t15) / args.steps
+    cs15.free()
+    c15.close()
+    return {"ms_per_step_proof": e15 * 1e3, "step_proofs_per_s": 1.0 / e15, "vpbs_proofs_per_s": 1.0 / e15 / STEPS_PER_VPBS, "chains": 1}
+
+
+def subprocess_json(cmd, env, timeout):
+    import subprocess
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps.  Default workload: CHAINED step proofs of every IVC chain on the GPU")
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--workload", choices=["ivc", "step"], default="ivc",
+                    help="ivc (default, the headline): vPBS proofs as the reference's IVC chains through vpbs_ivc_prove_pbs -- witness generation, "
+                         "chain dependency and uploads inside the clock.  step: the synthetic back-to-back step proof (rounds 1-2's headline; "
+                         "profiling scripts); with ivc it is still measured and reported as step_micro")
+    ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "3")),
+                    help="ivc workload: independent vPBS chains (own keys, context, witness plans, host threads) proven side by side per GPU.  "
+                         "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default is 3 (the "
+                         "single-chain latency figure is reported next to it as ivc_single_chain)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
+    ap.add_argument("--no-single-chain", action="store_true", help="ivc workload: skip the one-chain latency measurement")
+    ap.add_argument("--no-step-circuit", action="store_true", help="skip the witness -> proof pipeline on the real step circuit")
+    ap.add_argument("--no-whole-pbs", action="store_true", help="skip tools/prove_pbs.py (one whole vPBS, 730 step proofs, end to end)")
+    ap.add_argument("--no-survey-size", action="store_true", help="skip the secondary degree-2^15 measurement (profiling runs)")
+    ap.add_argument("--no-ivc", action="store_true", help="skip the FULL 730-step IVC chains in their own processes (tools/prove_ivc.py: one chain, three chains)")
+    ap.add_argument("--no-batch128", action="store_true", help="skip the BASELINE config 3 leg (128 independent proofs through a pool of contexts)")
+    ap.add_argument("--step-chains", type=int, default=1, help="step workload: independent synthetic chains proven concurrently per GPU")
+    ap.add_argument("--batch-chains", type=int, default=4,
+                    help="after the single-chain synthetic step, also time this many concurrent synthetic chains (1 GPU only)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N > 1: 'replicas' = independent chains per GPU (weak scaling, default, no data-path collective); "
+                         "'sharded' = ONE chain whose commitments are coset-sharded over the GPUs (strong scaling: per-step "
+                         "latency; collectives: all-gather of cap hashes + one all-reduce of query records per step)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
+    ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        assert world == args.gpus, "WORLD_SIZE must equal --gpus"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.device is not None:
+        local_rank = args.device
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
+    log_n = args.log_n
+    secondary = rank == 0 and world == 1 and log_n == LOG_N
+
+    out, state = None, None
+    if args.workload == "ivc":
+        out = measure_ivc(args, rank, local_rank, world, distributed)
+        if secondary and not args.no_single_chain and args.chains > 1:
+            one = argparse.Namespace(**vars(args))
+            one.chains = 1
+            r1 = measure_ivc(one, rank, local_rank, world, distributed)
+            # the dominant kernel's roofline is priced where its launches have the device to themselves: with several chains in flight a
+            # leaf-hash launch shares the CUs with the other chains' kernels and its event time measures the sharing, not the kernel
+            conc = out["roofline"]
+            out["roofline"] = dict(r1["roofline"], measured_in="the ivc_single_chain leg of this run (one chain: every launch alone on the device; HIP "
+                                                               "events on the prover's stream over its timed chained steps)",
+                                   concurrent_chains={"chains": args.chains, "kernel_ms_per_step": conc["kernel_ms_per_step"], "launches": conc["launches"],
+                                                      "shader_clock_mhz_in_kernel": conc["shader_clock_mhz_in_kernel"],
+                                                      "what": "the same kernel's event time per step proof inside the headline region, where launches "
+                                                              "of different chains overlap on the device"})
+            out["ivc_single_chain"] = {"what": "ONE chain alone on the GPU, same clock placement: the latency of a chained step (the GPU waits "
+                                               "for the chain's host phases)", "ms_per_step": r1["ms_per_step"], "steps": r1["steps"], "warmup": r1["warmup"],
+                                       "vpbs_proofs_per_s": r1["value"], "seconds_per_vpbs_extrapolated": r1["ms_per_step"] * STEPS_PER_VPBS / 1e3,
+                                       "chain_ms_per_step_split": r1["chain_ms_per_step_split"],
+                                       "leaf_hash_ms_per_step": r1["roofline"]["kernel_ms_per_step"],
+                                       "shader_clock_mhz_in_kernel": r1["roofline"]["shader_clock_mhz_in_kernel"]}
+        if secondary and not args.no_step_micro:
+            sargs = argparse.Namespace(**vars(args))
+            sargs.steps, sargs.warmup = min(args.steps, 20), min(max(args.warmup, 1), 5)
+            micro, state = measure_step(sargs, rank, local_rank, world, distributed, log_n)
+            out["step_micro"] = {k: micro[k] for k in ("ms_per_step_proof", "step_proofs_per_s", "kernel_ms_one_step") if k in micro}
+            out["step_micro"].update({"what": micro["config"]["workload"], "vpbs_proofs_per_s_by_step_rate": micro["value"],
+                                      "steps": sargs.steps, "warmup": sargs.warmup,
+                                      "leaf_hash_ms_per_step": micro["roofline"]["kernel_ms_per_step"],
+                                      "int_issue_frac": micro["roofline"]["frac"], "hbm_frac": micro["roofline"]["hbm"]["frac"],
+                                      "shader_clock_mhz_in_kernel": micro["roofline"]["shader_clock_mhz_in_kernel"]})
+            if "batch" in micro:
+                out["step_micro"]["batch"] = micro["batch"]
+    else:
+        out, state = measure_step(args, rank, local_rank, world, distributed, log_n)
+
+    if rank == 0:
+        if secondary and state is not None and not args.no_survey_size:
+            out["survey_degree_2pow15"] = survey_size_leg(local_rank, args if args.workload == "step" else sargs, state)
+        gpu_proof = state["gpu_proof"] if state is not None else None
+        if state is not None:
+            for ctx in state["ctxs"]:
+                ctx.close()
+            state["ctxs"] = []
+            state["keep"] = []
+            torch.cuda.empty_cache()
+        if secondary and not args.no_batch128:
             try:
                 out["batch_of_128"] = batch_of_128(local_rank)
             except Exception as e:   # a secondary figure must not take the headline line down with it
                 out["batch_of_128"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_step_circuit:
+        if secondary and not args.no_step_circuit:
             try:
                 out["step_circuit_pipeline"] = step_circuit_pipeline(local_rank)
             except Exception as e:   # a secondary figure must not take the headline line down with it
@@ -734,51 +997,26 @@ def main():
                 out["step_circuit_pipeline"]["device_witness"] = step_circuit_device_pipeline(local_rank)
             except Exception as e:
                 out["step_circuit_pipeline"]["device_witness"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_whole_pbs:
-            # one whole vPBS end to end (tools/prove_pbs.py) in its own process, after this one has released the device
-            for ctx in ctxs:
-                ctx.close()
-            ctxs = []
-            torch.cuda.empty_cache()
-            import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_pbs.py")], capture_output=True, text=True, timeout=600,
-                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank), WORLD_SIZE="1", RANK="0"))
-                out["whole_pbs"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
-            except Exception as e:
-                out["whole_pbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and n_chains == 1 and log_n == LOG_N and not args.no_ivc:
-            # the reference's actual object: ONE vPBS proof = an IVC chain of 730 step proofs of the CYCLIC circuit (each verifies its
-            # predecessor in circuit), measured end to end in its own process (tools/prove_ivc.py)
-            for ctx in ctxs:
-                ctx.close()
-            ctxs = []
-            torch.cuda.empty_cache()
-            import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], capture_output=True, text=True, timeout=900,
-                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank)))
-                out["ivc_chain"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
-            except Exception as e:
-                out["ivc_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            # ... and three independent PBS side by side on the same GPU (throughput: one chain leaves the GPU idle during its host phases)
-            try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], capture_output=True, text=True, timeout=900,
-                                   env=dict(os.environ, VPBS_PBS_DEVICE=str(local_rank), VPBS_IVC_CHAINS="3"))
-                d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
-                out["ivc_three_chains"] = {k: d[k] for k in ("what", "chains", "seconds", "vpbs_proofs_per_s", "ms_per_step", "ms_per_step_split",
-                                                              "decrypted", "other_chains") if k in d} if "error" not in d else d
-            except Exception as e:
-                out["ivc_three_chains"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        env = dict(os.environ, VPBS_PBS_DEVICE=str(local_rank), WORLD_SIZE="1", RANK="0")
+        if secondary and not args.no_whole_pbs:
+            # one whole vPBS end to end on the step circuit WITHOUT recursion (tools/prove_pbs.py) in its own process
+            out["whole_pbs"] = subprocess_json([sys.executable, os.path.join(ROOT, "tools", "prove_pbs.py")], env, 600)
+        if secondary and not args.no_ivc:
+            # the complete object: ONE vPBS proof = base proof + all 730 chained proofs, verify_pbs on the last, decrypted (own process) ...
+            out["ivc_chain"] = subprocess_json([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], env, 900)
+            # ... and three whole chains side by side
+            d = subprocess_json([sys.executable, os.path.join(ROOT, "tools", "prove_ivc.py")], dict(env, VPBS_IVC_CHAINS="3"), 900)
+            out["ivc_three_chains"] = {k: d[k] for k in ("what", "chains", "seconds", "vpbs_proofs_per_s", "ms_per_step", "ms_per_step_split",
+                                                          "decrypted", "other_chains") if k in d} if "error" not in d else d
         if world == 1 and not args.no_cpu_baseline and log_n == LOG_N:
             parity, out["cpu_baseline"] = cpu_baseline(gpu_proof)
             out["parity_checked_full_size"] = parity is not None
             out["parity_full_size"] = parity
         print(json.dumps(out))
-    if native_comm and comm is not None and ctxs:
-        sharding.free_comm_rccl(comm)
-    for ctx in ctxs:
-        ctx.close()
+    elif state is not None:
+        for ctx in state["ctxs"]:
+            ctx.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -543,6 +543,13 @@ typedef struct {
 int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_ivc_circuit* dummy, unsigned N, unsigned K, size_t ggsw_len,
                     const vpbs_comm* comm, vpbs_ivc** out, char* err, size_t err_len);
 void vpbs_ivc_free(vpbs_ivc* ivc);
+/* Progress hook: fn(user, done) is called on the thread inside vpbs_ivc_prove_pbs with done = 0 when the base proof exists and with
+ * done = 1 .. steps after each chained step proof (its words are on the host, nothing of that step is left on the device).  A host places
+ * its clock with it -- bench.py times K chained steps after W warm-up steps between done == W and the return -- or reports progress.  The
+ * early witness phases of later steps keep running on their own threads while the hook runs (that pipelining is the design, not warm-up).
+ * NULL removes the hook. */
+typedef void (*vpbs_ivc_step_fn)(void* user, unsigned done);
+int vpbs_ivc_set_step_callback(vpbs_ivc* ivc, vpbs_ivc_step_fn fn, void* user);
 /* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */
 int vpbs_ivc_verifier_data(const vpbs_ivc* ivc, uint64_t* cyclic_vk, uint64_t* dummy_vk);
 long vpbs_ivc_prove_pbs(vpbs_ivc* ivc, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,

@@ -401,9 +401,15 @@ def test_ivc_chain_bit_identical_to_the_cpu_oracle_chain():
     frozen = json.load(open(GOLDEN_CHAIN))
     assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"])
     vk, _ = ivc.verifier_data()
+    # the bootstrapped ciphertext the verifier holds: the native accumulator chain's last element (the statement the proof is bound to)
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), np.asarray(testv, np.uint64).reshape(1, N)])
+    out_ct = c.pbs_accumulator_chain(acc_init, ct, bsk_flat, ksk_flat, K, ELL, LOGB)[-1]
     ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates, N, K,
-                             testv, ct, bsk_flat, ksk_flat)
+                             testv, ct, bsk_flat, ksk_flat, out_ct)
     assert ok, why
+    with pytest.raises(api.VpbsError):   # no verdict without the ciphertext (ivc_based_vpbs.rs:440-442)
+        api.verify_pbs(blob, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates, N, K,
+                       testv, ct, bsk_flat, ksk_flat, None)
     ivc.free()
     c.close()
 
@@ -426,16 +432,31 @@ def test_ivc_driver_through_the_python_binding():
     ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
     blob, t = ivc.prove_pbs(testv, ct, keys["bsk"], keys["ksk"])
     vk, _ = ivc.verifier_data()
+    acc_init = np.concatenate([np.zeros((K - 1, N), np.uint64), np.asarray(testv, np.uint64).reshape(1, N)])
+    out_of = lambda c_: c.pbs_accumulator_chain(acc_init, c_, keys["bsk"], keys["ksk"], K, ELL, LOGB)[-1]   # the bootstrapped ciphertext
     ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates, N, K,
-                             testv, ct, keys["bsk"], keys["ksk"])
+                             testv, ct, keys["bsk"], keys["ksk"], out_of(ct))
     assert ok, why
     assert t["steps"] == n_lwe + 2
     ct2 = api.lwe_encrypt(keys["params"], keys["s_lwe"], 0, nonce=1)
+    # the progress hook: 0 after the base proof, then once per chained step, on the proving thread
+    seen = []
+    ivc.on_step(seen.append)
     blob2, _ = ivc.prove_pbs(testv, ct2, keys["bsk"], keys["ksk"])
-    vp = lambda b, c_: api.verify_pbs(b, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates,
-                                      N, K, testv, c_, keys["bsk"], keys["ksk"])
-    assert vp(blob2, ct2)[0] and vp(blob2, ct) == (False, "the LWE hash chain does not match") and not vp(blob, ct2)[0]
+    assert seen == list(range(n_lwe + 3))
+    ivc.on_step(None)
+    vp = lambda b, c_, o_: api.verify_pbs(b, vk[4:].reshape(-1, 4), [cyc.n_constants + 80, 135, 20, 16], vk[:4], log_n, cyc.n_constants, 80, cyc.gates,
+                                          N, K, testv, c_, keys["bsk"], keys["ksk"], o_)
+    assert vp(blob2, ct2, out_of(ct2))[0] and vp(blob2, ct, out_of(ct2)) == (False, "the LWE hash chain does not match")
+    assert vp(blob2, ct2, out_of(ct)) == (False, "the output ciphertext is not the proof's accumulator") and not vp(blob, ct2, out_of(ct2))[0]
     ivc.free()
+    # a context of another FriConfig shape cannot carry the chain (the in-circuit verifier is built for rate 1/8, cap height 4): rejected at
+    # creation instead of overflowing the cap buffer or producing a verifier key that fails later in circuit
+    for rate_bits, cap_height in ((3, 5), (3, 3), (2, 4)):
+        c2 = vpbs_amd.Context(0, log_n_max=16, rate_bits=rate_bits, cap_height=cap_height)
+        with pytest.raises(api.VpbsError, match="rate_bits = 3 and cap_height = 4"):
+            api.Ivc(c2, cyc, dum, N, K, g)
+        c2.close()
     c.close()
 
 

@@ -208,6 +208,37 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
             "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
 
 
+def check_chain(ctx, d, vk, blob, keys, testv, delta, ct, N, n_lwe, log_n, steps, message):
+    """verify_pbs (ivc_based_vpbs.rs:388-489) on the LAST proof of a chain of `steps` proofs (bytes as vpbs_ivc_prove_pbs returned them): parse,
+    full vpbs_verify_step, test vector, counter, verifier data, the native accumulator chain; the whole chain (steps = n + 2) also through
+    vpbs_verify_pbs and decrypted, a prefix against the prefix of both hash chains -> (seconds of the proof verification, decrypted message)"""
+    total, kn = n_lwe + 2, K * N
+    ncols = [d.n_constants + 80, 135, 20, 16]
+    tv = time.perf_counter()
+    back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, d.n_constants)
+    assert api.verify_step(back, vk[4:].reshape(-1, 4), ncols, vk[:4], back_pis, log_n, n_constants=d.n_constants, n_routed=80, gates=d.gates), \
+        "the final proof does not verify"
+    t_verify = time.perf_counter() - tv
+    acc_init = np.concatenate([np.zeros((K - 1) * N, np.uint64), testv])
+    assert (back_pis[:kn] == acc_init).all() and int(back_pis[kn]) == steps and (back_pis[-68:] == vk).all()
+    accs = ctx.pbs_accumulator_chain(acc_init.reshape(K, N), ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
+    assert (back_pis[kn + 1:2 * kn + 1] == accs[steps - 1].reshape(-1)).all()                    # the accumulator the native chain reaches
+    decrypted = None
+    if steps == total:
+        ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), ncols, vk[:4], log_n, d.n_constants, 80, d.gates, N, K, testv, ct, keys["bsk"],
+                                 keys["ksk"], out_ct=accs[-1])
+        assert ok, why
+        m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
+        decrypted = round(int(m_bar[0]) / delta) % 4
+        assert decrypted == message, (decrypted, message)
+    else:   # a prefix of the chain: the hash chains against the prefix of the keys
+        zero = np.zeros(K * ELL * K * N, np.uint64)
+        bsk_items = np.stack([zero] + [keys["bsk"][x] for x in range(min(steps - 1, n_lwe))])
+        lwe_items = np.array([[int(ct[n_lwe])]] + [[int(ct[x])] for x in range(min(steps - 1, n_lwe))], np.uint64)
+        assert api.hash_chain(bsk_items, back_pis[2 * kn + 1:2 * kn + 5])[1] and api.hash_chain(lwe_items, back_pis[2 * kn + 5:2 * kn + 9])[1]
+    return t_verify, decrypted
+
+
 def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start, dist=None):
     """the same PBS through the library's own driver (vpbs_ivc_prove_pbs: the loop of run_chain in C++, csrc/ivc.hip) -> result dict"""
     total, kn = n_lwe + 2, K * N
@@ -223,29 +254,7 @@ def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start, 
     blob, t = ivc.prove_pbs(testv, ct, keys["bsk"], keys["ksk"], steps)
     if dist:
         dist.barrier()
-    # verify_pbs (:388-489) on the LAST proof only
-    tv = time.perf_counter()
-    back, back_pis = api.step_proof_from_bytes(blob, ncols, log_n, d.n_constants)
-    assert api.verify_step(back, vk[4:].reshape(-1, 4), ncols, vk[:4], back_pis, log_n, n_constants=d.n_constants, n_routed=80, gates=d.gates), \
-        "the final proof does not verify"
-    t_verify = time.perf_counter() - tv
-    acc_init = np.concatenate([np.zeros((K - 1) * N, np.uint64), testv])
-    assert (back_pis[:kn] == acc_init).all() and int(back_pis[kn]) == steps and (back_pis[-68:] == vk).all()
-    accs = ctx.pbs_accumulator_chain(acc_init.reshape(K, N), ct, keys["bsk"], keys["ksk"], K, ELL, LOGB)
-    assert (back_pis[kn + 1:2 * kn + 1] == accs[steps - 1].reshape(-1)).all()                    # the accumulator the native chain reaches
-    decrypted = None
-    if steps == total:
-        ok, why = api.verify_pbs(blob, vk[4:].reshape(-1, 4), ncols, vk[:4], log_n, d.n_constants, 80, d.gates, N, K, testv, ct, keys["bsk"],
-                                 keys["ksk"], out_ct=back_pis[kn + 1:2 * kn + 1])
-        assert ok, why
-        m_bar = ctx.glwe_decrypt(keys["s_to"], back_pis[kn + 1:2 * kn + 1].reshape(K, N))
-        decrypted = round(int(m_bar[0]) / delta) % 4
-        assert decrypted == message, (decrypted, message)
-    else:   # a prefix of the chain: the hash chains against the prefix of the keys
-        zero = np.zeros(K * ELL * K * N, np.uint64)
-        bsk_items = np.stack([zero] + [keys["bsk"][x] for x in range(min(steps - 1, n_lwe))])
-        lwe_items = np.array([[int(ct[n_lwe])]] + [[int(ct[x])] for x in range(min(steps - 1, n_lwe))], np.uint64)
-        assert api.hash_chain(bsk_items, back_pis[2 * kn + 1:2 * kn + 5])[1] and api.hash_chain(lwe_items, back_pis[2 * kn + 5:2 * kn + 9])[1]
+    t_verify, decrypted = check_chain(ctx, d, vk, blob, keys, testv, delta, ct, N, n_lwe, log_n, steps, message)
     return {"seconds": t["seconds"], "split": {"witness_late_phase_host": t["late_witness_ms"], "late_rows_to_device": t["late_rows_upload_ms"],
                                                "prove_step": t["prove_step_ms"], "base_proof_once": t["base_proof_ms"],
                                                "witness_early_phase_on_a_second_thread": t["early_witness_ms"]},

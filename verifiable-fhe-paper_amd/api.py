@@ -141,6 +141,7 @@ class StepSizesC(C.Structure):
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t, U64P)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, C.c_size_t)
 ALLGATHER_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+IVC_STEP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint)
 
 
 class CommC(C.Structure):
@@ -228,6 +229,7 @@ SIGNATURES = {
     "vpbs_ivc_create": (_i, [_vp, C.POINTER(IvcCircuitC), C.POINTER(IvcCircuitC), _ui, _ui, _sz, C.POINTER(CommC), C.POINTER(_vp), C.c_char_p, _sz]),
     "vpbs_ivc_free": (None, [_vp]),
     "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
+    "vpbs_ivc_set_step_callback": (_i, [_vp, IVC_STEP_FN, _vp]),
     "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
     "vpbs_verify_pbs": (_i, [C.POINTER(VerifyPbsInputsC), C.POINTER(C.c_uint8), _sz, C.c_char_p, _sz]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
@@ -682,6 +684,24 @@ class Ivc:
         lib().vpbs_ivc_verifier_data(self.h, _ptr(a), _ptr(b))
         return a, b
 
+    def on_step(self, fn):
+        """vpbs_ivc_set_step_callback: fn(done) runs on the proving thread with done = 0 after the base proof and 1 .. steps after each
+        chained step proof (None removes it).  An exception raised by fn is kept and re-raised by prove_pbs."""
+        self._step_error = None
+        if fn is None:
+            self._step_cb = None
+            lib().vpbs_ivc_set_step_callback(self.h, C.cast(None, IVC_STEP_FN), None)
+            return
+
+        def trampoline(_user, done):
+            try:
+                if self._step_error is None:
+                    fn(int(done))
+            except BaseException as e:   # noqa: BLE001 -- must not unwind through the C frames
+                self._step_error = e
+        self._step_cb = IVC_STEP_FN(trampoline)
+        lib().vpbs_ivc_set_step_callback(self.h, self._step_cb, None)
+
     def prove_pbs(self, testv, ct, bsk, ksk, steps=0):
         """-> (ProofWithPublicInputs bytes of the LAST proof of the chain, timing dict)"""
         tv, c, ks = _u64(testv).reshape(-1), _u64(ct).reshape(-1), _u64(ksk).reshape(-1)
@@ -689,6 +709,9 @@ class Ivc:
         buf, t, err = (C.c_uint8 * self.max_bytes)(), IvcTimingC(), C.create_string_buffer(512)
         n = lib().vpbs_ivc_prove_pbs(self.h, _ptr(tv), _ptr(c), _ptr(bs) if bs is not None else None, _ptr(ks), c.size - 1, steps, buf,
                                      self.max_bytes, C.byref(t), err, 512)
+        if getattr(self, "_step_error", None) is not None:
+            e, self._step_error = self._step_error, None
+            raise e
         if n < 0:
             raise VpbsError("vpbs_ivc_prove_pbs: " + err.value.decode())
         return bytes(buf[:n]), {f: getattr(t, f) for f, _ in IvcTimingC._fields_}

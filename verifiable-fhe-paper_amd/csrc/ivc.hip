@@ -122,6 +122,8 @@ struct vpbs_ivc {
     bool filled[NBUF] = {false, false, false};
     std::string err;
     vpbs_comm comm{};
+    vpbs_ivc_step_fn step_fn = nullptr;
+    void* step_user = nullptr;
     ~vpbs_ivc() {
         for (auto b : bufs)
             if (b) vpbs_host_free(b);
@@ -197,6 +199,13 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
 }
 
 void vpbs_ivc_free(vpbs_ivc* v) { delete v; }
+
+int vpbs_ivc_set_step_callback(vpbs_ivc* v, vpbs_ivc_step_fn fn, void* user) {
+    if (!v) return VPBS_ERR_INVALID;
+    v->step_fn = fn;
+    v->step_user = user;
+    return VPBS_OK;
+}
 
 int vpbs_ivc_verifier_data(const vpbs_ivc* v, uint64_t* cyclic_vk, uint64_t* dummy_vk) {
     if (!v) return VPBS_ERR_INVALID;
@@ -354,6 +363,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     int rc = dum.prove(in, caps, openings, fri);
     if (rc != 0) return stop(std::string("base proof: ") + vpbs_last_error(ctx), rc);
     const double t_base = now() - t0;
+    if (v->step_fn) v->step_fn(v->step_user, 0);
     double t_late = 0, t_rows = 0, t_prove = 0;
     for (unsigned s = 0; s < steps; ++s) {
         Ready r;
@@ -389,6 +399,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
             free_bufs.push_back(r.buf);
         }
         cv.notify_all();
+        if (v->step_fn) v->step_fn(v->step_user, s + 1);
     }
     early.join();
     uploader.join();
