@@ -415,9 +415,36 @@ def batch_of_128(device, pools=(1, 2, 4, 8), proofs=128):
     return out
 
 
-def cpu_baseline(gpu_proof=None):
-    """One full step proof on the host cores with the CPU oracle (kind 'port': restated algorithm, OpenMP).  gpu_proof = (proof, bytes,
-    constants/sigmas cap) of the GPU for the same instance: compared word for word (the bench fails if they differ)."""
+def reference_probe():
+    """is the reference's own toolchain on this box?  `cargo --version` and the pinned crates (plonky2 0.2.0,
+    /root/reference/Cargo.lock:371-374) in an offline registry.  The reference itself is never at /root/reference on the GPU box, and its
+    `cargo run --release` is one whole vPBS at N = 1024 (the paper: ~20 min on 192 cores) -- outside any bench budget -- so even with a
+    toolchain the figure reported next to the GPU's is the restated CPU prover; the probe records what was found."""
+    import shutil
+    import subprocess
+    cargo = shutil.which("cargo")
+    out = {"cargo": None, "plonky2_0_2_0_in_offline_registry": False, "reference_run": False}
+    if cargo:
+        try:
+            out["cargo"] = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception as e:   # noqa: BLE001
+            out["cargo"] = "present, but `cargo --version` failed: %s" % e
+        reg = os.path.expanduser("~/.cargo/registry/src")
+        if os.path.isdir(reg):
+            out["plonky2_0_2_0_in_offline_registry"] = any(os.path.isdir(os.path.join(reg, d, "plonky2-0.2.0")) for d in os.listdir(reg))
+    out["why_not_run"] = ("no Rust toolchain on this box" if not cargo else
+                          "toolchain present; the reference's only binary proves one whole vPBS (730 steps, minutes to hours of CPU) and its "
+                          "sources are not part of this repository's snapshot")
+    return out
+
+
+def cpu_baseline(gpu_proof=None, runs=5):
+    """Complete step proofs on the host cores with the CPU oracle (kind 'port': the restated algorithm in C, OpenMP over every CPU the
+    container may use, the Poseidon permutation eight at a time on AVX-512 lanes where the CPU has them -- oracle/poseidon_x8.c), timed
+    stage by stage the way the reference prints its TimingTree (ivc_based_vpbs.rs:301,309,332,340); `runs` repetitions, the MEDIAN is
+    reported.  gpu_proof = (proof, bytes, constants/sigmas cap) of the GPU for the same instance: compared word for word with the first
+    run's proof (the bench fails if they differ)."""
+    import statistics
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gates_oracle
     import oracle as orc
@@ -427,12 +454,53 @@ def cpu_baseline(gpu_proof=None):
     pis = synth.field_elements(0xABCD, N_PUBLIC_INPUTS)
     digest = np.array([11, 22, 33, 44], np.uint64)
     cs = orc.Batch(inputs["constants_sigmas"], 3, 4, True)   # committed once per circuit: untimed
-    t0 = time.time()
     sig = np.ascontiguousarray(inputs["constants_sigmas"][N_CONSTANTS:N_CONSTANTS + N_ROUTED])
-    inputs["quotient"] = None   # quotient chunks evaluated (permutation-argument constraints), like the GPU step
-    want = step_oracle.prove_step(inputs, digest, pis, LOG_N, cs_batch=cs, sigmas=sig, n_routed=N_ROUTED, n_constants=N_CONSTANTS,
-                                  gates=gates_oracle.GateSet(GATES))
-    dt = time.time() - t0
+    gs = gates_oracle.GateSet(GATES)
+    x8 = bool(orc.lib().orc_poseidon_x8_available())
+
+    def one():
+        """plonk/prover.rs prove() after witness generation, stage by stage (the transcript order of step_oracle.prove_step)"""
+        T = {}
+
+        def timed(name, f):
+            t = time.perf_counter()
+            r = f()
+            T[name] = T.get(name, 0.0) + 1e3 * (time.perf_counter() - t)
+            return r
+        t_all = time.perf_counter()
+        pi_hash = timed("public_inputs_hash", lambda: orc.hash_no_pad(pis))
+        w = timed("wires_commit (ifft + lde + transpose + merkle)", lambda: orc.Batch(inputs["wires"], 3, 4, True))
+        ch = orc.ChallengerState()
+        ch.observe(digest); ch.observe(pi_hash); ch.observe(w.cap())
+        betas, gammas = ch.get_n(2), ch.get_n(2)
+        zs = timed("partial_products", lambda: orc.partial_products(inputs["wires"][:N_ROUTED], sig, betas, gammas))
+        zb = timed("zs_partial_products_commit", lambda: orc.Batch(zs, 3, 4, True))
+        ch.observe(zb.cap())
+        alphas = ch.get_n(2)
+        gt = timed("quotient: gate constraints on the coset", lambda: gs.terms_coset(cs.coeffs()[:N_CONSTANTS], w.coeffs(), pi_hash, alphas))
+        q = timed("quotient: permutation terms, / Z_H, coset ifft", lambda: orc.quotient_permutation(
+            w.coeffs()[:N_ROUTED], cs.coeffs()[N_CONSTANTS:N_CONSTANTS + N_ROUTED], zb.coeffs(), betas, gammas, alphas, gate_terms=gt))
+        qb = timed("quotient_commit", lambda: orc.Batch(q, 3, 4, False))
+        ch.observe(qb.cap())
+        zeta = ch.get_ext()
+        oracles = [cs, w, zb, qb]
+        ncols = [o.ncols for o in oracles]
+        batches, zeta_next = step_oracle.step_batches(ncols, 2, zeta, LOG_N)
+        openings = timed("openings", lambda: np.concatenate([o.eval_ext(zeta) for o in oracles] + [zb.eval_ext(zeta_next)[:2]]))
+        ch.observe(openings)
+        fri = timed("fri: prove_openings (combine, folds, trees, PoW, queries)", lambda: orc.prove_openings(oracles, batches, ch, orc.fri_params(LOG_N), LOG_N))
+        total = 1e3 * (time.perf_counter() - t_all)
+        proof = {"caps": np.stack([w.cap(), zb.cap(), qb.cap()]), "openings": openings, "fri": fri,
+                 "challenges": np.array(betas + gammas + alphas + [int(zeta[0]), int(zeta[1])], np.uint64), "cs_cap": cs.cap(), "ncols": ncols}
+        return total, T, proof
+
+    totals, stages, want = [], [], None
+    for r in range(max(1, runs)):
+        total, T, proof = one()
+        totals.append(total)
+        stages.append(T)
+        if want is None:
+            want = proof
     parity = None
     if gpu_proof is not None:
         # the oracle proved the very instance chain 0 of the GPU proved (same seeded columns, gates, public inputs, digest): every
@@ -447,15 +515,18 @@ def cpu_baseline(gpu_proof=None):
             raise RuntimeError("full-size GPU step proof differs from the CPU oracle's in: " + ", ".join(bad))
         parity = {"compared": ["cs_cap", "caps", "challenges", "openings", "fri", "bytes"], "proof_bytes": len(got_bytes),
                   "fri_words": int(np.asarray(want["fri"]).size)}
-    return parity, {"value": (1.0 / dt) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": dt * 1e3,
-            "cores": orc.effective_cpus(), "kind": "port",
-            "sample": "1 complete step proof (2^%d rows, 135/20/16 columns, same seeded inputs, partial products, gate constraints "
-                      "and quotient included) with the C oracle, OpenMP on every CPU the container may use "
-                      "(cgroup CPU quota; os.cpu_count() = %d)" % (LOG_N, os.cpu_count() or 0),
-            "note": "NOT a tuned CPU prover and not the reference: the checker's scalar restatement (naive Poseidon at ~8.7 us per permutation per "
-                    "core where the product's own host permutation takes 1.3 us and plonky2's AVX2 one is in that class; PoW and Merkle top "
-                    "levels serial).  Reported because the contract asks for a CPU figure measured in the same run; a GPU / CPU ratio "
-                    "against it says nothing and is not quoted"}
+    med = statistics.median(totals)
+    return parity, {"value": (1e3 / med) / STEPS_PER_VPBS, "unit": "vPBS proofs/s", "ms_per_step": med,
+            "cores": orc.effective_cpus(), "kind": "port", "runs": len(totals), "ms_per_step_runs": [round(t, 1) for t in totals],
+            "stages_ms_median": {k: round(statistics.median(s[k] for s in stages), 2) for k in stages[0]},
+            "poseidon": "oracle/poseidon_x8.c: eight permutations per AVX-512 register" if x8 else "oracle/poseidon.c: scalar (no AVX-512 on this CPU)",
+            "sample": "%d complete step proofs of the SYNTHETIC step (2^%d rows, 135/20/16 columns, same seeded inputs as step_micro, partial "
+                      "products, gate constraints of 14 gate types and quotient included; witness generation excluded, as in step_micro), median; C "
+                      "oracle, OpenMP on every CPU the container may use (cgroup CPU quota; os.cpu_count() = %d)" % (len(totals), LOG_N, os.cpu_count() or 0),
+            "reference_probe": reference_probe(),
+            "note": "the restated CPU prover (not plonky2, not tuned beyond its Poseidon): FFTs are plain radix-2, the gate constraints are "
+                    "evaluated in the extension-field form the verifier uses.  A stated baseline measured in the same run on the same box; the "
+                    "optimisation target is the roofline fraction, and no GPU / CPU ratio is quoted"}
 
 
 def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches, measured_in):
@@ -530,6 +601,9 @@ def measure_ivc(args, rank, local_rank, world, distributed):
         dist.barrier()
     cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
     t_setup = time.perf_counter()
+    if distributed:
+        # one process per GPU: every rank would size its witness pools for the whole machine -- each gets its share of the CPUs instead
+        api.host_set_cpu_budget(max(2, api.host_set_cpu_budget(0) // world))
     chains, comm, native_comm = [], None, False
     for ci in range(n_chains):
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)

@@ -309,6 +309,12 @@ void vpbs_witness_plan_free(vpbs_witness_plan* plan);
  * wide levels are shared, long hash chains run as lanes beside them.  run_early and run_late of one plan may run concurrently with each
  * other; a second concurrent run of the SAME phase finds the pool taken and runs on its calling thread alone. */
 typedef struct vpbs_witness_state vpbs_witness_state;
+/* The CPUs this process may use for those pools.  Default: the hardware threads capped by the scheduler affinity and the cgroup CPU quota.
+ * A launcher that starts one prover process per GPU of a node gives each its share (bench.py: quota / ranks): every process otherwise sizes
+ * its pools for the whole machine.  0 restores the default.  Takes effect for pools created afterwards (a phase's pool keeps the size of its
+ * first run).  vpbs_host_cpu_budget returns the figure in force. */
+int vpbs_host_set_cpu_budget(unsigned cpus);
+unsigned vpbs_host_cpu_budget(void);
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
                                 vpbs_witness_state** state_out, char* err, size_t err_len);

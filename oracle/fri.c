@@ -157,7 +157,18 @@ int orc_prove_openings(const orc_batch* const* oracles, size_t n_oracles, const 
         pow_witness = forced_pow;
     } else {
         pow_witness = 0;
-        while (!pow_ok(ch, pow_witness, params->pow_bits)) ++pow_witness;
+        if (orc_poseidon_x8_available()) {
+            /* whichever of observe / get performs it, ONE duplexing happens after the witness is observed: the buffered inputs and the
+             * witness (at position input_len) overwrite the state, the permutation runs, the response is state[7] -- scanned eight
+             * candidates per permutation, in order, so the witness is still the smallest valid one */
+            u64 pre[12];
+            memcpy(pre, ch->sponge, sizeof pre);
+            memcpy(pre, ch->input, sizeof(u64) * ch->input_len);
+            pow_witness = orc_pow_search_x8(pre, ch->input_len, params->pow_bits, 0);
+            if (!pow_ok(ch, pow_witness, params->pow_bits)) return -4;
+        } else {
+            while (!pow_ok(ch, pow_witness, params->pow_bits)) ++pow_witness;
+        }
     }
     orc_challenger_observe(ch, &pow_witness, 1);
     (void)orc_challenger_get(ch); /* pow_response */

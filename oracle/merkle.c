@@ -32,12 +32,24 @@ orc_merkle* orc_merkle_new(const u64* leaves, size_t n_leaves, size_t leaf_len, 
     unsigned n_levels = log_leaves - cap_height + 1;
     t->levels = (u64**)calloc(n_levels, sizeof(u64*));
     t->levels[0] = (u64*)malloc(sizeof(u64) * 4 * n_leaves);
+    const int x8 = orc_poseidon_x8_available();   /* eight leaves / nodes per permutation on AVX-512 lanes, same digests */
+    if (x8) {
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n_leaves; ++i) orc_hash_or_noop(t->leaves + i * leaf_len, leaf_len, t->levels[0] + 4 * i);
+        for (size_t i = 0; i < n_leaves; i += 8)
+            orc_hash_rows_x8(t->leaves + i * leaf_len, leaf_len, leaf_len, n_leaves - i < 8 ? n_leaves - i : 8, t->levels[0] + 4 * i);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n_leaves; ++i) orc_hash_or_noop(t->leaves + i * leaf_len, leaf_len, t->levels[0] + 4 * i);
+    }
     ORC_TRACE("  leaf hashing", t0); t0 = orc_now();
     for (unsigned k = 1; k < n_levels; ++k) {
         size_t cnt = n_leaves >> k;
         t->levels[k] = (u64*)malloc(sizeof(u64) * 4 * cnt);
+        if (x8 && cnt >= 8) {
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < cnt; i += 8) orc_two_to_one_x8(t->levels[k - 1] + 8 * i, cnt - i < 8 ? cnt - i : 8, t->levels[k] + 4 * i);
+            continue;
+        }
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < cnt; ++i)
             orc_two_to_one(t->levels[k - 1] + 8 * i, t->levels[k - 1] + 8 * i + 4, t->levels[k] + 4 * i);

@@ -37,6 +37,10 @@ void orc_poseidon(u64 s[12]) {
 }
 
 void orc_poseidon_batch(u64* states, size_t n) {
+    if (n >= 8 && orc_poseidon_x8_available()) {
+        orc_poseidon_batch_x8(states, n);
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) orc_poseidon(states + 12 * i);
 }

@@ -44,6 +44,15 @@ void orc_poseidon_batch(u64* states, size_t n);                 /* n independent
 void orc_hash_no_pad(const u64* in, size_t n, u64 out[4]);      /* PoseidonHash::hash_no_pad   */
 void orc_hash_or_noop(const u64* in, size_t n, u64 out[4]);     /* H::hash_or_noop             */
 void orc_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]);/* H::two_to_one               */
+/* The same permutation eight at a time on AVX-512 lanes (poseidon_x8.c; naive round structure, lazy reductions): used by orc_poseidon_batch,
+ * the Merkle trees and the proof-of-work scan when the CPU has AVX-512F/DQ (ORC_POSEIDON_X8=0 or orc_poseidon_x8_enable(0): scalar only).
+ * Checked against orc_poseidon by tests/test_oracle_cpu.py. */
+int orc_poseidon_x8_available(void);
+int orc_poseidon_x8_enable(int on);
+void orc_poseidon_batch_x8(u64* states, size_t n);
+void orc_hash_rows_x8(const u64* rows, size_t stride, size_t len, size_t count, u64* out /* [count][4] */);
+void orc_two_to_one_x8(const u64* children /* [2 count][4] */, size_t count, u64* parents /* [count][4] */);
+u64 orc_pow_search_x8(const u64 state[12], unsigned pos, unsigned pow_bits, u64 start);
 /* Hasher::hash_pad (plonk/config.rs): pad10*1 -- push 1, zeros until len + 1 is a multiple of the rate 8, push 1 -- then hash_no_pad */
 void orc_hash_pad(const u64* in, size_t n, u64 out[4]);
 /* hash chain of verify_hash_output, /root/reference/src/vtfhe/ivc_based_vpbs.rs:64-78 */

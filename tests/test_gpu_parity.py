@@ -794,6 +794,27 @@ def test_native_rccl_collectives_single_rank(ctx):
 
 
 @pytest.mark.gpu
+def test_native_rccl_world_gt1():
+    """The library's RCCL communicator with MORE than one rank -- one process per GPU, ncclAllGather / ncclAllReduce over xGMI: a sharded step
+    proof of the frozen regression circuits ends, on every rank, with the frozen single-GPU words and bytes.  Runs by itself wherever at least
+    two devices are visible (an 8-GPU node: 2, 4 and 8 ranks); the one-GPU boxes of the test pool skip it -- there the same vpbs_comm contract
+    is covered with one native rank (test_native_rccl_collectives_single_rank) and with 2 / 4 / 8 callback ranks over gloo."""
+    import subprocess
+    import sys
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two GPUs (this box shows %d)" % n_dev)
+    script = os.path.join(ROOT, "tests", "rccl_world_step_gpu.py")
+    for world in [w for w in (2, 4, 8) if w <= n_dev]:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                            "--master-port", str(29560 + world), script], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert "RCCL_WORLD_OK world=%d" % world in r.stdout
+
+
+@pytest.mark.gpu
 def test_host_to_device_helpers():
     """vpbs_device_upload_bg (the context's upload stream, callable beside a running proof) and vpbs_device_upload_rows (a row range of every
     column of a column-major matrix): the device ends up with exactly the bytes asked for, nothing else touched"""

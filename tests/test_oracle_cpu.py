@@ -409,3 +409,56 @@ def test_oracle_reproduces_frozen_step_proofs():
             p = step_oracle.prove_step(b["inputs"], rc.DIGEST, b["pis"], b["log_n"], sigmas=b["sigma"], n_routed=80,
                                        n_constants=b["n_constants"], gates=go.GateSet(b["gates"]))
         rc.check(case, p)
+
+
+def test_oracle_x8_poseidon_matches_the_kat_pinned_scalar_form():
+    """oracle/poseidon_x8.c (eight permutations per AVX-512 register: what the oracle's Merkle trees, its proof-of-work scan and bench.py's
+    cpu_baseline use where the CPU has AVX-512) against the scalar orc_poseidon that the upstream KATs pin: the KAT vectors themselves,
+    random and edge-valued states, ragged batch sizes, leaf hashing / tree levels / the PoW scan in both forms."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_poseidon_x8_enable.restype, L.orc_poseidon_x8_enable.argtypes = C.c_int, [C.c_int]
+    if not L.orc_poseidon_x8_enable(1):
+        pytest.skip("no AVX-512F/DQ on this CPU: the oracle only has its scalar permutation here")
+    try:
+        import step_oracle
+        kat = json.load(open(os.path.join(GOLD, "poseidon_kat.json")))["kats"]
+        rng = np.random.default_rng(77)
+        edge = np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 1 << 32, 0xFFFFFFFF00000000, 1 << 63], np.uint64)
+        for n in (8, 9, 15, 16, 23, 1000):
+            st = rng.integers(0, P, size=(n, 12), dtype=np.uint64)
+            st[rng.random(st.shape) < 0.2] = edge[rng.integers(0, edge.size)]
+            for i, v in enumerate(kat[:min(n, len(kat))]):
+                st[i] = np.array([int(x) for x in v["input"]], np.uint64)
+            want = np.stack([orc.poseidon(s) for s in st])
+            got = st.copy()
+            L.orc_poseidon_batch(orc.ptr(got), n)          # n >= 8: the x8 path
+            assert (got == want).all(), n
+            for i, v in enumerate(kat[:min(n, len(kat))]):
+                assert [int(x) for x in got[i]] == [int(x) for x in v["output"]]
+        # trees: leaf lengths on both sides of the hash_or_noop boundary and of the sponge blocks, ragged leaf counts via the cap height
+        for leaf_len, log_leaves, cap in ((3, 5, 1), (4, 4, 0), (5, 6, 2), (8, 5, 4), (9, 7, 3), (135, 6, 4), (32, 4, 4)):
+            leaves = rng.integers(0, P, size=(1 << log_leaves, leaf_len), dtype=np.uint64)
+            L.orc_poseidon_x8_enable(0)
+            a = orc.Merkle(leaves, cap)
+            cap_a, path_a = a.cap(), a.prove(3)
+            L.orc_poseidon_x8_enable(1)
+            b = orc.Merkle(leaves, cap)
+            assert (b.cap() == cap_a).all() and (b.prove(3) == path_a).all(), (leaf_len, log_leaves, cap)
+        # a whole FRI proof (trees, proof-of-work scan: the smallest nonce) in both forms
+        log_n = 6
+        datas = [rng.integers(0, P, size=(nc, 1 << log_n), dtype=np.uint64) for nc in (4, 6, 3, 2)]
+        proofs = []
+        for on in (0, 1):
+            L.orc_poseidon_x8_enable(on)
+            ob = [orc.Batch(d, 3, 4, from_values=(i != 3)) for i, d in enumerate(datas)]
+            ch = orc.ChallengerState()
+            for o in ob:
+                ch.observe(o.cap())
+            zeta = ch.get_ext()
+            batches, zeta_next = step_oracle.step_batches([4, 6, 3, 2], 2, zeta, log_n)
+            ch.observe(np.concatenate([o.eval_ext(zeta) for o in ob] + [ob[2].eval_ext(zeta_next)[:2]]))
+            proofs.append(orc.prove_openings(ob, batches, ch, orc.fri_params(log_n), log_n))
+        assert (proofs[0] == proofs[1]).all()
+    finally:
+        L.orc_poseidon_x8_enable(1)

@@ -164,6 +164,8 @@ SIGNATURES = {
     "vpbs_compat_default": (None, [C.POINTER(CompatC)]),
     "vpbs_ctx_set_compat": (_i, [_vp, C.POINTER(CompatC)]),
     "vpbs_ctx_get_compat": (_i, [_vp, C.POINTER(CompatC)]),
+    "vpbs_host_set_cpu_budget": (_i, [_ui]),
+    "vpbs_host_cpu_budget": (_ui, []),
     "vpbs_hash_pad": (None, [U64P, _sz, U64P]),
     "vpbs_circuit_digest": (_i, [C.POINTER(CompatC), U64P, _sz, _ui, U64P]),
     "vpbs_ctx_rate_bits": (_ui, [_vp]),
@@ -337,6 +339,12 @@ def hash_no_pad(x):
     out = np.zeros(4, np.uint64)
     lib().vpbs_hash_no_pad(_ptr(x), x.size, _ptr(out))
     return out
+
+
+def host_set_cpu_budget(cpus):
+    """vpbs_host_set_cpu_budget: the CPUs this process may use for the witness-generation pools (0 = the default: affinity and cgroup quota)"""
+    lib().vpbs_host_set_cpu_budget(int(cpus))
+    return lib().vpbs_host_cpu_budget()
 
 
 def hash_pad(x=()):

@@ -1554,10 +1554,15 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     return rc;
 }
 
-// CPUs this process may really use: the hardware threads, capped by the scheduler affinity and by the cgroup's CPU quota (a container on a
-// 256-thread host is often given 16)
+// vpbs_host_set_cpu_budget: what the host says this PROCESS may use (0 = not set).  Several prover processes share one machine when every
+// GPU of a node has its own rank: each of them sees the whole cgroup quota, so the launcher divides it.
+std::atomic<unsigned> g_cpu_budget{0};
+
+// CPUs this process may really use: the hardware threads, capped by the scheduler affinity, by the cgroup's CPU quota (a container on a
+// 256-thread host is often given 16) and by the budget the host set
 unsigned usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (const unsigned b = g_cpu_budget.load()) n = std::min(n, b);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, (unsigned)std::max(1, CPU_COUNT(&set)));
     if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
@@ -1580,6 +1585,12 @@ unsigned default_phase_threads() {
 }  // namespace vpbs
 
 extern "C" {
+
+int vpbs_host_set_cpu_budget(unsigned cpus) {
+    vpbs::g_cpu_budget.store(cpus);
+    return VPBS_OK;
+}
+unsigned vpbs_host_cpu_budget(void) { return vpbs::usable_cpus(); }
 
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late, char* err, size_t err_len) {
     std::string msg;
@@ -1611,12 +1622,9 @@ static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_
         if (!p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
     lap("presets");
     std::string msg = s.error;
-    if (threads == 0) {
-        static const unsigned early_threads = [] {
-            const char* e = std::getenv("VPBS_EARLY_THREADS");
-            return e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
-        }();
-        threads = early_threads;
+    if (threads == 0) {   // the environment variable overrides the default; the pool keeps the size of the phase's first run either way
+        static const char* const e = std::getenv("VPBS_EARLY_THREADS");
+        threads = e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
     }
     // the generators, then every wire takes its class's value: the late classes are still zero and are overwritten by run_late
     auto fill = [&](unsigned t, unsigned of) {
@@ -1666,10 +1674,8 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
         if (p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
     lap("presets");
     std::string msg = s.error;
-    static const unsigned late_threads = [] {
-        const char* e = std::getenv("VPBS_LATE_THREADS");
-        return e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
-    }();
+    static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
+    const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
     auto scatter = [&](unsigned t, unsigned of) {
         const size_t cnt = p.late_out.size();
         for (size_t k = cnt * t / of, hi = cnt * (t + 1) / of; k < hi; ++k) {
