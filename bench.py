@@ -37,7 +37,7 @@ STEPS_PER_VPBS = 730       # n + 2 with n = 728 (reference src/main.rs:27, ivc_b
 # Degree of the step circuit at N = 1024.  /root/reference/src/vtfhe/ivc_based_vpbs.rs:54-61 pads the common-data circuit with NoopGates
 # until it HAS 2^15 gates and only then calls build(), which appends the public-input hash rows, the PublicInputGate and the constant
 # gates and pads to the next power of two: 2^16 rows (plonky2's cyclic-recursion test uses the same idiom).  Independent check: the
-# step logic without the recursive verifier, described gate by gate in tests/step_circuit.py, already needs 38 312 rows at the paper's
+# step logic without the recursive verifier, described gate by gate in circuitgen/step_circuit.py, already needs 38 312 rows at the paper's
 # parameters (tests/test_gpu_step_circuit.py proves that circuit).  SURVEY.md 8d quotes 2^15; that size is kept as a secondary figure
 # (`survey_degree_2pow15` in the JSON line, `--log-n 15`).
 LOG_N = 16
@@ -103,7 +103,7 @@ def step_circuit():
 
 def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     """The reference's step circuit without its recursive verifier (build_step_circuit, ivc_based_vpbs.rs:80-155, described by
-    tests/step_circuit.py at the paper's parameters: 38 312 gate rows, degree 2^16, 4 105 public inputs) through the whole product
+    circuitgen/step_circuit.py at the paper's parameters: 38 312 gate rows, degree 2^16, 4 105 public inputs) through the whole product
     pipeline: compiled witness generation on host threads into pinned buffers -> H2D -> step proof on the device, `provers` prover
     contexts in flight.  Reported next to the headline: it is a different circuit (6 gate types, real copy constraints, no recursion
     rows) and includes the host stage and the PCIe copy that `value` excludes."""
@@ -445,7 +445,7 @@ def cpu_baseline(gpu_proof=None, runs=5):
     reported.  gpu_proof = (proof, bytes, constants/sigmas cap) of the GPU for the same instance: compared word for word with the first
     run's proof (the bench fails if they differ)."""
     import statistics
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen")]   # the checker and the big-integer model it leans on
     import gates_oracle
     import oracle as orc
     import step_oracle

@@ -24,7 +24,7 @@ GATE_SPEC = ["noop", "constant", "public_input", "arithmetic", "base_sum", "pose
 
 
 class Builder:
-    gate_spec = GATE_SPEC          # the circuit's gate set (tests/cyclic_circuit.py widens it to the 14 standard gates)
+    gate_spec = GATE_SPEC          # the circuit's gate set (circuitgen/cyclic_circuit.py widens it to the 14 standard gates)
 
     def __init__(self):
         self.parent, self.t_row, self.t_col = [], [], []      # targets: ids; wire targets carry (row, column), virtual ones (-1, -1)

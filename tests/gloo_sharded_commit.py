@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen")]
 import oracle as orc  # noqa: E402
 import vpbs_amd  # noqa: E402
 from vpbs_amd import sharding, synth  # noqa: E402

@@ -1,5 +1,5 @@
 """The reference's CYCLIC step circuit (ivc_based_vpbs.rs:159-386: each step proof verifies the previous one in circuit) on the CPU: the
-circuit description of tests/cyclic_circuit.py, witnesses by the PRODUCT's generators (host), proofs by the CPU oracle's prover, every
+circuit description of circuitgen/cyclic_circuit.py, witnesses by the PRODUCT's generators (host), proofs by the CPU oracle's prover, every
 proof accepted by the product's host verifier.  The GPU twin is tests/test_gpu_step_circuit.py::test_ivc_chain_*."""
 import os
 import random

@@ -1,5 +1,5 @@
 """GPU tests (-m gpu): the reference's step circuit without the recursive verifier (build_step_circuit,
-/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155; described by tests/step_circuit.py) through the whole product: compiled witness
+/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155; described by circuitgen/step_circuit.py) through the whole product: compiled witness
 generation on the host (vpbs_witness_plan), the native TFHE data path on the device for the expected accumulators
 (vpbs_pbs_accumulator_chain / vpbs_blind_rotate_step), step proofs on the device with the gate constraints of the six gate types the
 circuit uses, the host verifier -- a verifiable PBS with the IVC hand-over (accumulator, counter, hash chains) done by the caller

@@ -303,16 +303,24 @@ def test_seeded_lwe_encrypt_and_testv_match_the_oracle():
 
 
 def test_prover_tools_load_the_circuit_as_data():
-    """bench.py and tools/prove_pbs.py get the step circuit from the exported file through the product package; neither imports the
-    test-side circuit builder (bench.py touches tests/ only inside its cpu_baseline leg, for the oracle)"""
-    import re
+    """Layering: the product package imports nothing from tests/, circuitgen/ or oracle/; bench.py and the prover tools get their circuits
+    from exported files through the product package and never import the circuit builder (circuitgen/); bench.py touches tests/ (the
+    checker) only inside its cpu_baseline leg; only the exporter tools import circuitgen/"""
+    import glob
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pbs = open(os.path.join(root, "tools", "prove_pbs.py")).read()
-    assert "import step_circuit" not in pbs and '"tests"' not in pbs
+    for path in glob.glob(os.path.join(root, "verifiable-fhe-paper_amd", "*.py")):
+        src = open(path).read()
+        for word in ('"tests"', '"circuitgen"', '"oracle"', "import step_circuit", "import cyclic_circuit", "import pymodel", "import oracle"):
+            assert word not in src, (path, word)
+    for tool in ("prove_pbs.py", "prove_ivc.py"):
+        src = open(os.path.join(root, "tools", tool)).read()
+        assert "import step_circuit" not in src and "import cyclic_circuit" not in src and '"tests"' not in src and '"circuitgen"' not in src, tool
     bench = open(os.path.join(root, "bench.py")).read()
-    assert "import step_circuit" not in bench
-    legs = re.findall(r'sys\.path\.insert\(0, os\.path\.join\(ROOT, "tests"\)\)', bench)
-    assert len(legs) == 1 and bench.index('def cpu_baseline') < bench.index(legs[0])
+    assert "import step_circuit" not in bench and "import cyclic_circuit" not in bench
+    assert bench.count('os.path.join(ROOT, "tests")') == 1 and bench.index("def cpu_baseline") < bench.index('os.path.join(ROOT, "tests")')
+    exporters = {os.path.basename(p) for p in glob.glob(os.path.join(root, "tools", "*.py")) if '"circuitgen"' in open(p).read() or "'circuitgen'" in open(p).read()}
+    assert {"export_step_circuit.py", "step_circuit_sizes.py"} <= exporters
+    assert not {"prove_pbs.py", "prove_ivc.py", "soak.py", "verify_speed.py"} & exporters
 
 
 def test_circuit_file_round_trip(tmp_path):
@@ -352,7 +360,7 @@ COMPAT_POSITIONS = [dict(fri_mul_final_by_x=m, bytes_pi_len_prefix=b, digest_dom
 
 def test_compat_defaults_and_digest_agree_with_the_oracle():
     """the switch table of include/vpbs_prover.h and its copy in oracle/vpbs_oracle.h: same fields, same defaults; hash_pad and the circuit
-    digest of CircuitBuilder::build agree in both formulas, and with a third restatement in plain Python (tests/cyclic_circuit.py)"""
+    digest of CircuitBuilder::build agree in both formulas, and with a third restatement in plain Python (circuitgen/cyclic_circuit.py)"""
     import cyclic_circuit as cc
     assert api.compat_dict() == orc.compat_dict() == dict(fri_mul_final_by_x=0, bytes_pi_len_prefix=1, digest_domain_separator=1, pow_smallest_nonce=1)
     for words in ([], [5], list(range(1, 7)), list(range(1, 8)), list(range(1, 9)), list(range(3, 23))):

@@ -1,5 +1,5 @@
 """CPU tests (-m "not gpu"): the reference's step circuit without the recursive verifier (build_step_circuit,
-/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155) described by the test-side builder (tests/step_circuit.py), witness generated and
+/root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155) described by the test-side builder (circuitgen/step_circuit.py), witness generated and
 checked by the PRODUCT's host code (vpbs_generate_witness / vpbs_check_witness), public inputs compared with the native restatement
 of the same step (tests/tfhe_oracle.py) and the native hash chain.  No device compute."""
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes the step circuit (tests/step_circuit.py: build_step_circuit of the reference without its recursive verifier) as the flat
+"""Writes the step circuit (circuitgen/step_circuit.py: build_step_circuit of the reference without its recursive verifier) as the flat
 circuit description a non-Python host hands to the C ABI -- the same arrays the Rust side would export from CircuitData after
 builder.build(): gates, gate per row, constants columns, copy constraints, gadget generators, the targets the
 PartialWitness sets, the public-input targets; plus one sample PartialWitness and the public inputs it must produce.
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "circuitgen")]
 import step_circuit as sc  # noqa: E402
 from vpbs_amd import api  # noqa: E402
 
@@ -55,7 +55,7 @@ def export(path, N=8, K=2, ELL=4, LOGB=5, n_lwe=6, seed=1):
 
 
 def export_cyclic(path, dummy_path, N, K, ELL, LOGB, n_lwe, log_n):
-    """the CYCLIC step circuit (tests/cyclic_circuit.py: build_step_circuit + the in-circuit verifier of its own previous proof,
+    """the CYCLIC step circuit (circuitgen/cyclic_circuit.py: build_step_circuit + the in-circuit verifier of its own previous proof,
     ivc_based_vpbs.rs:159-275) and the dummy circuit of its base case.  PartialWitness order of the cyclic file: the inner proof's words
     (caps, openings, FriProof as vpbs_prove_step emits them), the inner proof's public inputs, the condition bit, the GGSW, the mask, the
     circuit's own verifier data (digest, cap), the dummy circuit's verifier data.  No sample witness (it would need a proof): the sample

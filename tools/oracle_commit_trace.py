@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),'tests')]
+sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),'tests'), os.path.join(os.getcwd(),'circuitgen')]
 import torch
 import numpy as np, oracle as orc
 from vpbs_amd import synth

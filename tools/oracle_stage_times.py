@@ -1,7 +1,7 @@
 """stage timing of the CPU oracle's step proof (the cpu_baseline of bench.py) on this machine's host cores"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen")]
 import numpy as np, oracle as orc, step_oracle, gates_oracle as go, pymodel
 from vpbs_amd import synth
 import bench

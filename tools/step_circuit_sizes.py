@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Gate rows of the reference's step circuit without its recursive verifier (tests/step_circuit.py) for every ring dimension the
+"""Gate rows of the reference's step circuit without its recursive verifier (circuitgen/step_circuit.py) for every ring dimension the
 reference ships NTT parameters for, at the decomposition parameters of src/main.rs (k = 1, ELL = 4, LOGB = 5, n = 728).  CPU only."""
 import collections
 import os
@@ -7,7 +7,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "circuitgen")]
 import step_circuit as sc  # noqa: E402
 from vpbs_amd import api  # noqa: E402
 

@@ -2,7 +2,7 @@
 edge-valued columns (0, 1, p-1, 2^32-1, 2^63), 1..4 challenges.  Run on the GPU box: python tools/stress_gates.py [cases]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen")]
 import numpy as np, torch
 import gates_oracle as go
 import vpbs_amd
