@@ -47,6 +47,22 @@ int vpbs_ctx_synchronize(vpbs_ctx* ctx);
  * for throughput when several contexts already keep the device busy (-2 % with three chains otherwise). */
 int vpbs_ctx_set_gate_lanes(vpbs_ctx* ctx, unsigned lanes);
 void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share device buffers with the ctx */
+/* Launch heuristics of a context.  Every option has an environment variable of the same meaning that only sets the DEFAULT a new context
+ * starts with (read at vpbs_ctx_create); results never depend on any of them -- they choose between bit-identical kernel arrangements. */
+typedef enum {
+    VPBS_OPT_GATE_LANES = 0,      /* 1 | 3: streams of the gate-constraint stage (= vpbs_ctx_set_gate_lanes).            VPBS_GATE_LANES     */
+    VPBS_OPT_GATES_FUSED = 1,     /* 1 (default): all gate constraints in one launch; 0: one launch per gate type.       VPBS_GATES_FUSED    */
+    VPBS_OPT_GATE_ITEMS = 2,      /* 1..8 (default 5): work items per point tile of the one-launch gate kernel.          VPBS_GATE_ITEMS     */
+    VPBS_OPT_WIDE_THRESHOLD = 3,  /* launches with at most this many independent permutations use the 16-lane Poseidon
+                                     form (default 2^14).                                                                VPBS_WIDE_THRESHOLD */
+    VPBS_OPT_MERKLE_CLIMB = 4     /* 1 (default): the upper levels of a tree in fused multi-level launches; 0: per level. VPBS_MERKLE_CLIMB  */
+} vpbs_option;
+int vpbs_ctx_set_option(vpbs_ctx* ctx, int option, uint64_t value);
+int vpbs_ctx_get_option(const vpbs_ctx* ctx, int option, uint64_t* value_out);
+/* Host side (process-wide): independent Poseidon permutations eight at a time on AVX-512 lanes (witness generation, the verifier's Merkle
+ * paths) where the CPU has them.  on = 0 forces the scalar form (A/B measurements, tests); returns what is in force.  Default: on, or the
+ * environment variable VPBS_POSEIDON_X8. */
+int vpbs_host_set_poseidon_x8(int on);
 /* the FriConfig shape the context was created for (vpbs_ctx_create's rate_bits / cap_height); 0 for a null context */
 unsigned vpbs_ctx_rate_bits(const vpbs_ctx* ctx);
 unsigned vpbs_ctx_cap_height(const vpbs_ctx* ctx);

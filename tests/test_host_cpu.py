@@ -178,11 +178,9 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
     rnd = np.random.default_rng(17)
     sweep = [("fri", 0), ("fri", proof["fri"].size // 2), ("fri", proof["fri"].size - 1), ("openings", 3), ("caps", 5)] + \
             [("fri", int(q)) for q in rnd.integers(0, proof["fri"].size, 120)]
-    for form in ("", "0"):
-        os.environ["VPBS_POSEIDON_X8"] = form
+    for form in (True, False):
+        api.host_set_poseidon_x8(form)
         try:
-            if not form:
-                del os.environ["VPBS_POSEIDON_X8"]
             assert api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis, log_n)
             for key, pos in sweep:
                 bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in proof.items()}
@@ -190,7 +188,7 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering():
                 flat[pos] = (int(flat[pos]) + 1) % P
                 assert not api.verify_step_fri_only(bad, proof["cs_cap"], ncols, digest, pis, log_n), (key, pos)
         finally:
-            os.environ.pop("VPBS_POSEIDON_X8", None)
+            api.host_set_poseidon_x8(True)
     assert not api.verify_step_fri_only(proof, proof["cs_cap"], ncols, digest, pis[:-1], log_n)   # different public inputs
     # the default is the full check: without the circuit's shape it refuses instead of quietly running the FRI part alone
     with pytest.raises(ValueError):

@@ -164,6 +164,9 @@ SIGNATURES = {
     "vpbs_compat_default": (None, [C.POINTER(CompatC)]),
     "vpbs_ctx_set_compat": (_i, [_vp, C.POINTER(CompatC)]),
     "vpbs_ctx_get_compat": (_i, [_vp, C.POINTER(CompatC)]),
+    "vpbs_ctx_set_option": (_i, [_vp, _i, _u64]),
+    "vpbs_ctx_get_option": (_i, [_vp, _i, U64P]),
+    "vpbs_host_set_poseidon_x8": (_i, [_i]),
     "vpbs_host_set_cpu_budget": (_i, [_ui]),
     "vpbs_host_cpu_budget": (_ui, []),
     "vpbs_hash_pad": (None, [U64P, _sz, U64P]),
@@ -339,6 +342,11 @@ def hash_no_pad(x):
     out = np.zeros(4, np.uint64)
     lib().vpbs_hash_no_pad(_ptr(x), x.size, _ptr(out))
     return out
+
+
+def host_set_poseidon_x8(on):
+    """vpbs_host_set_poseidon_x8: the host's eight-permutations-per-AVX-512-register Poseidon on / off (process-wide) -> what is in force"""
+    return bool(lib().vpbs_host_set_poseidon_x8(1 if on else 0))
 
 
 def host_set_cpu_budget(cpus):
@@ -914,6 +922,18 @@ class Context:
     def set_gate_lanes(self, lanes):
         """3 (default): gate-constraint kernels over three streams (best single-chain latency); 1: one stream (multi-chain throughput)"""
         self._check(lib().vpbs_ctx_set_gate_lanes(self.h, lanes))
+
+    OPTIONS = {"gate_lanes": 0, "gates_fused": 1, "gate_items": 2, "wide_threshold": 3, "merkle_climb": 4}
+
+    def set_option(self, name, value):
+        """vpbs_ctx_set_option: a launch heuristic of this context (never changes a result); names: Context.OPTIONS"""
+        if lib().vpbs_ctx_set_option(self.h, self.OPTIONS[name], int(value)):
+            raise VpbsError("vpbs_ctx_set_option(%s, %r): not a valid value" % (name, value))
+
+    def get_option(self, name):
+        v = C.c_uint64()
+        self._check(lib().vpbs_ctx_get_option(self.h, self.OPTIONS[name], C.byref(v)))
+        return int(v.value)
 
     def set_compat(self, k=None, **over):
         """the context proves and serialises under this switch table (vpbs_ctx_set_compat); set_compat() restores the defaults"""

@@ -208,7 +208,7 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
         }
         {
             Timed t(ctx, "merkle_levels");
-            launch_merkle_tree(ctx->stream, b->d_digests, b->level_off.data(), b->n_levels(), L);
+            launch_merkle_tree(ctx->stream, ctx->tune, b->d_digests, b->level_off.data(), b->n_levels(), L);
         }
         VPBS_HIP(hipGetLastError());
     } catch (...) {
@@ -310,6 +310,31 @@ int vpbs_ctx_set_gate_lanes(vpbs_ctx* c, unsigned lanes) {
     if (!c || (lanes != 1 && lanes != 3)) return VPBS_ERR_INVALID;
     c->gate_lanes = lanes;
     return VPBS_OK;
+}
+int vpbs_ctx_set_option(vpbs_ctx* c, int option, uint64_t value) {
+    if (!c) return VPBS_ERR_INVALID;
+    switch (option) {
+        case VPBS_OPT_GATE_LANES: return vpbs_ctx_set_gate_lanes(c, (unsigned)value);
+        case VPBS_OPT_GATES_FUSED: c->tune.gates_fused = value != 0; return VPBS_OK;
+        case VPBS_OPT_GATE_ITEMS:
+            if (value < 1 || value > 8) return VPBS_ERR_INVALID;
+            c->tune.gate_items = (unsigned)value;
+            return VPBS_OK;
+        case VPBS_OPT_WIDE_THRESHOLD: c->tune.wide_threshold = (size_t)value; return VPBS_OK;
+        case VPBS_OPT_MERKLE_CLIMB: c->tune.merkle_climb = value != 0; return VPBS_OK;
+        default: return VPBS_ERR_INVALID;
+    }
+}
+int vpbs_ctx_get_option(const vpbs_ctx* c, int option, uint64_t* out) {
+    if (!c || !out) return VPBS_ERR_INVALID;
+    switch (option) {
+        case VPBS_OPT_GATE_LANES: *out = c->gate_lanes; return VPBS_OK;
+        case VPBS_OPT_GATES_FUSED: *out = c->tune.gates_fused; return VPBS_OK;
+        case VPBS_OPT_GATE_ITEMS: *out = c->tune.gate_items; return VPBS_OK;
+        case VPBS_OPT_WIDE_THRESHOLD: *out = c->tune.wide_threshold; return VPBS_OK;
+        case VPBS_OPT_MERKLE_CLIMB: *out = c->tune.merkle_climb; return VPBS_OK;
+        default: return VPBS_ERR_INVALID;
+    }
 }
 const char* vpbs_last_error(const vpbs_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int vpbs_ctx_synchronize(vpbs_ctx* c) {
@@ -590,7 +615,7 @@ int vpbs_k_merkle_cap(vpbs_ctx* c, const uint64_t* leaves, size_t n_leaves, unsi
         } else {
             vpbs::launch_hash_rows(c->stream, in.p, n_leaves, leaf_len, dig.p);
         }
-        vpbs::launch_merkle_tree(c->stream, dig.p, off.data(), (unsigned)off.size(), n_leaves);
+        vpbs::launch_merkle_tree(c->stream, c->tune, dig.p, off.data(), (unsigned)off.size(), n_leaves);
         VPBS_HIP(hipMemcpyAsync(cap_out, dig.p + off.back(), sizeof(u64) * ((size_t)4 << cap_height), hipMemcpyDeviceToHost, c->stream));
         VPBS_HIP(hipStreamSynchronize(c->stream));
     });
@@ -852,10 +877,20 @@ int vpbs_circuit_digest(const vpbs_compat* compat, const uint64_t* cap, size_t c
     return VPBS_OK;
 }
 
+int vpbs_host_set_poseidon_x8(int on) {
+#if defined(VPBS_HAVE_POSEIDON_X8)
+    poseidon_x8::switch_state().store(on ? 1 : 0);
+    return poseidon_x8::enabled() ? 1 : 0;
+#else
+    (void)on;
+    return 0;
+#endif
+}
+
 int vpbs_k_poseidon_host(uint64_t* states, size_t n) {
     if (!states && n) return VPBS_ERR_INVALID;
 #if defined(VPBS_HAVE_POSEIDON_X8)
-    if (poseidon_x8::available()) {
+    if (poseidon_x8::enabled()) {
         poseidon_x8::permute_many(states, n);
         return 1;
     }

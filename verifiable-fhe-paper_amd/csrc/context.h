@@ -37,6 +37,7 @@ struct vpbs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t upload_stream = nullptr;   // vpbs_device_upload_bg: host->device copies next to the work on `stream`
     unsigned log_n_max = 0, rate_bits = 3, cap_height = 4;
+    vpbs::Tuning tune = vpbs::Tuning::from_env();   // vpbs_ctx_set_option
     vpbs_compat compat{0, 1, 1, 1};   // vpbs_compat_default: plonky2 0.2.0 as restated (include/vpbs_prover.h, the switch table)
     std::string err;
 
@@ -69,7 +70,11 @@ struct vpbs_ctx {
     hipStream_t gate_streams[2] = {nullptr, nullptr};
     hipEvent_t gate_fork = nullptr, gate_join[2] = {nullptr, nullptr};
     void ensure_gate_lanes();
-    unsigned gate_lanes = 3;
+    unsigned gate_lanes = default_gate_lanes();   // 3, or 1 with VPBS_GATE_LANES=1 in the environment; vpbs_ctx_set_gate_lanes
+    static unsigned default_gate_lanes() {
+        const char* e = getenv("VPBS_GATE_LANES");
+        return e && atoi(e) == 1 ? 1u : 3u;
+    }
 
     // ---- timing ----
     vpbs::u64* d_clock_samples = nullptr;   // [CLOCK_SAMPLES][2], one pair per leaf-hash launch while timing is on (ring)

@@ -487,7 +487,7 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
 // Work items of the one-launch path: the gates with constraints, heaviest first, packed into n_items groups of about equal weight (the
 // PoseidonGate is an item by itself).  Fewer items = fewer output planes; more items = more blocks sharing one tile's columns in L2.
 // Returns false when the gate set does not fit the plan (more gates than FUSED_MAX_GATES, or two CosetInterpolationGates).
-static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, FusedPlan& plan) {
+static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, unsigned max_items, FusedPlan& plan) {
     std::vector<unsigned> order;
     unsigned n_coset = 0, total = 0, heaviest = 1;
     for (unsigned i = 0; i < n_gates; ++i) {
@@ -501,7 +501,6 @@ static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, FusedPlan& pl
         }
     }
     if (order.empty() || order.size() > FUSED_MAX_GATES) return false;
-    static const unsigned max_items = [] { const char* e = getenv("VPBS_GATE_ITEMS"); return e ? (unsigned)atoi(e) : 5u; }();
     const unsigned n_items = std::max(1u, std::min({(unsigned)order.size(), (total + heaviest - 1) / heaviest, max_items, FUSED_MAX_ITEMS}));
     std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return gate_weight(gs[a]) > gate_weight(gs[b]); });
     std::vector<std::vector<unsigned>> bins(n_items);
@@ -521,16 +520,17 @@ static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, FusedPlan& pl
     return true;
 }
 
-unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates) {
+unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates, unsigned max_items) {
     FusedPlan plan{};
-    return make_fused_plan(gs, n_gates, plan) ? plan.n_items : 0;
+    return make_fused_plan(gs, n_gates, max_items, plan) ? plan.n_items : 0;
 }
 
 // d_planes: [n_items][nc][len]; returns the number of planes written (0: the gate set does not fit the one-launch path, nothing launched)
-unsigned launch_gate_terms_fused(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs, unsigned n_gates,
-                                 unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes) {
+unsigned launch_gate_terms_fused(hipStream_t s, unsigned max_items, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs,
+                                 unsigned n_gates, unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc,
+                                 u64* d_planes) {
     FusedPlan plan{};
-    if (!make_fused_plan(gs, n_gates, plan)) return 0;
+    if (!make_fused_plan(gs, n_gates, max_items, plan)) return 0;
     PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
     const unsigned n_tiles = (unsigned)((len + FUSED_TILE - 1) / FUSED_TILE);
     const int xcd_map = n_tiles % 8 == 0;

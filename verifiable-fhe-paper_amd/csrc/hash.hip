@@ -219,17 +219,19 @@ void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_le
     hipLaunchKernelGGL(leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
                        col_stride, digests, clock_sample);
 }
-// below this many independent permutations a launch is latency-bound and the 16-lane form wins (measured)
-static size_t wide_threshold() {
-    static const size_t t = [] {
-        const char* e = getenv("VPBS_WIDE_THRESHOLD");
-        return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 14);
-    }();
+// the defaults of a context's launch heuristics: below wide_threshold independent permutations a launch is latency-bound and the 16-lane
+// form wins (measured)
+Tuning Tuning::from_env() {
+    Tuning t;
+    if (const char* e = getenv("VPBS_WIDE_THRESHOLD")) t.wide_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("VPBS_MERKLE_CLIMB")) t.merkle_climb = atoi(e) != 0;
+    if (const char* e = getenv("VPBS_GATES_FUSED")) t.gates_fused = atoi(e) != 0;
+    if (const char* e = getenv("VPBS_GATE_ITEMS")) t.gate_items = (unsigned)std::max(1, atoi(e));
     return t;
 }
 
-void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests) {
-    if (n_leaves <= wide_threshold() && (2u << arity_bits) > 4) {
+void launch_fri_leaf_hash(hipStream_t s, const Tuning& tune, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests) {
+    if (n_leaves <= tune.wide_threshold && (2u << arity_bits) > 4) {
         hipLaunchKernelGGL(fri_leaf_hash_wide_kernel, dim3((unsigned)((n_leaves * 16 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, v0,
                            v1, n_leaves, arity_bits, digests);
         return;
@@ -237,8 +239,8 @@ void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_
     hipLaunchKernelGGL(fri_leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, v0, v1, n_leaves,
                        arity_bits, digests);
 }
-void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_t n_parents) {
-    if (n_parents <= wide_threshold()) {
+void launch_merkle_level(hipStream_t s, const Tuning& tune, const u64* children, u64* parents, size_t n_parents) {
+    if (n_parents <= tune.wide_threshold) {
         hipLaunchKernelGGL(merkle_level_wide_kernel, dim3((unsigned)((n_parents * 16 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
                            children, parents, n_parents);
         return;
@@ -246,18 +248,18 @@ void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_
     hipLaunchKernelGGL(merkle_level_kernel, dim3((n_parents + THREADS - 1) / THREADS), dim3(THREADS), 0, s, children, parents,
                        n_parents);
 }
-void launch_merkle_tree(hipStream_t s, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves) {
+void launch_merkle_tree(hipStream_t s, const Tuning& tune, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves) {
     unsigned k = 1;
     // big levels: one launch each (the chip is full)
-    for (; k < n_levels && (n_leaves >> k) > wide_threshold(); ++k)
-        launch_merkle_level(s, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
+    for (; k < n_levels && (n_leaves >> k) > tune.wide_threshold; ++k)
+        launch_merkle_level(s, tune, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
     // the latency-bound rest: up to CLIMB_MAX_LEVELS levels per launch
-    static const bool fused = [] { const char* e = getenv("VPBS_MERKLE_CLIMB"); return !e || atoi(e) != 0; }();
+    const bool fused = tune.merkle_climb;
     while (k < n_levels) {
         const size_t n_children = n_leaves >> (k - 1);
         unsigned levels = std::min(CLIMB_MAX_LEVELS, n_levels - k);
         if (!fused || levels < 2) {
-            launch_merkle_level(s, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
+            launch_merkle_level(s, tune, digests + level_off[k - 1], digests + level_off[k], n_leaves >> k);
             ++k;
             continue;
         }

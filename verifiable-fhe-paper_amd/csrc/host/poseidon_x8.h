@@ -10,6 +10,9 @@
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
 
+#include <atomic>
+#include <cstdlib>
+
 #include "../poseidon.h"
 
 namespace poseidon_x8 {
@@ -22,6 +25,20 @@ using V = __m512i;
 inline bool available() {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
     return ok;
+}
+// vpbs_host_set_poseidon_x8: -1 = not set (the environment variable VPBS_POSEIDON_X8 decides, default on)
+inline std::atomic<int>& switch_state() {
+    static std::atomic<int> s{-1};
+    return s;
+}
+inline bool enabled() {
+    int s = switch_state().load(std::memory_order_relaxed);
+    if (s < 0) {
+        const char* e = std::getenv("VPBS_POSEIDON_X8");
+        s = !(e && std::atoi(e) == 0);
+        switch_state().store(s, std::memory_order_relaxed);
+    }
+    return s != 0 && available();
 }
 
 X8 V bc(u64 x) { return _mm512_set1_epi64((long long)x); }

@@ -86,8 +86,8 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
 // The same sum in ONE launch over (point tile x work item) with an XCD-aware block numbering (gates.hip): every item writes its own plane
 // d_planes[item][nc][len]; the sum over the planes is the value launch_gate_terms would produce.  gate_terms_planes: how many planes the gate
 // set needs (0 = not supported by this path, use launch_gate_terms).
-unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates);
-unsigned launch_gate_terms_fused(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
+unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates, unsigned max_items);
+unsigned launch_gate_terms_fused(hipStream_t s, unsigned max_items, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                                  unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes);
 void launch_sum_planes(hipStream_t s, const u64* d_planes, unsigned n_planes, size_t words, u64* d_out);
 // throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
@@ -104,16 +104,26 @@ void launch_blind_rotate_step(hipStream_t s, const u64* acc_in, const u64* masks
                               const u64* roots, const u64* invroots, u64 ninv, unsigned log_n, unsigned K, unsigned ELL, unsigned LOGB,
                               unsigned batch, int first_step, int last_step, u64* limbs_hat, u64* acc_out);
 
+// Launch heuristics of one context (vpbs_ctx_set_option; the environment variables of the same names are only the DEFAULTS a context is
+// created with: VPBS_WIDE_THRESHOLD, VPBS_MERKLE_CLIMB, VPBS_GATES_FUSED, VPBS_GATE_ITEMS, VPBS_GATE_LANES)
+struct Tuning {
+    size_t wide_threshold = (size_t)1 << 14;   // launches with at most this many independent permutations use the 16-lane Poseidon form
+    bool merkle_climb = true;                  // the latency-bound upper levels of a tree in fused multi-level launches
+    bool gates_fused = true;                   // all gate constraints in one launch (false: one launch per gate type)
+    unsigned gate_items = 5;                   // work items per point tile of the one-launch gate kernel
+    static Tuning from_env();
+};
+
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)
 // clock_sample: nullptr, or two device words that receive {shader cycles, 100 MHz ticks} over the lifetime of one wave of the launch
 void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests, u64* clock_sample = nullptr);
 // FRI round leaves: leaf l = flatten(values[arity*l .. arity*(l+1))) of ext values stored SoA [2][m]
-void launch_fri_leaf_hash(hipStream_t s, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests);
+void launch_fri_leaf_hash(hipStream_t s, const Tuning& tune, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests);
 // parents[i] = two_to_one(children[2i], children[2i+1])
-void launch_merkle_level(hipStream_t s, const u64* children, u64* parents, size_t n_parents);
+void launch_merkle_level(hipStream_t s, const Tuning& tune, const u64* children, u64* parents, size_t n_parents);
 // builds every level above `level0` up to the cap; levels are stored back to back: level k at digests + off[k]
-void launch_merkle_tree(hipStream_t s, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves);
+void launch_merkle_tree(hipStream_t s, const Tuning& tune, u64* digests, const size_t* level_off, unsigned n_levels, size_t n_leaves);
 // batch of independent permutations (test hook)
 void launch_permute_batch(hipStream_t s, u64* states, size_t n);
 // hash_no_pad over rows of a row-major matrix [n][len] (test hook / chain hashing of key material)

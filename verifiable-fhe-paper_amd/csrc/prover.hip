@@ -206,8 +206,8 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         t.digests = words(dig_words);
         {
             Timed tm(ctx, "fri_tree");
-            vpbs::launch_fri_leaf_hash(s, t.values, t.values + lde_len, t.n_leaves, ab, t.digests);
-            vpbs::launch_merkle_tree(s, t.digests, t.level_off.data(), (unsigned)t.level_off.size(), t.n_leaves);
+            vpbs::launch_fri_leaf_hash(s, ctx->tune, t.values, t.values + lde_len, t.n_leaves, ab, t.digests);
+            vpbs::launch_merkle_tree(s, ctx->tune, t.digests, t.level_off.data(), (unsigned)t.level_off.size(), t.n_leaves);
         }
         ctx->d2h_sync(w, t.digests + t.level_off.back(), sizeof(u64) * cap_words);
         challenger.observe_cap(w, cap_words / 4);
@@ -333,11 +333,8 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
     VPBS_REQUIRE(flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
 }
 
-// the one-launch gate kernel (gates.hip) is the default; VPBS_GATES_FUSED=0 selects the per-gate launches (kept for comparison)
-static bool gates_fused_enabled() {
-    static const bool on = [] { const char* e = getenv("VPBS_GATES_FUSED"); return !e || atoi(e) != 0; }();
-    return on;
-}
+// the one-launch gate kernel (gates.hip) is the default; vpbs_ctx_set_option(VPBS_OPT_GATES_FUSED, 0) selects the per-gate launches (kept
+// for comparison)
 
 // evaluate_gate_constraints_base_batch folded with the alphas, on the device; d_out: [nc][local LDE length]
 void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors,
@@ -358,19 +355,18 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
     }
     u64* d_apow = ctx->alloc_words(h_apow.size());
     // three lanes (streams) when the gate set is large enough to be worth the fork / join (vpbs_ctx_set_gate_lanes; the environment
-    // variable VPBS_GATE_LANES=1 forces one stream for every context)
-    static const bool env_single = [] { const char* e = getenv("VPBS_GATE_LANES"); return e && atoi(e) == 1; }();
-    const bool multi = !env_single && ctx->gate_lanes == 3;
+    // variable VPBS_GATE_LANES=1 makes one stream the default of every context)
+    const bool multi = ctx->gate_lanes == 3;
     const size_t len = wires->lde_len();
     u64* lane_buf = nullptr;
-    const unsigned n_planes = gates_fused_enabled() ? vpbs::gate_terms_planes(gs, n_gates) : 0;
+    const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gs, n_gates, ctx->tune.gate_items) : 0;
     if (n_planes) {  // one launch over (tile x item), then the sum of the items' planes
         u64* planes = nullptr;
         try {
             planes = ctx->alloc_words((size_t)n_planes * nc * len);
             VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
             Timed t(ctx, "gate_constraints");
-            vpbs::launch_gate_terms_fused(ctx->stream, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, planes);
+            vpbs::launch_gate_terms_fused(ctx->stream, ctx->tune.gate_items, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, planes);
             vpbs::launch_sum_planes(ctx->stream, planes, n_planes, (size_t)nc * len, d_out);
             VPBS_HIP(hipGetLastError());
         } catch (...) {
@@ -485,7 +481,7 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                 }
             }
             d_gpow = ctx->alloc_words(h_gpow.size());
-            const unsigned n_planes = gates_fused_enabled() ? vpbs::gate_terms_planes(gw->gates, gw->n_gates) : 0;
+            const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gw->gates, gw->n_gates, ctx->tune.gate_items) : 0;
             lane_buf = ctx->alloc_words(std::max(3u, n_planes) * (size_t)nc * local_len);
             VPBS_HIP(hipMemcpyAsync(d_gpow, h_gpow.data(), sizeof(u64) * h_gpow.size(), hipMemcpyHostToDevice, s));
             ctx->ensure_gate_lanes();
@@ -501,7 +497,7 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                                              ctx->roots(log_big, false), l0, nullptr, d_apow, betas, gammas, n_routed, log_n, rate_bits, max_degree, nc,
                                              leaf_offset, local_len, q_local, true);
                 VPBS_HIP(hipEventRecord(ctx->gate_join[0], ctx->gate_streams[0]));
-                vpbs::launch_gate_terms_fused(s, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride,
+                vpbs::launch_gate_terms_fused(s, ctx->tune.gate_items, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride,
                                               nc, lane_buf);
                 VPBS_HIP(hipStreamWaitEvent(s, ctx->gate_join[0], 0));
                 vpbs::launch_quotient_combine_planes(s, q_local, lane_buf, n_planes, apow_last, log_n, rate_bits, nc, leaf_offset, local_len);
@@ -793,8 +789,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             u64* d_q = ctx->alloc_words((size_t)in->n_quotient * n);
             staged.push_back(d_q);
             u64* d_gate = nullptr;
-            static const bool env_single = [] { const char* e = getenv("VPBS_GATE_LANES"); return e && atoi(e) == 1; }();
-            const bool overlapped = in->gates && in->n_gates >= 4 && ctx->gate_lanes == 3 && !env_single;
+            const bool overlapped = in->gates && in->n_gates >= 4 && ctx->gate_lanes == 3;
             if (in->gates && in->n_gates && !overlapped) {  // evaluate_gate_constraints_base_batch for the circuit's gate set
                 VPBS_REQUIRE(in->num_selectors <= in->n_constants, "selector columns must be leading constants columns");
                 d_gate = ctx->alloc_words((size_t)nc * wires.h->lde_len());

@@ -109,8 +109,7 @@ bool merkle_verify_x8(const MerkleJob* jobs, unsigned cnt) {   // cnt <= 8 jobs 
 #endif
 bool merkle_verify_all(std::vector<MerkleJob>& jobs) {
 #if defined(VPBS_HAVE_POSEIDON_X8)
-    const char* sw = std::getenv("VPBS_POSEIDON_X8");   // "0": one path after the other (A/B measurements, tests of that form)
-    if (poseidon_x8::available() && !(sw && std::atoi(sw) == 0)) {
+    if (poseidon_x8::enabled()) {   // vpbs_host_set_poseidon_x8(0): one path after the other (A/B measurements, tests of that form)
         std::stable_sort(jobs.begin(), jobs.end(), [](const MerkleJob& a, const MerkleJob& b) {
             return a.leaf_len != b.leaf_len ? a.leaf_len < b.leaf_len : a.n_sib < b.n_sib;
         });

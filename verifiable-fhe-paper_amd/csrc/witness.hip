@@ -1411,7 +1411,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     }
     threads = pool->threads;
 #if defined(VPBS_HAVE_POSEIDON_X8)
-    static const bool x8 = poseidon_x8::available() && !(std::getenv("VPBS_POSEIDON_X8") && std::atoi(std::getenv("VPBS_POSEIDON_X8")) == 0);
+    const bool x8 = poseidon_x8::enabled();   // vpbs_host_set_poseidon_x8
 #endif
     std::atomic<bool> failed{false};
     std::vector<std::string> errs(threads);
