@@ -5,7 +5,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=/tmp/vpbs_asan; mkdir -p $OUT
 cd "$ROOT/verifiable-fhe-paper_amd/csrc"
-for f in ntt hash fri permutation quotient gates witness tfhe keygen comm_rccl api prover verifier ivc; do
+for f in ntt hash fri permutation quotient gates witness witness_device tfhe keygen comm_rccl api prover verifier ivc; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-gpu-sanitize -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o $OUT/libvpbs_hip.so $OUT/*.o

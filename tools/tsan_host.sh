@@ -6,7 +6,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=/tmp/vpbs_tsan; mkdir -p $OUT
 cd "$ROOT/verifiable-fhe-paper_amd/csrc"
-for f in ntt hash fri permutation quotient gates tfhe keygen comm_rccl api prover verifier ivc; do
+for f in ntt hash fri permutation quotient gates witness_device tfhe keygen comm_rccl api prover verifier ivc; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
 done
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=thread -Wno-unused-function -Wno-pass-failed -c witness.hip -o $OUT/witness.o &

@@ -1,5 +1,5 @@
 // Witness generation for circuits made of the supported gates: on the host (vpbs_generate_witness, vpbs_witness_plan_*) and, for a
-// batch of PartialWitnesses of one circuit, on the device (vpbs_witness_device_*, at the end of the file).
+// batch of PartialWitnesses of one circuit, on the device (vpbs_witness_device_*: witness_device.hip).  Generators: witness_gen.h; plan + pools: witness_plan.h.
 // Replaces plonky2 0.2.0 iop/generator.rs `generate_partial_witness` (run every generator whose watched targets are set,
 // propagate through the copy-constraint partition, repeat), iop/witness.rs `PartitionWitness::full_witness`, the gates' own
 // `SimpleGenerator::run_once` implementations (gates/*.rs), plonk/permutation_argument.rs `WirePartition::get_sigma_polys` and
@@ -8,586 +8,7 @@
 // reference's own circuit builder (vec_arithmetic, the recursive verifier) are outside: the caller presets their targets.
 // Restated from the published crate: parity unpinned; checked against an independent Python restatement and against the
 // gate constraints (every generated row must satisfy them).
-#include <pthread.h>
-#include <sched.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <numeric>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "context.h"
-#include "gates.h"
-#include "host/poseidon_x8.h"
-#include "../../include/vpbs_prover.h"
-
-namespace vpbs {
-namespace {
-using gl::u32;
-using gl::u64;
-using A = gates::Alg<u64>;
-
-struct GenError {
-    std::string what;
-};
-
-// A gate instance owns `gen_count` generators (one per operation / copy, like plonky2); generator `sub` watches `deps` wires of
-// its row and writes the wires it owns.
-unsigned gen_count(const vpbs_gate& g) {
-    switch (g.kind) {
-        case VPBS_GATE_CONSTANT:
-        case VPBS_GATE_ARITHMETIC:
-        case VPBS_GATE_ARITHMETIC_EXT:
-        case VPBS_GATE_MUL_EXT: return g.p0;
-        case VPBS_GATE_RANDOM_ACCESS: return g.p1 + g.p2;  // one per copy + RandomAccessExtraConstants
-        case VPBS_GATE_BASE_SUM:
-        case VPBS_GATE_POSEIDON:
-        case VPBS_GATE_POSEIDON_MDS:
-        case VPBS_GATE_REDUCING:
-        case VPBS_GATE_REDUCING_EXT:
-        case VPBS_GATE_EXPONENTIATION:
-        case VPBS_GATE_COSET_INTERPOLATION: return 1;
-        default: return 0;  // NoopGate, PublicInputGate (its wires are copy-constrained to the in-circuit hash)
-    }
-}
-
-void gen_deps(const vpbs_gate& g, unsigned sub, std::vector<unsigned>& d) {
-    d.clear();
-    auto range = [&](unsigned a, unsigned b) { for (unsigned i = a; i < b; ++i) d.push_back(i); };
-    switch (g.kind) {
-        case VPBS_GATE_ARITHMETIC: range(4 * sub, 4 * sub + 3); break;
-        case VPBS_GATE_ARITHMETIC_EXT: range(8 * sub, 8 * sub + 6); break;
-        case VPBS_GATE_MUL_EXT: range(6 * sub, 6 * sub + 4); break;
-        case VPBS_GATE_BASE_SUM: d.push_back(0); break;
-        case VPBS_GATE_POSEIDON: range(0, 12); d.push_back(24); break;
-        case VPBS_GATE_POSEIDON_MDS: range(0, 24); break;
-        case VPBS_GATE_REDUCING: range(2, 6 + g.p0); break;
-        case VPBS_GATE_REDUCING_EXT: range(2, 6 + 2 * g.p0); break;
-        case VPBS_GATE_RANDOM_ACCESS:
-            if (sub < g.p1) {
-                const unsigned vec = 1u << g.p0, base = (2 + vec) * sub;
-                d.push_back(base);
-                range(base + 2, base + 2 + vec);
-            }
-            break;
-        case VPBS_GATE_EXPONENTIATION: range(0, 1 + g.p0); break;
-        case VPBS_GATE_COSET_INTERPOLATION: range(0, 1 + 2 * (1u << g.p0) + 2); break;
-        default: break;
-    }
-}
-
-// R: get(wire) -> u64, set(wire, value)
-template <class R> GL_HD A ralg(R& r, unsigned i) { return A{r.get(i), r.get(i + 1)}; }
-template <class R> GL_HD void walg(R& r, unsigned i, A x) {
-    r.set(i, x.a);
-    r.set(i + 1, x.b);
-}
-
-// host and device (the device witness generator runs it once per PoseidonGate row and instance); failures go through the accessor
-template <class R> GL_HD void poseidon_generate(R& r) {
-    const u64 swap = r.get(24);
-    if (swap > 1) {
-        r.fail("PoseidonGate: swap wire is not boolean");
-        return;
-    }
-    u64 st[12];
-    for (int i = 0; i < 4; ++i) {
-        const u64 lhs = r.get(i), rhs = r.get(i + 4);
-        const u64 delta = gl::mul(swap, gl::sub(rhs, lhs));
-        r.set(25 + i, delta);
-        st[i] = gl::add(lhs, delta);
-        st[i + 4] = gl::sub(rhs, delta);
-    }
-    for (int i = 8; i < 12; ++i) st[i] = r.get(i);
-    // st holds the S-box inputs of the current round as arbitrary u64 residues; the MDS layer adds the next round's constants.  Same
-    // schedule as poseidon::permute (the 22 partial rounds as 7 fused groups of three + one), with every S-box input the gate carries
-    // as a wire written on the way.
-    for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], poseidon::rc(i));
-    auto full_round = [&](int round, int wire0) {
-        u64 kc[12];
-        if (round + 1 < 30)
-            for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * (round + 1) + i);
-        for (int i = 0; i < 12; ++i) {
-            if (wire0 >= 0) r.set(wire0 + i, gl::canon(st[i]));
-            st[i] = poseidon::sbox(st[i]);
-        }
-        poseidon::mds_add_const(st, round + 1 < 30 ? kc : nullptr);
-    };
-    for (int round = 0; round < 4; ++round) full_round(round, round ? 29 + 12 * (round - 1) : -1);
-    for (int g = 0; g < 7; ++g) {
-        u64 x[2];
-        r.set(65 + 3 * g, gl::canon(st[0]));
-        poseidon::partial_group3_core<false>(st, g, nullptr, x);
-        r.set(65 + 3 * g + 1, x[0]);
-        r.set(65 + 3 * g + 2, x[1]);
-    }
-    {
-        u64 kc[12];
-        for (int i = 0; i < 12; ++i) kc[i] = poseidon::rc(12 * 26 + i);
-        r.set(65 + 21, gl::canon(st[0]));
-        st[0] = poseidon::sbox(st[0]);
-        poseidon::mds_add_const(st, kc);
-    }
-    for (int round = 26; round < 30; ++round) full_round(round, 87 + 12 * (round - 26));
-    for (int i = 0; i < 12; ++i) r.set(12 + i, gl::canon(st[i]));
-}
-
-// host and device; `t`: the interpolation tables of a CosetInterpolationGate (gates::coset_tables(g.p0)), unused otherwise
-template <class R> GL_HD void gen_run(const vpbs_gate& g, unsigned sub, const u64* c, R& r, const gates::CosetTables* t = nullptr) {
-    switch (g.kind) {
-        case VPBS_GATE_CONSTANT: r.set(sub, c[sub]); break;
-        case VPBS_GATE_ARITHMETIC:
-            r.set(4 * sub + 3, gl::add(gl::mul(gl::mul(r.get(4 * sub), r.get(4 * sub + 1)), c[0]), gl::mul(r.get(4 * sub + 2), c[1])));
-            break;
-        case VPBS_GATE_BASE_SUM: {  // BaseSplitGenerator: little-endian base-B digits of the canonical sum
-            u64 x = r.get(0);
-            if (g.p1 == 2) {
-                for (unsigned i = 0; i < g.p0; ++i, x >>= 1) r.set(1 + i, x & 1);
-            } else {
-                for (unsigned i = 0; i < g.p0; ++i) {
-                    r.set(1 + i, x % g.p1);
-                    x /= g.p1;
-                }
-            }
-            if (x != 0) r.fail("BaseSumGate: integer too large to fit in the given number of limbs");
-            break;
-        }
-        case VPBS_GATE_POSEIDON: poseidon_generate(r); break;
-        case VPBS_GATE_POSEIDON_MDS: {
-            const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-            A in[12];
-            for (unsigned i = 0; i < 12; ++i) in[i] = ralg(r, 2 * i);
-            for (unsigned row = 0; row < 12; ++row) {
-                A acc{0, 0};
-                for (unsigned i = 0; i < 12; ++i) acc = acc + gates::scalec(in[(i + row) % 12], C[i]);
-                if (row == 0) acc = acc + gates::scalec(in[0], 8);
-                walg(r, 2 * (12 + row), acc);
-            }
-            break;
-        }
-        case VPBS_GATE_ARITHMETIC_EXT:
-            walg(r, 8 * sub + 6, gates::scale(ralg(r, 8 * sub) * ralg(r, 8 * sub + 2), c[0]) + gates::scale(ralg(r, 8 * sub + 4), c[1]));
-            break;
-        case VPBS_GATE_MUL_EXT: walg(r, 6 * sub + 4, gates::scale(ralg(r, 6 * sub) * ralg(r, 6 * sub + 2), c[0])); break;
-        case VPBS_GATE_REDUCING:
-        case VPBS_GATE_REDUCING_EXT: {
-            const bool ext = g.kind == VPBS_GATE_REDUCING_EXT;
-            const unsigned n = g.p0, start_accs = ext ? 6 + 2 * n : 6 + n;
-            const A alpha = ralg(r, 2);
-            A acc = ralg(r, 4);
-            for (unsigned i = 0; i < n; ++i) {
-                const A coeff = ext ? ralg(r, 6 + 2 * i) : A{r.get(6 + i), 0};
-                acc = acc * alpha + coeff;
-                walg(r, i == n - 1 ? 0 : start_accs + 2 * i, acc);
-            }
-            break;
-        }
-        case VPBS_GATE_RANDOM_ACCESS: {
-            const unsigned bits = g.p0, vec = 1u << bits, routed = (2 + vec) * g.p1 + g.p2;
-            if (sub >= g.p1) {  // RandomAccessExtraConstantsGenerator
-                const unsigned i = sub - g.p1;
-                r.set((2 + vec) * g.p1 + i, c[i]);
-                break;
-            }
-            const unsigned base = (2 + vec) * sub;
-            const u64 idx = r.get(base);
-            if (idx >= vec) {
-                r.fail("RandomAccessGate: access index out of range");
-                break;
-            }
-            r.set(base + 1, r.get(base + 2 + (unsigned)idx));
-            for (unsigned b = 0; b < bits; ++b) r.set(routed + sub * bits + b, (idx >> b) & 1);
-            break;
-        }
-        case VPBS_GATE_EXPONENTIATION: {
-            const unsigned n = g.p0;
-            const u64 base = r.get(0);
-            u64 prev = 1;
-            for (unsigned i = 0; i < n; ++i) {
-                const u64 sq = i == 0 ? 1 : gl::mul(prev, prev);
-                const u64 bit = r.get(1 + (n - 1 - i));
-                if (bit > 1) {
-                    r.fail("ExponentiationGate: power bit is not boolean");
-                    return;
-                }
-                prev = bit ? gl::mul(sq, base) : sq;
-                r.set(2 + n + i, prev);
-            }
-            r.set(1 + n, prev);
-            break;
-        }
-        case VPBS_GATE_COSET_INTERPOLATION: {
-            const unsigned points = 1u << g.p0, degree = g.p1, ni = (points - 2) / (degree - 1);
-            const unsigned start_point = 1 + 2 * points, start_value = start_point + 2, start_inter = start_value + 2;
-            const unsigned start_shifted = start_inter + 4 * ni;
-            const u64 shift = r.get(0);
-            if (shift == 0 || !t) {
-                r.fail("CosetInterpolationGate: zero shift");
-                break;
-            }
-            const A shifted = gates::scale(ralg(r, start_point), gl::inv(shift));
-            walg(r, start_shifted, shifted);
-            A eval{0, 0}, prod{1, 0};
-            auto run = [&](unsigned from, unsigned to) {
-                for (unsigned i = from; i < to; ++i) {
-                    const A term = gates::sub_base(shifted, t->domain[i]);
-                    eval = eval * term + gates::scalec(ralg(r, 1 + 2 * i), t->weights[i]) * prod;
-                    prod = prod * term;
-                }
-            };
-            run(0, degree < points ? degree : points);
-            for (unsigned i = 0; i < ni; ++i) {
-                walg(r, start_inter + 2 * i, eval);
-                walg(r, start_inter + 2 * (ni + i), prod);
-                const unsigned from = 1 + (degree - 1) * (i + 1);
-                run(from, from + degree - 1 < points ? from + degree - 1 : points);
-            }
-            walg(r, start_value, eval);
-            break;
-        }
-        default: break;
-    }
-}
-
-inline const gates::CosetTables* tables_of(const vpbs_gate& g) {
-    return g.kind == VPBS_GATE_COSET_INTERPOLATION ? &gates::coset_tables(g.p0) : nullptr;
-}
-
-struct PlainRow {
-    u64* w;
-    u64 get(unsigned i) const { return w[i]; }
-    void set(unsigned i, u64 v) { w[i] = v; }
-    void fail(const char* m) { throw GenError{m}; }
-};
-
-// ---- the copy-constraint partition (plonk/copy_constraint.rs + permutation_argument.rs Forest) ----
-struct Partition {
-    std::vector<u32> parent;
-    explicit Partition(size_t n) : parent(n) { std::iota(parent.begin(), parent.end(), 0u); }
-    u32 find(u32 x) {
-        while (parent[x] != x) {
-            parent[x] = parent[parent[x]];
-            x = parent[x];
-        }
-        return x;
-    }
-    void merge(u32 a, u32 b) {
-        a = find(a);
-        b = find(b);
-        if (a != b) parent[a] = b;
-    }
-};
-
-bool check_circuit(const vpbs_circuit* c) {
-    if (!c || !c->gates || !c->n_gates || !c->row_gate || c->log_n == 0 || c->log_n > 24 || c->n_routed > c->n_wires) return false;
-    if (c->n_copies && !c->copies) return false;
-    const size_t n = (size_t)1 << c->log_n;
-    for (size_t r = 0; r < n; ++r)
-        if (c->row_gate[r] >= c->n_gates) return false;
-    for (size_t i = 0; i < 2 * c->n_copies; ++i)
-        if (c->copies[i] >= (size_t)c->n_routed * n) return false;
-    for (unsigned i = 0; i < c->n_gates; ++i)
-        if (c->gates[i].num_wires > c->n_wires) return false;
-    if (c->n_generators && !c->generators) return false;
-    const size_t total = (size_t)c->n_wires * n;
-    for (size_t i = 0; i < c->n_generators; ++i) {
-        const vpbs_generator& g = c->generators[i];
-        if ((g.n_in && !g.in) || (g.n_out && !g.out)) return false;
-        for (unsigned k = 0; k < g.n_in; ++k)
-            if (g.in[k] >= total) return false;
-        for (unsigned k = 0; k < g.n_out; ++k)
-            if (g.out[k] >= total) return false;
-        if (g.kind == VPBS_GEN_EQUALITY && (g.n_in != 2 || g.n_out != 2)) return false;
-        if (g.kind == VPBS_GEN_BASE_SUM && (g.p0 < 2 || g.n_out != 1)) return false;
-        if (g.kind == VPBS_GEN_WIRE_SPLIT && (g.p0 < 1 || g.p0 > 63 || g.n_in != 1 || g.n_out < 1)) return false;
-        if (g.kind == VPBS_GEN_QUOTIENT_EXT && (g.n_in != 4 || g.n_out != 2)) return false;
-        if (g.kind == VPBS_GEN_COPY && (g.n_in != 1 || g.n_out != 1)) return false;
-        if (g.kind == VPBS_GEN_LOW_HIGH && (g.p0 < 1 || g.p0 > 63 || g.n_in != 1 || g.n_out != 2)) return false;
-        if (g.kind > VPBS_GEN_LOW_HIGH) return false;
-    }
-    return true;
-}
-// ---- compiled witness generation -------------------------------------------------------------------------------------------------
-// Which generator can run when depends only on the circuit and on WHICH targets the PartialWitness sets, never on the values: the
-// readiness loop of generate_partial_witness is therefore run once, at plan creation, and recorded as a straight-line schedule over
-// value slots (one slot per copy-constraint class).  A run is then: presets -> slots, the schedule in order (no readiness checks, no
-// union-find), slots -> wires (full_witness) in parallel.  The step circuit is proven n + 2 times per PBS with the same plan.
-}  // namespace
-
-// spin for up to 150 us (the other side usually answers within microseconds), then sleep in short naps: a pool's workers wait
-// through the stretches of a phase that only the calling thread or the chain lanes work on, and a container's CPU quota is spent by
-// spinning threads as by working ones
-template <class Pred> void spin_until(Pred ready) {
-    std::chrono::steady_clock::time_point t0;
-    for (unsigned i = 0; !ready(); ++i) {
-        __builtin_ia32_pause();
-        if ((i & 63) != 63) continue;
-        const auto t = std::chrono::steady_clock::now();
-        if (i == 63) t0 = t;
-        else if (t - t0 > std::chrono::milliseconds(1)) std::this_thread::sleep_for(std::chrono::microseconds(100));   // a very long wait
-        else if (t - t0 > std::chrono::microseconds(150)) std::this_thread::sleep_for(std::chrono::microseconds(20));  // a long wait: nap
-    }
-}
-
-// The host threads that share the wide dependency levels of a split plan's phase.  They belong to the plan and live as long as it does:
-// asleep on a condition variable between runs, spinning on a phase counter while a run is active (a run is hundreds of levels within a
-// few milliseconds; waking a sleeping thread per level would cost more than the level).  One run at a time per pool (`busy`); a second
-// concurrent run of the same phase finds the pool taken and proceeds on its own thread alone.
-struct LevelPool {
-    const unsigned threads;                       // including the calling thread (number 0)
-    std::mutex busy;
-    explicit LevelPool(unsigned n) : threads(std::max(1u, n)) {
-        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([this, t] { work(t); });
-        place_near_caller();
-    }
-    ~LevelPool() {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            quit = true;
-        }
-        cv.notify_all();
-        for (auto& w : workers) w.join();
-        if (domain >= 0) domains().give_back(domain, threads);
-    }
-    void begin() {   // wake the workers for a run
-        {
-            std::lock_guard<std::mutex> lk(m);
-            active.store(true, std::memory_order_release);
-        }
-        cv.notify_all();
-    }
-    void end() {
-        std::lock_guard<std::mutex> lk(m);
-        active.store(false, std::memory_order_release);
-    }
-    // every thread of the pool (the caller as number 0) runs job(t); returns when all have finished
-    template <class Job> void share(Job&& j) {
-        job = std::ref(j);
-        done.store(0, std::memory_order_relaxed);
-        phase.fetch_add(1, std::memory_order_release);
-        j(0u);
-        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
-    }
-
-    // the same without the caller: the workers run job(t), t = 1 .. threads - 1, while the caller does something else; finish() waits for them
-    template <class Job> void start(Job&& j) {
-        job = std::ref(j);
-        done.store(0, std::memory_order_relaxed);
-        phase.fetch_add(1, std::memory_order_release);
-    }
-    void finish() {
-        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
-    }
-
-  private:
-    // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs of ONE
-    // last-level-cache domain (Linux: cache/index3/shared_cpu_list) -- the caller's when it still has room for them, otherwise the least
-    // taken domain of the same package (a process runs several pools: two phases per plan, one plan per concurrent chain; two pools spinning
-    // on the same sixteen hardware threads cost more than the placement gains).  The caller's own affinity is left alone.
-    // VPBS_POOL_PIN=0 turns the placement off.
-    struct Domains {
-        struct D {
-            cpu_set_t set;
-            unsigned cpus = 0, taken = 0;
-            int package = -1;
-        };
-        std::mutex m;
-        std::vector<D> all;
-        std::vector<int> of_cpu;   // cpu -> index into all, -1 unknown
-        static bool read_line(const char* fmt, int cpu, char* line, size_t len) {
-            char path[160];
-            std::snprintf(path, sizeof path, fmt, cpu);
-            FILE* f = std::fopen(path, "r");
-            if (!f) return false;
-            const bool got = std::fgets(line, (int)len, f) != nullptr;
-            std::fclose(f);
-            return got;
-        }
-        Domains() {
-            const long n = std::min<long>(sysconf(_SC_NPROCESSORS_CONF), CPU_SETSIZE);
-            of_cpu.assign(n > 0 ? (size_t)n : 0, -1);
-            for (int cpu = 0; cpu < (int)of_cpu.size(); ++cpu) {
-                if (of_cpu[cpu] >= 0) continue;
-                char line[512] = {0};
-                if (!read_line("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, line, sizeof line)) continue;
-                D d;
-                CPU_ZERO(&d.set);
-                for (const char* q = line; *q;) {   // "0-7,128-135"
-                    char* end = nullptr;
-                    const long a = std::strtol(q, &end, 10);
-                    if (end == q) break;
-                    long b = a;
-                    if (*end == '-') b = std::strtol(end + 1, &end, 10);
-                    for (long c = a; c <= b && c < (long)of_cpu.size(); ++c) {
-                        CPU_SET((int)c, &d.set);
-                        ++d.cpus;
-                        of_cpu[c] = (int)all.size();
-                    }
-                    if (*end != ',') break;
-                    q = end + 1;
-                }
-                char pk[64] = {0};
-                if (read_line("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu, pk, sizeof pk)) d.package = std::atoi(pk);
-                if (d.cpus) all.push_back(d);
-            }
-        }
-        // -> index of the domain that takes `n` more threads, or -1
-        int take(unsigned n) {
-            std::lock_guard<std::mutex> lk(m);
-            const int cpu = sched_getcpu();
-            const int home = cpu >= 0 && cpu < (int)of_cpu.size() ? of_cpu[cpu] : -1;
-            if (home < 0) return -1;
-            int best = -1;
-            if (all[home].taken + n <= all[home].cpus) best = home;
-            for (int pass = 0; pass < 2 && best < 0; ++pass)   // same package first
-                for (int i = 0; i < (int)all.size(); ++i) {
-                    if (all[i].cpus < n || (pass == 0 && all[i].package != all[home].package)) continue;
-                    if (best < 0 || all[i].taken < all[best].taken) best = i;
-                }
-            if (best >= 0) all[best].taken += n;
-            return best;
-        }
-        void give_back(int i, unsigned n) {
-            std::lock_guard<std::mutex> lk(m);
-            if (i >= 0) all[i].taken -= std::min(n, all[i].taken);
-        }
-    };
-    static Domains& domains() {
-        static Domains d;
-        return d;
-    }
-    int domain = -1;
-    void place_near_caller() {
-        const char* e = std::getenv("VPBS_POOL_PIN");
-        if ((e && std::atoi(e) == 0) || workers.empty()) return;
-        domain = domains().take(threads);
-        if (domain < 0) return;   // no cache topology to read, or no domain can hold the pool: the scheduler places the threads
-        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof(cpu_set_t), &domains().all[domain].set);
-    }
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv;
-    std::atomic<u32> phase{0}, done{0};
-    std::atomic<bool> active{false};
-    bool quit = false;
-    std::function<void(unsigned)> job;
-    void work(unsigned t) {
-        u32 seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return quit || active.load(std::memory_order_acquire); });
-                if (quit) return;
-            }
-            for (;;) {
-                spin_until([&] { return phase.load(std::memory_order_acquire) != seen || !active.load(std::memory_order_acquire); });
-                if (phase.load(std::memory_order_acquire) == seen) break;   // the run is over: back to sleep
-                ++seen;
-                job(t);
-                done.fetch_add(1, std::memory_order_release);
-            }
-        }
-    }
-};
-}  // namespace vpbs
-
-struct vpbs_witness_plan {
-    using u32 = vpbs::u32;
-    using u64 = vpbs::u64;
-    size_t n = 0, total = 0, n_slots = 0;
-    unsigned max_consts = 0;
-    std::vector<vpbs_gate> gates;
-    std::vector<u32> row_gate;                  // [n]
-    std::vector<u64> consts;                    // [n][max_consts]: the gate constants of every row
-    std::vector<u32> row_off, row_slots;        // row -> offset into row_slots: the slot of every wire of a row that owns generators
-    struct Gadget {
-        unsigned kind, p0;
-        u32 at, n_in, n_out;                    // gadget_slots / gadget_pos [at, at + n_in) inputs, then n_out outputs
-    };
-    std::vector<Gadget> gadgets;
-    std::vector<u32> gadget_slots, gadget_pos;
-    struct Step {
-        u32 row, sub;                           // row == NO_ROW: gadget number `sub`
-    };
-    std::vector<Step> schedule;
-    std::vector<u32> preset_slot, preset_pos;
-    std::vector<u32> out_pos, out_slot;         // every position that carries a slot, ascending (full_witness)
-    // ---- two-phase runs (vpbs_witness_plan_split): some presets arrive late (the previous proof of an IVC step); a generator is LATE when
-    // anything it reads is, everything else can run before the late values exist
-    bool is_split = false;
-    std::vector<uint8_t> preset_late, step_late;
-    std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late
-    // the late generators by dependency level (a generator of level L reads only what levels < L wrote, and two generators of one level
-    // never write the same slot: a second writer of a slot is placed above the first and compares): the wide levels -- the 28 FRI queries
-    // of an in-circuit verifier are independent of each other -- are run by several host threads
-    // Both phases hold their generators by dependency level like that (the early phase of the step circuit: the NTT / external-product
-    // arithmetic is wide, the hash chains are one PoseidonGate row per level).
-    struct Phase {
-        std::vector<u32> order, level_off;      // schedule indices sorted by level; level l = order[level_off[l], level_off[l + 1])
-        std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
-    };
-    Phase phase[2];                             // [0] early, [1] late
-    // Chain lanes: PoseidonGate rows whose results nothing but other such rows reads inside the phase (the hash chains over the GGSW and
-    // over the public inputs: thousands of permutations, each needing the one before).  They are taken out of the levels and run on
-    // threads of their own next to them, in schedule order, waiting on the set flag of a value another lane or a level still has to produce.
-    struct Lane {
-        std::vector<u32> steps;                 // schedule indices, ascending
-        std::vector<u32> wait_off, wait;        // step k waits for slots wait[wait_off[k], wait_off[k + 1])
-    };
-    std::vector<Lane> lanes[2];
-    std::vector<u32> lane_steps_sorted[2];      // all lane steps of a phase, ascending (a run without threads for the lanes)
-    mutable std::unique_ptr<vpbs::LevelPool> pool[2], lane_pool[2];
-    mutable std::mutex pool_mutex;              // creation of the pools (first run of a phase)
-
-    // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
-    // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
-    // writer earlier in the schedule (a preset, or a generator whose output is copy-constrained to this one), so the operation
-    // compares instead of writing ("set twice with different values") -- the order is static, so no per-slot flag is needed at run time.
-    static constexpr u32 CHECK = 0x80000000u;
-    struct ArithOp {
-        u32 x, y, z, out;
-        u64 c0, c1;
-    };
-    struct ConstOp {
-        u32 out, pad;
-        u64 value;
-    };
-    struct BitsOp {                             // out[k] = (in >> (k * bits)) & mask, k < n_out; the rest must be zero
-        u32 in, out_at, n_out, bits;            // BaseSumGate<2> generator, WireSplitGenerator
-    };
-    struct MiscOp {                             // gadget generators that are not bit splits
-        u32 kind, p0, at, n_in, n_out, pad;
-    };
-    struct RowOp {                              // any other gate generator: gen_run on the row's slot table
-        u32 row, sub;
-    };
-    struct DeviceSchedule {
-        bool supported = false;
-        std::string unsupported;                // why not (a gate or generator kind without a device form)
-        u32 n_levels = 0;
-        std::vector<ArithOp> arith;
-        std::vector<ConstOp> consts;            // no inputs: written before level 1
-        std::vector<BitsOp> bits;
-        std::vector<u32> poseidon;              // offsets into row_slots (135 slots per PoseidonGate row)
-        std::vector<MiscOp> misc;
-        std::vector<RowOp> rowops;
-        std::vector<u32> arith_off, bits_off, poseidon_off, misc_off, rowops_off;   // [n_levels + 2]: operations of level L = [off[L], off[L + 1])
-        std::vector<u32> aux;                   // slot lists of BitsOp outputs and MiscOp inputs / outputs
-        std::vector<u32> row_slots;             // copy of row_slots with CHECK marks on outputs that compare
-        std::vector<u32> preset_slot;           // with CHECK marks (a target preset twice)
-    } dev;
-};
+#include "witness_plan.h"
 
 namespace vpbs {
 namespace {
@@ -1889,480 +1310,6 @@ int vpbs_check_witness(const vpbs_circuit* c, const uint64_t* wires, const uint6
     }
     if (err && err_len) err[0] = 0;
     return 1;
-}
-
-}  // extern "C"
-
-// ---- device witness generation: one circuit, a batch of PartialWitnesses -----------------------------------------------------------
-// The n + 2 step witnesses of a PBS are independent once the accumulator chain is known (vpbs_pbs_accumulator_chain), and they share
-// one circuit: the plan's level schedule is replayed for all of them at once.  Values live in HBM as val[slot][batch] (instances
-// innermost: every access of an operation is one coalesced run over the batch); an operation is a thread per instance.  The
-// sequential spine of the step circuit is its bootstrapping-key hash chain (2 049 PoseidonGate rows, one level each), so a run is ~2 050 levels
-// of small launches -- latency-bound, amortised over the batch; the wires of one instance are then gathered straight into the
-// [n_wires][n] matrix vpbs_prove_step takes as a device input: they never cross PCIe.
-namespace vpbs {
-namespace {
-using Plan = vpbs_witness_plan;
-constexpr unsigned WT = 256;
-enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8, DE_GATE = 16 };
-
-struct Vals {
-    u64* v;
-    unsigned* err;
-    u32 batch, b;
-    // volatile: inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line)
-    __device__ u64 get(u32 slot) const { return *(volatile const u64*)(v + (size_t)(slot & ~Plan::CHECK) * batch + b); }
-    __device__ void set(u32 slot, u64 x) const {
-        if (x >= gl::P) x -= gl::P;
-        u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
-        if (slot & Plan::CHECK) {
-            if (*p != x) atomicOr(err, DE_SET_TWICE);
-        } else {
-            *p = x;
-        }
-    }
-};
-
-__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_preset * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    a.set(slots[gid / batch], values[gid]);
-}
-
-__global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    a.set(ops[gid / batch].out, ops[gid / batch].value);
-}
-
-__global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::ArithOp op = ops[gid / batch];
-    a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
-}
-
-__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::BitsOp op = ops[gid / batch];
-    u64 x = a.get(op.in);
-    const u64 mask = ((u64)1 << op.bits) - 1;
-    for (u32 k = 0; k < op.n_out; ++k) {
-        a.set(aux[op.out_at + k], x & mask);
-        x >>= op.bits;
-    }
-    if (x != 0) atomicOr(err, DE_TOO_LARGE);
-}
-
-// every gate generator without a special form: gen_run (the host's code) through the row's slot table, one thread per instance
-struct DevRow {
-    Vals a;
-    const u32* rs;
-    __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
-    __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
-    __device__ void fail(const char*) const { atomicOr(a.err, DE_GATE); }
-};
-
-struct RowTables {
-    const vpbs_gate* gates;
-    const u32 *row_gate, *row_off;
-    const u64* consts;
-    const gates::CosetTables* coset;  // [n_gates]
-    u32 max_consts;
-};
-
-__global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
-                                                       u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Plan::RowOp op = ops[gid / batch];
-    const u32 gi = t.row_gate[op.row];
-    const vpbs_gate g = t.gates[gi];
-    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + t.row_off[op.row]};
-    gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
-}
-
-// PoseidonGate generator, 16 lanes per row and instance: lane l < 12 owns state element l (the latency form of the prover's tree
-// kernels: a row is ~13 us of dependent instructions instead of ~65 us with one lane per row -- the step circuit's witness is a chain
-// of 2 049 such rows).  Every lane of the group runs the shuffles; lanes 12..15 carry zeros.
-__device__ __forceinline__ u64 shfl64(u64 x, unsigned src_lane) {
-    const u32 lo = (u32)__shfl((int)(u32)x, (int)src_lane, 64), hi = (u32)__shfl((int)(u32)(x >> 32), (int)src_lane, 64);
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ void poseidon_generate_wide(const Vals& a, const u32* rs) {
-    const unsigned lane = threadIdx.x & 63u, l = lane & 15u, base = lane & ~15u;
-    const bool own = l < 12;
-    const unsigned lm = own ? l : 0;
-    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const u64 swap = a.get(rs[24]);
-    if (swap > 1) {  // the same for every lane of the group
-        if (l == 0) atomicOr(a.err, DE_NOT_BOOLEAN);
-        return;
-    }
-    u64 s = own ? a.get(rs[l]) : 0;
-    const u64 rhs = shfl64(s, base + ((l + 4) & 15u));
-    const u64 delta = l < 4 ? gl::mul(swap, gl::sub(rhs, s)) : 0;   // swap * (rhs - lhs): lanes 0..3
-    const u64 delta_lo = shfl64(delta, base + ((l + 12) & 15u));     // lanes 4..7 see the delta of lane l - 4
-    if (l < 4) {
-        a.set(rs[25 + l], delta);
-        s = gl::add(s, delta);
-    } else if (l < 8) {
-        s = gl::sub(s, delta_lo);
-    }
-    if (own) s = gl::add_nc(s, poseidon::rc((int)l));
-    for (int round = 0; round < 30; ++round) {
-        const bool full = round < 4 || round >= 26;
-        if (own) {
-            if (round >= 1 && round < 4) a.set(rs[29 + 12 * (round - 1) + l], gl::canon(s));
-            else if (round >= 26) a.set(rs[87 + 12 * (round - 26) + l], gl::canon(s));
-            else if (!full && l == 0) a.set(rs[65 + (round - 4)], gl::canon(s));
-        }
-        if (full || l == 0) s = poseidon::sbox(s);
-        u64 acc_lo = 0, acc_hi = 0;  // row lm of the MDS matrix in 32-bit halves
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            unsigned src = lm + i;
-            if (src >= 12) src -= 12;
-            const u64 x = shfl64(s, base + src);
-            acc_lo += (u64)(u32)x * C[i];
-            acc_hi += (x >> 32) * C[i];
-        }
-        if (l == 0) {  // MDS_MATRIX_DIAG[0] = 8
-            acc_lo += (u64)(u32)s * 8;
-            acc_hi += (s >> 32) * 8;
-        }
-        const u64 k = round + 1 < 30 ? poseidon::rc(12 * (round + 1) + (int)lm) : 0;
-        acc_lo += (u32)k;
-        acc_hi += k >> 32;
-        s = own ? poseidon::fold96(acc_lo, acc_hi) : 0;
-    }
-    if (own) a.set(rs[12 + l], gl::canon(s));
-}
-
-__global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, u32 batch) {
-    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
-    if (group >= (size_t)n_ops * batch) return;
-    poseidon_generate_wide(Vals{v, err, batch, (u32)(group % batch)}, row_slots + rows[group / batch]);
-}
-
-// The tail of the schedule where every level holds PoseidonGate rows only (the hash chain): instances are independent of each other,
-// so one group per instance walks the levels by itself -- one launch instead of one per level.
-__global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned* err, const u32* rows, const u32* level_off, u32 first_level,
-                                                                u32 last_level, const u32* row_slots, u32 batch) {
-    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
-    if (group >= batch) return;
-    const Vals a{v, err, batch, (u32)group};
-    for (u32 level = first_level; level <= last_level; ++level) {
-        for (u32 op = level_off[level]; op < level_off[level + 1]; ++op) poseidon_generate_wide(a, row_slots + rows[op]);
-        __threadfence_block();  // the next level reads what this one stored
-    }
-}
-
-__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, u32 batch) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::MiscOp op = ops[gid / batch];
-    const u32 *in = aux + op.at, *out = in + op.n_in;
-    switch (op.kind) {
-        case VPBS_GEN_EQUALITY: {
-            const u64 x = a.get(in[0]), y = a.get(in[1]);
-            a.set(out[0], x == y ? 1 : 0);
-            a.set(out[1], x == y ? 0 : gl::inv(gl::sub(x, y)));
-            break;
-        }
-        case VPBS_GEN_BASE_SUM: {
-            u64 sum = 0;
-            for (u32 k = op.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, op.p0), a.get(in[k]));
-            a.set(out[0], sum);
-            break;
-        }
-        case VPBS_GEN_QUOTIENT_EXT: {
-            const A num{a.get(in[0]), a.get(in[1])}, den{a.get(in[2]), a.get(in[3])};
-            if (den.a == 0 && den.b == 0) {
-                atomicOr(err, DE_DIV_ZERO);
-                break;
-            }
-            const u64 norm = gl::sub(gl::mul(den.a, den.a), gl::mul(7, gl::mul(den.b, den.b)));
-            const A q = gates::scale(num * A{den.a, gl::neg(den.b)}, gl::inv(norm));
-            a.set(out[0], q.a);
-            a.set(out[1], q.b);
-            break;
-        }
-        case VPBS_GEN_COPY: a.set(out[0], a.get(in[0])); break;
-        case VPBS_GEN_LOW_HIGH: {
-            const u64 x = a.get(in[0]);
-            a.set(out[0], x & (((u64)1 << op.p0) - 1));
-            a.set(out[1], x >> op.p0);
-            break;
-        }
-        case 0xC0u: a.set(out[0], (u64)out[1] | ((u64)out[2] << 32)); break;  // a ConstantGate wire that is also set elsewhere
-        default: break;
-    }
-}
-
-// wires[pos] = val[slot][b] for every position that carries a slot (the matrix is zeroed first)
-__global__ void __launch_bounds__(WT) wd_gather_kernel(const u64* v, const u32* pos, const u32* slot, size_t count, u32 batch, u32 b, u64* wires) {
-    const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (i < count) wires[pos[i]] = v[(size_t)slot[i] * batch + b];
-}
-
-__global__ void __launch_bounds__(WT) wd_read_kernel(const u64* v, const u32* slots, u32 count, u32 batch, u32 b, u64* out) {
-    const u32 i = blockIdx.x * WT + threadIdx.x;
-    if (i < count) out[i] = v[(size_t)slots[i] * batch + b];
-}
-
-template <class T> T* upload(vpbs_ctx* c, const std::vector<T>& h, std::vector<void*>& owned) {
-    if (h.empty()) return nullptr;
-    void* d = c->alloc_bytes(h.size() * sizeof(T));
-    owned.push_back(d);
-    VPBS_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    return static_cast<T*>(d);
-}
-}  // namespace
-}  // namespace vpbs
-
-struct vpbs_witness_device {
-    vpbs_ctx* ctx = nullptr;
-    const vpbs_witness_plan* plan = nullptr;
-    unsigned max_batch = 0, batch = 0;
-    std::vector<void*> owned;
-    vpbs::u64* val = nullptr;
-    unsigned* err = nullptr;
-    const vpbs_witness_plan::ArithOp* arith = nullptr;
-    const vpbs_witness_plan::ConstOp* consts = nullptr;
-    const vpbs_witness_plan::BitsOp* bits = nullptr;
-    const vpbs_witness_plan::MiscOp* misc = nullptr;
-    const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
-    const vpbs::u32* poseidon_off = nullptr;
-    const vpbs_witness_plan::RowOp* rowops = nullptr;
-    vpbs::RowTables tables{};
-    unsigned tail_first = 0;          // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
-    hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
-    unsigned graph_batch = 0;
-    std::mutex mu;                    // run / wires / read share the context's stream and memory pool: one at a time per object
-};
-
-namespace vpbs {
-namespace {
-void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
-    const Plan::DeviceSchedule& ds = d->plan->dev;
-    auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
-    if (!ds.consts.empty())
-        hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
-    const u32 last_stepwise = d->tail_first ? d->tail_first - 1 : ds.n_levels;
-    for (u32 l = 1; l <= last_stepwise; ++l) {
-        if (const u32 k = ds.arith_off[l + 1] - ds.arith_off[l])
-            hipLaunchKernelGGL(wd_arith_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->arith + ds.arith_off[l], k, batch);
-        if (const u32 k = ds.bits_off[l + 1] - ds.bits_off[l])
-            hipLaunchKernelGGL(wd_bits_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->bits + ds.bits_off[l], d->aux, k, batch);
-        if (const u32 k = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
-            hipLaunchKernelGGL(wd_poseidon_kernel, blocks((size_t)k * 16, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l],
-                               d->row_slots, k, batch);
-        if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
-            hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
-        if (const u32 k = ds.rowops_off[l + 1] - ds.rowops_off[l])
-            hipLaunchKernelGGL(wd_rowop_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->rowops + ds.rowops_off[l], d->tables, d->row_slots, k,
-                               batch);
-    }
-    if (d->tail_first)
-        hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((batch * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, d->poseidon, d->poseidon_off,
-                           d->tail_first, ds.n_levels, d->row_slots, batch);
-}
-}  // namespace
-}  // namespace vpbs
-
-extern "C" {
-
-int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
-    if (!ctx || !plan || !out || max_batch == 0) return VPBS_ERR_INVALID;
-    try {
-        VPBS_HIP(hipSetDevice(ctx->device));
-        VPBS_REQUIRE(plan->dev.supported, ("this circuit has no device witness generator: " + plan->dev.unsupported).c_str());
-        auto d = std::make_unique<vpbs_witness_device>();
-        d->ctx = ctx;
-        d->plan = plan;
-        d->max_batch = max_batch;
-        const auto& ds = plan->dev;
-        using namespace vpbs;
-        d->arith = upload(ctx, ds.arith, d->owned);
-        d->consts = upload(ctx, ds.consts, d->owned);
-        d->bits = upload(ctx, ds.bits, d->owned);
-        d->misc = upload(ctx, ds.misc, d->owned);
-        d->poseidon = upload(ctx, ds.poseidon, d->owned);
-        d->aux = upload(ctx, ds.aux, d->owned);
-        d->row_slots = upload(ctx, ds.row_slots, d->owned);
-        d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
-        d->out_pos = upload(ctx, plan->out_pos, d->owned);
-        d->out_slot = upload(ctx, plan->out_slot, d->owned);
-        d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
-        d->rowops = upload(ctx, ds.rowops, d->owned);
-        if (!ds.rowops.empty()) {
-            std::vector<gates::CosetTables> coset(plan->gates.size());
-            for (size_t i = 0; i < plan->gates.size(); ++i)
-                if (plan->gates[i].kind == VPBS_GATE_COSET_INTERPOLATION) coset[i] = gates::coset_tables(plan->gates[i].p0);
-            d->tables = RowTables{upload(ctx, plan->gates, d->owned), upload(ctx, plan->row_gate, d->owned), upload(ctx, plan->row_off, d->owned),
-                                  upload(ctx, plan->consts, d->owned), upload(ctx, coset, d->owned), std::max(1u, plan->max_consts)};
-        }
-        {
-            u32 l = ds.n_levels;
-            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
-                   ds.rowops_off[l + 1] == ds.rowops_off[l])
-                --l;
-            d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
-        }
-        d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
-        d->owned.push_back(d->val);
-        d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
-        d->owned.push_back(d->err);
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
-        *out = d.release();
-        return VPBS_OK;
-    } catch (const vpbs::DeviceError& e) {
-        ctx->err = e.what;
-        return e.status;
-    }
-}
-
-void vpbs_witness_device_free(vpbs_witness_device* d) {
-    if (!d) return;
-    (void)hipSetDevice(d->ctx->device);
-    (void)hipStreamSynchronize(d->ctx->stream);
-    if (d->graph) (void)hipGraphExecDestroy(d->graph);
-    for (void* p : d->owned) d->ctx->release(p);
-    delete d;
-}
-
-int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, unsigned batch) {
-    if (!d || batch == 0 || batch > d->max_batch || (!d->plan->preset_slot.empty() && !preset_val)) return VPBS_ERR_INVALID;
-    vpbs_ctx* ctx = d->ctx;
-    std::lock_guard<std::mutex> lock(d->mu);
-    vpbs::u64* d_vals = nullptr;
-    try {
-        using namespace vpbs;
-        VPBS_HIP(hipSetDevice(ctx->device));
-        hipStream_t s = ctx->stream;
-        const size_t n_preset = d->plan->preset_slot.size();
-        d->batch = batch;
-        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * d->plan->n_slots * batch, s));
-        VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
-        if (n_preset) {
-            d_vals = ctx->alloc_words(n_preset * batch);
-            VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
-                               d_vals, (u32)n_preset, batch);
-        }
-        // the level launches are a static sequence: captured once per batch size, replayed afterwards
-        if (!d->graph || d->graph_batch != batch) {
-            if (d->graph) {
-                VPBS_HIP(hipGraphExecDestroy(d->graph));
-                d->graph = nullptr;
-            }
-            hipGraph_t g = nullptr;
-            VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            launch_levels(d, s, batch);
-            const hipError_t launched = hipGetLastError();
-            const hipError_t ended = hipStreamEndCapture(s, &g);   // always leave capture mode
-            hipError_t e = launched != hipSuccess ? launched : ended;
-            if (e == hipSuccess) e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
-            if (g) (void)hipGraphDestroy(g);
-            if (e != hipSuccess) d->graph = nullptr;
-            VPBS_HIP(e);
-            d->graph_batch = batch;
-        }
-        VPBS_HIP(hipGraphLaunch(d->graph, s));
-        unsigned flags = 0;
-        VPBS_HIP(hipMemcpyAsync(&flags, d->err, sizeof flags, hipMemcpyDeviceToHost, s));
-        VPBS_HIP(hipStreamSynchronize(s));
-        if (d_vals) ctx->release(d_vals);
-        d_vals = nullptr;
-        if (flags) {
-            std::string m;
-            if (flags & DE_SET_TWICE) m += "a partition was set twice with different values; ";
-            if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
-            if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
-            if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
-            if (flags & DE_GATE) m += "a gate generator rejected its inputs (limbs that do not fit, an access index out of range, a non-boolean bit, a zero shift); ";
-            throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
-        }
-        return VPBS_OK;
-    } catch (const vpbs::DeviceError& e) {
-        if (d_vals) {
-            (void)hipStreamSynchronize(ctx->stream);
-            ctx->release(d_vals);
-        }
-        ctx->err = e.what;
-        return e.status;
-    }
-}
-
-int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_t* d_wires) {
-    if (!d || !d_wires) return VPBS_ERR_INVALID;
-    vpbs_ctx* ctx = d->ctx;
-    std::lock_guard<std::mutex> lock(d->mu);
-    if (instance >= d->batch) return VPBS_ERR_INVALID;
-    try {
-        using namespace vpbs;
-        VPBS_HIP(hipSetDevice(ctx->device));
-        const size_t count = d->plan->out_pos.size();
-        VPBS_HIP(hipMemsetAsync(d_wires, 0, sizeof(u64) * d->plan->total, ctx->stream));
-        hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
-                           d->batch, instance, d_wires);
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
-        return VPBS_OK;
-    } catch (const vpbs::DeviceError& e) {
-        ctx->err = e.what;
-        return e.status;
-    }
-}
-
-int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const uint32_t* positions, size_t count, uint64_t* out) {
-    if (!d || (count && (!positions || !out))) return VPBS_ERR_INVALID;
-    vpbs_ctx* ctx = d->ctx;
-    std::lock_guard<std::mutex> lock(d->mu);
-    if (instance >= d->batch) return VPBS_ERR_INVALID;
-    vpbs::u32* d_slots = nullptr;
-    vpbs::u64* d_out = nullptr;
-    try {
-        using namespace vpbs;
-        VPBS_HIP(hipSetDevice(ctx->device));
-        // positions -> slots through the plan's ascending (position, slot) list; a position without a slot reads 0
-        const auto& pos = d->plan->out_pos;
-        std::vector<u32> slots(count);
-        std::vector<size_t> missing;
-        for (size_t i = 0; i < count; ++i) {
-            const auto it = std::lower_bound(pos.begin(), pos.end(), positions[i]);
-            if (it != pos.end() && *it == positions[i]) slots[i] = d->plan->out_slot[it - pos.begin()];
-            else {
-                slots[i] = 0;
-                missing.push_back(i);
-            }
-        }
-        if (count == 0) return VPBS_OK;
-        d_slots = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32) * count));
-        d_out = ctx->alloc_words(count);
-        VPBS_HIP(hipMemcpyAsync(d_slots, slots.data(), sizeof(u32) * count, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d_slots, (u32)count, d->batch,
-                           instance, d_out);
-        VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->release(d_slots);
-        ctx->release(d_out);
-        for (size_t i : missing) out[i] = 0;
-        return VPBS_OK;
-    } catch (const vpbs::DeviceError& e) {
-        (void)hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
-        if (d_slots) ctx->release(d_slots);
-        if (d_out) ctx->release(d_out);
-        ctx->err = e.what;
-        return e.status;
-    }
 }
 
 }  // extern "C"

@@ -1,0 +1,477 @@
+// Witness generation on the device for a batch of PartialWitnesses of one circuit (vpbs_witness_device_*): the level schedule a compiled
+// plan carries (witness_plan.h, built by witness.hip) replayed on the GPU with the generators of witness_gen.h.  SURVEY.md 8f-2.
+#include "witness_plan.h"
+
+// ---- device witness generation: one circuit, a batch of PartialWitnesses -----------------------------------------------------------
+// The n + 2 step witnesses of a PBS are independent once the accumulator chain is known (vpbs_pbs_accumulator_chain), and they share
+// one circuit: the plan's level schedule is replayed for all of them at once.  Values live in HBM as val[slot][batch] (instances
+// innermost: every access of an operation is one coalesced run over the batch); an operation is a thread per instance.  The
+// sequential spine of the step circuit is its bootstrapping-key hash chain (2 049 PoseidonGate rows, one level each), so a run is ~2 050 levels
+// of small launches -- latency-bound, amortised over the batch; the wires of one instance are then gathered straight into the
+// [n_wires][n] matrix vpbs_prove_step takes as a device input: they never cross PCIe.
+namespace vpbs {
+namespace {
+using Plan = vpbs_witness_plan;
+constexpr unsigned WT = 256;
+enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8, DE_GATE = 16 };
+
+struct Vals {
+    u64* v;
+    unsigned* err;
+    u32 batch, b;
+    // volatile: inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line)
+    __device__ u64 get(u32 slot) const { return *(volatile const u64*)(v + (size_t)(slot & ~Plan::CHECK) * batch + b); }
+    __device__ void set(u32 slot, u64 x) const {
+        if (x >= gl::P) x -= gl::P;
+        u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
+        if (slot & Plan::CHECK) {
+            if (*p != x) atomicOr(err, DE_SET_TWICE);
+        } else {
+            *p = x;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_preset * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    a.set(slots[gid / batch], values[gid]);
+}
+
+__global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    a.set(ops[gid / batch].out, ops[gid / batch].value);
+}
+
+__global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::ArithOp op = ops[gid / batch];
+    a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
+}
+
+__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::BitsOp op = ops[gid / batch];
+    u64 x = a.get(op.in);
+    const u64 mask = ((u64)1 << op.bits) - 1;
+    for (u32 k = 0; k < op.n_out; ++k) {
+        a.set(aux[op.out_at + k], x & mask);
+        x >>= op.bits;
+    }
+    if (x != 0) atomicOr(err, DE_TOO_LARGE);
+}
+
+// every gate generator without a special form: gen_run (the host's code) through the row's slot table, one thread per instance
+struct DevRow {
+    Vals a;
+    const u32* rs;
+    __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
+    __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
+    __device__ void fail(const char*) const { atomicOr(a.err, DE_GATE); }
+};
+
+struct RowTables {
+    const vpbs_gate* gates;
+    const u32 *row_gate, *row_off;
+    const u64* consts;
+    const gates::CosetTables* coset;  // [n_gates]
+    u32 max_consts;
+};
+
+__global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
+                                                       u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Plan::RowOp op = ops[gid / batch];
+    const u32 gi = t.row_gate[op.row];
+    const vpbs_gate g = t.gates[gi];
+    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + t.row_off[op.row]};
+    gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
+}
+
+// PoseidonGate generator, 16 lanes per row and instance: lane l < 12 owns state element l (the latency form of the prover's tree
+// kernels: a row is ~13 us of dependent instructions instead of ~65 us with one lane per row -- the step circuit's witness is a chain
+// of 2 049 such rows).  Every lane of the group runs the shuffles; lanes 12..15 carry zeros.
+__device__ __forceinline__ u64 shfl64(u64 x, unsigned src_lane) {
+    const u32 lo = (u32)__shfl((int)(u32)x, (int)src_lane, 64), hi = (u32)__shfl((int)(u32)(x >> 32), (int)src_lane, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ void poseidon_generate_wide(const Vals& a, const u32* rs) {
+    const unsigned lane = threadIdx.x & 63u, l = lane & 15u, base = lane & ~15u;
+    const bool own = l < 12;
+    const unsigned lm = own ? l : 0;
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const u64 swap = a.get(rs[24]);
+    if (swap > 1) {  // the same for every lane of the group
+        if (l == 0) atomicOr(a.err, DE_NOT_BOOLEAN);
+        return;
+    }
+    u64 s = own ? a.get(rs[l]) : 0;
+    const u64 rhs = shfl64(s, base + ((l + 4) & 15u));
+    const u64 delta = l < 4 ? gl::mul(swap, gl::sub(rhs, s)) : 0;   // swap * (rhs - lhs): lanes 0..3
+    const u64 delta_lo = shfl64(delta, base + ((l + 12) & 15u));     // lanes 4..7 see the delta of lane l - 4
+    if (l < 4) {
+        a.set(rs[25 + l], delta);
+        s = gl::add(s, delta);
+    } else if (l < 8) {
+        s = gl::sub(s, delta_lo);
+    }
+    if (own) s = gl::add_nc(s, poseidon::rc((int)l));
+    for (int round = 0; round < 30; ++round) {
+        const bool full = round < 4 || round >= 26;
+        if (own) {
+            if (round >= 1 && round < 4) a.set(rs[29 + 12 * (round - 1) + l], gl::canon(s));
+            else if (round >= 26) a.set(rs[87 + 12 * (round - 26) + l], gl::canon(s));
+            else if (!full && l == 0) a.set(rs[65 + (round - 4)], gl::canon(s));
+        }
+        if (full || l == 0) s = poseidon::sbox(s);
+        u64 acc_lo = 0, acc_hi = 0;  // row lm of the MDS matrix in 32-bit halves
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            unsigned src = lm + i;
+            if (src >= 12) src -= 12;
+            const u64 x = shfl64(s, base + src);
+            acc_lo += (u64)(u32)x * C[i];
+            acc_hi += (x >> 32) * C[i];
+        }
+        if (l == 0) {  // MDS_MATRIX_DIAG[0] = 8
+            acc_lo += (u64)(u32)s * 8;
+            acc_hi += (s >> 32) * 8;
+        }
+        const u64 k = round + 1 < 30 ? poseidon::rc(12 * (round + 1) + (int)lm) : 0;
+        acc_lo += (u32)k;
+        acc_hi += k >> 32;
+        s = own ? poseidon::fold96(acc_lo, acc_hi) : 0;
+    }
+    if (own) a.set(rs[12 + l], gl::canon(s));
+}
+
+__global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, u32 batch) {
+    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
+    if (group >= (size_t)n_ops * batch) return;
+    poseidon_generate_wide(Vals{v, err, batch, (u32)(group % batch)}, row_slots + rows[group / batch]);
+}
+
+// The tail of the schedule where every level holds PoseidonGate rows only (the hash chain): instances are independent of each other,
+// so one group per instance walks the levels by itself -- one launch instead of one per level.
+__global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned* err, const u32* rows, const u32* level_off, u32 first_level,
+                                                                u32 last_level, const u32* row_slots, u32 batch) {
+    const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
+    if (group >= batch) return;
+    const Vals a{v, err, batch, (u32)group};
+    for (u32 level = first_level; level <= last_level; ++level) {
+        for (u32 op = level_off[level]; op < level_off[level + 1]; ++op) poseidon_generate_wide(a, row_slots + rows[op]);
+        __threadfence_block();  // the next level reads what this one stored
+    }
+}
+
+__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * batch) return;
+    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Plan::MiscOp op = ops[gid / batch];
+    const u32 *in = aux + op.at, *out = in + op.n_in;
+    switch (op.kind) {
+        case VPBS_GEN_EQUALITY: {
+            const u64 x = a.get(in[0]), y = a.get(in[1]);
+            a.set(out[0], x == y ? 1 : 0);
+            a.set(out[1], x == y ? 0 : gl::inv(gl::sub(x, y)));
+            break;
+        }
+        case VPBS_GEN_BASE_SUM: {
+            u64 sum = 0;
+            for (u32 k = op.n_in; k-- > 0;) sum = gl::add(gl::mul(sum, op.p0), a.get(in[k]));
+            a.set(out[0], sum);
+            break;
+        }
+        case VPBS_GEN_QUOTIENT_EXT: {
+            const A num{a.get(in[0]), a.get(in[1])}, den{a.get(in[2]), a.get(in[3])};
+            if (den.a == 0 && den.b == 0) {
+                atomicOr(err, DE_DIV_ZERO);
+                break;
+            }
+            const u64 norm = gl::sub(gl::mul(den.a, den.a), gl::mul(7, gl::mul(den.b, den.b)));
+            const A q = gates::scale(num * A{den.a, gl::neg(den.b)}, gl::inv(norm));
+            a.set(out[0], q.a);
+            a.set(out[1], q.b);
+            break;
+        }
+        case VPBS_GEN_COPY: a.set(out[0], a.get(in[0])); break;
+        case VPBS_GEN_LOW_HIGH: {
+            const u64 x = a.get(in[0]);
+            a.set(out[0], x & (((u64)1 << op.p0) - 1));
+            a.set(out[1], x >> op.p0);
+            break;
+        }
+        case 0xC0u: a.set(out[0], (u64)out[1] | ((u64)out[2] << 32)); break;  // a ConstantGate wire that is also set elsewhere
+        default: break;
+    }
+}
+
+// wires[pos] = val[slot][b] for every position that carries a slot (the matrix is zeroed first)
+__global__ void __launch_bounds__(WT) wd_gather_kernel(const u64* v, const u32* pos, const u32* slot, size_t count, u32 batch, u32 b, u64* wires) {
+    const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (i < count) wires[pos[i]] = v[(size_t)slot[i] * batch + b];
+}
+
+__global__ void __launch_bounds__(WT) wd_read_kernel(const u64* v, const u32* slots, u32 count, u32 batch, u32 b, u64* out) {
+    const u32 i = blockIdx.x * WT + threadIdx.x;
+    if (i < count) out[i] = v[(size_t)slots[i] * batch + b];
+}
+
+template <class T> T* upload(vpbs_ctx* c, const std::vector<T>& h, std::vector<void*>& owned) {
+    if (h.empty()) return nullptr;
+    void* d = c->alloc_bytes(h.size() * sizeof(T));
+    owned.push_back(d);
+    VPBS_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return static_cast<T*>(d);
+}
+}  // namespace
+}  // namespace vpbs
+
+struct vpbs_witness_device {
+    vpbs_ctx* ctx = nullptr;
+    const vpbs_witness_plan* plan = nullptr;
+    unsigned max_batch = 0, batch = 0;
+    std::vector<void*> owned;
+    vpbs::u64* val = nullptr;
+    unsigned* err = nullptr;
+    const vpbs_witness_plan::ArithOp* arith = nullptr;
+    const vpbs_witness_plan::ConstOp* consts = nullptr;
+    const vpbs_witness_plan::BitsOp* bits = nullptr;
+    const vpbs_witness_plan::MiscOp* misc = nullptr;
+    const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
+    const vpbs::u32* poseidon_off = nullptr;
+    const vpbs_witness_plan::RowOp* rowops = nullptr;
+    vpbs::RowTables tables{};
+    unsigned tail_first = 0;          // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
+    hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
+    unsigned graph_batch = 0;
+    std::mutex mu;                    // run / wires / read share the context's stream and memory pool: one at a time per object
+};
+
+namespace vpbs {
+namespace {
+void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
+    const Plan::DeviceSchedule& ds = d->plan->dev;
+    auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
+    if (!ds.consts.empty())
+        hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
+    const u32 last_stepwise = d->tail_first ? d->tail_first - 1 : ds.n_levels;
+    for (u32 l = 1; l <= last_stepwise; ++l) {
+        if (const u32 k = ds.arith_off[l + 1] - ds.arith_off[l])
+            hipLaunchKernelGGL(wd_arith_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->arith + ds.arith_off[l], k, batch);
+        if (const u32 k = ds.bits_off[l + 1] - ds.bits_off[l])
+            hipLaunchKernelGGL(wd_bits_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->bits + ds.bits_off[l], d->aux, k, batch);
+        if (const u32 k = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
+            hipLaunchKernelGGL(wd_poseidon_kernel, blocks((size_t)k * 16, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l],
+                               d->row_slots, k, batch);
+        if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
+            hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
+        if (const u32 k = ds.rowops_off[l + 1] - ds.rowops_off[l])
+            hipLaunchKernelGGL(wd_rowop_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->rowops + ds.rowops_off[l], d->tables, d->row_slots, k,
+                               batch);
+    }
+    if (d->tail_first)
+        hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((batch * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, d->poseidon, d->poseidon_off,
+                           d->tail_first, ds.n_levels, d->row_slots, batch);
+}
+}  // namespace
+}  // namespace vpbs
+
+extern "C" {
+
+int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
+    if (!ctx || !plan || !out || max_batch == 0) return VPBS_ERR_INVALID;
+    try {
+        VPBS_HIP(hipSetDevice(ctx->device));
+        VPBS_REQUIRE(plan->dev.supported, ("this circuit has no device witness generator: " + plan->dev.unsupported).c_str());
+        auto d = std::make_unique<vpbs_witness_device>();
+        d->ctx = ctx;
+        d->plan = plan;
+        d->max_batch = max_batch;
+        const auto& ds = plan->dev;
+        using namespace vpbs;
+        d->arith = upload(ctx, ds.arith, d->owned);
+        d->consts = upload(ctx, ds.consts, d->owned);
+        d->bits = upload(ctx, ds.bits, d->owned);
+        d->misc = upload(ctx, ds.misc, d->owned);
+        d->poseidon = upload(ctx, ds.poseidon, d->owned);
+        d->aux = upload(ctx, ds.aux, d->owned);
+        d->row_slots = upload(ctx, ds.row_slots, d->owned);
+        d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
+        d->out_pos = upload(ctx, plan->out_pos, d->owned);
+        d->out_slot = upload(ctx, plan->out_slot, d->owned);
+        d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
+        d->rowops = upload(ctx, ds.rowops, d->owned);
+        if (!ds.rowops.empty()) {
+            std::vector<gates::CosetTables> coset(plan->gates.size());
+            for (size_t i = 0; i < plan->gates.size(); ++i)
+                if (plan->gates[i].kind == VPBS_GATE_COSET_INTERPOLATION) coset[i] = gates::coset_tables(plan->gates[i].p0);
+            d->tables = RowTables{upload(ctx, plan->gates, d->owned), upload(ctx, plan->row_gate, d->owned), upload(ctx, plan->row_off, d->owned),
+                                  upload(ctx, plan->consts, d->owned), upload(ctx, coset, d->owned), std::max(1u, plan->max_consts)};
+        }
+        {
+            u32 l = ds.n_levels;
+            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
+                   ds.rowops_off[l + 1] == ds.rowops_off[l])
+                --l;
+            d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
+        }
+        d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
+        d->owned.push_back(d->val);
+        d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
+        d->owned.push_back(d->err);
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        *out = d.release();
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+void vpbs_witness_device_free(vpbs_witness_device* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->graph) (void)hipGraphExecDestroy(d->graph);
+    for (void* p : d->owned) d->ctx->release(p);
+    delete d;
+}
+
+int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, unsigned batch) {
+    if (!d || batch == 0 || batch > d->max_batch || (!d->plan->preset_slot.empty() && !preset_val)) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    vpbs::u64* d_vals = nullptr;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const size_t n_preset = d->plan->preset_slot.size();
+        d->batch = batch;
+        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * d->plan->n_slots * batch, s));
+        VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
+        if (n_preset) {
+            d_vals = ctx->alloc_words(n_preset * batch);
+            VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
+                               d_vals, (u32)n_preset, batch);
+        }
+        // the level launches are a static sequence: captured once per batch size, replayed afterwards
+        if (!d->graph || d->graph_batch != batch) {
+            if (d->graph) {
+                VPBS_HIP(hipGraphExecDestroy(d->graph));
+                d->graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            launch_levels(d, s, batch);
+            const hipError_t launched = hipGetLastError();
+            const hipError_t ended = hipStreamEndCapture(s, &g);   // always leave capture mode
+            hipError_t e = launched != hipSuccess ? launched : ended;
+            if (e == hipSuccess) e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) d->graph = nullptr;
+            VPBS_HIP(e);
+            d->graph_batch = batch;
+        }
+        VPBS_HIP(hipGraphLaunch(d->graph, s));
+        unsigned flags = 0;
+        VPBS_HIP(hipMemcpyAsync(&flags, d->err, sizeof flags, hipMemcpyDeviceToHost, s));
+        VPBS_HIP(hipStreamSynchronize(s));
+        if (d_vals) ctx->release(d_vals);
+        d_vals = nullptr;
+        if (flags) {
+            std::string m;
+            if (flags & DE_SET_TWICE) m += "a partition was set twice with different values; ";
+            if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
+            if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
+            if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
+            if (flags & DE_GATE) m += "a gate generator rejected its inputs (limbs that do not fit, an access index out of range, a non-boolean bit, a zero shift); ";
+            throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
+        }
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        if (d_vals) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->release(d_vals);
+        }
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_t* d_wires) {
+    if (!d || !d_wires) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        const size_t count = d->plan->out_pos.size();
+        VPBS_HIP(hipMemsetAsync(d_wires, 0, sizeof(u64) * d->plan->total, ctx->stream));
+        hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
+                           d->batch, instance, d_wires);
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const uint32_t* positions, size_t count, uint64_t* out) {
+    if (!d || (count && (!positions || !out))) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
+    vpbs::u32* d_slots = nullptr;
+    vpbs::u64* d_out = nullptr;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        // positions -> slots through the plan's ascending (position, slot) list; a position without a slot reads 0
+        const auto& pos = d->plan->out_pos;
+        std::vector<u32> slots(count);
+        std::vector<size_t> missing;
+        for (size_t i = 0; i < count; ++i) {
+            const auto it = std::lower_bound(pos.begin(), pos.end(), positions[i]);
+            if (it != pos.end() && *it == positions[i]) slots[i] = d->plan->out_slot[it - pos.begin()];
+            else {
+                slots[i] = 0;
+                missing.push_back(i);
+            }
+        }
+        if (count == 0) return VPBS_OK;
+        d_slots = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32) * count));
+        d_out = ctx->alloc_words(count);
+        VPBS_HIP(hipMemcpyAsync(d_slots, slots.data(), sizeof(u32) * count, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d_slots, (u32)count, d->batch,
+                           instance, d_out);
+        VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(d_slots);
+        ctx->release(d_out);
+        for (size_t i : missing) out[i] = 0;
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        (void)hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
+        if (d_slots) ctx->release(d_slots);
+        if (d_out) ctx->release(d_out);
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+// The compiled witness plan (vpbs_witness_plan: value slots, generator schedule, the split into an early and a late phase, the device
+// schedule) and the host thread pools that share the wide dependency levels of a phase.  Shared by witness.hip (creation, host runs) and
+// witness_device.hip (which replays plan.dev on the GPU).
+#pragma once
+#include "witness_gen.h"
+
+namespace vpbs {
+
+// spin for up to 150 us (the other side usually answers within microseconds), then sleep in short naps: a pool's workers wait
+// through the stretches of a phase that only the calling thread or the chain lanes work on, and a container's CPU quota is spent by
+// spinning threads as by working ones
+template <class Pred> void spin_until(Pred ready) {
+    std::chrono::steady_clock::time_point t0;
+    for (unsigned i = 0; !ready(); ++i) {
+        __builtin_ia32_pause();
+        if ((i & 63) != 63) continue;
+        const auto t = std::chrono::steady_clock::now();
+        if (i == 63) t0 = t;
+        else if (t - t0 > std::chrono::milliseconds(1)) std::this_thread::sleep_for(std::chrono::microseconds(100));   // a very long wait
+        else if (t - t0 > std::chrono::microseconds(150)) std::this_thread::sleep_for(std::chrono::microseconds(20));  // a long wait: nap
+    }
+}
+
+// The host threads that share the wide dependency levels of a split plan's phase.  They belong to the plan and live as long as it does:
+// asleep on a condition variable between runs, spinning on a phase counter while a run is active (a run is hundreds of levels within a
+// few milliseconds; waking a sleeping thread per level would cost more than the level).  One run at a time per pool (`busy`); a second
+// concurrent run of the same phase finds the pool taken and proceeds on its own thread alone.
+struct LevelPool {
+    const unsigned threads;                       // including the calling thread (number 0)
+    std::mutex busy;
+    explicit LevelPool(unsigned n) : threads(std::max(1u, n)) {
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([this, t] { work(t); });
+        place_near_caller();
+    }
+    ~LevelPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto& w : workers) w.join();
+        if (domain >= 0) domains().give_back(domain, threads);
+    }
+    void begin() {   // wake the workers for a run
+        {
+            std::lock_guard<std::mutex> lk(m);
+            active.store(true, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    void end() {
+        std::lock_guard<std::mutex> lk(m);
+        active.store(false, std::memory_order_release);
+    }
+    // every thread of the pool (the caller as number 0) runs job(t); returns when all have finished
+    template <class Job> void share(Job&& j) {
+        job = std::ref(j);
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+        j(0u);
+        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+    }
+
+    // the same without the caller: the workers run job(t), t = 1 .. threads - 1, while the caller does something else; finish() waits for them
+    template <class Job> void start(Job&& j) {
+        job = std::ref(j);
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+    }
+    void finish() {
+        spin_until([&] { return done.load(std::memory_order_acquire) == threads - 1; });
+    }
+
+  private:
+    // The workers share slot values with the calling thread level after level: on a many-chiplet host they are kept on the CPUs of ONE
+    // last-level-cache domain (Linux: cache/index3/shared_cpu_list) -- the caller's when it still has room for them, otherwise the least
+    // taken domain of the same package (a process runs several pools: two phases per plan, one plan per concurrent chain; two pools spinning
+    // on the same sixteen hardware threads cost more than the placement gains).  The caller's own affinity is left alone.
+    // VPBS_POOL_PIN=0 turns the placement off.
+    struct Domains {
+        struct D {
+            cpu_set_t set;
+            unsigned cpus = 0, taken = 0;
+            int package = -1;
+        };
+        std::mutex m;
+        std::vector<D> all;
+        std::vector<int> of_cpu;   // cpu -> index into all, -1 unknown
+        static bool read_line(const char* fmt, int cpu, char* line, size_t len) {
+            char path[160];
+            std::snprintf(path, sizeof path, fmt, cpu);
+            FILE* f = std::fopen(path, "r");
+            if (!f) return false;
+            const bool got = std::fgets(line, (int)len, f) != nullptr;
+            std::fclose(f);
+            return got;
+        }
+        Domains() {
+            const long n = std::min<long>(sysconf(_SC_NPROCESSORS_CONF), CPU_SETSIZE);
+            of_cpu.assign(n > 0 ? (size_t)n : 0, -1);
+            for (int cpu = 0; cpu < (int)of_cpu.size(); ++cpu) {
+                if (of_cpu[cpu] >= 0) continue;
+                char line[512] = {0};
+                if (!read_line("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, line, sizeof line)) continue;
+                D d;
+                CPU_ZERO(&d.set);
+                for (const char* q = line; *q;) {   // "0-7,128-135"
+                    char* end = nullptr;
+                    const long a = std::strtol(q, &end, 10);
+                    if (end == q) break;
+                    long b = a;
+                    if (*end == '-') b = std::strtol(end + 1, &end, 10);
+                    for (long c = a; c <= b && c < (long)of_cpu.size(); ++c) {
+                        CPU_SET((int)c, &d.set);
+                        ++d.cpus;
+                        of_cpu[c] = (int)all.size();
+                    }
+                    if (*end != ',') break;
+                    q = end + 1;
+                }
+                char pk[64] = {0};
+                if (read_line("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu, pk, sizeof pk)) d.package = std::atoi(pk);
+                if (d.cpus) all.push_back(d);
+            }
+        }
+        // -> index of the domain that takes `n` more threads, or -1
+        int take(unsigned n) {
+            std::lock_guard<std::mutex> lk(m);
+            const int cpu = sched_getcpu();
+            const int home = cpu >= 0 && cpu < (int)of_cpu.size() ? of_cpu[cpu] : -1;
+            if (home < 0) return -1;
+            int best = -1;
+            if (all[home].taken + n <= all[home].cpus) best = home;
+            for (int pass = 0; pass < 2 && best < 0; ++pass)   // same package first
+                for (int i = 0; i < (int)all.size(); ++i) {
+                    if (all[i].cpus < n || (pass == 0 && all[i].package != all[home].package)) continue;
+                    if (best < 0 || all[i].taken < all[best].taken) best = i;
+                }
+            if (best >= 0) all[best].taken += n;
+            return best;
+        }
+        void give_back(int i, unsigned n) {
+            std::lock_guard<std::mutex> lk(m);
+            if (i >= 0) all[i].taken -= std::min(n, all[i].taken);
+        }
+    };
+    static Domains& domains() {
+        static Domains d;
+        return d;
+    }
+    int domain = -1;
+    void place_near_caller() {
+        const char* e = std::getenv("VPBS_POOL_PIN");
+        if ((e && std::atoi(e) == 0) || workers.empty()) return;
+        domain = domains().take(threads);
+        if (domain < 0) return;   // no cache topology to read, or no domain can hold the pool: the scheduler places the threads
+        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof(cpu_set_t), &domains().all[domain].set);
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<u32> phase{0}, done{0};
+    std::atomic<bool> active{false};
+    bool quit = false;
+    std::function<void(unsigned)> job;
+    void work(unsigned t) {
+        u32 seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || active.load(std::memory_order_acquire); });
+                if (quit) return;
+            }
+            for (;;) {
+                spin_until([&] { return phase.load(std::memory_order_acquire) != seen || !active.load(std::memory_order_acquire); });
+                if (phase.load(std::memory_order_acquire) == seen) break;   // the run is over: back to sleep
+                ++seen;
+                job(t);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        }
+    }
+};
+}  // namespace vpbs
+
+struct vpbs_witness_plan {
+    using u32 = vpbs::u32;
+    using u64 = vpbs::u64;
+    size_t n = 0, total = 0, n_slots = 0;
+    unsigned max_consts = 0;
+    std::vector<vpbs_gate> gates;
+    std::vector<u32> row_gate;                  // [n]
+    std::vector<u64> consts;                    // [n][max_consts]: the gate constants of every row
+    std::vector<u32> row_off, row_slots;        // row -> offset into row_slots: the slot of every wire of a row that owns generators
+    struct Gadget {
+        unsigned kind, p0;
+        u32 at, n_in, n_out;                    // gadget_slots / gadget_pos [at, at + n_in) inputs, then n_out outputs
+    };
+    std::vector<Gadget> gadgets;
+    std::vector<u32> gadget_slots, gadget_pos;
+    struct Step {
+        u32 row, sub;                           // row == NO_ROW: gadget number `sub`
+    };
+    std::vector<Step> schedule;
+    std::vector<u32> preset_slot, preset_pos;
+    std::vector<u32> out_pos, out_slot;         // every position that carries a slot, ascending (full_witness)
+    // ---- two-phase runs (vpbs_witness_plan_split): some presets arrive late (the previous proof of an IVC step); a generator is LATE when
+    // anything it reads is, everything else can run before the late values exist
+    bool is_split = false;
+    std::vector<uint8_t> preset_late, step_late;
+    std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late
+    // the late generators by dependency level (a generator of level L reads only what levels < L wrote, and two generators of one level
+    // never write the same slot: a second writer of a slot is placed above the first and compares): the wide levels -- the 28 FRI queries
+    // of an in-circuit verifier are independent of each other -- are run by several host threads
+    // Both phases hold their generators by dependency level like that (the early phase of the step circuit: the NTT / external-product
+    // arithmetic is wide, the hash chains are one PoseidonGate row per level).
+    struct Phase {
+        std::vector<u32> order, level_off;      // schedule indices sorted by level; level l = order[level_off[l], level_off[l + 1])
+        std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
+    };
+    Phase phase[2];                             // [0] early, [1] late
+    // Chain lanes: PoseidonGate rows whose results nothing but other such rows reads inside the phase (the hash chains over the GGSW and
+    // over the public inputs: thousands of permutations, each needing the one before).  They are taken out of the levels and run on
+    // threads of their own next to them, in schedule order, waiting on the set flag of a value another lane or a level still has to produce.
+    struct Lane {
+        std::vector<u32> steps;                 // schedule indices, ascending
+        std::vector<u32> wait_off, wait;        // step k waits for slots wait[wait_off[k], wait_off[k + 1])
+    };
+    std::vector<Lane> lanes[2];
+    std::vector<u32> lane_steps_sorted[2];      // all lane steps of a phase, ascending (a run without threads for the lanes)
+    mutable std::unique_ptr<vpbs::LevelPool> pool[2], lane_pool[2];
+    mutable std::mutex pool_mutex;              // creation of the pools (first run of a phase)
+
+    // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
+    // written at levels < L; within a level the operations are grouped by kind.  CHECK in an output slot index: the slot already has a
+    // writer earlier in the schedule (a preset, or a generator whose output is copy-constrained to this one), so the operation
+    // compares instead of writing ("set twice with different values") -- the order is static, so no per-slot flag is needed at run time.
+    static constexpr u32 CHECK = 0x80000000u;
+    struct ArithOp {
+        u32 x, y, z, out;
+        u64 c0, c1;
+    };
+    struct ConstOp {
+        u32 out, pad;
+        u64 value;
+    };
+    struct BitsOp {                             // out[k] = (in >> (k * bits)) & mask, k < n_out; the rest must be zero
+        u32 in, out_at, n_out, bits;            // BaseSumGate<2> generator, WireSplitGenerator
+    };
+    struct MiscOp {                             // gadget generators that are not bit splits
+        u32 kind, p0, at, n_in, n_out, pad;
+    };
+    struct RowOp {                              // any other gate generator: gen_run on the row's slot table
+        u32 row, sub;
+    };
+    struct DeviceSchedule {
+        bool supported = false;
+        std::string unsupported;                // why not (a gate or generator kind without a device form)
+        u32 n_levels = 0;
+        std::vector<ArithOp> arith;
+        std::vector<ConstOp> consts;            // no inputs: written before level 1
+        std::vector<BitsOp> bits;
+        std::vector<u32> poseidon;              // offsets into row_slots (135 slots per PoseidonGate row)
+        std::vector<MiscOp> misc;
+        std::vector<RowOp> rowops;
+        std::vector<u32> arith_off, bits_off, poseidon_off, misc_off, rowops_off;   // [n_levels + 2]: operations of level L = [off[L], off[L + 1])
+        std::vector<u32> aux;                   // slot lists of BitsOp outputs and MiscOp inputs / outputs
+        std::vector<u32> row_slots;             // copy of row_slots with CHECK marks on outputs that compare
+        std::vector<u32> preset_slot;           // with CHECK marks (a target preset twice)
+    } dev;
+};
