@@ -983,15 +983,22 @@ def main():
     ap.add_argument("--step-chains", type=int, default=1, help="step workload: independent synthetic chains proven concurrently per GPU")
     ap.add_argument("--batch-chains", type=int, default=4,
                     help="after the single-chain synthetic step, also time this many concurrent synthetic chains (1 GPU only)")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+    ap.add_argument("--mode", choices=["replicas", "sharded", "sharded-replay"], default="replicas",
                     help="N > 1: 'replicas' = independent chains per GPU (weak scaling, default, no data-path collective); "
                          "'sharded' = ONE chain whose commitments are coset-sharded over the GPUs (strong scaling: per-step "
-                         "latency; collectives: all-gather of cap hashes + one all-reduce of query records per step)")
+                         "latency; collectives: all-gather of cap hashes + one all-reduce of query records per step).  "
+                         "'sharded-replay' (ONE GPU, not a bench line): per-rank compute time of the sharded step for worlds 2 / 4 / 8, each "
+                         "rank alone on the device with its collectives answered from a recording (tools/sharded_replay.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
     ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.mode == "sharded-replay":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import sharded_replay
+        print(json.dumps(sharded_replay.run(args.log_n, args.steps if args.steps <= 50 else 10, device=args.device or 0)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
