@@ -11,6 +11,14 @@ __global__ void k_mul(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(gl::mul_nc(a[i], b[i]));
 }
+__global__ void k_dot2(const u64* a, const u64* b, u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gl::dot2_nc(a[i], b[i], b[(i + 7) % n], a[(i + 13) % n]));
+}
+__global__ void k_mad(const u64* a, const u64* b, u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gl::mad_nc(a[i], b[i], a[(i + 5) % n]));
+}
 __global__ void k_fold(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(poseidon::fold96(a[i], b[i]));
@@ -45,6 +53,28 @@ int main(int argc, char** argv) {
             if (out[i] != want) { if (bad < 5) printf("mul mismatch %d: %016lx * %016lx -> %016lx want %016lx\n", i, a[i], b[i], out[i], want); ++bad; }
         }
         printf("mul_nc: %d mismatches of %d\n", bad, n);
+    }
+    if (argc < 2 || argv[1][0] == 'd') {   // the fused products of the gate kernels: a b + c d and a b + c with one reduction
+        bad = 0;
+        hipLaunchKernelGGL(k_dot2, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const u64 c = b[(i + 7) % n], d = a[(i + 13) % n];
+            const u64 want = (u64)((((unsigned __int128)a[i] * b[i]) % gl::P + ((unsigned __int128)c * d) % gl::P) % gl::P);
+            if (out[i] != want) { if (bad < 5) printf("dot2 mismatch %d: %016lx %016lx %016lx %016lx -> %016lx want %016lx\n", i, a[i], b[i], c, d, out[i], want); ++bad; }
+        }
+        printf("dot2_nc: %d mismatches of %d\n", bad, n);
+        bad = 0;
+        hipLaunchKernelGGL(k_mad, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const u64 c = a[(i + 5) % n];
+            const u64 want = (u64)((((unsigned __int128)a[i] * b[i]) % gl::P + c % gl::P) % gl::P);
+            if (out[i] != want) { if (bad < 5) printf("mad mismatch %d: %016lx %016lx %016lx -> %016lx want %016lx\n", i, a[i], b[i], c, out[i], want); ++bad; }
+        }
+        printf("mad_nc: %d mismatches of %d\n", bad, n);
     }
     if (argc < 2 || argv[1][0] == 'f') {
         bad = 0;

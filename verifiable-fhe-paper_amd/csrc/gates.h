@@ -51,6 +51,33 @@ template <class F> GL_HD Alg<F> operator-(Alg<F> x, Alg<F> y) { return Alg<F>{gl
 template <class F> GATES_FN Alg<F> operator*(Alg<F> x, Alg<F> y) {
     return Alg<F>{gl::add(gl::mul(x.a, y.a), mulc(gl::mul(x.b, y.b), 7)), gl::add(gl::mul(x.a, y.b), gl::mul(x.b, y.a))};
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Base field on the GPU: (a + b X)(c + d X) = (a c + 7 b d) + (a d + b c) X as two FUSED products -- the 128-bit products of a component
+// are added before ONE reduction (gl::dot2_nc: 29 instructions instead of two multiplications and a modular addition, 48) -- and 7 d is
+// two multiply-adds and a fold.  times7 / mul_lazy expose the pieces for loops that multiply by one fixed element (the ReducingGates'
+// alpha) and whose consumers accept any u64 residue; operator* itself returns canonical components like the generic form.
+GL_HD u64 times7(u64 x) { return poseidon::fold96((u64)(u32)x * 7u, (u64)(u32)(x >> 32) * 7u); }   // any residue in, a residue out
+// x * y with y7 = times7(y.b): components are u64 RESIDUES, not canonical -- fine as the first operand of gl::add / gl::sub with a
+// canonical second operand and as a constraint handed to the sink, nowhere else
+GL_HD Alg<u64> mul_lazy(Alg<u64> x, Alg<u64> y, u64 y7) {
+    return Alg<u64>{gl::dot2_nc(x.a, y.a, x.b, y7), gl::dot2_nc(x.a, y.b, x.b, y.a)};
+}
+GL_HD Alg<u64> operator*(Alg<u64> x, Alg<u64> y) {   // a plain overload: preferred to the template above for the base field
+    const Alg<u64> r = mul_lazy(x, y, times7(y.b));
+    return Alg<u64>{gl::canon(r.a), gl::canon(r.b)};
+}
+// e t + v p (the step of the barycentric interpolation), canonical components
+GL_HD Alg<u64> fma2(Alg<u64> e, Alg<u64> t, Alg<u64> v, Alg<u64> p) {
+    const Alg<u64> x = mul_lazy(e, t, times7(t.b)), y = mul_lazy(v, p, times7(p.b));
+    return Alg<u64>{gl::canon(gl::add_nn(x.a, y.a)), gl::canon(gl::add_nn(x.b, y.b))};
+}
+// x + b (y - x) for canonical x, y and any residue b (RandomAccessGate's binary selection): one fused multiply-add
+GL_HD u64 select_lerp(u64 x, u64 y, u64 b) { return gl::canon(gl::mad_nc(b, gl::sub(y, x), x)); }
+#endif
+template <class F> GL_HD F times7(F x) { return mulc(x, 7); }
+template <class F> GATES_FN Alg<F> mul_lazy(Alg<F> x, Alg<F> y, F) { return x * y; }
+template <class F> GATES_FN Alg<F> fma2(Alg<F> e, Alg<F> t, Alg<F> v, Alg<F> p) { return e * t + v * p; }
+template <class F> GL_HD F select_lerp(F x, F y, F b) { return gl::add(x, gl::mul(b, gl::sub(y, x))); }
 template <class F> GL_HD Alg<F> scale(Alg<F> x, F s) { return Alg<F>{gl::mul(x.a, s), gl::mul(x.b, s)}; }  // scalar_mul
 template <class F> GL_HD Alg<F> scalec(Alg<F> x, u64 c) { return Alg<F>{mulc(x.a, c), mulc(x.b, c)}; }
 template <class F> GL_HD Alg<F> sub_base(Alg<F> x, u64 c) { return Alg<F>{gl::sub(x.a, Fld<F>::lift(c)), x.b}; }
@@ -239,11 +266,12 @@ template <class F, class V, class S> GATES_FN void eval_mul_ext(const vpbs_gate&
 template <class F, class V, class S> GATES_FN void eval_reducing(const vpbs_gate& g, const V& v, S& s) {
     const unsigned n = g.p0;
     const Alg<F> alpha = wire_alg<F>(v, 2);
+    const F alpha7 = times7(alpha.b);   // the one fixed multiplier of the loop
     Alg<F> acc = wire_alg<F>(v, 4);
 #pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + n + 2 * i);
-        Alg<F> c = acc * alpha;
+        Alg<F> c = mul_lazy(acc, alpha, alpha7);   // residues (GPU): every use below has a canonical wire as its second operand
         c.a = gl::add(c.a, v.wire(6 + i));
         push_alg(s, c - next);
         acc = next;
@@ -253,11 +281,12 @@ template <class F, class V, class S> GATES_FN void eval_reducing(const vpbs_gate
 template <class F, class V, class S> GATES_FN void eval_reducing_ext(const vpbs_gate& g, const V& v, S& s) {
     const unsigned n = g.p0;
     const Alg<F> alpha = wire_alg<F>(v, 2);
+    const F alpha7 = times7(alpha.b);
     Alg<F> acc = wire_alg<F>(v, 4);
 #pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + 2 * n + 2 * i);
-        push_alg(s, acc * alpha + wire_alg<F>(v, 6 + 2 * i) - next);
+        push_alg(s, mul_lazy(acc, alpha, alpha7) + wire_alg<F>(v, 6 + 2 * i) - next);   // residue + canonical wire - canonical wire
         acc = next;
     }
 }
@@ -286,7 +315,7 @@ template <class F, unsigned BITS, class V, class S> GATES_FN void eval_random_ac
         for (unsigned b = 0; b < BITS; ++b) {
 #pragma unroll
             for (unsigned i = 0; i < (vec >> (b + 1)); ++i)
-                items[i] = gl::add(items[2 * i], gl::mul(bit[b], gl::sub(items[2 * i + 1], items[2 * i])));
+                items[i] = select_lerp(items[2 * i], items[2 * i + 1], bit[b]);
         }
         s.push(gl::sub(items[0], v.wire(base + 1)));
     }
@@ -330,7 +359,7 @@ GL_HD void partial_interpolate(const CosetTables& t, const V& v, unsigned from, 
     for (unsigned i = from; i < to; ++i) {
         const Alg<F> val = scalec(wire_alg<F>(v, 1 + 2 * i), t.weights[i]);
         const Alg<F> term = sub_base(x, t.domain[i]);
-        eval = eval * term + val * prod;
+        eval = fma2(eval, term, val, prod);
         prod = prod * term;
     }
 }

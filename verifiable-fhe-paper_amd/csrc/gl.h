@@ -48,6 +48,16 @@ GL_HD u64 add_nc(u64 a, u64 b_canonical) {
     return s;
 }
 
+// any u64 residues in, any residue out: the sum can wrap, and the corrected sum can wrap once more (never a third time)
+GL_HD u64 add_nn(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a) {
+        s += EPS;
+        if (s < EPS) s += EPS;
+    }
+    return s;
+}
+
 GL_HD void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -183,11 +193,95 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
     r = ((u64)r1 << 32) | r0;
     q = ((u64)q1 << 32) | q0;
 }
+// a * b + c * d with ONE reduction: the two 128-bit products are added (the sum can reach 2^129: its top bit k joins hi_hi) and then
+// lo + hi_lo 2^64 + (hi_hi + k 2^32) 2^96 is reduced as in mul_nc.  The subtrahend hi_hi + k 2^32 is below 2^33 instead of 2^32, and
+// the single correction (c - b)(2^32 - 1) still cannot wrap: c = 1 means u < 2^64 - 2^33 + 1, so u + 2^32 - 1 < 2^64; b = 1 without c
+// means the wrapped difference is at least 2^64 - 2^33, so taking 2^32 - 1 away stays positive.  Any u64 residues in, a residue out.
+// 29 VALU + 2 SALU against 2 x 16 + 8 for two products and a modular addition.
+__device__ __forceinline__ u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
+    u32 r0, r1;
+    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 v[88:89], vcc, %6, %8, 0\n\t"
+        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 v[90:91], vcc, %6, %9, 0\n\t"
+        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
+        "v_mad_u64_u32 v[90:91], s[86:87], %7, %8, v[90:91]\n\t"
+        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
+        "v_mad_u64_u32 v[92:93], vcc, %7, %9, 0\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v94, 0, 1, s[86:87]\n\t"
+        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
+        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
+        "v_add_co_u32_e32 v89, vcc, v89, v90\n\t"
+        "v_addc_co_u32_e32 v92, vcc, v92, v91, vcc\n\t"
+        "v_addc_co_u32_e32 v93, vcc, v93, v94, vcc\n\t"
+        "v_add_co_u32_e32 v80, vcc, v80, v88\n\t"
+        "v_addc_co_u32_e32 v81, vcc, v81, v89, vcc\n\t"
+        "v_addc_co_u32_e32 v84, vcc, v84, v92, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, v85, v93, vcc\n\t"
+        "v_addc_co_u32_e64 v86, vcc, 0, 0, vcc\n\t"
+        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
+        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
+        "v_subb_co_u32_e32 v81, vcc, v81, v86, vcc\n\t"
+        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
+        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
+        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
+          "v"((u32)(d >> 32))
+        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "vcc", "scc",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+    return ((u64)r1 << 32) | r0;
+}
+// a * b + c with one reduction (the product plus a 64-bit addend stays below 2^128).  Any residues in, a residue out; 20 VALU + 2 SALU.
+__device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
+    u32 r0, r1;
+    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
+        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
+        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
+        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
+        "v_add_co_u32_e32 v80, vcc, v80, %6\n\t"
+        "v_addc_co_u32_e32 v81, vcc, v81, %7, vcc\n\t"
+        "v_addc_co_u32_e32 v84, vcc, 0, v84, vcc\n\t"
+        "v_addc_co_u32_e32 v85, vcc, 0, v85, vcc\n\t"
+        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
+        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
+        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
+        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
+        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32))
+        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+    return ((u64)r1 << 32) | r0;
+}
 #else
 GL_HD u64 mul_nc(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide(a, b, lo, hi);
     return reduce128_nc(lo, hi);
+}
+// host forms of the device's fused products (same residue classes)
+GL_HD u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
+    const unsigned __int128 s = (unsigned __int128)mul_nc(a, b) + mul_nc(c, d);
+    return reduce128_nc((u64)s, (u64)(s >> 64));
+}
+GL_HD u64 mad_nc(u64 a, u64 b, u64 c) {
+    const unsigned __int128 s = (unsigned __int128)mul_nc(a, b) + c;
+    return reduce128_nc((u64)s, (u64)(s >> 64));
 }
 GL_HD void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64& q) {
     r = mul_nc(a, b);
