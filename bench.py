@@ -968,10 +968,11 @@ def main():
                     help="ivc (default, the headline): vPBS proofs as the reference's IVC chains through vpbs_ivc_prove_pbs -- witness generation, "
                          "chain dependency and uploads inside the clock.  step: the synthetic back-to-back step proof (rounds 1-2's headline; "
                          "profiling scripts); with ivc it is still measured and reported as step_micro")
-    ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "3")),
+    ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "0")),
                     help="ivc workload: independent vPBS chains (own keys, context, witness plans, host threads) proven side by side per GPU.  "
-                         "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default is 3 (the "
-                         "single-chain latency figure is reported next to it as ivc_single_chain)")
+                         "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default (0 = auto) is 4 where "
+                         "this rank's share of the host CPUs carries it (a chain keeps about four host threads busy), fewer on a small CPU "
+                         "quota (the single-chain latency figure is reported next to it as ivc_single_chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
     ap.add_argument("--no-single-chain", action="store_true", help="ivc workload: skip the one-chain latency measurement")
@@ -1016,6 +1017,9 @@ def main():
             dist.init_process_group(args.dist_backend)
     log_n = args.log_n
     secondary = rank == 0 and world == 1 and log_n == LOG_N
+    if args.chains <= 0:
+        cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)      # this rank's share of the CPUs the container may use
+        args.chains = max(1, min(4, cpus // 4))
 
     out, state = None, None
     if args.workload == "ivc":
