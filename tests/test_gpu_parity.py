@@ -793,6 +793,44 @@ def test_native_rccl_collectives_single_rank(ctx):
     sharding.free_comm_rccl(comm)
 
 
+def test_context_options_choose_between_bit_identical_arrangements(ctx):
+    """vpbs_ctx_set_option: the launch heuristics are per-context settings (the environment variables only set their defaults) and never
+    change a result -- one launch per gate type vs the one-launch kernel, one or three gate streams, per-level Merkle launches vs the fused
+    climb, the 16-lane Poseidon form everywhere / nowhere: the same proof, word for word"""
+    import random
+    import gates_oracle as go
+    defaults = {name: ctx.get_option(name) for name in ctx.OPTIONS}
+    assert defaults == {"gate_lanes": 3, "gates_fused": 1, "gate_items": 5, "wide_threshold": 1 << 14, "merkle_climb": 1}
+    gate_spec = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "reducing", ("random_access", 4), "coset_interpolation"]
+    gs, ps = go.GateSet(gate_spec), api.GateSet(gate_spec)
+    rnd = random.Random(5)
+    log_c = 7
+    cpis = [rnd.randrange(api.P) for _ in range(4)]
+    constants, wires, sigma, _ = go.demo_circuit(rnd, gs, log_c, cpis)
+    nconst = constants.shape[0]
+    cs = ctx.commit_values(np.concatenate([constants, sigma]))
+    si = ctx.make_step_inputs(log_c, wires, None, None, cs, DIGEST, cpis, sigmas=sigma, n_routed=80, n_constants=nconst, gates=ps)
+    want = ctx.prove_step(si)
+    try:
+        for over in ({"gates_fused": 0}, {"gate_lanes": 1}, {"gates_fused": 0, "gate_lanes": 1}, {"gate_items": 2}, {"gate_items": 8}, {"merkle_climb": 0},
+                     {"wide_threshold": 0}, {"wide_threshold": 1 << 30}):
+            for name, v in over.items():
+                ctx.set_option(name, v)
+                assert ctx.get_option(name) == v
+            got = ctx.prove_step(si)
+            for key in ("caps", "challenges", "openings", "fri"):
+                assert (got[key] == want[key]).all(), (over, key)
+            for name in over:
+                ctx.set_option(name, defaults[name])
+        for name, bad in (("gate_lanes", 2), ("gate_items", 0), ("gate_items", 9)):
+            with pytest.raises(api.VpbsError):
+                ctx.set_option(name, bad)
+    finally:
+        for name, v in defaults.items():
+            ctx.set_option(name, v)
+    cs.free()
+
+
 @pytest.mark.gpu
 def test_native_rccl_world_gt1():
     """The library's RCCL communicator with MORE than one rank -- one process per GPU, ncclAllGather / ncclAllReduce over xGMI: a sharded step

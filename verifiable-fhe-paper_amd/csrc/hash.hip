@@ -223,7 +223,8 @@ void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_le
 // form wins (measured)
 Tuning Tuning::from_env() {
     Tuning t;
-    if (const char* e = getenv("VPBS_WIDE_THRESHOLD")) t.wide_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("VPBS_WIDE_THRESHOLD")) t.wide_threshold = t.fri_leaf_wide_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("VPBS_FRI_LEAF_WIDE_THRESHOLD")) t.fri_leaf_wide_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("VPBS_MERKLE_CLIMB")) t.merkle_climb = atoi(e) != 0;
     if (const char* e = getenv("VPBS_GATES_FUSED")) t.gates_fused = atoi(e) != 0;
     if (const char* e = getenv("VPBS_GATE_ITEMS")) t.gate_items = (unsigned)std::max(1, atoi(e));
@@ -231,7 +232,7 @@ Tuning Tuning::from_env() {
 }
 
 void launch_fri_leaf_hash(hipStream_t s, const Tuning& tune, const u64* v0, const u64* v1, size_t n_leaves, unsigned arity_bits, u64* digests) {
-    if (n_leaves <= tune.wide_threshold && (2u << arity_bits) > 4) {
+    if (n_leaves <= tune.fri_leaf_wide_threshold && (2u << arity_bits) > 4) {
         hipLaunchKernelGGL(fri_leaf_hash_wide_kernel, dim3((unsigned)((n_leaves * 16 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, v0,
                            v1, n_leaves, arity_bits, digests);
         return;

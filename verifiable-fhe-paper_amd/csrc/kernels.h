@@ -108,6 +108,7 @@ void launch_blind_rotate_step(hipStream_t s, const u64* acc_in, const u64* masks
 // created with: VPBS_WIDE_THRESHOLD, VPBS_MERKLE_CLIMB, VPBS_GATES_FUSED, VPBS_GATE_ITEMS, VPBS_GATE_LANES)
 struct Tuning {
     size_t wide_threshold = (size_t)1 << 14;   // launches with at most this many independent permutations use the 16-lane Poseidon form
+    size_t fri_leaf_wide_threshold = (size_t)1 << 14;   // the same for the FRI round leaves (several dependent permutations per leaf)
     bool merkle_climb = true;                  // the latency-bound upper levels of a tree in fused multi-level launches
     bool gates_fused = true;                   // all gate constraints in one launch (false: one launch per gate type)
     unsigned gate_items = 5;                   // work items per point tile of the one-launch gate kernel
