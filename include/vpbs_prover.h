@@ -55,7 +55,9 @@ typedef enum {
     VPBS_OPT_GATE_ITEMS = 2,      /* 1..8 (default 5): work items per point tile of the one-launch gate kernel.          VPBS_GATE_ITEMS     */
     VPBS_OPT_WIDE_THRESHOLD = 3,  /* launches with at most this many independent permutations use the 16-lane Poseidon
                                      form (default 2^14).                                                                VPBS_WIDE_THRESHOLD */
-    VPBS_OPT_MERKLE_CLIMB = 4     /* 1 (default): the upper levels of a tree in fused multi-level launches; 0: per level. VPBS_MERKLE_CLIMB  */
+    VPBS_OPT_MERKLE_CLIMB = 4,    /* 1 (default): the upper levels of a tree in fused multi-level launches; 0: per level. VPBS_MERKLE_CLIMB  */
+    VPBS_OPT_GATES_TILE = 5       /* 1 (default): the one-launch gate kernel stages a 64-point tile of every column in LDS and its eight
+                                     waves share the gates; 0: the (tile x item) kernel that leaves the re-reads to the caches.  VPBS_GATES_TILE */
 } vpbs_option;
 int vpbs_ctx_set_option(vpbs_ctx* ctx, int option, uint64_t value);
 int vpbs_ctx_get_option(const vpbs_ctx* ctx, int option, uint64_t* value_out);

@@ -33,10 +33,11 @@ def main():
     alphas = [int(x) for x in rng.integers(0, api.P, size=2, dtype=np.uint64)]
     res = {}
     sets = [(g if isinstance(g, str) else g[0], ["noop", g]) for g in ALL[1:]] + [("all_14", ALL), ("cyclic_13", CYCLIC)]
-    for lanes in (1, 3):
+    for lanes, tile in ((1, 1), (3, 1), (1, 0)):
         ctx.set_gate_lanes(lanes)
+        ctx.set_option("gates_tile", tile)
         for name, spec in sets:
-            if lanes == 3 and not name.startswith(("all", "cyclic")):
+            if (lanes == 3 or tile == 0) and not name.startswith(("all", "cyclic")):
                 continue
             ps = api.GateSet(spec)
             consts = rng.integers(0, api.P, size=(ps.num_selectors + ps.num_constants, n), dtype=np.uint64)
@@ -51,7 +52,7 @@ def main():
             rep = ctx.timing_report()
             ctx.timing_enable(0)
             t = sum(v["ms"] for k, v in rep.items()) / reps
-            res["%s%s" % (name, "" if lanes == 1 else "_3lanes")] = round(1e3 * t, 1)
+            res["%s%s%s" % (name, "" if lanes == 1 else "_3lanes", "" if tile else "_tile_x_item_kernel")] = round(1e3 * t, 1)
             cs.free()
     print(json.dumps({"log_n": log_n, "points": 8 * n, "us_per_call": res}))
 

@@ -923,7 +923,7 @@ class Context:
         """3 (default): gate-constraint kernels over three streams (best single-chain latency); 1: one stream (multi-chain throughput)"""
         self._check(lib().vpbs_ctx_set_gate_lanes(self.h, lanes))
 
-    OPTIONS = {"gate_lanes": 0, "gates_fused": 1, "gate_items": 2, "wide_threshold": 3, "merkle_climb": 4}
+    OPTIONS = {"gate_lanes": 0, "gates_fused": 1, "gate_items": 2, "wide_threshold": 3, "merkle_climb": 4, "gates_tile": 5}
 
     def set_option(self, name, value):
         """vpbs_ctx_set_option: a launch heuristic of this context (never changes a result); names: Context.OPTIONS"""

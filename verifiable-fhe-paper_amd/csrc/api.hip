@@ -322,6 +322,7 @@ int vpbs_ctx_set_option(vpbs_ctx* c, int option, uint64_t value) {
             return VPBS_OK;
         case VPBS_OPT_WIDE_THRESHOLD: c->tune.wide_threshold = (size_t)value; return VPBS_OK;
         case VPBS_OPT_MERKLE_CLIMB: c->tune.merkle_climb = value != 0; return VPBS_OK;
+        case VPBS_OPT_GATES_TILE: c->tune.gates_tile = value != 0; return VPBS_OK;
         default: return VPBS_ERR_INVALID;
     }
 }
@@ -333,6 +334,7 @@ int vpbs_ctx_get_option(const vpbs_ctx* c, int option, uint64_t* out) {
         case VPBS_OPT_GATE_ITEMS: *out = c->tune.gate_items; return VPBS_OK;
         case VPBS_OPT_WIDE_THRESHOLD: *out = c->tune.wide_threshold; return VPBS_OK;
         case VPBS_OPT_MERKLE_CLIMB: *out = c->tune.merkle_climb; return VPBS_OK;
+        case VPBS_OPT_GATES_TILE: *out = c->tune.gates_tile; return VPBS_OK;
         default: return VPBS_ERR_INVALID;
     }
 }

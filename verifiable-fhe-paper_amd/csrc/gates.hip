@@ -10,6 +10,7 @@
 // into out[challenge][point].  The constraints of different gates share constraint indices (plonky2 adds them: at most one
 // filter is non-zero on a trace row), hence the accumulation.  HBM traffic: each gate reads only its own wires once.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -83,7 +84,7 @@ template <int NC> struct DevSinkT {
 
 // PoseidonMdsGate on the GPU: the MDS acts on the two components of the algebra elements separately, so it is two runs of the
 // hashing kernels' multiply-add MDS layer (poseidon.h) instead of 2 x 156 modular multiplications by MDS entries.
-template <class DevSink> __device__ __forceinline__ void poseidon_mds_dev(const DevVars& v, DevSink& s) {
+template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_mds_dev(const Vars& v, DevSink& s) {
     u64 a[12], b[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -102,7 +103,7 @@ template <class DevSink> __device__ __forceinline__ void poseidon_mds_dev(const 
 // PoseidonGate on the GPU (same constraints, same order as gates::eval_poseidon): the hashing kernels' round functions with the
 // S-box inputs swapped for the gate's wires -- paired S-boxes, multiply-add MDS with the next round's constants folded in, and the
 // 22 partial rounds as 7 fused groups of three (one dense M^3 pass per group, poseidon.h) + 1.
-template <class DevSink> __device__ __forceinline__ void poseidon_gate_dev(const DevVars& v, DevSink& s) {
+template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_gate_dev(const Vars& v, DevSink& s) {
     using poseidon::rc;
     const u64 swap = v.wire(24);
     s.push(gl::mul(swap, gl::sub(swap, 1)));
@@ -171,7 +172,103 @@ template <class DevSink> __device__ __forceinline__ void poseidon_gate_dev(const
     for (int i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), gl::canon(st[i])));
 }
 
-template <unsigned KIND, class DevSink> __device__ __forceinline__ void eval_kind(const vpbs_gate& g, const gates::CosetTables& t, const DevVars& v, DevSink& s) {
+// The PoseidonGate in independent pieces (the one-launch tile kernel gives them to different waves): every full round's S-box inputs are
+// wires, so a stretch of rounds between two such wire sets needs nothing from the rounds before it.  PART 1: the S-box wires of round 3 ->
+// S-box, MDS, the 22 partial rounds -> the S-box wires of round 26 (constraints 41..74); PART 2: swap / delta constraints, rounds 0..2
+// against the S-box wires of rounds 1..3 (constraints 0..40); PART 3: rounds 26..29 and the outputs (constraints 75..122).  Same values, same
+// constraint indices (the sink's index is set to the piece's first constraint) as poseidon_gate_dev.
+template <int PART, class Vars, class DevSink> __device__ __forceinline__ void poseidon_gate_part(const Vars& v, DevSink& s) {
+    using poseidon::rc;
+    u64 st[12];
+    if constexpr (PART == 2) {
+        s.idx = 0;
+        const u64 swap = v.wire(24);
+        s.push(gl::mul(swap, gl::sub(swap, 1)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u64 lhs = v.wire(i), rhs = v.wire(i + 4), delta = v.wire(25 + i);
+            s.push(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+            st[i] = gl::add(lhs, delta);
+            st[i + 4] = gl::sub(rhs, delta);
+        }
+#pragma unroll
+        for (int i = 8; i < 12; ++i) st[i] = v.wire(i);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], rc(i));
+        for (int r = 0; r < 3; ++r) {   // round r: S-box, MDS + constants of round r + 1, compared with the S-box wires of round r + 1
+            u64 kc[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) kc[i] = rc(12 * (r + 1) + i);
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) poseidon::sbox2(st[i], st[i + 1]);
+            poseidon::mds_add_const(st, kc);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const u64 in = v.wire(29 + 12 * r + i);
+                s.push(gl::sub(gl::canon(st[i]), in));
+                st[i] = in;
+            }
+        }
+    }
+    if constexpr (PART == 1) {
+        s.idx = 41;
+        {
+            u64 kc[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                kc[i] = rc(12 * 4 + i);
+                st[i] = v.wire(29 + 24 + i);   // the S-box wires of round 3
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) poseidon::sbox2(st[i], st[i + 1]);
+            poseidon::mds_add_const(st, kc);
+        }
+        for (int g = 0; g < 7; ++g) {  // partial rounds 0..20
+            u64 w[3], x[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = v.wire(65 + 3 * g + i);
+            s.push(gl::sub(gl::canon(st[0]), w[0]));
+            poseidon::partial_group3_core<true>(st, g, w, x);
+            s.push(gl::sub(x[0], w[1]));
+            s.push(gl::sub(x[1], w[2]));
+        }
+        {  // partial round 21
+            u64 kc[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) kc[i] = rc(12 * 26 + i);
+            const u64 in = v.wire(65 + 21);
+            s.push(gl::sub(gl::canon(st[0]), in));
+            st[0] = poseidon::sbox(in);
+            poseidon::mds_add_const(st, kc);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s.push(gl::sub(gl::canon(st[i]), v.wire(87 + i)));
+    }
+    if constexpr (PART == 3) {
+        s.idx = 75;
+        for (int r = 0; r < 4; ++r) {  // round 26 + r from its S-box wires; compared with the next round's wires, the last with the outputs
+            u64 kc[12];
+            const int next = r < 3 ? 12 * (27 + r) : 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                kc[i] = rc(next + i);
+                st[i] = v.wire(87 + 12 * r + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) poseidon::sbox2(st[i], st[i + 1]);
+            poseidon::mds_add_const(st, r < 3 ? kc : nullptr);
+            if (r < 3) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s.push(gl::sub(gl::canon(st[i]), v.wire(87 + 12 * (r + 1) + i)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), gl::canon(st[i])));
+    }
+}
+
+template <unsigned KIND, class Vars, class DevSink>
+__device__ __forceinline__ void eval_kind(const vpbs_gate& g, const gates::CosetTables& t, const Vars& v, DevSink& s) {
     if constexpr (KIND == VPBS_GATE_CONSTANT) gates::eval_constant<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_PUBLIC_INPUT) gates::eval_public_input<u64>(g, v, s);
     if constexpr (KIND == VPBS_GATE_ARITHMETIC) gates::eval_arithmetic<u64>(g, v, s);
@@ -288,6 +385,114 @@ gate_fused_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts,
 #pragma unroll
     for (int a = 0; a < NC; ++a)
         if ((unsigned)a < nc) out[((size_t)item * nc + a) * len + j] = total[a];
+}
+
+// ---- all gates in ONE launch, the tile's columns staged in LDS (the default path) ----
+// The (tile x item) kernel above leaves the re-reads of a tile's columns to the caches: the counters show 4.7 x the algorithmic bytes leaving
+// the XCDs' L2 and the waves waiting on memory 43 % of their cycles.  Here a workgroup of eight waves owns 64 LDE points: it copies the
+// 135 wire values and the selector / gate-constant values of those points into LDS ONCE (coalesced 512-byte rows, [column][64]), and
+// after one barrier every wave evaluates ITS share of the gates for the same 64 points out of LDS (ds_read_b64 at constant offsets: no
+// address arithmetic, ~100 cycles instead of a trip to L2 / HBM).  The shares are balanced by weight; the PoseidonGate -- a third of the
+// work -- is cut into three independent pieces (poseidon_gate_part).  The waves' sums are added through LDS and ONE plane is written.
+// HBM traffic = the algorithmic bytes; 73 KB of LDS per workgroup, two workgroups per CU = 4 waves per SIMD.
+constexpr unsigned TILE_PTS = 64, TILE_WAVES = 8, TILE_MAX_COLS = 135 + 8, TILE_MAX_UNITS = FUSED_MAX_GATES + 2;
+struct TilePlan {
+    vpbs_gate gates[TILE_MAX_UNITS];   // work units ordered by wave
+    uint8_t part[TILE_MAX_UNITS];      // 0: the whole gate; 1..3: a piece of the PoseidonGate
+    gates::CosetTables tables;
+    unsigned wave_first[TILE_WAVES + 1];
+    unsigned n_wires, n_consts;        // columns staged: wires [0, n_wires), then constants_sigmas columns [0, n_consts)
+};
+struct LdsVars {
+    using F = u64;
+    const u64* lds;    // [n_wires + n_consts][64], this lane's column of it
+    unsigned n_wires, first_const;   // first_const: LDS column of the first gate constant (n_wires + num_selectors)
+    PiHash pih;
+    __device__ __forceinline__ u64 wire(unsigned i) const { return lds[i * TILE_PTS]; }
+    __device__ __forceinline__ u64 constant(unsigned i) const { return lds[(first_const + i) * TILE_PTS]; }
+    __device__ __forceinline__ u64 pi_hash(unsigned i) const { return pih.h[i]; }
+};
+template <int NC>
+__global__ void __launch_bounds__(TILE_PTS * TILE_WAVES, 4)
+gate_tile_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, TilePlan plan, unsigned num_selectors,
+                 const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out,
+                 unsigned long long* __restrict__ prof /* VPBS_TRACE_GATES: shader cycles per work unit, [TILE_MAX_UNITS]; else nullptr */) {
+    __shared__ u64 lds[TILE_MAX_COLS * TILE_PTS];
+    const unsigned lane = threadIdx.x & (TILE_PTS - 1), wave = threadIdx.x / TILE_PTS;
+    const size_t j = (size_t)blockIdx.x * TILE_PTS + lane;
+    // stage the tile: wave w copies columns w, w + 8, ... -- six 512-byte rows requested before the first is written to LDS, so that a
+    // wave pays three memory round trips for its 18 columns, not eighteen
+    {
+        constexpr unsigned IN_FLIGHT = 6;
+        const unsigned n_cols = plan.n_wires + plan.n_consts;
+        for (unsigned c0 = wave; c0 < n_cols; c0 += TILE_WAVES * IN_FLIGHT) {
+            u64 t[IN_FLIGHT];
+#pragma unroll
+            for (unsigned k = 0; k < IN_FLIGHT; ++k) {
+                const unsigned c = c0 + TILE_WAVES * k;
+                t[k] = c >= n_cols ? 0 : (c < plan.n_wires ? wires[(size_t)c * len + j] : consts[(size_t)(c - plan.n_wires) * len + j]);
+            }
+#pragma unroll
+            for (unsigned k = 0; k < IN_FLIGHT; ++k) {
+                const unsigned c = c0 + TILE_WAVES * k;
+                if (c < n_cols) lds[c * TILE_PTS + lane] = t[k];
+            }
+        }
+    }
+    __syncthreads();
+    u64 total[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) total[a] = 0;
+    for (unsigned u = plan.wave_first[wave]; u < plan.wave_first[wave + 1]; ++u) {
+        const vpbs_gate& g = plan.gates[u];
+        const unsigned long long t_unit = prof ? __builtin_amdgcn_s_memtime() : 0;
+        const u64* base = lds + lane;
+        asm volatile("" : "+v"(base));   // opaque per unit: keeps the cases' LDS addresses from being hoisted and kept live across all of them
+        LdsVars v{base, plan.n_wires, plan.n_wires + num_selectors, pih};
+        DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
+        if (g.kind == VPBS_GATE_POSEIDON && plan.part[u]) {
+            switch (plan.part[u]) {
+                case 1: poseidon_gate_part<1>(v, s); break;
+                case 2: poseidon_gate_part<2>(v, s); break;
+                default: poseidon_gate_part<3>(v, s); break;
+            }
+        } else {
+            switch (g.kind) {  // wave-uniform
+#define VPBS_TILE_CASE(K) case K: eval_kind<K>(g, plan.tables, v, s); break;
+                VPBS_TILE_CASE(VPBS_GATE_CONSTANT)
+                VPBS_TILE_CASE(VPBS_GATE_PUBLIC_INPUT)
+                VPBS_TILE_CASE(VPBS_GATE_ARITHMETIC)
+                VPBS_TILE_CASE(VPBS_GATE_BASE_SUM)
+                VPBS_TILE_CASE(VPBS_GATE_POSEIDON)
+                VPBS_TILE_CASE(VPBS_GATE_POSEIDON_MDS)
+                VPBS_TILE_CASE(VPBS_GATE_ARITHMETIC_EXT)
+                VPBS_TILE_CASE(VPBS_GATE_MUL_EXT)
+                VPBS_TILE_CASE(VPBS_GATE_REDUCING)
+                VPBS_TILE_CASE(VPBS_GATE_REDUCING_EXT)
+                VPBS_TILE_CASE(VPBS_GATE_RANDOM_ACCESS)
+                VPBS_TILE_CASE(VPBS_GATE_EXPONENTIATION)
+                VPBS_TILE_CASE(VPBS_GATE_COSET_INTERPOLATION)
+#undef VPBS_TILE_CASE
+                default: break;
+            }
+        }
+        const u64 filter = gates::compute_filter<u64>(g, base[(plan.n_wires + g.selector_index) * TILE_PTS], num_selectors > 1);
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if ((unsigned)a < nc) total[a] = gl::add(total[a], gl::mul(filter, s.acc[a].reduce()));
+        if (prof && lane == 0) atomicAdd(prof + u, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_unit) + (total[0] & 0));
+    }
+    // the waves' sums: through LDS (the tile is not needed any more), added by the first nc waves
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+        if ((unsigned)a < nc) lds[(wave * NC + a) * TILE_PTS + lane] = total[a];
+    __syncthreads();
+    if (wave < nc) {
+        u64 r = lds[wave * TILE_PTS + lane];   // wave 0's sum for challenge `wave`
+        for (unsigned w = 1; w < TILE_WAVES; ++w) r = gl::add(r, lds[(w * NC + wave) * TILE_PTS + lane]);
+        out[(size_t)wave * len + j] = r;
+    }
 }
 
 __global__ void sum_planes_kernel(const u64* __restrict__ planes, unsigned n_planes, size_t words, u64* __restrict__ out) {
@@ -520,18 +725,137 @@ static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, unsigned max_
     return true;
 }
 
-unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates, unsigned max_items) {
+// Work units of the LDS-tile kernel: every gate with constraints, the PoseidonGate as three pieces, packed heaviest first into the eight
+// waves of a workgroup.  False when the gate set does not fit (too many gates, two CosetInterpolationGates, more constant columns than
+// the tile holds).
+// Relative cost of a gate's constraints in the tile kernel: microseconds of a launch over 2^19 points in which ONE wave per workgroup
+// evaluates that gate alone (tools/time_gates.py, staging time subtracted) -- a lone wave runs at its dependent-instruction latency, so the
+// figure follows the instruction count (~0.07 per instruction) -- scaled by the gate's parameters.  TILE_UNIT_COST: what every work unit
+// carries besides (selector filter, the reductions of the lazily folded sums, dispatch: ~700 instructions).  (The s_memtime spans that
+// VPBS_TRACE_GATES prints are NOT such a measure: a wave's span stretches with whatever shares its SIMD.)
+constexpr double TILE_UNIT_COST = 50;
+static double tile_weight(const vpbs_gate& g) {
+    switch (g.kind) {
+        case VPBS_GATE_ARITHMETIC: return 8.0 * g.p0;
+        case VPBS_GATE_BASE_SUM: return 8.0 * g.p0 * (g.p1 - 1);
+        case VPBS_GATE_POSEIDON_MDS: return 60;
+        case VPBS_GATE_ARITHMETIC_EXT: return 17.0 * g.p0;
+        case VPBS_GATE_MUL_EXT: return 13.5 * g.p0;
+        case VPBS_GATE_REDUCING: return 10.5 * g.p0;
+        case VPBS_GATE_REDUCING_EXT: return 11.7 * g.p0;
+        case VPBS_GATE_RANDOM_ACCESS: return 235.0 * g.p1 * (1u << g.p0) / 64;
+        case VPBS_GATE_EXPONENTIATION: return 8.0 * g.p0;
+        case VPBS_GATE_COSET_INTERPOLATION: return 13.4 * (1u << g.p0);
+        default: return 0.5 * g.num_constraints;
+    }
+}
+static bool make_tile_plan(const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors, TilePlan& plan) {
+    struct Unit {
+        unsigned gate, part;
+        double weight;
+    };
+    std::vector<Unit> units;
+    unsigned n_coset = 0, max_consts = 0, n_wires = 0;
+    for (unsigned i = 0; i < n_gates; ++i) {
+        if (!gs[i].num_constraints) continue;
+        max_consts = std::max(max_consts, gs[i].num_constants);
+        n_wires = std::max(n_wires, gs[i].num_wires);
+        if (gs[i].kind == VPBS_GATE_POSEIDON) {   // the three pieces: 7.5 k / 4.7 k / 6.0 k of the gate's 18 k instructions
+            units.push_back({i, 1, 510 + TILE_UNIT_COST});
+            units.push_back({i, 2, 298 + TILE_UNIT_COST});
+            units.push_back({i, 3, 404 + TILE_UNIT_COST});
+            continue;
+        }
+        if (gs[i].kind == VPBS_GATE_COSET_INTERPOLATION) {
+            if (n_coset++) return false;
+            plan.tables = gates::coset_tables(gs[i].p0);
+        }
+        units.push_back({i, 0, tile_weight(gs[i]) + TILE_UNIT_COST});
+    }
+    if (units.empty() || units.size() > TILE_MAX_UNITS || n_wires > 135 || n_wires + num_selectors + max_consts > TILE_MAX_COLS) return false;
+    // heaviest first onto the lightest wave.  (Cutting the loop gates -- BaseSum, Reducing, ... -- into iteration ranges to level the
+    // waves exactly was built and measured: the run-time loop bounds cost the evaluators 6 % and every extra unit its fixed cost, more than
+    // the better balance returned: 995-1050 us against 939 us for the cyclic circuit's gate set.)
+    std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.weight > b.weight; });
+    std::vector<std::vector<Unit>> bins(TILE_WAVES);
+    double load[TILE_WAVES] = {0};
+    for (const Unit& u : units) {
+        const unsigned b = (unsigned)(std::min_element(load, load + TILE_WAVES) - load);
+        bins[b].push_back(u);
+        load[b] += u.weight;
+    }
+    unsigned k = 0;
+    for (unsigned w = 0; w < TILE_WAVES; ++w) {
+        plan.wave_first[w] = k;
+        for (const Unit& u : bins[w]) {
+            plan.gates[k] = gs[u.gate];
+            plan.part[k] = (uint8_t)u.part;
+            ++k;
+        }
+    }
+    plan.wave_first[TILE_WAVES] = k;
+    plan.n_wires = n_wires;
+    plan.n_consts = num_selectors + max_consts;
+    static const bool trace = getenv("VPBS_TRACE_GATES") != nullptr;
+    if (trace) {
+        for (unsigned w = 0; w < TILE_WAVES; ++w) {
+            std::fprintf(stderr, "[gate tile] wave %u load %.0f:", w, load[w]);
+            for (const Unit& u : bins[w]) std::fprintf(stderr, " kind %u part %u", gs[u.gate].kind, u.part);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    return true;
+}
+
+unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates, unsigned num_selectors, const Tuning& tune, size_t len) {
+    if (tune.gates_tile && len % TILE_PTS == 0) {
+        TilePlan tp{};
+        if (make_tile_plan(gs, n_gates, num_selectors, tp)) return 1;
+    }
     FusedPlan plan{};
-    return make_fused_plan(gs, n_gates, max_items, plan) ? plan.n_items : 0;
+    return make_fused_plan(gs, n_gates, tune.gate_items, plan) ? plan.n_items : 0;
 }
 
 // d_planes: [n_items][nc][len]; returns the number of planes written (0: the gate set does not fit the one-launch path, nothing launched)
-unsigned launch_gate_terms_fused(hipStream_t s, unsigned max_items, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs,
+unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs,
                                  unsigned n_gates, unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc,
                                  u64* d_planes) {
+    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+    if (tune.gates_tile && len % TILE_PTS == 0) {
+        TilePlan tp{};
+        if (make_tile_plan(gs, n_gates, num_selectors, tp)) {
+            const dim3 grid((unsigned)(len / TILE_PTS)), block(TILE_PTS * TILE_WAVES);
+            static const bool trace = getenv("VPBS_TRACE_GATES") != nullptr;
+            unsigned long long* prof = nullptr;
+            if (trace) {   // development aid: the shader cycles every work unit really takes inside the loaded kernel (what tile_weight approximates)
+                (void)hipMalloc(&prof, sizeof(unsigned long long) * TILE_MAX_UNITS);
+                (void)hipMemsetAsync(prof, 0, sizeof(unsigned long long) * TILE_MAX_UNITS, s);
+            }
+            if (nc <= 2)
+                hipLaunchKernelGGL((gate_tile_kernel<2>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof);
+            else
+                hipLaunchKernelGGL((gate_tile_kernel<4>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof);
+            if (trace) {
+                unsigned long long h[TILE_MAX_UNITS];
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h, prof, sizeof h, hipMemcpyDeviceToHost);
+                (void)hipFree(prof);
+                for (unsigned w = 0; w < TILE_WAVES; ++w) {
+                    unsigned long long sum = 0;
+                    std::fprintf(stderr, "[gate tile cycles] wave %u:", w);
+                    for (unsigned u = tp.wave_first[w]; u < tp.wave_first[w + 1]; ++u) {
+                        std::fprintf(stderr, " kind %u part %u %.0f", tp.gates[u].kind, tp.part[u], (double)h[u] / grid.x);
+                        sum += h[u];
+                    }
+                    std::fprintf(stderr, "  total %.0f\n", (double)sum / grid.x);
+                }
+            }
+            return 1;
+        }
+    }
+    const unsigned max_items = tune.gate_items;
     FusedPlan plan{};
     if (!make_fused_plan(gs, n_gates, max_items, plan)) return 0;
-    PiHash pih{{pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
     const unsigned n_tiles = (unsigned)((len + FUSED_TILE - 1) / FUSED_TILE);
     const int xcd_map = n_tiles % 8 == 0;
     const dim3 grid(n_tiles * plan.n_items);

@@ -228,6 +228,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("VPBS_MERKLE_CLIMB")) t.merkle_climb = atoi(e) != 0;
     if (const char* e = getenv("VPBS_GATES_FUSED")) t.gates_fused = atoi(e) != 0;
     if (const char* e = getenv("VPBS_GATE_ITEMS")) t.gate_items = (unsigned)std::max(1, atoi(e));
+    if (const char* e = getenv("VPBS_GATES_TILE")) t.gates_tile = atoi(e) != 0;
     return t;
 }
 

@@ -63,6 +63,18 @@ void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u
 void launch_quotient_finish(hipStream_t s, const u64* q_gathered, size_t local_len, const u64* inv_roots_big, const u64* unshift_table,
                             unsigned log_n, unsigned rate_bits, unsigned nc, u64* q_nat, u64* scratch, u64* out_coeffs);
 
+// Launch heuristics of one context (vpbs_ctx_set_option; the environment variables of the same names are only the DEFAULTS a context is
+// created with: VPBS_WIDE_THRESHOLD, VPBS_MERKLE_CLIMB, VPBS_GATES_FUSED, VPBS_GATE_ITEMS, VPBS_GATE_LANES)
+struct Tuning {
+    size_t wide_threshold = (size_t)1 << 14;   // launches with at most this many independent permutations use the 16-lane Poseidon form
+    size_t fri_leaf_wide_threshold = (size_t)1 << 14;   // the same for the FRI round leaves (several dependent permutations per leaf)
+    bool merkle_climb = true;                  // the latency-bound upper levels of a tree in fused multi-level launches
+    bool gates_fused = true;                   // all gate constraints in one launch (false: one launch per gate type)
+    unsigned gate_items = 5;                   // work items per point tile of the (tile x item) one-launch gate kernel
+    bool gates_tile = true;                    // the one-launch gate kernel that stages a 64-point tile of every column in LDS
+    static Tuning from_env();
+};
+
 // ---------- gates.hip ----------
 // evaluate_gate_constraints_base_batch folded with the alphas: d_out[a][j] = sum_i alpha_a^i sum_g filter_g(j) c_{g,i}(j) for the
 // `len` local leaves of the wires / constants LDEs (column stride len).  d_apow: [nc][pow_stride] powers of the alphas,
@@ -86,8 +98,9 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
 // The same sum in ONE launch over (point tile x work item) with an XCD-aware block numbering (gates.hip): every item writes its own plane
 // d_planes[item][nc][len]; the sum over the planes is the value launch_gate_terms would produce.  gate_terms_planes: how many planes the gate
 // set needs (0 = not supported by this path, use launch_gate_terms).
-unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates, unsigned max_items);
-unsigned launch_gate_terms_fused(hipStream_t s, unsigned max_items, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
+// With tune.gates_tile (default) and len a multiple of 64: the LDS-tile kernel, one plane (gates.hip); otherwise the (tile x item) kernel.
+unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, const Tuning& tune, size_t len);
+unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                                  unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes);
 void launch_sum_planes(hipStream_t s, const u64* d_planes, unsigned n_planes, size_t words, u64* d_out);
 // throws DeviceError(VPBS_ERR_INVALID) unless the gate list fits batches with these column counts
@@ -103,17 +116,6 @@ void gate_terms_at(const vpbs_gate* gates, unsigned n_gates, unsigned num_select
 void launch_blind_rotate_step(hipStream_t s, const u64* acc_in, const u64* masks, const u64* ggsw, size_t ggsw_instance_stride,
                               const u64* roots, const u64* invroots, u64 ninv, unsigned log_n, unsigned K, unsigned ELL, unsigned LOGB,
                               unsigned batch, int first_step, int last_step, u64* limbs_hat, u64* acc_out);
-
-// Launch heuristics of one context (vpbs_ctx_set_option; the environment variables of the same names are only the DEFAULTS a context is
-// created with: VPBS_WIDE_THRESHOLD, VPBS_MERKLE_CLIMB, VPBS_GATES_FUSED, VPBS_GATE_ITEMS, VPBS_GATE_LANES)
-struct Tuning {
-    size_t wide_threshold = (size_t)1 << 14;   // launches with at most this many independent permutations use the 16-lane Poseidon form
-    size_t fri_leaf_wide_threshold = (size_t)1 << 14;   // the same for the FRI round leaves (several dependent permutations per leaf)
-    bool merkle_climb = true;                  // the latency-bound upper levels of a tree in fused multi-level launches
-    bool gates_fused = true;                   // all gate constraints in one launch (false: one launch per gate type)
-    unsigned gate_items = 5;                   // work items per point tile of the one-launch gate kernel
-    static Tuning from_env();
-};
 
 // ---------- hash.hip ----------
 // digests[j] = hash_or_noop(leaf j), leaf j = lde[c][j] over c (column-major LDE, leaf-order index)

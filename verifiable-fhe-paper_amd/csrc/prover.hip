@@ -359,14 +359,14 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
     const bool multi = ctx->gate_lanes == 3;
     const size_t len = wires->lde_len();
     u64* lane_buf = nullptr;
-    const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gs, n_gates, ctx->tune.gate_items) : 0;
+    const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gs, n_gates, num_selectors, ctx->tune, len) : 0;
     if (n_planes) {  // one launch over (tile x item), then the sum of the items' planes
         u64* planes = nullptr;
         try {
             planes = ctx->alloc_words((size_t)n_planes * nc * len);
             VPBS_HIP(hipMemcpyAsync(d_apow, h_apow.data(), sizeof(u64) * h_apow.size(), hipMemcpyHostToDevice, ctx->stream));
             Timed t(ctx, "gate_constraints");
-            vpbs::launch_gate_terms_fused(ctx->stream, ctx->tune.gate_items, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, planes);
+            vpbs::launch_gate_terms_fused(ctx->stream, ctx->tune, wires->d_lde, cs->d_lde, len, gs, n_gates, num_selectors, pi_hash, d_apow, stride, nc, planes);
             vpbs::launch_sum_planes(ctx->stream, planes, n_planes, (size_t)nc * len, d_out);
             VPBS_HIP(hipGetLastError());
         } catch (...) {
@@ -481,7 +481,7 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                 }
             }
             d_gpow = ctx->alloc_words(h_gpow.size());
-            const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gw->gates, gw->n_gates, ctx->tune.gate_items) : 0;
+            const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gw->gates, gw->n_gates, gw->num_selectors, ctx->tune, local_len) : 0;
             lane_buf = ctx->alloc_words(std::max(3u, n_planes) * (size_t)nc * local_len);
             VPBS_HIP(hipMemcpyAsync(d_gpow, h_gpow.data(), sizeof(u64) * h_gpow.size(), hipMemcpyHostToDevice, s));
             ctx->ensure_gate_lanes();
@@ -497,7 +497,7 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                                              ctx->roots(log_big, false), l0, nullptr, d_apow, betas, gammas, n_routed, log_n, rate_bits, max_degree, nc,
                                              leaf_offset, local_len, q_local, true);
                 VPBS_HIP(hipEventRecord(ctx->gate_join[0], ctx->gate_streams[0]));
-                vpbs::launch_gate_terms_fused(s, ctx->tune.gate_items, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride,
+                vpbs::launch_gate_terms_fused(s, ctx->tune, wires->d_lde, cs->d_lde, local_len, gw->gates, gw->n_gates, gw->num_selectors, gw->pi_hash, d_gpow, stride,
                                               nc, lane_buf);
                 VPBS_HIP(hipStreamWaitEvent(s, ctx->gate_join[0], 0));
                 vpbs::launch_quotient_combine_planes(s, q_local, lane_buf, n_planes, apow_last, log_n, rate_bits, nc, leaf_offset, local_len);
