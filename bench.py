@@ -128,7 +128,6 @@ def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     ctxs = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in ctxs]
     for c in ctxs:
-        c.set_gate_lanes(1 if provers > 1 else 3)
     n_buf = witness_threads + provers + 1
     bufs = [torch.empty((135, b.n), dtype=torch.int64).pin_memory() for _ in range(n_buf)]
     views = [t.numpy().view(np.uint64) for t in bufs]
@@ -248,7 +247,6 @@ def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
     pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
     for c in pctx:
-        c.set_gate_lanes(1 if provers > 1 else 3)
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda:%d" % device) for _ in range(provers)]
     rng = np.random.default_rng(4048)
     base = rng.integers(0, synth.P, size=len(targets), dtype=np.uint64)
@@ -855,7 +853,6 @@ def measure_step(args, rank, local_rank, world, distributed, log_n):
             extra.append((cx, cx.make_step_inputs(log_n, dv["wires"].data_ptr(), None, None, csb, digest, pi2,
                                                   on_device=True, shapes=(COLS["wires"], COLS["zs_partial_products"], COLS["quotient"]),
                                                   sigmas=sp, n_routed=N_ROUTED, n_constants=N_CONSTANTS, gates=gates), dv, csb, pi2))
-        ctxs[0].set_gate_lanes(1)   # batch mode: one stream per chain
         ctxs += [e[0] for e in extra]; sis += [e[1] for e in extra]
         n_chains = len(ctxs)
         run_steps(1)
@@ -868,7 +865,6 @@ def measure_step(args, rank, local_rank, world, distributed, log_n):
                         "vpbs_proofs_per_s": args.steps * n_chains / eb / STEPS_PER_VPBS,
                         "ms_per_step_proof": eb / (args.steps * n_chains) * 1e3}
         n_chains = 1
-        ctxs[0].set_gate_lanes(3)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")

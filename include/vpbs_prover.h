@@ -42,15 +42,15 @@ int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, 
 void vpbs_ctx_destroy(vpbs_ctx* ctx);
 const char* vpbs_last_error(const vpbs_ctx* ctx);
 int vpbs_ctx_synchronize(vpbs_ctx* ctx);
-/* Streams used for the gate-constraint kernels of a step proof: 3 (default) overlaps the VALU-bound PoseidonGate kernel with the
- * HBM-bound gates (-18 % on that stage, best latency for one chain); 1 keeps them on the context's stream, which is slightly better
- * for throughput when several contexts already keep the device busy (-2 % with three chains otherwise). */
+/* Streams used for the gate-constraint stage of a step proof: 1 (default) keeps the gate kernel and the permutation part of the quotient on
+ * the context's stream -- right for the LDS-tile gate kernel, whose workgroups fill a CU by themselves; 3 spreads the per-gate launches and
+ * the permutation part over two helper streams (the better arrangement for VPBS_OPT_GATES_FUSED = 0 / VPBS_OPT_GATES_TILE = 0). */
 int vpbs_ctx_set_gate_lanes(vpbs_ctx* ctx, unsigned lanes);
 void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share device buffers with the ctx */
 /* Launch heuristics of a context.  Every option has an environment variable of the same meaning that only sets the DEFAULT a new context
  * starts with (read at vpbs_ctx_create); results never depend on any of them -- they choose between bit-identical kernel arrangements. */
 typedef enum {
-    VPBS_OPT_GATE_LANES = 0,      /* 1 | 3: streams of the gate-constraint stage (= vpbs_ctx_set_gate_lanes).            VPBS_GATE_LANES     */
+    VPBS_OPT_GATE_LANES = 0,      /* 1 (default) | 3: streams of the gate-constraint stage (= vpbs_ctx_set_gate_lanes).  VPBS_GATE_LANES     */
     VPBS_OPT_GATES_FUSED = 1,     /* 1 (default): all gate constraints in one launch; 0: one launch per gate type.       VPBS_GATES_FUSED    */
     VPBS_OPT_GATE_ITEMS = 2,      /* 1..8 (default 5): work items per point tile of the one-launch gate kernel.          VPBS_GATE_ITEMS     */
     VPBS_OPT_WIDE_THRESHOLD = 3,  /* launches with at most this many independent permutations use the 16-lane Poseidon

@@ -391,7 +391,7 @@ def test_gate_lanes_setting_does_not_change_the_proof(ctx):
     for lanes in (3, 1, 3):
         ctx.set_gate_lanes(lanes)
         proofs.append(ctx.prove_step(si))
-    ctx.set_gate_lanes(3)
+    ctx.set_gate_lanes(1)   # the default
     for key in ("caps", "openings", "fri"):
         assert (proofs[0][key] == proofs[1][key]).all() and (proofs[0][key] == proofs[2][key]).all()
     with pytest.raises(api.VpbsError):

@@ -800,7 +800,7 @@ def test_context_options_choose_between_bit_identical_arrangements(ctx):
     import random
     import gates_oracle as go
     defaults = {name: ctx.get_option(name) for name in ctx.OPTIONS}
-    assert defaults == {"gate_lanes": 3, "gates_fused": 1, "gate_items": 5, "wide_threshold": 1 << 14, "merkle_climb": 1, "gates_tile": 1}
+    assert defaults == {"gate_lanes": 1, "gates_fused": 1, "gate_items": 5, "wide_threshold": 1 << 14, "merkle_climb": 1, "gates_tile": 1}
     gate_spec = ["noop", "constant", "public_input", "arithmetic", "base_sum", "poseidon", "reducing", ("random_access", 4), "coset_interpolation"]
     gs, ps = go.GateSet(gate_spec), api.GateSet(gate_spec)
     rnd = random.Random(5)
@@ -812,7 +812,7 @@ def test_context_options_choose_between_bit_identical_arrangements(ctx):
     si = ctx.make_step_inputs(log_c, wires, None, None, cs, DIGEST, cpis, sigmas=sigma, n_routed=80, n_constants=nconst, gates=ps)
     want = ctx.prove_step(si)
     try:
-        for over in ({"gates_tile": 0}, {"gates_tile": 0, "gate_lanes": 1}, {"gates_fused": 0}, {"gate_lanes": 1}, {"gates_fused": 0, "gate_lanes": 1}, {"gates_tile": 0, "gate_items": 2}, {"gates_tile": 0, "gate_items": 8}, {"merkle_climb": 0},
+        for over in ({"gates_tile": 0}, {"gates_fused": 0}, {"gate_lanes": 3}, {"gates_fused": 0, "gate_lanes": 3}, {"gates_tile": 0, "gate_lanes": 3}, {"gates_tile": 0, "gate_items": 2}, {"gates_tile": 0, "gate_items": 8}, {"merkle_climb": 0},
                      {"wide_threshold": 0}, {"wide_threshold": 1 << 30}):
             for name, v in over.items():
                 ctx.set_option(name, v)

@@ -130,7 +130,6 @@ def main():
     pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
     for c in pctx:
-        c.set_gate_lanes(1 if provers > 1 else 3)
     d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda()
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda") for _ in range(provers)]
     digest = np.array([11, 22, 33, 44], np.uint64)

@@ -920,7 +920,8 @@ class Context:
         self._check(lib().vpbs_ctx_synchronize(self.h))
 
     def set_gate_lanes(self, lanes):
-        """3 (default): gate-constraint kernels over three streams (best single-chain latency); 1: one stream (multi-chain throughput)"""
+        """1 (default): the gate-constraint stage on the context's stream (right for the LDS-tile gate kernel); 3: three streams (the
+        per-gate launches of VPBS_OPT_GATES_FUSED = 0)"""
         self._check(lib().vpbs_ctx_set_gate_lanes(self.h, lanes))
 
     OPTIONS = {"gate_lanes": 0, "gates_fused": 1, "gate_items": 2, "wide_threshold": 3, "merkle_climb": 4, "gates_tile": 5}

@@ -70,10 +70,13 @@ struct vpbs_ctx {
     hipStream_t gate_streams[2] = {nullptr, nullptr};
     hipEvent_t gate_fork = nullptr, gate_join[2] = {nullptr, nullptr};
     void ensure_gate_lanes();
-    unsigned gate_lanes = default_gate_lanes();   // 3, or 1 with VPBS_GATE_LANES=1 in the environment; vpbs_ctx_set_gate_lanes
+    // 1 (one stream): the default since the gate constraints run in the LDS-tile kernel -- its workgroups fill a CU's LDS and registers, so
+    // the permutation part gains nothing beside it (9.67 vs 9.93 ms per step proof); 3: the helper streams of rounds 1-2, still the better
+    // arrangement for the per-gate launches.  VPBS_GATE_LANES=3 in the environment makes that the default; vpbs_ctx_set_gate_lanes.
+    unsigned gate_lanes = default_gate_lanes();
     static unsigned default_gate_lanes() {
         const char* e = getenv("VPBS_GATE_LANES");
-        return e && atoi(e) == 1 ? 1u : 3u;
+        return e && atoi(e) == 3 ? 3u : 1u;
     }
 
     // ---- timing ----

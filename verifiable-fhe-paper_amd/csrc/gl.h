@@ -106,6 +106,16 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 #define GL_P01 "v[24:25]"
 #define GL_P23 "v[26:27]"
 #define GL_P45 "v[28:29]"
+#define GL_Q0 "v32"
+#define GL_Q1 "v33"
+#define GL_Q2 "v34"
+#define GL_Q3 "v35"
+#define GL_Q4 "v36"
+#define GL_Q5 "v37"
+#define GL_Q6 "v38"
+#define GL_Q01 "v[32:33]"
+#define GL_Q23 "v[34:35]"
+#define GL_Q45 "v[36:37]"
 #else
 #define GL_R0 "v80"
 #define GL_R1 "v81"
@@ -118,6 +128,16 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 #define GL_P01 "v[80:81]"
 #define GL_P23 "v[82:83]"
 #define GL_P45 "v[84:85]"
+#define GL_Q0 "v88"
+#define GL_Q1 "v89"
+#define GL_Q2 "v90"
+#define GL_Q3 "v91"
+#define GL_Q4 "v92"
+#define GL_Q5 "v93"
+#define GL_Q6 "v94"
+#define GL_Q01 "v[88:89]"
+#define GL_Q23 "v[90:91]"
+#define GL_Q45 "v[92:93]"
 #endif
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     u32 r0, r1;
@@ -200,72 +220,72 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
 // 29 VALU + 2 SALU against 2 x 16 + 8 for two products and a modular addition.
 __device__ __forceinline__ u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
     u32 r0, r1;
-    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
-        "v_mad_u64_u32 v[88:89], vcc, %6, %8, 0\n\t"
-        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
-        "v_mad_u64_u32 v[90:91], vcc, %6, %9, 0\n\t"
-        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
-        "v_mad_u64_u32 v[90:91], s[86:87], %7, %8, v[90:91]\n\t"
-        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
-        "v_mad_u64_u32 v[92:93], vcc, %7, %9, 0\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
-        "v_cndmask_b32_e64 v94, 0, 1, s[86:87]\n\t"
-        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
-        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
-        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
-        "v_add_co_u32_e32 v89, vcc, v89, v90\n\t"
-        "v_addc_co_u32_e32 v92, vcc, v92, v91, vcc\n\t"
-        "v_addc_co_u32_e32 v93, vcc, v93, v94, vcc\n\t"
-        "v_add_co_u32_e32 v80, vcc, v80, v88\n\t"
-        "v_addc_co_u32_e32 v81, vcc, v81, v89, vcc\n\t"
-        "v_addc_co_u32_e32 v84, vcc, v84, v92, vcc\n\t"
-        "v_addc_co_u32_e32 v85, vcc, v85, v93, vcc\n\t"
-        "v_addc_co_u32_e64 v86, vcc, 0, 0, vcc\n\t"
-        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
-        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
-        "v_subb_co_u32_e32 v81, vcc, v81, v86, vcc\n\t"
+    asm("v_mad_u64_u32 " GL_P01 ", vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 " GL_Q01 ", vcc, %6, %8, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 " GL_Q23 ", vcc, %6, %9, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", s[80:81], %3, %4, " GL_P23 "\n\t"
+        "v_mad_u64_u32 " GL_Q23 ", s[86:87], %7, %8, " GL_Q23 "\n\t"
+        "v_mad_u64_u32 " GL_P45 ", vcc, %3, %5, 0\n\t"
+        "v_mad_u64_u32 " GL_Q45 ", vcc, %7, %9, 0\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[80:81]\n\t"
+        "v_cndmask_b32_e64 " GL_Q6 ", 0, 1, s[86:87]\n\t"
+        "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R2 "\n\t"
+        "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_R3 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_R6 ", vcc\n\t"
+        "v_add_co_u32_e32 " GL_Q1 ", vcc, " GL_Q1 ", " GL_Q2 "\n\t"
+        "v_addc_co_u32_e32 " GL_Q4 ", vcc, " GL_Q4 ", " GL_Q3 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_Q5 ", vcc, " GL_Q5 ", " GL_Q6 ", vcc\n\t"
+        "v_add_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_Q0 "\n\t"
+        "v_addc_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_Q1 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_Q4 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_Q5 ", vcc\n\t"
+        "v_addc_co_u32_e64 " GL_R6 ", vcc, 0, 0, vcc\n\t"
+        "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
+        "v_subb_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R6 ", vcc\n\t"
         "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
         "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
-        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
           "v"((u32)(d >> 32))
-        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "vcc", "scc",
+        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, GL_Q0, GL_Q1, GL_Q2, GL_Q3, GL_Q4, GL_Q5, GL_Q6, "vcc", "scc",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
     return ((u64)r1 << 32) | r0;
 }
 // a * b + c with one reduction (the product plus a 64-bit addend stays below 2^128).  Any residues in, a residue out; 20 VALU + 2 SALU.
 __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
     u32 r0, r1;
-    asm("v_mad_u64_u32 v[80:81], vcc, %2, %4, 0\n\t"
-        "v_mad_u64_u32 v[82:83], vcc, %2, %5, 0\n\t"
-        "v_mad_u64_u32 v[82:83], s[80:81], %3, %4, v[82:83]\n\t"
-        "v_mad_u64_u32 v[84:85], vcc, %3, %5, 0\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[80:81]\n\t"
-        "v_add_co_u32_e32 v81, vcc, v81, v82\n\t"
-        "v_addc_co_u32_e32 v84, vcc, v84, v83, vcc\n\t"
-        "v_addc_co_u32_e32 v85, vcc, v85, v86, vcc\n\t"
-        "v_add_co_u32_e32 v80, vcc, v80, %6\n\t"
-        "v_addc_co_u32_e32 v81, vcc, v81, %7, vcc\n\t"
-        "v_addc_co_u32_e32 v84, vcc, 0, v84, vcc\n\t"
-        "v_addc_co_u32_e32 v85, vcc, 0, v85, vcc\n\t"
-        "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
-        "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
-        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+    asm("v_mad_u64_u32 " GL_P01 ", vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 " GL_P23 ", s[80:81], %3, %4, " GL_P23 "\n\t"
+        "v_mad_u64_u32 " GL_P45 ", vcc, %3, %5, 0\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[80:81]\n\t"
+        "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R2 "\n\t"
+        "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_R3 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_R6 ", vcc\n\t"
+        "v_add_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", %6\n\t"
+        "v_addc_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", %7, vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R4 ", vcc, 0, " GL_R4 ", vcc\n\t"
+        "v_addc_co_u32_e32 " GL_R5 ", vcc, 0, " GL_R5 ", vcc\n\t"
+        "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
+        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
         "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
         "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
-        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32))
-        : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
 #else
