@@ -127,7 +127,6 @@ def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     digest = np.array([11, 22, 33, 44], np.uint64)
     ctxs = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in ctxs]
-    for c in ctxs:
     n_buf = witness_threads + provers + 1
     bufs = [torch.empty((135, b.n), dtype=torch.int64).pin_memory() for _ in range(n_buf)]
     views = [t.numpy().view(np.uint64) for t in bufs]
@@ -246,7 +245,6 @@ def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
     wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
     pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
-    for c in pctx:
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda:%d" % device) for _ in range(provers)]
     rng = np.random.default_rng(4048)
     base = rng.integers(0, synth.P, size=len(targets), dtype=np.uint64)

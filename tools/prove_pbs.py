@@ -129,7 +129,6 @@ def main():
     wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
     pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
-    for c in pctx:
     d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda()
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda") for _ in range(provers)]
     digest = np.array([11, 22, 33, 44], np.uint64)
