@@ -102,15 +102,16 @@ def main():
         wv = [float(r["Counter_Value"]) for r in counter_rows(write_dir, "WRITE_SIZE") if pred(short(r["Kernel_Name"]))]
         tr = [r for r in trace if pred(short(r["Kernel_Name"]))]
         return fv, wv, [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
-    fused = traffic(lambda k: k == "gate_fused_kernel")
+    fused = traffic(lambda k: k == "gate_fused_kernel" or k == "gate_tile_kernel")
     per_gate = traffic(lambda k: k.startswith("gate_kernel<"))
     steps = len(by_kind["wires"])
     gates = {"algorithmic_bytes_per_step": lde * (135 + 6) * 8,
              "note": "algorithmic = every column a gate can read, once: 135 wire + 6 selector / gate-constant columns x 2^19 x 8 B (the sigma and Z "
-                     "columns belong to the permutation part, quotient_perm_kernel, which runs beside it; the items' output planes -- "
-                     "n_items x 2 x 2^19 x 8 B written once -- and the alpha powers are not counted); measured = FETCH_SIZE x 2 + WRITE_SIZE "
+                     "columns belong to the permutation part, quotient_perm_kernel; the output planes -- one plane of 2 x 2^19 x 8 B for "
+                     "gate_tile_kernel, n_items planes for gate_fused_kernel -- and the alpha powers are not counted); measured = FETCH_SIZE x 2 + WRITE_SIZE "
                      "per step (FETCH_SIZE counts what leaves the XCD's L2, whether the memory-side cache or HBM serves it)"}
-    for name, (fv, wv, du) in (("gate_fused_kernel", fused), ("per_gate_kernels", per_gate)):
+    one_launch_name = "gate_tile_kernel" if any(short(r["Kernel_Name"]) == "gate_tile_kernel" for r in trace) else "gate_fused_kernel"
+    for name, (fv, wv, du) in ((one_launch_name, fused), ("per_gate_kernels", per_gate)):
         if fv:
             hbm = (2 * sum(fv) + sum(wv)) * 1024 / max(1, steps)
             gates[name] = {"launches": len(fv), "hbm_bytes_per_step": hbm, "ratio_to_algorithmic": hbm / gates["algorithmic_bytes_per_step"],
