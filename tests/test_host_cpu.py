@@ -232,21 +232,28 @@ def test_hash_chain_matches_oracle_and_reference_semantics():
 
 
 def test_recorded_bench_line_keeps_the_contract():
-    """profiles/r01_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read"""
+    """profiles/r03_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  Since
+    round 3 the parsed headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs), the roofline is priced against the integer
+    issue rate with the HBM fraction beside it, and the CPU baseline is a median of stage-timed runs."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_latest.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_latest.json")
     d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["scaling"] == "weak"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and "vpbs_ivc_prove_pbs" in d["config"]["workload"]
+    chains = d["config"]["chains_per_gpu"]
+    assert chains >= 1 and abs(d["value"] - chains * 1e3 / d["ms_per_step"] / 730) / d["value"] < 1e-6      # chained proofs/s / 730
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] == "int-valu-issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
+    assert r["hbm"]["bound"] == "hbm" and abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / r["hbm"]["peak"]) < 1e-9 and r["hbm"]["unit"] == "GB/s"
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert abs(d["value"] - 1e3 / d["ms_per_step"] / 730) / d["value"] < 1e-6      # vPBS proofs/s = step proofs/s / 730
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["runs"] >= 5
+    assert len(c["ms_per_step_runs"]) == c["runs"] and sum(c["stages_ms_median"].values()) < 1.05 * c["ms_per_step"]
+    assert "cargo" in c["reference_probe"]
+    assert d["parity_checked_full_size"] is True and d["step_micro"]["ms_per_step_proof"] > 0 and d["ivc_single_chain"]["ms_per_step"] > d["ms_per_step"] / chains
 
 
 def test_proof_bytes_round_trip_and_verify():
