@@ -137,7 +137,9 @@ class ExtBuilder(Builder):
         return q
 
     def select_ext(self, b, x, y):
-        return (self.select(b, x[0], y[0]), self.select(b, x[1], y[1]))
+        """gadgets/select.rs select_ext: b x - (b y - y) on two ArithmeticExtensionGate operations, b lifted to the extension"""
+        be = self.to_ext(b)
+        return self.mul_sub_ext(be, x, self.mul_sub_ext(be, y, y))
 
     # ---- util/reducing.rs ReducingFactorTarget ----
     def reduce_base(self, coeffs, alpha):
@@ -585,6 +587,23 @@ class Shape:
         self.proof_words = self.caps_words + self.openings_words + self.fri_words
         self.vk_words = 4 + cap_words
 
+    def ext_pairs(self):
+        """offsets (of the first word) of the pairs of the flat proof that are ExtensionTargets in plonky2's ProofTarget -- the openings, the
+        16 evaluations of every FriQueryStep, the final polynomial's coefficients; every other word is a base Target (cap and sibling
+        hashes, the initial trees' leaf values, the proof-of-work witness)"""
+        out = [self.caps_words + 2 * j for j in range(self.total_cols + self.nc)]
+        fri0 = self.caps_words + self.openings_words
+        q_at = len(self.arity_bits) * 4 * self.cap_len
+        for qi in range(self.n_queries):
+            w = q_at + qi * self.query_words + sum(c + 4 * self.nsib0 for c in self.ncols)
+            for r, ab in enumerate(self.arity_bits):
+                out += [fri0 + w + 2 * i for i in range(1 << ab)]
+                w += (2 << ab) + 4 * self.nsib[r]
+            assert w == q_at + (qi + 1) * self.query_words
+        final_at = self.fri_words - 1 - 2 * self.final_len
+        out += [fri0 + final_at + 2 * i for i in range(self.final_len)]
+        return out
+
     def flat_proof(self, proof):
         """the product's proof dict -> the flat word list the proof targets take"""
         out = np.concatenate([np.asarray(proof[k], dtype=np.uint64).reshape(-1) for k in ("caps", "openings", "fri")])
@@ -871,25 +890,41 @@ class CyclicStepCircuit:
         for a, b in zip(step.lwe_hash_in, inner_lwe_hash):
             cb.connect(a, cb.select(cond, b, zero))
         cb.connect(step.counter, cb.mul_add(cond, inner_counter, cb.one()))          # :268-269
-        # conditionally_verify_cyclic_proof_or_dummy (:271-277): the inner proof's verifier data are this circuit's own; the proof is
-        # checked against them when `condition` holds and against the dummy circuit's otherwise (base case)
+        # conditionally_verify_cyclic_proof_or_dummy (:271-277; plonky2 recursion/cyclic_recursion.rs + conditional_recursive_verifier.rs):
+        #  * the verifier data carried by the cyclic proof's public inputs are this circuit's own (connect_hashes / connect_merkle_caps,
+        #    unconditionally: the base proof carries them too);
+        #  * a SECOND proof slot -- the dummy circuit's proof with its public inputs and verifier data, free targets that plonky2's
+        #    DummyProofGenerator fills (dummy_proof_and_vk) and the driver presets here;
+        #  * select_proof_with_pis: EVERY word of the proof and of its public inputs is selected between the two slots by `condition`, the
+        #    verifier data between own and dummy (select_hash / select_cap), and ONE verifier checks the selection (verify_proof).
         own_vk = self.vk_digest + [t for h in self.vk_cap for t in h]
         for a, b in zip(own_vk, ip[n_pi - 68:]):
             cb.connect(a, b)
+        self.dummy_proof = cb.virtuals(shape.proof_words)
+        self.dummy_pis = cb.virtuals(n_pi)
         self.dummy_vk = cb.virtuals(68)
+        sel_proof = [None] * shape.proof_words
+        for at in shape.ext_pairs():      # ExtensionTargets of the ProofTarget go through select_ext, the rest through select
+            sel_proof[at], sel_proof[at + 1] = cb.select_ext(cond, (self.proof[at], self.proof[at + 1]), (self.dummy_proof[at], self.dummy_proof[at + 1]))
+        for at in range(shape.proof_words):
+            if sel_proof[at] is None:
+                sel_proof[at] = cb.select(cond, self.proof[at], self.dummy_proof[at])
+        sel_pis = [cb.select(cond, a, b) for a, b in zip(ip, self.dummy_pis)]
         sel = [cb.select(cond, a, b) for a, b in zip(own_vk, self.dummy_vk)]
-        verify_proof(cb, shape, self.proof, ip, sel[:4], [sel[4 + 4 * i:8 + 4 * i] for i in range(16)])
+        verify_proof(cb, shape, sel_proof, sel_pis, sel[:4], [sel[4 + 4 * i:8 + 4 * i] for i in range(16)])
         self.built = cb.build(api, log_n)
         if self.built.log_n != log_n:
             raise ValueError("the cyclic circuit needs %d rows: it does not fit degree 2^%d" % (self.built.used_rows, log_n))
-        self.targets = (self.proof + ip + [cond] + step.ggsw_flat + [step.mask] + own_vk + self.dummy_vk)
+        self.targets = (self.proof + ip + [cond] + step.ggsw_flat + [step.mask] + own_vk + self.dummy_vk + self.dummy_proof + self.dummy_pis)
         self.positions = [self.built.pos(t) for t in self.targets]
 
-    def values(self, flat_proof, inner_pis, condition, ggsw_flat, mask, own_vk, dummy_vk):
-        """the PartialWitness of one step in the order of self.targets / self.positions (ivc_based_vpbs.rs:283-299, 314-330, 345-361)"""
+    def values(self, flat_proof, inner_pis, condition, ggsw_flat, mask, own_vk, dummy_vk, dummy_flat_proof, dummy_pis=None):
+        """the PartialWitness of one step in the order of self.targets / self.positions (ivc_based_vpbs.rs:283-299, 314-330, 345-361); the
+        last two entries are what plonky2's DummyProofGenerator sets: the dummy circuit's proof (of all-zero public inputs) and those inputs"""
+        dummy_pis = np.zeros(len(self.dummy_pis), np.uint64) if dummy_pis is None else np.asarray(dummy_pis, np.uint64)
         v = np.concatenate([np.asarray(flat_proof, np.uint64), np.asarray(inner_pis, np.uint64), np.array([condition], np.uint64),
                             np.asarray(ggsw_flat, np.uint64).reshape(-1), np.array([int(mask) % P], np.uint64), np.asarray(own_vk, np.uint64),
-                            np.asarray(dummy_vk, np.uint64)])
+                            np.asarray(dummy_vk, np.uint64), np.asarray(dummy_flat_proof, np.uint64), dummy_pis])
         assert v.size == len(self.targets)
         return v
 

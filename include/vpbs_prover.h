@@ -536,12 +536,17 @@ int vpbs_verify_step(const vpbs_verify_inputs* in, const uint64_t* caps /* [3][c
  * The cyclic step circuit and its dummy circuit arrive as data (what CircuitBuilder::build leaves behind: vpbs_circuit + the PartialWitness
  * targets in the order verified_pbs sets them + the public-input targets).  vpbs_ivc_create commits their constants / sigmas, derives the
  * verifier data, compiles and splits the witness plans and allocates the wire matrices; vpbs_ivc_prove_pbs then runs
- *     base proof of the dummy circuit -> n + 2 step proofs of the cyclic circuit, each taking the previous proof as a witness
+ *     base proof (cyclic_base_proof: a proof of the dummy circuit whose public inputs carry the initial values) -> n + 2 step proofs of the cyclic circuit, each taking the previous proof as a witness
  * with the early witness phase of the next step and its upload running on two host threads beside the proof of the current one, and
  * returns the LAST proof serialised (ProofWithPublicInputs bytes): the input of vpbs_verify_pbs.  One chain at a time per vpbs_ivc; several
  * vpbs_ivc objects (one context each) run side by side.
  *   preset_pos of the cyclic circuit: previous proof's words [proof_words] | its public inputs [n_pi] | condition | GGSW [ggsw_len] | mask |
- *                                     own verifier data [4 + cap] | dummy verifier data [4 + cap]      (wire positions column * n + row)
+ *                                     own verifier data [4 + cap] | dummy verifier data [4 + cap] | the dummy circuit's proof [proof_words] |
+ *                                     its public inputs [n_pi]                                          (wire positions column * n + row)
+ *                                     -- the last three are what plonky2's DummyProofGenerator fills (recursion/dummy_circuit.rs): the SECOND
+ *                                     proof slot of conditionally_verify_cyclic_proof_or_dummy, every word of which the circuit selects
+ *                                     against the first by `condition`; vpbs_ivc_create proves the dummy circuit once (all-zero public
+ *                                     inputs) and presets its proof in every step
  *   preset_pos of the dummy circuit : its public inputs [n_pi];  n_pi = 2 K N + 9 + 4 + cap words
  *   bsk [n_lwe][ggsw_len] NTT domain (vpbs_keygen's layout), ksk [ggsw_len], ct [n_lwe + 1], testv [N]: host arrays
  *   steps: 0 or n_lwe + 2 = the whole chain; fewer = a prefix (tests)

@@ -101,6 +101,9 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     flat = lambda acc: [int(v) for p in acc for v in p]
     base_pis = np.array(flat(acc_init) + [0] + [0] * (K * N) + [0] * 8 + [int(v) for v in C.vk], np.uint64)
     proof, pis = prove_d(dm.witness(base_pis), base_pis), base_pis
+    # the second slot (dummy_proof_and_vk): the dummy circuit's proof of all-zero public inputs, the same in every step
+    zero_pis = np.zeros(base_pis.size, np.uint64)
+    dummy_flat = cy.shape.flat_proof(prove_d(dm.witness(zero_pis), zero_pis))
     plan = cy.built.circuit.witness_plan(cy.positions)
     zero_ggsw = np.zeros(K * ELL * K * N, np.uint64)
     steps = [(0, zero_ggsw, ct[n_lwe])] + [(1, bsk[x], ct[x]) for x in range(n_lwe)] + [(1, ksk, 0)]
@@ -111,7 +114,7 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     late[:cy.shape.proof_words] = 1
     split.split(late)
     for cond, ggsw, mask in steps:
-        values = cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk)
+        values = cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk, dummy_flat)
         wires = plan.run(values)
         early_values = values.copy()
         early_values[:cy.shape.proof_words] = 0xDEAD                  # the late entries are not read by the early phase
@@ -124,6 +127,25 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
             state = split.run_early(early_values, two)
             with pytest.raises(api.VpbsError):
                 split.run_late(state, bad, two)
+        # the two proof slots (select_proof_with_pis): the verifier sees the slot `condition` selects and nothing of the other one
+        W = cy.shape.proof_words
+        at = (104729 * len(proofs) + 7) % W
+        other_slot = values.copy()
+        if cond:
+            other_slot[len(values) - len(pis) - W + at] ^= np.uint64(1)          # a word of the dummy proof: not looked at
+            in_slot = None
+        else:
+            other_slot[at] ^= np.uint64(1)                                       # base step: the cyclic slot's proof words are free ...
+            in_slot = values.copy()
+            in_slot[len(values) - len(pis) - W + at] ^= np.uint64(1)             # ... and the dummy proof is the one verified
+        got = plan.run(other_slot)
+        assert (cy.public_inputs(got) == cy.public_inputs(wires))
+        if check and len(proofs) < 2:
+            ok, msg = cy.built.circuit.check_witness(got, api.hash_no_pad(np.array(cy.public_inputs(got), np.uint64)))
+            assert ok, msg
+        if in_slot is not None:
+            with pytest.raises(api.VpbsError):
+                plan.run(in_slot)
         pis = np.array(cy.public_inputs(wires), np.uint64)
         if check:
             ok, msg = cy.built.circuit.check_witness(wires, api.hash_no_pad(pis))

@@ -58,7 +58,8 @@ def export_cyclic(path, dummy_path, N, K, ELL, LOGB, n_lwe, log_n):
     """the CYCLIC step circuit (circuitgen/cyclic_circuit.py: build_step_circuit + the in-circuit verifier of its own previous proof,
     ivc_based_vpbs.rs:159-275) and the dummy circuit of its base case.  PartialWitness order of the cyclic file: the inner proof's words
     (caps, openings, FriProof as vpbs_prove_step emits them), the inner proof's public inputs, the condition bit, the GGSW, the mask, the
-    circuit's own verifier data (digest, cap), the dummy circuit's verifier data.  No sample witness (it would need a proof): the sample
+    circuit's own verifier data (digest, cap), the dummy circuit's verifier data, the dummy circuit's proof (second proof slot) and its public
+    inputs.  No sample witness (it would need a proof): the sample
     sections are zero and the trailer says so (kind)."""
     import cyclic_circuit as cyc
     cy = cyc.CyclicStepCircuit(api, N, K, ELL, LOGB, n_lwe, api.ntt_params(N.bit_length() - 1), log_n)

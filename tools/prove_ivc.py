@@ -118,7 +118,8 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
                 cond, ggsw, mask = plan_steps[s]
                 b = free_bufs.get()
                 t = time.perf_counter()
-                values = np.concatenate([zeros, pis_prev, np.array([cond], np.uint64), ggsw, np.array([mask], np.uint64), cyc.vk, dum.vk])
+                values = np.concatenate([zeros, pis_prev, np.array([cond], np.uint64), ggsw, np.array([mask], np.uint64), cyc.vk, dum.vk,
+                                         dummy_flat, np.zeros(base_pis.size, np.uint64)])
                 state = cyc.plan.run_early(values, views[b], recycled=b in filled)   # a matrix this plan filled before: values only
                 filled.add(b)
                 pis_prev = views[b][cyc.pi_cols, cyc.pi_rows].copy()     # public inputs never depend on the inner proof's words
@@ -141,6 +142,11 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
         if errs:
             ready.put(None)
 
+    # the second proof slot (dummy_proof_and_vk): the dummy circuit's proof of all-zero public inputs, the same in every step -- before the clock
+    base_host = torch.empty((135, dum.d.n), dtype=torch.int64).pin_memory()
+    zero_pis = np.zeros(base_pis.size, np.uint64)
+    dum.plan.run(zero_pis, out=base_host.numpy().view(np.uint64))
+    dummy_flat = flat(dum.prove(base_host.cuda().data_ptr(), zero_pis)[0])
     t_wit = t_copy = t_prove = 0.0
     torch.cuda.synchronize()
     start.wait()
@@ -151,7 +157,6 @@ def run_chain(ctx, cyc, dum, N, n_lwe, log_n, steps, seed, message, start, dist=
     uploader.start()
     # cyclic_base_proof (ivc_based_vpbs.rs:292-299): a proof of the dummy circuit whose public inputs carry the initial accumulator and the
     # cyclic circuit's verifier data
-    base_host = torch.empty((135, dum.d.n), dtype=torch.int64).pin_memory()
     dum.plan.run(base_pis, out=base_host.numpy().view(np.uint64))
     d_base = base_host.cuda()
     torch.cuda.synchronize()

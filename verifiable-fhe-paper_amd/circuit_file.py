@@ -102,7 +102,7 @@ def verifier_data_words(cs_cap, log_n, compat=None):
 
 
 def cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n):
-    stem = "N%d_K%d_ELL%d_LOGB%d_n%d_deg%d.bin" % (N, K, ELL, LOGB, n_lwe, log_n)
+    stem = "N%d_K%d_ELL%d_LOGB%d_n%d_deg%d_slots2.bin" % (N, K, ELL, LOGB, n_lwe, log_n)   # slots2: the two-proof-slot PartialWitness layout
     return os.path.join(DIR, "cyclic_" + stem), os.path.join(DIR, "dummy_" + stem)
 
 

@@ -116,6 +116,7 @@ struct vpbs_ivc {
     Side cyc, dum;
     unsigned N = 0, K = 0;
     size_t proof_words = 0, ggsw_len = 0, kn = 0, n_pi = 0, wire_words = 0;
+    std::vector<u64> dummy_proof;   // the second proof slot: the dummy circuit's proof of all-zero public inputs (vpbs_ivc_create)
     size_t late_rows[2] = {0, 0};
     static constexpr int NBUF = 3;
     u64 *bufs[NBUF] = {nullptr, nullptr, nullptr}, *d_bufs[NBUF] = {nullptr, nullptr, nullptr}, *base_wires = nullptr;
@@ -161,8 +162,10 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
     }
     const size_t kn = (size_t)K * N, cap_words = (size_t)4 << cap_height, n_pi = 2 * kn + 9 + 4 + cap_words;
     // the PartialWitness of a step, in the order the reference sets it (:314-330): previous proof | its public inputs | condition | GGSW |
-    // mask | own verifier data | dummy verifier data; the dummy circuit's PartialWitness is its public inputs
-    if (cyclic->n_pi != n_pi || dummy->n_preset != n_pi || (dummy->n_pi != 0 && dummy->n_pi != n_pi) || cyclic->n_preset != cyclic->proof_words + n_pi + 1 + ggsw_len + 1 + 2 * (4 + cap_words)) {
+    // mask | own verifier data | then what plonky2's DummyProofGenerator sets: dummy verifier data | the dummy circuit's proof | its public
+    // inputs (the second proof slot of conditionally_verify_cyclic_proof_or_dummy); the dummy circuit's PartialWitness is its public inputs
+    if (cyclic->n_pi != n_pi || dummy->n_preset != n_pi || (dummy->n_pi != 0 && dummy->n_pi != n_pi) ||
+        cyclic->n_preset != 2 * (cyclic->proof_words + n_pi) + 1 + ggsw_len + 1 + 2 * (4 + cap_words)) {
         say("the circuits are not a cyclic step circuit and its dummy circuit for these parameters (public inputs / PartialWitness layout)");
         return VPBS_ERR_INVALID;
     }
@@ -188,6 +191,31 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
             if (rc == 0) rc = vpbs_device_alloc(ctx, v->wire_words, &d);
         if (!(v->base_wires = static_cast<u64*>(vpbs_host_alloc(8 * (size_t)v->dum.n_wires * v->dum.n)))) rc = VPBS_ERR_OOM;
         if (rc != 0) v->err = "wire matrices: out of (pinned or device) memory";
+    }
+    if (rc == 0) {
+        // dummy_proof_and_vk (recursion/dummy_circuit.rs): the dummy circuit's proof of all-zero public inputs -- the content of the second
+        // proof slot in every step of every chain, so it is proven once here
+        char e[256] = {0};
+        const std::vector<u64> zero_pis(n_pi, 0);
+        vpbs_step_inputs in;
+        vpbs_step_sizes sz{};
+        if (vpbs_witness_plan_run(v->dum.plan, zero_pis.data(), 0, v->base_wires, e, sizeof e) != 0) {
+            v->err = std::string("dummy witness: ") + e;
+            rc = VPBS_ERR_INVALID;
+        }
+        if (rc == 0) {
+            v->dum.step_inputs(in, v->base_wires, false, zero_pis.data());
+            if (vpbs_step_sizes_get(ctx, &in, &sz) != 0 || 3 * sz.cap_words + sz.openings_words + sz.fri_words != v->proof_words) {
+                v->err = "the proof of this shape does not have the number of words the cyclic circuit expects";
+                rc = VPBS_ERR_INVALID;
+            }
+        }
+        if (rc == 0) {
+            v->dummy_proof.assign(v->proof_words, 0);
+            u64 *caps = v->dummy_proof.data(), *openings = caps + 3 * sz.cap_words, *fri = openings + sz.openings_words;
+            rc = v->dum.prove(in, caps, openings, fri);
+            if (rc != 0) v->err = std::string("dummy proof: ") + vpbs_last_error(ctx);
+        }
     }
     if (rc != 0) {
         say(v->err);
@@ -299,6 +327,8 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
             r.values.push_back(mask_of(s));
             r.values.insert(r.values.end(), cyc.vk.begin(), cyc.vk.end());
             r.values.insert(r.values.end(), dum.vk.begin(), dum.vk.end());
+            r.values.insert(r.values.end(), v->dummy_proof.begin(), v->dummy_proof.end());
+            r.values.insert(r.values.end(), n_pi, 0);   // the dummy proof's public inputs
             // a matrix this plan has filled before only gets its value-carrying positions rewritten
             const auto run_early = v->filled[b] ? vpbs_witness_plan_run_early_recycled : vpbs_witness_plan_run_early;
             if (run_early(cyc.plan, r.values.data(), 0, v->bufs[b], &r.state, e2, sizeof e2) != 0)
