@@ -166,6 +166,9 @@ class Builder:
             row = self.add_row("base_sum")
             sums.append(self._wire(row, 0))
             bits += [self._wire(row, 1 + i) for i in range(BASE_SUM_LIMBS)]
+        zero = self.zero()
+        for b in bits[num_bits:]:                               # gadgets/split_join.rs: `for b in bits.drain(num_bits..) { assert_zero(b) }`
+            self.connect(b, zero)
         del bits[num_bits:]
         acc = self.zero()
         for s in reversed(sums):

@@ -292,6 +292,73 @@ def test_split_plan_levels_threads_and_concurrent_runs():
     whole.free()
 
 
+def test_split_le_asserts_its_unused_limbs_zero():
+    """gadgets/split_join.rs split_le: the limbs of the last BaseSumGate beyond num_bits are asserted zero -- split_le(x, 20) IS the range
+    check x < 2^20 (the in-circuit proof-of-work check and the decomposition's digits rest on it), not x < 2^63"""
+    cb = sc.Builder()
+    x, y = cb.virtual(), cb.virtual()
+    bits = cb.split_le(x, 20)
+    wide = cb.split_le(y, 70)                                # two rows: 63 limbs + 7, the other 56 limbs of the second row are zero
+    assert len(bits) == 20 and len(wide) == 70
+    cb.register_public_inputs(bits[:4] + wide[60:])
+    built = cb.build(api)
+
+    def run(xv, yv):
+        w = built.circuit.generate_witness(built.presets({x: xv, y: yv}))
+        ok, msg = built.circuit.check_witness(w, api.hash_no_pad(np.array(built.values(w, built.public_inputs), np.uint64)))
+        assert ok, msg
+        return built.values(w, bits), built.values(w, wide)
+    b, wv = run((1 << 20) - 1, P - 1)
+    assert b == [1] * 20 and sum(v << i for i, v in enumerate(wv)) == P - 1
+    assert run(0b1011, 5)[0][:4] == [1, 1, 0, 1]
+    for too_big in (1 << 20, (1 << 62) + 3, 1 << 47):
+        with pytest.raises(api.VpbsError, match="set twice"):
+            run(too_big, 0)
+
+
+def test_a_late_check_against_an_early_value_keeps_the_early_phase_early():
+    """vpbs_witness_plan_split: a late generator that writes into a copy class the early phase already knows (the limbs a late range check
+    connects to the constant zero, a late value connected to an early one) is a comparer -- it must not drag every reader of that class
+    into the late phase.  The late rows are the range check's own; a late value that violates the check is still caught."""
+    cb = sc.Builder()
+    early = cb.virtuals(40)
+    late_v = cb.virtual()
+    zero = cb.zero()
+    acc = zero
+    for t in early:                                           # early logic that reads the constant zero all over
+        acc = cb.mul_add(acc, t, cb.add(t, zero))
+    cb.split_le(late_v, 10)                                   # late: its 53 unused limbs are connected to zero
+    cb.connect(cb.mul(late_v, late_v), cb.mul(early[0], early[0]))   # ... and its square is compared with an early value
+    cb.register_public_inputs([acc])
+    built = cb.build(api)
+    positions = [built.pos(t) for t in early + [late_v]]
+    plan, whole = built.circuit.witness_plan(positions), built.circuit.witness_plan(positions)
+    late = np.zeros(len(positions), np.uint8)
+    late[-1] = 1
+    plan.split(late)
+    lo, hi = plan.late_rows()
+    vals = np.array([7 + 3 * i for i in range(40)] + [7], np.uint64)
+    want = whole.run(vals)
+    out = np.full_like(want, 0xABCD)
+    early_only = vals.copy()
+    early_only[-1] = 0xDEAD
+    st = plan.run_early(early_only, out)
+    acc_pos = built.pos(acc)
+    assert out[acc_pos[0], acc_pos[1]] == want[acc_pos[0], acc_pos[1]]      # the early chain is complete before the late value exists
+    before = out.copy()
+    plan.run_late(st, vals, out)
+    assert (out == want).all()
+    changed = np.nonzero((before != out).any(axis=0))[0]
+    assert 0 < changed.size <= 4 and lo <= changed.min() and changed.max() < hi  # the range-check row, the preset, the square: nothing else
+    for bad in (8, (1 << 10) + 7):                            # another square; beyond the range
+        v = vals.copy()
+        v[-1] = bad
+        with pytest.raises(api.VpbsError):
+            plan.run_late(plan.run_early(early_only, out), v, out)
+    plan.free()
+    whole.free()
+
+
 def test_cxx_ivc_host_builds_and_fails_loudly_without_a_device(tmp_path):
     """examples/prove_ivc.cpp (the IVC chain from a plain C++ host) compiles against include/vpbs_prover.h with g++ alone, rejects a file
     that is not a circuit, and without a GPU stops at context creation instead of computing anything on the CPU."""

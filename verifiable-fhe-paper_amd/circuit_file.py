@@ -74,7 +74,7 @@ def load(path):
 
 
 def step_circuit_path(N, K, ELL, LOGB, n_lwe):
-    return os.path.join(DIR, "step_N%d_K%d_ELL%d_LOGB%d_n%d.bin" % (N, K, ELL, LOGB, n_lwe))
+    return os.path.join(DIR, "step_N%d_K%d_ELL%d_LOGB%d_n%d_v2.bin" % (N, K, ELL, LOGB, n_lwe))   # v2: split_le asserts its unused limbs zero
 
 
 def ensure_step_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728):

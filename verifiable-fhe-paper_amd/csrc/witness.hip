@@ -475,17 +475,29 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
 }
 // ---- two-phase runs ----
 // Taint propagation along the schedule: the late presets taint their slots, a step that reads a tainted slot is late and taints what it
-// writes.  Reads / writes of a gate generator are found the way plan creation finds them (gen_run on flags).
+// writes -- unless the early phase knows that value anyway (an early preset, or an early step writes it too: the late step is then the
+// second writer of the slot and only compares; e.g. the limbs a late range check connects to the constant zero must not make every
+// reader of zero late).  Reads / writes of a gate generator are found the way plan creation finds them (gen_run on flags).
 int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     if (!pp || !late) {
         err = "malformed arguments";
         return VPBS_ERR_INVALID;
     }
     vpbs_witness_plan& p = *pp;
-    std::vector<uint8_t> taint(p.n_slots, 0), ready(p.n_slots, 1);
+    std::vector<uint8_t> taint(p.n_slots, 0), ready(p.n_slots, 1), known_early(p.n_slots, 0);
     p.preset_late.assign(late, late + p.preset_slot.size());
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
-        if (late[i]) taint[p.preset_slot[i]] = 1;
+        if (!late[i]) known_early[p.preset_slot[i]] = 1;
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (late[i] && !known_early[p.preset_slot[i]]) taint[p.preset_slot[i]] = 1;
+    auto wrote = [&](u32 slot, bool is_late) {
+        if (!is_late) {
+            known_early[slot] = 1;
+            taint[slot] = 0;   // a late step may have been the first to reach it in the schedule: the early phase has the value all the same
+        } else if (!known_early[slot]) {
+            taint[slot] = 1;
+        }
+    };
     p.step_late.assign(p.schedule.size(), 0);
     const unsigned mc = std::max(1u, p.max_consts);
     std::vector<unsigned> deps;
@@ -509,8 +521,9 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             std::vector<u32>& sl = slot_level[is_late];
             for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, sl[gs[k]] + 1);
             for (unsigned k = 0; k < gg.n_out; ++k) {
-                if (is_late) taint[gs[gg.n_in + k]] = 1;
-                if (sl[gs[gg.n_in + k]] == 0) sl[gs[gg.n_in + k]] = lvl;
+                wrote(gs[gg.n_in + k], is_late);
+                // a late step that writes a value the early phase has is a comparer: nothing in the late phase waits for it
+                if (sl[gs[gg.n_in + k]] == 0 && !(is_late && known_early[gs[gg.n_in + k]])) sl[gs[gg.n_in + k]] = lvl;
             }
         } else {
             const vpbs_gate& g = p.gates[p.row_gate[st.row]];
@@ -533,8 +546,8 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             for (unsigned w : deps) lvl = std::max(lvl, sl[rs[w]] + 1);
             for (u32 slot : written) lvl = std::max(lvl, sl[slot] + 1);   // an earlier writer of the phase: this one compares, after it
             for (u32 slot : written) {
-                if (is_late) taint[slot] = 1;
-                if (sl[slot] == 0) sl[slot] = lvl;
+                wrote(slot, is_late);
+                if (sl[slot] == 0 && !(is_late && known_early[slot])) sl[slot] = lvl;
             }
         }
         step_level[i] = lvl;
