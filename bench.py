@@ -576,7 +576,7 @@ IVC_N, IVC_K, IVC_ELL, IVC_LOGB, IVC_NLWE = 1024, 2, 4, 5, 728   # the paper's p
 def measure_ivc(args, rank, local_rank, world, distributed):
     """The headline: the reference's own object -- vPBS proofs as IVC chains (verified_pbs, ivc_based_vpbs.rs:159-386) through the library's
     driver vpbs_ivc_prove_pbs.  A step = one CHAINED step proof of the cyclic circuit (step logic + in-circuit verifier of the previous
-    proof, 44 250 gate rows, degree 2^16) of every chain on this GPU: witness generation (host, two phases), upload, proof -- everything a
+    proof, 46 656 gate rows, degree 2^16) of every chain on this GPU: witness generation (host, two phases), upload, proof -- everything a
     step of the chain costs, the chain dependency included.  --warmup chained steps run untimed (after the base proof), then exactly --steps
     are timed between barrier + synchronise on both sides; the clock is placed from the library's progress hook."""
     import threading

@@ -11,11 +11,11 @@ and a RandomAccessGate into the cap), iop/challenger.rs `RecursiveChallenger`, r
 inputs, inner == outer check, base case).  The verifier gadget mirrors, step by step, the product's host verifier (csrc/verifier.hip), which
 verifies the same proofs natively.
 
-Differences from plonky2, stated: row placement and gadget packing are this builder's own; the base case uses ONE proof slot and selects the
-verifier data (the cyclic circuit's own, or the dummy circuit's) instead of selecting between two proof slots -- the proof is prover-supplied
-either way.  The circuit digest is CircuitBuilder::build's (`circuit_digest` below: cap, hash_pad of the empty domain separator, degree bits),
-carried in the verifier data.  Parity with the crate is unpinned; the semantics are those of the reference: ONE proof attests to
-the whole chain.
+Differences from plonky2, stated: row placement and gadget packing are this builder's own.  The base case is plonky2's: TWO proof slots (the
+cyclic proof; the dummy circuit's proof with its public inputs and verifier data, the targets plonky2's DummyProofGenerator fills), every
+word selected by `condition` (select_proof_with_pis), one verifier on the selection.  The circuit digest is CircuitBuilder::build's
+(`circuit_digest` below: cap, hash_pad of the empty domain separator, degree bits), carried in the verifier data.  Parity with the crate is
+unpinned; the semantics are those of the reference: ONE proof attests to the whole chain.
 """
 import numpy as np
 
