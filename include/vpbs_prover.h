@@ -345,6 +345,14 @@ int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const ui
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
                                char* err, size_t err_len);   /* the state is consumed whether the run succeeds or not */
 void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that never reached run_late */
+/* The late phase without the matrix: the values of the late wire positions, packed in the order of vpbs_witness_plan_late_positions
+ * (count = vpbs_witness_plan_late_count; positions column * n + row, fixed once the plan is split).  For a host whose early matrix is
+ * already on the device: upload `values_out` (a few MB instead of the row range of every column) and let vpbs_device_scatter put the
+ * words in place.  The host matrix of the early phase is not touched.  Consumes the state like vpbs_witness_plan_run_late. */
+int vpbs_witness_plan_run_late_packed(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val,
+                                      uint64_t* values_out /* [late_count] */, char* err, size_t err_len);
+size_t vpbs_witness_plan_late_count(const vpbs_witness_plan* plan);   /* 0 before the split */
+int vpbs_witness_plan_late_positions(const vpbs_witness_plan* plan, uint32_t* out /* [late_count] */);
 /* out = {row_lo, row_hi}: every wire position run_late writes lies in rows [row_lo, row_hi) -- what has to be uploaded again when the
  * matrix run_early produced is already on the device.  (0, 0) for a plan without late wires. */
 int vpbs_witness_plan_late_rows(const vpbs_witness_plan* plan, size_t out[2]);
@@ -695,6 +703,12 @@ int vpbs_device_upload_bg(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* host_s
 /* Rows [row_lo, row_hi) of every column of a column-major [n_cols][n] matrix (one strided copy; the late phase of a split witness plan
  * only changes the rows vpbs_witness_plan_late_rows reports).  Returns after the copy has completed. */
 int vpbs_device_upload_rows(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* host_src, unsigned n_cols, size_t n, size_t row_lo, size_t row_hi);
+/* d_dst[positions[i]] = host_values[i], i < count: the packed values of a late witness phase (vpbs_witness_plan_run_late_packed) put in
+ * place in the device-resident matrix of the early phase.  d_positions: the uint32 positions of vpbs_witness_plan_late_positions, uploaded
+ * once (vpbs_device_alloc of (count + 1) / 2 words + vpbs_device_upload); d_stage: count words of device scratch; host_values should be
+ * pinned (vpbs_host_alloc).  One copy of 8 count bytes + one kernel on the context's stream; returns when both have completed. */
+int vpbs_device_scatter(vpbs_ctx* ctx, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count,
+                        uint64_t* d_stage);
 void vpbs_device_free(vpbs_ctx* ctx, uint64_t* d_ptr);
 
 /* ---- per-kernel device timing (HIP events on the ctx stream) ---- */

@@ -869,6 +869,20 @@ def test_host_to_device_helpers():
     assert (got[:, 100:357] == host[:, 100:357]).all() and (got[:, :100] == -1).all() and (got[:, 357:] == -1).all()
     c.upload_rows(dev.data_ptr(), host.data_ptr(), cols, n, 5, 5)                      # empty range: nothing moves
     assert (dev.cpu() == got).all()
+    # vpbs_device_scatter: packed values (the late witness phase's) put in place through uint32 positions resident on the device
+    for count in (1, 2, 4097):
+        pos = rng.choice(cols * n, count, replace=False).astype(np.uint32)
+        vals = torch.from_numpy(rng.integers(0, 1 << 62, size=count, dtype=np.int64)).pin_memory()
+        packed = np.zeros((count + 1) // 2, np.uint64)
+        packed.view(np.uint32)[:count] = pos
+        d_pos = torch.from_numpy(packed.view(np.int64)).cuda()
+        d_stage = torch.empty(count, dtype=torch.int64, device="cuda")
+        before = dev.cpu().reshape(-1).clone()
+        torch.cuda.synchronize()
+        c.scatter(dev.data_ptr(), d_pos.data_ptr(), vals.data_ptr(), count, d_stage.data_ptr())
+        after = dev.cpu().reshape(-1)
+        before[torch.from_numpy(pos.astype(np.int64))] = vals
+        assert (after == before).all()
     with pytest.raises(api.VpbsError):
         c.upload_rows(dev.data_ptr(), host.data_ptr(), cols, n, 10, n + 1)
     # the background upload from a second host thread while the context proves

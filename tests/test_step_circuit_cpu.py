@@ -256,6 +256,19 @@ def test_split_plan_levels_threads_and_concurrent_runs():
         assert (out == want).all()
         changed = np.nonzero((before != out).any(axis=0))[0]
         assert changed.size and lo <= changed.min() and changed.max() < hi
+    # the late phase without the matrix (vpbs_witness_plan_run_late_packed): the same values, packed in the order of late_positions()
+    pos = plan.late_positions()
+    assert pos.size and np.unique(pos).size == pos.size and lo <= (pos % b.circuit.n).min() and (pos % b.circuit.n).max() < hi
+    v = vals(presets(31, 2))
+    want = whole.run(v)
+    out = np.full_like(want, 0xABCD)
+    st = plan.run_early(v, out)
+    early_matrix = out.copy()
+    packed = plan.run_late_packed(st, v)
+    assert (out == early_matrix).all()                                      # the host matrix is left alone
+    assert (packed == want.reshape(-1)[pos]).all()
+    out.reshape(-1)[pos] = packed
+    assert (out == want).all()                                              # early matrix + scattered late values = the witness
     # a recycled matrix (it holds the previous run's result): only the positions that carry values are rewritten
     v = vals(presets(77, 4))
     plan.run_late(plan.run_early(v, out, recycled=True), v, out)

@@ -223,6 +223,9 @@ SIGNATURES = {
     "vpbs_witness_plan_run_early_recycled": (_i, [C.c_void_p, U64P, C.c_uint, U64P, C.POINTER(C.c_void_p), C.c_char_p, _sz]),
     "vpbs_witness_plan_run_late": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_state_free": (None, [C.c_void_p]),
+    "vpbs_witness_plan_run_late_packed": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
+    "vpbs_witness_plan_late_count": (_sz, [C.c_void_p]),
+    "vpbs_witness_plan_late_positions": (_i, [C.c_void_p, U32P]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "vpbs_witness_device_run": (_i, [C.c_void_p, U64P, C.c_uint]),
@@ -246,6 +249,7 @@ SIGNATURES = {
     "vpbs_device_upload_bg": (_i, [_vp, _vp, _vp, _sz]),
     "vpbs_device_upload_rows": (_i, [_vp, _vp, _vp, _ui, _sz, _sz, _sz]),
     "vpbs_witness_plan_late_rows": (_i, [_vp, C.POINTER(_sz)]),
+    "vpbs_device_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "vpbs_device_free": (None, [_vp, _vp]),
     "vpbs_keygen": (_i, [_vp, C.POINTER(KeygenParamsC), U64P, U64P, U64P, _vp, _vp, _i]),
     "vpbs_lwe_encrypt": (_i, [C.POINTER(KeygenParamsC), U64P, _u64, _u64, U64P]),
@@ -553,6 +557,23 @@ class WitnessPlan:
         err = C.create_string_buffer(512)
         if lib().vpbs_witness_plan_run_late(self.h, state, _ptr(val), _ptr(out), err, 512):
             raise VpbsError("vpbs_witness_plan_run_late: " + err.value.decode())
+        return out
+
+    def run_late_packed(self, state, values):
+        """the late phase without the matrix -> the values of late_positions(), in that order; consumes the state"""
+        val = _u64(values)
+        assert val.size == self.n_preset
+        out = np.zeros(int(lib().vpbs_witness_plan_late_count(self.h)), np.uint64)
+        err = C.create_string_buffer(512)
+        if lib().vpbs_witness_plan_run_late_packed(self.h, state, _ptr(val), _ptr(out), err, 512):
+            raise VpbsError("vpbs_witness_plan_run_late_packed: " + err.value.decode())
+        return out
+
+    def late_positions(self):
+        """-> uint32 wire positions (column * n + row) the late phase writes (vpbs_witness_plan_late_positions)"""
+        out = np.zeros(int(lib().vpbs_witness_plan_late_count(self.h)), np.uint32)
+        if lib().vpbs_witness_plan_late_positions(self.h, out.ctypes.data_as(U32P)):
+            raise VpbsError("vpbs_witness_plan_late_positions: the plan is not split")
         return out
 
     def late_rows(self):
@@ -1196,6 +1217,11 @@ class Context:
     def upload_rows(self, d_dst, host, n_cols, n, row_lo, row_hi):
         """vpbs_device_upload_rows: rows [row_lo, row_hi) of every column of a column-major [n_cols][n] matrix"""
         self._check(lib().vpbs_device_upload_rows(self.h, C.c_void_p(int(d_dst)), C.c_void_p(int(host)), n_cols, n, row_lo, row_hi))
+
+    def scatter(self, d_dst, d_positions, host_values, count, d_stage):
+        """vpbs_device_scatter: d_dst[positions[i]] = host_values[i] (pointers as integers)"""
+        self._check(lib().vpbs_device_scatter(self.h, C.c_void_p(int(d_dst)), C.c_void_p(int(d_positions)), C.c_void_p(int(host_values)), count,
+                                              C.c_void_p(int(d_stage))))
 
     def glwe_decrypt(self, s, ct):
         """Glwe::decrypt: s [K-1][N] (or [K][N]: the leading K-1 polynomials are used), ct [K][N] -> m [N]"""

@@ -771,6 +771,25 @@ int vpbs_device_upload_rows(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_s
         VPBS_HIP(hipStreamSynchronize(c->stream));
     });
 }
+namespace {
+__global__ void __launch_bounds__(256) scatter_words_kernel(vpbs::u64* __restrict__ dst, const uint32_t* __restrict__ pos,
+                                                            const vpbs::u64* __restrict__ val, size_t count) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < count) dst[pos[i]] = val[i];
+}
+}  // namespace
+int vpbs_device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count,
+                        uint64_t* d_stage) {
+    if (!c || !d_dst || !d_positions || !host_values || !d_stage) return VPBS_ERR_INVALID;
+    if (count == 0) return VPBS_OK;
+    return guarded(c, [&] {
+        VPBS_HIP(hipMemcpyAsync(d_stage, host_values, sizeof(u64) * count, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d_dst,
+                           reinterpret_cast<const uint32_t*>(d_positions), d_stage, count);
+        VPBS_HIP(hipGetLastError());
+        VPBS_HIP(hipStreamSynchronize(c->stream));
+    });
+}
 void vpbs_device_free(vpbs_ctx* c, uint64_t* d_ptr) {
     if (c && d_ptr) {
         (void)hipStreamSynchronize(c->stream);

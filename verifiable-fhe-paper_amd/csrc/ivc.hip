@@ -118,6 +118,9 @@ struct vpbs_ivc {
     size_t proof_words = 0, ggsw_len = 0, kn = 0, n_pi = 0, wire_words = 0;
     std::vector<u64> dummy_proof;   // the second proof slot: the dummy circuit's proof of all-zero public inputs (vpbs_ivc_create)
     size_t late_rows[2] = {0, 0};
+    size_t late_count = 0;                       // wire positions the late witness phase writes (vpbs_witness_plan_late_count)
+    u64 *late_vals = nullptr;                    // their values, packed, pinned (vpbs_witness_plan_run_late_packed)
+    u64 *d_late_pos = nullptr, *d_late_stage = nullptr;   // device: the uint32 positions, the staging buffer of vpbs_device_scatter
     static constexpr int NBUF = 3;
     u64 *bufs[NBUF] = {nullptr, nullptr, nullptr}, *d_bufs[NBUF] = {nullptr, nullptr, nullptr}, *base_wires = nullptr;
     bool filled[NBUF] = {false, false, false};
@@ -131,6 +134,9 @@ struct vpbs_ivc {
         for (auto d : d_bufs)
             if (d) vpbs_device_free(ctx, d);
         if (base_wires) vpbs_host_free(base_wires);
+        if (late_vals) vpbs_host_free(late_vals);
+        if (d_late_pos) vpbs_device_free(ctx, d_late_pos);
+        if (d_late_stage) vpbs_device_free(ctx, d_late_stage);
         cyc.release();
         dum.release();
     }
@@ -182,6 +188,7 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
         rc = vpbs_witness_plan_split(v->cyc.plan, late.data(), e, sizeof e);
         if (rc != 0) v->err = std::string("split: ") + e;
         if (rc == 0) rc = vpbs_witness_plan_late_rows(v->cyc.plan, v->late_rows);
+        if (rc == 0) v->late_count = vpbs_witness_plan_late_count(v->cyc.plan);
     }
     if (rc == 0) {
         v->wire_words = (size_t)v->cyc.n_wires * v->cyc.n;
@@ -190,6 +197,15 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
         for (auto& d : v->d_bufs)
             if (rc == 0) rc = vpbs_device_alloc(ctx, v->wire_words, &d);
         if (!(v->base_wires = static_cast<u64*>(vpbs_host_alloc(8 * (size_t)v->dum.n_wires * v->dum.n)))) rc = VPBS_ERR_OOM;
+        // the late phase's values travel packed (a few MB per step instead of the row range of all 135 columns) and are scattered on the device
+        if (rc == 0 && v->late_count) {
+            const size_t pos_words = (v->late_count + 1) / 2;
+            if (!(v->late_vals = static_cast<u64*>(vpbs_host_alloc(8 * std::max(v->late_count, pos_words))))) rc = VPBS_ERR_OOM;
+            if (rc == 0) rc = vpbs_device_alloc(ctx, pos_words, &v->d_late_pos);
+            if (rc == 0) rc = vpbs_device_alloc(ctx, v->late_count, &v->d_late_stage);
+            if (rc == 0) rc = vpbs_witness_plan_late_positions(v->cyc.plan, reinterpret_cast<uint32_t*>(v->late_vals));
+            if (rc == 0) rc = vpbs_device_upload(ctx, v->d_late_pos, v->late_vals, pos_words);
+        }
         if (rc != 0) v->err = "wire matrices: out of (pinned or device) memory";
     }
     if (rc == 0) {
@@ -411,12 +427,12 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         std::copy(proof.begin(), proof.end(), r.values.begin());
         vpbs_witness_state* st = r.state;
         r.state = nullptr;
-        rc = vpbs_witness_plan_run_late(cyc.plan, st, r.values.data(), v->bufs[r.buf], e, sizeof e);   // consumes the state, also when it fails
+        rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, r.values.data(), v->late_vals, e, sizeof e);   // consumes the state, also when it fails
         if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
         t_late += now() - t;
         t = now();
-        rc = vpbs_device_upload_rows(ctx, v->d_bufs[r.buf], v->bufs[r.buf], cyc.n_wires, cyc.n, v->late_rows[0], v->late_rows[1]);
-        if (rc != 0) return stop(std::string("upload of the late rows: ") + vpbs_last_error(ctx), rc);
+        rc = vpbs_device_scatter(ctx, v->d_bufs[r.buf], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
+        if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
         t_rows += now() - t;
         t = now();
         pis = std::move(r.pis);

@@ -1087,8 +1087,8 @@ int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const ui
     return run_early_impl(plan, preset_val, threads, wires_out, true, state_out, err, err_len);
 }
 
-int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
-                               char* err, size_t err_len) {
+static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
+                         bool packed, char* err, size_t err_len) {
     using namespace vpbs;
     if (!plan || !plan->is_split || !state || !preset_val || !wires_out) {
         report(err, err_len, "malformed arguments");
@@ -1114,7 +1114,7 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
         const size_t cnt = p.late_out.size();
         for (size_t k = cnt * t / of, hi = cnt * (t + 1) / of; k < hi; ++k) {
             const u32 slot = p.out_slot[p.late_out[k]];
-            wires_out[p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
+            wires_out[packed ? k : p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
         }
     };
     const int rc = msg.empty() ? run_levels(p, 1, s, late_threads, scatter, msg) : VPBS_ERR_INVALID;
@@ -1147,6 +1147,21 @@ int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state
     report(err, err_len, msg);
     delete state;
     return rc;
+}
+
+int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
+                               char* err, size_t err_len) {
+    return run_late_impl(plan, state, preset_val, wires_out, false, err, err_len);
+}
+int vpbs_witness_plan_run_late_packed(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val,
+                                      uint64_t* values_out, char* err, size_t err_len) {
+    return run_late_impl(plan, state, preset_val, values_out, true, err, err_len);
+}
+size_t vpbs_witness_plan_late_count(const vpbs_witness_plan* plan) { return plan && plan->is_split ? plan->late_out.size() : 0; }
+int vpbs_witness_plan_late_positions(const vpbs_witness_plan* plan, uint32_t* out) {
+    if (!plan || !plan->is_split || !out) return VPBS_ERR_INVALID;
+    for (size_t k = 0; k < plan->late_out.size(); ++k) out[k] = (uint32_t)plan->out_pos[plan->late_out[k]];
+    return VPBS_OK;
 }
 
 void vpbs_witness_state_free(vpbs_witness_state* state) { delete state; }
