@@ -527,3 +527,27 @@ def test_ivc_chain_tool_sharded_over_two_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1
+
+
+def test_bench_contract_with_two_ranks_sharing_the_gpu():
+    """The driver's multi-GPU launch of bench.py (torch.distributed.run, one rank per GPU, replicas: independent chains per rank, no
+    data-path collective) with both ranks on the one device of the test box (--device 0, gloo for the barriers): ONE JSON line from rank 0,
+    n_gpus = 2, exactly --steps timed chained steps, value = the chains of BOTH ranks over the slower rank's time, every chain's last proof
+    checked after the clock."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", entry.ROOT + "/bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--device", "0",
+                        "--dist-backend", "gloo", "--chains", "1"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["vs_baseline"]) == (2, 12, 2, "weak", None)
+    assert d["config"]["chains_per_gpu"] == 1 and "vpbs_ivc_prove_pbs" in d["config"]["workload"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 * d["value"] + 1e-12       # both ranks' chains over the MAX time
+    assert d["roofline"]["bound"] == "int-valu-issue" and d["chain_checks"]["proof_bytes"] == 192716
+    assert "cpu_baseline" not in d                                                              # N = 1 only
