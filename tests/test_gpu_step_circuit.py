@@ -551,3 +551,13 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 * d["value"] + 1e-12       # both ranks' chains over the MAX time
     assert d["roofline"]["bound"] == "int-valu-issue" and d["chain_checks"]["proof_bytes"] == 192716
     assert "cpu_baseline" not in d                                                              # N = 1 only
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- in its own process (it opens its own context)"""
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=entry.ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("smoke ok") >= 2
