@@ -964,8 +964,8 @@ def main():
                          "profiling scripts); with ivc it is still measured and reported as step_micro")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("VPBS_BENCH_CHAINS", "0")),
                     help="ivc workload: independent vPBS chains (own keys, context, witness plans, host threads) proven side by side per GPU.  "
-                         "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default (0 = auto) is 4 where "
-                         "this rank's share of the host CPUs carries it (a chain keeps about four host threads busy), fewer on a small CPU "
+                         "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default (0 = auto) is 6 where "
+                         "this rank's share of the host CPUs carries it (three chains per eight CPUs, measured), fewer on a small CPU "
                          "quota (the single-chain latency figure is reported next to it as ivc_single_chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
@@ -1013,7 +1013,9 @@ def main():
     secondary = rank == 0 and world == 1 and log_n == LOG_N
     if args.chains <= 0:
         cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)      # this rank's share of the CPUs the container may use
-        args.chains = max(1, min(4, cpus // 4))
+        # measured on the 16-CPU quota of the GPU boxes (tools/experiments/chains_ab.sh): 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 /
+        # 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof -- six chains, i.e. three chains per eight CPUs of the rank's share
+        args.chains = max(1, min(6, (3 * cpus) // 8))
 
     out, state = None, None
     if args.workload == "ivc":
