@@ -351,6 +351,15 @@ void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state t
  * words in place.  The host matrix of the early phase is not touched.  Consumes the state like vpbs_witness_plan_run_late. */
 int vpbs_witness_plan_run_late_packed(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val,
                                       uint64_t* values_out /* [late_count] */, char* err, size_t err_len);
+/* The late phase on its own, for a host whose EARLY phase ran elsewhere (on the device, in batches: vpbs_witness_device_create_early): the
+ * early-known values the late phase touches -- what its generators read, what they write as comparers -- are `late_input_count` values, one
+ * per copy class, listed by a wire position each (vpbs_witness_plan_late_input_positions: column * n + row); a state seeded with them
+ * (vpbs_witness_state_from_late_inputs, values in that order, canonical) is what vpbs_witness_plan_run_late[_packed] then consumes, exactly
+ * as if vpbs_witness_plan_run_early had produced it. */
+size_t vpbs_witness_plan_late_input_count(const vpbs_witness_plan* plan);   /* 0 before the split */
+int vpbs_witness_plan_late_input_positions(const vpbs_witness_plan* plan, uint32_t* out /* [late_input_count] */);
+int vpbs_witness_state_from_late_inputs(const vpbs_witness_plan* plan, const uint64_t* values /* [late_input_count] */,
+                                        vpbs_witness_state** state_out);
 size_t vpbs_witness_plan_late_count(const vpbs_witness_plan* plan);   /* 0 before the split */
 int vpbs_witness_plan_late_positions(const vpbs_witness_plan* plan, uint32_t* out /* [late_count] */);
 /* out = {row_lo, row_hi}: every wire position run_late writes lies in rows [row_lo, row_hi) -- what has to be uploaded again when the

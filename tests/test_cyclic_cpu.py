@@ -120,6 +120,8 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
         early_values[:cy.shape.proof_words] = 0xDEAD                  # the late entries are not read by the early phase
         two = np.empty_like(wires)
         state = split.run_early(early_values, two)
+        seeded = split.state_from_late_inputs(two.reshape(-1)[split.late_input_positions()])   # what a device-side early phase hands over
+        assert (split.run_late_packed(seeded, values) == wires.reshape(-1)[split.late_positions()]).all()
         assert (split.run_late(state, values, two) == wires).all()
         if cond:   # a proof with one flipped word makes the late phase fail (its generators run on several threads), whatever the word
             bad = values.copy()

@@ -269,6 +269,16 @@ def test_split_plan_levels_threads_and_concurrent_runs():
     assert (packed == want.reshape(-1)[pos]).all()
     out.reshape(-1)[pos] = packed
     assert (out == want).all()                                              # early matrix + scattered late values = the witness
+    # the late phase seeded from outside (an early phase that ran elsewhere, e.g. on the device): the early-known values it touches, read
+    # from the early matrix at late_input_positions(), give the same late values
+    lin = plan.late_input_positions()
+    assert lin.size and (lin != 0xFFFFFFFF).all() and np.unique(lin).size == lin.size
+    st2 = plan.state_from_late_inputs(early_matrix.reshape(-1)[lin])
+    assert (plan.run_late_packed(st2, v) == packed).all()
+    bad_in = early_matrix.reshape(-1)[lin].copy()
+    bad_in[0] = np.uint64(P)                                                # not canonical
+    with pytest.raises(api.VpbsError):
+        plan.state_from_late_inputs(bad_in)
     # a recycled matrix (it holds the previous run's result): only the positions that carry values are rewritten
     v = vals(presets(77, 4))
     plan.run_late(plan.run_early(v, out, recycled=True), v, out)

@@ -225,6 +225,9 @@ SIGNATURES = {
     "vpbs_witness_state_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_run_late_packed": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_late_count": (_sz, [C.c_void_p]),
+    "vpbs_witness_plan_late_input_count": (_sz, [C.c_void_p]),
+    "vpbs_witness_plan_late_input_positions": (_i, [C.c_void_p, U32P]),
+    "vpbs_witness_state_from_late_inputs": (_i, [C.c_void_p, U64P, C.POINTER(C.c_void_p)]),
     "vpbs_witness_plan_late_positions": (_i, [C.c_void_p, U32P]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
@@ -568,6 +571,22 @@ class WitnessPlan:
         if lib().vpbs_witness_plan_run_late_packed(self.h, state, _ptr(val), _ptr(out), err, 512):
             raise VpbsError("vpbs_witness_plan_run_late_packed: " + err.value.decode())
         return out
+
+    def late_input_positions(self):
+        """-> uint32 wire positions, one per early-known copy class the late phase touches (vpbs_witness_plan_late_input_positions)"""
+        out = np.zeros(int(lib().vpbs_witness_plan_late_input_count(self.h)), np.uint32)
+        if lib().vpbs_witness_plan_late_input_positions(self.h, out.ctypes.data_as(U32P)):
+            raise VpbsError("vpbs_witness_plan_late_input_positions: the plan is not split")
+        return out
+
+    def state_from_late_inputs(self, values):
+        """a late-phase state seeded with the values of late_input_positions() (an early phase that ran elsewhere) -> state for run_late"""
+        val = _u64(values)
+        assert val.size == int(lib().vpbs_witness_plan_late_input_count(self.h))
+        st = C.c_void_p()
+        if lib().vpbs_witness_state_from_late_inputs(self.h, _ptr(val), C.byref(st)):
+            raise VpbsError("vpbs_witness_state_from_late_inputs failed (plan not split, or a non-canonical value)")
+        return st
 
     def late_positions(self):
         """-> uint32 wire positions (column * n + row) the late phase writes (vpbs_witness_plan_late_positions)"""

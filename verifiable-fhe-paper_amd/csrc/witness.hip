@@ -93,18 +93,26 @@ struct SlotRow {
 
 // Levels and typed operation lists for the device (see vpbs_witness_plan::DeviceSchedule).  step_out: the slots every step of the
 // schedule writes, in the order the generator sets them.
-void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_out, const std::vector<u32>& step_out_w,
-                           const std::vector<u32>& step_out_off) {
+// skip_step / skip_preset (nullable): the steps and presets of the late phase, left out of the early-only schedule (such a preset is routed
+// to the scratch slot n_slots, which nothing reads).
+void build_device_schedule(vpbs_witness_plan& p, vpbs_witness_plan::DeviceSchedule& d, const std::vector<u32>& step_out,
+                           const std::vector<u32>& step_out_w, const std::vector<u32>& step_out_off, const uint8_t* skip_step = nullptr,
+                           const uint8_t* skip_preset = nullptr) {
     using Plan = vpbs_witness_plan;
-    Plan::DeviceSchedule& d = p.dev;
+    d = Plan::DeviceSchedule{};
     constexpr u32 CHECK = Plan::CHECK, UNSET = 0xFFFFFFFFu;
-    if (p.n_slots >= CHECK) {
+    if (p.n_slots + 1 >= CHECK) {
         d.unsupported = "too many value slots";
         return;
     }
     std::vector<u32> level(p.n_slots, UNSET);  // the level at which a slot gets its value
     d.preset_slot = p.preset_slot;
-    for (u32& s : d.preset_slot) {
+    for (size_t i = 0; i < d.preset_slot.size(); ++i) {
+        u32& s = d.preset_slot[i];
+        if (skip_preset && skip_preset[i]) {
+            s = (u32)p.n_slots;
+            continue;
+        }
         if (level[s] != UNSET) s |= CHECK;
         else level[s] = 0;
     }
@@ -122,6 +130,7 @@ void build_device_schedule(vpbs_witness_plan& p, const std::vector<u32>& step_ou
     std::vector<unsigned> deps;
     u32 max_level = 0;
     for (size_t i = 0; i < p.schedule.size(); ++i) {
+        if (skip_step && skip_step[i]) continue;
         const auto& st = p.schedule[i];
         const u32* outs = step_out.data() + step_out_off[i];
         const u32 n_outs = step_out_off[i + 1] - step_out_off[i];
@@ -368,7 +377,10 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
         for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot, &step_out})
             for (u32& s : *v) s = renum[s];
     }
-    build_device_schedule(p, step_out, step_out_w, step_out_off);
+    build_device_schedule(p, p.dev, step_out, step_out_w, step_out_off);
+    p.step_out = std::move(step_out);
+    p.step_out_w = std::move(step_out_w);
+    p.step_out_off = std::move(step_out_off);
     *out = plan.release();
     return VPBS_OK;
 }
@@ -682,6 +694,25 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     p.late_out.clear();
     for (size_t i = 0; i < p.out_slot.size(); ++i)
         if (taint[p.out_slot[i]]) p.late_out.push_back((u32)i);
+    // the early-known values the late phase touches: what its steps read, what they write as comparers, what late presets are compared with
+    {
+        std::vector<uint8_t> seen(p.n_slots, 0);
+        p.late_in_slots.clear();
+        auto touch = [&](u32 slot) {
+            if (!taint[slot] && !seen[slot]) {
+                seen[slot] = 1;
+                p.late_in_slots.push_back(slot);
+            }
+        };
+        for (size_t i = 0; i < p.preset_slot.size(); ++i)
+            if (late[i]) touch(p.preset_slot[i]);
+        for (size_t i = 0; i < p.schedule.size(); ++i)
+            if (p.step_late[i])
+                for (u32 k = step_io_off[i]; k < step_io_off[i + 1]; ++k) touch(step_io[k]);
+        std::sort(p.late_in_slots.begin(), p.late_in_slots.end());
+    }
+    // the early phase alone as a device schedule (vpbs_witness_device_create_early)
+    build_device_schedule(p, p.dev_early, p.step_out, p.step_out_w, p.step_out_off, p.step_late.data(), p.preset_late.data());
     if (std::getenv("VPBS_TRACE_WITNESS")) {
         std::vector<uint8_t> row_late(p.n, 0);
         for (u32 i : p.late_out) row_late[p.out_pos[i] % p.n] = 1;
@@ -1161,6 +1192,32 @@ size_t vpbs_witness_plan_late_count(const vpbs_witness_plan* plan) { return plan
 int vpbs_witness_plan_late_positions(const vpbs_witness_plan* plan, uint32_t* out) {
     if (!plan || !plan->is_split || !out) return VPBS_ERR_INVALID;
     for (size_t k = 0; k < plan->late_out.size(); ++k) out[k] = (uint32_t)plan->out_pos[plan->late_out[k]];
+    return VPBS_OK;
+}
+
+size_t vpbs_witness_plan_late_input_count(const vpbs_witness_plan* plan) { return plan && plan->is_split ? plan->late_in_slots.size() : 0; }
+int vpbs_witness_plan_late_input_positions(const vpbs_witness_plan* plan, uint32_t* out) {
+    if (!plan || !plan->is_split || !out) return VPBS_ERR_INVALID;
+    // one wire position per slot: the first of its copy class (out_pos is ascending)
+    std::vector<vpbs::u32> first(plan->n_slots, 0xFFFFFFFFu);
+    for (size_t i = plan->out_slot.size(); i-- > 0;) first[plan->out_slot[i]] = plan->out_pos[i];
+    for (size_t k = 0; k < plan->late_in_slots.size(); ++k) out[k] = first[plan->late_in_slots[k]];
+    return VPBS_OK;
+}
+int vpbs_witness_state_from_late_inputs(const vpbs_witness_plan* plan, const uint64_t* values, vpbs_witness_state** state_out) {
+    using namespace vpbs;
+    if (!plan || !plan->is_split || !state_out || (!values && !plan->late_in_slots.empty())) return VPBS_ERR_INVALID;
+    const vpbs_witness_plan& p = *plan;
+    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
+    for (size_t k = 0; k < p.late_in_slots.size(); ++k) {
+        if (values[k] >= gl::P) {
+            delete st;
+            return VPBS_ERR_INVALID;
+        }
+        st->s.val[p.late_in_slots[k]] = values[k];
+        st->s.is_set[p.late_in_slots[k]] = 1;
+    }
+    *state_out = st;
     return VPBS_OK;
 }
 

@@ -268,4 +268,12 @@ struct vpbs_witness_plan {
         std::vector<u32> row_slots;             // copy of row_slots with CHECK marks on outputs that compare
         std::vector<u32> preset_slot;           // with CHECK marks (a target preset twice)
     } dev;
+    // After vpbs_witness_plan_split: the schedule of the EARLY phase alone (late steps left out, late presets routed to the scratch slot
+    // n_slots), for a host that generates the early part of a chain's witnesses on the device in batches and runs only the late phase --
+    // the part that needs the previous proof -- on its CPUs; and the early-known slots that late phase touches (reads, or writes as a
+    // comparer), which such a host reads back per instance to seed the late phase's state.
+    DeviceSchedule dev_early;
+    std::vector<u32> late_in_slots;
+    // what every scheduled step writes (slots; wire index for row steps, NONE for gadget outputs): kept for building dev_early
+    std::vector<u32> step_out, step_out_w, step_out_off;
 };
