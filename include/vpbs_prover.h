@@ -382,6 +382,15 @@ int vpbs_witness_plan_stats(const vpbs_witness_plan* plan, uint64_t out[4]);
  * overlap with other work of the same process. */
 typedef struct vpbs_witness_device vpbs_witness_device;
 int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out);
+/* The EARLY phase of a split plan alone (vpbs_witness_plan_split), for a chain whose steps take the previous proof as a late input: the
+ * early parts of a batch of steps are generated here ahead of the chain -- every step's early presets must be known up front, i.e. the
+ * host computes the chain's public inputs natively (vpbs_pbs_accumulator_chain, vpbs_hash_chain) -- the late presets' entries of
+ * preset_val are ignored.  Per step the host then gathers the instance's wires into the device matrix (vpbs_witness_device_wires: late
+ * positions hold zeros), reads back the early values its late phase needs (vpbs_witness_device_read_late_inputs, the order of
+ * vpbs_witness_plan_late_input_positions) and runs vpbs_witness_state_from_late_inputs + vpbs_witness_plan_run_late_packed +
+ * vpbs_device_scatter: the early phase costs no host CPU and its 70 MB matrix never crosses PCIe. */
+int vpbs_witness_device_create_early(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out);
+int vpbs_witness_device_read_late_inputs(vpbs_witness_device* dev, unsigned instance, uint64_t* out /* host [late_input_count] */);
 int vpbs_witness_device_run(vpbs_witness_device* dev, const uint64_t* preset_val, unsigned batch);
 /* gathers instance `instance` of the last run into d_wires (device, [n_wires][n], fully written) */
 int vpbs_witness_device_wires(vpbs_witness_device* dev, unsigned instance, uint64_t* d_wires);

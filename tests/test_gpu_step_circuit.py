@@ -561,3 +561,48 @@ def test_graft_entry_smoke_runs():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=entry.ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("smoke ok") >= 2
+
+
+@pytest.mark.parametrize("N,n_lwe,log_n,batch", [(8, 6, 13, 3), (1024, 728, 16, 2)])
+def test_device_early_phase_of_the_cyclic_circuit(ctx, N, n_lwe, log_n, batch):
+    """vpbs_witness_device_create_early: the EARLY phase of the split cyclic-circuit plan (everything that does not need the previous proof)
+    for a batch of steps on the device.  Per instance: the gathered matrix equals the host's early matrix (late positions zero), and the
+    values read back for the host's late phase (vpbs_witness_device_read_late_inputs) are the host early phase's -- so a late phase seeded
+    with them produces the same packed late values.  The late presets' rows of the batch are garbage on purpose."""
+    import torch
+    from vpbs_amd import circuit_file
+    K, ELL, LOGB = 2, 4, 5
+    cyc, _ = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    W, n_pi = cyc.meta["proof_words"], len(cyc.pi_pos)
+    plan = cyc.circuit.witness_plan(cyc.preset_pos)
+    late = np.zeros(len(cyc.preset_pos), np.uint8)
+    late[:W] = 1
+    plan.split(late)
+    rng = np.random.default_rng(N)
+    fe = lambda k: rng.integers(0, int(P), size=k, dtype=np.uint64)
+    g = K * ELL * K * N
+    own_vk, dummy_vk, dummy_proof = fe(68), fe(68), fe(W)
+    cols = []
+    for i in range(batch):
+        inner_pis = fe(n_pi)
+        inner_pis[-68:] = own_vk                                             # connected to the circuit's own verifier data
+        cols.append(np.concatenate([fe(W), inner_pis, np.array([i % 2], np.uint64), fe(g), fe(1), own_vk, dummy_vk, dummy_proof,
+                                    np.zeros(n_pi, np.uint64)]))
+    values = np.ascontiguousarray(np.stack(cols, axis=1))
+    assert values.shape == (len(cyc.preset_pos), batch)
+    dev = api.WitnessDevice(ctx, plan, max_batch=4, early=True)
+    dev.run(values)
+    d_wires = torch.zeros((135, cyc.n), dtype=torch.int64, device="cuda")
+    lin, lpos = plan.late_input_positions(), plan.late_positions()
+    for i in range(batch):
+        host = np.zeros((135, cyc.n), np.uint64)
+        state = plan.run_early(values[:, i], host)
+        dev.wires(i, d_wires.data_ptr())
+        got = d_wires.cpu().numpy().view(np.uint64)
+        assert (got == host).all(), (i, np.argwhere(got != host)[:5])
+        assert (got.reshape(-1)[lpos] == 0).all()
+        seed = dev.read_late_inputs(i)
+        assert (seed == host.reshape(-1)[lin]).all()
+        api.lib().vpbs_witness_state_free(state)
+    dev.free()
+    plan.free()

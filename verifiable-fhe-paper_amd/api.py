@@ -231,6 +231,8 @@ SIGNATURES = {
     "vpbs_witness_plan_late_positions": (_i, [C.c_void_p, U32P]),
     "vpbs_witness_plan_stats": (_i, [C.c_void_p, U64P]),
     "vpbs_witness_device_create": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
+    "vpbs_witness_device_create_early": (_i, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
+    "vpbs_witness_device_read_late_inputs": (_i, [C.c_void_p, C.c_uint, U64P]),
     "vpbs_witness_device_run": (_i, [C.c_void_p, U64P, C.c_uint]),
     "vpbs_witness_device_wires": (_i, [C.c_void_p, C.c_uint, C.c_void_p]),
     "vpbs_witness_device_read": (_i, [C.c_void_p, C.c_uint, U32P, _sz, U64P]),
@@ -624,11 +626,18 @@ class WitnessPlan:
 class WitnessDevice:
     """vpbs_witness_device: the plan's schedule replayed on the device for a batch of PartialWitnesses (create once per circuit)."""
 
-    def __init__(self, ctx, plan, max_batch):
+    def __init__(self, ctx, plan, max_batch, early=False):
+        """early: the early phase of a split plan alone (vpbs_witness_device_create_early); the late presets' rows of `values` are ignored"""
         self.ctx, self.plan, self.max_batch = ctx, plan, max_batch
         h = C.c_void_p()
-        ctx._check(lib().vpbs_witness_device_create(ctx.h, plan.h, max_batch, C.byref(h)))
+        ctx._check((lib().vpbs_witness_device_create_early if early else lib().vpbs_witness_device_create)(ctx.h, plan.h, max_batch, C.byref(h)))
         self.h = h
+
+    def read_late_inputs(self, instance):
+        """the early values the host's late phase needs of one instance, in the order of plan.late_input_positions()"""
+        out = np.zeros(int(lib().vpbs_witness_plan_late_input_count(self.plan.h)), np.uint64)
+        self.ctx._check(lib().vpbs_witness_device_read_late_inputs(self.h, instance, _ptr(out)))
+        return out
 
     def run(self, values):
         """values: [n_preset][batch] (rows in the order of the plan's positions)"""

@@ -240,6 +240,8 @@ template <class T> T* upload(vpbs_ctx* c, const std::vector<T>& h, std::vector<v
 struct vpbs_witness_device {
     vpbs_ctx* ctx = nullptr;
     const vpbs_witness_plan* plan = nullptr;
+    const vpbs_witness_plan::DeviceSchedule* ds = nullptr;   // plan->dev, or plan->dev_early (the early phase of a split plan alone)
+    const vpbs::u32* late_in = nullptr;                      // early-only objects: the slots the host's late phase wants back (device copy)
     unsigned max_batch = 0, batch = 0;
     std::vector<void*> owned;
     vpbs::u64* val = nullptr;
@@ -261,7 +263,7 @@ struct vpbs_witness_device {
 namespace vpbs {
 namespace {
 void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
-    const Plan::DeviceSchedule& ds = d->plan->dev;
+    const Plan::DeviceSchedule& ds = *d->ds;
     auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
     if (!ds.consts.empty())
         hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
@@ -289,17 +291,19 @@ void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
 
 extern "C" {
 
-int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
-    if (!ctx || !plan || !out || max_batch == 0) return VPBS_ERR_INVALID;
+static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, bool early, vpbs_witness_device** out) {
+    if (!ctx || !plan || !out || max_batch == 0 || (early && !plan->is_split)) return VPBS_ERR_INVALID;
     try {
         VPBS_HIP(hipSetDevice(ctx->device));
-        VPBS_REQUIRE(plan->dev.supported, ("this circuit has no device witness generator: " + plan->dev.unsupported).c_str());
+        const auto& ds = early ? plan->dev_early : plan->dev;
+        VPBS_REQUIRE(ds.supported, ("this circuit has no device witness generator: " + ds.unsupported).c_str());
         auto d = std::make_unique<vpbs_witness_device>();
         d->ctx = ctx;
         d->plan = plan;
+        d->ds = &ds;
         d->max_batch = max_batch;
-        const auto& ds = plan->dev;
         using namespace vpbs;
+        if (early) d->late_in = upload(ctx, plan->late_in_slots, d->owned);
         d->arith = upload(ctx, ds.arith, d->owned);
         d->consts = upload(ctx, ds.consts, d->owned);
         d->bits = upload(ctx, ds.bits, d->owned);
@@ -326,7 +330,7 @@ int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, uns
                 --l;
             d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
         }
-        d->val = ctx->alloc_words(plan->n_slots * (size_t)max_batch);
+        d->val = ctx->alloc_words((plan->n_slots + 1) * (size_t)max_batch);   // + the scratch slot late presets are routed to
         d->owned.push_back(d->val);
         d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
         d->owned.push_back(d->err);
@@ -337,6 +341,13 @@ int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, uns
         ctx->err = e.what;
         return e.status;
     }
+}
+
+int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
+    return device_create(ctx, plan, max_batch, false, out);
+}
+int vpbs_witness_device_create_early(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out) {
+    return device_create(ctx, plan, max_batch, true, out);
 }
 
 void vpbs_witness_device_free(vpbs_witness_device* d) {
@@ -359,7 +370,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         hipStream_t s = ctx->stream;
         const size_t n_preset = d->plan->preset_slot.size();
         d->batch = batch;
-        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * d->plan->n_slots * batch, s));
+        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, s));
         VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
         if (n_preset) {
             d_vals = ctx->alloc_words(n_preset * batch);
@@ -426,6 +437,32 @@ int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_
         VPBS_HIP(hipStreamSynchronize(ctx->stream));
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_read_late_inputs(vpbs_witness_device* d, unsigned instance, uint64_t* out) {
+    if (!d || !d->late_in || !out) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
+    const size_t count = d->plan->late_in_slots.size();
+    if (count == 0) return VPBS_OK;
+    vpbs::u64* d_out = nullptr;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        d_out = ctx->alloc_words(count);
+        hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->late_in, (u32)count, d->batch,
+                           instance, d_out);
+        VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
+        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(d_out);
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_out) ctx->release(d_out);
         ctx->err = e.what;
         return e.status;
     }
