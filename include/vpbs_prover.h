@@ -68,6 +68,7 @@ int vpbs_host_set_poseidon_x8(int on);
 /* the FriConfig shape the context was created for (vpbs_ctx_create's rate_bits / cap_height); 0 for a null context */
 unsigned vpbs_ctx_rate_bits(const vpbs_ctx* ctx);
 unsigned vpbs_ctx_cap_height(const vpbs_ctx* ctx);
+int vpbs_ctx_device(const vpbs_ctx* ctx);   /* the device ordinal the context was created on; -1 for a null context */
 
 /* ---- compatibility switch table ----
  * plonky2 0.2.0 is an un-vendored dependency of the reference (/root/reference/Cargo.lock:371-374) and cannot be run in the authoring image,
@@ -603,6 +604,15 @@ void vpbs_ivc_free(vpbs_ivc* ivc);
  * its clock with it -- bench.py times K chained steps after W warm-up steps between done == W and the return -- or reports progress.  The
  * early witness phases of later steps keep running on their own threads while the hook runs (that pipelining is the design, not warm-up).
  * NULL removes the hook. */
+/* The early witness phases on the DEVICE: batch > 0 switches vpbs_ivc_prove_pbs to a pipeline in which the host runs only the late phase
+ * (the in-circuit verifier's rows, which need the previous proof).  What a step's early phase needs of its predecessor are the
+ * predecessor's public inputs, and those are known without proving anything -- accumulators from vpbs_pbs_accumulator_chain (hence ELL and
+ * LOGB here), the two chain hashes from the native sponge (one host thread), counter, verifier data -- so the early phases of `batch`
+ * consecutive steps are generated at once by two early-only device objects on contexts of their own (vpbs_witness_device_create_early),
+ * gathered per step into the matrix the prover reads, and only the early values the late phase touches come back to the host.  The 70 MB
+ * matrix of a step no longer crosses PCIe and a chain needs about one host CPU instead of five; the proofs are the same bytes.  A batch of
+ * 32 costs 2 x 160 MB of device memory at the paper's parameters.  batch = 0 returns to the host pipeline. */
+int vpbs_ivc_set_device_witness(vpbs_ivc* ivc, unsigned ELL, unsigned LOGB, unsigned batch);
 typedef void (*vpbs_ivc_step_fn)(void* user, unsigned done);
 int vpbs_ivc_set_step_callback(vpbs_ivc* ivc, vpbs_ivc_step_fn fn, void* user);
 /* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */

@@ -606,3 +606,48 @@ def test_device_early_phase_of_the_cyclic_circuit(ctx, N, n_lwe, log_n, batch):
         api.lib().vpbs_witness_state_free(state)
     dev.free()
     plan.free()
+
+
+def test_ivc_chain_with_the_early_phases_on_the_device():
+    """vpbs_ivc_set_device_witness: the chain with the early witness phases generated on the device in batches (the host keeps the late
+    phase): the N = 8 chain ends in the frozen bytes of the CPU oracle's chain -- with a batch smaller than the chain, equal to it and larger
+    -- and going back to the host pipeline on the same object gives them again; at the paper's parameters a prefix of the chain (two
+    batches) passes the checks of verify_pbs's prefix form."""
+    import hashlib
+    import json
+    import sys
+    import __graft_entry__ as entry
+    from test_cyclic_cpu import GOLDEN_CHAIN, n8_chain_inputs
+    from vpbs_amd import circuit_file
+    N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
+    ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
+    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    c = vpbs_amd.Context(0, log_n_max=16)
+    ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
+    frozen = json.load(open(GOLDEN_CHAIN))
+    bsk_flat, ksk_flat = np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk)
+    for batch in (2, 3, 8, 0):
+        ivc.set_device_witness(ELL, LOGB, batch)
+        blob, t = ivc.prove_pbs(testv, ct, bsk_flat, ksk_flat)
+        assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"]), batch
+    with pytest.raises(api.VpbsError):
+        ivc.set_device_witness(ELL + 1, LOGB, 4)                      # does not fit the GGSW length of the circuit
+    ivc.free()
+    c.close()
+    # paper parameters: 7 chained steps in batches of 3 through the tool's checks (accumulator, counter, both hash-chain prefixes, verifier data)
+    sys.path.insert(0, entry.ROOT + "/tools")
+    import prove_ivc
+    N, n_lwe, log_n, steps = 1024, 728, 16, 7
+    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    c = vpbs_amd.Context(0, log_n_max=16)
+    ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
+    ivc.set_device_witness(ELL, LOGB, 3)
+    keys = c.keygen(N, K, ELL, LOGB, n_lwe, 5, 4.99027217501041e-8, 1.17021618159313e-5)
+    tv, delta = api.testv(N, 2)
+    ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
+    blob, t = ivc.prove_pbs(tv, ct, keys["bsk"], keys["ksk"], steps)
+    vk, _ = ivc.verifier_data()
+    prove_ivc.check_chain(c, cyc, vk, blob, keys, tv, delta, ct, N, n_lwe, log_n, steps, 1)
+    assert t["steps"] == steps and t["early_witness_ms"] > 0
+    ivc.free()
+    c.close()

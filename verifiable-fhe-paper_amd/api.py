@@ -243,6 +243,8 @@ SIGNATURES = {
     "vpbs_ivc_free": (None, [_vp]),
     "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
     "vpbs_ivc_set_step_callback": (_i, [_vp, IVC_STEP_FN, _vp]),
+    "vpbs_ivc_set_device_witness": (_i, [_vp, _ui, _ui, _ui]),
+    "vpbs_ctx_device": (_i, [_vp]),
     "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
     "vpbs_verify_pbs": (_i, [C.POINTER(VerifyPbsInputsC), C.POINTER(C.c_uint8), _sz, C.c_char_p, _sz]),
     "vpbs_blind_rotate_step": (_i, [_vp, C.POINTER(TfheParamsC), _ui, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
@@ -748,6 +750,10 @@ class Ivc:
         a, b = np.zeros(self.vk_words, np.uint64), np.zeros(self.vk_words, np.uint64)
         lib().vpbs_ivc_verifier_data(self.h, _ptr(a), _ptr(b))
         return a, b
+
+    def set_device_witness(self, ELL, LOGB, batch):
+        """vpbs_ivc_set_device_witness: the early witness phases of `batch` steps at a time on the device (0: back to the host pipeline)"""
+        self.ctx._check(lib().vpbs_ivc_set_device_witness(self.h, ELL, LOGB, batch))
 
     def on_step(self, fn):
         """vpbs_ivc_set_step_callback: fn(done) runs on the proving thread with done = 0 after the base proof and 1 .. steps after each

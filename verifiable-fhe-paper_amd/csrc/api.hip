@@ -363,6 +363,7 @@ int vpbs_ctx_get_compat(const vpbs_ctx* c, vpbs_compat* out) {
 }
 unsigned vpbs_ctx_rate_bits(const vpbs_ctx* c) { return c ? c->rate_bits : 0; }
 unsigned vpbs_ctx_cap_height(const vpbs_ctx* c) { return c ? c->cap_height : 0; }
+int vpbs_ctx_device(const vpbs_ctx* c) { return c ? c->device : -1; }
 
 // shader clock of one CU over ~20 us: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
 __global__ void clock_probe_kernel(unsigned long long* out) {

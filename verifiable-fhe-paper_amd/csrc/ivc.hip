@@ -12,6 +12,7 @@
 //              thread U  vpbs_device_upload_bg         that matrix to the device while the previous step is being proven
 //              caller    vpbs_witness_plan_run_late -> vpbs_device_upload_rows -> vpbs_prove_step
 //            and the last proof serialised (ProofWithPublicInputs::to_bytes)
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -128,9 +129,28 @@ struct vpbs_ivc {
     vpbs_comm comm{};
     vpbs_ivc_step_fn step_fn = nullptr;
     void* step_user = nullptr;
+    // early witness phases on the device (vpbs_ivc_set_device_witness): two early-only device objects, each on a context of its own (their
+    // runs overlap with the prover's context and with each other's gathers), filled alternately with batches of `dw_batch` steps
+    unsigned dw_batch = 0, ELL = 0, LOGB = 0;
+    vpbs_ctx* wctx[2] = {nullptr, nullptr};
+    vpbs_witness_device* wdev[2] = {nullptr, nullptr};
+    u64* dw_presets = nullptr;   // pinned [n_preset][dw_batch]
+    size_t late_in_count = 0;
+    void drop_device_witness() {
+        for (int i = 0; i < 2; ++i) {
+            if (wdev[i]) vpbs_witness_device_free(wdev[i]);
+            if (wctx[i]) vpbs_ctx_destroy(wctx[i]);
+            wdev[i] = nullptr;
+            wctx[i] = nullptr;
+        }
+        if (dw_presets) vpbs_host_free(dw_presets);
+        dw_presets = nullptr;
+        dw_batch = 0;
+    }
     ~vpbs_ivc() {
         for (auto b : bufs)
             if (b) vpbs_host_free(b);
+        drop_device_witness();
         for (auto d : d_bufs)
             if (d) vpbs_device_free(ctx, d);
         if (base_wires) vpbs_host_free(base_wires);
@@ -258,6 +278,253 @@ int vpbs_ivc_verifier_data(const vpbs_ivc* v, uint64_t* cyclic_vk, uint64_t* dum
     return VPBS_OK;
 }
 
+int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsigned batch) {
+    if (!v) return VPBS_ERR_INVALID;
+    v->drop_device_witness();
+    if (batch == 0) return VPBS_OK;
+    if (ELL == 0 || LOGB == 0 || v->ggsw_len != (size_t)v->K * ELL * v->K * v->N) {
+        v->err = "device witness: ELL / LOGB do not fit the circuit's GGSW length";
+        return VPBS_ERR_INVALID;
+    }
+    int rc = VPBS_OK;
+    for (int i = 0; i < 2 && rc == 0; ++i) {
+        rc = vpbs_ctx_create(vpbs_ctx_device(v->ctx), v->cyc.log_n, vpbs_ctx_rate_bits(v->ctx), vpbs_ctx_cap_height(v->ctx), &v->wctx[i]);
+        if (rc == 0) rc = vpbs_witness_device_create_early(v->wctx[i], v->cyc.plan, batch, &v->wdev[i]);
+        if (rc != 0) v->err = std::string("device witness: ") + (v->wctx[i] ? vpbs_last_error(v->wctx[i]) : "no context");
+    }
+    if (rc == 0 && !(v->dw_presets = static_cast<u64*>(vpbs_host_alloc(8 * v->cyc.n_preset * (size_t)batch)))) {
+        v->err = "device witness: out of pinned memory";
+        rc = VPBS_ERR_OOM;
+    }
+    if (rc != 0) {
+        v->drop_device_witness();
+        return rc;
+    }
+    v->late_in_count = vpbs_witness_plan_late_input_count(v->cyc.plan);
+    v->ELL = ELL; v->LOGB = LOGB; v->dw_batch = batch;
+    return VPBS_OK;
+}
+
+// The chain with the early witness phases on the device.  What a step's early phase needs of its predecessor are the predecessor's PUBLIC
+// INPUTS, and those are known without proving anything: the accumulators from the native chain (vpbs_pbs_accumulator_chain), the two chain
+// hashes from the native sponge (one host thread walks them ahead of the batches), counter and verifier data.  So the early phases of
+// `dw_batch` consecutive steps run on the device at once (thread B), a stager thread gathers an instance's wires into the device matrix
+// the prover will read and fetches the early values the late phase needs (thread S), and the caller is left with the late phase (the
+// in-circuit verifier's rows), the scatter of its values and the proof.
+static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,
+                                     unsigned steps, uint8_t* proof_out, size_t capacity, vpbs_ivc_timing* timing, char* err, size_t err_len) {
+    auto say = [&](const std::string& m) {
+        if (err && err_len) {
+            std::strncpy(err, m.c_str(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+    };
+    Side &cyc = v->cyc, &dum = v->dum;
+    vpbs_ctx* ctx = v->ctx;
+    const size_t kn = v->kn, n_pi = v->n_pi, proof_words = v->proof_words, ggsw_len = v->ggsw_len, n_preset = cyc.n_preset;
+    const unsigned B = v->dw_batch, total = n_lwe + 2;
+    const std::vector<u64> zero_ggsw(ggsw_len, 0);
+    auto ggsw_of = [&](unsigned s) { return s == 0 ? zero_ggsw.data() : (s <= n_lwe ? bsk + (size_t)(s - 1) * ggsw_len : ksk); };
+    auto mask_of = [&](unsigned s) { return s == 0 ? ct[n_lwe] : (s <= n_lwe ? ct[s - 1] : (u64)0); };
+    const double t0 = now();
+    // ---- the chain's public inputs, natively ----
+    std::vector<u64> acc_init(kn, 0), accs((size_t)total * kn);
+    std::memcpy(acc_init.data() + kn - v->N, testv, 8 * (size_t)v->N);
+    unsigned log_N = 0;
+    while ((1u << log_N) < v->N) ++log_N;
+    const vpbs_tfhe_params tp{log_N, v->K, v->ELL, v->LOGB};
+    if (vpbs_pbs_accumulator_chain(ctx, &tp, n_lwe, acc_init.data(), ct, bsk, ksk, accs.data()) != 0) {
+        say(std::string("native accumulator chain: ") + vpbs_last_error(ctx));
+        return VPBS_ERR_INVALID;
+    }
+    // pis[s + 1] = public inputs of step s (pis[0]: of the base proof): acc_init | counter | accumulator | key hash | LWE hash | verifier data
+    std::vector<u64> pis((size_t)(steps + 1) * n_pi, 0);
+    for (unsigned s = 0; s <= steps; ++s) {
+        u64* q = pis.data() + (size_t)s * n_pi;
+        std::memcpy(q, acc_init.data(), 8 * kn);
+        q[kn] = s;
+        if (s) std::memcpy(q + kn + 1, accs.data() + (size_t)(s - 1) * kn, 8 * kn);
+        std::memcpy(q + n_pi - cyc.vk.size(), cyc.vk.data(), 8 * cyc.vk.size());
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> failed{false};
+    std::string thread_err;
+    auto fail = [&](const std::string& m) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (thread_err.empty()) thread_err = m;
+        }
+        failed = true;
+        cv.notify_all();
+    };
+    unsigned hashed = 0;        // steps whose chain hashes are in pis (guarded by mu)
+    unsigned batches_run = 0;   // batches whose early phases are on the device
+    unsigned staged = 0;        // steps gathered and read back
+    unsigned consumed = 0;      // steps the caller has finished with (their device matrix is free again)
+    double t_early = 0;
+    // thread H: the two hash chains of verify_hash_output (:64-78), h_s = hash_no_pad(h_{s-1} || item_s), one permutation after the other
+    std::thread hasher([&] {
+        std::vector<u64> in(4 + ggsw_len), in2(5);
+        u64 hb[4] = {0, 0, 0, 0}, hl[4] = {0, 0, 0, 0};
+        for (unsigned s = 0; s < steps && !failed; ++s) {
+            std::memcpy(in.data(), hb, 32);
+            std::memcpy(in.data() + 4, ggsw_of(s), 8 * ggsw_len);
+            vpbs_hash_no_pad(in.data(), in.size(), hb);
+            std::memcpy(in2.data(), hl, 32);
+            in2[4] = mask_of(s);
+            vpbs_hash_no_pad(in2.data(), 5, hl);
+            u64* q = pis.data() + (size_t)(s + 1) * n_pi + 2 * kn + 1;
+            std::memcpy(q, hb, 32);
+            std::memcpy(q + 4, hl, 32);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                hashed = s + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    // thread B: batch b = steps [b B, (b + 1) B) on device object b & 1, once their public inputs exist and the object's previous batch is consumed
+    const unsigned n_batches = (steps + B - 1) / B;
+    std::thread batcher([&] {
+        for (unsigned b = 0; b < n_batches && !failed; ++b) {
+            const unsigned first = b * B, cnt = std::min(B, steps - first);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                // step s needs the public inputs of step s - 1: hashed >= first + cnt - 1; the object held batch b - 2
+                cv.wait(lk, [&] { return failed || (hashed + 1 >= first + cnt && (b < 2 || consumed >= (b - 1) * B)); });
+                if (failed) return;
+            }
+            const double t = now();
+            u64* m = v->dw_presets;   // [n_preset][cnt]: previous proof (late: ignored) | its public inputs | condition | GGSW | mask | vks | dummy proof | its pis
+            auto row = [&](size_t r) { return m + r * cnt; };
+            for (size_t r = 0; r < proof_words; ++r) std::memset(row(r), 0, 8 * cnt);
+            for (unsigned i = 0; i < cnt; ++i) {
+                const unsigned s = first + i;
+                const u64* q = pis.data() + (size_t)s * n_pi;
+                size_t r = proof_words;
+                for (size_t k = 0; k < n_pi; ++k) row(r++)[i] = q[k];
+                row(r++)[i] = s == 0 ? 0 : 1;
+                const u64* g = ggsw_of(s);
+                for (size_t k = 0; k < ggsw_len; ++k) row(r++)[i] = g[k];
+                row(r++)[i] = mask_of(s);
+                for (u64 x : cyc.vk) row(r++)[i] = x;
+                for (u64 x : dum.vk) row(r++)[i] = x;
+                for (u64 x : v->dummy_proof) row(r++)[i] = x;
+                for (size_t k = 0; k < n_pi; ++k) row(r++)[i] = 0;
+            }
+            if (vpbs_witness_device_run(v->wdev[b & 1], m, cnt) != 0)
+                return fail("early witness phases of steps " + std::to_string(first) + ".. on the device: " + vpbs_last_error(v->wctx[b & 1]));
+            t_early += now() - t;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                batches_run = b + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    // thread S: per step, the instance's wires into one of the device matrices and the late phase's inputs to the host
+    std::vector<std::vector<u64>> late_in(vpbs_ivc::NBUF, std::vector<u64>(v->late_in_count));
+    std::thread stager([&] {
+        for (unsigned s = 0; s < steps && !failed; ++s) {
+            const unsigned b = s / B, k = s % vpbs_ivc::NBUF;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || (batches_run > b && s < consumed + vpbs_ivc::NBUF); });
+                if (failed) return;
+            }
+            if (vpbs_witness_device_wires(v->wdev[b & 1], s % B, v->d_bufs[k]) != 0 ||
+                vpbs_witness_device_read_late_inputs(v->wdev[b & 1], s % B, late_in[k].data()) != 0)
+                return fail("gathering the early wires of step " + std::to_string(s) + ": " + vpbs_last_error(v->wctx[b & 1]));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                staged = s + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    auto stop = [&](const std::string& m, int rc) {
+        fail(m);
+        hasher.join();
+        batcher.join();
+        stager.join();
+        std::string first;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            first = thread_err;
+        }
+        say(first);
+        return (long)rc;
+    };
+    // cyclic_base_proof (:292-299)
+    char e[256] = {0};
+    vpbs_step_inputs in;
+    vpbs_step_sizes sz{};
+    if (vpbs_witness_plan_run(dum.plan, pis.data(), 0, v->base_wires, e, sizeof e) != 0) return stop(std::string("dummy witness: ") + e, VPBS_ERR_INVALID);
+    dum.step_inputs(in, v->base_wires, false, pis.data());
+    if (vpbs_step_sizes_get(ctx, &in, &sz) != 0 || 3 * sz.cap_words + sz.openings_words + sz.fri_words != proof_words)
+        return stop("the proof of this shape does not have the number of words the cyclic circuit expects", VPBS_ERR_INVALID);
+    std::vector<u64> values(n_preset, 0);   // run_late reads the late presets only: the previous proof's words, at the front
+    u64 *caps = values.data(), *openings = caps + 3 * sz.cap_words, *fri = openings + sz.openings_words;
+    int rc = dum.prove(in, caps, openings, fri);
+    if (rc != 0) return stop(std::string("base proof: ") + vpbs_last_error(ctx), rc);
+    const double t_base = now() - t0;
+    if (v->step_fn) v->step_fn(v->step_user, 0);
+    double t_late = 0, t_rows = 0, t_prove = 0;
+    for (unsigned s = 0; s < steps; ++s) {
+        const unsigned k = s % vpbs_ivc::NBUF;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || (staged > s && hashed > s); });   // its wires are in place, its own public inputs complete
+            if (failed) {
+                lk.unlock();
+                return stop("", VPBS_ERR_INVALID);
+            }
+        }
+        double t = now();
+        vpbs_witness_state* st = nullptr;
+        rc = vpbs_witness_state_from_late_inputs(cyc.plan, late_in[k].data(), &st);
+        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + ": the early values read back from the device are malformed", rc);
+        rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, values.data(), v->late_vals, e, sizeof e);
+        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+        t_late += now() - t;
+        t = now();
+        rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
+        if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
+        t_rows += now() - t;
+        t = now();
+        cyc.step_inputs(in, v->d_bufs[k], true, pis.data() + (size_t)(s + 1) * n_pi);
+        rc = cyc.prove(in, caps, openings, fri);
+        if (rc != 0) return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        t_prove += now() - t;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = s + 1;
+        }
+        cv.notify_all();
+        if (v->step_fn) v->step_fn(v->step_user, s + 1);
+    }
+    hasher.join();
+    batcher.join();
+    stager.join();
+    const double seconds = now() - t0;
+    const long n_bytes = vpbs_step_proof_to_bytes(ctx, &in, cyc.n_const_cols, caps, openings, fri, proof_out, capacity);
+    if (n_bytes <= 0) {
+        say("the output buffer is too small for the proof");
+        return VPBS_ERR_INVALID;
+    }
+    if (timing) {
+        timing->seconds = seconds;
+        timing->steps = steps;
+        timing->base_proof_ms = 1e3 * t_base;
+        timing->late_witness_ms = 1e3 * t_late / steps;
+        timing->late_rows_upload_ms = 1e3 * t_rows / steps;
+        timing->prove_step_ms = 1e3 * t_prove / steps;
+        timing->early_witness_ms = 1e3 * t_early / steps;
+    }
+    return n_bytes;
+}
+
 long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,
                         unsigned steps, uint8_t* proof_out, size_t capacity, vpbs_ivc_timing* timing, char* err, size_t err_len) {
     auto say = [&](const std::string& m) {
@@ -273,6 +540,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     }
     const unsigned total = n_lwe + 2;
     if (steps == 0 || steps > total) steps = total;
+    if (v->dw_batch) return prove_pbs_device_witness(v, testv, ct, bsk, ksk, n_lwe, steps, proof_out, capacity, timing, err, err_len);
     Side &cyc = v->cyc, &dum = v->dum;
     vpbs_ctx* ctx = v->ctx;
     const size_t kn = v->kn, n_pi = v->n_pi, proof_words = v->proof_words, ggsw_len = v->ggsw_len;
