@@ -25,18 +25,26 @@ struct Vals {
         if (x >= gl::P) x -= gl::P;
         u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
         if (slot & Plan::CHECK) {
-            if (*p != x) atomicOr(err, DE_SET_TWICE);
+            if (*p != x) {
+                atomicOr(err, DE_SET_TWICE);
+                atomicCAS(err + 1, 0u, (slot & ~Plan::CHECK) + 1);   // the first class caught (for the message)
+            }
         } else {
             *p = x;
         }
     }
 };
 
-__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch) {
+// compare_pass 0: the presets that write their class; 1: the ones that find it written (a class preset twice: the cyclic circuit's own verifier
+// data and the tail of the inner proof's public inputs) and compare -- in a launch of their own, after the writers
+__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch,
+                                                        u32 compare_pass) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
     if (gid >= (size_t)n_preset * batch) return;
+    const u32 slot = slots[gid / batch];
+    if (((slot & Plan::CHECK) != 0) != (compare_pass != 0)) return;
     const Vals a{v, err, batch, (u32)(gid % batch)};
-    a.set(slots[gid / batch], values[gid]);
+    a.set(slot, values[gid]);
 }
 
 __global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, u32 batch) {
@@ -241,6 +249,7 @@ struct vpbs_witness_device {
     vpbs_ctx* ctx = nullptr;
     const vpbs_witness_plan* plan = nullptr;
     const vpbs_witness_plan::DeviceSchedule* ds = nullptr;   // plan->dev, or plan->dev_early (the early phase of a split plan alone)
+    bool preset_compares = false;                            // some class is preset twice: the second preset compares, in a launch after the writers
     const vpbs::u32* late_in = nullptr;                      // early-only objects: the slots the host's late phase wants back (device copy)
     unsigned max_batch = 0, batch = 0;
     std::vector<void*> owned;
@@ -312,6 +321,7 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
         d->aux = upload(ctx, ds.aux, d->owned);
         d->row_slots = upload(ctx, ds.row_slots, d->owned);
         d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
+        for (u32 sl : ds.preset_slot) d->preset_compares |= (sl & Plan::CHECK) != 0;
         d->out_pos = upload(ctx, plan->out_pos, d->owned);
         d->out_slot = upload(ctx, plan->out_slot, d->owned);
         d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
@@ -332,7 +342,7 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
         }
         d->val = ctx->alloc_words((plan->n_slots + 1) * (size_t)max_batch);   // + the scratch slot late presets are routed to
         d->owned.push_back(d->val);
-        d->err = static_cast<unsigned*>(ctx->alloc_bytes(sizeof(unsigned)));
+        d->err = static_cast<unsigned*>(ctx->alloc_bytes(2 * sizeof(unsigned)));   // flags, first conflicting slot + 1
         d->owned.push_back(d->err);
         VPBS_HIP(hipStreamSynchronize(ctx->stream));
         *out = d.release();
@@ -371,12 +381,13 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         const size_t n_preset = d->plan->preset_slot.size();
         d->batch = batch;
         VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, s));
-        VPBS_HIP(hipMemsetAsync(d->err, 0, sizeof(unsigned), s));
+        VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));
         if (n_preset) {
             d_vals = ctx->alloc_words(n_preset * batch);
             VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
-                               d_vals, (u32)n_preset, batch);
+            for (u32 pass = 0; pass < (d->preset_compares ? 2u : 1u); ++pass)
+                hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
+                                   d_vals, (u32)n_preset, batch, pass);
         }
         // the level launches are a static sequence: captured once per batch size, replayed afterwards
         if (!d->graph || d->graph_batch != batch) {
@@ -397,14 +408,27 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
             d->graph_batch = batch;
         }
         VPBS_HIP(hipGraphLaunch(d->graph, s));
-        unsigned flags = 0;
-        VPBS_HIP(hipMemcpyAsync(&flags, d->err, sizeof flags, hipMemcpyDeviceToHost, s));
+        unsigned report[2] = {0, 0};
+        VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
         VPBS_HIP(hipStreamSynchronize(s));
         if (d_vals) ctx->release(d_vals);
         d_vals = nullptr;
+        const unsigned flags = report[0];
         if (flags) {
             std::string m;
-            if (flags & DE_SET_TWICE) m += "a partition was set twice with different values; ";
+            if (flags & DE_SET_TWICE) {
+                m += "a partition was set twice with different values";
+                if (report[1]) {   // a wire of that class: the first position that carries the slot
+                    const u32 slot = report[1] - 1;
+                    for (size_t i = 0; i < d->plan->out_slot.size(); ++i)
+                        if (d->plan->out_slot[i] == slot) {
+                            m += " (the class of wire column " + std::to_string(d->plan->out_pos[i] / d->plan->n) + ", row " +
+                                 std::to_string(d->plan->out_pos[i] % d->plan->n) + ")";
+                            break;
+                        }
+                }
+                m += "; ";
+            }
             if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
             if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
             if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
