@@ -614,6 +614,8 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                                    stage_device=torch.device("cuda", local_rank))
         cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
         ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
+        if args.device_witness:
+            ivc.set_device_witness(ELL, LOGB, args.device_witness)
         inst = 0 if sharded else rank * n_chains + ci        # every chain of every rank is its own PBS: own keys, own message
         keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728 + inst, 4.99027217501041e-8, 1.17021618159313e-5)
         testv, delta = api.testv(N, 2)
@@ -723,7 +725,9 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                                        "all-gather of quotient values, 1 all-reduce of query records per step; %s); every rank generates the "
                                        "identical witness" % (world, "native RCCL (dlopen) on the prover's stream" if native_comm else args.dist_backend))
                                       if sharded else "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
-                       "chains_per_gpu": n_chains},
+                       "chains_per_gpu": n_chains,
+                       "early_witness_phase": ("on the device, %d steps per batch (vpbs_ivc_set_device_witness): the host runs the late phase only"
+                                               % args.device_witness) if args.device_witness else "on the host (a second thread per chain)"},
             "roofline": roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, dominant["count"],
                                     "the timed chained steps of this run (HIP events on each prover's stream)"),
             "chain_ms_per_step_split": {"witness_late_phase_host": t0s["late_witness_ms"], "late_rows_to_device": t0s["late_rows_upload_ms"],
@@ -967,6 +971,10 @@ def main():
                          "One chain leaves the GPU idle during its host phases; the metric is throughput, so the default (0 = auto) is 6 where "
                          "this rank's share of the host CPUs carries it (three chains per eight CPUs, measured), fewer on a small CPU "
                          "quota (the single-chain latency figure is reported next to it as ivc_single_chain)")
+    ap.add_argument("--device-witness", type=int, default=int(os.environ.get("VPBS_BENCH_DEVICE_WITNESS", "-1")),
+                    help="ivc workload: generate the early witness phases of this many steps at a time on the device "
+                         "(vpbs_ivc_set_device_witness; the host keeps the late phase); 0 = host pipeline; -1 (default) = auto: on the device "
+                         "where this rank's CPU share is too small to carry the host pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
     ap.add_argument("--no-single-chain", action="store_true", help="ivc workload: skip the one-chain latency measurement")
@@ -1016,6 +1024,8 @@ def main():
         # measured on the 16-CPU quota of the GPU boxes (tools/experiments/chains_ab.sh): 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 /
         # 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof -- six chains, i.e. three chains per eight CPUs of the rank's share
         args.chains = max(1, min(6, (3 * cpus) // 8))
+    if args.device_witness < 0:
+        args.device_witness = 0
 
     out, state = None, None
     if args.workload == "ivc":
