@@ -1019,13 +1019,17 @@ def main():
             dist.init_process_group(args.dist_backend)
     log_n = args.log_n
     secondary = rank == 0 and world == 1 and log_n == LOG_N
-    if args.chains <= 0:
-        cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)      # this rank's share of the CPUs the container may use
-        # measured on the 16-CPU quota of the GPU boxes (tools/experiments/chains_ab.sh): 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 /
-        # 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof -- six chains, i.e. three chains per eight CPUs of the rank's share
-        args.chains = max(1, min(6, (3 * cpus) // 8))
+    # What a rank's share of the host CPUs carries (measured on one MI355X with the affinity mask as the share, tools/experiments/cpu_share.sh,
+    # vPBS proofs/s per GPU): with the early witness phases on the HOST 2 / 4 / 8 / 16 CPUs give 0.072 / 0.092 / 0.149 / 0.161 (1 / 1 / 4 / 6
+    # chains); with the early phases on the DEVICE in batches of 64 (the host keeps the late phase and one hash-chain thread per chain)
+    # 0.117 / 0.149 / 0.152 / 0.151 (3 / 4 / 4 / 6 chains).  So: below 8 CPUs the device pipeline, from 8 on the host pipeline.
+    cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)          # this rank's share of the CPUs the container may use
     if args.device_witness < 0:
-        args.device_witness = 0
+        args.device_witness = 64 if cpus < 8 else 0
+    if args.chains <= 0:
+        # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
+        # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most
+        args.chains = (3 if cpus <= 2 else 4) if args.device_witness else max(1, min(6, cpus // 2))
 
     out, state = None, None
     if args.workload == "ivc":

@@ -529,6 +529,22 @@ def test_ivc_chain_tool_sharded_over_two_ranks():
     assert d["n_gpus"] == 2 and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1
 
 
+def test_bench_with_the_early_witness_phases_on_the_device():
+    """bench.py --device-witness: the headline workload through the device pipeline (what a rank with a small CPU share runs by default);
+    the same contract line, every chain's last proof checked after the clock"""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    r = subprocess.run([sys.executable, entry.ROOT + "/bench.py", "--steps", "10", "--warmup", "3", "--chains", "2", "--device-witness", "4",
+                        "--no-single-chain", "--no-step-micro", "--no-cpu-baseline", "--no-survey-size", "--no-step-circuit", "--no-batch128",
+                        "--no-whole-pbs", "--no-ivc"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["steps"] == 10 and d["config"]["chains_per_gpu"] == 2 and d["config"]["early_witness_phase"].startswith("on the device, 4 steps")
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 and d["chain_checks"]["proof_bytes"] == 192716
+
+
 def test_bench_contract_with_two_ranks_sharing_the_gpu():
     """The driver's multi-GPU launch of bench.py (torch.distributed.run, one rank per GPU, replicas: independent chains per rank, no
     data-path collective) with both ranks on the one device of the test box (--device 0, gloo for the barriers): ONE JSON line from rank 0,
@@ -540,7 +556,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     import __graft_entry__ as entry
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", entry.ROOT + "/bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--device", "0",
-                        "--dist-backend", "gloo", "--chains", "1"], capture_output=True, text=True, timeout=1500,
+                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0"], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
