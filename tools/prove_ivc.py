@@ -306,7 +306,10 @@ def main():
                 sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
         if native_driver:
             cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
-            chains.append((ctx, api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm), cd))
+            ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
+            if int(os.environ.get("VPBS_IVC_DEVICE_WITNESS", "0")):   # early witness phases on the device, this many steps per batch
+                ivc.set_device_witness(ELL, LOGB, int(os.environ["VPBS_IVC_DEVICE_WITNESS"]))
+            chains.append((ctx, ivc, cd))
         else:
             chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))
     t_setup = time.perf_counter() - t_setup
