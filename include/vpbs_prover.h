@@ -611,7 +611,7 @@ void vpbs_ivc_free(vpbs_ivc* ivc);
  * consecutive steps are generated at once by two early-only device objects on contexts of their own (vpbs_witness_device_create_early),
  * gathered per step into the matrix the prover reads, and only the early values the late phase touches come back to the host.  The 70 MB
  * matrix of a step no longer crosses PCIe and a chain needs about one host CPU instead of five; the proofs are the same bytes.  A batch of
- * 32 costs 2 x 160 MB of device memory at the paper's parameters.  batch = 0 returns to the host pipeline. */
+ * 64 costs 2 x 0.9 GB of device memory at the paper's parameters (1.78 M value slots per instance).  batch = 0 returns to the host pipeline. */
 int vpbs_ivc_set_device_witness(vpbs_ivc* ivc, unsigned ELL, unsigned LOGB, unsigned batch);
 typedef void (*vpbs_ivc_step_fn)(void* user, unsigned done);
 int vpbs_ivc_set_step_callback(vpbs_ivc* ivc, vpbs_ivc_step_fn fn, void* user);
