@@ -25,6 +25,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Several chains per GPU mean 20-30 HIP streams (per chain: the prover's, its upload stream, the witness contexts').  The HIP runtime maps a
+# process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise: measured with six chains per
+# GPU (tools/experiments/hwq_ab.sh), 4 / 8 / 16 / 24 queues = 8.45-8.54 / 8.35-8.40 / 8.69-8.75 / 8.73-8.78 ms per chained proof with the host
+# witness pipeline and 8.72-8.74 / 8.32-8.35 / 8.31-8.32 / 8.58-8.66 with the device pipeline.  Read by the runtime when it is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its bundled HIP runtime must be the one the prover library binds to)
@@ -1019,17 +1024,19 @@ def main():
             dist.init_process_group(args.dist_backend)
     log_n = args.log_n
     secondary = rank == 0 and world == 1 and log_n == LOG_N
-    # What a rank's share of the host CPUs carries (measured on one MI355X with the affinity mask as the share, tools/experiments/cpu_share.sh,
-    # vPBS proofs/s per GPU): with the early witness phases on the HOST 2 / 4 / 8 / 16 CPUs give 0.072 / 0.092 / 0.149 / 0.161 (1 / 1 / 4 / 6
-    # chains); with the early phases on the DEVICE in batches of 64 (the host keeps the late phase and one hash-chain thread per chain)
-    # 0.117 / 0.149 / 0.152 / 0.151 (3 / 4 / 4 / 6 chains).  So: below 8 CPUs the device pipeline, from 8 on the host pipeline.
+    # What a rank's share of the host CPUs carries (measured on one MI355X with the affinity mask as the share and 8 hardware queues,
+    # tools/experiments/cpu_share.sh, vPBS proofs/s per GPU): with the early witness phases on the HOST 2 / 4 / 8 / 16 CPUs give 0.074 / 0.086 /
+    # 0.144 / 0.163 (1 / 1 / 4 / 6 chains); with the early phases on the DEVICE in batches of 64 (the host keeps the late phase and one
+    # hash-chain thread per chain) 0.123 / 0.159 / 0.163 / 0.164 (4 / 6 / 6 / 6 chains).  The device pipeline is the default wherever the
+    # share is below 12 CPUs -- the ranks of a multi-GPU node on a small container -- and the host pipeline, equal there and two rounds
+    # older, from 12 CPUs on.
     cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)          # this rank's share of the CPUs the container may use
     if args.device_witness < 0:
-        args.device_witness = 64 if cpus < 8 else 0
+        args.device_witness = 64 if cpus < 12 else 0
     if args.chains <= 0:
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
         # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most
-        args.chains = (3 if cpus <= 2 else 4) if args.device_witness else max(1, min(6, cpus // 2))
+        args.chains = (4 if cpus <= 2 else 6) if args.device_witness else max(1, min(6, cpus // 2))
 
     out, state = None, None
     if args.workload == "ivc":

@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # several chains = many streams: see bench.py
 import torch  # noqa: E402
 
 import vpbs_amd  # noqa: E402

@@ -16,6 +16,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -470,12 +472,17 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     if (rc != 0) return stop(std::string("base proof: ") + vpbs_last_error(ctx), rc);
     const double t_base = now() - t0;
     if (v->step_fn) v->step_fn(v->step_user, 0);
-    double t_late = 0, t_rows = 0, t_prove = 0;
+    double t_late = 0, t_rows = 0, t_prove = 0, t_wait_staged = 0, t_wait_hashed = 0;
     for (unsigned s = 0; s < steps; ++s) {
         const unsigned k = s % vpbs_ivc::NBUF;
         {
+            const double tw = now();
             std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || staged > s; });
+            const double tw2 = now();
+            t_wait_staged += tw2 - tw;
             cv.wait(lk, [&] { return failed || (staged > s && hashed > s); });   // its wires are in place, its own public inputs complete
+            t_wait_hashed += now() - tw2;
             if (failed) {
                 lk.unlock();
                 return stop("", VPBS_ERR_INVALID);
@@ -508,6 +515,10 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     batcher.join();
     stager.join();
     const double seconds = now() - t0;
+    if (std::getenv("VPBS_TRACE_IVC"))
+        std::fprintf(stderr, "[ivc device witness] per step: waited %.2f ms for the staged wires, %.2f ms for the hash chain; late %.2f, scatter %.2f, "
+                     "prove %.2f, device batch run %.2f ms\n", 1e3 * t_wait_staged / steps, 1e3 * t_wait_hashed / steps, 1e3 * t_late / steps,
+                     1e3 * t_rows / steps, 1e3 * t_prove / steps, 1e3 * t_early / steps);
     const long n_bytes = vpbs_step_proof_to_bytes(ctx, &in, cyc.n_const_cols, caps, openings, fri, proof_out, capacity);
     if (n_bytes <= 0) {
         say("the output buffer is too small for the proof");
