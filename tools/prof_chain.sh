@@ -5,6 +5,7 @@
 CH=${1:-1}
 TAG=${2:-chain${CH}}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export GPU_MAX_HW_QUEUES=8   # what bench.py sets for itself; under the profiler the runtime is loaded before bench.py starts
 rm -rf gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --chains $CH --steps 60 --warmup 6 \
   --no-single-chain --no-step-micro --no-cpu-baseline --no-survey-size --no-step-circuit --no-batch128 --no-whole-pbs --no-ivc \

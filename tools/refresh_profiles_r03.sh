@@ -13,4 +13,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof
 bash tools/pmc_kernels.sh > /dev/null 2>&1
 # the headline workload (chained step proofs of the cyclic circuit): one chain (every kernel alone), then the headline's four chains
 bash tools/prof_chain.sh 1 chain1 | tail -2
-bash tools/prof_chain.sh 4 chain4 | tail -2
+bash tools/prof_chain.sh 6 chain6 | tail -2
