@@ -10,6 +10,7 @@
 //              -Wl,-rpath,$PWD/verifiable-fhe-paper_amd -o examples/prove_ivc
 //   run  : python tools/export_step_circuit.py --cyclic /tmp/cyc.bin /tmp/dum.bin 8 2 4 5 6 13 && examples/prove_ivc /tmp/cyc.bin /tmp/dum.bin
 //          examples/prove_ivc CYCLIC.bin DUMMY.bin [steps]        (steps < n + 2: a prefix of the chain; verify_pbs then does not apply)
+//          VPBS_IVC_DEVICE_WITNESS=64 examples/prove_ivc ...       the early witness phases on the device, 64 steps per batch
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -131,6 +132,9 @@ int main(int argc, char** argv) {
     REQUIRE(vpbs_ivc_create(ctx, &c_desc, &d_desc, N, K, ggsw_len, /* comm: one GPU */ nullptr, &ivc, err, sizeof err) == 0, "vpbs_ivc_create: %s", err);
     std::vector<u64> vk(68);
     vpbs_ivc_verifier_data(ivc, vk.data(), nullptr);
+    // VPBS_IVC_DEVICE_WITNESS=b: the early witness phases of b steps at a time on the device (the host keeps the late phase); same proof
+    if (const char* dw = std::getenv("VPBS_IVC_DEVICE_WITNESS"))
+        REQUIRE(vpbs_ivc_set_device_witness(ivc, ELL, LOGB, (unsigned)std::atoi(dw)) == 0, "vpbs_ivc_set_device_witness failed");
 
     // ---- main.rs:40-52 with seeded generators ----
     vpbs_keygen_params kp{log_N, K, ELL, LOGB, n_lwe, 0x5EED0728ull, 4.99027217501041e-8, 1.17021618159313e-5};

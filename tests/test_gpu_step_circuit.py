@@ -365,8 +365,8 @@ def test_ivc_chain_tool(args, expect_steps):
     print(d["ms_per_step_split"], d["seconds"])
 
 
-@pytest.mark.parametrize("N,n_lwe,log_n,steps", [(8, 6, 13, 8), (1024, 728, 16, 4)])
-def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
+@pytest.mark.parametrize("N,n_lwe,log_n,steps,device_witness", [(8, 6, 13, 8, 0), (1024, 728, 16, 4, 0), (8, 6, 13, 8, 3), (1024, 728, 16, 5, 2)])
+def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps, device_witness):
     """examples/prove_ivc.cpp: the IVC chain driven by a plain C++ host of the C ABI (no Python, no torch in the process) from the exported
     cyclic + dummy circuit files: split witness plan with the early phase on its own thread, pinned wires, the final proof alone verified
     after a byte round trip, chain hashes, and -- for the whole chain at N = 8 -- decryption to the message."""
@@ -375,7 +375,8 @@ def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps):
     from vpbs_amd import circuit_file
     cyc, dum = circuit_file.ensure_cyclic_circuit(N, 2, 4, 5, n_lwe, log_n)
     exe = entry.build_example("prove_ivc")
-    r = subprocess.run([exe, cyc, dum, str(steps)], capture_output=True, text=True, timeout=1500)
+    env = dict(os.environ, VPBS_IVC_DEVICE_WITNESS=str(device_witness)) if device_witness else dict(os.environ)   # the other witness pipeline
+    r = subprocess.run([exe, cyc, dum, str(steps)], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "IVC chain: %d of %d step proofs" % (steps, n_lwe + 2) in r.stdout and "verified: 1" in r.stdout
     if steps == n_lwe + 2:
