@@ -620,7 +620,7 @@ def measure_ivc(args, rank, local_rank, world, distributed):
         cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
         ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
         if args.device_witness:
-            ivc.set_device_witness(ELL, LOGB, args.device_witness)
+            ivc.set_device_witness(ELL, LOGB, args.device_witness, args.device_late)
         inst = 0 if sharded else rank * n_chains + ci        # every chain of every rank is its own PBS: own keys, own message
         keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0x5EED0728 + inst, 4.99027217501041e-8, 1.17021618159313e-5)
         testv, delta = api.testv(N, 2)
@@ -731,8 +731,9 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                                        "identical witness" % (world, "native RCCL (dlopen) on the prover's stream" if native_comm else args.dist_backend))
                                       if sharded else "replicas: %d independent chain(s) per GPU, no data-path collective" % n_chains,
                        "chains_per_gpu": n_chains,
-                       "early_witness_phase": ("on the device, %d steps per batch (vpbs_ivc_set_device_witness): the host runs the late phase only"
-                                               % args.device_witness) if args.device_witness else "on the host (a second thread per chain)"},
+                       "early_witness_phase": ("on the device, %d steps per batch (vpbs_ivc_set_device_witness): %s"
+                                               % (args.device_witness, "the late phase there as well" if args.device_late else "the host runs the late phase only"))
+                                              if args.device_witness else "on the host (a second thread per chain)"},
             "roofline": roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, dominant["count"],
                                     "the timed chained steps of this run (HIP events on each prover's stream)"),
             "chain_ms_per_step_split": {"witness_late_phase_host": t0s["late_witness_ms"], "late_rows_to_device": t0s["late_rows_upload_ms"],
@@ -980,6 +981,8 @@ def main():
                     help="ivc workload: generate the early witness phases of this many steps at a time on the device "
                          "(vpbs_ivc_set_device_witness; the host keeps the late phase); 0 = host pipeline; -1 (default) = auto: on the device "
                          "where this rank's CPU share is too small to carry the host pipeline")
+    ap.add_argument("--device-late", action="store_true", default=os.environ.get("VPBS_BENCH_DEVICE_LATE", "") not in ("", "0"),
+                    help="with --device-witness: the late witness phase on the device too (the host generates no witness)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
     ap.add_argument("--no-single-chain", action="store_true", help="ivc workload: skip the one-chain latency measurement")

@@ -134,7 +134,8 @@ int main(int argc, char** argv) {
     vpbs_ivc_verifier_data(ivc, vk.data(), nullptr);
     // VPBS_IVC_DEVICE_WITNESS=b: the early witness phases of b steps at a time on the device (the host keeps the late phase); same proof
     if (const char* dw = std::getenv("VPBS_IVC_DEVICE_WITNESS"))
-        REQUIRE(vpbs_ivc_set_device_witness(ivc, ELL, LOGB, (unsigned)std::atoi(dw)) == 0, "vpbs_ivc_set_device_witness failed");
+        REQUIRE(vpbs_ivc_set_device_witness(ivc, ELL, LOGB, (unsigned)std::atoi(dw), std::getenv("VPBS_IVC_DEVICE_LATE") != nullptr) == 0,
+                "vpbs_ivc_set_device_witness failed");
 
     // ---- main.rs:40-52 with seeded generators ----
     vpbs_keygen_params kp{log_N, K, ELL, LOGB, n_lwe, 0x5EED0728ull, 4.99027217501041e-8, 1.17021618159313e-5};

@@ -392,6 +392,11 @@ int vpbs_witness_device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, uns
  * vpbs_device_scatter: the early phase costs no host CPU and its 70 MB matrix never crosses PCIe. */
 int vpbs_witness_device_create_early(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, vpbs_witness_device** out);
 int vpbs_witness_device_read_late_inputs(vpbs_witness_device* dev, unsigned instance, uint64_t* out /* host [late_input_count] */);
+/* The late phase of ONE instance of the last batch, on the device, on top of the early values the object holds for it: preset_val [n_preset]
+ * in the plan's order, of which only the late entries (the previous proof's words) are read.  A late value that conflicts with what the
+ * circuit fixes -- a proof that does not verify in circuit -- fails the call (vpbs_last_error names the class).  Afterwards
+ * vpbs_witness_device_wires gathers the complete witness of the instance. */
+int vpbs_witness_device_run_late(vpbs_witness_device* dev, unsigned instance, const uint64_t* preset_val);
 int vpbs_witness_device_run(vpbs_witness_device* dev, const uint64_t* preset_val, unsigned batch);
 /* gathers instance `instance` of the last run into d_wires (device, [n_wires][n], fully written) */
 int vpbs_witness_device_wires(vpbs_witness_device* dev, unsigned instance, uint64_t* d_wires);
@@ -612,7 +617,12 @@ void vpbs_ivc_free(vpbs_ivc* ivc);
  * gathered per step into the matrix the prover reads, and only the early values the late phase touches come back to the host.  The 70 MB
  * matrix of a step no longer crosses PCIe and a chain needs about one host CPU instead of five; the proofs are the same bytes.  A batch of
  * 64 costs 2 x 0.9 GB of device memory at the paper's parameters (1.78 M value slots per instance).  batch = 0 returns to the host pipeline. */
-int vpbs_ivc_set_device_witness(vpbs_ivc* ivc, unsigned ELL, unsigned LOGB, unsigned batch);
+int vpbs_ivc_set_device_witness(vpbs_ivc* ivc, unsigned ELL, unsigned LOGB, unsigned batch, int late_on_device);
+/* late_on_device != 0: the late phase on the device as well -- once the previous proof exists its words go to the device object that holds
+ * the step's early values, the late generators run there as a level schedule of their own (vpbs_witness_device_run_late: ~160 dependent
+ * levels, one instance), and all the step's wires are gathered into the prover's matrix: the host generates no witness at all (it keeps
+ * the transcript, the native hash chains and the launches).  For ranks with very few CPUs; with CPUs to spare the host's late phase
+ * (eight threads, AVX-512 Poseidon) is the faster one. */
 typedef void (*vpbs_ivc_step_fn)(void* user, unsigned done);
 int vpbs_ivc_set_step_callback(vpbs_ivc* ivc, vpbs_ivc_step_fn fn, void* user);
 /* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */

@@ -621,6 +621,9 @@ def test_device_early_phase_of_the_cyclic_circuit(ctx, N, n_lwe, log_n, batch):
         seed = dev.read_late_inputs(i)
         assert (seed == host.reshape(-1)[lin]).all()
         api.lib().vpbs_witness_state_free(state)
+    # a late phase on the device cannot succeed on garbage proof words: the call fails and says which class caught it
+    with pytest.raises(api.VpbsError, match="device witness generation"):
+        dev.run_late(0, values[:, 0])
     dev.free()
     plan.free()
 
@@ -643,10 +646,10 @@ def test_ivc_chain_with_the_early_phases_on_the_device():
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
     frozen = json.load(open(GOLDEN_CHAIN))
     bsk_flat, ksk_flat = np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk)
-    for batch in (2, 3, 8, 0):
-        ivc.set_device_witness(ELL, LOGB, batch)
+    for batch, late in ((2, False), (3, False), (8, False), (2, True), (8, True), (0, False)):
+        ivc.set_device_witness(ELL, LOGB, batch, late)
         blob, t = ivc.prove_pbs(testv, ct, bsk_flat, ksk_flat)
-        assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"]), batch
+        assert (len(blob), hashlib.sha256(blob).hexdigest()) == (frozen["bytes"], frozen["sha256"]), (batch, late)
     with pytest.raises(api.VpbsError):
         ivc.set_device_witness(ELL + 1, LOGB, 4)                      # does not fit the GGSW length of the circuit
     ivc.free()
@@ -658,13 +661,17 @@ def test_ivc_chain_with_the_early_phases_on_the_device():
     cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
-    ivc.set_device_witness(ELL, LOGB, 3)
     keys = c.keygen(N, K, ELL, LOGB, n_lwe, 5, 4.99027217501041e-8, 1.17021618159313e-5)
     tv, delta = api.testv(N, 2)
     ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
-    blob, t = ivc.prove_pbs(tv, ct, keys["bsk"], keys["ksk"], steps)
     vk, _ = ivc.verifier_data()
-    prove_ivc.check_chain(c, cyc, vk, blob, keys, tv, delta, ct, N, n_lwe, log_n, steps, 1)
-    assert t["steps"] == steps and t["early_witness_ms"] > 0
+    blobs = []
+    for late in (False, True):
+        ivc.set_device_witness(ELL, LOGB, 3, late)
+        blob, t = ivc.prove_pbs(tv, ct, keys["bsk"], keys["ksk"], steps)
+        prove_ivc.check_chain(c, cyc, vk, blob, keys, tv, delta, ct, N, n_lwe, log_n, steps, 1)
+        assert t["steps"] == steps and t["early_witness_ms"] > 0
+        blobs.append(blob)
+    assert blobs[0] == blobs[1]                                       # the late phase on the host or on the device: the same proof
     ivc.free()
     c.close()

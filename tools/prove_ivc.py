@@ -309,7 +309,7 @@ def main():
             cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
             ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
             if int(os.environ.get("VPBS_IVC_DEVICE_WITNESS", "0")):   # early witness phases on the device, this many steps per batch
-                ivc.set_device_witness(ELL, LOGB, int(os.environ["VPBS_IVC_DEVICE_WITNESS"]))
+                ivc.set_device_witness(ELL, LOGB, int(os.environ["VPBS_IVC_DEVICE_WITNESS"]), os.environ.get("VPBS_IVC_DEVICE_LATE", "") not in ("", "0"))
             chains.append((ctx, ivc, cd))
         else:
             chains.append((ctx, Circuit(ctx, cyc_path, comm, dist_device), Circuit(ctx, dummy_path)))

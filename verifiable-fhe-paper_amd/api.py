@@ -243,7 +243,8 @@ SIGNATURES = {
     "vpbs_ivc_free": (None, [_vp]),
     "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
     "vpbs_ivc_set_step_callback": (_i, [_vp, IVC_STEP_FN, _vp]),
-    "vpbs_ivc_set_device_witness": (_i, [_vp, _ui, _ui, _ui]),
+    "vpbs_ivc_set_device_witness": (_i, [_vp, _ui, _ui, _ui, _i]),
+    "vpbs_witness_device_run_late": (_i, [C.c_void_p, C.c_uint, U64P]),
     "vpbs_ctx_device": (_i, [_vp]),
     "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
     "vpbs_verify_pbs": (_i, [C.POINTER(VerifyPbsInputsC), C.POINTER(C.c_uint8), _sz, C.c_char_p, _sz]),
@@ -635,6 +636,12 @@ class WitnessDevice:
         ctx._check((lib().vpbs_witness_device_create_early if early else lib().vpbs_witness_device_create)(ctx.h, plan.h, max_batch, C.byref(h)))
         self.h = h
 
+    def run_late(self, instance, values):
+        """the late phase of one instance of the last batch on top of its early values (values: [n_preset], the late entries are read)"""
+        v = _u64(values)
+        assert v.size == self.plan.n_preset
+        self.ctx._check(lib().vpbs_witness_device_run_late(self.h, instance, _ptr(v)))
+
     def read_late_inputs(self, instance):
         """the early values the host's late phase needs of one instance, in the order of plan.late_input_positions()"""
         out = np.zeros(int(lib().vpbs_witness_plan_late_input_count(self.plan.h)), np.uint64)
@@ -751,9 +758,10 @@ class Ivc:
         lib().vpbs_ivc_verifier_data(self.h, _ptr(a), _ptr(b))
         return a, b
 
-    def set_device_witness(self, ELL, LOGB, batch):
-        """vpbs_ivc_set_device_witness: the early witness phases of `batch` steps at a time on the device (0: back to the host pipeline)"""
-        self.ctx._check(lib().vpbs_ivc_set_device_witness(self.h, ELL, LOGB, batch))
+    def set_device_witness(self, ELL, LOGB, batch, late_on_device=False):
+        """vpbs_ivc_set_device_witness: the early witness phases of `batch` steps at a time on the device (0: back to the host pipeline);
+        late_on_device: the late phase there as well (the host generates no witness)"""
+        self.ctx._check(lib().vpbs_ivc_set_device_witness(self.h, ELL, LOGB, batch, 1 if late_on_device else 0))
 
     def on_step(self, fn):
         """vpbs_ivc_set_step_callback: fn(done) runs on the proving thread with done = 0 after the base proof and 1 .. steps after each

@@ -134,6 +134,7 @@ struct vpbs_ivc {
     // early witness phases on the device (vpbs_ivc_set_device_witness): two early-only device objects, each on a context of its own (their
     // runs overlap with the prover's context and with each other's gathers), filled alternately with batches of `dw_batch` steps
     unsigned dw_batch = 0, ELL = 0, LOGB = 0;
+    bool dw_late = false;   // the late phase on the device too (vpbs_witness_device_run_late): the host generates no witness at all
     vpbs_ctx* wctx[2] = {nullptr, nullptr};
     vpbs_witness_device* wdev[2] = {nullptr, nullptr};
     u64* dw_presets = nullptr;   // pinned [n_preset][dw_batch]
@@ -280,9 +281,10 @@ int vpbs_ivc_verifier_data(const vpbs_ivc* v, uint64_t* cyclic_vk, uint64_t* dum
     return VPBS_OK;
 }
 
-int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsigned batch) {
+int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsigned batch, int late_on_device) {
     if (!v) return VPBS_ERR_INVALID;
     v->drop_device_witness();
+    v->dw_late = false;
     if (batch == 0) return VPBS_OK;
     if (ELL == 0 || LOGB == 0 || v->ggsw_len != (size_t)v->K * ELL * v->K * v->N) {
         v->err = "device witness: ELL / LOGB do not fit the circuit's GGSW length";
@@ -304,6 +306,7 @@ int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsign
     }
     v->late_in_count = vpbs_witness_plan_late_input_count(v->cyc.plan);
     v->ELL = ELL; v->LOGB = LOGB; v->dw_batch = batch;
+    v->dw_late = late_on_device != 0;
     return VPBS_OK;
 }
 
@@ -428,6 +431,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     // thread S: per step, the instance's wires into one of the device matrices and the late phase's inputs to the host
     std::vector<std::vector<u64>> late_in(vpbs_ivc::NBUF, std::vector<u64>(v->late_in_count));
     std::thread stager([&] {
+        if (v->dw_late) return;   // the caller runs the late phase on the device object itself and gathers afterwards
         for (unsigned s = 0; s < steps && !failed; ++s) {
             const unsigned b = s / B, k = s % vpbs_ivc::NBUF;
             {
@@ -478,10 +482,11 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
         {
             const double tw = now();
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return failed || staged > s; });
+            const unsigned b = s / B;
+            cv.wait(lk, [&] { return failed || (v->dw_late ? batches_run > b : staged > s); });
             const double tw2 = now();
             t_wait_staged += tw2 - tw;
-            cv.wait(lk, [&] { return failed || (staged > s && hashed > s); });   // its wires are in place, its own public inputs complete
+            cv.wait(lk, [&] { return failed || hashed > s; });   // its own public inputs are complete
             t_wait_hashed += now() - tw2;
             if (failed) {
                 lk.unlock();
@@ -489,16 +494,30 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             }
         }
         double t = now();
-        vpbs_witness_state* st = nullptr;
-        rc = vpbs_witness_state_from_late_inputs(cyc.plan, late_in[k].data(), &st);
-        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + ": the early values read back from the device are malformed", rc);
-        rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, values.data(), v->late_vals, e, sizeof e);
-        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
-        t_late += now() - t;
-        t = now();
-        rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
-        if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
-        t_rows += now() - t;
+        if (v->dw_late) {
+            // the late phase on the device object that holds the step's early values, then ALL its wires into the prover's matrix
+            vpbs_witness_device* dev = v->wdev[(s / B) & 1];
+            rc = vpbs_witness_device_run_late(dev, s % B, values.data());
+            if (rc != 0)
+                return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " +
+                            vpbs_last_error(v->wctx[(s / B) & 1]), rc);
+            t_late += now() - t;
+            t = now();
+            rc = vpbs_witness_device_wires(dev, s % B, v->d_bufs[k]);
+            if (rc != 0) return stop(std::string("gathering the wires: ") + vpbs_last_error(v->wctx[(s / B) & 1]), rc);
+            t_rows += now() - t;
+        } else {
+            vpbs_witness_state* st = nullptr;
+            rc = vpbs_witness_state_from_late_inputs(cyc.plan, late_in[k].data(), &st);
+            if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + ": the early values read back from the device are malformed", rc);
+            rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, values.data(), v->late_vals, e, sizeof e);
+            if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+            t_late += now() - t;
+            t = now();
+            rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
+            if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
+            t_rows += now() - t;
+        }
         t = now();
         cyc.step_inputs(in, v->d_bufs[k], true, pis.data() + (size_t)(s + 1) * n_pi);
         rc = cyc.prove(in, caps, openings, fri);

@@ -95,9 +95,10 @@ struct SlotRow {
 // schedule writes, in the order the generator sets them.
 // skip_step / skip_preset (nullable): the steps and presets of the late phase, left out of the early-only schedule (such a preset is routed
 // to the scratch slot n_slots, which nothing reads).
+// pre_set (nullable, per slot): classes that hold a value before the schedule starts (the late-only schedule runs on the early phase's values).
 void build_device_schedule(vpbs_witness_plan& p, vpbs_witness_plan::DeviceSchedule& d, const std::vector<u32>& step_out,
                            const std::vector<u32>& step_out_w, const std::vector<u32>& step_out_off, const uint8_t* skip_step = nullptr,
-                           const uint8_t* skip_preset = nullptr) {
+                           const uint8_t* skip_preset = nullptr, const uint8_t* pre_set = nullptr) {
     using Plan = vpbs_witness_plan;
     d = Plan::DeviceSchedule{};
     constexpr u32 CHECK = Plan::CHECK, UNSET = 0xFFFFFFFFu;
@@ -106,6 +107,9 @@ void build_device_schedule(vpbs_witness_plan& p, vpbs_witness_plan::DeviceSchedu
         return;
     }
     std::vector<u32> level(p.n_slots, UNSET);  // the level at which a slot gets its value
+    if (pre_set)
+        for (size_t sl = 0; sl < p.n_slots; ++sl)
+            if (pre_set[sl]) level[sl] = 0;
     d.preset_slot = p.preset_slot;
     for (size_t i = 0; i < d.preset_slot.size(); ++i) {
         u32& s = d.preset_slot[i];
@@ -713,6 +717,13 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     }
     // the early phase alone as a device schedule (vpbs_witness_device_create_early)
     build_device_schedule(p, p.dev_early, p.step_out, p.step_out_w, p.step_out_off, p.step_late.data(), p.preset_late.data());
+    {   // ... and the late phase alone, on top of the early phase's values
+        std::vector<uint8_t> early_step(p.schedule.size()), early_preset(p.preset_slot.size()), early_known(p.n_slots);
+        for (size_t i = 0; i < early_step.size(); ++i) early_step[i] = !p.step_late[i];
+        for (size_t i = 0; i < early_preset.size(); ++i) early_preset[i] = !p.preset_late[i];
+        for (size_t sl = 0; sl < p.n_slots; ++sl) early_known[sl] = !taint[sl];
+        build_device_schedule(p, p.dev_late, p.step_out, p.step_out_w, p.step_out_off, early_step.data(), early_preset.data(), early_known.data());
+    }
     if (std::getenv("VPBS_TRACE_WITNESS")) {
         std::vector<uint8_t> row_late(p.n, 0);
         for (u32 i : p.late_out) row_late[p.out_pos[i] % p.n] = 1;

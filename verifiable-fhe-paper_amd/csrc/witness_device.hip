@@ -15,10 +15,19 @@ using Plan = vpbs_witness_plan;
 constexpr unsigned WT = 256;
 enum DevErr : unsigned { DE_SET_TWICE = 1, DE_TOO_LARGE = 2, DE_NOT_BOOLEAN = 4, DE_DIV_ZERO = 8, DE_GATE = 16 };
 
+// Which instances a launch works on: `n` instances starting at *first (0 when first is null) of a value array laid out for `stride`
+// instances per slot.  A batch run: n = stride = the batch.  The late phase of ONE instance of a batch (vpbs_witness_device_run_late):
+// n = 1, stride = the batch, *first = the instance -- read from device memory so that one captured graph serves every instance.
+struct Launch {
+    u32 stride, n;
+    const u32* first;
+    __device__ u32 instance(size_t gid) const { return (first ? *first : 0u) + (u32)(gid % n); }
+};
+
 struct Vals {
     u64* v;
     unsigned* err;
-    u32 batch, b;
+    u32 batch, b;   // batch: the stride between slots
     // volatile: inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line)
     __device__ u64 get(u32 slot) const { return *(volatile const u64*)(v + (size_t)(slot & ~Plan::CHECK) * batch + b); }
     __device__ void set(u32 slot, u64 x) const {
@@ -37,36 +46,36 @@ struct Vals {
 
 // compare_pass 0: the presets that write their class; 1: the ones that find it written (a class preset twice: the cyclic circuit's own verifier
 // data and the tail of the inner proof's public inputs) and compare -- in a launch of their own, after the writers
-__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, u32 batch,
+__global__ void __launch_bounds__(WT) wd_preset_kernel(u64* v, unsigned* err, const u32* slots, const u64* values, u32 n_preset, Launch L,
                                                         u32 compare_pass) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_preset * batch) return;
-    const u32 slot = slots[gid / batch];
+    if (gid >= (size_t)n_preset * L.n) return;
+    const u32 slot = slots[gid / L.n];
     if (((slot & Plan::CHECK) != 0) != (compare_pass != 0)) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
+    const Vals a{v, err, L.stride, L.instance(gid)};
     a.set(slot, values[gid]);
 }
 
-__global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, u32 batch) {
+__global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, const Plan::ConstOp* ops, u32 n_ops, Launch L) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    a.set(ops[gid / batch].out, ops[gid / batch].value);
+    if (gid >= (size_t)n_ops * L.n) return;
+    const Vals a{v, err, L.stride, L.instance(gid)};
+    a.set(ops[gid / L.n].out, ops[gid / L.n].value);
 }
 
-__global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, u32 batch) {
+__global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, Launch L) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::ArithOp op = ops[gid / batch];
+    if (gid >= (size_t)n_ops * L.n) return;
+    const Vals a{v, err, L.stride, L.instance(gid)};
+    const Plan::ArithOp op = ops[gid / L.n];
     a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
 }
 
-__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, Launch L) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::BitsOp op = ops[gid / batch];
+    if (gid >= (size_t)n_ops * L.n) return;
+    const Vals a{v, err, L.stride, L.instance(gid)};
+    const Plan::BitsOp op = ops[gid / L.n];
     u64 x = a.get(op.in);
     const u64 mask = ((u64)1 << op.bits) - 1;
     for (u32 k = 0; k < op.n_out; ++k) {
@@ -94,13 +103,13 @@ struct RowTables {
 };
 
 __global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
-                                                       u32 batch) {
+                                                       Launch L) {
     const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Plan::RowOp op = ops[gid / batch];
+    if (gid >= (size_t)n_ops * L.n) return;
+    const Plan::RowOp op = ops[gid / L.n];
     const u32 gi = t.row_gate[op.row];
     const vpbs_gate g = t.gates[gi];
-    DevRow r{Vals{v, err, batch, (u32)(gid % batch)}, row_slots + t.row_off[op.row]};
+    DevRow r{Vals{v, err, L.stride, L.instance(gid)}, row_slots + t.row_off[op.row]};
     gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
 }
 
@@ -162,30 +171,30 @@ __device__ void poseidon_generate_wide(const Vals& a, const u32* rs) {
     if (own) a.set(rs[12 + l], gl::canon(s));
 }
 
-__global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, u32 batch) {
+__global__ void __launch_bounds__(64) wd_poseidon_kernel(u64* v, unsigned* err, const u32* rows, const u32* row_slots, u32 n_ops, Launch L) {
     const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
-    if (group >= (size_t)n_ops * batch) return;
-    poseidon_generate_wide(Vals{v, err, batch, (u32)(group % batch)}, row_slots + rows[group / batch]);
+    if (group >= (size_t)n_ops * L.n) return;
+    poseidon_generate_wide(Vals{v, err, L.stride, L.instance(group)}, row_slots + rows[group / L.n]);
 }
 
 // The tail of the schedule where every level holds PoseidonGate rows only (the hash chain): instances are independent of each other,
 // so one group per instance walks the levels by itself -- one launch instead of one per level.
 __global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned* err, const u32* rows, const u32* level_off, u32 first_level,
-                                                                u32 last_level, const u32* row_slots, u32 batch) {
+                                                                u32 last_level, const u32* row_slots, Launch L) {
     const size_t group = (blockIdx.x * (size_t)64 + threadIdx.x) >> 4;
-    if (group >= batch) return;
-    const Vals a{v, err, batch, (u32)group};
+    if (group >= L.n) return;
+    const Vals a{v, err, L.stride, L.instance(group)};
     for (u32 level = first_level; level <= last_level; ++level) {
         for (u32 op = level_off[level]; op < level_off[level + 1]; ++op) poseidon_generate_wide(a, row_slots + rows[op]);
         __threadfence_block();  // the next level reads what this one stored
     }
 }
 
-__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, u32 batch) {
+__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, Launch L) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * batch) return;
-    const Vals a{v, err, batch, (u32)(gid % batch)};
-    const Plan::MiscOp op = ops[gid / batch];
+    if (gid >= (size_t)n_ops * L.n) return;
+    const Vals a{v, err, L.stride, L.instance(gid)};
+    const Plan::MiscOp op = ops[gid / L.n];
     const u32 *in = aux + op.at, *out = in + op.n_in;
     switch (op.kind) {
         case VPBS_GEN_EQUALITY: {
@@ -245,25 +254,40 @@ template <class T> T* upload(vpbs_ctx* c, const std::vector<T>& h, std::vector<v
 }  // namespace
 }  // namespace vpbs
 
+namespace vpbs {
+namespace {
+// the device copies of one DeviceSchedule's arrays
+struct DevSched {
+    const Plan::ArithOp* arith = nullptr;
+    const Plan::ConstOp* consts = nullptr;
+    const Plan::BitsOp* bits = nullptr;
+    const Plan::MiscOp* misc = nullptr;
+    const u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *poseidon_off = nullptr;
+    const Plan::RowOp* rowops = nullptr;
+    unsigned tail_first = 0;        // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
+    bool preset_compares = false;   // some class is preset twice: the second preset compares, in a launch after the writers
+};
+}  // namespace
+}  // namespace vpbs
+
 struct vpbs_witness_device {
     vpbs_ctx* ctx = nullptr;
     const vpbs_witness_plan* plan = nullptr;
     const vpbs_witness_plan::DeviceSchedule* ds = nullptr;   // plan->dev, or plan->dev_early (the early phase of a split plan alone)
-    bool preset_compares = false;                            // some class is preset twice: the second preset compares, in a launch after the writers
+    vpbs::DevSched k;                                        // ... on the device
     const vpbs::u32* late_in = nullptr;                      // early-only objects: the slots the host's late phase wants back (device copy)
+    // early-only objects: the LATE phase as a schedule of its own, run for one instance of the batch at a time (vpbs_witness_device_run_late)
+    bool has_late = false;
+    vpbs::DevSched k_late;
+    vpbs::u32* d_instance = nullptr;   // which instance the late graph works on (read by its kernels)
+    hipGraphExec_t late_graph = nullptr;
+    unsigned late_graph_stride = 0;
     unsigned max_batch = 0, batch = 0;
     std::vector<void*> owned;
     vpbs::u64* val = nullptr;
     unsigned* err = nullptr;
-    const vpbs_witness_plan::ArithOp* arith = nullptr;
-    const vpbs_witness_plan::ConstOp* consts = nullptr;
-    const vpbs_witness_plan::BitsOp* bits = nullptr;
-    const vpbs_witness_plan::MiscOp* misc = nullptr;
-    const vpbs::u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *out_pos = nullptr, *out_slot = nullptr;
-    const vpbs::u32* poseidon_off = nullptr;
-    const vpbs_witness_plan::RowOp* rowops = nullptr;
+    const vpbs::u32 *out_pos = nullptr, *out_slot = nullptr;
     vpbs::RowTables tables{};
-    unsigned tail_first = 0;          // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
     hipGraphExec_t graph = nullptr;   // the level launches of one run for `graph_batch` instances
     unsigned graph_batch = 0;
     std::mutex mu;                    // run / wires / read share the context's stream and memory pool: one at a time per object
@@ -271,34 +295,59 @@ struct vpbs_witness_device {
 
 namespace vpbs {
 namespace {
-void launch_levels(vpbs_witness_device* d, hipStream_t s, unsigned batch) {
-    const Plan::DeviceSchedule& ds = *d->ds;
-    auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * batch + threads - 1) / threads)); };
+void launch_levels(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const DevSched& k, hipStream_t s, Launch L) {
+    auto blocks = [&](size_t ops, unsigned threads) { return dim3((unsigned)((ops * L.n + threads - 1) / threads)); };
     if (!ds.consts.empty())
-        hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, d->consts, (u32)ds.consts.size(), batch);
-    const u32 last_stepwise = d->tail_first ? d->tail_first - 1 : ds.n_levels;
+        hipLaunchKernelGGL(wd_const_kernel, blocks(ds.consts.size(), WT), dim3(WT), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(), L);
+    const u32 last_stepwise = k.tail_first ? k.tail_first - 1 : ds.n_levels;
     for (u32 l = 1; l <= last_stepwise; ++l) {
-        if (const u32 k = ds.arith_off[l + 1] - ds.arith_off[l])
-            hipLaunchKernelGGL(wd_arith_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->arith + ds.arith_off[l], k, batch);
-        if (const u32 k = ds.bits_off[l + 1] - ds.bits_off[l])
-            hipLaunchKernelGGL(wd_bits_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->bits + ds.bits_off[l], d->aux, k, batch);
-        if (const u32 k = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
-            hipLaunchKernelGGL(wd_poseidon_kernel, blocks((size_t)k * 16, 64), dim3(64), 0, s, d->val, d->err, d->poseidon + ds.poseidon_off[l],
-                               d->row_slots, k, batch);
-        if (const u32 k = ds.misc_off[l + 1] - ds.misc_off[l])
-            hipLaunchKernelGGL(wd_misc_kernel, blocks(k, WT), dim3(WT), 0, s, d->val, d->err, d->misc + ds.misc_off[l], d->aux, k, batch);
-        if (const u32 k = ds.rowops_off[l + 1] - ds.rowops_off[l])
-            hipLaunchKernelGGL(wd_rowop_kernel, blocks(k, 64), dim3(64), 0, s, d->val, d->err, d->rowops + ds.rowops_off[l], d->tables, d->row_slots, k,
-                               batch);
+        if (const u32 c = ds.arith_off[l + 1] - ds.arith_off[l])
+            hipLaunchKernelGGL(wd_arith_kernel, blocks(c, WT), dim3(WT), 0, s, d->val, d->err, k.arith + ds.arith_off[l], c, L);
+        if (const u32 c = ds.bits_off[l + 1] - ds.bits_off[l])
+            hipLaunchKernelGGL(wd_bits_kernel, blocks(c, WT), dim3(WT), 0, s, d->val, d->err, k.bits + ds.bits_off[l], k.aux, c, L);
+        if (const u32 c = ds.poseidon_off[l + 1] - ds.poseidon_off[l])
+            hipLaunchKernelGGL(wd_poseidon_kernel, blocks((size_t)c * 16, 64), dim3(64), 0, s, d->val, d->err, k.poseidon + ds.poseidon_off[l],
+                               k.row_slots, c, L);
+        if (const u32 c = ds.misc_off[l + 1] - ds.misc_off[l])
+            hipLaunchKernelGGL(wd_misc_kernel, blocks(c, WT), dim3(WT), 0, s, d->val, d->err, k.misc + ds.misc_off[l], k.aux, c, L);
+        if (const u32 c = ds.rowops_off[l + 1] - ds.rowops_off[l])
+            hipLaunchKernelGGL(wd_rowop_kernel, blocks(c, 64), dim3(64), 0, s, d->val, d->err, k.rowops + ds.rowops_off[l], d->tables, k.row_slots, c, L);
     }
-    if (d->tail_first)
-        hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((batch * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, d->poseidon, d->poseidon_off,
-                           d->tail_first, ds.n_levels, d->row_slots, batch);
+    if (k.tail_first)
+        hipLaunchKernelGGL(wd_poseidon_chain_kernel, dim3((L.n * 16u + 63) / 64), dim3(64), 0, s, d->val, d->err, k.poseidon, k.poseidon_off,
+                           k.tail_first, ds.n_levels, k.row_slots, L);
 }
 }  // namespace
 }  // namespace vpbs
 
 extern "C" {
+
+extern "C++" {
+namespace vpbs {
+namespace {
+DevSched upload_schedule(vpbs_ctx* ctx, const Plan::DeviceSchedule& ds, std::vector<void*>& owned) {
+    DevSched k;
+    k.arith = upload(ctx, ds.arith, owned);
+    k.consts = upload(ctx, ds.consts, owned);
+    k.bits = upload(ctx, ds.bits, owned);
+    k.misc = upload(ctx, ds.misc, owned);
+    k.poseidon = upload(ctx, ds.poseidon, owned);
+    k.aux = upload(ctx, ds.aux, owned);
+    k.row_slots = upload(ctx, ds.row_slots, owned);
+    k.preset_slot = upload(ctx, ds.preset_slot, owned);
+    for (u32 sl : ds.preset_slot) k.preset_compares |= (sl & Plan::CHECK) != 0 && (sl & ~Plan::CHECK) != 0xFFFFFFFFu;
+    k.poseidon_off = upload(ctx, ds.poseidon_off, owned);
+    k.rowops = upload(ctx, ds.rowops, owned);
+    u32 l = ds.n_levels;
+    while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
+           ds.rowops_off[l + 1] == ds.rowops_off[l])
+        --l;
+    k.tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
+    return k;
+}
+}  // namespace
+}  // namespace vpbs
+}  // extern "C++"
 
 static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned max_batch, bool early, vpbs_witness_device** out) {
     if (!ctx || !plan || !out || max_batch == 0 || (early && !plan->is_split)) return VPBS_ERR_INVALID;
@@ -312,35 +361,26 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
         d->ds = &ds;
         d->max_batch = max_batch;
         using namespace vpbs;
-        if (early) d->late_in = upload(ctx, plan->late_in_slots, d->owned);
-        d->arith = upload(ctx, ds.arith, d->owned);
-        d->consts = upload(ctx, ds.consts, d->owned);
-        d->bits = upload(ctx, ds.bits, d->owned);
-        d->misc = upload(ctx, ds.misc, d->owned);
-        d->poseidon = upload(ctx, ds.poseidon, d->owned);
-        d->aux = upload(ctx, ds.aux, d->owned);
-        d->row_slots = upload(ctx, ds.row_slots, d->owned);
-        d->preset_slot = upload(ctx, ds.preset_slot, d->owned);
-        for (u32 sl : ds.preset_slot) d->preset_compares |= (sl & Plan::CHECK) != 0;
+        d->k = upload_schedule(ctx, ds, d->owned);
+        if (early) {
+            d->late_in = upload(ctx, plan->late_in_slots, d->owned);
+            if (plan->dev_late.supported) {
+                d->k_late = upload_schedule(ctx, plan->dev_late, d->owned);
+                d->d_instance = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32)));
+                d->owned.push_back(d->d_instance);
+                d->has_late = true;
+            }
+        }
         d->out_pos = upload(ctx, plan->out_pos, d->owned);
         d->out_slot = upload(ctx, plan->out_slot, d->owned);
-        d->poseidon_off = upload(ctx, ds.poseidon_off, d->owned);
-        d->rowops = upload(ctx, ds.rowops, d->owned);
-        if (!ds.rowops.empty()) {
+        if (!ds.rowops.empty() || (d->has_late && !plan->dev_late.rowops.empty())) {
             std::vector<gates::CosetTables> coset(plan->gates.size());
             for (size_t i = 0; i < plan->gates.size(); ++i)
                 if (plan->gates[i].kind == VPBS_GATE_COSET_INTERPOLATION) coset[i] = gates::coset_tables(plan->gates[i].p0);
             d->tables = RowTables{upload(ctx, plan->gates, d->owned), upload(ctx, plan->row_gate, d->owned), upload(ctx, plan->row_off, d->owned),
                                   upload(ctx, plan->consts, d->owned), upload(ctx, coset, d->owned), std::max(1u, plan->max_consts)};
         }
-        {
-            u32 l = ds.n_levels;
-            while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
-                   ds.rowops_off[l + 1] == ds.rowops_off[l])
-                --l;
-            d->tail_first = ds.n_levels - l >= 8 ? l + 1 : 0;
-        }
-        d->val = ctx->alloc_words((plan->n_slots + 1) * (size_t)max_batch);   // + the scratch slot late presets are routed to
+        d->val = ctx->alloc_words((plan->n_slots + 1) * (size_t)max_batch);   // + the scratch slot the other phase's presets are routed to
         d->owned.push_back(d->val);
         d->err = static_cast<unsigned*>(ctx->alloc_bytes(2 * sizeof(unsigned)));   // flags, first conflicting slot + 1
         d->owned.push_back(d->err);
@@ -365,9 +405,80 @@ void vpbs_witness_device_free(vpbs_witness_device* d) {
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->graph) (void)hipGraphExecDestroy(d->graph);
+    if (d->late_graph) (void)hipGraphExecDestroy(d->late_graph);
     for (void* p : d->owned) d->ctx->release(p);
     delete d;
 }
+
+extern "C++" {
+namespace vpbs {
+namespace {
+void throw_on_flags(const vpbs_witness_device* d, const unsigned report[2]) {
+    const unsigned flags = report[0];
+    if (!flags) return;
+    std::string m;
+    if (flags & DE_SET_TWICE) {
+        m += "a partition was set twice with different values";
+        if (report[1]) {   // a wire of that class: the first position that carries the slot
+            const u32 slot = report[1] - 1;
+            for (size_t i = 0; i < d->plan->out_slot.size(); ++i)
+                if (d->plan->out_slot[i] == slot) {
+                    m += " (the class of wire column " + std::to_string(d->plan->out_pos[i] / d->plan->n) + ", row " +
+                         std::to_string(d->plan->out_pos[i] % d->plan->n) + ")";
+                    break;
+                }
+        }
+        m += "; ";
+    }
+    if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
+    if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
+    if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
+    if (flags & DE_GATE) m += "a gate generator rejected its inputs (limbs that do not fit, an access index out of range, a non-boolean bit, a zero shift); ";
+    throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
+}
+// presets -> (captured) level launches -> error flags, on the context's stream; returns after the stream has drained
+void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const DevSched& k, hipGraphExec_t& graph, unsigned& graph_key, unsigned key,
+                  Launch L, const u64* preset_val, u64*& d_vals) {
+    vpbs_ctx* ctx = d->ctx;
+    hipStream_t s = ctx->stream;
+    const size_t n_preset = d->plan->preset_slot.size();
+    VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));
+    if (n_preset) {
+        d_vals = ctx->alloc_words(n_preset * L.n);
+        VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * L.n, hipMemcpyHostToDevice, s));
+        for (u32 pass = 0; pass < (k.preset_compares ? 2u : 1u); ++pass)
+            hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * L.n + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, k.preset_slot, d_vals,
+                               (u32)n_preset, L, pass);
+    }
+    // the level launches are a static sequence: captured once per batch size (stride), replayed afterwards
+    if (!graph || graph_key != key) {
+        if (graph) {
+            VPBS_HIP(hipGraphExecDestroy(graph));
+            graph = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        launch_levels(d, ds, k, s, L);
+        const hipError_t launched = hipGetLastError();
+        const hipError_t ended = hipStreamEndCapture(s, &g);   // always leave capture mode
+        hipError_t e = launched != hipSuccess ? launched : ended;
+        if (e == hipSuccess) e = hipGraphInstantiate(&graph, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e != hipSuccess) graph = nullptr;
+        VPBS_HIP(e);
+        graph_key = key;
+    }
+    VPBS_HIP(hipGraphLaunch(graph, s));
+    unsigned report[2] = {0, 0};
+    VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
+    VPBS_HIP(hipStreamSynchronize(s));
+    if (d_vals) ctx->release(d_vals);
+    d_vals = nullptr;
+    throw_on_flags(d, report);
+}
+}  // namespace
+}  // namespace vpbs
+}  // extern "C++"
 
 int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, unsigned batch) {
     if (!d || batch == 0 || batch > d->max_batch || (!d->plan->preset_slot.empty() && !preset_val)) return VPBS_ERR_INVALID;
@@ -377,64 +488,33 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
     try {
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
-        hipStream_t s = ctx->stream;
-        const size_t n_preset = d->plan->preset_slot.size();
         d->batch = batch;
-        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, s));
-        VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));
-        if (n_preset) {
-            d_vals = ctx->alloc_words(n_preset * batch);
-            VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * batch, hipMemcpyHostToDevice, s));
-            for (u32 pass = 0; pass < (d->preset_compares ? 2u : 1u); ++pass)
-                hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * batch + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, d->preset_slot,
-                                   d_vals, (u32)n_preset, batch, pass);
+        VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, ctx->stream));
+        run_schedule(d, *d->ds, d->k, d->graph, d->graph_batch, batch, Launch{batch, batch, nullptr}, preset_val, d_vals);
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        if (d_vals) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->release(d_vals);
         }
-        // the level launches are a static sequence: captured once per batch size, replayed afterwards
-        if (!d->graph || d->graph_batch != batch) {
-            if (d->graph) {
-                VPBS_HIP(hipGraphExecDestroy(d->graph));
-                d->graph = nullptr;
-            }
-            hipGraph_t g = nullptr;
-            VPBS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            launch_levels(d, s, batch);
-            const hipError_t launched = hipGetLastError();
-            const hipError_t ended = hipStreamEndCapture(s, &g);   // always leave capture mode
-            hipError_t e = launched != hipSuccess ? launched : ended;
-            if (e == hipSuccess) e = hipGraphInstantiate(&d->graph, g, nullptr, nullptr, 0);
-            if (g) (void)hipGraphDestroy(g);
-            if (e != hipSuccess) d->graph = nullptr;
-            VPBS_HIP(e);
-            d->graph_batch = batch;
-        }
-        VPBS_HIP(hipGraphLaunch(d->graph, s));
-        unsigned report[2] = {0, 0};
-        VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
-        VPBS_HIP(hipStreamSynchronize(s));
-        if (d_vals) ctx->release(d_vals);
-        d_vals = nullptr;
-        const unsigned flags = report[0];
-        if (flags) {
-            std::string m;
-            if (flags & DE_SET_TWICE) {
-                m += "a partition was set twice with different values";
-                if (report[1]) {   // a wire of that class: the first position that carries the slot
-                    const u32 slot = report[1] - 1;
-                    for (size_t i = 0; i < d->plan->out_slot.size(); ++i)
-                        if (d->plan->out_slot[i] == slot) {
-                            m += " (the class of wire column " + std::to_string(d->plan->out_pos[i] / d->plan->n) + ", row " +
-                                 std::to_string(d->plan->out_pos[i] % d->plan->n) + ")";
-                            break;
-                        }
-                }
-                m += "; ";
-            }
-            if (flags & DE_TOO_LARGE) m += "an integer too large to fit in the given number of limbs; ";
-            if (flags & DE_NOT_BOOLEAN) m += "PoseidonGate: swap wire is not boolean; ";
-            if (flags & DE_DIV_ZERO) m += "QuotientGeneratorExtension: division by zero; ";
-            if (flags & DE_GATE) m += "a gate generator rejected its inputs (limbs that do not fit, an access index out of range, a non-boolean bit, a zero shift); ";
-            throw DeviceError{VPBS_ERR_INVALID, "device witness generation: " + m.substr(0, m.size() - 2)};
-        }
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+
+int vpbs_witness_device_run_late(vpbs_witness_device* d, unsigned instance, const uint64_t* preset_val) {
+    if (!d || !d->has_late || !preset_val) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch) return VPBS_ERR_INVALID;
+    vpbs::u64* d_vals = nullptr;
+    try {
+        using namespace vpbs;
+        VPBS_HIP(hipSetDevice(ctx->device));
+        const u32 inst = instance;
+        VPBS_HIP(hipMemcpyAsync(d->d_instance, &inst, sizeof inst, hipMemcpyHostToDevice, ctx->stream));   // run_schedule drains the stream before returning
+        run_schedule(d, d->plan->dev_late, d->k_late, d->late_graph, d->late_graph_stride, d->batch, Launch{d->batch, 1, d->d_instance}, preset_val,
+                     d_vals);
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
         if (d_vals) {

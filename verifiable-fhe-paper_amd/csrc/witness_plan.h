@@ -273,6 +273,9 @@ struct vpbs_witness_plan {
     // the part that needs the previous proof -- on its CPUs; and the early-known slots that late phase touches (reads, or writes as a
     // comparer), which such a host reads back per instance to seed the late phase's state.
     DeviceSchedule dev_early;
+    // ... and the LATE phase alone: the late steps over a value array in which the early phase's results already sit (the early-known
+    // classes count as set: a late step that writes one compares), early presets routed to the scratch slot
+    DeviceSchedule dev_late;
     std::vector<u32> late_in_slots;
     // what every scheduled step writes (slots; wire index for row steps, NONE for gadget outputs): kept for building dev_early
     std::vector<u32> step_out, step_out_w, step_out_off;
