@@ -63,26 +63,28 @@ __global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, con
     a.set(ops[gid / L.n].out, ops[gid / L.n].value);
 }
 
+__device__ __forceinline__ void do_arith(const Vals& a, const Plan::ArithOp& op) {
+    a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
+}
 __global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, Launch L) {
     const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
     if (gid >= (size_t)n_ops * L.n) return;
-    const Vals a{v, err, L.stride, L.instance(gid)};
-    const Plan::ArithOp op = ops[gid / L.n];
-    a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
+    do_arith(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n]);
 }
 
-__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, Launch L) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * L.n) return;
-    const Vals a{v, err, L.stride, L.instance(gid)};
-    const Plan::BitsOp op = ops[gid / L.n];
+__device__ __forceinline__ void do_bits(const Vals& a, const Plan::BitsOp& op, const u32* aux) {
     u64 x = a.get(op.in);
     const u64 mask = ((u64)1 << op.bits) - 1;
     for (u32 k = 0; k < op.n_out; ++k) {
         a.set(aux[op.out_at + k], x & mask);
         x >>= op.bits;
     }
-    if (x != 0) atomicOr(err, DE_TOO_LARGE);
+    if (x != 0) atomicOr(a.err, DE_TOO_LARGE);
+}
+__global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, const Plan::BitsOp* ops, const u32* aux, u32 n_ops, Launch L) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * L.n) return;
+    do_bits(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n], aux);
 }
 
 // every gate generator without a special form: gen_run (the host's code) through the row's slot table, one thread per instance
@@ -102,15 +104,17 @@ struct RowTables {
     u32 max_consts;
 };
 
+__device__ __forceinline__ void do_rowop(const Vals& a, const Plan::RowOp& op, const RowTables& t, const u32* row_slots) {
+    const u32 gi = t.row_gate[op.row];
+    const vpbs_gate g = t.gates[gi];
+    DevRow r{a, row_slots + t.row_off[op.row]};
+    gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
+}
 __global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
                                                        Launch L) {
     const size_t gid = blockIdx.x * (size_t)64 + threadIdx.x;
     if (gid >= (size_t)n_ops * L.n) return;
-    const Plan::RowOp op = ops[gid / L.n];
-    const u32 gi = t.row_gate[op.row];
-    const vpbs_gate g = t.gates[gi];
-    DevRow r{Vals{v, err, L.stride, L.instance(gid)}, row_slots + t.row_off[op.row]};
-    gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
+    do_rowop(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n], t, row_slots);
 }
 
 // PoseidonGate generator, 16 lanes per row and instance: lane l < 12 owns state element l (the latency form of the prover's tree
@@ -190,11 +194,8 @@ __global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned*
     }
 }
 
-__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, Launch L) {
-    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
-    if (gid >= (size_t)n_ops * L.n) return;
-    const Vals a{v, err, L.stride, L.instance(gid)};
-    const Plan::MiscOp op = ops[gid / L.n];
+__device__ __forceinline__ void do_misc(const Vals& a, const Plan::MiscOp& op, const u32* aux) {
+    unsigned* err = a.err;
     const u32 *in = aux + op.at, *out = in + op.n_in;
     switch (op.kind) {
         case VPBS_GEN_EQUALITY: {
@@ -232,6 +233,37 @@ __global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, cons
         default: break;
     }
 }
+__global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, const Plan::MiscOp* ops, const u32* aux, u32 n_ops, Launch L) {
+    const size_t gid = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (gid >= (size_t)n_ops * L.n) return;
+    do_misc(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n], aux);
+}
+
+// A whole schedule walked by ONE workgroup, a barrier between levels: for the late phase of a single instance (~160 levels of a few
+// hundred operations each) the per-level launches of the batch form cost 6.9 ms of launch latency; here a level costs its slowest
+// operation.  The PoseidonGate rows of a level take 16 lanes each.  Everything goes through global memory: a workgroup's barrier orders it.
+constexpr unsigned WALK_THREADS = 512;
+struct WalkOffsets {
+    const u32 *arith, *bits, *poseidon, *misc, *rowops;   // [n_levels + 2] each
+};
+__global__ void __launch_bounds__(WALK_THREADS) wd_walk_kernel(u64* v, unsigned* err, const Plan::ConstOp* consts, u32 n_consts, const Plan::ArithOp* arith,
+                                                                const Plan::BitsOp* bits, const u32* poseidon, const Plan::MiscOp* misc,
+                                                                const Plan::RowOp* rowops, const u32* aux, const u32* row_slots, WalkOffsets off,
+                                                                RowTables t, u32 n_levels, Launch L) {
+    const unsigned tid = threadIdx.x;
+    const Vals a{v, err, L.stride, L.instance(0)};   // L.n == 1
+    for (u32 i = tid; i < n_consts; i += WALK_THREADS) a.set(consts[i].out, consts[i].value);
+    __syncthreads();
+    for (u32 l = 1; l <= n_levels; ++l) {
+        for (u32 i = off.arith[l] + tid; i < off.arith[l + 1]; i += WALK_THREADS) do_arith(a, arith[i]);
+        for (u32 i = off.bits[l] + tid; i < off.bits[l + 1]; i += WALK_THREADS) do_bits(a, bits[i], aux);
+        for (u32 i = off.misc[l] + tid; i < off.misc[l + 1]; i += WALK_THREADS) do_misc(a, misc[i], aux);
+        for (u32 i = off.rowops[l] + tid; i < off.rowops[l + 1]; i += WALK_THREADS) do_rowop(a, rowops[i], t, row_slots);
+        for (u32 i = off.poseidon[l] + (tid >> 4); i < off.poseidon[l + 1]; i += WALK_THREADS / 16) poseidon_generate_wide(a, row_slots + poseidon[i]);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 
 // wires[pos] = val[slot][b] for every position that carries a slot (the matrix is zeroed first)
 __global__ void __launch_bounds__(WT) wd_gather_kernel(const u64* v, const u32* pos, const u32* slot, size_t count, u32 batch, u32 b, u64* wires) {
@@ -263,6 +295,7 @@ struct DevSched {
     const Plan::BitsOp* bits = nullptr;
     const Plan::MiscOp* misc = nullptr;
     const u32 *poseidon = nullptr, *aux = nullptr, *row_slots = nullptr, *preset_slot = nullptr, *poseidon_off = nullptr;
+    const u32 *arith_off = nullptr, *bits_off = nullptr, *misc_off = nullptr, *rowops_off = nullptr;   // for the one-workgroup walk
     const Plan::RowOp* rowops = nullptr;
     unsigned tail_first = 0;        // levels >= tail_first hold PoseidonGate rows only (0: no such tail)
     bool preset_compares = false;   // some class is preset twice: the second preset compares, in a launch after the writers
@@ -337,6 +370,10 @@ DevSched upload_schedule(vpbs_ctx* ctx, const Plan::DeviceSchedule& ds, std::vec
     k.preset_slot = upload(ctx, ds.preset_slot, owned);
     for (u32 sl : ds.preset_slot) k.preset_compares |= (sl & Plan::CHECK) != 0 && (sl & ~Plan::CHECK) != 0xFFFFFFFFu;
     k.poseidon_off = upload(ctx, ds.poseidon_off, owned);
+    k.arith_off = upload(ctx, ds.arith_off, owned);
+    k.bits_off = upload(ctx, ds.bits_off, owned);
+    k.misc_off = upload(ctx, ds.misc_off, owned);
+    k.rowops_off = upload(ctx, ds.rowops_off, owned);
     k.rowops = upload(ctx, ds.rowops, owned);
     u32 l = ds.n_levels;
     while (l >= 1 && ds.arith_off[l + 1] == ds.arith_off[l] && ds.bits_off[l + 1] == ds.bits_off[l] && ds.misc_off[l + 1] == ds.misc_off[l] &&
@@ -438,7 +475,7 @@ void throw_on_flags(const vpbs_witness_device* d, const unsigned report[2]) {
 }
 // presets -> (captured) level launches -> error flags, on the context's stream; returns after the stream has drained
 void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const DevSched& k, hipGraphExec_t& graph, unsigned& graph_key, unsigned key,
-                  Launch L, const u64* preset_val, u64*& d_vals) {
+                  Launch L, const u64* preset_val, u64*& d_vals, bool walk = false) {
     vpbs_ctx* ctx = d->ctx;
     hipStream_t s = ctx->stream;
     const size_t n_preset = d->plan->preset_slot.size();
@@ -450,8 +487,12 @@ void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const 
             hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * L.n + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, k.preset_slot, d_vals,
                                (u32)n_preset, L, pass);
     }
-    // the level launches are a static sequence: captured once per batch size (stride), replayed afterwards
-    if (!graph || graph_key != key) {
+    if (walk) {   // one instance: one workgroup walks the levels
+        hipLaunchKernelGGL(wd_walk_kernel, dim3(1), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(), k.arith, k.bits, k.poseidon,
+                           k.misc, k.rowops, k.aux, k.row_slots, WalkOffsets{k.arith_off, k.bits_off, k.poseidon_off, k.misc_off, k.rowops_off}, d->tables,
+                           ds.n_levels, L);
+        VPBS_HIP(hipGetLastError());
+    } else if (!graph || graph_key != key) {   // the level launches are a static sequence: captured once per batch size (stride), replayed afterwards
         if (graph) {
             VPBS_HIP(hipGraphExecDestroy(graph));
             graph = nullptr;
@@ -468,7 +509,7 @@ void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const 
         VPBS_HIP(e);
         graph_key = key;
     }
-    VPBS_HIP(hipGraphLaunch(graph, s));
+    if (!walk) VPBS_HIP(hipGraphLaunch(graph, s));
     unsigned report[2] = {0, 0};
     VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
     VPBS_HIP(hipStreamSynchronize(s));
@@ -513,8 +554,9 @@ int vpbs_witness_device_run_late(vpbs_witness_device* d, unsigned instance, cons
         VPBS_HIP(hipSetDevice(ctx->device));
         const u32 inst = instance;
         VPBS_HIP(hipMemcpyAsync(d->d_instance, &inst, sizeof inst, hipMemcpyHostToDevice, ctx->stream));   // run_schedule drains the stream before returning
+        static const bool per_level = std::getenv("VPBS_DEVICE_LATE_LAUNCHES") != nullptr;   // A-B: one launch per level and kind (6.9 ms per step)
         run_schedule(d, d->plan->dev_late, d->k_late, d->late_graph, d->late_graph_stride, d->batch, Launch{d->batch, 1, d->d_instance}, preset_val,
-                     d_vals);
+                     d_vals, !per_level);
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
         if (d_vals) {
