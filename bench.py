@@ -618,6 +618,10 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                 sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None, stage_words=stage_words,
                                    stage_device=torch.device("cuda", local_rank))
         cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
+        if n_chains > 1 and "VPBS_WIDE_THRESHOLD" not in os.environ:
+            # the chains hide each other's latency-bound phases: what counts is the instruction count, and the 16-lane Poseidon form of the
+            # small tree levels issues 3.7 x the instructions of the one-lane form (tools/experiments/wide_ab.sh: 8.33 -> 8.14-8.22 ms per proof)
+            ctx.set_option("wide_threshold", 2048)
         ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
         if args.device_witness:
             ivc.set_device_witness(ELL, LOGB, args.device_witness, args.device_late)

@@ -307,6 +307,8 @@ def main():
                 sharding.make_comm(device=dist_device, stage_words=stage_words, stage_device=torch.device("cuda", device))
         if native_driver:
             cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
+            if n_chains > 1 and "VPBS_WIDE_THRESHOLD" not in os.environ:
+                ctx.set_option("wide_threshold", 2048)   # chains side by side hide latency: the one-lane Poseidon form down to 2048 nodes (bench.py)
             ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
             if int(os.environ.get("VPBS_IVC_DEVICE_WITNESS", "0")):   # early witness phases on the device, this many steps per batch
                 ivc.set_device_witness(ELL, LOGB, int(os.environ["VPBS_IVC_DEVICE_WITNESS"]), os.environ.get("VPBS_IVC_DEVICE_LATE", "") not in ("", "0"))

@@ -320,7 +320,7 @@ int vpbs_ctx_set_option(vpbs_ctx* c, int option, uint64_t value) {
             if (value < 1 || value > 8) return VPBS_ERR_INVALID;
             c->tune.gate_items = (unsigned)value;
             return VPBS_OK;
-        case VPBS_OPT_WIDE_THRESHOLD: c->tune.wide_threshold = (size_t)value; return VPBS_OK;
+        case VPBS_OPT_WIDE_THRESHOLD: c->tune.wide_threshold = c->tune.fri_leaf_wide_threshold = (size_t)value; return VPBS_OK;   // as the environment variable
         case VPBS_OPT_MERKLE_CLIMB: c->tune.merkle_climb = value != 0; return VPBS_OK;
         case VPBS_OPT_GATES_TILE: c->tune.gates_tile = value != 0; return VPBS_OK;
         default: return VPBS_ERR_INVALID;
