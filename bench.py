@@ -38,6 +38,15 @@ import torch.distributed as dist  # noqa: E402
 import vpbs_amd  # noqa: E402
 from vpbs_amd import synth  # noqa: E402
 
+def shares_the_gpu(ctx):
+    """a context that proves beside others on the same GPU: their work hides its latency-bound phases, so it trades the 16-lane Poseidon form
+    (a third of the latency, 3.7 x the instructions) for the one-lane form down to 2048 nodes (VPBS_OPT_WIDE_THRESHOLD; 8.33 -> 8.14-8.22 ms
+    per chained proof with six chains, tools/experiments/wide_ab.sh).  An explicit VPBS_WIDE_THRESHOLD wins."""
+    if "VPBS_WIDE_THRESHOLD" not in os.environ:
+        ctx.set_option("wide_threshold", 2048)
+    return ctx
+
+
 STEPS_PER_VPBS = 730       # n + 2 with n = 728 (reference src/main.rs:27, ivc_based_vpbs.rs:433-436)
 # Degree of the step circuit at N = 1024.  /root/reference/src/vtfhe/ivc_based_vpbs.rs:54-61 pads the common-data circuit with NoopGates
 # until it HAS 2^15 gates and only then calls build(), which appends the public-input hash rows, the PublicInputGate and the constant
@@ -130,7 +139,7 @@ def step_circuit_pipeline(device, proofs=24, witness_threads=6, provers=3):
     cs_values = np.concatenate([b.constants, sigma])
     d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda(device)
     digest = np.array([11, 22, 33, 44], np.uint64)
-    ctxs = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
+    ctxs = [shares_the_gpu(vpbs_amd.Context(device, log_n_max=16)) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in ctxs]
     n_buf = witness_threads + provers + 1
     bufs = [torch.empty((135, b.n), dtype=torch.int64).pin_memory() for _ in range(n_buf)]
@@ -248,7 +257,7 @@ def step_circuit_device_pipeline(device, batch=64, batches=4, provers=4):
     digest = np.array([11, 22, 33, 44], np.uint64)
     wctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(2)]
     wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
-    pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
+    pctx = [shares_the_gpu(vpbs_amd.Context(device, log_n_max=16)) for _ in range(provers)]
     css = [c.commit_values(cs_values) for c in pctx]
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda:%d" % device) for _ in range(provers)]
     rng = np.random.default_rng(4048)
@@ -366,7 +375,7 @@ def batch_of_128(device, pools=(1, 2, 4, 8), proofs=128):
     distinct = set()
     for pool in pools:
         while len(ctxs) < pool:
-            c = vpbs_amd.Context(device, log_n_max=16)
+            c = shares_the_gpu(vpbs_amd.Context(device, log_n_max=16))
             c.set_gate_lanes(1)
             ctxs.append(c)
             css.append(c.commit_values(cs_values))
@@ -618,10 +627,8 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                 sharding.make_comm(device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None, stage_words=stage_words,
                                    stage_device=torch.device("cuda", local_rank))
         cd, dd = circuit_file.load(cyc_path), circuit_file.load(dummy_path)
-        if n_chains > 1 and "VPBS_WIDE_THRESHOLD" not in os.environ:
-            # the chains hide each other's latency-bound phases: what counts is the instruction count, and the 16-lane Poseidon form of the
-            # small tree levels issues 3.7 x the instructions of the one-lane form (tools/experiments/wide_ab.sh: 8.33 -> 8.14-8.22 ms per proof)
-            ctx.set_option("wide_threshold", 2048)
+        if n_chains > 1:
+            shares_the_gpu(ctx)
         ivc = api.Ivc(ctx, cd, dd, N, K, K * ELL * K * N, comm)
         if args.device_witness:
             ivc.set_device_witness(ELL, LOGB, args.device_witness, args.device_late)
@@ -855,7 +862,7 @@ def measure_step(args, rank, local_rank, world, distributed, log_n):
     if world == 1 and n_chains == 1 and args.batch_chains > 1:
         extra = []
         for c in range(1, args.batch_chains):
-            cx = vpbs_amd.Context(local_rank, log_n_max=16)
+            cx = shares_the_gpu(vpbs_amd.Context(local_rank, log_n_max=16))
             cx.set_gate_lanes(1)
             inp = synth.step_inputs(log_n, instance=c, cols=COLS)
             dv = {k: torch.from_numpy(inp[k].view(np.int64)).cuda() for k in ("wires", "quotient", "constants_sigmas")}

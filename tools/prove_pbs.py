@@ -128,6 +128,9 @@ def main():
     wctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(2)]
     wdev = [api.WitnessDevice(c, plan, batch) for c in wctx]
     pctx = [vpbs_amd.Context(device, log_n_max=16) for _ in range(provers)]
+    if "VPBS_WIDE_THRESHOLD" not in os.environ:
+        for c in pctx:   # provers side by side hide each other's latency: the one-lane Poseidon form down to 2048 nodes (bench.py shares_the_gpu)
+            c.set_option("wide_threshold", 2048)
     css = [c.commit_values(cs_values) for c in pctx]
     d_sigma = torch.from_numpy(sigma.view(np.int64)).cuda()
     d_wires = [torch.zeros((135, b.n), dtype=torch.int64, device="cuda") for _ in range(provers)]
