@@ -21,6 +21,8 @@ N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 6, 13
 cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
 c = vpbs_amd.Context(0, log_n_max=16)
 ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
+if len(sys.argv) > 1:   # the device witness pipeline: batch size [late-on-device flag]
+    ivc.set_device_witness(ELL, LOGB, int(sys.argv[1]), len(sys.argv) > 2)
 keys = c.keygen(N, K, ELL, LOGB, n_lwe, 1, 4.99027217501041e-8, 1.17021618159313e-5)
 testv, delta = api.testv(N, 2)
 ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % api.P)
