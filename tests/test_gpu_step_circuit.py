@@ -514,14 +514,16 @@ def test_ivc_chain_tool_two_chains_side_by_side():
     assert [c["decrypted"] for c in d["other_chains"]] == [c["message"] for c in d["other_chains"]] == [0]
 
 
-def test_ivc_chain_tool_sharded_over_two_ranks():
+@pytest.mark.parametrize("device_witness", [0, 3])
+def test_ivc_chain_tool_sharded_over_two_ranks(device_witness):
     """BASELINE config 4's mechanism on the one GPU of the test box: the IVC chain with every step proof coset-sharded over two ranks (gloo,
-    callback communicator; both ranks on device 0) -- same final proof checks as the single-rank chain, decrypting to the message"""
+    callback communicator; both ranks on device 0) -- same final proof checks as the single-rank chain, decrypting to the message; with the
+    host witness pipeline and with the early phases on the device (every rank generates the identical witnesses either way)"""
     import json
     import subprocess
     import sys
     import __graft_entry__ as entry
-    env = dict(os.environ, VPBS_PBS_BACKEND="gloo", VPBS_PBS_DEVICE="0")
+    env = dict(os.environ, VPBS_PBS_BACKEND="gloo", VPBS_PBS_DEVICE="0", VPBS_IVC_DEVICE_WITNESS=str(device_witness))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29571",
            entry.ROOT + "/tools/prove_ivc.py", "8", "6", "13"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
