@@ -322,7 +322,11 @@ void vpbs_witness_plan_free(vpbs_witness_plan* plan);
 /* Two-phase runs, for a chain in which part of the PartialWitness arrives late -- the previous proof of an IVC step
  * (/root/reference/src/vtfhe/ivc_based_vpbs.rs:314-330: set_proof_with_pis_target(&inner_cyclic_proof_with_pis, &proof)): everything that does
  * not depend on the late targets is generated while the previous proof is still being computed.
- *   split     : late[i] != 0 marks preset i (plan order) as late; every generator that reads a late value, directly or not, becomes late
+ *   split     : late[i] != 0 marks preset i (plan order) as late; every generator that reads a late value, directly or not, becomes late.
+ *               late[i] = 1, 2, .. k (k <= 16) splits the late phase into STAGES: preset i arrives in stage late[i], a late generator belongs
+ *               to the highest stage among what it reads, and stage s can run (vpbs_witness_plan_run_late_stage) as soon as the presets of
+ *               stages <= s exist -- an IVC host runs the in-circuit verifier's transcript and vanishing check on the caps and openings of the
+ *               previous proof while that proof's FRI stage is still on the device (vpbs_step_inputs.on_section)
  *   run_early : the early presets (the late entries of preset_val are ignored), the early generators, the whole wire matrix (late wires 0)
  *   run_late  : the late presets, the late generators, the late wires written into the same matrix; consumes the state
  * run_early + run_late produce exactly the matrix of vpbs_witness_plan_run.
@@ -349,6 +353,15 @@ int vpbs_witness_plan_run_early_recycled(const vpbs_witness_plan* plan, const ui
 int vpbs_witness_plan_run_late(const vpbs_witness_plan* plan, vpbs_witness_state* state, const uint64_t* preset_val, uint64_t* wires_out,
                                char* err, size_t err_len);   /* the state is consumed whether the run succeeds or not */
 void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state that never reached run_late */
+/* Stages of the late phase (1 unless vpbs_witness_plan_split was given stage numbers; 0 before the split).  run_late_stage runs ONE stage
+ * ahead of run_late: the presets of that stage are read from preset_val (entries of other stages are not touched), its generators run on
+ * the late pool; stages run once each, in ascending order; the state is NOT consumed.  vpbs_witness_plan_run_late[_packed] then runs
+ * whatever stages are left and writes the late wires -- the result is the same matrix whichever stages ran ahead.  A failing stage (a
+ * value of the proof section that contradicts the circuit) returns VPBS_ERR_INVALID with the message; the state then only goes to
+ * vpbs_witness_state_free or run_late (which fails the same way). */
+unsigned vpbs_witness_plan_late_stages(const vpbs_witness_plan* plan);
+int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness_state* state, unsigned stage, const uint64_t* preset_val,
+                                     char* err, size_t err_len);
 /* The late phase without the matrix: the values of the late wire positions, packed in the order of vpbs_witness_plan_late_positions
  * (count = vpbs_witness_plan_late_count; positions column * n + row, fixed once the plan is split).  For a host whose early matrix is
  * already on the device: upload `values_out` (a few MB instead of the row range of every column) and let vpbs_device_scatter put the
@@ -400,6 +413,9 @@ int vpbs_witness_device_read_late_inputs(vpbs_witness_device* dev, unsigned inst
  * circuit fixes -- a proof that does not verify in circuit -- fails the call (vpbs_last_error names the class).  Afterwards
  * vpbs_witness_device_wires gathers the complete witness of the instance. */
 int vpbs_witness_device_run_late(vpbs_witness_device* dev, unsigned instance, const uint64_t* preset_val);
+/* 1 when the object carries a device schedule of the late phase (an early-only object of a split plan whose late generators all have a
+ * device form), 0 otherwise: vpbs_witness_device_run_late is only valid on such an object */
+int vpbs_witness_device_has_late(const vpbs_witness_device* dev);
 int vpbs_witness_device_run(vpbs_witness_device* dev, const uint64_t* preset_val, unsigned batch);
 /* gathers instance `instance` of the last run into d_wires (device, [n_wires][n], fully written) */
 int vpbs_witness_device_wires(vpbs_witness_device* dev, unsigned instance, uint64_t* d_wires);
@@ -415,6 +431,14 @@ int vpbs_check_witness(const vpbs_circuit* circuit, const uint64_t* wires /* [n_
                        char* err, size_t err_len);
 
 /* ---- one step proof minus the host-only stages (transcript order of Appendix A.3) ---- */
+/* Progress of a step proof, for a host that starts consuming the proof before it is complete (the IVC chain: the next step's in-circuit
+ * verifier, ivc_based_vpbs.rs:323-353): fn(user, section) runs on the proving thread, between two launches, when a SECTION of the proof is
+ * final in the caller's output buffers --
+ *   1: caps_out (all three caps) and openings_out                                   (the FRI stage starts now)
+ *   2: fri_out's commit-phase caps [n_rounds][cap], final polynomial and proof-of-work witness, at their final offsets
+ *      (the query rounds in between are still missing: they arrive with the return of the call)
+ * It must return quickly (hand the work to another thread): the device idles while it runs. */
+typedef void (*vpbs_step_section_fn)(void* user, int section);
 typedef struct {
     unsigned log_n;                   /* degree_bits: 16 for N=1024, 13 for N=8 (ivc_based_vpbs.rs:54-61 pads to 2^15 / 2^12 gates BEFORE build()) */
     unsigned n_wires;                 /* 135 */
@@ -444,6 +468,8 @@ typedef struct {
     unsigned num_selectors;           /* leading constants columns that are selector polynomials */
     int sigmas_on_device;             /* 1: sigmas_values is a device pointer even when inputs_on_device == 0 -- the sigma values are
                                          circuit data, uploaded once, while the wires of each proof arrive from the host */
+    vpbs_step_section_fn on_section;  /* NULL (zero-initialised struct): no progress calls */
+    void* on_section_user;
 } vpbs_step_inputs;
 
 /* Collectives for a step proof sharded over the GPUs of one node: supplied by the host, so the library
@@ -599,6 +625,8 @@ typedef struct {
     double seconds;             /* base proof + steps, wall clock */
     unsigned steps;
     double base_proof_ms, late_witness_ms, late_rows_upload_ms, prove_step_ms, early_witness_ms;   /* per step, except the base proof */
+    double late_ahead_ms;       /* per step: late witness stages that ran on a second thread WHILE the previous proof's FRI stage was on the
+                                   device (not part of late_witness_ms, which is what is left on the critical path after the proof) */
 } vpbs_ivc_timing;
 /* comm: NULL = one GPU.  Otherwise (BASELINE config 4) every rank of the node calls with its own context and its vpbs_comm (callbacks or
  * vpbs_comm_rccl_create): the chain is sequential, so the GPUs share every STEP -- constants / sigmas committed with
@@ -628,6 +656,8 @@ int vpbs_ivc_set_device_witness(vpbs_ivc* ivc, unsigned ELL, unsigned LOGB, unsi
  * (eight threads, AVX-512 Poseidon) is the faster one. */
 typedef void (*vpbs_ivc_step_fn)(void* user, unsigned done);
 int vpbs_ivc_set_step_callback(vpbs_ivc* ivc, vpbs_ivc_step_fn fn, void* user);
+/* text of the last failure of a vpbs_ivc_set_* call on this object ("" when none); valid until the next call on the object */
+const char* vpbs_ivc_last_error(const vpbs_ivc* ivc);
 /* circuit digest [4] then constants/sigmas cap of either circuit (what a verifier of the chain holds); either pointer may be NULL */
 int vpbs_ivc_verifier_data(const vpbs_ivc* ivc, uint64_t* cyclic_vk, uint64_t* dummy_vk);
 long vpbs_ivc_prove_pbs(vpbs_ivc* ivc, const uint64_t* testv, const uint64_t* ct, const uint64_t* bsk, const uint64_t* ksk, unsigned n_lwe,

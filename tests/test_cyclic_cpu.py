@@ -113,9 +113,42 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     late = np.zeros(len(cy.positions), np.uint8)
     late[:cy.shape.proof_words] = 1
     split.split(late)
+    # the late phase in STAGES (the sections of the previous proof in the order the prover finishes them: caps + openings | FRI commit caps,
+    # final polynomial, proof-of-work witness | query rounds): stages run ahead one by one give the wires of the one-stage plan
+    staged = cy.built.circuit.witness_plan(cy.positions)
+    sh = cy.shape
+    stage_of = np.zeros(len(cy.positions), np.uint8)
+    stage_of[:sh.proof_words] = 3
+    stage_of[:sh.caps_words + sh.openings_words] = 1
+    fri0 = sh.caps_words + sh.openings_words
+    stage_of[fri0:fri0 + len(sh.arity_bits) * 4 * sh.cap_len] = 2
+    stage_of[fri0 + sh.fri_words - 1 - 2 * sh.final_len:fri0 + sh.fri_words] = 2
+    staged.split(stage_of)
+    assert staged.late_stages() == 3 and split.late_stages() == 1
+    assert (staged.late_positions() == split.late_positions()).all() and (staged.late_input_positions() == split.late_input_positions()).all()
     for cond, ggsw, mask in steps:
         values = cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk, dummy_flat)
         wires = plan.run(values)
+        for ahead in (0, 1, 2, 3):   # how many stages run before run_late
+            three = np.empty_like(wires)
+            st3 = staged.run_early(values, three)
+            partial = values.copy()
+            for k in range(1, ahead + 1):
+                partial[:sh.proof_words][stage_of[:sh.proof_words] > k] = 0xBAD   # words of later stages do not exist yet
+                staged.run_late_stage(st3, k, partial)
+                partial = values.copy()
+            assert (staged.run_late_packed(st3, values) == wires.reshape(-1)[staged.late_positions()]).all(), ahead
+        if cond:   # a wrong word of the FIRST section is noticed by the first stage already (the transcript and the cap connections are there)
+            bad = values.copy()
+            bad[5] ^= np.uint64(1)       # a word of the wires cap
+            st3 = staged.run_early(values, np.empty_like(wires))
+            try:
+                staged.run_late_stage(st3, 1, bad)
+                staged.run_late_stage(st3, 2, bad)
+                with pytest.raises(api.VpbsError):
+                    staged.run_late_packed(st3, bad)
+            except api.VpbsError:
+                api.lib().vpbs_witness_state_free(st3)
         early_values = values.copy()
         early_values[:cy.shape.proof_words] = 0xDEAD                  # the late entries are not read by the early phase
         two = np.empty_like(wires)
@@ -156,6 +189,7 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
         proofs.append((proof, pis))
     plan.free()
     split.free()
+    staged.free()
     return proofs
 
 

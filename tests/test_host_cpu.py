@@ -36,6 +36,48 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(api.SIGNATURES), declared ^ set(api.SIGNATURES)
 
 
+def test_rust_binding_matches_the_header():
+    """The Rust side of the boundary (no rustc in the authoring image, so this test stands where the compiler would):
+    bindings/rust/vpbs_sys.rs is what tools/gen_rust_ffi.py makes of the header TODAY (a stale binding fails), it declares every function
+    the header does with the header's arity, and every `fn vpbs_*` declaration INTEGRATION.md shows is one of its lines -- a document that
+    drifts from the header (round 3: vpbs_ivc_set_device_witness had four arguments there and five here) is a test failure."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi
+    want = gen_rust_ffi.generate()
+    have = open(gen_rust_ffi.OUT).read()
+    assert have == want, "bindings/rust/vpbs_sys.rs is stale: run tools/gen_rust_ffi.py"
+    norm = lambda line: " ".join(line.replace("pub fn", "fn").split())
+    generated = {}
+    for line in have.splitlines():
+        m = re.match(r"\s*pub fn (vpbs_\w+)\(", line)
+        if m:
+            generated[m.group(1)] = norm(line)
+    # arity against an independent reading of the header (comma count of every prototype)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vpbs_prover.h")).read(), flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(vpbs_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr) if "(*" not in m.group(0)}
+    assert set(protos) == set(generated) and len(generated) >= 120
+    for name, args in protos.items():
+        n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        inner = generated[name][generated[name].index("(") + 1:generated[name].rindex(")")]
+        n_r = 0 if not inner.strip() else inner.count(",") + 1
+        assert n_c == n_r, (name, n_c, n_r)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shown = []
+    for block in re.findall(r"```rust\n(.*?)```", doc, flags=re.S):
+        for line in block.splitlines():
+            m = re.match(r"\s*(?:pub )?fn (vpbs_\w+)\(", line)
+            if m:
+                shown.append((m.group(1), norm(line.split("//")[0].rstrip())))
+    assert len(shown) >= 50
+    for name, line in shown:
+        assert name in generated, "INTEGRATION.md declares a function the header does not have: " + name
+        assert line == generated[name], "INTEGRATION.md and the header disagree on %s:\n  doc:    %s\n  header: %s" % (name, line, generated[name])
+    for must in ("vpbs_prove_step", "vpbs_verify_step", "vpbs_step_proof_to_bytes", "vpbs_rccl_unique_id", "vpbs_comm_rccl_create",
+                 "vpbs_comm_rccl_destroy", "vpbs_ivc_set_device_witness"):
+        assert must in dict(shown), must
+    assert "late_on_device: i32" in dict(shown)["vpbs_ivc_set_device_witness"]
+
+
 def test_no_device_fails_loudly():
     import torch
     if torch.cuda.is_available():

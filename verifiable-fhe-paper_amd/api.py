@@ -98,7 +98,7 @@ class StepInputsC(C.Structure):
                 ("public_inputs", U64P), ("n_public_inputs", C.c_size_t), ("forced_pow", C.c_uint64),
                 ("sigmas_values", C.c_void_p), ("n_routed", C.c_uint), ("quotient_degree_factor", C.c_uint),
                 ("n_constants", C.c_uint), ("gates", C.POINTER(GateC)), ("n_gates", C.c_uint), ("num_selectors", C.c_uint),
-                ("sigmas_on_device", C.c_int)]
+                ("sigmas_on_device", C.c_int), ("on_section", C.c_void_p), ("on_section_user", C.c_void_p)]
 
 
 class VerifyInputsC(C.Structure):
@@ -122,7 +122,8 @@ class IvcCircuitC(C.Structure):
 
 class IvcTimingC(C.Structure):
     _fields_ = [("seconds", C.c_double), ("steps", C.c_uint), ("base_proof_ms", C.c_double), ("late_witness_ms", C.c_double),
-                ("late_rows_upload_ms", C.c_double), ("prove_step_ms", C.c_double), ("early_witness_ms", C.c_double)]
+                ("late_rows_upload_ms", C.c_double), ("prove_step_ms", C.c_double), ("early_witness_ms", C.c_double),
+                ("late_ahead_ms", C.c_double)]
 
 
 class TfheParamsC(C.Structure):
@@ -225,6 +226,8 @@ SIGNATURES = {
     "vpbs_witness_state_free": (None, [C.c_void_p]),
     "vpbs_witness_plan_run_late_packed": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_late_count": (_sz, [C.c_void_p]),
+    "vpbs_witness_plan_late_stages": (_ui, [C.c_void_p]),
+    "vpbs_witness_plan_run_late_stage": (_i, [C.c_void_p, C.c_void_p, _ui, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_late_input_count": (_sz, [C.c_void_p]),
     "vpbs_witness_plan_late_input_positions": (_i, [C.c_void_p, U32P]),
     "vpbs_witness_state_from_late_inputs": (_i, [C.c_void_p, U64P, C.POINTER(C.c_void_p)]),
@@ -244,6 +247,8 @@ SIGNATURES = {
     "vpbs_ivc_verifier_data": (_i, [_vp, U64P, U64P]),
     "vpbs_ivc_set_step_callback": (_i, [_vp, IVC_STEP_FN, _vp]),
     "vpbs_ivc_set_device_witness": (_i, [_vp, _ui, _ui, _ui, _i]),
+    "vpbs_ivc_last_error": (C.c_char_p, [_vp]),
+    "vpbs_witness_device_has_late": (_i, [_vp]),
     "vpbs_witness_device_run_late": (_i, [C.c_void_p, C.c_uint, U64P]),
     "vpbs_ctx_device": (_i, [_vp]),
     "vpbs_ivc_prove_pbs": (C.c_long, [_vp, U64P, U64P, U64P, U64P, _ui, _ui, C.POINTER(C.c_uint8), _sz, C.POINTER(IvcTimingC), C.c_char_p, _sz]),
@@ -567,6 +572,18 @@ class WitnessPlan:
             raise VpbsError("vpbs_witness_plan_run_late: " + err.value.decode())
         return out
 
+    def late_stages(self):
+        """vpbs_witness_plan_late_stages: stages of the late phase (split() with stage numbers 1, 2, ..)"""
+        return int(lib().vpbs_witness_plan_late_stages(self.h))
+
+    def run_late_stage(self, state, stage, values):
+        """one late stage ahead of run_late (stages once each, ascending); the state is kept"""
+        val = _u64(values)
+        assert val.size == self.n_preset
+        err = C.create_string_buffer(512)
+        if lib().vpbs_witness_plan_run_late_stage(self.h, state, stage, _ptr(val), err, 512):
+            raise VpbsError("vpbs_witness_plan_run_late_stage: " + err.value.decode())
+
     def run_late_packed(self, state, values):
         """the late phase without the matrix -> the values of late_positions(), in that order; consumes the state"""
         val = _u64(values)
@@ -761,7 +778,9 @@ class Ivc:
     def set_device_witness(self, ELL, LOGB, batch, late_on_device=False):
         """vpbs_ivc_set_device_witness: the early witness phases of `batch` steps at a time on the device (0: back to the host pipeline);
         late_on_device: the late phase there as well (the host generates no witness)"""
-        self.ctx._check(lib().vpbs_ivc_set_device_witness(self.h, ELL, LOGB, batch, 1 if late_on_device else 0))
+        rc = lib().vpbs_ivc_set_device_witness(self.h, ELL, LOGB, batch, 1 if late_on_device else 0)
+        if rc != 0:
+            raise VpbsError("vpbs_ivc_set_device_witness: status %d: %s" % (rc, lib().vpbs_ivc_last_error(self.h).decode()))
 
     def on_step(self, fn):
         """vpbs_ivc_set_step_callback: fn(done) runs on the proving thread with done = 0 after the base proof and 1 .. steps after each

@@ -50,6 +50,20 @@ static double trace_now_us() {
     static const auto t0 = std::chrono::steady_clock::now();
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
+void vpbs_ctx::ensure_pinned() {
+    constexpr size_t STAGE = (size_t)1 << 20;
+    if (pinned) return;
+    if (hipHostMalloc(&pinned, STAGE, hipHostMallocDefault) == hipSuccess) pinned_bytes = STAGE - 64;   // the last 64 bytes: deferred flags
+    else pinned = nullptr;
+}
+volatile unsigned* vpbs_ctx::d2h_deferred_flag(const void* d_src) {
+    ensure_pinned();
+    if (!pinned) return nullptr;
+    auto* slot = reinterpret_cast<volatile unsigned*>(static_cast<char*>(pinned) + pinned_bytes);
+    *slot = 0xFFFFFFFFu;
+    VPBS_HIP(hipMemcpyAsync(const_cast<unsigned*>(slot), d_src, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return slot;
+}
 void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
     static const bool trace = getenv("VPBS_TRACE") != nullptr;
     const double t_begin = trace ? trace_now_us() : 0;
@@ -57,11 +71,7 @@ void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
         bool on; double t0; size_t b;
         ~Tr() { if (on) std::fprintf(stderr, "[vpbs trace] d2h_sync %zu B: host arrived %.1f us, returned %.1f us (waited %.1f)\n", b, t0, trace_now_us(), trace_now_us() - t0); }
     } tr{trace, t_begin, bytes};
-    constexpr size_t STAGE = (size_t)1 << 20;
-    if (!pinned) {
-        if (hipHostMalloc(&pinned, STAGE, hipHostMallocDefault) == hipSuccess) pinned_bytes = STAGE;
-        else pinned = nullptr;
-    }
+    ensure_pinned();
     if (pinned && bytes <= pinned_bytes) {
         VPBS_HIP(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, stream));
         VPBS_HIP(hipStreamSynchronize(stream));

@@ -55,6 +55,10 @@ struct vpbs_ctx {
     size_t pinned_bytes = 0;
     // copy + stream synchronise; dst is ordinary (pageable) caller memory
     void d2h_sync(void* dst, const void* d_src, size_t bytes);
+    void ensure_pinned();
+    // a 4-byte device flag copied to pinned memory WITHOUT a synchronisation of its own: the value is there after the next d2h_sync (or
+    // any synchronisation of the stream).  One flag in flight per context.  nullptr when no pinned memory could be had (the caller syncs).
+    volatile unsigned* d2h_deferred_flag(const void* d_src);
 
     // ---- tables ----
     std::map<std::pair<unsigned, bool>, vpbs::u64*> root_tables;                 // (log_n, inverse)

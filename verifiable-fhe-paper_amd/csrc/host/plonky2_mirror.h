@@ -148,7 +148,7 @@ public:
     // comm: needed when any oracle is sharded (query records are merged with comm->allreduce_sum)
     static void prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& instance, const std::vector<vpbs_batch*>& oracles,
                                Challenger& challenger, const FriParams& fri_params, u64 forced_pow, u64* proof_out,
-                               const vpbs_comm* comm = nullptr);
+                               const vpbs_comm* comm = nullptr, vpbs_step_section_fn on_section = nullptr, void* on_section_user = nullptr);
 };
 
 size_t fri_proof_words(const FriParams& p, const std::vector<size_t>& ncols);

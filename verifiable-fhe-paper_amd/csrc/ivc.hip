@@ -112,6 +112,109 @@ struct Side {   // one circuit on the context
         plan = nullptr; cs = nullptr; d_sigma = nullptr; d_csv = nullptr;
     }
 };
+// The late witness phase of step s + 1 in STAGES, started before the proof of step s is complete (the reference's loop
+// ivc_based_vpbs.rs:323-353 hands a finished proof to the next step -- here the next step's in-circuit verifier starts on the sections of
+// the proof as the prover finishes them).  The proof words are late presets of three stages (vpbs_witness_plan_split with stage numbers):
+//   1  caps and openings            -> the in-circuit transcript up to the FRI challenges, the vanishing check at zeta, the reduced openings
+//   2  FRI commit caps, final polynomial, proof-of-work witness -> the rest of the transcript, the query indices
+//   3  the query rounds             -> Merkle paths, folds: what is left on the critical path when the proof returns
+// A worker thread runs stages 1 and 2 on the next step's state (vpbs_witness_plan_run_late_stage) while the previous proof's FRI stage is
+// still on the device; vpbs_step_inputs.on_section posts them.  The caller then drains the worker and runs vpbs_witness_plan_run_late_packed,
+// which only has stage 3 left.
+struct LateAhead {
+    const vpbs_witness_plan* plan = nullptr;
+    std::vector<std::vector<std::pair<size_t, size_t>>> ranges;   // per stage: [begin, end) word ranges of the flat proof
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    vpbs_witness_state* st = nullptr;   // the job: state and PartialWitness values of the NEXT step, the proof being written
+    u64* values = nullptr;
+    const u64* proof = nullptr;
+    unsigned posted = 0, done = 0;
+    bool quit = false, failed = false;
+    std::string err;
+    double busy_s = 0;
+
+    // stage of every proof word -> late mask for vpbs_witness_plan_split (the other presets: 0) and the ranges a stage copies
+    void layout(size_t cap_words, size_t openings_words, size_t fri_words, unsigned n_rounds, size_t final_words, std::vector<uint8_t>& late) {
+        const size_t head = 3 * cap_words + openings_words, fri_caps = (size_t)n_rounds * cap_words, tail = final_words + 1;
+        ranges.assign(3, {});
+        ranges[0].push_back({0, head});
+        ranges[1].push_back({head, head + fri_caps});
+        ranges[1].push_back({head + fri_words - tail, head + fri_words});
+        ranges[2].push_back({head + fri_caps, head + fri_words - tail});
+        for (size_t k = 0; k < 3; ++k)
+            for (auto& r : ranges[k]) std::fill(late.begin() + r.first, late.begin() + r.second, (uint8_t)(k + 1));
+    }
+    void start(const vpbs_witness_plan* p) {
+        plan = p;
+        th = std::thread([this] { run(); });
+    }
+    bool active() const { return st != nullptr; }
+    void begin(vpbs_witness_state* state, u64* vals, const u64* proof_words) {   // proving thread, nothing posted yet
+        std::lock_guard<std::mutex> lk(m);
+        st = state; values = vals; proof = proof_words;
+        posted = done = 0;
+        failed = false;
+        err.clear();
+    }
+    void post(unsigned stage) {   // proving thread (on_section): the words of stages <= stage are final
+        {
+            std::lock_guard<std::mutex> lk(m);
+            posted = std::max(posted, std::min<unsigned>(stage, 2));
+        }
+        cv.notify_all();
+    }
+    // waits for the posted stages; afterwards the job is the caller's again (run_late for the rest).  false: a stage failed (msg)
+    bool drain(std::string& msg) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done >= posted; });
+        st = nullptr;
+        if (failed) msg = err;
+        return !failed;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    ~LateAhead() { stop(); }
+
+  private:
+    void run() {
+        char e[256];
+        for (;;) {
+            unsigned stage;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || (st && done < posted); });
+                if (quit) return;
+                stage = done + 1;
+            }
+            const double t = now();
+            bool ok = !failed;
+            if (ok) {
+                if (values != proof)
+                    for (auto& r : ranges[stage - 1]) std::memcpy(values + r.first, proof + r.first, 8 * (r.second - r.first));
+                e[0] = 0;
+                ok = vpbs_witness_plan_run_late_stage(plan, st, stage, values, e, sizeof e) == 0;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                busy_s += now() - t;
+                if (!ok && !failed) {
+                    failed = true;
+                    err = e;
+                }
+                done = stage;
+            }
+            cv.notify_all();
+        }
+    }
+};
 }  // namespace
 
 struct vpbs_ivc {
@@ -120,6 +223,8 @@ struct vpbs_ivc {
     unsigned N = 0, K = 0;
     size_t proof_words = 0, ggsw_len = 0, kn = 0, n_pi = 0, wire_words = 0;
     std::vector<u64> dummy_proof;   // the second proof slot: the dummy circuit's proof of all-zero public inputs (vpbs_ivc_create)
+    bool staged = false;            // the cyclic plan is split into three late stages (LateAhead)
+    LateAhead ahead_layout;         // ranges only (the worker belongs to a prove_pbs call)
     size_t late_rows[2] = {0, 0};
     size_t late_count = 0;                       // wire positions the late witness phase writes (vpbs_witness_plan_late_count)
     u64 *late_vals = nullptr;                    // their values, packed, pinned (vpbs_witness_plan_run_late_packed)
@@ -207,6 +312,23 @@ int vpbs_ivc_create(vpbs_ctx* ctx, const vpbs_ivc_circuit* cyclic, const vpbs_iv
     if (rc == 0) {
         std::vector<uint8_t> late(cyclic->n_preset, 0);
         std::fill(late.begin(), late.begin() + cyclic->proof_words, 1);
+        // the proof's sections as late STAGES (LateAhead); VPBS_IVC_LATE_STAGES=0: one late phase after the proof, as in rounds 2-3 (A-B runs)
+        const char* ev = std::getenv("VPBS_IVC_LATE_STAGES");
+        if (!(ev && std::atoi(ev) == 0)) {
+            vpbs_fri_params fp;
+            vpbs_fri_params_standard(v->cyc.log_n, &fp);
+            unsigned final_bits = v->cyc.log_n;
+            for (unsigned i = 0; i < fp.n_rounds; ++i) final_bits -= fp.arity_bits[i];
+            vpbs_step_inputs shape;
+            vpbs_step_sizes sz{};
+            v->cyc.step_inputs(shape, nullptr, true, nullptr);
+            const size_t fri_fixed = (size_t)fp.n_rounds * cap_words + ((size_t)2 << final_bits) + 1;
+            if (vpbs_step_sizes_get(ctx, &shape, &sz) == 0 && sz.cap_words == cap_words &&
+                3 * sz.cap_words + sz.openings_words + sz.fri_words == cyclic->proof_words && sz.fri_words > fri_fixed) {
+                v->ahead_layout.layout(cap_words, sz.openings_words, sz.fri_words, fp.n_rounds, (size_t)2 << final_bits, late);
+                v->staged = true;
+            }
+        }
         char e[256] = {0};
         rc = vpbs_witness_plan_split(v->cyc.plan, late.data(), e, sizeof e);
         if (rc != 0) v->err = std::string("split: ") + e;
@@ -274,6 +396,8 @@ int vpbs_ivc_set_step_callback(vpbs_ivc* v, vpbs_ivc_step_fn fn, void* user) {
     return VPBS_OK;
 }
 
+const char* vpbs_ivc_last_error(const vpbs_ivc* v) { return v ? v->err.c_str() : ""; }
+
 int vpbs_ivc_verifier_data(const vpbs_ivc* v, uint64_t* cyclic_vk, uint64_t* dummy_vk) {
     if (!v) return VPBS_ERR_INVALID;
     if (cyclic_vk) std::memcpy(cyclic_vk, v->cyc.vk.data(), 8 * v->cyc.vk.size());
@@ -285,6 +409,7 @@ int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsign
     if (!v) return VPBS_ERR_INVALID;
     v->drop_device_witness();
     v->dw_late = false;
+    v->err.clear();
     if (batch == 0) return VPBS_OK;
     if (ELL == 0 || LOGB == 0 || v->ggsw_len != (size_t)v->K * ELL * v->K * v->N) {
         v->err = "device witness: ELL / LOGB do not fit the circuit's GGSW length";
@@ -295,6 +420,11 @@ int vpbs_ivc_set_device_witness(vpbs_ivc* v, unsigned ELL, unsigned LOGB, unsign
         rc = vpbs_ctx_create(vpbs_ctx_device(v->ctx), v->cyc.log_n, vpbs_ctx_rate_bits(v->ctx), vpbs_ctx_cap_height(v->ctx), &v->wctx[i]);
         if (rc == 0) rc = vpbs_witness_device_create_early(v->wctx[i], v->cyc.plan, batch, &v->wdev[i]);
         if (rc != 0) v->err = std::string("device witness: ") + (v->wctx[i] ? vpbs_last_error(v->wctx[i]) : "no context");
+        if (rc == 0 && late_on_device && !vpbs_witness_device_has_late(v->wdev[i])) {
+            v->err = "device witness: late_on_device was requested, but the late phase of this circuit has no device schedule (a late generator "
+                     "without a device form); use late_on_device = 0";
+            rc = VPBS_ERR_INVALID;
+        }
     }
     if (rc == 0 && !(v->dw_presets = static_cast<u64*>(vpbs_host_alloc(8 * v->cyc.n_preset * (size_t)batch)))) {
         v->err = "device witness: out of pinned memory";
@@ -356,11 +486,11 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     std::atomic<bool> failed{false};
     std::string thread_err;
     auto fail = [&](const std::string& m) {
-        {
+        {   // the flag changes under the lock: a waiter that has just evaluated its predicate cannot miss the notification
             std::lock_guard<std::mutex> lk(mu);
             if (thread_err.empty()) thread_err = m;
+            failed = true;
         }
-        failed = true;
         cv.notify_all();
     };
     unsigned hashed = 0;        // steps whose chain hashes are in pis (guarded by mu)
@@ -428,8 +558,16 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             cv.notify_all();
         }
     });
-    // thread S: per step, the instance's wires into one of the device matrices and the late phase's inputs to the host
+    // thread S: per step, the instance's wires into one of the device matrices, the late phase's inputs to the host and the late phase's
+    // state seeded with them (allocation and first touch of its pages happen here, ahead of the chain)
     std::vector<std::vector<u64>> late_in(vpbs_ivc::NBUF, std::vector<u64>(v->late_in_count));
+    struct States {   // owned here until the caller takes one; whatever is left at the end is freed
+        vpbs_witness_state* st[vpbs_ivc::NBUF] = {nullptr, nullptr, nullptr};
+        ~States() {
+            for (auto* x : st)
+                if (x) vpbs_witness_state_free(x);
+        }
+    } states;
     std::thread stager([&] {
         if (v->dw_late) return;   // the caller runs the late phase on the device object itself and gathers afterwards
         for (unsigned s = 0; s < steps && !failed; ++s) {
@@ -442,8 +580,12 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             if (vpbs_witness_device_wires(v->wdev[b & 1], s % B, v->d_bufs[k]) != 0 ||
                 vpbs_witness_device_read_late_inputs(v->wdev[b & 1], s % B, late_in[k].data()) != 0)
                 return fail("gathering the early wires of step " + std::to_string(s) + ": " + vpbs_last_error(v->wctx[b & 1]));
+            vpbs_witness_state* st = nullptr;
+            if (vpbs_witness_state_from_late_inputs(cyc.plan, late_in[k].data(), &st) != 0)
+                return fail("late witness phase of step " + std::to_string(s) + ": the early values read back from the device are malformed");
             {
                 std::lock_guard<std::mutex> lk(mu);
+                states.st[k] = st;
                 staged = s + 1;
             }
             cv.notify_all();
@@ -477,6 +619,41 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     const double t_base = now() - t0;
     if (v->step_fn) v->step_fn(v->step_user, 0);
     double t_late = 0, t_rows = 0, t_prove = 0, t_wait_staged = 0, t_wait_hashed = 0;
+    // late stages 1 and 2 of the next step while this step's FRI stage runs (LateAhead); here the prover writes the proof straight into
+    // `values`, the array the late phase reads its presets from
+    vpbs_witness_state* next_state = nullptr;   // taken from `states` by the hook; declared before the worker (joined first)
+    struct NextGuard {
+        vpbs_witness_state*& p;
+        ~NextGuard() {
+            if (p) vpbs_witness_state_free(p);
+        }
+    } next_guard{next_state};
+    LateAhead ahead;
+    if (v->staged && !v->dw_late) {
+        ahead.ranges = v->ahead_layout.ranges;
+        ahead.start(cyc.plan);
+    }
+    struct Hook {
+        LateAhead* ahead;
+        std::mutex* mu;
+        const unsigned* staged;
+        States* states;
+        vpbs_witness_state** next_state;
+        u64* values;
+        unsigned step = 0;   // the step being proven
+        static void section(void* user, int sec) {
+            auto* h = static_cast<Hook*>(user);
+            if (!*h->next_state) {
+                std::lock_guard<std::mutex> lk(*h->mu);
+                if (*h->staged <= h->step + 1) return;   // the next step is not staged yet: its late phase runs whole, after the proof
+                const unsigned k = (h->step + 1) % vpbs_ivc::NBUF;
+                *h->next_state = h->states->st[k];
+                h->states->st[k] = nullptr;
+                h->ahead->begin(*h->next_state, h->values, h->values);
+            }
+            h->ahead->post((unsigned)sec);
+        }
+    } hook{&ahead, &mu, &staged, &states, &next_state, values.data()};
     for (unsigned s = 0; s < steps; ++s) {
         const unsigned k = s % vpbs_ivc::NBUF;
         {
@@ -507,9 +684,19 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             if (rc != 0) return stop(std::string("gathering the wires: ") + vpbs_last_error(v->wctx[(s / B) & 1]), rc);
             t_rows += now() - t;
         } else {
-            vpbs_witness_state* st = nullptr;
-            rc = vpbs_witness_state_from_late_inputs(cyc.plan, late_in[k].data(), &st);
-            if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + ": the early values read back from the device are malformed", rc);
+            vpbs_witness_state* st = next_state;
+            next_state = nullptr;
+            if (st) {   // stages ran ahead on it: wait for the last of them
+                std::string msg;
+                if (!ahead.drain(msg)) {
+                    vpbs_witness_state_free(st);
+                    return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
+                }
+            } else {
+                std::lock_guard<std::mutex> lk(mu);
+                st = states.st[k];
+                states.st[k] = nullptr;
+            }
             rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, values.data(), v->late_vals, e, sizeof e);
             if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
             t_late += now() - t;
@@ -520,8 +707,19 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
         }
         t = now();
         cyc.step_inputs(in, v->d_bufs[k], true, pis.data() + (size_t)(s + 1) * n_pi);
+        if (v->staged && !v->dw_late && s + 1 < steps) {
+            hook.step = s;
+            in.on_section = &Hook::section;
+            in.on_section_user = &hook;
+        }
         rc = cyc.prove(in, caps, openings, fri);
-        if (rc != 0) return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        if (rc != 0) {
+            if (ahead.active()) {   // the worker may be inside a stage of the next step's state
+                std::string ignored;
+                (void)ahead.drain(ignored);
+            }
+            return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        }
         t_prove += now() - t;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -551,6 +749,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
         timing->late_rows_upload_ms = 1e3 * t_rows / steps;
         timing->prove_step_ms = 1e3 * t_prove / steps;
         timing->early_witness_ms = 1e3 * t_early / steps;
+        timing->late_ahead_ms = 1e3 * ahead.busy_s / steps;
     }
     return n_bytes;
 }
@@ -613,11 +812,11 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     std::string thread_err;
     double t_early = 0;
     auto fail = [&](const std::string& m) {
-        {
+        {   // the flag changes under the lock: a waiter that has just evaluated its predicate cannot miss the notification
             std::lock_guard<std::mutex> lk(mu);
             if (thread_err.empty()) thread_err = m;
+            failed = true;
         }
-        failed = true;
         cv.notify_all();
     };
     std::thread early([&] {
@@ -709,9 +908,41 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     const double t_base = now() - t0;
     if (v->step_fn) v->step_fn(v->step_user, 0);
     double t_late = 0, t_rows = 0, t_prove = 0;
+    // the next step's late stages 1 and 2 run on a worker while this step's FRI stage is on the device (LateAhead): the prover reports its
+    // sections (on_section, on this thread); the first report that finds the next step's early phase finished and uploaded takes it
+    Ready next;   // declared before the worker: the worker is joined before the state it may be working on goes away
+    bool have_next = false;
+    LateAhead ahead;
+    if (v->staged) {
+        ahead.ranges = v->ahead_layout.ranges;
+        ahead.start(cyc.plan);
+    }
+    struct Hook {
+        LateAhead* ahead;
+        std::mutex* mu;
+        std::deque<Ready>* ready;
+        Ready* next;
+        bool* have_next;
+        const u64* proof;
+        static void section(void* user, int sec) {
+            auto* h = static_cast<Hook*>(user);
+            if (!*h->have_next) {
+                std::lock_guard<std::mutex> lk(*h->mu);
+                if (h->ready->empty()) return;   // its early phase is still running: this step's late phase runs whole, after the proof
+                *h->next = std::move(h->ready->front());
+                h->ready->pop_front();
+                *h->have_next = true;
+                h->ahead->begin(h->next->state, h->next->values.data(), h->proof);
+            }
+            h->ahead->post((unsigned)sec);
+        }
+    } hook{&ahead, &mu, &ready, &next, &have_next, proof.data()};
     for (unsigned s = 0; s < steps; ++s) {
         Ready r;
-        {
+        if (have_next) {
+            r = std::move(next);
+            have_next = false;
+        } else {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !ready.empty() || failed; });
             if (failed) {
@@ -722,6 +953,10 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
             ready.pop_front();
         }
         double t = now();
+        if (ahead.active()) {   // stages that ran ahead on this step's state: wait for the last of them (usually long finished)
+            std::string msg;
+            if (!ahead.drain(msg)) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
+        }
         std::copy(proof.begin(), proof.end(), r.values.begin());
         vpbs_witness_state* st = r.state;
         r.state = nullptr;
@@ -735,8 +970,18 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         t = now();
         pis = std::move(r.pis);
         cyc.step_inputs(in, v->d_bufs[r.buf], true, pis.data());
+        if (v->staged && s + 1 < steps) {
+            in.on_section = &Hook::section;
+            in.on_section_user = &hook;
+        }
         rc = cyc.prove(in, caps, openings, fri);
-        if (rc != 0) return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        if (rc != 0) {
+            if (ahead.active()) {   // the worker may be inside a stage of the next step's state: let it finish before that state is freed
+                std::string ignored;
+                (void)ahead.drain(ignored);
+            }
+            return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
+        }
         t_prove += now() - t;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -761,6 +1006,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         timing->late_rows_upload_ms = 1e3 * t_rows / steps;
         timing->prove_step_ms = 1e3 * t_prove / steps;
         timing->early_witness_ms = 1e3 * t_early / steps;
+        timing->late_ahead_ms = 1e3 * ahead.busy_s / steps;
     }
     return n_bytes;
 }

@@ -84,7 +84,7 @@ u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forc
 
 void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& instance, const std::vector<vpbs_batch*>& oracles,
                                      Challenger& challenger, const FriParams& fp, u64 forced_pow, u64* proof_out,
-                                     const vpbs_comm* comm) {
+                                     const vpbs_comm* comm, vpbs_step_section_fn on_section, void* on_section_user) {
     hipStream_t s = ctx->stream;
     const unsigned degree_bits = fp.degree_bits, rate_bits = fp.config.rate_bits, cap_h = fp.config.cap_height;
     const size_t n = (size_t)1 << degree_bits;
@@ -235,6 +235,15 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
 
     // ---- fri_proof_of_work ----
     const u64 pow_witness = fri_proof_of_work(ctx, challenger, fp.config.proof_of_work_bits, forced_pow);
+    {   // final polynomial and nonce go to their final place now (behind the query rounds), so that a host reading the proof section by
+        // section (vpbs_step_inputs.on_section, section 2) finds everything but the query rounds
+        std::vector<size_t> ncols;
+        for (auto* o : oracles) ncols.push_back(o->ncols);
+        u64* tail = proof_out + fri_proof_words(fp, ncols) - 1 - final_words.size();
+        std::memcpy(tail, final_words.data(), sizeof(u64) * final_words.size());
+        tail[final_words.size()] = pow_witness;
+        if (on_section) on_section(on_section_user, 2);
+    }
 
     // ---- fri_prover_query_rounds ----
     vpbs::OpenArgs args{};
@@ -292,17 +301,23 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
     if (multi && comm->allreduce_sum(comm->user, w, off * args.n_queries) != 0)
         throw DeviceError{VPBS_ERR_DEVICE, "query-record all-reduce failed"};
     w += off * args.n_queries;
-    std::memcpy(w, final_words.data(), sizeof(u64) * final_words.size());
-    w += final_words.size();
-    *w++ = pow_witness;
+    {   // the tail was written right after the proof of work; the two layouts must agree
+        std::vector<size_t> ncols;
+        for (auto* o : oracles) ncols.push_back(o->ncols);
+        VPBS_REQUIRE(w == proof_out + fri_proof_words(fp, ncols) - 1 - final_words.size(), "FRI proof layout: query rounds and word count disagree");
+    }
     VPBS_HIP(hipGetLastError());
 }
 }  // namespace plonky2
 
 namespace {
 // all_wires_permutation_partial_products on the device; d_out: [nc * (num_prods + 1)][n]
+// deferred (nullable): instead of synchronising for the zero-denominator flag here, the flag travels to pinned memory behind the kernels and
+// *deferred points at it -- the caller checks it after ITS next synchronisation (the step proof: with the cap of the Z commitment), so the
+// host goes on enqueueing that commitment at once.  *deferred stays null when the flag was checked here.
 void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sigmas, unsigned n_routed, unsigned log_n,
-                             const u64* betas, const u64* gammas, unsigned nc, unsigned max_degree, u64* d_out) {
+                             const u64* betas, const u64* gammas, unsigned nc, unsigned max_degree, u64* d_out,
+                             volatile unsigned** deferred = nullptr) {
     VPBS_REQUIRE(log_n >= 1 && n_routed >= 1 && max_degree >= 1 && nc >= 1, "bad partial-product shape");
     const size_t n = (size_t)1 << log_n;
     hipStream_t s = ctx->stream;
@@ -322,7 +337,8 @@ void partial_products_device(vpbs_ctx* ctx, const u64* d_wires, const u64* d_sig
             vpbs::launch_partial_products(s, d_wires, d_sigmas, ctx->roots(log_n, false), n_routed, log_n, max_degree, d_ch, d_ch + nc, nc,
                                           d_out, scratch, reinterpret_cast<unsigned*>(d_ch + 2 * nc));
         }
-        ctx->d2h_sync(&flag, d_ch + 2 * nc, sizeof(unsigned));
+        if (deferred) *deferred = ctx->d2h_deferred_flag(d_ch + 2 * nc);
+        if (!deferred || !*deferred) ctx->d2h_sync(&flag, d_ch + 2 * nc, sizeof(unsigned));
     } catch (...) {
         ctx->release(d_ch);
         ctx->release(scratch);
@@ -772,15 +788,18 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         const std::vector<u64> betas = challenger.get_n_challenges(nc);
         const std::vector<u64> gammas = challenger.get_n_challenges(nc);
         // all_wires_permutation_partial_products(betas, gammas): on the device when no precomputed matrix is supplied
+        volatile unsigned* pp_flag = nullptr;
         if (!d_zs) {
             u64* d_pp = ctx->alloc_words((size_t)in->n_zs_partial_products * n);
             staged.push_back(d_pp);
             partial_products_device(ctx, d_wires, d_sigmas, in->n_routed, log_n, betas.data(), gammas.data(), nc,
-                                    in->quotient_degree_factor, d_pp);
+                                    in->quotient_degree_factor, d_pp, &pp_flag);
             d_zs = d_pp;
         }
         PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n, false, comm);
         zs_pp.merkle_cap(caps_out + cap_words, comm);
+        // the flag of the partial products arrived with the cap (one round trip instead of two)
+        VPBS_REQUIRE(!pp_flag || *pp_flag == 0, "zero denominator in the permutation argument (the reference's batch inverse would panic)");
         challenger.observe_cap(caps_out + cap_words, cap_words / 4);
         const std::vector<u64> alphas = challenger.get_n_challenges(nc);
         // compute_quotient_polys(alphas): supplied coefficient chunks, or evaluated on the device (permutation argument +
@@ -847,12 +866,13 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             vpbs::launch_eval_ext_multi(s, segs, n, d_open);
         }
         ctx->d2h_sync(openings_out, d_open, sizeof(u64) * 2 * (total_cols + nc));
+        if (in->on_section) in->on_section(in->on_section_user, 1);   // caps and openings are final
         // challenger.observe_openings(&openings.to_fri_openings()): zeta batch then zeta_next batch
         challenger.observe_elements(openings_out, 2 * (total_cols + nc));
 
         FriParams fp = FriParams::standard(log_n, ctx->rate_bits, ctx->cap_height);
         fp.mul_final_by_x = ctx->compat.fri_mul_final_by_x != 0;   // the switch table of include/vpbs_prover.h
-        PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out, comm);
+        PolynomialBatch::prove_openings(ctx, instance, oracles, challenger, fp, in->forced_pow, fri_out, comm, in->on_section, in->on_section_user);
         if (challenger_out) *challenger_out = challenger.st;
     });
 }

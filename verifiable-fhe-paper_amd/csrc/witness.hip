@@ -500,21 +500,35 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
         return VPBS_ERR_INVALID;
     }
     vpbs_witness_plan& p = *pp;
+    // taint[slot]: 0 = the early phase has the value; k > 0 = it exists once late stage k has run (late[i] is the stage preset i arrives
+    // in: 1, 2, ...; a step belongs to the highest stage among what it reads)
     std::vector<uint8_t> taint(p.n_slots, 0), ready(p.n_slots, 1), known_early(p.n_slots, 0);
     p.preset_late.assign(late, late + p.preset_slot.size());
-    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+    unsigned n_stages = 1;
+    for (size_t i = 0; i < p.preset_slot.size(); ++i) {
         if (!late[i]) known_early[p.preset_slot[i]] = 1;
+        n_stages = std::max<unsigned>(n_stages, late[i]);
+    }
+    if (n_stages > 16) {
+        err = "more than 16 late stages";
+        return VPBS_ERR_INVALID;
+    }
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
-        if (late[i] && !known_early[p.preset_slot[i]]) taint[p.preset_slot[i]] = 1;
-    auto wrote = [&](u32 slot, bool is_late) {
-        if (!is_late) {
+        if (late[i] && !known_early[p.preset_slot[i]]) {
+            uint8_t& t = taint[p.preset_slot[i]];
+            t = t ? std::min(t, late[i]) : late[i];   // a class preset in two stages has its value from the first one on (the second compares)
+        }
+    auto wrote = [&](u32 slot, uint8_t stage) {
+        if (!stage) {
             known_early[slot] = 1;
             taint[slot] = 0;   // a late step may have been the first to reach it in the schedule: the early phase has the value all the same
-        } else if (!known_early[slot]) {
-            taint[slot] = 1;
+        } else if (!known_early[slot] && !taint[slot]) {
+            taint[slot] = stage;   // the first writer in schedule order decides from when on readers may count on the value
         }
     };
+    p.n_stages = n_stages;
     p.step_late.assign(p.schedule.size(), 0);
+    p.step_stage.assign(p.schedule.size(), 0);
     const unsigned mc = std::max(1u, p.max_consts);
     std::vector<unsigned> deps;
     std::vector<u32> written, written_w;
@@ -527,17 +541,19 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     for (size_t i = 0; i < p.schedule.size(); ++i) {
         const auto& st = p.schedule[i];
         bool is_late = false;
+        uint8_t stage = 0;
         u32 lvl = 1;
         if (st.row == NO_ROW) {
             const auto& gg = p.gadgets[st.sub];
             const u32* gs = p.gadget_slots.data() + gg.at;
-            for (unsigned k = 0; k < gg.n_in; ++k) is_late |= taint[gs[k]] != 0;
+            for (unsigned k = 0; k < gg.n_in; ++k) stage = std::max(stage, taint[gs[k]]);
+            is_late = stage != 0;
             step_io.insert(step_io.end(), gs, gs + gg.n_in + gg.n_out);
             step_n_in[i] = gg.n_in;
             std::vector<u32>& sl = slot_level[is_late];
             for (unsigned k = 0; k < gg.n_in + gg.n_out; ++k) lvl = std::max(lvl, sl[gs[k]] + 1);
             for (unsigned k = 0; k < gg.n_out; ++k) {
-                wrote(gs[gg.n_in + k], is_late);
+                wrote(gs[gg.n_in + k], stage);
                 // a late step that writes a value the early phase has is a comparer: nothing in the late phase waits for it
                 if (sl[gs[gg.n_in + k]] == 0 && !(is_late && known_early[gs[gg.n_in + k]])) sl[gs[gg.n_in + k]] = lvl;
             }
@@ -545,7 +561,8 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             const vpbs_gate& g = p.gates[p.row_gate[st.row]];
             const u32* rs = p.row_slots.data() + p.row_off[st.row];
             gen_deps(g, st.sub, deps);
-            for (unsigned w : deps) is_late |= taint[rs[w]] != 0;
+            for (unsigned w : deps) stage = std::max(stage, taint[rs[w]]);
+            is_late = stage != 0;
             written.clear();
             written_w.clear();
             FlagRow fr{ready, rs, written, written_w};
@@ -562,13 +579,14 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             for (unsigned w : deps) lvl = std::max(lvl, sl[rs[w]] + 1);
             for (u32 slot : written) lvl = std::max(lvl, sl[slot] + 1);   // an earlier writer of the phase: this one compares, after it
             for (u32 slot : written) {
-                wrote(slot, is_late);
+                wrote(slot, stage);
                 if (sl[slot] == 0 && !(is_late && known_early[slot])) sl[slot] = lvl;
             }
         }
         step_level[i] = lvl;
         max_level[is_late] = std::max(max_level[is_late], lvl);
         p.step_late[i] = is_late ? 1 : 0;
+        p.step_stage[i] = stage;
         step_io_off[i + 1] = (u32)step_io.size();
     }
     // ---- chain lanes (see vpbs_witness_plan::Lane) ----
@@ -630,6 +648,7 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             ++chain_rows[chain_of[i]];
         }
         if (n_cand < LANE_MIN_ROWS) continue;
+        if (ph == 1 && n_stages > 1) continue;   // a staged late phase runs stage by stage: its (few) chain rows stay in the levels
         std::vector<std::pair<u32, u32>> comps;   // (rows, chain)
         for (u32 c = 0; c < chain_rows.size(); ++c) comps.push_back({chain_rows[c], c});
         std::sort(comps.begin(), comps.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
@@ -657,18 +676,29 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             L.wait_off.push_back((u32)L.wait.size());
         }
     }
-    for (int ph = 0; ph < 2; ++ph) {
-        vpbs_witness_plan::Phase& P = p.phase[ph];
+    p.late_stage.assign(n_stages > 1 ? n_stages : 0, vpbs_witness_plan::Phase{});
+    for (unsigned q = 0; q < 2 + p.late_stage.size(); ++q) {
+        // q = 0, 1: the early and the late phase as a whole; q = 2 + k: stage k + 1 of a staged late phase alone
+        const int ph = q < 2 ? (int)q : 1;
+        const uint8_t only_stage = q < 2 ? 0 : (uint8_t)(q - 1);
+        vpbs_witness_plan::Phase& P = q < 2 ? p.phase[q] : p.late_stage[q - 2];
+        auto mine = [&](size_t i) { return p.step_late[i] == ph && lane_of[i] < 0 && (!only_stage || p.step_stage[i] == only_stage); };
         // counting sort of the phase's steps by level (schedule order kept inside a level)
         P.level_off.assign(max_level[ph] + 2, 0);
         for (size_t i = 0; i < p.schedule.size(); ++i)
-            if (p.step_late[i] == ph && lane_of[i] < 0) ++P.level_off[step_level[i] + 1];
+            if (mine(i)) ++P.level_off[step_level[i] + 1];
         for (u32 l = 1; l <= max_level[ph] + 1; ++l) P.level_off[l] += P.level_off[l - 1];
         P.order.assign(P.level_off[max_level[ph] + 1], 0);
         {
             std::vector<u32> at(P.level_off.begin(), P.level_off.end() - 1);
             for (size_t i = 0; i < p.schedule.size(); ++i)
-                if (p.step_late[i] == ph && lane_of[i] < 0) P.order[at[step_level[i]]++] = (u32)i;
+                if (mine(i)) P.order[at[step_level[i]]++] = (u32)i;
+        }
+        if (only_stage) {   // a stage only walks the levels it has generators on
+            std::vector<u32> off{0};
+            for (u32 l = 0; l + 1 < P.level_off.size(); ++l)
+                if (P.level_off[l + 1] != P.level_off[l]) off.push_back(P.level_off[l + 1]);
+            P.level_off.swap(off);
         }
         // Estimated cost per generator (measured, VPBS_TRACE_WITNESS with one thread, EPYC 9575F): a PoseidonGate row is a whole
         // permutation (1.4 us), most others a handful of field operations (30 ns).  The threads of a wide level take equal COST, not
@@ -693,7 +723,7 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             }
             P.cost[k + 1] = P.cost[k] + cost;
         }
-        p.pool[ph].reset();
+        if (q < 2) p.pool[ph].reset();
     }
     p.late_out.clear();
     for (size_t i = 0; i < p.out_slot.size(); ++i)
@@ -714,6 +744,12 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             if (p.step_late[i])
                 for (u32 k = step_io_off[i]; k < step_io_off[i + 1]; ++k) touch(step_io[k]);
         std::sort(p.late_in_slots.begin(), p.late_in_slots.end());
+    }
+    p.late_slot_runs.clear();
+    for (size_t sl = 0; sl < p.n_slots; ++sl) {
+        if (!taint[sl]) continue;
+        if (!p.late_slot_runs.empty() && p.late_slot_runs.back().first + p.late_slot_runs.back().second == sl) ++p.late_slot_runs.back().second;
+        else p.late_slot_runs.push_back({(u32)sl, 1u});
     }
     // the early phase alone as a device schedule (vpbs_witness_device_create_early)
     build_device_schedule(p, p.dev_early, p.step_out, p.step_out_w, p.step_out_off, p.step_late.data(), p.preset_late.data());
@@ -737,6 +773,16 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             }
         std::fprintf(stderr, "[witness split] %zu late wire positions on %zu rows in [%zu, %zu], %zu runs of consecutive rows\n", p.late_out.size(), rows,
                      lo, hi, runs);
+        for (size_t k = 0; k < p.late_stage.size(); ++k) {
+            const vpbs_witness_plan::Phase& P = p.late_stage[k];
+            size_t pos_rows = 0, wide = 0;
+            for (u32 i : P.order)
+                if (p.schedule[i].row != NO_ROW && p.gates[p.row_gate[p.schedule[i].row]].kind == VPBS_GATE_POSEIDON) ++pos_rows;
+            for (size_t l = 0; l + 1 < P.level_off.size(); ++l)
+                if (P.cost[P.level_off[l + 1]] - P.cost[P.level_off[l]] >= 600) ++wide;
+            std::fprintf(stderr, "[witness split] late stage %zu: %zu generators (%zu PoseidonGate rows) on %zu levels, %zu of them wide\n", k + 1,
+                         P.order.size(), pos_rows, P.level_off.size() - 1, wide);
+        }
     }
     p.is_split = true;
     return VPBS_OK;
@@ -744,8 +790,33 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
 }  // namespace
 }  // namespace vpbs
 
+namespace vpbs {
+namespace {
+// touches the pages of a fresh state under the slots only the late phase writes (nothing reads a value whose flag is clear, so the zero
+// written here is never seen); values the state already holds are left alone
+void prefault_late_slots(const vpbs_witness_plan& p, SlotState& s) {
+    constexpr uintptr_t PAGE = 4096;
+    uintptr_t last = 0;
+    for (const auto& run : p.late_slot_runs) {
+        for (u32 k = 0; k < run.second;) {
+            const u32 slot = run.first + k;
+            const uintptr_t page = reinterpret_cast<uintptr_t>(&s.val[slot]) / PAGE;
+            if (page != last && !s.is_set[slot]) {
+                s.val[slot] = 0;
+                last = page;
+            }
+            const uintptr_t next_page_addr = (page + 1) * PAGE;
+            const u32 skip = (u32)((next_page_addr - reinterpret_cast<uintptr_t>(&s.val[slot]) + sizeof(u64) - 1) / sizeof(u64));
+            k += std::max(1u, skip);
+        }
+    }
+}
+}  // namespace
+}  // namespace vpbs
+
 struct vpbs_witness_state {
     vpbs::SlotState s;
+    unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
 };
 
 namespace vpbs {
@@ -849,10 +920,11 @@ struct KindProfile {
 // few field operations) stay on the calling thread.  Generators of one level touch disjoint slots (plan_split), so the slot state needs no
 // locking; a "set twice with different values" report goes through SlotState's mutex.  `after` (may be empty) is one more shared job at
 // the end -- the wires of the phase written into the matrix.
-int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned threads, const std::function<void(unsigned, unsigned)>& after,
-               std::string& err) {
+// stage: 0 = the whole phase; k > 0 (late phase of a plan split into stages) = the generators of late stage k only.
+int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s, unsigned threads,
+               const std::function<void(unsigned, unsigned)>& after, std::string& err) {
     constexpr u32 PAR_MIN_COST = 600;   // ~6 us of work: four PoseidonGate rows
-    const vpbs_witness_plan::Phase& P = p.phase[ph];
+    const vpbs_witness_plan::Phase& P = stage ? p.late_stage[stage - 1] : p.phase[ph];
     const unsigned mc = std::max(1u, p.max_consts);
     const u32 n_levels = (u32)P.level_off.size() - 1;
     static const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
@@ -871,7 +943,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, SlotState& s, unsigned thread
     if (!pool) {   // alone: the plan's own schedule order (generators of a row's neighbourhood together: far fewer cache misses than level order)
         KindProfile prof;
         for (size_t i = 0; i < p.schedule.size(); ++i) {
-            if (p.step_late[i] != ph) continue;
+            if (p.step_late[i] != ph || (stage && p.step_stage[i] != stage)) continue;
             prof.start();
             const bool ok = run_one(p, s, i, mc, err);
             prof.stop(p, i);
@@ -1109,13 +1181,15 @@ static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_
         const size_t a = std::lower_bound(p.out_pos.begin(), p.out_pos.end(), (u32)lo) - p.out_pos.begin();
         for (size_t i = a; i < p.out_pos.size() && p.out_pos[i] < hi; ++i) wires_out[p.out_pos[i]] = s.is_set[p.out_slot[i]] ? s.val[p.out_slot[i]] : 0;
     };
-    const int rc = msg.empty() ? run_levels(p, 0, s, threads, fill, msg) : VPBS_ERR_INVALID;
+    const int rc = msg.empty() ? run_levels(p, 0, 0, s, threads, fill, msg) : VPBS_ERR_INVALID;
     if (rc != VPBS_OK) {
         report(err, err_len, msg);
         delete st;
         return rc;
     }
     lap("generators + wires");
+    prefault_late_slots(p, s);
+    lap("late pages");
     *state_out = st;
     return VPBS_OK;
 }
@@ -1146,10 +1220,6 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
         if (trace) std::fprintf(stderr, "[witness late] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    for (size_t i = 0; i < p.preset_slot.size(); ++i)
-        if (p.preset_late[i]) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
-    lap("presets");
-    std::string msg = s.error;
     static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
     const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
     auto scatter = [&](unsigned t, unsigned of) {
@@ -1159,8 +1229,23 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
             wires_out[packed ? k : p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
         }
     };
-    const int rc = msg.empty() ? run_levels(p, 1, s, late_threads, scatter, msg) : VPBS_ERR_INVALID;
-    lap("generators + late wires");
+    // the stages that have not run yet (all of them unless vpbs_witness_plan_run_late_stage ran some ahead), in order; the wires after the last
+    std::string msg;
+    int rc = VPBS_OK;
+    for (unsigned stage = state->stages_done + 1; stage <= p.n_stages && rc == VPBS_OK; ++stage) {
+        for (size_t i = 0; i < p.preset_slot.size(); ++i)
+            if (p.preset_late[i] == stage) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+        lap("presets");
+        msg = s.error;
+        const bool last = stage == p.n_stages;
+        rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, last ? scatter : std::function<void(unsigned, unsigned)>(), msg)
+                         : VPBS_ERR_INVALID;
+        lap(last ? "generators + late wires" : "generators");
+    }
+    if (rc == VPBS_OK && state->stages_done >= p.n_stages) {   // every stage ran ahead: only the wires are left
+        scatter(0, 1);
+        lap("late wires");
+    }
     if (trace) {
         for (int ph = 0; ph < 2; ++ph) {
             const vpbs_witness_plan::Phase& P = p.phase[ph];
@@ -1199,6 +1284,29 @@ int vpbs_witness_plan_run_late_packed(const vpbs_witness_plan* plan, vpbs_witnes
                                       uint64_t* values_out, char* err, size_t err_len) {
     return run_late_impl(plan, state, preset_val, values_out, true, err, err_len);
 }
+unsigned vpbs_witness_plan_late_stages(const vpbs_witness_plan* plan) { return plan && plan->is_split ? plan->n_stages : 0; }
+
+int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness_state* state, unsigned stage, const uint64_t* preset_val,
+                                     char* err, size_t err_len) {
+    using namespace vpbs;
+    if (!plan || !plan->is_split || !state || !preset_val || stage == 0 || stage > plan->n_stages || stage != state->stages_done + 1) {
+        report(err, err_len, "malformed arguments (stages run once each, in ascending order)");
+        return VPBS_ERR_INVALID;
+    }
+    const vpbs_witness_plan& p = *plan;
+    SlotState& s = state->s;
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (p.preset_late[i] == stage) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
+    std::string msg = s.error;
+    static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
+    const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
+    const int rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, std::function<void(unsigned, unsigned)>(), msg)
+                               : VPBS_ERR_INVALID;
+    state->stages_done = stage;   // also after a failure: the state is only good for vpbs_witness_state_free / run_late (which reports again)
+    report(err, err_len, msg);
+    return rc;
+}
+
 size_t vpbs_witness_plan_late_count(const vpbs_witness_plan* plan) { return plan && plan->is_split ? plan->late_out.size() : 0; }
 int vpbs_witness_plan_late_positions(const vpbs_witness_plan* plan, uint32_t* out) {
     if (!plan || !plan->is_split || !out) return VPBS_ERR_INVALID;
@@ -1228,6 +1336,7 @@ int vpbs_witness_state_from_late_inputs(const vpbs_witness_plan* plan, const uin
         st->s.val[p.late_in_slots[k]] = values[k];
         st->s.is_set[p.late_in_slots[k]] = 1;
     }
+    prefault_late_slots(p, st->s);
     *state_out = st;
     return VPBS_OK;
 }

@@ -543,6 +543,8 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
     }
 }
 
+int vpbs_witness_device_has_late(const vpbs_witness_device* d) { return d && d->has_late ? 1 : 0; }
+
 int vpbs_witness_device_run_late(vpbs_witness_device* d, unsigned instance, const uint64_t* preset_val) {
     if (!d || !d->has_late || !preset_val) return VPBS_ERR_INVALID;
     vpbs_ctx* ctx = d->ctx;

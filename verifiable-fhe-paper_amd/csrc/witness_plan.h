@@ -219,6 +219,13 @@ struct vpbs_witness_plan {
         std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
     };
     Phase phase[2];                             // [0] early, [1] late
+    // The late presets may arrive in STAGES (vpbs_witness_plan_split: late[i] = 1, 2, ...: the sections of a proof become final at
+    // different moments of the prover's run -- caps and openings before the FRI stage, the query rounds at its very end): a late
+    // generator belongs to the highest stage among what it reads, and late_stage[k - 1] holds the generators of stage k by dependency
+    // level, so that stage k can run as soon as its presets exist, while the values of the stages above are still being computed.
+    unsigned n_stages = 1;
+    std::vector<uint8_t> step_stage;            // per scheduled step: 0 early, otherwise its late stage
+    std::vector<Phase> late_stage;              // [n_stages] (only filled when n_stages > 1; one stage = phase[1])
     // Chain lanes: PoseidonGate rows whose results nothing but other such rows reads inside the phase (the hash chains over the GGSW and
     // over the public inputs: thousands of permutations, each needing the one before).  They are taken out of the levels and run on
     // threads of their own next to them, in schedule order, waiting on the set flag of a value another lane or a level still has to produce.
@@ -277,6 +284,9 @@ struct vpbs_witness_plan {
     // classes count as set: a late step that writes one compares), early presets routed to the scratch slot
     DeviceSchedule dev_late;
     std::vector<u32> late_in_slots;
+    // runs [first, first + count) of consecutive value slots that only the late phase writes: a fresh state's pages under them are touched
+    // by whoever creates the state (the early thread, the stager) instead of faulting in one by one on the critical path of the late phase
+    std::vector<std::pair<u32, u32>> late_slot_runs;
     // what every scheduled step writes (slots; wire index for row steps, NONE for gadget outputs): kept for building dev_early
     std::vector<u32> step_out, step_out_w, step_out_off;
 };
