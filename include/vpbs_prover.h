@@ -356,11 +356,14 @@ void vpbs_witness_state_free(vpbs_witness_state* state);   /* only for a state t
 /* Stages of the late phase (1 unless vpbs_witness_plan_split was given stage numbers; 0 before the split).  run_late_stage runs ONE stage
  * ahead of run_late: the presets of that stage are read from preset_val (entries of other stages are not touched), its generators run on
  * the late pool; stages run once each, in ascending order; the state is NOT consumed.  vpbs_witness_plan_run_late[_packed] then runs
- * whatever stages are left and writes the late wires -- the result is the same matrix whichever stages ran ahead.  A failing stage (a
+ * whatever stages are left and writes the late wires -- the result is the same matrix whichever stages ran ahead.  The late wire positions
+ * (vpbs_witness_plan_late_positions) are ordered by stage, so with packed_out a stage leaves its share of the packed values in place at once
+ * and run_late_packed (same buffer) only adds the shares of the stages it runs itself.  A failing stage (a
  * value of the proof section that contradicts the circuit) returns VPBS_ERR_INVALID with the message; the state then only goes to
  * vpbs_witness_state_free or run_late (which fails the same way). */
 unsigned vpbs_witness_plan_late_stages(const vpbs_witness_plan* plan);
 int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness_state* state, unsigned stage, const uint64_t* preset_val,
+                                     uint64_t* packed_out /* NULL, or the [late_count] buffer the later run_late_packed gets */,
                                      char* err, size_t err_len);
 /* The late phase without the matrix: the values of the late wire positions, packed in the order of vpbs_witness_plan_late_positions
  * (count = vpbs_witness_plan_late_count; positions column * n + row, fixed once the plan is split).  For a host whose early matrix is
@@ -434,9 +437,10 @@ int vpbs_check_witness(const vpbs_circuit* circuit, const uint64_t* wires /* [n_
 /* Progress of a step proof, for a host that starts consuming the proof before it is complete (the IVC chain: the next step's in-circuit
  * verifier, ivc_based_vpbs.rs:323-353): fn(user, section) runs on the proving thread, between two launches, when a SECTION of the proof is
  * final in the caller's output buffers --
- *   1: caps_out (all three caps) and openings_out                                   (the FRI stage starts now)
- *   2: fri_out's commit-phase caps [n_rounds][cap], final polynomial and proof-of-work witness, at their final offsets
- *      (the query rounds in between are still missing: they arrive with the return of the call)
+ *   1              : caps_out (all three caps) and openings_out                      (the FRI stage starts now)
+ *   2 .. 1 + R     : fri_out's commit-phase cap of reduction round section - 2           (R = n_rounds of the FRI parameters)
+ *   2 + R          : final polynomial and proof-of-work witness, at their final offsets at the end of fri_out
+ *                    (the query rounds in between are still missing: they arrive with the return of the call)
  * It must return quickly (hand the work to another thread): the device idles while it runs. */
 typedef void (*vpbs_step_section_fn)(void* user, int section);
 typedef struct {

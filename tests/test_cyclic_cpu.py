@@ -117,27 +117,30 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
     # final polynomial, proof-of-work witness | query rounds): stages run ahead one by one give the wires of the one-stage plan
     staged = cy.built.circuit.witness_plan(cy.positions)
     sh = cy.shape
+    R = len(sh.arity_bits)                      # the sections vpbs_prove_step reports (vpbs_step_inputs.on_section): R + 3 stages
     stage_of = np.zeros(len(cy.positions), np.uint8)
-    stage_of[:sh.proof_words] = 3
+    stage_of[:sh.proof_words] = R + 3
     stage_of[:sh.caps_words + sh.openings_words] = 1
     fri0 = sh.caps_words + sh.openings_words
-    stage_of[fri0:fri0 + len(sh.arity_bits) * 4 * sh.cap_len] = 2
-    stage_of[fri0 + sh.fri_words - 1 - 2 * sh.final_len:fri0 + sh.fri_words] = 2
+    for r in range(R):
+        stage_of[fri0 + r * 4 * sh.cap_len:fri0 + (r + 1) * 4 * sh.cap_len] = 2 + r
+    stage_of[fri0 + sh.fri_words - 1 - 2 * sh.final_len:fri0 + sh.fri_words] = 2 + R
     staged.split(stage_of)
-    assert staged.late_stages() == 3 and split.late_stages() == 1
-    assert (staged.late_positions() == split.late_positions()).all() and (staged.late_input_positions() == split.late_input_positions()).all()
+    assert staged.late_stages() == R + 3 and split.late_stages() == 1
+    assert sorted(staged.late_positions()) == sorted(split.late_positions())       # the same wires, ordered by stage in the staged plan
+    assert (staged.late_input_positions() == split.late_input_positions()).all()
     for cond, ggsw, mask in steps:
         values = cy.values(cy.shape.flat_proof(proof), pis, cond, ggsw, mask, C.vk, D.vk, dummy_flat)
         wires = plan.run(values)
-        for ahead in (0, 1, 2, 3):   # how many stages run before run_late
+        for ahead in (0, 1, 2, R + 2, R + 3):   # how many stages run before run_late; packed in place on the way (odd counts) or at the end
             three = np.empty_like(wires)
             st3 = staged.run_early(values, three)
-            partial = values.copy()
+            packed = np.full(staged.late_positions().size, 0xDEAD, np.uint64) if ahead % 2 else None
             for k in range(1, ahead + 1):
-                partial[:sh.proof_words][stage_of[:sh.proof_words] > k] = 0xBAD   # words of later stages do not exist yet
-                staged.run_late_stage(st3, k, partial)
                 partial = values.copy()
-            assert (staged.run_late_packed(st3, values) == wires.reshape(-1)[staged.late_positions()]).all(), ahead
+                partial[:sh.proof_words][stage_of[:sh.proof_words] > k] = 0xBAD   # words of later stages do not exist yet
+                staged.run_late_stage(st3, k, partial, packed)
+            assert (staged.run_late_packed(st3, values, packed) == wires.reshape(-1)[staged.late_positions()]).all(), ahead
         if cond:   # a wrong word of the FIRST section is noticed by the first stage already (the transcript and the cap connections are there)
             bad = values.copy()
             bad[5] ^= np.uint64(1)       # a word of the wires cap

@@ -227,7 +227,7 @@ SIGNATURES = {
     "vpbs_witness_plan_run_late_packed": (_i, [C.c_void_p, C.c_void_p, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_late_count": (_sz, [C.c_void_p]),
     "vpbs_witness_plan_late_stages": (_ui, [C.c_void_p]),
-    "vpbs_witness_plan_run_late_stage": (_i, [C.c_void_p, C.c_void_p, _ui, U64P, C.c_char_p, _sz]),
+    "vpbs_witness_plan_run_late_stage": (_i, [C.c_void_p, C.c_void_p, _ui, U64P, U64P, C.c_char_p, _sz]),
     "vpbs_witness_plan_late_input_count": (_sz, [C.c_void_p]),
     "vpbs_witness_plan_late_input_positions": (_i, [C.c_void_p, U32P]),
     "vpbs_witness_state_from_late_inputs": (_i, [C.c_void_p, U64P, C.POINTER(C.c_void_p)]),
@@ -576,19 +576,21 @@ class WitnessPlan:
         """vpbs_witness_plan_late_stages: stages of the late phase (split() with stage numbers 1, 2, ..)"""
         return int(lib().vpbs_witness_plan_late_stages(self.h))
 
-    def run_late_stage(self, state, stage, values):
-        """one late stage ahead of run_late (stages once each, ascending); the state is kept"""
+    def run_late_stage(self, state, stage, values, packed_out=None):
+        """one late stage ahead of run_late (stages once each, ascending); the state is kept.  packed_out: the uint64 [late_count] array a
+        later run_late_packed(.., out=packed_out) completes -- the stage writes its share of the packed wires at once"""
         val = _u64(values)
         assert val.size == self.n_preset
         err = C.create_string_buffer(512)
-        if lib().vpbs_witness_plan_run_late_stage(self.h, state, stage, _ptr(val), err, 512):
+        if lib().vpbs_witness_plan_run_late_stage(self.h, state, stage, _ptr(val), _ptr(packed_out) if packed_out is not None else None, err, 512):
             raise VpbsError("vpbs_witness_plan_run_late_stage: " + err.value.decode())
 
-    def run_late_packed(self, state, values):
+    def run_late_packed(self, state, values, out=None):
         """the late phase without the matrix -> the values of late_positions(), in that order; consumes the state"""
         val = _u64(values)
         assert val.size == self.n_preset
-        out = np.zeros(int(lib().vpbs_witness_plan_late_count(self.h)), np.uint64)
+        if out is None:
+            out = np.zeros(int(lib().vpbs_witness_plan_late_count(self.h)), np.uint64)
         err = C.create_string_buffer(512)
         if lib().vpbs_witness_plan_run_late_packed(self.h, state, _ptr(val), _ptr(out), err, 512):
             raise VpbsError("vpbs_witness_plan_run_late_packed: " + err.value.decode())

@@ -115,10 +115,11 @@ struct Side {   // one circuit on the context
 // The late witness phase of step s + 1 in STAGES, started before the proof of step s is complete (the reference's loop
 // ivc_based_vpbs.rs:323-353 hands a finished proof to the next step -- here the next step's in-circuit verifier starts on the sections of
 // the proof as the prover finishes them).  The proof words are late presets of three stages (vpbs_witness_plan_split with stage numbers):
-//   1  caps and openings            -> the in-circuit transcript up to the FRI challenges, the vanishing check at zeta, the reduced openings
-//   2  FRI commit caps, final polynomial, proof-of-work witness -> the rest of the transcript, the query indices
-//   3  the query rounds             -> Merkle paths, folds: what is left on the critical path when the proof returns
-// A worker thread runs stages 1 and 2 on the next step's state (vpbs_witness_plan_run_late_stage) while the previous proof's FRI stage is
+//   1            caps and openings        -> the in-circuit transcript up to the FRI challenges, the vanishing check at zeta, the reduced openings
+//   2 .. 1 + R   the commit cap of FRI round r    -> the transcript absorbs it, the round's folding challenge
+//   2 + R        final polynomial, proof-of-work witness -> the rest of the transcript, the query indices
+//   3 + R        the query rounds         -> Merkle paths, folds: what is left on the critical path when the proof returns
+// (R = 3 reduction rounds at degree 2^16.)  A worker thread runs all but the last on the next step's state (vpbs_witness_plan_run_late_stage) while the previous proof's FRI stage is
 // still on the device; vpbs_step_inputs.on_section posts them.  The caller then drains the worker and runs vpbs_witness_plan_run_late_packed,
 // which only has stage 3 left.
 struct LateAhead {
@@ -130,6 +131,7 @@ struct LateAhead {
     vpbs_witness_state* st = nullptr;   // the job: state and PartialWitness values of the NEXT step, the proof being written
     u64* values = nullptr;
     const u64* proof = nullptr;
+    u64* packed = nullptr;              // the pinned buffer of the packed late wires: a stage leaves its share there at once
     unsigned posted = 0, done = 0;
     bool quit = false, failed = false;
     std::string err;
@@ -138,12 +140,12 @@ struct LateAhead {
     // stage of every proof word -> late mask for vpbs_witness_plan_split (the other presets: 0) and the ranges a stage copies
     void layout(size_t cap_words, size_t openings_words, size_t fri_words, unsigned n_rounds, size_t final_words, std::vector<uint8_t>& late) {
         const size_t head = 3 * cap_words + openings_words, fri_caps = (size_t)n_rounds * cap_words, tail = final_words + 1;
-        ranges.assign(3, {});
-        ranges[0].push_back({0, head});
-        ranges[1].push_back({head, head + fri_caps});
-        ranges[1].push_back({head + fri_words - tail, head + fri_words});
-        ranges[2].push_back({head + fri_caps, head + fri_words - tail});
-        for (size_t k = 0; k < 3; ++k)
+        ranges.assign(n_rounds + 3, {});
+        ranges[0].push_back({0, head});                                                                  // section 1
+        for (unsigned r = 0; r < n_rounds; ++r) ranges[1 + r].push_back({head + r * cap_words, head + (r + 1) * cap_words});   // sections 2 .. 1 + n_rounds
+        ranges[n_rounds + 1].push_back({head + fri_words - tail, head + fri_words});                     // section 2 + n_rounds
+        ranges[n_rounds + 2].push_back({head + fri_caps, head + fri_words - tail});                      // the return of the call
+        for (size_t k = 0; k < ranges.size(); ++k)
             for (auto& r : ranges[k]) std::fill(late.begin() + r.first, late.begin() + r.second, (uint8_t)(k + 1));
     }
     void start(const vpbs_witness_plan* p) {
@@ -161,7 +163,7 @@ struct LateAhead {
     void post(unsigned stage) {   // proving thread (on_section): the words of stages <= stage are final
         {
             std::lock_guard<std::mutex> lk(m);
-            posted = std::max(posted, std::min<unsigned>(stage, 2));
+            posted = std::max(posted, std::min<unsigned>(stage, (unsigned)ranges.size() - 1));   // the last stage waits for the return
         }
         cv.notify_all();
     }
@@ -200,7 +202,7 @@ struct LateAhead {
                 if (values != proof)
                     for (auto& r : ranges[stage - 1]) std::memcpy(values + r.first, proof + r.first, 8 * (r.second - r.first));
                 e[0] = 0;
-                ok = vpbs_witness_plan_run_late_stage(plan, st, stage, values, e, sizeof e) == 0;
+                ok = vpbs_witness_plan_run_late_stage(plan, st, stage, values, packed, e, sizeof e) == 0;
             }
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -223,7 +225,7 @@ struct vpbs_ivc {
     unsigned N = 0, K = 0;
     size_t proof_words = 0, ggsw_len = 0, kn = 0, n_pi = 0, wire_words = 0;
     std::vector<u64> dummy_proof;   // the second proof slot: the dummy circuit's proof of all-zero public inputs (vpbs_ivc_create)
-    bool staged = false;            // the cyclic plan is split into three late stages (LateAhead)
+    bool staged = false;            // the cyclic plan is split into late stages by proof section (LateAhead)
     LateAhead ahead_layout;         // ranges only (the worker belongs to a prove_pbs call)
     size_t late_rows[2] = {0, 0};
     size_t late_count = 0;                       // wire positions the late witness phase writes (vpbs_witness_plan_late_count)
@@ -631,6 +633,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     LateAhead ahead;
     if (v->staged && !v->dw_late) {
         ahead.ranges = v->ahead_layout.ranges;
+        ahead.packed = v->late_vals;
         ahead.start(cyc.plan);
     }
     struct Hook {
@@ -915,6 +918,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
     LateAhead ahead;
     if (v->staged) {
         ahead.ranges = v->ahead_layout.ranges;
+        ahead.packed = v->late_vals;
         ahead.start(cyc.plan);
     }
     struct Hook {

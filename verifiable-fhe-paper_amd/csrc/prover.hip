@@ -212,6 +212,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         ctx->d2h_sync(w, t.digests + t.level_off.back(), sizeof(u64) * cap_words);
         challenger.observe_cap(w, cap_words / 4);
         w += cap_words;
+        if (on_section) on_section(on_section_user, 2 + (int)r);   // this round's cap is final in proof_out
         const Ext beta = challenger.get_extension_challenge();
         const size_t new_len = len >> ab;
         u64* folded = words(2 * new_len);
@@ -242,7 +243,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         u64* tail = proof_out + fri_proof_words(fp, ncols) - 1 - final_words.size();
         std::memcpy(tail, final_words.data(), sizeof(u64) * final_words.size());
         tail[final_words.size()] = pow_witness;
-        if (on_section) on_section(on_section_user, 2);
+        if (on_section) on_section(on_section_user, 2 + (int)n_rounds);
     }
 
     // ---- fri_prover_query_rounds ----

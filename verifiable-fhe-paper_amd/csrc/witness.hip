@@ -494,6 +494,8 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
 // writes -- unless the early phase knows that value anyway (an early preset, or an early step writes it too: the late step is then the
 // second writer of the slot and only compares; e.g. the limbs a late range check connects to the constant zero must not make every
 // reader of zero late).  Reads / writes of a gate generator are found the way plan creation finds them (gen_run on flags).
+unsigned default_phase_threads();   // further down: the pool size a phase gets by default (CPU budget of the process)
+
 int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     if (!pp || !late) {
         err = "malformed arguments";
@@ -724,10 +726,92 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             P.cost[k + 1] = P.cost[k] + cost;
         }
         if (q < 2) p.pool[ph].reset();
+        // ---- strands of a late stage (vpbs_witness_plan::Phase) ----
+        P.strand_threads = 0;
+        P.strand_steps.clear(); P.strand_level.clear(); P.strand_off.clear();
+        static const bool no_strands = std::getenv("VPBS_LATE_STRANDS") && std::atoi(std::getenv("VPBS_LATE_STRANDS")) == 0;
+        if (only_stage && !no_strands && P.order.size() >= 512) {
+            static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
+            const unsigned T = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
+            // components: two generators of the stage belong together when one reads what the other writes during the stage, or both write
+            // the same class during the stage (the second compares).  A value that exists before the stage starts -- early, a preset of a
+            // stage <= this one, the result of an earlier stage -- ties nothing together.
+            std::vector<uint8_t> preset_before(p.n_slots, 0);
+            for (size_t i = 0; i < p.preset_slot.size(); ++i)
+                if (late[i] && late[i] <= only_stage) preset_before[p.preset_slot[i]] = 1;
+            auto known_before = [&](u32 slot) { return known_early[slot] || preset_before[slot] || (taint[slot] && taint[slot] < only_stage); };
+            std::vector<u32> parent(P.order.size()), stage_writer(p.n_slots, NONE);
+            for (u32 k = 0; k < parent.size(); ++k) parent[k] = k;
+            auto find = [&](u32 x) {
+                while (parent[x] != x) x = parent[x] = parent[parent[x]];
+                return x;
+            };
+            auto unite = [&](u32 a, u32 b) {
+                a = find(a); b = find(b);
+                if (a != b) parent[std::max(a, b)] = std::min(a, b);
+            };
+            // in SCHEDULE order (a reader comes after a writer of each of its inputs); P.order is sorted by level, so map back
+            std::vector<std::pair<u32, u32>> by_schedule(P.order.size());   // (schedule index, position in P.order)
+            for (u32 k = 0; k < P.order.size(); ++k) by_schedule[k] = {P.order[k], k};
+            std::sort(by_schedule.begin(), by_schedule.end());
+            for (const auto& e : by_schedule) {
+                const size_t i = e.first;
+                for (u32 x = step_io_off[i]; x < step_io_off[i] + step_n_in[i]; ++x)
+                    if (stage_writer[step_io[x]] != NONE) unite(e.second, stage_writer[step_io[x]]);
+                for (u32 x = step_io_off[i] + step_n_in[i]; x < step_io_off[i + 1]; ++x) {
+                    const u32 slot = step_io[x];
+                    if (known_before(slot)) continue;
+                    if (stage_writer[slot] == NONE) stage_writer[slot] = e.second;
+                    else unite(e.second, stage_writer[slot]);
+                }
+            }
+            std::vector<u64> comp_cost(P.order.size(), 0);
+            for (u32 k = 0; k < P.order.size(); ++k) comp_cost[find(k)] += P.cost[k + 1] - P.cost[k];
+            std::vector<std::pair<u64, u32>> comps;
+            for (u32 k = 0; k < P.order.size(); ++k)
+                if (comp_cost[k]) comps.push_back({comp_cost[k], k});
+            std::sort(comps.begin(), comps.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+            std::vector<u64> load(T, 0);
+            std::vector<u32> bin_of(P.order.size(), 0);
+            for (const auto& c : comps) {   // heaviest first, each to the lightest bin
+                const u32 b = (u32)(std::min_element(load.begin(), load.end()) - load.begin());
+                load[b] += c.first;
+                bin_of[c.second] = b;
+            }
+            const u64 total = P.cost[P.order.size()], heaviest = *std::max_element(load.begin(), load.end());
+            if (T >= 2 && heaviest * T <= total + total / 2) {   // balanced within 1.5 x: worth it (one giant component is not)
+                std::vector<u32> cnt(T + 1, 0);
+                for (u32 k = 0; k < P.order.size(); ++k) ++cnt[bin_of[find(k)] + 1];
+                for (u32 b = 0; b < T; ++b) cnt[b + 1] += cnt[b];
+                P.strand_off = cnt;
+                P.strand_steps.assign(P.order.size(), 0);
+                P.strand_level.assign(P.order.size(), 0);
+                std::vector<u32> at(cnt.begin(), cnt.end() - 1);
+                for (u32 k = 0; k < P.order.size(); ++k) {   // P.order is sorted by level: so is every strand
+                    const u32 b = bin_of[find(k)];
+                    P.strand_steps[at[b]] = P.order[k];
+                    P.strand_level[at[b]++] = step_level[P.order[k]];
+                }
+                P.strand_threads = T;
+            }
+            if (std::getenv("VPBS_TRACE_WITNESS"))
+                std::fprintf(stderr, "[witness split] late stage %u: %zu components, heaviest %.1f %% of the stage, %u bins, heaviest bin %.2f x the mean -> %s\n",
+                             (unsigned)only_stage, comps.size(), comps.empty() ? 0.0 : 100.0 * comps[0].first / std::max<u64>(1, total), T,
+                             total ? (double)heaviest * T / total : 0.0, P.strand_threads ? "strands" : "levels");
+        }
     }
+    // the late wire positions, ordered by the stage their value exists from and then by value slot: a stage's share is one contiguous range
+    // of the packed output (written as soon as the stage has run), and packing reads the slot array front to back
     p.late_out.clear();
     for (size_t i = 0; i < p.out_slot.size(); ++i)
         if (taint[p.out_slot[i]]) p.late_out.push_back((u32)i);
+    std::stable_sort(p.late_out.begin(), p.late_out.end(), [&](u32 a, u32 b) {
+        const u32 sa = p.out_slot[a], sb = p.out_slot[b];
+        return taint[sa] != taint[sb] ? taint[sa] < taint[sb] : sa < sb;
+    });
+    p.late_out_stage_off.assign(n_stages + 1, 0);
+    for (u32 i : p.late_out) ++p.late_out_stage_off[taint[p.out_slot[i]]];
+    for (unsigned k = 1; k <= n_stages; ++k) p.late_out_stage_off[k] += p.late_out_stage_off[k - 1];
     // the early-known values the late phase touches: what its steps read, what they write as comparers, what late presets are compared with
     {
         std::vector<uint8_t> seen(p.n_slots, 0);
@@ -817,6 +901,7 @@ void prefault_late_slots(const vpbs_witness_plan& p, SlotState& s) {
 struct vpbs_witness_state {
     vpbs::SlotState s;
     unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
+    unsigned stages_packed = 0; // ... and how many of them have their wires in the caller's packed buffer already
 };
 
 namespace vpbs {
@@ -963,6 +1048,62 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
 #endif
     std::atomic<bool> failed{false};
     std::vector<std::string> errs(threads);
+    if (stage && P.strand_threads == threads) {
+        // STRANDS: every thread runs its bin of independent components from the first level to the last, no barrier in between
+        const double t_begin = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
+        pool->begin();
+        pool->share([&](unsigned t) {
+            const u32 lo = P.strand_off[t], hi = P.strand_off[t + 1];
+#if defined(VPBS_HAVE_POSEIDON_X8)
+            u32 pending[8];
+            unsigned np = 0;
+            auto flush = [&] {
+                if (np >= 3) {
+                    if (!poseidon_rows_x8(p, s, pending, np, errs[t])) failed.store(true);
+                } else {
+                    for (unsigned q = 0; q < np; ++q)
+                        if (!run_one(p, s, pending[q], mc, errs[t])) failed.store(true);
+                }
+                np = 0;
+            };
+#endif
+            for (u32 k = lo; k < hi && !failed.load(std::memory_order_relaxed); ++k) {
+                const u32 i = P.strand_steps[k];
+#if defined(VPBS_HAVE_POSEIDON_X8)
+                // the PoseidonGate rows of one level are independent: eight at a time; everything else of the level right away (a later
+                // level may read either, so the batch is flushed when the level changes)
+                if (k > lo && P.strand_level[k] != P.strand_level[k - 1]) flush();
+                const auto& st = p.schedule[i];
+                if (x8 && st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) {
+                    pending[np++] = i;
+                    if (np == 8) flush();
+                    continue;
+                }
+#endif
+                if (!run_one(p, s, i, mc, errs[t])) failed.store(true);
+            }
+#if defined(VPBS_HAVE_POSEIDON_X8)
+            if (!failed.load(std::memory_order_relaxed)) flush();
+#endif
+        });
+        int rc = failed.load() || s.failed() ? VPBS_ERR_INVALID : VPBS_OK;
+        const double t_mid = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
+        if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
+        pool->end();
+        if (trace)
+            std::fprintf(stderr, "[witness %s] stage %u, %u threads: %zu generators in strands %.2f ms, wires %.2f ms\n", name, stage, threads,
+                         P.order.size(), t_mid - t_begin,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_mid);
+        if (rc != VPBS_OK) {
+            for (const auto& e : errs)
+                if (err.empty() && !e.empty()) err = e;
+            if (err.empty()) {
+                const std::string set_twice = s.error_text();
+                err = set_twice.empty() ? "a generator failed" : set_twice;
+            }
+        }
+        return rc;
+    }
     // the chain lanes start now, on threads of their own, and run next to the levels
     const std::vector<vpbs_witness_plan::Lane>& lanes = p.lanes[ph];
     LevelPool* lane_pool = nullptr;
@@ -1222,14 +1363,21 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
     };
     static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
     const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
-    auto scatter = [&](unsigned t, unsigned of) {
-        const size_t cnt = p.late_out.size();
-        for (size_t k = cnt * t / of, hi = cnt * (t + 1) / of; k < hi; ++k) {
+    // the wires of late_out[lo, hi) (a stage's share is one such range), thread t of `of`
+    auto emit = [&](size_t lo, size_t hi, unsigned t, unsigned of) {
+        const size_t cnt = hi - lo;
+        for (size_t k = lo + cnt * t / of, end = lo + cnt * (t + 1) / of; k < end; ++k) {
             const u32 slot = p.out_slot[p.late_out[k]];
             wires_out[packed ? k : p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
         }
     };
-    // the stages that have not run yet (all of them unless vpbs_witness_plan_run_late_stage ran some ahead), in order; the wires after the last
+    // stages that ran ahead without leaving their wires in the packed buffer (a host that wants them there passes it to run_late_stage)
+    const unsigned have = packed ? state->stages_packed : 0;
+    if (have < state->stages_done) {
+        emit(p.late_out_stage_off[have], p.late_out_stage_off[state->stages_done], 0, 1);
+        lap("wires of earlier stages");
+    }
+    // the stages that have not run yet (all of them unless vpbs_witness_plan_run_late_stage ran some ahead), in order, each followed by its wires
     std::string msg;
     int rc = VPBS_OK;
     for (unsigned stage = state->stages_done + 1; stage <= p.n_stages && rc == VPBS_OK; ++stage) {
@@ -1237,14 +1385,10 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
             if (p.preset_late[i] == stage) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
         lap("presets");
         msg = s.error;
-        const bool last = stage == p.n_stages;
-        rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, last ? scatter : std::function<void(unsigned, unsigned)>(), msg)
+        const size_t lo = p.late_out_stage_off[stage - 1], hi = p.late_out_stage_off[stage];
+        rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, [&](unsigned t, unsigned of) { emit(lo, hi, t, of); }, msg)
                          : VPBS_ERR_INVALID;
-        lap(last ? "generators + late wires" : "generators");
-    }
-    if (rc == VPBS_OK && state->stages_done >= p.n_stages) {   // every stage ran ahead: only the wires are left
-        scatter(0, 1);
-        lap("late wires");
+        lap("generators + late wires");
     }
     if (trace) {
         for (int ph = 0; ph < 2; ++ph) {
@@ -1287,7 +1431,7 @@ int vpbs_witness_plan_run_late_packed(const vpbs_witness_plan* plan, vpbs_witnes
 unsigned vpbs_witness_plan_late_stages(const vpbs_witness_plan* plan) { return plan && plan->is_split ? plan->n_stages : 0; }
 
 int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness_state* state, unsigned stage, const uint64_t* preset_val,
-                                     char* err, size_t err_len) {
+                                     uint64_t* packed_out, char* err, size_t err_len) {
     using namespace vpbs;
     if (!plan || !plan->is_split || !state || !preset_val || stage == 0 || stage > plan->n_stages || stage != state->stages_done + 1) {
         report(err, err_len, "malformed arguments (stages run once each, in ascending order)");
@@ -1300,8 +1444,21 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
     std::string msg = s.error;
     static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
     const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
-    const int rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, std::function<void(unsigned, unsigned)>(), msg)
-                               : VPBS_ERR_INVALID;
+    // with a packed buffer the stage leaves its share of the late wires there at once (the order of vpbs_witness_plan_late_positions is by stage)
+    std::function<void(unsigned, unsigned)> after;
+    const bool pack = packed_out && state->stages_packed + 1 == stage;
+    if (pack) {
+        const size_t lo = p.late_out_stage_off[stage - 1], hi = p.late_out_stage_off[stage];
+        after = [&p, &s, packed_out, lo, hi](unsigned t, unsigned of) {
+            const size_t cnt = hi - lo;
+            for (size_t k = lo + cnt * t / of, end = lo + cnt * (t + 1) / of; k < end; ++k) {
+                const u32 slot = p.out_slot[p.late_out[k]];
+                packed_out[k] = s.is_set[slot] ? s.val[slot] : 0;
+            }
+        };
+    }
+    const int rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg) : VPBS_ERR_INVALID;
+    if (pack && rc == VPBS_OK) state->stages_packed = stage;
     state->stages_done = stage;   // also after a failure: the state is only good for vpbs_witness_state_free / run_late (which reports again)
     report(err, err_len, msg);
     return rc;

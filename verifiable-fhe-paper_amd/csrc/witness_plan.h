@@ -208,7 +208,8 @@ struct vpbs_witness_plan {
     // anything it reads is, everything else can run before the late values exist
     bool is_split = false;
     std::vector<uint8_t> preset_late, step_late;
-    std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late
+    std::vector<u32> late_out;                  // indices into out_pos / out_slot whose slot is late, ordered by (stage the value exists from, slot)
+    std::vector<u32> late_out_stage_off;        // [n_stages + 1]: late_out entries of stage k = [off[k - 1], off[k])
     // the late generators by dependency level (a generator of level L reads only what levels < L wrote, and two generators of one level
     // never write the same slot: a second writer of a slot is placed above the first and compares): the wide levels -- the 28 FRI queries
     // of an in-circuit verifier are independent of each other -- are run by several host threads
@@ -217,6 +218,14 @@ struct vpbs_witness_plan {
     struct Phase {
         std::vector<u32> order, level_off;      // schedule indices sorted by level; level l = order[level_off[l], level_off[l + 1])
         std::vector<u32> cost;                  // [order.size() + 1] prefix sums of the generators' estimated cost (units of 10 ns)
+        // STRANDS (stages of a staged late phase): when the stage's generators fall into many independent components -- the 28 FRI queries
+        // of an in-circuit verifier share nothing once the transcript (an earlier stage) has produced their indices -- the components are
+        // packed into `strand_threads` bins of about equal cost and every thread of the pool runs ONE bin from its first level to its last
+        // with no barrier at all: what a generator reads was written by the same thread (or by an earlier stage).  strand t =
+        // strand_steps[strand_off[t], strand_off[t + 1]), sorted by level; strand_level: the level of every entry (rows of one level are
+        // independent: the PoseidonGate rows among them go eight at a time).  Empty: the stage is one big component, it runs level by level.
+        unsigned strand_threads = 0;
+        std::vector<u32> strand_steps, strand_level, strand_off;
     };
     Phase phase[2];                             // [0] early, [1] late
     // The late presets may arrive in STAGES (vpbs_witness_plan_split: late[i] = 1, 2, ...: the sections of a proof become final at
