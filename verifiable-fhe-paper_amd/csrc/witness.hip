@@ -529,6 +529,9 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
         }
     };
     p.n_stages = n_stages;
+    p.stage_presets.assign(n_stages, {});
+    for (size_t i = 0; i < p.preset_slot.size(); ++i)
+        if (late[i]) p.stage_presets[late[i] - 1].push_back((u32)i);
     p.step_late.assign(p.schedule.size(), 0);
     p.step_stage.assign(p.schedule.size(), 0);
     const unsigned mc = std::max(1u, p.max_consts);
@@ -902,6 +905,10 @@ struct vpbs_witness_state {
     vpbs::SlotState s;
     unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
     unsigned stages_packed = 0; // ... and how many of them have their wires in the caller's packed buffer already
+    vpbs::LevelPool* awake = nullptr;   // the late pool was left spinning for the next stage of this state: whoever runs it (or frees the state) ends it
+    ~vpbs_witness_state() {
+        if (awake) awake->end();
+    }
 };
 
 namespace vpbs {
@@ -1006,8 +1013,12 @@ struct KindProfile {
 // locking; a "set twice with different values" report goes through SlotState's mutex.  `after` (may be empty) is one more shared job at
 // the end -- the wires of the phase written into the matrix.
 // stage: 0 = the whole phase; k > 0 (late phase of a plan split into stages) = the generators of late stage k only.
+// before (may be empty): a shared job in front of the generators (the presets of the stage); keep_awake: leave the pool's workers spinning
+// at the end -- the next stage of this state follows within a fraction of a millisecond (whoever runs it, or frees the state, ends the pool).
 int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s, unsigned threads,
-               const std::function<void(unsigned, unsigned)>& after, std::string& err) {
+               const std::function<void(unsigned, unsigned)>& after, std::string& err,
+               const std::function<void(unsigned, unsigned)>& before = std::function<void(unsigned, unsigned)>(), bool keep_awake = false,
+               LevelPool** awake_out = nullptr) {
     constexpr u32 PAR_MIN_COST = 600;   // ~6 us of work: four PoseidonGate rows
     const vpbs_witness_plan::Phase& P = stage ? p.late_stage[stage - 1] : p.phase[ph];
     const unsigned mc = std::max(1u, p.max_consts);
@@ -1026,6 +1037,11 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         if (!busy.owns_lock()) pool = nullptr;   // another run of this phase has the threads: this one goes alone
     }
     if (!pool) {   // alone: the plan's own schedule order (generators of a row's neighbourhood together: far fewer cache misses than level order)
+        if (before) before(0, 1);
+        if (s.failed()) {
+            err = s.error_text();
+            return VPBS_ERR_INVALID;
+        }
         KindProfile prof;
         for (size_t i = 0; i < p.schedule.size(); ++i) {
             if (p.step_late[i] != ph || (stage && p.step_stage[i] != stage)) continue;
@@ -1052,7 +1068,18 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         // STRANDS: every thread runs its bin of independent components from the first level to the last, no barrier in between
         const double t_begin = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
         pool->begin();
+        if (before) pool->share([&](unsigned t) { before(t, threads); });
+        std::vector<double> t_start(threads, 0), t_stop(threads, 0);   // trace: when each thread picked its strand up, when it was through
+        auto clock_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         pool->share([&](unsigned t) {
+            if (trace) t_start[t] = clock_ms();
+            struct Stop {
+                double& at;
+                bool on;
+                ~Stop() {
+                    if (on) at = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                }
+            } stop_clock{t_stop[t], trace};
             const u32 lo = P.strand_off[t], hi = P.strand_off[t + 1];
 #if defined(VPBS_HAVE_POSEIDON_X8)
             u32 pending[8];
@@ -1089,11 +1116,22 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         int rc = failed.load() || s.failed() ? VPBS_ERR_INVALID : VPBS_OK;
         const double t_mid = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
         if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
-        pool->end();
-        if (trace)
-            std::fprintf(stderr, "[witness %s] stage %u, %u threads: %zu generators in strands %.2f ms, wires %.2f ms\n", name, stage, threads,
-                         P.order.size(), t_mid - t_begin,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_mid);
+        if (keep_awake && rc == VPBS_OK) {
+            if (awake_out) *awake_out = pool;
+        } else {
+            pool->end();
+        }
+        if (trace) {
+            double late_start = 0, longest = 0, shortest = 1e9;
+            for (unsigned t = 0; t < threads; ++t) {
+                late_start = std::max(late_start, t_start[t] - t_begin);
+                longest = std::max(longest, t_stop[t] - t_start[t]);
+                shortest = std::min(shortest, t_stop[t] - t_start[t]);
+            }
+            std::fprintf(stderr, "[witness %s] stage %u, %u threads: %zu generators in strands %.2f ms (last thread started after %.2f ms; strands took "
+                         "%.2f .. %.2f ms), wires %.2f ms\n", name, stage, threads, P.order.size(), t_mid - t_begin, late_start, shortest, longest,
+                         clock_ms() - t_mid);
+        }
         if (rc != VPBS_OK) {
             for (const auto& e : errs)
                 if (err.empty() && !e.empty()) err = e;
@@ -1144,6 +1182,11 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
     bool pool_awake = last_wide > 0;
     if (pool_awake) pool->begin();
     int rc = VPBS_OK;
+    if (before) {
+        if (pool_awake) pool->share([&](unsigned t) { before(t, threads); });
+        else before(0, 1);
+        if (s.failed()) rc = VPBS_ERR_INVALID;
+    }
     for (u32 l = 0; l < n_levels && rc == VPBS_OK; ++l) {
         if (pool_awake && l >= last_wide) {
             pool->end();
@@ -1226,7 +1269,12 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         pool_awake = true;
         pool->share([&](unsigned t) { after(t, threads); });
     }
-    if (pool_awake) pool->end();
+    if (keep_awake && rc == VPBS_OK) {
+        if (!pool_awake) pool->begin();   // spinning by the time the next stage arrives
+        if (awake_out) *awake_out = pool;
+    } else if (pool_awake) {
+        pool->end();
+    }
     if (trace)
         std::fprintf(stderr, "[witness %s] %u threads: %u narrow levels %.2f ms, %u wide levels %.2f ms, wires %.2f ms\n", name, threads,
                      n_levels - n_wide, t_narrow, n_wide, t_wide, clock() - t_after);
@@ -1381,14 +1429,18 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
     std::string msg;
     int rc = VPBS_OK;
     for (unsigned stage = state->stages_done + 1; stage <= p.n_stages && rc == VPBS_OK; ++stage) {
-        for (size_t i = 0; i < p.preset_slot.size(); ++i)
-            if (p.preset_late[i] == stage) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
-        lap("presets");
-        msg = s.error;
+        const std::vector<u32>& pre = p.stage_presets[stage - 1];
+        auto presets = [&](unsigned t, unsigned of) {
+            for (size_t k = pre.size() * t / of, end = pre.size() * (t + 1) / of; k < end; ++k)
+                s.set(p.preset_slot[pre[k]], preset_val[pre[k]], p.preset_pos[pre[k]]);
+        };
         const size_t lo = p.late_out_stage_off[stage - 1], hi = p.late_out_stage_off[stage];
-        rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, [&](unsigned t, unsigned of) { emit(lo, hi, t, of); }, msg)
-                         : VPBS_ERR_INVALID;
-        lap("generators + late wires");
+        rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, [&](unsigned t, unsigned of) { emit(lo, hi, t, of); }, msg, presets);
+        if (state->awake) {   // the pool had been left spinning for this stage: asleep again now (end() twice is harmless)
+            state->awake->end();
+            state->awake = nullptr;
+        }
+        lap("presets + generators + late wires");
     }
     if (trace) {
         for (int ph = 0; ph < 2; ++ph) {
@@ -1439,9 +1491,12 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
     }
     const vpbs_witness_plan& p = *plan;
     SlotState& s = state->s;
-    for (size_t i = 0; i < p.preset_slot.size(); ++i)
-        if (p.preset_late[i] == stage) s.set(p.preset_slot[i], preset_val[i], p.preset_pos[i]);
-    std::string msg = s.error;
+    const std::vector<u32>& pre = p.stage_presets[stage - 1];
+    auto presets = [&](unsigned t, unsigned of) {
+        for (size_t k = pre.size() * t / of, end = pre.size() * (t + 1) / of; k < end; ++k)
+            s.set(p.preset_slot[pre[k]], preset_val[pre[k]], p.preset_pos[pre[k]]);
+    };
+    std::string msg;
     static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
     const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
     // with a packed buffer the stage leaves its share of the late wires there at once (the order of vpbs_witness_plan_late_positions is by stage)
@@ -1457,7 +1512,14 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
             }
         };
     }
-    const int rc = msg.empty() ? run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg) : VPBS_ERR_INVALID;
+    // the stage before the last leaves the pool spinning: the last one starts when the proof returns, a fraction of a millisecond later, and
+    // waking sleeping workers would cost it more than that
+    if (state->awake) {
+        state->awake->end();
+        state->awake = nullptr;
+    }
+    const bool keep = stage + 1 == p.n_stages;
+    const int rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg, presets, keep, keep ? &state->awake : nullptr);
     if (pack && rc == VPBS_OK) state->stages_packed = stage;
     state->stages_done = stage;   // also after a failure: the state is only good for vpbs_witness_state_free / run_late (which reports again)
     report(err, err_len, msg);

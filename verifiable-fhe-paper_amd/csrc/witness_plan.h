@@ -233,6 +233,7 @@ struct vpbs_witness_plan {
     // generator belongs to the highest stage among what it reads, and late_stage[k - 1] holds the generators of stage k by dependency
     // level, so that stage k can run as soon as its presets exist, while the values of the stages above are still being computed.
     unsigned n_stages = 1;
+    std::vector<std::vector<u32>> stage_presets;   // [n_stages]: indices of the presets that arrive in stage k + 1
     std::vector<uint8_t> step_stage;            // per scheduled step: 0 early, otherwise its late stage
     std::vector<Phase> late_stage;              // [n_stages] (only filled when n_stages > 1; one stage = phase[1])
     // Chain lanes: PoseidonGate rows whose results nothing but other such rows reads inside the phase (the hash chains over the GGSW and
