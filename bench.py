@@ -749,7 +749,9 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                                     "the timed chained steps of this run (HIP events on each prover's stream)"),
             "chain_ms_per_step_split": {"witness_late_phase_host": t0s["late_witness_ms"], "late_rows_to_device": t0s["late_rows_upload_ms"],
                                         "prove_step": t0s["prove_step_ms"], "witness_early_phase_on_a_second_thread": t0s["early_witness_ms"],
-                                        "base_proof_once": t0s["base_proof_ms"], "over": "chain 0, warm-up steps included"},
+                                        "base_proof_once": t0s["base_proof_ms"],
+                                        "late_stages_run_during_the_previous_proofs_fri_stage": t0s["late_ahead_ms"],
+                                        "over": "chain 0, warm-up steps included"},
             "chain_checks": {"last_proof_verify_ms": verify_ms, "proof_bytes": len(chains[0]["blob"]),
                              "what": "after the clock, per chain: the last proof serialised by the library, parsed back, fully verified by "
                                      "vpbs_verify_step (gate constraints at zeta included); test vector, counter = %d, verifier data, the "

@@ -263,7 +263,8 @@ def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start, 
     t_verify, decrypted = check_chain(ctx, d, vk, blob, keys, testv, delta, ct, N, n_lwe, log_n, steps, message)
     return {"seconds": t["seconds"], "split": {"witness_late_phase_host": t["late_witness_ms"], "late_rows_to_device": t["late_rows_upload_ms"],
                                                "prove_step": t["prove_step_ms"], "base_proof_once": t["base_proof_ms"],
-                                               "witness_early_phase_on_a_second_thread": t["early_witness_ms"]},
+                                               "witness_early_phase_on_a_second_thread": t["early_witness_ms"],
+                                               "late_stages_run_during_the_previous_proofs_fri_stage": t["late_ahead_ms"]},
             "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
 
 

@@ -494,7 +494,7 @@ int plan_run(const vpbs_witness_plan* pp, const u64* preset_val, unsigned thread
 // writes -- unless the early phase knows that value anyway (an early preset, or an early step writes it too: the late step is then the
 // second writer of the slot and only compares; e.g. the limbs a late range check connects to the constant zero must not make every
 // reader of zero late).  Reads / writes of a gate generator are found the way plan creation finds them (gen_run on flags).
-unsigned default_phase_threads();   // further down: the pool size a phase gets by default (CPU budget of the process)
+unsigned late_phase_threads();   // further down: the pool size of the late phase (environment, host setting, CPU budget of the process)
 
 int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
     if (!pp || !late) {
@@ -734,8 +734,7 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
         P.strand_steps.clear(); P.strand_level.clear(); P.strand_off.clear();
         static const bool no_strands = std::getenv("VPBS_LATE_STRANDS") && std::atoi(std::getenv("VPBS_LATE_STRANDS")) == 0;
         if (only_stage && !no_strands && P.order.size() >= 512) {
-            static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
-            const unsigned T = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
+            const unsigned T = late_phase_threads();
             // components: two generators of the stage belong together when one reads what the other writes during the stage, or both write
             // the same class during the stage (the second compares).  A value that exists before the stage starts -- early, a preset of a
             // stage <= this one, the result of an earlier stage -- ties nothing together.
@@ -1312,6 +1311,19 @@ unsigned usable_cpus() {
     return n;
 }
 
+std::atomic<unsigned> g_late_threads{0};   // vpbs_host_set_late_threads (0: default)
+unsigned default_phase_threads();
+// The late phase's pool: VPBS_LATE_THREADS, else vpbs_host_set_late_threads, else by the CPU budget -- up to 14: the last late stage of an
+// in-circuit verifier is 28 independent queries (strands), two per thread at 14, and it sits on the critical path of an IVC chain for a
+// fraction of a millisecond per step (measured on the 16-CPU GPU box, single chain: 8 threads 12.1 ms per chained step, 14 threads 11.5)
+unsigned late_phase_threads() {
+    static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
+    if (e_late) return (unsigned)std::max(1, atoi(e_late));
+    if (const unsigned t = g_late_threads.load()) return t;
+    const unsigned cpus = usable_cpus();
+    return cpus >= 12 ? std::min(14u, cpus - 2) : default_phase_threads();
+}
+
 unsigned default_phase_threads() {
     // 8 on the GPU box (256 hardware threads, 16 by its cgroup), 4 of 8.  With the PoseidonGate rows of a level generated eight per AVX-512
     // register, 6, 8 and 12 threads measure the same for one chain (the 112 rows of a query level are two batches per thread either way);
@@ -1328,6 +1340,10 @@ int vpbs_host_set_cpu_budget(unsigned cpus) {
     return VPBS_OK;
 }
 unsigned vpbs_host_cpu_budget(void) { return vpbs::usable_cpus(); }
+int vpbs_host_set_late_threads(unsigned threads) {
+    vpbs::g_late_threads.store(threads);
+    return VPBS_OK;
+}
 
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late, char* err, size_t err_len) {
     std::string msg;
@@ -1409,8 +1425,7 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
         if (trace) std::fprintf(stderr, "[witness late] %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
-    const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
+    const unsigned late_threads = late_phase_threads();
     // the wires of late_out[lo, hi) (a stage's share is one such range), thread t of `of`
     auto emit = [&](size_t lo, size_t hi, unsigned t, unsigned of) {
         const size_t cnt = hi - lo;
@@ -1497,8 +1512,7 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
             s.set(p.preset_slot[pre[k]], preset_val[pre[k]], p.preset_pos[pre[k]]);
     };
     std::string msg;
-    static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
-    const unsigned late_threads = e_late ? (unsigned)std::max(1, atoi(e_late)) : default_phase_threads();
+    const unsigned late_threads = late_phase_threads();
     // with a packed buffer the stage leaves its share of the late wires there at once (the order of vpbs_witness_plan_late_positions is by stage)
     std::function<void(unsigned, unsigned)> after;
     const bool pack = packed_out && state->stages_packed + 1 == stage;
