@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen")):   # circuitgen: the stand-in circuit builder
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "circuitgen"), os.path.join(ROOT, "tools")):   # circuitgen: the stand-in circuit builder; tools: export_circuits (the exporter front end: tests may run it, the product may not)
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -12,6 +12,7 @@ import pytest
 import gates_oracle as go
 import oracle as orc
 import step_oracle
+import export_circuits
 import vpbs_amd
 from vpbs_amd import api, circuit_file
 
@@ -46,7 +47,7 @@ def test_cyclic_step_circuit_at_paper_parameters_bit_exact_against_the_oracle():
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import prove_ivc
-    cyc_path, dum_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, N_LWE, LOG_N)
+    cyc_path, dum_path = export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, N_LWE, LOG_N)
     ctx = vpbs_amd.Context(0, log_n_max=LOG_N)
     cyc, dum = prove_ivc.Circuit(ctx, cyc_path), prove_ivc.Circuit(ctx, dum_path)
     shape_words = cyc.d.meta["proof_words"]
@@ -96,7 +97,7 @@ def test_step_circuit_at_paper_parameters_bit_exact_against_the_oracle():
     """build_step_circuit (ivc_based_vpbs.rs:80-157, no recursive verifier) at N = 1024: 38 312 gate rows -> degree 2^16, 4105 public inputs; the
     exported sample witness proven by the HIP path and by the C oracle: identical words and bytes."""
     import torch
-    d = circuit_file.load(circuit_file.ensure_step_circuit(N, K, ELL, LOGB, N_LWE))
+    d = circuit_file.load(export_circuits.ensure_step_circuit(N, K, ELL, LOGB, N_LWE))
     ctx = vpbs_amd.Context(0, log_n_max=d.log_n)
     sigma = d.circuit.sigma_values()
     cs_values = np.concatenate([d.constants, sigma])

@@ -14,6 +14,7 @@ import oracle as orc
 import step_circuit as sc
 import step_oracle
 import tfhe_oracle as T
+import export_circuits
 import vpbs_amd
 from vpbs_amd import api
 
@@ -274,6 +275,7 @@ def test_whole_pbs_tool(world):
     import sys
     import __graft_entry__ as entry
     tool = entry.ROOT + "/tools/prove_pbs.py"
+    export_circuits.ensure_step_circuit(1024, 2, 4, 5, 14)   # the tool loads circuit files, it does not make them
     env = dict(os.environ, VPBS_PBS_BACKEND="gloo", VPBS_PBS_DEVICE="0")
     if world == 1:
         cmd = [sys.executable, tool, "14", "4", "2"]
@@ -300,7 +302,7 @@ def test_device_witness_at_paper_parameters_against_independent_evaluations(ctx)
     import tfhe_oracle as T
     from vpbs_amd import circuit_file
     N, K, ELL, LOGB, n_lwe, batch = 1024, 2, 4, 5, 728, 73
-    d = circuit_file.load(circuit_file.ensure_step_circuit(N, K, ELL, LOGB, n_lwe))
+    d = circuit_file.load(export_circuits.ensure_step_circuit(N, K, ELL, LOGB, n_lwe))
     keys = ctx.keygen(N, K, ELL, LOGB, n_lwe, 0xA14, 4.99027217501041e-8, 1.17021618159313e-5)
     testv, delta = api.testv(N, 2)
     ct = api.lwe_encrypt(keys["params"], keys["s_lwe"], delta % P)
@@ -354,6 +356,7 @@ def test_ivc_chain_tool(args, expect_steps):
     import subprocess
     import sys
     import __graft_entry__ as entry
+    export_circuits.ensure_cyclic_circuit(int(args[0]), 2, 4, 5, int(args[1]), int(args[2]))   # the tool loads circuit files, it does not make them
     r = subprocess.run([sys.executable, entry.ROOT + "/tools/prove_ivc.py"] + args, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -373,7 +376,7 @@ def test_cxx_host_proves_an_ivc_chain(N, n_lwe, log_n, steps, device_witness):
     import subprocess
     import __graft_entry__ as entry
     from vpbs_amd import circuit_file
-    cyc, dum = circuit_file.ensure_cyclic_circuit(N, 2, 4, 5, n_lwe, log_n)
+    cyc, dum = export_circuits.ensure_cyclic_circuit(N, 2, 4, 5, n_lwe, log_n)
     exe = entry.build_example("prove_ivc")
     env = dict(os.environ, VPBS_IVC_DEVICE_WITNESS=str(device_witness)) if device_witness else dict(os.environ)   # the other witness pipeline
     r = subprocess.run([exe, cyc, dum, str(steps)], capture_output=True, text=True, timeout=1500, env=env)
@@ -394,7 +397,7 @@ def test_ivc_chain_bit_identical_to_the_cpu_oracle_chain():
     from vpbs_amd import circuit_file
     N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
     ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
-    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, dum = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
     bsk_flat, ksk_flat = np.stack([T.flatten_ggsw(g) for g in bsk]), T.flatten_ggsw(ksk)
@@ -420,7 +423,7 @@ def test_ivc_driver_through_the_python_binding():
     PBS with the same keys, different ciphertexts), each proof accepted by vpbs_verify_pbs for its own ciphertext only"""
     from vpbs_amd import circuit_file
     N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 6, 13
-    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, dum = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     g = K * ELL * K * N
     with pytest.raises(api.VpbsError, match="not a cyclic step circuit"):
@@ -473,7 +476,7 @@ def test_ivc_driver_with_the_native_rccl_communicator_on_one_rank():
         pytest.skip("librccl.so is not loadable here")
     N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
     ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
-    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, dum = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     comm = sharding.make_comm_rccl(c, stage_words=2 << (log_n + 3))
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N, comm)
@@ -591,7 +594,7 @@ def test_device_early_phase_of_the_cyclic_circuit(ctx, N, n_lwe, log_n, batch):
     import torch
     from vpbs_amd import circuit_file
     K, ELL, LOGB = 2, 4, 5
-    cyc, _ = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, _ = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     W, n_pi = cyc.meta["proof_words"], len(cyc.pi_pos)
     plan = cyc.circuit.witness_plan(cyc.preset_pos)
     late = np.zeros(len(cyc.preset_pos), np.uint8)
@@ -643,7 +646,7 @@ def test_ivc_chain_with_the_early_phases_on_the_device():
     from vpbs_amd import circuit_file
     N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
     ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
-    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, dum = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
     frozen = json.load(open(GOLDEN_CHAIN))
@@ -660,7 +663,7 @@ def test_ivc_chain_with_the_early_phases_on_the_device():
     sys.path.insert(0, entry.ROOT + "/tools")
     import prove_ivc
     N, n_lwe, log_n, steps = 1024, 728, 16, 7
-    cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+    cyc, dum = (circuit_file.load(p) for p in export_circuits.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
     c = vpbs_amd.Context(0, log_n_max=16)
     ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
     keys = c.keygen(N, K, ELL, LOGB, n_lwe, 5, 4.99027217501041e-8, 1.17021618159313e-5)

@@ -357,13 +357,20 @@ def test_prover_tools_load_the_circuit_as_data():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for path in glob.glob(os.path.join(root, "verifiable-fhe-paper_amd", "*.py")):
         src = open(path).read()
-        for word in ('"tests"', '"circuitgen"', '"oracle"', "import step_circuit", "import cyclic_circuit", "import pymodel", "import oracle"):
+        for word in ('"tests"', '"circuitgen"', '"oracle"', "import step_circuit", "import cyclic_circuit", "import pymodel", "import oracle",
+                     "export_step_circuit", "export_circuits.ensure"):   # the package neither imports nor RUNS a circuit builder
             assert word not in src, (path, word)
+        if path.endswith("circuit_file.py"):
+            assert "subprocess" not in src and "os.system" not in src, path   # (api.py's only child process is `make` of the library itself)
     for tool in ("prove_pbs.py", "prove_ivc.py"):
         src = open(os.path.join(root, "tools", tool)).read()
         assert "import step_circuit" not in src and "import cyclic_circuit" not in src and '"tests"' not in src and '"circuitgen"' not in src, tool
+        assert "export_circuits" not in src and "export_step_circuit" not in src and "ensure_" not in src, tool   # they locate circuit files (find_*)
+    from vpbs_amd import circuit_file
+    with pytest.raises(FileNotFoundError, match="tools/export_circuits.py --cyclic 16 2 4 5 3 13"):
+        circuit_file.find_cyclic_circuit(16, 2, 4, 5, 3, 13)   # a parameter set nobody exported: located, not built
     bench = open(os.path.join(root, "bench.py")).read()
-    assert "import step_circuit" not in bench and "import cyclic_circuit" not in bench
+    assert "import step_circuit" not in bench and "import cyclic_circuit" not in bench and "export_circuits" not in bench
     assert bench.count('os.path.join(ROOT, "tests")') == 1 and bench.index("def cpu_baseline") < bench.index('os.path.join(ROOT, "tests")')
     exporters = {os.path.basename(p) for p in glob.glob(os.path.join(root, "tools", "*.py")) if '"circuitgen"' in open(p).read() or "'circuitgen'" in open(p).read()}
     assert {"export_step_circuit.py", "step_circuit_sizes.py"} <= exporters

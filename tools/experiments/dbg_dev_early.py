@@ -9,7 +9,7 @@ from test_cyclic_cpu import n8_chain_inputs
 P = api.P
 N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 1, 13
 ring, (s_to, s_lwe, s_glwe, bsk, ksk), delta, testv, ct = n8_chain_inputs()
-cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+cyc, dum = (circuit_file.load(p) for p in circuit_file.find_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
 W, n_pi = cyc.meta["proof_words"], len(cyc.pi_pos)
 kn = K * N
 plan = cyc.circuit.witness_plan(cyc.preset_pos)

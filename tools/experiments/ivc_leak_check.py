@@ -18,7 +18,7 @@ def rss_mb():
 
 
 N, K, ELL, LOGB, n_lwe, log_n = 8, 2, 4, 5, 6, 13
-cyc, dum = (circuit_file.load(p) for p in circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
+cyc, dum = (circuit_file.load(p) for p in circuit_file.find_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n))
 c = vpbs_amd.Context(0, log_n_max=16)
 ivc = api.Ivc(c, cyc, dum, N, K, K * ELL * K * N)
 if len(sys.argv) > 1:   # the device witness pipeline: batch size [late-on-device flag]

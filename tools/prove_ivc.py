@@ -281,8 +281,6 @@ def main():
     torch.cuda.set_device(device)
     dist, comm, native, dist_device = None, None, False, None
     t_setup = time.perf_counter()
-    if rank == 0:
-        circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -293,7 +291,7 @@ def main():
         else:
             dist.init_process_group(backend)
         dist.barrier()
-    cyc_path, dummy_path = circuit_file.ensure_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
+    cyc_path, dummy_path = circuit_file.find_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
     # the chain runs inside the library (vpbs_ivc_prove_pbs; with several GPUs every rank calls it with its communicator);
     # VPBS_IVC_DRIVER=python: the same loop spelled out here over the C ABI
     native_driver = os.environ.get("VPBS_IVC_DRIVER", "library") != "python"

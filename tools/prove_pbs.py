@@ -46,7 +46,7 @@ def main():
     torch.cuda.set_device(device)
     my_first, my_end = steps * rank // world, steps * (rank + 1) // world      # this rank's steps: [my_first, my_end)
     t_all = time.perf_counter()
-    b = circuit_file.load(circuit_file.ensure_step_circuit(N, K, ELL, LOGB, n_lwe))
+    b = circuit_file.load(circuit_file.find_step_circuit(N, K, ELL, LOGB, n_lwe))
     sigma = b.circuit.sigma_values()
     targets = b.preset_pos      # acc_init, acc_in, GGSW, counter, mask, the two chain hashes (the exporter's order, ivc_based_vpbs.rs:325-330)
     plan = b.circuit.witness_plan(targets)

@@ -2,7 +2,8 @@
 columns, copy constraints, gadget generators, the targets the PartialWitness sets and the public-input targets -- in the little-endian
 u64 format of examples/prove_step_circuit.cpp (the C++ reader) and tools/export_step_circuit.py (the exporter that stands in for the Rust
 side, /root/reference/src/vtfhe/ivc_based_vpbs.rs:80-155 `build_step_circuit` -> CircuitData).  The prover-side tools
-(bench.py, tools/prove_pbs.py) load a circuit through this module and the C ABI only; they never import a circuit builder.
+(bench.py, tools/prove_pbs.py, tools/prove_ivc.py) load a circuit through this module and the C ABI only; they never import or run a circuit
+builder: find_* locate exported files and raise when one is missing (tools/export_circuits.py, run by __graft_entry__.build(), makes them).
 
 File: header {magic, log_n, n_wires, n_routed, n_gates, n_constants_cols, n_copies, n_generators, generator_words, n_preset, n_public_inputs};
 gates [n_gates][kind, p0, p1, p2]; row_gate [n]; constants [cols][n]; copies [n_copies][2]; generators {kind, p0, n_in, n_out, in.., out..}*;
@@ -10,8 +11,6 @@ preset positions; public-input positions; sample preset values; expected public 
 [, kind, proof_words]} (kind 1: the cyclic step circuit, 2: its dummy circuit -- no sample witness in those files).
 Positions are column * n + row."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 
@@ -77,16 +76,19 @@ def step_circuit_path(N, K, ELL, LOGB, n_lwe):
     return os.path.join(DIR, "step_N%d_K%d_ELL%d_LOGB%d_n%d_v2.bin" % (N, K, ELL, LOGB, n_lwe))   # v2: split_le asserts its unused limbs zero
 
 
-def ensure_step_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728):
-    """Path of the exported step circuit at these parameters.  __graft_entry__.build() exports the paper's parameters; when the file is not
-    there the exporter is run once, in its own process (the exporter is the stand-in for the Rust circuit builder; nothing of it is imported here)."""
+def _missing(what, paths, args):
+    return FileNotFoundError(
+        "%s: %s not found.  Circuit files are produced OUTSIDE the product package by the circuit builder's exporter -- here "
+        "`python tools/export_circuits.py %s` (what __graft_entry__.build() runs for the standard parameter sets); with the reference, "
+        "tools/plonky2_capture exports the Rust builder's own circuit in the same format" % (what, ", ".join(paths), args))
+
+
+def find_step_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728):
+    """Path of the exported step circuit at these parameters; FileNotFoundError when it has not been exported (this module only LOCATES
+    circuit files: it neither runs nor imports a circuit builder)."""
     path = step_circuit_path(N, K, ELL, LOGB, n_lwe)
     if not os.path.exists(path):
-        os.makedirs(DIR, exist_ok=True)
-        tmp = path + ".tmp%d" % os.getpid()
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_step_circuit.py"), tmp, str(N), str(K), str(ELL), str(LOGB),
-                               str(n_lwe)], stdout=subprocess.DEVNULL)
-        os.replace(tmp, path)
+        raise _missing("step circuit", [path], "--step %d %d %d %d %d" % (N, K, ELL, LOGB, n_lwe))
     return path
 
 
@@ -106,14 +108,9 @@ def cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n):
     return os.path.join(DIR, "cyclic_" + stem), os.path.join(DIR, "dummy_" + stem)
 
 
-def ensure_cyclic_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728, log_n=16):
-    """(cyclic circuit file, dummy circuit file) of the IVC chain at these parameters; exported on first use by the exporter process"""
+def find_cyclic_circuit(N=1024, K=2, ELL=4, LOGB=5, n_lwe=728, log_n=16):
+    """(cyclic circuit file, dummy circuit file) of the IVC chain at these parameters; FileNotFoundError when they have not been exported"""
     path, dummy = cyclic_circuit_paths(N, K, ELL, LOGB, n_lwe, log_n)
     if not (os.path.exists(path) and os.path.exists(dummy)):
-        os.makedirs(DIR, exist_ok=True)
-        tmp, tmpd = path + ".tmp%d" % os.getpid(), dummy + ".tmp%d" % os.getpid()
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_step_circuit.py"), "--cyclic", tmp, tmpd] +
-                              [str(x) for x in (N, K, ELL, LOGB, n_lwe, log_n)], stdout=subprocess.DEVNULL)
-        os.replace(tmpd, dummy)
-        os.replace(tmp, path)
+        raise _missing("cyclic step circuit", [path, dummy], "--cyclic %d %d %d %d %d %d" % (N, K, ELL, LOGB, n_lwe, log_n))
     return path, dummy
