@@ -549,6 +549,8 @@ def test_bench_with_the_early_witness_phases_on_the_device():
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d["steps"] == 10 and d["config"]["chains_per_gpu"] == 2 and d["config"]["early_witness_phase"].startswith("on the device, 4 steps")
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 and d["chain_checks"]["proof_bytes"] == 192716
+    # the window sits in the pipeline's steady state: two batches of run-in before the warm-up, two batches of tail after the clock
+    assert d["config"]["run_in_steps"] == 8 and d["config"]["tail_steps"] == 8 and "ON THE DEVICE" in d["config"]["stages"]
 
 
 def test_bench_contract_with_two_ranks_sharing_the_gpu():
@@ -571,7 +573,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["vs_baseline"]) == (2, 12, 2, "weak", None)
     assert d["config"]["chains_per_gpu"] == 1 and "vpbs_ivc_prove_pbs" in d["config"]["workload"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 * d["value"] + 1e-12       # both ranks' chains over the MAX time
-    assert d["roofline"]["bound"] == "int-valu-issue" and d["chain_checks"]["proof_bytes"] == 192716
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["int_valu_issue"]["bound"] == "int-valu-issue" and d["chain_checks"]["proof_bytes"] == 192716
     assert "cpu_baseline" not in d                                                              # N = 1 only
 
 
