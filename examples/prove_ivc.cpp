@@ -129,6 +129,8 @@ int main(int argc, char** argv) {
     char err[256];
     vpbs_ivc* ivc = nullptr;
     const vpbs_ivc_circuit c_desc = cyc.describe(proof_words), d_desc = dum.describe(0);
+    // one chain in this process: with 16 CPUs or more, 14 threads for the late witness phase (its last stage is 28 independent FRI queries)
+    if (vpbs_host_cpu_budget() >= 16) vpbs_host_set_late_threads(14);
     REQUIRE(vpbs_ivc_create(ctx, &c_desc, &d_desc, N, K, ggsw_len, /* comm: one GPU */ nullptr, &ivc, err, sizeof err) == 0, "vpbs_ivc_create: %s", err);
     std::vector<u64> vk(68);
     vpbs_ivc_verifier_data(ivc, vk.data(), nullptr);

@@ -341,9 +341,10 @@ typedef struct vpbs_witness_state vpbs_witness_state;
  * first run).  vpbs_host_cpu_budget returns the figure in force. */
 int vpbs_host_set_cpu_budget(unsigned cpus);
 unsigned vpbs_host_cpu_budget(void);
-/* Threads of the LATE phase's pool for plans split afterwards (0 = default: by the CPU budget, up to 14 -- the last late stage of an
- * in-circuit verifier is 28 independent FRI queries; the environment variable VPBS_LATE_THREADS overrides both).  A host that runs many
- * chains per GPU on few CPUs lowers it; results never depend on it. */
+/* Threads of the LATE phase's pool for plans split afterwards (0 = default: half the CPU budget, at most 8; the environment variable
+ * VPBS_LATE_THREADS overrides both).  The last late stage of an in-circuit verifier is 28 independent FRI queries: a host that runs ONE chain
+ * and has 16 CPUs sets 14 (two queries per thread: 11.5 instead of 12.1 ms per chained step); with several chains per GPU the default is the
+ * better setting.  Results never depend on it. */
 int vpbs_host_set_late_threads(unsigned threads);
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,

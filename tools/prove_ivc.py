@@ -278,6 +278,8 @@ def main():
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     device = int(os.environ.get("VPBS_PBS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     n_chains = int(os.environ.get("VPBS_IVC_CHAINS", "1")) if world == 1 else 1
+    # one chain on a host with the CPUs: 14 threads for the late witness phase (28 independent FRI queries in its last stage); several chains: the default
+    api.host_set_late_threads(api.late_threads_for(n_chains, api.host_cpu_budget() // max(1, world)))
     torch.cuda.set_device(device)
     dist, comm, native, dist_device = None, None, False, None
     t_setup = time.perf_counter()

@@ -373,6 +373,23 @@ def host_set_cpu_budget(cpus):
     return lib().vpbs_host_cpu_budget()
 
 
+def host_cpu_budget():
+    """vpbs_host_cpu_budget: the CPUs this process may use (affinity, cgroup quota, vpbs_host_set_cpu_budget), without changing anything"""
+    return lib().vpbs_host_cpu_budget()
+
+
+def host_set_late_threads(threads):
+    """vpbs_host_set_late_threads: threads of the late witness phase's pool for plans split afterwards (0 = default).  A host that runs ONE
+    IVC chain and has 16 CPUs asks for 14: the last late stage of the in-circuit verifier is 28 independent FRI queries."""
+    lib().vpbs_host_set_late_threads(int(threads))
+
+
+def late_threads_for(chains, cpus=None):
+    """what the tools ask for: 14 for a single chain on a host with at least 16 CPUs for this process, the default otherwise"""
+    cpus = host_cpu_budget() if cpus is None else cpus
+    return 14 if chains == 1 and cpus >= 16 else 0
+
+
 def hash_pad(x=()):
     """PoseidonHash::hash_pad (pad10*1, then hash_no_pad)"""
     x = _u64(x).reshape(-1)

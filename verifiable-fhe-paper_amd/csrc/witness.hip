@@ -1313,15 +1313,15 @@ unsigned usable_cpus() {
 
 std::atomic<unsigned> g_late_threads{0};   // vpbs_host_set_late_threads (0: default)
 unsigned default_phase_threads();
-// The late phase's pool: VPBS_LATE_THREADS, else vpbs_host_set_late_threads, else by the CPU budget -- up to 14: the last late stage of an
-// in-circuit verifier is 28 independent queries (strands), two per thread at 14, and it sits on the critical path of an IVC chain for a
-// fraction of a millisecond per step (measured on the 16-CPU GPU box, single chain: 8 threads 12.1 ms per chained step, 14 threads 11.5)
+// The late phase's pool: VPBS_LATE_THREADS, else vpbs_host_set_late_threads, else the default of every phase.  The last late stage of an
+// in-circuit verifier is 28 independent queries (strands): a host that runs ONE chain and has the CPUs asks for 14 (two queries per thread;
+// measured on the 16-CPU GPU box: 8 threads 12.1 ms per chained step, 14 threads 11.5); with six chains per GPU 14 threads per chain
+// cost throughput (8.64 against 8.27 ms per chained proof with 8), which is why 14 is not the default.
 unsigned late_phase_threads() {
     static const char* const e_late = std::getenv("VPBS_LATE_THREADS");
     if (e_late) return (unsigned)std::max(1, atoi(e_late));
     if (const unsigned t = g_late_threads.load()) return t;
-    const unsigned cpus = usable_cpus();
-    return cpus >= 12 ? std::min(14u, cpus - 2) : default_phase_threads();
+    return default_phase_threads();
 }
 
 unsigned default_phase_threads() {
