@@ -1083,9 +1083,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=vpbs_amd.sharding.group_timeout())
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=vpbs_amd.sharding.group_timeout())
     log_n = args.log_n
     secondary = rank == 0 and world == 1 and log_n == LOG_N
     # What a rank's share of the host CPUs carries (measured on one MI355X with the affinity mask as the share and 8 hardware queues,

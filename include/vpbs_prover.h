@@ -32,7 +32,9 @@ typedef enum {
     VPBS_ERR_INVALID = -1,   /* bad argument (size not a power of two, null pointer, ...) */
     VPBS_ERR_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
     VPBS_ERR_OOM = -3,       /* device allocation failed */
-    VPBS_ERR_POW = -4        /* forced proof-of-work nonce is not valid / search exhausted */
+    VPBS_ERR_POW = -4,       /* forced proof-of-work nonce is not valid / search exhausted */
+    VPBS_ERR_PEER = -5       /* a sharded step proof: ANOTHER rank of the communicator failed (its own call returns its own error); every
+                                rank of the step returns an error, none hangs in a collective */
 } vpbs_status;
 
 #define VPBS_POW_ANY UINT64_MAX
@@ -541,6 +543,18 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
 int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out,
                             uint64_t* openings_out, uint64_t* fri_out, vpbs_challenger_state* challenger_out,
                             uint64_t* challenges_out);
+/* Failure semantics of a sharded step (the reference unwraps every prover error and dies, ivc_based_vpbs.rs:308,339,370; ranks of a node must
+ * not hang instead).  Every host collective of vpbs_prove_step_sharded carries one more word per rank, its status: a rank that fails between
+ * two collectives still takes part in all the collectives the step has left -- with zeros and its error code -- and returns its own error;
+ * every other rank sees the non-zero status at its next collective, does the same, and returns VPBS_ERR_PEER.  No rank returns a proof, no
+ * rank waits for a peer that has gone.  (A peer that DIES is the communicator's business: the RCCL communicator of this library gives up
+ * after VPBS_COMM_TIMEOUT_S seconds (default 60) and aborts itself; torch.distributed groups take a timeout at creation.)
+ * vpbs_prove_step_sharded_fail is for a rank that cannot even start the step (its witness generation failed): it takes part in the step's
+ * collectives on the failing side, so that the peers' vpbs_prove_step_sharded calls return VPBS_ERR_PEER.  `in` gives the shape only.
+ * vpbs_comm_allgather_checked is the same idea for a host's own all-gathers around the library (the cap of a sharded constants / sigmas
+ * commitment): local_status != 0 on any rank makes it return VPBS_ERR_PEER (the failing rank: its status) on every rank. */
+int vpbs_prove_step_sharded_fail(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, int status);
+int vpbs_comm_allgather_checked(const vpbs_comm* comm, const uint64_t* local, size_t local_words, uint64_t* full, int local_status);
 /* ProofWithPublicInputs::to_bytes layout (util/serialization); returns bytes written or <0.
  * n_constants: how many leading columns of constants_sigmas are `constants` (the rest are plonk_sigmas).  The public-input prefix follows
  * the context's compat table. */

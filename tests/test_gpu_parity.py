@@ -187,6 +187,20 @@ def test_sharded_step_proof_multi_rank(world, log_n):
     assert "SHARDED_STEP_OK world=%d" % world in r.stdout
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_failure_semantics(world):
+    """a rank of a sharded step that fails outside a collective (before its 1st / 2nd / 3rd commitment, or before the step
+    starts) does not leave the others hanging: it returns its own error, every other rank VPBS_ERR_PEER, all within 10 s, no rank returns a
+    proof, and the next step on the same communicator is the single-GPU proof again (gloo, all ranks on this box's GPU)."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tests", "gloo_sharded_failure_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29570 + world), script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SHARDED_FAILURE_OK world=%d" % world in r.stdout
+
+
 # ---------- FRI ----------
 def _fri_case(ctx, log_n, cols, **over):
     datas = [rand_field(nc, 1 << log_n) for nc in cols]

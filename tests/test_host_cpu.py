@@ -177,6 +177,17 @@ def test_coset_sharded_commit_gloo_world2(tmp_path):
     assert "SHARDED_COMMIT_OK" in r.stdout
 
 
+def test_checked_allgather_reports_a_failing_rank_gloo_world2():
+    """Failure semantics between ranks (include/vpbs_prover.h; the reference has none: it unwraps and dies, ivc_based_vpbs.rs:308): world-2 gloo
+    run of vpbs_comm_allgather_checked -- the failing rank takes part with its status, both ranks return an error within the call, the
+    communicator stays in step.  (The sharded step proof's own protocol needs the device: tests/gloo_sharded_failure_gpu.py.)"""
+    script = os.path.join(ROOT, "tests", "gloo_comm_failure.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "COMM_FAILURE_OK world=2" in r.stdout
+
+
 def test_step_proof_byte_size_matches_paper_scale():
     """ProofWithPublicInputs::to_bytes size for the N=1024 step circuit from the restated layout (SURVEY.md Appendix A.8):
     3 caps + 258 extension openings + FRI proof (3 caps, 28 query rounds, 8-coefficient final poly, nonce) + 4173 public

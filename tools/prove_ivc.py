@@ -288,10 +288,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("VPBS_PBS_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=vpbs_amd.sharding.group_timeout())
             dist_device = torch.device("cuda", device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=vpbs_amd.sharding.group_timeout())
         dist.barrier()
     cyc_path, dummy_path = circuit_file.find_cyclic_circuit(N, K, ELL, LOGB, n_lwe, log_n)
     # the chain runs inside the library (vpbs_ivc_prove_pbs; with several GPUs every rank calls it with its communicator);

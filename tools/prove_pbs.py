@@ -42,7 +42,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get("VPBS_PBS_BACKEND", "nccl"))
+        dist.init_process_group(os.environ.get("VPBS_PBS_BACKEND", "nccl"), timeout=vpbs_amd.sharding.group_timeout())
     torch.cuda.set_device(device)
     my_first, my_end = steps * rank // world, steps * (rank + 1) // world      # this rank's steps: [my_first, my_end)
     t_all = time.perf_counter()

@@ -248,6 +248,8 @@ SIGNATURES = {
     "vpbs_ivc_set_step_callback": (_i, [_vp, IVC_STEP_FN, _vp]),
     "vpbs_ivc_set_device_witness": (_i, [_vp, _ui, _ui, _ui, _i]),
     "vpbs_ivc_last_error": (C.c_char_p, [_vp]),
+    "vpbs_prove_step_sharded_fail": (_i, [_vp, C.POINTER(StepInputsC), C.POINTER(CommC), _i]),
+    "vpbs_comm_allgather_checked": (_i, [C.POINTER(CommC), U64P, _sz, U64P, _i]),
     "vpbs_host_set_late_threads": (_i, [_ui]),
     "vpbs_witness_device_has_late": (_i, [_vp]),
     "vpbs_witness_device_run_late": (_i, [C.c_void_p, C.c_uint, U64P]),

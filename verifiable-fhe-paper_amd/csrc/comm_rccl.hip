@@ -9,9 +9,12 @@
 // (bench.py / sharding.py: a torch.distributed broadcast; a C++ host: its launcher); every rank then calls vpbs_comm_rccl_create.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include <rccl/rccl.h>
 
@@ -26,6 +29,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) get_unique_id = nullptr;
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommAbort) comm_abort = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
@@ -53,6 +57,7 @@ Rccl* rccl() {
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.handle, "ncclGetUniqueId"));
         r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(r.handle, "ncclCommInitRank"));
         r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.handle, "ncclCommDestroy"));
+        r.comm_abort = reinterpret_cast<decltype(r.comm_abort)>(dlsym(r.handle, "ncclCommAbort"));   // optional: the timeout path
         r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(r.handle, "ncclAllGather"));
         r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.handle, "ncclAllReduce"));
         r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.handle, "ncclGetErrorString"));
@@ -69,6 +74,7 @@ struct RcclComm {
     u64* d_stage_local = nullptr;  // the device-resident all-gather of the quotient values
     u64* d_stage_full = nullptr;
     size_t stage_words = 0;
+    bool dead = false;             // a collective timed out: the communicator was aborted, every later call fails at once
 };
 constexpr size_t SMALL_WORDS = 1 << 14;  // 128 KiB per rank: cap hashes (64 words) and query records (a few thousand words) fit
 
@@ -78,40 +84,81 @@ int fail(RcclComm* c, const char* what, ncclResult_t rc) {
     return -1;
 }
 
+// A collective whose peer never arrives would block hipStreamSynchronize for ever (a rank that failed outside the library, a process that
+// died): the stream is polled instead, and after VPBS_COMM_TIMEOUT_S seconds (default 60) the communicator is aborted (ncclCommAbort) and
+// the call fails -- the rank returns an error and its process can exit non-zero; a process that has touched the GPU is never restarted.
+double comm_timeout_s() {
+    static const double t = [] {
+        const char* e = std::getenv("VPBS_COMM_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 60.0;
+        return v > 0 ? v : 60.0;
+    }();
+    return t;
+}
+int wait_collective(RcclComm* c, hipStream_t s, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return -1;
+        if (spins < 20000) continue;                                   // the usual case: microseconds
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) {
+            c->dead = true;
+            if (Rccl* r = rccl(); r && r->comm_abort) (void)r->comm_abort(c->comm);
+            c->comm = nullptr;
+            c->ctx->err = std::string(what) + ": no answer from the other ranks within " + std::to_string((int)comm_timeout_s()) +
+                          " s (VPBS_COMM_TIMEOUT_S): communicator aborted";
+            return -1;
+        }
+    }
+}
+
 // vpbs_allgather_fn: `local` / `full` are host arrays (tiny); device staging + ncclAllGather on the context's stream
 int allgather_host(void* user, const uint64_t* local, size_t words, uint64_t* full) {
     auto* c = static_cast<RcclComm*>(user);
-    if (words > SMALL_WORDS) return -1;
+    if (words > SMALL_WORDS || c->dead) return -1;
     hipStream_t s = c->ctx->stream;
     u64* d_local = c->d_small;
     u64* d_full = c->d_small + SMALL_WORDS;
     if (hipMemcpyAsync(d_local, local, 8 * words, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     const ncclResult_t rc = rccl()->all_gather(d_local, d_full, words, ncclUint64, c->comm, s);
     if (rc != ncclSuccess) return fail(c, "ncclAllGather", rc);
-    if (hipMemcpyAsync(full, d_full, 8 * words * c->world, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+    // through pinned memory: a device-to-host copy into pageable memory blocks inside hipMemcpyAsync until the collective in front of it has
+    // completed -- i.e. for ever when a peer never arrives -- and the timeout below would never be reached
+    const size_t bytes = 8 * words * c->world;
+    c->ctx->ensure_pinned();
+    void* via = c->ctx->pinned && bytes <= c->ctx->pinned_bytes ? c->ctx->pinned : static_cast<void*>(full);
+    if (hipMemcpyAsync(via, d_full, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (wait_collective(c, s, "ncclAllGather") != 0) return -1;
+    if (via != full) std::memcpy(full, via, bytes);
+    return 0;
 }
 // vpbs_allreduce_sum_fn: element-wise wrapping u64 sum (the owning rank fills a query record, the others contribute zeros)
 int allreduce_host(void* user, uint64_t* inout, size_t words) {
     auto* c = static_cast<RcclComm*>(user);
+    if (c->dead) return -1;
     hipStream_t s = c->ctx->stream;
     for (size_t done = 0; done < words; done += SMALL_WORDS) {
         const size_t cnt = words - done < SMALL_WORDS ? words - done : SMALL_WORDS;
         if (hipMemcpyAsync(c->d_small, inout + done, 8 * cnt, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
         const ncclResult_t rc = rccl()->all_reduce(c->d_small, c->d_small, cnt, ncclUint64, ncclSum, c->comm, s);
         if (rc != ncclSuccess) return fail(c, "ncclAllReduce", rc);
-        if (hipMemcpyAsync(inout + done, c->d_small, 8 * cnt, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        c->ctx->ensure_pinned();
+        void* via = c->ctx->pinned && 8 * cnt <= c->ctx->pinned_bytes ? c->ctx->pinned : static_cast<void*>(inout + done);
+        if (hipMemcpyAsync(via, c->d_small, 8 * cnt, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (wait_collective(c, s, "ncclAllReduce") != 0) return -1;
+        if (via != inout + done) std::memcpy(inout + done, via, 8 * cnt);
     }
     return 0;
 }
 // vpbs_allgather_dev_fn: d_stage_local -> d_stage_full on every rank, device to device
 int allgather_dev(void* user, size_t local_words) {
     auto* c = static_cast<RcclComm*>(user);
-    if (local_words > c->stage_words) return -1;
+    if (local_words > c->stage_words || c->dead) return -1;
     const ncclResult_t rc = rccl()->all_gather(c->d_stage_local, c->d_stage_full, local_words, ncclUint64, c->comm, c->ctx->stream);
     if (rc != ncclSuccess) return fail(c, "ncclAllGather (device)", rc);
-    return hipStreamSynchronize(c->ctx->stream) == hipSuccess ? 0 : -1;
+    return wait_collective(c, c->ctx->stream, "ncclAllGather (device)");
 }
 }  // namespace
 
@@ -182,8 +229,8 @@ int vpbs_comm_rccl_create(vpbs_ctx* ctx, const uint8_t unique_id[128], unsigned 
 void vpbs_comm_rccl_destroy(vpbs_comm* comm) {
     if (!comm || !comm->user || comm->allgather != &allgather_host) return;
     auto* c = static_cast<RcclComm*>(comm->user);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (Rccl* r = rccl()) r->comm_destroy(c->comm);
+    if (!c->dead) (void)hipStreamSynchronize(c->ctx->stream);
+    if (Rccl* r = rccl(); r && c->comm) r->comm_destroy(c->comm);   // an aborted communicator is gone already
     c->ctx->release(c->d_small);
     if (c->d_stage_local) c->ctx->release(c->d_stage_local);
     if (c->d_stage_full) c->ctx->release(c->d_stage_full);

@@ -71,7 +71,11 @@ struct Side {   // one circuit on the context
             if (rc == 0) rc = vpbs_device_upload(ctx, d_csv, csv.data(), csv.size());
             std::vector<u64> local(cap_words / comm->world);
             if (rc == 0) rc = vpbs_commit_sharded_dev(ctx, d_csv, 1, n_const_cols + n_routed, log_n, comm->rank, comm->world, &cs, local.data());
-            if (rc == 0 && comm->allgather(comm->user, local.data(), local.size(), cs_cap.data()) != 0) return err = "all-gather of the cap failed", VPBS_ERR_DEVICE;
+            // the all-gather carries every rank's status: a rank whose commitment failed still takes part, and all ranks return an error
+            const int own = rc;
+            rc = vpbs_comm_allgather_checked(comm, local.data(), local.size(), cs_cap.data(), own);
+            if (rc != 0 && own == 0)
+                return err = rc == VPBS_ERR_PEER ? "constants / sigmas commitment: another rank failed" : "all-gather of the cap failed", rc;
         }
         if (rc != 0) return err = std::string("constants / sigmas commitment: ") + vpbs_last_error(ctx), rc;
         vk.assign(4, 0);
@@ -657,6 +661,15 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             h->ahead->post((unsigned)sec);
         }
     } hook{&ahead, &mu, &staged, &states, &next_state, values.data()};
+    // a rank of a SHARDED chain that cannot start a step's proof takes part in the step's collectives on the failing side (see the host pipeline)
+    auto stop_step = [&](const std::string& m, int why) {
+        if (cyc.comm) {
+            vpbs_step_inputs shape;
+            cyc.step_inputs(shape, nullptr, true, nullptr);
+            (void)vpbs_prove_step_sharded_fail(ctx, &shape, cyc.comm, why);
+        }
+        return stop(m, why);
+    };
     for (unsigned s = 0; s < steps; ++s) {
         const unsigned k = s % vpbs_ivc::NBUF;
         {
@@ -670,7 +683,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             t_wait_hashed += now() - tw2;
             if (failed) {
                 lk.unlock();
-                return stop("", VPBS_ERR_INVALID);
+                return stop_step("", VPBS_ERR_INVALID);
             }
         }
         double t = now();
@@ -679,12 +692,12 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             vpbs_witness_device* dev = v->wdev[(s / B) & 1];
             rc = vpbs_witness_device_run_late(dev, s % B, values.data());
             if (rc != 0)
-                return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " +
+                return stop_step("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " +
                             vpbs_last_error(v->wctx[(s / B) & 1]), rc);
             t_late += now() - t;
             t = now();
             rc = vpbs_witness_device_wires(dev, s % B, v->d_bufs[k]);
-            if (rc != 0) return stop(std::string("gathering the wires: ") + vpbs_last_error(v->wctx[(s / B) & 1]), rc);
+            if (rc != 0) return stop_step(std::string("gathering the wires: ") + vpbs_last_error(v->wctx[(s / B) & 1]), rc);
             t_rows += now() - t;
         } else {
             vpbs_witness_state* st = next_state;
@@ -693,7 +706,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
                 std::string msg;
                 if (!ahead.drain(msg)) {
                     vpbs_witness_state_free(st);
-                    return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
+                    return stop_step("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
                 }
             } else {
                 std::lock_guard<std::mutex> lk(mu);
@@ -701,11 +714,11 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
                 states.st[k] = nullptr;
             }
             rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, values.data(), v->late_vals, e, sizeof e);
-            if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+            if (rc != 0) return stop_step("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
             t_late += now() - t;
             t = now();
             rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
-            if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
+            if (rc != 0) return stop_step(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
             t_rows += now() - t;
         }
         t = now();
@@ -941,6 +954,14 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
             h->ahead->post((unsigned)sec);
         }
     } hook{&ahead, &mu, &ready, &next, &have_next, proof.data()};
+    // a rank of a SHARDED chain that cannot start a step's proof (its witness failed) takes part in that step's collectives on the failing
+    // side: the other ranks' proofs of the step return VPBS_ERR_PEER and the chain ends on every rank instead of hanging on the others
+    auto abandon_step = [&](int why) {
+        if (!cyc.comm) return;
+        vpbs_step_inputs shape;
+        cyc.step_inputs(shape, nullptr, true, nullptr);
+        (void)vpbs_prove_step_sharded_fail(ctx, &shape, cyc.comm, why);
+    };
     for (unsigned s = 0; s < steps; ++s) {
         Ready r;
         if (have_next) {
@@ -951,6 +972,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
             cv.wait(lk, [&] { return !ready.empty() || failed; });
             if (failed) {
                 lk.unlock();
+                abandon_step(VPBS_ERR_INVALID);
                 return stop("", VPBS_ERR_INVALID);
             }
             r = std::move(ready.front());
@@ -959,17 +981,26 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         double t = now();
         if (ahead.active()) {   // stages that ran ahead on this step's state: wait for the last of them (usually long finished)
             std::string msg;
-            if (!ahead.drain(msg)) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
+            if (!ahead.drain(msg)) {
+                abandon_step(VPBS_ERR_INVALID);
+                return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + msg, VPBS_ERR_INVALID);
+            }
         }
         std::copy(proof.begin(), proof.end(), r.values.begin());
         vpbs_witness_state* st = r.state;
         r.state = nullptr;
         rc = vpbs_witness_plan_run_late_packed(cyc.plan, st, r.values.data(), v->late_vals, e, sizeof e);   // consumes the state, also when it fails
-        if (rc != 0) return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+        if (rc != 0) {
+            abandon_step(rc);
+            return stop("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
+        }
         t_late += now() - t;
         t = now();
         rc = vpbs_device_scatter(ctx, v->d_bufs[r.buf], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
-        if (rc != 0) return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
+        if (rc != 0) {
+            abandon_step(rc);
+            return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
+        }
         t_rows += now() - t;
         t = now();
         pis = std::move(r.pis);

@@ -6,6 +6,8 @@
 // The Fiat-Shamir transcript is strictly sequential: every cap / opening set comes back to the host (512 B..4 KiB),
 // is absorbed by the host Challenger, and the next challenge is passed to the next kernel as an argument.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "host/plonky2_mirror.h"
 
@@ -728,6 +730,133 @@ int vpbs_step_sizes_get(const vpbs_ctx* ctx, const vpbs_step_inputs* in, vpbs_st
     return VPBS_OK;
 }
 
+namespace {
+// The collectives of ONE sharded step proof, with a status word per rank riding on every host collective (include/vpbs_prover.h, "failure
+// semantics").  `outer` is the communicator the prover's stages see: its callbacks append this rank's status to the payload, strip the
+// peers' on the way back and note a failure; `plan` is the fixed sequence of collectives of the step, so that a rank that fails (or learns
+// that a peer has) can take part in what is left of it with zeros (finish()), instead of leaving the others waiting.
+struct ShardSession {
+    enum Kind { GATHER, GATHER_DEV, REDUCE };
+    struct Coll {
+        Kind kind;
+        size_t words;
+    };
+    const vpbs_comm* inner;
+    vpbs_comm outer;
+    std::vector<Coll> plan;
+    size_t next = 0;
+    int status = 0;           // this rank's: 0 while it is fine
+    bool peer_failed = false, broken = false;   // broken: a collective itself failed -- nothing more can be exchanged
+    std::vector<u64> buf_a, buf_b;
+
+    ShardSession(const vpbs_comm* c, size_t cap_local_words, size_t quotient_dev_words, size_t query_words) : inner(c), outer(*c) {
+        plan = {{GATHER, cap_local_words}, {GATHER, cap_local_words}};
+        if (quotient_dev_words) plan.push_back({GATHER_DEV, quotient_dev_words});
+        plan.push_back({GATHER, cap_local_words});
+        plan.push_back({REDUCE, query_words});
+        outer.user = this;
+        outer.allgather = [](void* u, const uint64_t* local, size_t words, uint64_t* full) { return static_cast<ShardSession*>(u)->gather(local, words, full); };
+        outer.allreduce_sum = [](void* u, uint64_t* inout, size_t words) { return static_cast<ShardSession*>(u)->reduce(inout, words); };
+        if (c->allgather_dev) outer.allgather_dev = [](void* u, size_t words) { return static_cast<ShardSession*>(u)->gather_dev(words); };
+    }
+    int gather(const uint64_t* local, size_t words, uint64_t* full) {
+        if (broken || next >= plan.size() || plan[next].kind != GATHER || plan[next].words != words) return broken = true, -1;
+        ++next;
+        const unsigned world = inner->world;
+        buf_a.assign(words + 1, 0);
+        if (local) std::memcpy(buf_a.data(), local, 8 * words);
+        buf_a[words] = status ? 1 : 0;
+        buf_b.assign((size_t)world * (words + 1), 0);
+        if (inner->allgather(inner->user, buf_a.data(), words + 1, buf_b.data()) != 0) return broken = true, -1;
+        for (unsigned r = 0; r < world; ++r) {
+            if (full) std::memcpy(full + (size_t)r * words, buf_b.data() + (size_t)r * (words + 1), 8 * words);
+            if (r != inner->rank && buf_b[(size_t)r * (words + 1) + words] != 0) peer_failed = true;
+        }
+        return peer_failed ? -1 : 0;
+    }
+    int reduce(uint64_t* inout, size_t words) {
+        if (broken || next >= plan.size() || plan[next].kind != REDUCE || plan[next].words != words) return broken = true, -1;
+        ++next;
+        buf_a.assign(words + 1, 0);
+        if (inout) std::memcpy(buf_a.data(), inout, 8 * words);
+        buf_a[words] = status ? 1 : 0;
+        if (inner->allreduce_sum(inner->user, buf_a.data(), words + 1) != 0) return broken = true, -1;
+        if (inout) std::memcpy(inout, buf_a.data(), 8 * words);
+        if (buf_a[words] != (status ? 1u : 0u)) peer_failed = true;
+        return peer_failed ? -1 : 0;
+    }
+    int gather_dev(size_t words) {   // device payload: no status of its own (a failure shows at the next host collective)
+        if (broken || next >= plan.size() || plan[next].kind != GATHER_DEV || plan[next].words != words) return broken = true, -1;
+        ++next;
+        if (inner->allgather_dev(inner->user, words) != 0) return broken = true, -1;
+        return 0;
+    }
+    // this rank is out (its own failure, or a peer's): the collectives the step has left, with zeros and the status
+    void finish(int why) {
+        if (!status) status = why ? why : VPBS_ERR_PEER;
+        while (!broken && next < plan.size()) {
+            const Coll c = plan[next];
+            if (c.kind == GATHER) (void)gather(nullptr, c.words, nullptr);
+            else if (c.kind == REDUCE) (void)reduce(nullptr, c.words);
+            else if (inner->allgather_dev) (void)gather_dev(c.words);
+            else broken = true;
+        }
+    }
+};
+
+// shape of the step's collectives from its inputs: words of a rank's cap share, of its quotient values (0: quotient supplied), of the query records
+void shard_plan_sizes(const vpbs_ctx* ctx, const vpbs_step_inputs* in, unsigned world, size_t& cap_local, size_t& quot_dev, size_t& query_words) {
+    const plonky2::FriParams fp = plonky2::FriParams::standard(in->log_n, ctx->rate_bits, ctx->cap_height);
+    const size_t cap_words = (size_t)4 << ctx->cap_height, n_cs = in->constants_sigmas->ncols;
+    cap_local = cap_words / world;
+    quot_dev = in->quotient_coeffs ? 0 : (size_t)in->num_challenges * (((size_t)1 << (in->log_n + ctx->rate_bits)) / world);
+    const size_t total = plonky2::fri_proof_words(fp, {n_cs, in->n_wires, in->n_zs_partial_products, in->n_quotient});
+    query_words = total - fp.reduction_arity_bits.size() * cap_words - ((size_t)2 << fp.final_poly_bits()) - 1;
+}
+
+// fault injection for the failure-semantics tests (the reference has no failure handling to mirror: SURVEY.md section 5): VPBS_FAULT_INJECT=
+// "<rank>:<stage>" makes that rank of a sharded step throw before its <stage>-th commitment (1 = wires, 2 = Z / partial products, 3 = quotient)
+void maybe_inject_fault(const vpbs_comm* comm, int stage) {
+    if (!comm) return;
+    const char* const e = std::getenv("VPBS_FAULT_INJECT");   // read at every sharded step: a test switches it between two steps
+    if (!e) return;
+    unsigned rank = 0;
+    int at = 0;
+    if (std::sscanf(e, "%u:%d", &rank, &at) == 2 && rank == comm->rank && at == stage)
+        throw DeviceError{VPBS_ERR_DEVICE, "injected failure before commitment " + std::to_string(stage) + " (VPBS_FAULT_INJECT)"};
+}
+}  // namespace
+
+static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
+                           uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out);
+
+// the sharded form: the same prover under a ShardSession, which sees to it that every rank leaves the step through all of its collectives
+static int prove_step_sharded_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
+                                   uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
+    if (!ctx || !in || !in->constants_sigmas || !comm || comm->world < 2 || comm->rank >= comm->world || !comm->allgather || !comm->allreduce_sum ||
+        (((size_t)4 << ctx->cap_height) % comm->world) != 0)
+        return VPBS_ERR_INVALID;
+    size_t cap_local, quot_dev, query_words;
+    shard_plan_sizes(ctx, in, comm->world, cap_local, quot_dev, query_words);
+    ShardSession session(comm, cap_local, quot_dev, query_words);
+    int rc = prove_step_impl(ctx, in, &session.outer, caps_out, openings_out, fri_out, challenger_out, challenges_out);
+    if (rc == VPBS_OK && session.next != session.plan.size()) {
+        ctx->err = "sharded step: the prover left collectives of the step undone";   // cannot happen with matching shapes; do not leave peers waiting
+        rc = VPBS_ERR_INVALID;
+    }
+    if (rc != VPBS_OK) {
+        const bool peer = session.peer_failed && !session.status;
+        session.finish(peer ? VPBS_ERR_PEER : rc);
+        if (peer) {
+            ctx->err = "sharded step: another rank failed (" + ctx->err + ")";
+            rc = VPBS_ERR_PEER;
+        } else if (session.broken) {
+            ctx->err += " [a collective itself failed: peers may be waiting until their communicator's timeout]";
+        }
+    }
+    return rc;
+}
+
 static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
                            uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
     if (!ctx || !in || !caps_out || !openings_out || !fri_out || !in->constants_sigmas) return VPBS_ERR_INVALID;
@@ -778,6 +907,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         }
 
         // prove(): public_inputs_hash, wires commitment, transcript
+        maybe_inject_fault(comm, 1);
         PolynomialBatch wires = PolynomialBatch::from_values(ctx, d_wires, in->n_wires, log_n, false, comm);
         HashOut pi_hash;  // hashed on the host while the device works on the wires commitment
         vpbs_hash_no_pad(in->public_inputs, in->n_public_inputs, pi_hash.data());
@@ -797,6 +927,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
                                     in->quotient_degree_factor, d_pp, &pp_flag);
             d_zs = d_pp;
         }
+        maybe_inject_fault(comm, 2);
         PolynomialBatch zs_pp = PolynomialBatch::from_values(ctx, d_zs, in->n_zs_partial_products, log_n, false, comm);
         zs_pp.merkle_cap(caps_out + cap_words, comm);
         // the flag of the partial products arrived with the cap (one round trip instead of two)
@@ -821,6 +952,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
                                         gammas.data(), alphas.data(), nc, in->quotient_degree_factor, d_gate, d_q, comm, overlapped ? &gw : nullptr);
             d_quot = d_q;
         }
+        maybe_inject_fault(comm, 3);
         PolynomialBatch quotient = PolynomialBatch::from_coeffs(ctx, d_quot, in->n_quotient, log_n, false, comm);
         quotient.merkle_cap(caps_out + 2 * cap_words, comm);
         challenger.observe_cap(caps_out + 2 * cap_words, cap_words / 4);
@@ -885,7 +1017,33 @@ int vpbs_prove_step(vpbs_ctx* ctx, const vpbs_step_inputs* in, uint64_t* caps_ou
 int vpbs_prove_step_sharded(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, uint64_t* caps_out, uint64_t* openings_out,
                             uint64_t* fri_out, vpbs_challenger_state* challenger_out, uint64_t* challenges_out) {
     if (!comm) return VPBS_ERR_INVALID;
-    return prove_step_impl(ctx, in, comm, caps_out, openings_out, fri_out, challenger_out, challenges_out);
+    if (comm->world == 1) return prove_step_impl(ctx, in, nullptr, caps_out, openings_out, fri_out, challenger_out, challenges_out);
+    return prove_step_sharded_impl(ctx, in, comm, caps_out, openings_out, fri_out, challenger_out, challenges_out);
+}
+
+int vpbs_prove_step_sharded_fail(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs_comm* comm, int status) {
+    if (!ctx || !in || !in->constants_sigmas || !comm || comm->world == 0 || comm->rank >= comm->world) return VPBS_ERR_INVALID;
+    if (comm->world == 1) return VPBS_OK;
+    if (!comm->allgather || !comm->allreduce_sum) return VPBS_ERR_INVALID;
+    size_t cap_local, quot_dev, query_words;
+    shard_plan_sizes(ctx, in, comm->world, cap_local, quot_dev, query_words);
+    ShardSession session(comm, cap_local, quot_dev, query_words);
+    session.finish(status ? status : VPBS_ERR_INVALID);
+    return session.broken ? VPBS_ERR_DEVICE : VPBS_OK;
+}
+
+int vpbs_comm_allgather_checked(const vpbs_comm* comm, const uint64_t* local, size_t local_words, uint64_t* full, int local_status) {
+    if (!comm || !comm->allgather || comm->world == 0 || !full || (!local && local_words)) return VPBS_ERR_INVALID;
+    std::vector<u64> a(local_words + 1, 0), b((size_t)comm->world * (local_words + 1), 0);
+    if (local && !local_status) std::memcpy(a.data(), local, 8 * local_words);
+    a[local_words] = local_status ? 1 : 0;
+    if (comm->allgather(comm->user, a.data(), local_words + 1, b.data()) != 0) return VPBS_ERR_DEVICE;
+    bool peer = false;
+    for (unsigned r = 0; r < comm->world; ++r) {
+        std::memcpy(full + (size_t)r * local_words, b.data() + (size_t)r * (local_words + 1), 8 * local_words);
+        if (r != comm->rank && b[(size_t)r * (local_words + 1) + local_words]) peer = true;
+    }
+    return local_status ? local_status : (peer ? VPBS_ERR_PEER : VPBS_OK);
 }
 
 // ProofWithPublicInputs::to_bytes (util/serialization): caps, OpeningSet, FriProof, then public inputs

@@ -11,6 +11,20 @@ This module is pure index arithmetic + one torch.distributed all_gather; the com
 import numpy as np
 
 
+def group_timeout():
+    """The timeout a host gives its torch.distributed process group (and the library's RCCL communicator takes from the same variable):
+    VPBS_COMM_TIMEOUT_S seconds, default 60.  The status words of the sharded step make every rank leave a failed step by itself; the timeout is
+    the backstop for a peer PROCESS that died -- the survivors then fail instead of waiting for ever, and exit non-zero (a process that has
+    touched the GPU is never restarted in place)."""
+    import datetime
+    import os
+    try:
+        s = float(os.environ.get("VPBS_COMM_TIMEOUT_S", "60"))
+    except ValueError:
+        s = 60.0
+    return datetime.timedelta(seconds=s if s > 0 else 60.0)
+
+
 def brev(x, bits):
     r = 0
     for _ in range(bits):
