@@ -268,6 +268,56 @@ def run_chain_native(ctx, ivc, d, N, n_lwe, log_n, steps, seed, message, start, 
             "proof_bytes": len(blob), "verify_ms": 1e3 * t_verify, "message": message, "decrypted": decrypted, "keygen_s": t_keys}
 
 
+class CpuByRole:
+    """VPBS_CPU_BY_ROLE=1: CPU time of this process by thread role while the chains run -- /proc/self/task/*/stat sampled twice a second (threads
+    come and go), the library names its threads (vpbs-early-pool, vpbs-late-pool, vpbs-hash, vpbs-early, vpbs-upload, vpbs-late-ahead,
+    vpbs-batcher, vpbs-stager), the chains' calling threads are named vpbs-chain here, everything else keeps its own name (HIP runtime
+    threads, python).  What a rank's share of the host CPUs is spent on: VERDICT r03 next 7."""
+
+    def __init__(self):
+        import threading
+        self.seen, self.base, self.stop = {}, {}, threading.Event()
+        self.hz = os.sysconf("SC_CLK_TCK")
+        self.sample(self.base)
+        self.thread = threading.Thread(target=self.loop, daemon=True)
+        self.thread.start()
+
+    def sample(self, into):
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open("/proc/self/task/%s/stat" % tid).read()
+            except OSError:
+                continue
+            name = raw[raw.index("(") + 1:raw.rindex(")")]
+            f = raw[raw.rindex(")") + 2:].split()
+            into[tid] = (name, (int(f[11]) + int(f[12])) / self.hz)      # utime + stime, seconds
+
+    def loop(self):
+        while not self.stop.wait(0.5):
+            self.sample(self.seen)
+
+    def report(self, steps_total):
+        self.stop.set()
+        self.thread.join()
+        self.sample(self.seen)
+        by_role = {}
+        for tid, (name, secs) in self.seen.items():
+            secs -= self.base.get(tid, (name, 0.0))[1] if self.base.get(tid, (None,))[0] == name else 0.0
+            by_role[name] = by_role.get(name, 0.0) + secs
+        total = sum(by_role.values())
+        return {"cpu_seconds_total": round(total, 3), "cpu_ms_per_chained_step": round(1e3 * total / max(1, steps_total), 3),
+                "cpu_ms_per_chained_step_by_role": {k: round(1e3 * v / max(1, steps_total), 3) for k, v in sorted(by_role.items(), key=lambda kv: -kv[1])
+                                                    if v > 0}}
+
+
+def name_this_thread(name):
+    import ctypes
+    try:
+        ctypes.CDLL(None).prctl(15, name.encode(), 0, 0, 0)      # PR_SET_NAME
+    except Exception:
+        pass
+
+
 def main():
     import threading
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -323,6 +373,7 @@ def main():
 
     def chain_thread(ci):
         try:
+            name_this_thread("vpbs-chain")
             torch.cuda.set_device(device)
             ctx, cyc, dum = chains[ci]
             if native_driver:
@@ -333,6 +384,7 @@ def main():
             errors.append(e)
             start.abort()
 
+    cpu_by_role = CpuByRole() if os.environ.get("VPBS_CPU_BY_ROLE", "") not in ("", "0") else None
     t_all = time.perf_counter()
     threads = [threading.Thread(target=chain_thread, args=(ci,)) for ci in range(1, n_chains)]
     for th in threads:
@@ -341,6 +393,7 @@ def main():
     for th in threads:
         th.join()
     t_all = time.perf_counter() - t_all
+    cpu_report = cpu_by_role.report(steps * n_chains) if cpu_by_role else None   # (includes each chain's verification after its clock)
     if errors:
         raise errors[0]
     ctx, cyc, dum = chains[0]
@@ -374,6 +427,7 @@ def main():
         "proof_bytes": r0["proof_bytes"], "verify_last_proof_ms": r0["verify_ms"], "message": r0["message"], "decrypted": r0["decrypted"],
         "other_chains": [{k: r[k] for k in ("seconds", "message", "decrypted")} for r in results[1:]],
         "before_the_clock": {"circuit_files_commit_plan_s": t_setup, "seeded_keygen_s": r0["keygen_s"]},
+        "cpu_by_role": cpu_report,
         "checks": "final proof serialised, parsed back and verified by vpbs_verify_step (full check); its public inputs carry the test vector, "
                   "counter = number of steps, the circuit's own verifier data, the native accumulator and both native chain hashes"
                   + ("; the bootstrapped ciphertext decrypts to the message" if steps == total else "")}))

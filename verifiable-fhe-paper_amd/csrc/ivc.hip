@@ -21,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,6 +32,8 @@ namespace {
 using u64 = uint64_t;
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// the role of a thread in /proc/<pid>/task/*/comm: CPU time by role is how a host sizes a rank's CPU share (tools/prove_ivc.py VPBS_CPU_BY_ROLE)
+void name_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }
 
 struct Side {   // one circuit on the context
     vpbs_ctx* ctx = nullptr;
@@ -154,7 +157,10 @@ struct LateAhead {
     }
     void start(const vpbs_witness_plan* p) {
         plan = p;
-        th = std::thread([this] { run(); });
+        th = std::thread([this] {
+            name_thread("vpbs-late-ahead");
+            run();
+        });
     }
     bool active() const { return st != nullptr; }
     void begin(vpbs_witness_state* state, u64* vals, const u64* proof_words) {   // proving thread, nothing posted yet
@@ -506,6 +512,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     double t_early = 0;
     // thread H: the two hash chains of verify_hash_output (:64-78), h_s = hash_no_pad(h_{s-1} || item_s), one permutation after the other
     std::thread hasher([&] {
+        name_thread("vpbs-hash");
         std::vector<u64> in(4 + ggsw_len), in2(5);
         u64 hb[4] = {0, 0, 0, 0}, hl[4] = {0, 0, 0, 0};
         for (unsigned s = 0; s < steps && !failed; ++s) {
@@ -528,6 +535,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     // thread B: batch b = steps [b B, (b + 1) B) on device object b & 1, once their public inputs exist and the object's previous batch is consumed
     const unsigned n_batches = (steps + B - 1) / B;
     std::thread batcher([&] {
+        name_thread("vpbs-batcher");
         for (unsigned b = 0; b < n_batches && !failed; ++b) {
             const unsigned first = b * B, cnt = std::min(B, steps - first);
             {
@@ -575,6 +583,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
         }
     } states;
     std::thread stager([&] {
+        name_thread("vpbs-stager");
         if (v->dw_late) return;   // the caller runs the late phase on the device object itself and gathers afterwards
         for (unsigned s = 0; s < steps && !failed; ++s) {
             const unsigned b = s / B, k = s % vpbs_ivc::NBUF;
@@ -836,6 +845,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         cv.notify_all();
     };
     std::thread early([&] {
+        name_thread("vpbs-early");
         std::vector<u64> pis_prev(base_pis);
         char e2[256];
         for (unsigned s = 0; s < steps && !failed; ++s) {
@@ -875,6 +885,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         }
     });
     std::thread uploader([&] {
+        name_thread("vpbs-upload");
         for (unsigned s = 0; s < steps; ++s) {
             Ready r;
             {

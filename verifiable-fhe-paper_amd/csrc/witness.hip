@@ -1029,7 +1029,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
     if (threads > 1) {
         {
             std::lock_guard<std::mutex> lk(p.pool_mutex);
-            if (!p.pool[ph]) p.pool[ph].reset(new LevelPool(threads));   // the phase's pool keeps the size of its first run
+            if (!p.pool[ph]) p.pool[ph].reset(new LevelPool(threads, ph ? "vpbs-late-pool" : "vpbs-early-pool"));   // the phase's pool keeps the size of its first run
             pool = p.pool[ph].get();
         }
         busy = std::unique_lock<std::mutex>(pool->busy, std::try_to_lock);
@@ -1149,7 +1149,7 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
     if (!lanes.empty()) {
         {
             std::lock_guard<std::mutex> lk(p.pool_mutex);
-            if (!p.lane_pool[ph]) p.lane_pool[ph].reset(new LevelPool((unsigned)lanes.size() + 1));
+            if (!p.lane_pool[ph]) p.lane_pool[ph].reset(new LevelPool((unsigned)lanes.size() + 1, ph ? "vpbs-late-lane" : "vpbs-early-lane"));
             lane_pool = p.lane_pool[ph].get();
         }
         lane_busy = std::unique_lock<std::mutex>(lane_pool->busy, std::try_to_lock);

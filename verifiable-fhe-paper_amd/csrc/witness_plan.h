@@ -28,8 +28,12 @@ template <class Pred> void spin_until(Pred ready) {
 struct LevelPool {
     const unsigned threads;                       // including the calling thread (number 0)
     std::mutex busy;
-    explicit LevelPool(unsigned n) : threads(std::max(1u, n)) {
-        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([this, t] { work(t); });
+    explicit LevelPool(unsigned n, const char* role = "vpbs-pool") : threads(std::max(1u, n)) {
+        for (unsigned t = 1; t < threads; ++t)
+            workers.emplace_back([this, t, role] {
+                (void)pthread_setname_np(pthread_self(), role);   // CPU time by role: /proc/<pid>/task/*/comm
+                work(t);
+            });
         place_near_caller();
     }
     ~LevelPool() {
