@@ -1,5 +1,6 @@
 // extern "C" surface: context, PolynomialBatch handles, kernel-level hooks.  See include/vpbs_prover.h for the
 // plonky2 function each entry point replaces.
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +39,7 @@ void vpbs_ctx::release(void* p) {
     if (it != block_size.end()) free_blocks.emplace(it->second, p);  // unknown pointers are ignored, never thrown on
 }
 void vpbs_ctx::trim() {
-    (void)hipStreamSynchronize(stream);
+    (void)vpbs::stream_sync(stream);
     for (auto& kv : free_blocks) {
         pool_bytes -= kv.first;
         block_size.erase(kv.second);
@@ -46,6 +47,46 @@ void vpbs_ctx::trim() {
     }
     free_blocks.clear();
 }
+namespace vpbs {
+std::atomic<int> g_blocking_sync{-1};   // vpbs_host_set_blocking_sync: -1 = not set (environment, then AUTO)
+std::atomic<int> g_blocking_auto{-1};   // AUTO's answer, computed once per CPU budget (vpbs_host_set_cpu_budget resets it)
+int blocking_sync_mode() {
+    const int m = g_blocking_sync.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    static const int from_env = [] {
+        const char* e = getenv("VPBS_BLOCKING_SYNC");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    if (from_env >= 0) return from_env;
+    int a = g_blocking_auto.load(std::memory_order_relaxed);
+    if (a < 0) {
+        a = vpbs_host_cpu_budget() < 8 ? 1 : 0;   // AUTO: a process with few CPUs cannot afford a spinning thread per chain
+        g_blocking_auto.store(a, std::memory_order_relaxed);
+    }
+    return a;
+}
+void blocking_sync_budget_changed() { g_blocking_auto.store(-1, std::memory_order_relaxed); }
+hipError_t stream_sync(hipStream_t s) {
+    if (!blocking_sync_mode()) return hipStreamSynchronize(s);
+    // one blocking event per host thread and device (events belong to the device that was current when they were made)
+    constexpr int MAX_DEV = 16;
+    static thread_local hipEvent_t ev[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return hipStreamSynchronize(s);
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+        ev[dev] = nullptr;
+        return hipStreamSynchronize(s);
+    }
+    const hipError_t rc = hipEventRecord(ev[dev], s);
+    return rc != hipSuccess ? rc : hipEventSynchronize(ev[dev]);
+}
+}  // namespace vpbs
+
+extern "C" int vpbs_host_set_blocking_sync(int on) {
+    vpbs::g_blocking_sync.store(on < 0 ? -1 : (on ? 1 : 0));
+    return vpbs::blocking_sync_mode();
+}
+
 static double trace_now_us() {
     static const auto t0 = std::chrono::steady_clock::now();
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -74,11 +115,11 @@ void vpbs_ctx::d2h_sync(void* dst, const void* d_src, size_t bytes) {
     ensure_pinned();
     if (pinned && bytes <= pinned_bytes) {
         VPBS_HIP(hipMemcpyAsync(pinned, d_src, bytes, hipMemcpyDeviceToHost, stream));
-        VPBS_HIP(hipStreamSynchronize(stream));
+        VPBS_HIP(vpbs::stream_sync(stream));
         std::memcpy(dst, pinned, bytes);
     } else {
         VPBS_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
-        VPBS_HIP(hipStreamSynchronize(stream));
+        VPBS_HIP(vpbs::stream_sync(stream));
     }
 }
 void vpbs_ctx::ensure_gate_lanes() {
@@ -105,7 +146,7 @@ const u64* vpbs_ctx::ring_table(unsigned log_n_ring) {
     if (vpbs_ntt_params(log_n_ring, h.data(), h.data() + n, &ninv) != 0) throw DeviceError{VPBS_ERR_INVALID, "unsupported ring dimension"};
     u64* t = alloc_words(2 * n);
     VPBS_HIP(hipMemcpyAsync(t, h.data(), sizeof(u64) * 2 * n, hipMemcpyHostToDevice, stream));
-    VPBS_HIP(hipStreamSynchronize(stream));
+    VPBS_HIP(vpbs::stream_sync(stream));
     ring_tables[log_n_ring] = t;
     return t;
 }
@@ -144,7 +185,7 @@ hipEvent_t vpbs_ctx::get_event() {
 }
 void vpbs_ctx::resolve_timing() {
     if (pending.empty()) return;
-    (void)hipStreamSynchronize(stream);
+    (void)vpbs::stream_sync(stream);
     for (auto& p : pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
@@ -264,7 +305,7 @@ struct DevTemp {
         }
     }
     ~DevTemp() {
-        (void)hipStreamSynchronize(c->stream);
+        (void)vpbs::stream_sync(c->stream);
         c->release(p);
     }
 };
@@ -295,7 +336,7 @@ int vpbs_ctx_create(int device_ordinal, unsigned log_n_max, unsigned rate_bits, 
 void vpbs_ctx_destroy(vpbs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)vpbs::stream_sync(c->stream);
     if (c->d_clock_samples) c->release(c->d_clock_samples);
     for (auto& kv : c->root_tables) c->release(kv.second);
     for (auto& kv : c->prescale_tables) c->release(kv.second);
@@ -310,7 +351,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     if (c->gate_fork) (void)hipEventDestroy(c->gate_fork);
     for (auto e : c->gate_join)
         if (e) (void)hipEventDestroy(e);
-    (void)hipStreamSynchronize(c->upload_stream);
+    (void)vpbs::stream_sync(c->upload_stream);
     (void)hipStreamDestroy(c->upload_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -350,7 +391,7 @@ int vpbs_ctx_get_option(const vpbs_ctx* c, int option, uint64_t* out) {
 }
 const char* vpbs_last_error(const vpbs_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int vpbs_ctx_synchronize(vpbs_ctx* c) {
-    return guarded(c, [&] { VPBS_HIP(hipStreamSynchronize(c->stream)); });
+    return guarded(c, [&] { VPBS_HIP(vpbs::stream_sync(c->stream)); });
 }
 void* vpbs_ctx_stream(vpbs_ctx* c) { return c ? (void*)c->stream : nullptr; }
 // the switch table (include/vpbs_prover.h): defaults = plonky2 0.2.0 as restated
@@ -476,7 +517,7 @@ int vpbs_batch_coeffs(vpbs_batch* b, uint64_t* out) {
     if (!b || !out) return VPBS_ERR_INVALID;
     return guarded(b->ctx, [&] {
         VPBS_HIP(hipMemcpyAsync(out, b->d_coeffs, sizeof(u64) * b->ncols * b->n(), hipMemcpyDeviceToHost, b->ctx->stream));
-        VPBS_HIP(hipStreamSynchronize(b->ctx->stream));
+        VPBS_HIP(vpbs::stream_sync(b->ctx->stream));
     });
 }
 
@@ -509,7 +550,7 @@ int vpbs_batch_lde_rows(vpbs_batch* b, size_t row_start, size_t nrows, size_t st
             }
             VPBS_HIP(hipMemcpyAsync(d_args, &a, sizeof a, hipMemcpyHostToDevice, c->stream));
             vpbs::launch_open_queries(c->stream, d_args, 1, cnt, d_out + done * b->ncols);
-            VPBS_HIP(hipStreamSynchronize(c->stream));
+            VPBS_HIP(vpbs::stream_sync(c->stream));
         }
         VPBS_HIP(hipMemcpy(out, d_out, sizeof(u64) * nrows * b->ncols, hipMemcpyDeviceToHost));
         c->release(d_out);
@@ -529,7 +570,7 @@ int vpbs_batch_eval_ext(vpbs_batch* b, const uint64_t zeta[2], uint64_t* out) {
         vpbs::launch_ext_powers(c->stream, &zp, 1, n, zpow);
         vpbs::launch_eval_ext(c->stream, b->d_coeffs, b->ncols, n, n, zpow, d_out);
         VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * 2 * b->ncols, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
         c->release(zpow);
         c->release(d_out);
     });
@@ -562,7 +603,7 @@ int vpbs_batch_open(vpbs_batch* b, size_t leaf_index, uint64_t* leaf_out, uint64
         vpbs::launch_open_queries(c->stream, d_args, 1, 1, d_out);
         std::vector<u64> rec(a.record_words);
         VPBS_HIP(hipMemcpyAsync(rec.data(), d_out, sizeof(u64) * a.record_words, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
         std::memcpy(leaf_out, rec.data(), sizeof(u64) * b->ncols);
         std::memcpy(siblings_out, rec.data() + b->ncols, sizeof(u64) * 4 * t.n_siblings);
         c->release(d_out);
@@ -577,7 +618,7 @@ int vpbs_k_poseidon_batch(vpbs_ctx* c, uint64_t* states, size_t n) {
         DevTemp d(c, states, 12 * n);
         vpbs::launch_permute_batch(c->stream, d.p, n);
         VPBS_HIP(hipMemcpyAsync(states, d.p, sizeof(u64) * 12 * n, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 int vpbs_k_hash_rows(vpbs_ctx* c, const uint64_t* rows, size_t n, unsigned len, uint64_t* out) {
@@ -587,7 +628,7 @@ int vpbs_k_hash_rows(vpbs_ctx* c, const uint64_t* rows, size_t n, unsigned len, 
         DevTemp o(c, nullptr, 4 * n);
         vpbs::launch_hash_rows(c->stream, d.p, n, len, o.p);
         VPBS_HIP(hipMemcpyAsync(out, o.p, sizeof(u64) * 4 * n, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 int vpbs_k_intt(vpbs_ctx* c, const uint64_t* values, unsigned ncols, unsigned log_n, uint64_t* coeffs_out) {
@@ -597,7 +638,7 @@ int vpbs_k_intt(vpbs_ctx* c, const uint64_t* values, unsigned ncols, unsigned lo
         DevTemp in(c, values, words), out(c, nullptr, words), scratch(c, nullptr, words);
         vpbs::launch_intt(c->stream, in.p, out.p, scratch.p, c->roots(log_n, true), ncols, log_n);
         VPBS_HIP(hipMemcpyAsync(coeffs_out, out.p, sizeof(u64) * words, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 int vpbs_k_coset_lde(vpbs_ctx* c, const uint64_t* coeffs, unsigned ncols, unsigned log_n, unsigned rate_bits, uint64_t shift,
@@ -609,7 +650,7 @@ int vpbs_k_coset_lde(vpbs_ctx* c, const uint64_t* coeffs, unsigned ncols, unsign
         vpbs::launch_coset_lde(c->stream, in.p, out.p, c->roots(log_n, false), c->prescale(log_n, rate_bits, shift), ncols, log_n,
                                rate_bits);
         VPBS_HIP(hipMemcpyAsync(out_host, out.p, sizeof(u64) * (words << rate_bits), hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 int vpbs_k_merkle_cap(vpbs_ctx* c, const uint64_t* leaves, size_t n_leaves, unsigned leaf_len, unsigned cap_height, uint64_t* cap_out) {
@@ -624,13 +665,13 @@ int vpbs_k_merkle_cap(vpbs_ctx* c, const uint64_t* leaves, size_t n_leaves, unsi
             for (size_t i = 0; i < n_leaves; ++i)
                 for (unsigned k = 0; k < leaf_len; ++k) padded[4 * i + k] = leaves[i * leaf_len + k];
             VPBS_HIP(hipMemcpyAsync(dig.p, padded.data(), sizeof(u64) * 4 * n_leaves, hipMemcpyHostToDevice, c->stream));
-            VPBS_HIP(hipStreamSynchronize(c->stream));
+            VPBS_HIP(vpbs::stream_sync(c->stream));
         } else {
             vpbs::launch_hash_rows(c->stream, in.p, n_leaves, leaf_len, dig.p);
         }
         vpbs::launch_merkle_tree(c->stream, c->tune, dig.p, off.data(), (unsigned)off.size(), n_leaves);
         VPBS_HIP(hipMemcpyAsync(cap_out, dig.p + off.back(), sizeof(u64) * ((size_t)4 << cap_height), hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 
@@ -657,7 +698,7 @@ int vpbs_k_negacyclic_ntt(vpbs_ctx* c, uint64_t* data, unsigned batch, unsigned 
         DevTemp tab(c, inverse ? inv.data() : roots.data(), n), d(c, data, batch * n);
         vpbs::launch_negacyclic(c->stream, d.p, tab.p, batch, log_n, inverse != 0, ninv);
         VPBS_HIP(hipMemcpyAsync(data, d.p, sizeof(u64) * batch * n, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 
@@ -680,7 +721,7 @@ int vpbs_blind_rotate_step(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigned ba
             vpbs_ctx* c;
             std::vector<void*>& v;
             ~Cleanup() {
-                (void)hipStreamSynchronize(c->stream);
+                (void)vpbs::stream_sync(c->stream);
                 for (void* p : v) c->release(p);
             }
         } cleanup{c, tmp};
@@ -707,7 +748,7 @@ int vpbs_blind_rotate_step(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigned ba
         VPBS_HIP(hipGetLastError());
         if (!on_device) {
             VPBS_HIP(hipMemcpyAsync(acc_out, d_out, sizeof(u64) * acc_words, hipMemcpyDeviceToHost, c->stream));
-            VPBS_HIP(hipStreamSynchronize(c->stream));
+            VPBS_HIP(vpbs::stream_sync(c->stream));
         }
     });
 }
@@ -743,7 +784,7 @@ int vpbs_pbs_accumulator_chain(vpbs_ctx* c, const vpbs_tfhe_params* prm, unsigne
         }
         VPBS_HIP(hipGetLastError());
         VPBS_HIP(hipMemcpyAsync(accs_out, accs.p + acc_words, sizeof(u64) * (size_t)(n_lwe + 2) * acc_words, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 
@@ -763,7 +804,7 @@ int vpbs_device_upload(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, s
     if (!c || !d_dst || !host_src) return VPBS_ERR_INVALID;
     return guarded(c, [&] {
         VPBS_HIP(hipMemcpyAsync(d_dst, host_src, sizeof(u64) * words, hipMemcpyHostToDevice, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 int vpbs_device_upload_bg(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, size_t words) {
@@ -771,7 +812,7 @@ int vpbs_device_upload_bg(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src
     if (!c || !d_dst || !host_src) return VPBS_ERR_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return VPBS_ERR_DEVICE;
     if (hipMemcpyAsync(d_dst, host_src, sizeof(u64) * words, hipMemcpyHostToDevice, c->upload_stream) != hipSuccess) return VPBS_ERR_DEVICE;
-    return hipStreamSynchronize(c->upload_stream) == hipSuccess ? VPBS_OK : VPBS_ERR_DEVICE;
+    return vpbs::stream_sync(c->upload_stream) == hipSuccess ? VPBS_OK : VPBS_ERR_DEVICE;
 }
 int vpbs_device_upload_rows(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_src, unsigned n_cols, size_t n, size_t row_lo, size_t row_hi) {
     if (!c || !d_dst || !host_src || row_lo > row_hi || row_hi > n) return VPBS_ERR_INVALID;
@@ -779,7 +820,7 @@ int vpbs_device_upload_rows(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* host_s
     return guarded(c, [&] {
         VPBS_HIP(hipMemcpy2DAsync(d_dst + row_lo, n * sizeof(u64), host_src + row_lo, n * sizeof(u64), (row_hi - row_lo) * sizeof(u64), n_cols,
                                   hipMemcpyHostToDevice, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 namespace {
@@ -798,12 +839,12 @@ int vpbs_device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_position
         hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d_dst,
                            reinterpret_cast<const uint32_t*>(d_positions), d_stage, count);
         VPBS_HIP(hipGetLastError());
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
     });
 }
 void vpbs_device_free(vpbs_ctx* c, uint64_t* d_ptr) {
     if (c && d_ptr) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)vpbs::stream_sync(c->stream);
         c->release(d_ptr);
     }
 }

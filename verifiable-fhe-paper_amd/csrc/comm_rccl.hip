@@ -229,7 +229,7 @@ int vpbs_comm_rccl_create(vpbs_ctx* ctx, const uint8_t unique_id[128], unsigned 
 void vpbs_comm_rccl_destroy(vpbs_comm* comm) {
     if (!comm || !comm->user || comm->allgather != &allgather_host) return;
     auto* c = static_cast<RcclComm*>(comm->user);
-    if (!c->dead) (void)hipStreamSynchronize(c->ctx->stream);
+    if (!c->dead) (void)vpbs::stream_sync(c->ctx->stream);
     if (Rccl* r = rccl(); r && c->comm) r->comm_destroy(c->comm);   // an aborted communicator is gone already
     c->ctx->release(c->d_small);
     if (c->d_stage_local) c->ctx->release(c->d_stage_local);

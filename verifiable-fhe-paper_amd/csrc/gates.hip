@@ -837,7 +837,7 @@ unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* w
                 hipLaunchKernelGGL((gate_tile_kernel<4>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof);
             if (trace) {
                 unsigned long long h[TILE_MAX_UNITS];
-                (void)hipStreamSynchronize(s);
+                (void)vpbs::stream_sync(s);
                 (void)hipMemcpy(h, prof, sizeof h, hipMemcpyDeviceToHost);
                 (void)hipFree(prof);
                 for (unsigned w = 0; w < TILE_WAVES; ++w) {

@@ -112,7 +112,7 @@ struct DevBuf {
     u64* p;
     DevBuf(vpbs_ctx* ctx, size_t words) : c(ctx), p(ctx->alloc_words(words)) {}
     ~DevBuf() {
-        (void)hipStreamSynchronize(c->stream);
+        (void)vpbs::stream_sync(c->stream);
         c->release(p);
     }
 };
@@ -185,9 +185,9 @@ int vpbs_keygen(vpbs_ctx* c, const vpbs_keygen_params* k, uint64_t* s_lwe, uint6
                 hipLaunchKernelGGL(ggsw_body_kernel, dim3((unsigned)((n_glwe * n + 255) / 256)), dim3(256), 0, c->stream, log_n, K, n_glwe, d_key.p, d_out);
                 VPBS_HIP(hipGetLastError());
                 if (!keys_on_device) VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * words, hipMemcpyDeviceToHost, c->stream));
-                VPBS_HIP(hipStreamSynchronize(c->stream));
+                VPBS_HIP(vpbs::stream_sync(c->stream));
             } catch (...) {
-                (void)hipStreamSynchronize(c->stream);
+                (void)vpbs::stream_sync(c->stream);
                 if (!keys_on_device) c->release(d_out);
                 throw;
             }
@@ -251,7 +251,7 @@ int vpbs_glwe_decrypt(vpbs_ctx* c, unsigned log_N, unsigned K, const uint64_t* s
         launch_negacyclic(c->stream, prod.p, tab + n, 1, log_N, true, ninv);
         std::vector<u64> mask(n);
         VPBS_HIP(hipMemcpyAsync(mask.data(), prod.p, sizeof(u64) * n, hipMemcpyDeviceToHost, c->stream));
-        VPBS_HIP(hipStreamSynchronize(c->stream));
+        VPBS_HIP(vpbs::stream_sync(c->stream));
         for (size_t i = 0; i < n; ++i) m_out[i] = gl::sub(ct[(size_t)(K - 1) * n + i], mask[i]);
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {

@@ -110,7 +110,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         vpbs_ctx* c;
         std::vector<void*>& v;
         ~Cleanup() {
-            (void)hipStreamSynchronize(c->stream);
+            (void)vpbs::stream_sync(c->stream);
             for (void* p : v) c->release(p);
         }
     } cleanup{ctx, scratch};
@@ -389,7 +389,7 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
             vpbs::launch_sum_planes(ctx->stream, planes, n_planes, (size_t)nc * len, d_out);
             VPBS_HIP(hipGetLastError());
         } catch (...) {
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)vpbs::stream_sync(ctx->stream);
             ctx->release(d_apow);
             if (planes) ctx->release(planes);
             throw;
@@ -413,9 +413,9 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
                                 use_lanes ? &lanes : nullptr);
         VPBS_HIP(hipGetLastError());
     } catch (...) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)vpbs::stream_sync(ctx->stream);
         for (auto st : ctx->gate_streams)
-            if (st) (void)hipStreamSynchronize(st);
+            if (st) (void)vpbs::stream_sync(st);
         ctx->release(d_apow);
         if (lane_buf) ctx->release(lane_buf);
         throw;
@@ -549,7 +549,7 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
         }
         if (world > 1) {
             // every rank needs all 8n values for the (cheap, replicated) inverse transform: device all-gather, 16 B per point
-            VPBS_HIP(hipStreamSynchronize(s));
+            VPBS_HIP(vpbs::stream_sync(s));
             if (comm->allgather_dev(comm->user, (size_t)nc * local_len) != 0) throw DeviceError{VPBS_ERR_DEVICE, "quotient all-gather failed"};
             gathered = comm->d_stage_full;
         }
@@ -559,11 +559,11 @@ void quotient_permutation_device(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_const
                                          rate_bits, nc, q_nat, q_leaf, d_out);
         }
         VPBS_HIP(hipGetLastError());
-        if (world > 1) VPBS_HIP(hipStreamSynchronize(s));  // the staging buffers belong to the communicator: done with them
+        if (world > 1) VPBS_HIP(vpbs::stream_sync(s));  // the staging buffers belong to the communicator: done with them
     } catch (...) {
-        (void)hipStreamSynchronize(s);
+        (void)vpbs::stream_sync(s);
         for (auto st : ctx->gate_streams)
-            if (st) (void)hipStreamSynchronize(st);
+            if (st) (void)vpbs::stream_sync(st);
         ctx->release(d_apow); ctx->release(q_leaf); ctx->release(q_nat);
         if (d_gpow) ctx->release(d_gpow);
         if (lane_buf) ctx->release(lane_buf);
@@ -664,7 +664,7 @@ int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* 
             vpbs_ctx* c;
             std::vector<void*>& v;
             ~Cleanup() {
-                (void)hipStreamSynchronize(c->stream);
+                (void)vpbs::stream_sync(c->stream);
                 for (void* p : v) c->release(p);
             }
         } cleanup{ctx, tmp};
@@ -685,7 +685,7 @@ int vpbs_partial_products(vpbs_ctx* ctx, const uint64_t* wires, const uint64_t* 
         partial_products_device(ctx, d_w, d_s, n_routed, log_n, betas, gammas, num_challenges, max_degree, d_o);
         if (!on_device) {
             VPBS_HIP(hipMemcpyAsync(out, d_o, sizeof(u64) * out_words, hipMemcpyDeviceToHost, ctx->stream));
-            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+            VPBS_HIP(vpbs::stream_sync(ctx->stream));
         }
     });
 }
@@ -704,9 +704,9 @@ int vpbs_quotient_permutation(vpbs_ctx* ctx, vpbs_batch* cs, unsigned n_constant
         try {
             quotient_permutation_device(ctx, cs, n_constants, wires, zs_pp, n_routed, betas, gammas, alphas, nc, max_degree, d_gate_terms, d_out);
             VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * words, hipMemcpyDeviceToHost, ctx->stream));
-            VPBS_HIP(hipStreamSynchronize(ctx->stream));
+            VPBS_HIP(vpbs::stream_sync(ctx->stream));
         } catch (...) {
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)vpbs::stream_sync(ctx->stream);
             ctx->release(d_out);
             throw;
         }
@@ -886,7 +886,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
             vpbs_ctx* c;
             std::vector<void*>& v;
             ~Cleanup() {
-                (void)hipStreamSynchronize(c->stream);
+                (void)vpbs::stream_sync(c->stream);
                 for (void* p : v) c->release(p);
             }
         } cleanup{ctx, staged};

@@ -1011,6 +1011,8 @@ struct KindProfile {
 // few field operations) stay on the calling thread.  Generators of one level touch disjoint slots (plan_split), so the slot state needs no
 // locking; a "set twice with different values" report goes through SlotState's mutex.  `after` (may be empty) is one more shared job at
 // the end -- the wires of the phase written into the matrix.
+bool lanes_of_phase_empty(const vpbs_witness_plan& p, int ph) { return p.lane_steps_sorted[ph].empty(); }
+
 // stage: 0 = the whole phase; k > 0 (late phase of a plan split into stages) = the generators of late stage k only.
 // before (may be empty): a shared job in front of the generators (the presets of the stage); keep_awake: leave the pool's workers spinning
 // at the end -- the next stage of this state follows within a fraction of a millisecond (whoever runs it, or frees the state, ends the pool).
@@ -1041,6 +1043,43 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
             err = s.error_text();
             return VPBS_ERR_INVALID;
         }
+#if defined(VPBS_HAVE_POSEIDON_X8)
+        // ... except for the LATE phase where the CPU has AVX-512: its cost is its PoseidonGate rows (3 649 of 31 613 generators of the cyclic
+        // circuit's in-circuit verifier, 1.2 us each one by one), and the rows of one dependency level are independent -- level by level, eight
+        // rows per permutation (0.41 us each): what a rank with ONE CPU for the late phase runs (4.5 -> 2 ms per chained step)
+        if (ph == 1 && poseidon_x8::enabled() && !std::getenv("VPBS_TRACE_WITNESS")) {
+            u32 pending[8];
+            unsigned np = 0;
+            bool ok = true;
+            auto flush = [&] {
+                if (np >= 3) ok = ok && poseidon_rows_x8(p, s, pending, np, err);
+                else
+                    for (unsigned q = 0; q < np; ++q) ok = ok && run_one(p, s, pending[q], mc, err);
+                np = 0;
+            };
+            for (u32 l = 0; l < n_levels && ok; ++l) {
+                for (u32 k = P.level_off[l]; k < P.level_off[l + 1] && ok; ++k) {
+                    const auto& st = p.schedule[P.order[k]];
+                    if (st.row != NO_ROW && p.gates[p.row_gate[st.row]].kind == VPBS_GATE_POSEIDON) {
+                        pending[np++] = P.order[k];
+                        if (np == 8) flush();
+                    } else {
+                        ok = run_one(p, s, P.order[k], mc, err);
+                    }
+                }
+                flush();
+            }
+            if (ok && !lanes_of_phase_empty(p, ph))
+                for (u32 i : p.lane_steps_sorted[ph])
+                    if (!(ok = run_one(p, s, i, mc, err))) break;
+            if (!ok || s.failed()) {
+                if (err.empty()) err = s.error_text();
+                return VPBS_ERR_INVALID;
+            }
+            if (after) after(0, 1);
+            return VPBS_OK;
+        }
+#endif
         KindProfile prof;
         for (size_t i = 0; i < p.schedule.size(); ++i) {
             if (p.step_late[i] != ph || (stage && p.step_stage[i] != stage)) continue;
@@ -1337,6 +1376,7 @@ extern "C" {
 
 int vpbs_host_set_cpu_budget(unsigned cpus) {
     vpbs::g_cpu_budget.store(cpus);
+    vpbs::blocking_sync_budget_changed();
     return VPBS_OK;
 }
 unsigned vpbs_host_cpu_budget(void) { return vpbs::usable_cpus(); }

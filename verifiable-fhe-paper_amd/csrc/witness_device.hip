@@ -421,7 +421,7 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
         d->owned.push_back(d->val);
         d->err = static_cast<unsigned*>(ctx->alloc_bytes(2 * sizeof(unsigned)));   // flags, first conflicting slot + 1
         d->owned.push_back(d->err);
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        VPBS_HIP(vpbs::stream_sync(ctx->stream));
         *out = d.release();
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
@@ -440,7 +440,7 @@ int vpbs_witness_device_create_early(vpbs_ctx* ctx, const vpbs_witness_plan* pla
 void vpbs_witness_device_free(vpbs_witness_device* d) {
     if (!d) return;
     (void)hipSetDevice(d->ctx->device);
-    (void)hipStreamSynchronize(d->ctx->stream);
+    (void)vpbs::stream_sync(d->ctx->stream);
     if (d->graph) (void)hipGraphExecDestroy(d->graph);
     if (d->late_graph) (void)hipGraphExecDestroy(d->late_graph);
     for (void* p : d->owned) d->ctx->release(p);
@@ -512,7 +512,7 @@ void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const 
     if (!walk) VPBS_HIP(hipGraphLaunch(graph, s));
     unsigned report[2] = {0, 0};
     VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
-    VPBS_HIP(hipStreamSynchronize(s));
+    VPBS_HIP(vpbs::stream_sync(s));
     if (d_vals) ctx->release(d_vals);
     d_vals = nullptr;
     throw_on_flags(d, report);
@@ -535,7 +535,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
         if (d_vals) {
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)vpbs::stream_sync(ctx->stream);
             ctx->release(d_vals);
         }
         ctx->err = e.what;
@@ -562,7 +562,7 @@ int vpbs_witness_device_run_late(vpbs_witness_device* d, unsigned instance, cons
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
         if (d_vals) {
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)vpbs::stream_sync(ctx->stream);
             ctx->release(d_vals);
         }
         ctx->err = e.what;
@@ -582,7 +582,7 @@ int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_
         VPBS_HIP(hipMemsetAsync(d_wires, 0, sizeof(u64) * d->plan->total, ctx->stream));
         hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
                            d->batch, instance, d_wires);
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        VPBS_HIP(vpbs::stream_sync(ctx->stream));
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
         ctx->err = e.what;
@@ -605,11 +605,11 @@ int vpbs_witness_device_read_late_inputs(vpbs_witness_device* d, unsigned instan
         hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->late_in, (u32)count, d->batch,
                            instance, d_out);
         VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        VPBS_HIP(vpbs::stream_sync(ctx->stream));
         ctx->release(d_out);
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)vpbs::stream_sync(ctx->stream);
         if (d_out) ctx->release(d_out);
         ctx->err = e.what;
         return e.status;
@@ -645,13 +645,13 @@ int vpbs_witness_device_read(vpbs_witness_device* d, unsigned instance, const ui
         hipLaunchKernelGGL(wd_read_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d_slots, (u32)count, d->batch,
                            instance, d_out);
         VPBS_HIP(hipMemcpyAsync(out, d_out, sizeof(u64) * count, hipMemcpyDeviceToHost, ctx->stream));
-        VPBS_HIP(hipStreamSynchronize(ctx->stream));
+        VPBS_HIP(vpbs::stream_sync(ctx->stream));
         ctx->release(d_slots);
         ctx->release(d_out);
         for (size_t i : missing) out[i] = 0;
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
-        (void)hipStreamSynchronize(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
+        (void)vpbs::stream_sync(ctx->stream);   // nothing may still be using the staging blocks when they go back to the pool
         if (d_slots) ctx->release(d_slots);
         if (d_out) ctx->release(d_out);
         ctx->err = e.what;

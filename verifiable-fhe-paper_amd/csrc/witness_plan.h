@@ -158,7 +158,14 @@ struct LevelPool {
         if ((e && std::atoi(e) == 0) || workers.empty()) return;
         domain = domains().take(threads);
         if (domain < 0) return;   // no cache topology to read, or no domain can hold the pool: the scheduler places the threads
-        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof(cpu_set_t), &domains().all[domain].set);
+        // inside what the process is allowed (a taskset / cpuset mask: the rank's CPU share) -- a pool must not leave it; when the domain and
+        // the mask share fewer CPUs than the pool has threads, the scheduler places them (inside the mask, which the workers inherit)
+        cpu_set_t allowed, both;
+        CPU_ZERO(&both);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+        CPU_AND(&both, &allowed, &domains().all[domain].set);
+        if ((unsigned)CPU_COUNT(&both) < std::min(threads, (unsigned)CPU_COUNT(&allowed))) return;
+        for (auto& w : workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof(cpu_set_t), &both);
     }
     std::vector<std::thread> workers;
     std::mutex m;
