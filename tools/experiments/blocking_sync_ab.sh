@@ -1,16 +1,21 @@
 #!/bin/bash
-# Spinning (hipStreamSynchronize) against blocking waits (vpbs_host_set_blocking_sync) at the CPU shares a rank of an 8-GPU node may get.
+# Spinning (hipStreamSynchronize) against sleeping waits (vpbs_host_set_blocking_sync) at the CPU shares a rank of an 8-GPU node may get
+# (taskset mask = the share; "16" = no mask: the container's 16-CPU quota floating over the host's hardware threads).
 # usage (GPU box): tools/experiments/blocking_sync_ab.sh OUTDIR [steps=200]
 out=${1:-gpurun_out/blocking_ab}; steps=${2:-200}
 mkdir -p "$out"
 run() {   # name cpus chains device_witness blocking
-  VPBS_CPU_BY_ROLE=1 VPBS_BLOCKING_SYNC=$5 VPBS_IVC_CHAINS=$3 VPBS_IVC_DEVICE_WITNESS=$4 taskset -c 0-$(( $2 - 1 )) python tools/prove_ivc.py 1024 728 16 "$steps" > "$out/$1.out" 2>&1
+  local pre=""
+  if [ "$2" != "16" ]; then pre="taskset -c 0-$(( $2 - 1 ))"; fi
+  VPBS_CPU_BY_ROLE=1 VPBS_BLOCKING_SYNC=$5 VPBS_IVC_CHAINS=$3 VPBS_IVC_DEVICE_WITNESS=$4 $pre python tools/prove_ivc.py 1024 728 16 "$steps" > "$out/$1.out" 2>&1
 }
 for rep in 1 2; do
   for b in 0 1; do
     run cpus2_dw_chains4_block${b}_$rep 2 4 64 $b
+    run cpus2_dw_chains6_block${b}_$rep 2 6 64 $b
     run cpus4_dw_chains6_block${b}_$rep 4 6 64 $b
     run cpus16_host_chains6_block${b}_$rep 16 6 0 $b
+    run cpus16_dw_chains6_block${b}_$rep 16 6 64 $b
     run cpus16_host_chains1_block${b}_$rep 16 1 0 $b
   done
 done

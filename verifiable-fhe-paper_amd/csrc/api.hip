@@ -1,6 +1,8 @@
 // extern "C" surface: context, PolynomialBatch handles, kernel-level hooks.  See include/vpbs_prover.h for the
 // plonky2 function each entry point replaces.
 #include <atomic>
+#include <sys/prctl.h>
+#include <time.h>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -68,22 +70,27 @@ int blocking_sync_mode() {
 void blocking_sync_budget_changed() { g_blocking_auto.store(-1, std::memory_order_relaxed); }
 hipError_t stream_sync(hipStream_t s) {
     if (!blocking_sync_mode()) return hipStreamSynchronize(s);
-    // one blocking event per host thread and device (events belong to the device that was current when they were made)
-    constexpr int MAX_DEV = 16;
-    static thread_local hipEvent_t ev[MAX_DEV] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return hipStreamSynchronize(s);
-    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
-        ev[dev] = nullptr;
-        return hipStreamSynchronize(s);
+    // Sleeping wait: poll the stream and give the CPU away in between.  (An event made with hipEventBlockingSync does not do it on this
+    // runtime: measured, the waiting thread still used 100 % of a CPU.)  A short spin first -- most transcript round trips of a step are tens
+    // of microseconds -- then naps of 30 us with the thread's timer slack lowered so that a nap is a nap: a wait ends at most ~50 us late,
+    // eleven times per step proof, which a GPU shared by several chains does not notice.
+    static thread_local bool slack_set = false;
+    if (!slack_set) {
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // 1 us instead of the default 50 us
+        slack_set = true;
     }
-    const hipError_t rc = hipEventRecord(ev[dev], s);
-    return rc != hipSuccess ? rc : hipEventSynchronize(ev[dev]);
+    for (unsigned i = 0;; ++i) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipErrorNotReady) return q;
+        if (i < 64) continue;
+        timespec ts{0, 30000};
+        (void)nanosleep(&ts, nullptr);
+    }
 }
 }  // namespace vpbs
 
 extern "C" int vpbs_host_set_blocking_sync(int on) {
-    vpbs::g_blocking_sync.store(on < 0 ? -1 : (on ? 1 : 0));
+    if (on >= -1) vpbs::g_blocking_sync.store(on < 0 ? -1 : (on ? 1 : 0));   // -2: only ask
     return vpbs::blocking_sync_mode();
 }
 

@@ -34,10 +34,9 @@ struct DeviceError {
 
 namespace vpbs {
 // How a host thread waits for its stream.  hipStreamSynchronize spins: the thread that proves a chain burns a whole CPU while the device
-// works (measured: 53 CPU-ms per chained proof of six chains on 16 CPUs, and with four chains on TWO CPUs the waiting threads alone take both,
-// tools/prove_ivc.py VPBS_CPU_BY_ROLE).  In blocking mode the wait is an event created with hipEventBlockingSync: the thread sleeps until the
-// interrupt.  Process-wide (it is about the CPUs the process has): vpbs_host_set_blocking_sync, default from VPBS_BLOCKING_SYNC, else AUTO --
-// block when the process may use fewer than 8 CPUs.
+// works (measured, VPBS_TRACE_IVC: with four chains on TWO CPUs a proving thread used 16 ms of CPU per proof inside vpbs_prove_step, of which
+// about one is work).  In blocking mode the wait polls hipStreamQuery and sleeps in between.  Process-wide (it is about the CPUs the process
+// has): vpbs_host_set_blocking_sync, default from VPBS_BLOCKING_SYNC, else AUTO -- block when the process may use fewer than 8 CPUs.
 int blocking_sync_mode();                 // 0 spin, 1 block
 hipError_t stream_sync(hipStream_t s);    // drop-in for hipStreamSynchronize
 void blocking_sync_budget_changed();      // the process's CPU budget was set: AUTO decides again

@@ -34,6 +34,11 @@ using u64 = uint64_t;
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // the role of a thread in /proc/<pid>/task/*/comm: CPU time by role is how a host sizes a rank's CPU share (tools/prove_ivc.py VPBS_CPU_BY_ROLE)
 void name_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }
+// CPU seconds the CALLING thread has used (VPBS_TRACE_IVC: what the proving thread burns while it waits for the device)
+double thread_cpu() {
+    timespec ts;
+    return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? ts.tv_sec + 1e-9 * ts.tv_nsec : 0.0;
+}
 
 struct Side {   // one circuit on the context
     vpbs_ctx* ctx = nullptr;
@@ -634,6 +639,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     const double t_base = now() - t0;
     if (v->step_fn) v->step_fn(v->step_user, 0);
     double t_late = 0, t_rows = 0, t_prove = 0, t_wait_staged = 0, t_wait_hashed = 0;
+    double c_late = 0, c_rows = 0, c_prove = 0;   // CPU time of THIS thread in the same sections (VPBS_TRACE_IVC)
     // late stages 1 and 2 of the next step while this step's FRI stage runs (LateAhead); here the prover writes the proof straight into
     // `values`, the array the late phase reads its presets from
     vpbs_witness_state* next_state = nullptr;   // taken from `states` by the hook; declared before the worker (joined first)
@@ -696,6 +702,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             }
         }
         double t = now();
+        double c0 = thread_cpu();
         if (v->dw_late) {
             // the late phase on the device object that holds the step's early values, then ALL its wires into the prover's matrix
             vpbs_witness_device* dev = v->wdev[(s / B) & 1];
@@ -726,11 +733,15 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             if (rc != 0) return stop_step("late witness phase of step " + std::to_string(s) + " (the previous proof does not verify in circuit): " + e, rc);
             t_late += now() - t;
             t = now();
+            c_late += thread_cpu() - c0;
+            c0 = thread_cpu();
             rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
             if (rc != 0) return stop_step(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
             t_rows += now() - t;
+            c_rows += thread_cpu() - c0;
         }
         t = now();
+        c0 = thread_cpu();
         cyc.step_inputs(in, v->d_bufs[k], true, pis.data() + (size_t)(s + 1) * n_pi);
         if (v->staged && !v->dw_late && s + 1 < steps) {
             hook.step = s;
@@ -746,6 +757,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             return stop("step " + std::to_string(s) + ": " + vpbs_last_error(ctx), rc);
         }
         t_prove += now() - t;
+        c_prove += thread_cpu() - c0;
         {
             std::lock_guard<std::mutex> lk(mu);
             consumed = s + 1;
@@ -759,8 +771,10 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     const double seconds = now() - t0;
     if (std::getenv("VPBS_TRACE_IVC"))
         std::fprintf(stderr, "[ivc device witness] per step: waited %.2f ms for the staged wires, %.2f ms for the hash chain; late %.2f, scatter %.2f, "
-                     "prove %.2f, device batch run %.2f ms\n", 1e3 * t_wait_staged / steps, 1e3 * t_wait_hashed / steps, 1e3 * t_late / steps,
-                     1e3 * t_rows / steps, 1e3 * t_prove / steps, 1e3 * t_early / steps);
+                     "prove %.2f, device batch run %.2f ms; CPU time of the proving thread: late %.2f, scatter %.2f, prove %.2f ms (blocking waits: %d)\n",
+                     1e3 * t_wait_staged / steps, 1e3 * t_wait_hashed / steps, 1e3 * t_late / steps,
+                     1e3 * t_rows / steps, 1e3 * t_prove / steps, 1e3 * t_early / steps, 1e3 * c_late / steps, 1e3 * c_rows / steps, 1e3 * c_prove / steps,
+                     vpbs_host_set_blocking_sync(-2));
     const long n_bytes = vpbs_step_proof_to_bytes(ctx, &in, cyc.n_const_cols, caps, openings, fri, proof_out, capacity);
     if (n_bytes <= 0) {
         say("the output buffer is too small for the proof");
