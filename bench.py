@@ -1102,7 +1102,8 @@ def main():
     if args.chains <= 0:
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
         # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most
-        args.chains = (4 if cpus <= 2 else 6) if args.device_witness else max(1, min(6, cpus // 2))
+        # device pipeline: six chains at every share since the waits sleep (2 CPUs: 0.122-0.124 with four chains, 0.127-0.130 with six: profiles/r04_cpu_share.json)
+        args.chains = 6 if args.device_witness else max(1, min(6, cpus // 2))
 
     out, state = None, None
     if args.workload == "ivc":
