@@ -201,6 +201,20 @@ def test_sharded_step_failure_semantics(world):
     assert "SHARDED_FAILURE_OK world=%d" % world in r.stdout
 
 
+def test_hand_scheduled_arithmetic_on_edge_values():
+    """ADVICE r03: the non-canonical-residue paths of the inline-asm products (gl::mul_nc, dot2_nc, mad_nc, add_nn, fold96), of the gate
+    kernels' lazy algebra products (times7, mul_lazy, fma2, select_lerp) and the permutation built from them, over every pair of
+    {0, 1, p-1, p, 2^64-1, 2^32-1, 2^32, 2^64-2^32, 2^63} plus 65 536 random operands, against big-integer arithmetic: tools/test_asm (built by
+    __graft_entry__.build()).  Random field elements reach a residue >= p with probability 2^-32: without this the wrap branches never run."""
+    import subprocess
+    import __graft_entry__ as entry
+    exe = entry.build_asm_edge_tool()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ASM_EDGE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    for name in ("mul_nc", "dot2_nc", "mad_nc", "fold96", "add_nn", "times7", "mul_lazy / fma2", "select_lerp", "permute"):
+        assert name + ": 0 mismatch" in r.stdout, (name, r.stdout)
+
+
 # ---------- FRI ----------
 def _fri_case(ctx, log_n, cols, **over):
     datas = [rand_field(nc, 1 << log_n) for nc in cols]

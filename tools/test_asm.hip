@@ -1,6 +1,7 @@
 // Standalone check of the hand-scheduled gfx950 primitives (gl::mul_nc, poseidon::fold96, poseidon::permute)
 // against their host C forms.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/test_asm.hip -o tools/test_asm
 #include "../verifiable-fhe-paper_amd/csrc/poseidon.h"
+#include "../verifiable-fhe-paper_amd/csrc/gates.h"
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -23,6 +24,30 @@ __global__ void k_fold(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(poseidon::fold96(a[i], b[i]));
 }
+// the non-canonical-residue forms the gate kernels use: add_nn, times7, the lazy algebra product, the fused e t + v p, select_lerp
+__global__ void k_addnn(const u64* a, const u64* b, u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gl::add_nn(a[i], b[i]));
+}
+__global__ void k_times7(const u64* a, u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gates::times7(a[i]));
+}
+__global__ void k_alg(const u64* a, const u64* b, u64* out, int n) {   // out[4 i ..]: mul_lazy (2 words), fma2 (2 words)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const gates::Alg<u64> x{a[i], b[i]}, y{b[(i + 3) % n], a[(i + 11) % n]}, v{a[(i + 17) % n], b[(i + 19) % n]}, p{gl::canon(b[(i + 23) % n]), gl::canon(a[(i + 29) % n])};
+    const gates::Alg<u64> m = gates::mul_lazy(x, y, gates::times7(y.b));
+    out[4 * i] = gl::canon(m.a);
+    out[4 * i + 1] = gl::canon(m.b);
+    const gates::Alg<u64> f = gates::fma2(x, y, v, p);
+    out[4 * i + 2] = f.a;
+    out[4 * i + 3] = f.b;
+}
+__global__ void k_lerp(const u64* a, const u64* b, u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gates::select_lerp(gl::canon(a[i]), gl::canon(b[i]), a[(i + 5) % n]);
+}
 __global__ void k_perm(u64* st, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -42,7 +67,7 @@ int main(int argc, char** argv) {
     u64 *da, *db, *dout;
     CK(hipMalloc(&da, n * 8)); CK(hipMalloc(&db, n * 8)); CK(hipMalloc(&dout, n * 8));
     CK(hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
-    int bad = 0;
+    int bad = 0, total_bad = 0;
     if (argc < 2 || argv[1][0] == 'm') {
         hipLaunchKernelGGL(k_mul, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
         CK(hipDeviceSynchronize());
@@ -52,7 +77,7 @@ int main(int argc, char** argv) {
             u64 want = (u64)(p % gl::P);
             if (out[i] != want) { if (bad < 5) printf("mul mismatch %d: %016lx * %016lx -> %016lx want %016lx\n", i, a[i], b[i], out[i], want); ++bad; }
         }
-        printf("mul_nc: %d mismatches of %d\n", bad, n);
+        printf("mul_nc: %d mismatches of %d\n", bad, n); total_bad += bad;
     }
     if (argc < 2 || argv[1][0] == 'd') {   // the fused products of the gate kernels: a b + c d and a b + c with one reduction
         bad = 0;
@@ -64,7 +89,7 @@ int main(int argc, char** argv) {
             const u64 want = (u64)((((unsigned __int128)a[i] * b[i]) % gl::P + ((unsigned __int128)c * d) % gl::P) % gl::P);
             if (out[i] != want) { if (bad < 5) printf("dot2 mismatch %d: %016lx %016lx %016lx %016lx -> %016lx want %016lx\n", i, a[i], b[i], c, d, out[i], want); ++bad; }
         }
-        printf("dot2_nc: %d mismatches of %d\n", bad, n);
+        printf("dot2_nc: %d mismatches of %d\n", bad, n); total_bad += bad;
         bad = 0;
         hipLaunchKernelGGL(k_mad, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
         CK(hipDeviceSynchronize());
@@ -74,7 +99,7 @@ int main(int argc, char** argv) {
             const u64 want = (u64)((((unsigned __int128)a[i] * b[i]) % gl::P + c % gl::P) % gl::P);
             if (out[i] != want) { if (bad < 5) printf("mad mismatch %d: %016lx %016lx %016lx -> %016lx want %016lx\n", i, a[i], b[i], c, out[i], want); ++bad; }
         }
-        printf("mad_nc: %d mismatches of %d\n", bad, n);
+        printf("mad_nc: %d mismatches of %d\n", bad, n); total_bad += bad;
     }
     if (argc < 2 || argv[1][0] == 'f') {
         bad = 0;
@@ -90,7 +115,51 @@ int main(int argc, char** argv) {
             u64 want = (u64)(v % gl::P);
             if (out[i] != want) { if (bad < 5) printf("fold mismatch %d: %016lx %016lx -> %016lx want %016lx\n", i, fa[i], fb[i], out[i], want); ++bad; }
         }
-        printf("fold96: %d mismatches of %d\n", bad, n);
+        printf("fold96: %d mismatches of %d\n", bad, n); total_bad += bad;
+    }
+    if (argc < 2 || argv[1][0] == 'g') {
+        auto mulm = [](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) * (y % gl::P)) % gl::P); };
+        auto addm = [](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) + (y % gl::P)) % gl::P); };
+        CK(hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
+        bad = 0;
+        hipLaunchKernelGGL(k_addnn, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) if (out[i] != addm(a[i], b[i])) { if (bad < 5) printf("add_nn mismatch %d: %016lx + %016lx -> %016lx\n", i, a[i], b[i], out[i]); ++bad; }
+        printf("add_nn: %d mismatches of %d\n", bad, n); total_bad += bad;
+        bad = 0;
+        hipLaunchKernelGGL(k_times7, dim3(n / 256), dim3(256), 0, 0, da, dout, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) if (out[i] != mulm(a[i], 7)) { if (bad < 5) printf("times7 mismatch %d: %016lx -> %016lx\n", i, a[i], out[i]); ++bad; }
+        printf("times7: %d mismatches of %d\n", bad, n); total_bad += bad;
+        bad = 0;
+        u64* dout4; CK(hipMalloc(&dout4, 4 * (size_t)n * 8));
+        std::vector<u64> out4(4 * (size_t)n);
+        hipLaunchKernelGGL(k_alg, dim3(n / 256), dim3(256), 0, 0, da, db, dout4, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out4.data(), dout4, 4 * (size_t)n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const u64 xa = a[i], xb = b[i], ya = b[(i + 3) % n], yb = a[(i + 11) % n], va = a[(i + 17) % n], vb = b[(i + 19) % n],
+                      pa = b[(i + 23) % n] % gl::P, pb = a[(i + 29) % n] % gl::P;
+            const u64 ma = addm(mulm(xa, ya), mulm(7, mulm(xb, yb))), mb = addm(mulm(xa, yb), mulm(xb, ya));
+            const u64 qa = addm(mulm(va, pa), mulm(7, mulm(vb, pb))), qb = addm(mulm(va, pb), mulm(vb, pa));
+            if (out4[4 * i] != ma || out4[4 * i + 1] != mb || out4[4 * i + 2] != addm(ma, qa) || out4[4 * i + 3] != addm(mb, qb)) {
+                if (bad < 5) printf("algebra product mismatch %d\n", i);
+                ++bad;
+            }
+        }
+        printf("mul_lazy / fma2: %d mismatches of %d\n", bad, n); total_bad += bad;
+        bad = 0;
+        hipLaunchKernelGGL(k_lerp, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const u64 x = a[i] % gl::P, y = b[i] % gl::P, sel = a[(i + 5) % n];
+            const u64 want = addm(x, mulm(sel, (y + gl::P - x) % gl::P));
+            if (out[i] != want) { if (bad < 5) printf("select_lerp mismatch %d\n", i); ++bad; }
+        }
+        printf("select_lerp: %d mismatches of %d\n", bad, n); total_bad += bad;
     }
     if (argc < 2 || argv[1][0] == 'p') {
         bad = 0;
@@ -105,7 +174,8 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(st.data(), dst, 12 * np * 8, hipMemcpyDeviceToHost));
         for (int i = 0; i < 12 * np; ++i) if (st[i] != ref[i]) ++bad;
-        printf("permute: %d mismatching words of %d\n", bad, 12 * np);
+        printf("permute: %d mismatching words of %d\n", bad, 12 * np); total_bad += bad;
     }
-    return 0;
+    printf("%s\n", total_bad ? "ASM_EDGE_FAILED" : "ASM_EDGE_OK");
+    return total_bad ? 1 : 0;
 }
