@@ -285,11 +285,12 @@ def test_hash_chain_matches_oracle_and_reference_semantics():
 
 
 def test_recorded_bench_line_keeps_the_contract():
-    """profiles/r03_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  Since
-    round 3 the parsed headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs), the roofline is priced against the integer
-    issue rate with the HBM fraction beside it, and the CPU baseline is a median of stage-timed runs."""
+    """profiles/r04_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  The parsed
+    headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs); since round 4 the roofline object has the contract's form
+    (bound hbm: algorithmic bytes per launch / launch duration / 8 TB/s, the PMC traffic and its source named) with the integer-issue pricing
+    beside it, the whole step priced against HBM, and a sustained figure (whole chains) next to the burst."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_latest.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_latest.json")
     d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):
@@ -299,14 +300,20 @@ def test_recorded_bench_line_keeps_the_contract():
     chains = d["config"]["chains_per_gpu"]
     assert chains >= 1 and abs(d["value"] - chains * 1e3 / d["ms_per_step"] / 730) / d["value"] < 1e-6      # chained proofs/s / 730
     r = d["roofline"]
-    assert r["bound"] == "int-valu-issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
-    assert r["hbm"]["bound"] == "hbm" and abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / r["hbm"]["peak"]) < 1e-9 and r["hbm"]["unit"] == "GB/s"
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 0.1
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05 and "profiles/" in r["traffic_measured_in"] and "single_chain" in r["measured_in"]
+    i = r["int_valu_issue"]
+    assert i["bound"] == "int-valu-issue" and abs(i["frac"] - i["achieved"] / i["peak"]) < 1e-9 and 0 < i["frac"] <= 1.0
+    assert 0.01 < r["step_hbm_frac"] < 0.2
+    s = d["sustained"]
+    assert s["chains"] == chains and abs(s["sustained_over_burst"] - s["vpbs_proofs_per_s"] / d["value"]) < 1e-9 and 0.9 < s["sustained_over_burst"] < 1.1
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["runs"] >= 5
     assert len(c["ms_per_step_runs"]) == c["runs"] and sum(c["stages_ms_median"].values()) < 1.05 * c["ms_per_step"]
     assert "cargo" in c["reference_probe"]
     assert d["parity_checked_full_size"] is True and d["step_micro"]["ms_per_step_proof"] > 0 and d["ivc_single_chain"]["ms_per_step"] > d["ms_per_step"] / chains
+    assert d["ivc_chain_n2048"]["ms_per_step"] > d["ivc_single_chain"]["ms_per_step"] and d["ivc_chain"]["decrypted"] == d["ivc_chain"]["message"]
 
 
 def test_proof_bytes_round_trip_and_verify():
