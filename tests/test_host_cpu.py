@@ -62,6 +62,7 @@ def test_rust_binding_matches_the_header():
         n_r = 0 if not inner.strip() else inner.count(",") + 1
         assert n_c == n_r, (name, n_c, n_r)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert gen_rust_ffi.integration_excerpt() in doc, "INTEGRATION.md's excerpt is stale: run tools/gen_rust_ffi.py --integration"
     shown = []
     for block in re.findall(r"```rust\n(.*?)```", doc, flags=re.S):
         for line in block.splitlines():

@@ -5,7 +5,8 @@ plonky2 cannot drift from the header.  No Rust toolchain exists in the authoring
 tests/test_host_cpu.py::test_rust_binding_matches_the_header (regenerated text == committed text; every declaration INTEGRATION.md shows is
 one of its lines) instead of by rustc.
 
-usage: tools/gen_rust_ffi.py [--check]     (writes bindings/rust/vpbs_sys.rs, or with --check exits 1 when it is stale)
+usage: tools/gen_rust_ffi.py [--check] [--integration]   (writes bindings/rust/vpbs_sys.rs, or with --check exits 1 when it is stale;
+       --integration also rewrites the excerpt INTEGRATION.md section 2 shows, between its BEGIN / END markers)
 
 The parser handles exactly the C subset the header uses: opaque struct typedefs, plain structs (scalar / pointer / fixed-array fields,
 several declarators per line), enums, function-pointer typedefs and prototypes."""
@@ -233,6 +234,53 @@ def generate():
     return Binding(open(HEADER).read()).render()
 
 
+# the declarations INTEGRATION.md section 2 shows (verbatim lines of the generated binding), by group
+EXCERPT = [
+    ("context, compatibility table, errors, host settings",
+     ["vpbs_ctx_create", "vpbs_ctx_destroy", "vpbs_last_error", "vpbs_compat_default", "vpbs_ctx_set_compat", "vpbs_ctx_set_option", "vpbs_host_set_cpu_budget",
+      "vpbs_host_set_late_threads", "vpbs_host_set_blocking_sync", "vpbs_hash_no_pad", "vpbs_hash_pad", "vpbs_circuit_digest"]),
+    ("PolynomialBatch / OpeningSet / prove_openings (fri/oracle.rs): the seam inside the patched plonky2",
+     ["vpbs_commit_values", "vpbs_commit_coeffs", "vpbs_batch_free", "vpbs_batch_lde_rows", "vpbs_batch_eval_ext", "vpbs_batch_open", "vpbs_fri_proof_words",
+      "vpbs_fri_prove"]),
+    ("permutation argument + quotient stage (device-resident: the batches never leave HBM)",
+     ["vpbs_partial_products", "vpbs_gates_layout", "vpbs_gate_terms", "vpbs_quotient_permutation"]),
+    ("the whole of prove() after witness generation, its serialiser, cd.verify (ivc_based_vpbs.rs:302,333,364 / :488 / :446)",
+     ["vpbs_step_sizes_get", "vpbs_prove_step", "vpbs_prove_step_sharded", "vpbs_prove_step_sharded_fail", "vpbs_comm_allgather_checked",
+      "vpbs_step_proof_to_bytes", "vpbs_step_proof_from_bytes", "vpbs_verify_step"]),
+    ("witness generation: compiled once per circuit; two-phase (late phase in stages) for a chain whose PartialWitness ends with the previous proof",
+     ["vpbs_witness_plan_create", "vpbs_witness_plan_run", "vpbs_witness_plan_split", "vpbs_witness_plan_run_early", "vpbs_witness_plan_late_stages",
+      "vpbs_witness_plan_run_late_stage", "vpbs_witness_plan_run_late_packed", "vpbs_witness_plan_late_count", "vpbs_witness_plan_late_positions",
+      "vpbs_device_scatter", "vpbs_witness_device_create", "vpbs_witness_device_run", "vpbs_witness_device_wires", "vpbs_witness_device_read"]),
+    ("one verifiable PBS as verified_pbs / verify_pbs see it (ivc_based_vpbs.rs:159-386, :388-489)",
+     ["vpbs_ivc_create", "vpbs_ivc_set_step_callback", "vpbs_ivc_set_device_witness", "vpbs_ivc_last_error", "vpbs_ivc_verifier_data", "vpbs_ivc_prove_pbs",
+      "vpbs_ivc_free", "vpbs_verify_pbs"]),
+    ("RCCL collectives of a sharded step (the library binds librccl.so itself)",
+     ["vpbs_rccl_available", "vpbs_rccl_unique_id", "vpbs_comm_rccl_create", "vpbs_comm_rccl_destroy"]),
+]
+BEGIN, END = "// BEGIN excerpt of bindings/rust/vpbs_sys.rs (tools/gen_rust_ffi.py --integration)", "// END excerpt"
+
+
+def integration_excerpt():
+    b = Binding(open(HEADER).read())
+    fn = {n: (ps, ret) for n, ps, ret in b.functions}
+    lines = [BEGIN, "extern \"C\" {"]
+    for title, names in EXCERPT:
+        lines.append("    // " + title)
+        lines += [b.fn_line(n, *fn[n]) for n in names]
+    lines += ["}", END]
+    return "\n".join(lines)
+
+
+def rewrite_integration():
+    path = os.path.join(ROOT, "INTEGRATION.md")
+    doc = open(path).read()
+    a, z = doc.index(BEGIN), doc.index(END) + len(END)
+    new = doc[:a] + integration_excerpt() + doc[z:]
+    if new != doc:
+        open(path, "w").write(new)
+    return new != doc
+
+
 if __name__ == "__main__":
     text = generate()
     if "--check" in sys.argv:
@@ -241,6 +289,8 @@ if __name__ == "__main__":
         sys.exit(1 if stale else 0)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     open(OUT, "w").write(text)
+    if "--integration" in sys.argv:
+        print("INTEGRATION.md excerpt %s" % ("rewritten" if rewrite_integration() else "up to date"))
     b = Binding(open(HEADER).read())
     print("%s: %d functions, %d structs, %d opaque types, %d enums, %d callback types" %
           (os.path.relpath(OUT, ROOT), len(b.functions), len(b.structs), len(b.opaque), len(b.enums), len(b.fnptrs)))
