@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
             const u64 x = a[i] % gl::P, y = b[i] % gl::P, sel = a[(i + 5) % n];
-            const u64 want = addm(x, mulm(sel, (y + gl::P - x) % gl::P));
+            const u64 want = addm(x, mulm(sel, (u64)(((unsigned __int128)y + gl::P - x) % gl::P)));
             if (out[i] != want) { if (bad < 5) printf("select_lerp mismatch %d\n", i); ++bad; }
         }
         printf("select_lerp: %d mismatches of %d\n", bad, n); total_bad += bad;
