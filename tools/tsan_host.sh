@@ -4,7 +4,7 @@
 # per context); device code is compiled without sanitizer.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-OUT=/tmp/vpbs_tsan; mkdir -p $OUT
+OUT=/tmp/vpbs_tsan; mkdir -p $OUT; rm -f $OUT/report.*   # reports of earlier runs are not this run's
 cd "$ROOT/verifiable-fhe-paper_amd/csrc"
 for f in ntt hash fri permutation quotient gates witness_device tfhe keygen comm_rccl api prover verifier ivc; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &

@@ -1180,6 +1180,18 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         }
         return rc;
     }
+    // the presets of the phase / stage first: the chain lanes started below read them without waiting (they only wait for what levels and
+    // other lanes produce) -- ThreadSanitizer found the lanes starting ahead of the presets when this job moved into the pool
+    bool pool_awake = false;
+    if (before) {
+        if (P.order.size() >= 64) {   // worth waking the pool for (a stage of a few generators sets its handful of presets here)
+            pool->begin();
+            pool_awake = true;
+            pool->share([&](unsigned t) { before(t, threads); });
+        } else {
+            before(0, 1);
+        }
+    }
     // the chain lanes start now, on threads of their own, and run next to the levels
     const std::vector<vpbs_witness_plan::Lane>& lanes = p.lanes[ph];
     LevelPool* lane_pool = nullptr;
@@ -1217,14 +1229,11 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
     u32 last_wide = 0;
     for (u32 l = 0; l < n_levels; ++l)
         if (P.cost[P.level_off[l + 1]] - P.cost[P.level_off[l]] >= PAR_MIN_COST) last_wide = l + 1;
-    bool pool_awake = last_wide > 0;
-    if (pool_awake) pool->begin();
-    int rc = VPBS_OK;
-    if (before) {
-        if (pool_awake) pool->share([&](unsigned t) { before(t, threads); });
-        else before(0, 1);
-        if (s.failed()) rc = VPBS_ERR_INVALID;
+    if (last_wide > 0 && !pool_awake) {
+        pool->begin();
+        pool_awake = true;
     }
+    int rc = before && s.failed() ? VPBS_ERR_INVALID : VPBS_OK;
     for (u32 l = 0; l < n_levels && rc == VPBS_OK; ++l) {
         if (pool_awake && l >= last_wide) {
             pool->end();
