@@ -1076,6 +1076,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # The circuit files the legs load are a BUILD product (__graft_entry__.build() -> tools/export_circuits.py; the product package only locates
+    # them).  A checkout that was never built gets them here, by the harness running that build step in a process of its own -- not by the
+    # product: before any device work, rank 0 only (the other ranks of a node find the files when their legs start, after the first barrier).
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        from vpbs_amd import circuit_file as _cf
+        try:
+            _cf.find_step_circuit(1024, 2, 4, 5, 728)
+            _cf.find_cyclic_circuit(IVC_N, IVC_K, IVC_ELL, IVC_LOGB, IVC_NLWE, LOG_N)
+            _cf.find_cyclic_circuit(2048, 2, 4, 5, 728, 17)
+        except FileNotFoundError as e:
+            import subprocess
+            print("bench.py: %s -- running tools/export_circuits.py (the build step) first" % str(e)[:120], file=sys.stderr)
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_circuits.py")], stdout=subprocess.DEVNULL)
     if distributed:
         assert world == args.gpus, "WORLD_SIZE must equal --gpus"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
