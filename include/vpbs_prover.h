@@ -351,9 +351,10 @@ int vpbs_host_set_late_threads(unsigned threads);
 /* How the library's host threads wait for the device.  0: hipStreamSynchronize (spins: lowest latency, one CPU per waiting thread -- a chain's
  * proving thread waits most of the time); 1: blocking (the thread polls the stream and sleeps in between: a wait ends up to ~50 us late,
  * next to no CPU while waiting); -1: default = the environment variable VPBS_BLOCKING_SYNC, else blocking when the process may use fewer than 8
- * CPUs; -2: change nothing.  Process-wide; returns the mode in force.  Measured with four chains per GPU on 2 CPUs: the spinning proving threads alone took both
+ * CPUs.  Process-wide; returns the mode in force (vpbs_host_blocking_sync: the same without changing anything).  Measured with four chains per GPU on 2 CPUs: the spinning proving threads alone took both
  * CPUs (tools/prove_ivc.py VPBS_CPU_BY_ROLE). */
 int vpbs_host_set_blocking_sync(int on);
+int vpbs_host_blocking_sync(void);
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
                                 vpbs_witness_state** state_out, char* err, size_t err_len);

@@ -90,9 +90,10 @@ hipError_t stream_sync(hipStream_t s) {
 }  // namespace vpbs
 
 extern "C" int vpbs_host_set_blocking_sync(int on) {
-    if (on >= -1) vpbs::g_blocking_sync.store(on < 0 ? -1 : (on ? 1 : 0));   // -2: only ask
+    vpbs::g_blocking_sync.store(on < 0 ? -1 : (on ? 1 : 0));
     return vpbs::blocking_sync_mode();
 }
+extern "C" int vpbs_host_blocking_sync(void) { return vpbs::blocking_sync_mode(); }
 
 static double trace_now_us() {
     static const auto t0 = std::chrono::steady_clock::now();

@@ -774,7 +774,7 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
                      "prove %.2f, device batch run %.2f ms; CPU time of the proving thread: late %.2f, scatter %.2f, prove %.2f ms (blocking waits: %d)\n",
                      1e3 * t_wait_staged / steps, 1e3 * t_wait_hashed / steps, 1e3 * t_late / steps,
                      1e3 * t_rows / steps, 1e3 * t_prove / steps, 1e3 * t_early / steps, 1e3 * c_late / steps, 1e3 * c_rows / steps, 1e3 * c_prove / steps,
-                     vpbs_host_set_blocking_sync(-2));
+                     vpbs_host_blocking_sync());
     const long n_bytes = vpbs_step_proof_to_bytes(ctx, &in, cyc.n_const_cols, caps, openings, fri, proof_out, capacity);
     if (n_bytes <= 0) {
         say("the output buffer is too small for the proof");
