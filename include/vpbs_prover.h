@@ -355,6 +355,12 @@ int vpbs_host_set_late_threads(unsigned threads);
  * CPUs (tools/prove_ivc.py VPBS_CPU_BY_ROLE). */
 int vpbs_host_set_blocking_sync(int on);
 int vpbs_host_blocking_sync(void);
+/* What a waiting thread looks at.  1 (default): a completion word -- a one-thread kernel behind the work writes a sequence number into host
+ * memory the device has mapped and the thread reads that word (spinning, or napping in blocking mode); the HIP runtime is not asked.
+ * 0: hipStreamSynchronize / hipStreamQuery.  Either of those makes the HSA runtime's event thread busy-wait for as long as the device has
+ * work -- one more CPU per process (measured: 8.5 ms of CPU per 8.9 ms of device work, tools/experiments/graph_cpu_probe.hip).  -1: default =
+ * the environment variable VPBS_SYNC_WORD, else 1.  Process-wide; returns the mode in force.  Results never depend on it. */
+int vpbs_host_set_sync_word(int on);
 int vpbs_witness_plan_split(vpbs_witness_plan* plan, const uint8_t* late /* [n_preset] */, char* err, size_t err_len);
 int vpbs_witness_plan_run_early(const vpbs_witness_plan* plan, const uint64_t* preset_val, unsigned threads, uint64_t* wires_out,
                                 vpbs_witness_state** state_out, char* err, size_t err_len);

@@ -8,12 +8,12 @@ VPBS_IVC_DEVICE_WITNESS=64 GPU_MAX_HW_QUEUES=8 ./examples/prove_ivc $C/cyclic_N1
 pid=$!
 last=""
 while kill -0 $pid 2>/dev/null; do
-  snap=$(for t in /proc/$pid/task/*; do [ -r $t/stat ] && awk -v n="$(cat $t/comm 2>/dev/null)" '{print n, $1, $14, $15}' $t/stat 2>/dev/null; done)
+  snap=$(for t in /proc/$pid/task/*; do [ -r $t/stat ] && awk -v n="$(cat $t/comm 2>/dev/null)" -v sw="$(awk '/^voluntary_ctxt/{print $2}' $t/status 2>/dev/null)" '{print n, $1, $14, $15, sw}' $t/stat 2>/dev/null; done)
   case "$snap" in *vpbs-stager*) last="$snap"; at=$(awk '{print $1}' /proc/uptime);; esac
   [ -z "$t0" ] && t0=$(awk '{print $1}' /proc/uptime)
   sleep 0.2
 done
 wait $pid
 tail -1 /tmp/cxx_ivc.out | cut -c1-200
-echo "thread comm, tid, utime, stime (ticks of 10 ms) at the last sample with the chain running, $(awk -v a="$at" -v b="$t0" "BEGIN{print a-b}") s after the start:"
+echo "thread comm, tid, utime, stime (ticks of 10 ms), voluntary context switches at the last sample with the chain running, $(awk -v a="$at" -v b="$t0" "BEGIN{print a-b}") s after the start:"
 echo "$last" | sort -k3 -n -r | head -${TOP:-4}

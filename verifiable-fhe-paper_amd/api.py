@@ -253,6 +253,7 @@ SIGNATURES = {
     "vpbs_host_set_late_threads": (_i, [_ui]),
     "vpbs_host_set_blocking_sync": (_i, [_i]),
     "vpbs_host_blocking_sync": (_i, []),
+    "vpbs_host_set_sync_word": (_i, [_i]),
     "vpbs_witness_device_has_late": (_i, [_vp]),
     "vpbs_witness_device_run_late": (_i, [C.c_void_p, C.c_uint, U64P]),
     "vpbs_ctx_device": (_i, [_vp]),

@@ -6,6 +6,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
 
 #include "context.h"
 #include "poseidon.h"
@@ -68,23 +71,104 @@ int blocking_sync_mode() {
     return a;
 }
 void blocking_sync_budget_changed() { g_blocking_auto.store(-1, std::memory_order_relaxed); }
-hipError_t stream_sync(hipStream_t s) {
-    if (!blocking_sync_mode()) return hipStreamSynchronize(s);
-    // Sleeping wait: poll the stream and give the CPU away in between.  (An event made with hipEventBlockingSync does not do it on this
-    // runtime: measured, the waiting thread still used 100 % of a CPU.)  A short spin first -- most transcript round trips of a step are tens
-    // of microseconds -- then naps of 30 us with the thread's timer slack lowered so that a nap is a nap: a wait ends at most ~50 us late,
-    // eleven times per step proof, which a GPU shared by several chains does not notice.
+
+// ---- completion words ----
+// Every wait INSIDE the runtime (hipStreamSynchronize, and equally the first hipStreamQuery on a busy stream) hands the stream's last command
+// to the HSA async-events thread, and that thread then busy-waits through KFD event ioctls until the command retires: one whole CPU for as
+// long as the device has work, next to the waiting thread itself (tools/experiments/graph_cpu_probe.hip: 8.5 ms of CPU per 8.9 ms of device
+// work, graph launch or not; 0.5 ms when nobody asks the runtime).  So the library does not ask: a one-thread kernel behind the work writes a
+// sequence number into a word of host memory the device has mapped, and the host reads that word -- spinning, or napping in blocking mode.
+// The copies ahead of it on the stream have landed when the word changes (stream order; the kernel fences at system scope before it writes).
+struct SyncWord {
+    volatile u64* host = nullptr;   // hipHostMalloc, mapped: the device writes, the host reads
+    u64* dev = nullptr;
+    std::atomic<u64> seq{0};
+};
+__global__ void sync_word_kernel(volatile u64* word, u64 seq) {
+    __threadfence_system();
+    *word = seq;
+}
+std::mutex g_sync_words_mu;
+std::unordered_map<hipStream_t, std::unique_ptr<SyncWord>> g_sync_words;
+std::atomic<int> g_sync_word_mode{-1};   // vpbs_host_set_sync_word: -1 = environment (VPBS_SYNC_WORD), default on
+int sync_word_mode() {
+    const int m = g_sync_word_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    static const int from_env = [] {
+        const char* e = getenv("VPBS_SYNC_WORD");
+        return e ? (atoi(e) != 0 ? 1 : 0) : 1;
+    }();
+    return from_env;
+}
+static SyncWord* sync_word_of(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_sync_words_mu);
+    auto& slot = g_sync_words[s];
+    if (!slot) {
+        std::unique_ptr<SyncWord> w(new SyncWord());
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
+        *static_cast<volatile u64*>(h) = 0;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipHostFree(h);
+            return nullptr;
+        }
+        w->host = static_cast<volatile u64*>(h);
+        w->dev = static_cast<u64*>(d);
+        slot = std::move(w);
+    }
+    return slot.get();
+}
+void stream_sync_forget(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_sync_words_mu);
+    auto it = g_sync_words.find(s);
+    if (it == g_sync_words.end()) return;
+    if (it->second && it->second->host) (void)hipHostFree(const_cast<u64*>(it->second->host));
+    g_sync_words.erase(it);
+}
+static void nap_30us() {
     static thread_local bool slack_set = false;
     if (!slack_set) {
-        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // 1 us instead of the default 50 us
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // 1 us instead of the default 50 us: a nap is a nap
         slack_set = true;
     }
+    timespec ts{0, 30000};
+    (void)nanosleep(&ts, nullptr);
+}
+hipError_t stream_sync(hipStream_t s) {
+    const bool block = blocking_sync_mode() != 0;
+    if (sync_word_mode()) {
+        if (SyncWord* w = sync_word_of(s)) {
+            const u64 seq = w->seq.fetch_add(1, std::memory_order_relaxed) + 1;
+            hipLaunchKernelGGL(sync_word_kernel, dim3(1), dim3(1), 0, s, w->dev, seq);
+            if (hipGetLastError() == hipSuccess) {
+                // the runtime is asked only once in a long while: a stream that faulted never writes its word
+                auto t_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+                for (unsigned i = 0;; ++i) {
+                    if (*w->host >= seq) return hipSuccess;
+                    if (block && i >= 64) nap_30us();
+                    else __builtin_ia32_pause();
+                    if ((i & 0xff) == 0xff || block) {
+                        const auto now = std::chrono::steady_clock::now();
+                        if (now >= t_check) {
+                            const hipError_t q = hipStreamQuery(s);
+                            if (q != hipErrorNotReady && *w->host < seq) return q == hipSuccess ? hipStreamSynchronize(s) : q;
+                            t_check = now + std::chrono::milliseconds(200);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!block) return hipStreamSynchronize(s);
+    // Sleeping wait through the runtime (VPBS_SYNC_WORD=0): poll the stream and give the CPU away in between.  (An event made with
+    // hipEventBlockingSync does not do it on this runtime: measured, the waiting thread still used 100 % of a CPU.)  A short spin first, then
+    // naps of 30 us: a wait ends at most ~50 us late, eleven times per step proof, which a GPU shared by several chains does not notice.
     for (unsigned i = 0;; ++i) {
         const hipError_t q = hipStreamQuery(s);
         if (q != hipErrorNotReady) return q;
         if (i < 64) continue;
-        timespec ts{0, 30000};
-        (void)nanosleep(&ts, nullptr);
+        nap_30us();
     }
 }
 }  // namespace vpbs
@@ -94,6 +178,10 @@ extern "C" int vpbs_host_set_blocking_sync(int on) {
     return vpbs::blocking_sync_mode();
 }
 extern "C" int vpbs_host_blocking_sync(void) { return vpbs::blocking_sync_mode(); }
+extern "C" int vpbs_host_set_sync_word(int on) {
+    vpbs::g_sync_word_mode.store(on < 0 ? -1 : (on ? 1 : 0));
+    return vpbs::sync_word_mode();
+}
 
 static double trace_now_us() {
     static const auto t0 = std::chrono::steady_clock::now();
@@ -355,11 +443,16 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto st : c->gate_streams)
-        if (st) (void)hipStreamDestroy(st);
+        if (st) {
+            vpbs::stream_sync_forget(st);
+            (void)hipStreamDestroy(st);
+        }
     if (c->gate_fork) (void)hipEventDestroy(c->gate_fork);
     for (auto e : c->gate_join)
         if (e) (void)hipEventDestroy(e);
     (void)vpbs::stream_sync(c->upload_stream);
+    vpbs::stream_sync_forget(c->upload_stream);
+    vpbs::stream_sync_forget(c->stream);
     (void)hipStreamDestroy(c->upload_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;

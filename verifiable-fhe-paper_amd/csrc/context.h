@@ -39,6 +39,8 @@ namespace vpbs {
 // has): vpbs_host_set_blocking_sync, default from VPBS_BLOCKING_SYNC, else AUTO -- block when the process may use fewer than 8 CPUs.
 int blocking_sync_mode();                 // 0 spin, 1 block
 hipError_t stream_sync(hipStream_t s);    // drop-in for hipStreamSynchronize
+void stream_sync_forget(hipStream_t s);   // before hipStreamDestroy: the stream's completion word (api.hip) is freed
+int sync_word_mode();                     // 1: waits read a word the device writes (default); 0: they go through the runtime
 void blocking_sync_budget_changed();      // the process's CPU budget was set: AUTO decides again
 }  // namespace vpbs
 
