@@ -28,8 +28,23 @@ sys.path.insert(0, ROOT)
 # Several chains per GPU mean 20-30 HIP streams (per chain: the prover's, its upload stream, the witness contexts').  The HIP runtime maps a
 # process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise: measured with six chains per
 # GPU (tools/experiments/hwq_ab.sh), 4 / 8 / 16 / 24 queues = 8.45-8.54 / 8.35-8.40 / 8.69-8.75 / 8.73-8.78 ms per chained proof with the host
-# witness pipeline and 8.72-8.74 / 8.32-8.35 / 8.31-8.32 / 8.58-8.66 with the device pipeline.  Read by the runtime when it is loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# witness pipeline and 8.72-8.74 / 8.32-8.35 / 8.31-8.32 / 8.58-8.66 with the device pipeline; with the waits on completion words (round 4) the
+# device pipeline -- a chain there has six streams -- gains from 16: 8.70 -> 8.48 on 16 CPUs, 9.49 -> 9.21 on 4 (tools/experiments/hw_queues_dw.sh),
+# the host pipeline loses (8.17 -> 8.38).  Read by the runtime when it starts: decided here, from the CPU share that later picks the pipeline.
+def _cpu_share_before_hip():
+    """this rank's share of the CPUs the container may use, without touching the library (the HIP runtime reads its environment when it starts):
+    affinity mask and cgroup CPU quota, divided among the ranks of the node -- the figure vpbs_host_cpu_budget() / world gives later"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if _cpu_share_before_hip() < 12 else "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its bundled HIP runtime must be the one the prover library binds to)
@@ -1116,8 +1131,9 @@ def main():
     if args.chains <= 0:
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
         # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most
-        # device pipeline: six chains at every share since the waits sleep (2 CPUs: 0.122-0.124 with four chains, 0.127-0.130 with six: profiles/r04_cpu_share.json)
-        args.chains = 6 if args.device_witness else max(1, min(6, cpus // 2))
+        # device pipeline: eight chains at every share (a chain's late phase and the scatter of its values are serial with its proof, and with
+        # few CPUs they are long: 4 CPUs 0.145-0.149 with six chains, 0.152 with eight or ten; 2 CPUs 0.140 either way: tools/experiments/hw_queues_dw2.sh)
+        args.chains = 8 if args.device_witness else max(1, min(6, cpus // 2))
 
     out, state = None, None
     if args.workload == "ivc":

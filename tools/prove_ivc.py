@@ -26,7 +26,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # several chains = many streams: see bench.py
+# several chains = many streams: see bench.py (16 hardware queues for the device witness pipeline, 8 for the host pipeline)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if os.environ.get("VPBS_IVC_DEVICE_WITNESS", "0") not in ("", "0") else "8")
 import torch  # noqa: E402
 
 import vpbs_amd  # noqa: E402

@@ -82,6 +82,41 @@ struct SlotState {
     bool ready(u32 slot) const { return __atomic_load_n(&is_set[slot], __ATOMIC_ACQUIRE) != 0; }
 };
 
+// The value and flag arrays of finished states, kept for the next state of the same size: a chained proof every 8 ms means a fresh 16 MB
+// pair every 8 ms per chain otherwise, and first-touching those pages (kernel zeroing, page faults) was a third of the stager thread's CPU
+// time.  Process-wide, at most 1 GiB retained; the flags are cleared on reuse, the values need not be (nothing reads an unset slot).
+struct SlotBufPool {
+    std::mutex m;
+    std::vector<std::pair<Buf<u64>, Buf<uint8_t>>> free;
+    size_t bytes = 0;
+    static SlotBufPool& get() {
+        static SlotBufPool* pool = new SlotBufPool();   // never destroyed: states may be freed while the process exits
+        return *pool;
+    }
+    SlotState make(size_t n_slots, size_t n) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t i = 0; i < free.size(); ++i)
+                if (free[i].first.size() == n_slots) {
+                    SlotState s{std::move(free[i].first), std::move(free[i].second), n, {}};
+                    free.erase(free.begin() + (long)i);
+                    bytes -= 9 * n_slots;
+                    std::memset(s.is_set.data(), 0, n_slots);
+                    return s;
+                }
+        }
+        return SlotState{Buf<u64>(n_slots, false), Buf<uint8_t>(n_slots, true), n, {}};
+    }
+    void give(SlotState& s) {
+        if (!s.val.data() || !s.is_set.data()) return;
+        std::lock_guard<std::mutex> lk(m);
+        const size_t b = 9 * s.val.size();
+        if (bytes + b > (size_t(1) << 30)) return;   // the arrays die with the state
+        bytes += b;
+        free.emplace_back(std::move(s.val), std::move(s.is_set));
+    }
+};
+
 struct SlotRow {
     SlotState& s;
     const u32* rs;
@@ -380,6 +415,30 @@ int plan_create(const vpbs_circuit* c, const u32* preset_pos, size_t n_preset, v
         for (u32 s = 0; s < n_slots; ++s) visit(s);
         for (auto* v : {&p.preset_slot, &p.row_slots, &p.gadget_slots, &p.out_slot, &step_out})
             for (u32& s : *v) s = renum[s];
+    }
+    {   // PoseidonGate rows whose private wires own a run of consecutive slots (vpbs_witness_plan::poseidon_private_base)
+        std::vector<uint8_t> refs(n_slots, 0);   // positions per class, saturating; anything a gadget or a preset refers to counts as shared
+        for (u32 sl : p.out_slot)
+            if (refs[sl] < 2) ++refs[sl];
+        for (u32 sl : p.gadget_slots) refs[sl] = 2;
+        for (u32 sl : p.preset_slot) refs[sl] = 2;
+        p.poseidon_private_base.assign(n, NONE);
+        for (size_t r = 0; r < n; ++r) {
+            if (p.row_off[r] == NONE || p.gates[p.row_gate[r]].kind != VPBS_GATE_POSEIDON || p.gates[p.row_gate[r]].num_wires < 135) continue;
+            const u32* rs = p.row_slots.data() + p.row_off[r];
+            bool ok = true;
+            for (unsigned w = 29; w < 135 && ok; ++w) ok = rs[w] == rs[29] + (w - 29) && refs[rs[w]] == 1;
+            if (ok) p.poseidon_private_base[r] = rs[29];
+        }
+        if (std::getenv("VPBS_TRACE_WITNESS")) {
+            size_t rows = 0, with_range = 0;
+            for (size_t r = 0; r < n; ++r)
+                if (p.row_off[r] != NONE && p.gates[p.row_gate[r]].kind == VPBS_GATE_POSEIDON) {
+                    ++rows;
+                    with_range += p.poseidon_private_base[r] != NONE;
+                }
+            std::fprintf(stderr, "[witness plan] %zu of %zu PoseidonGate rows keep their private wires on a slot range of their own\n", with_range, rows);
+        }
     }
     build_device_schedule(p, p.dev, step_out, step_out_w, step_out_off);
     p.step_out = std::move(step_out);
@@ -831,6 +890,13 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
                 for (u32 k = step_io_off[i]; k < step_io_off[i + 1]; ++k) touch(step_io[k]);
         std::sort(p.late_in_slots.begin(), p.late_in_slots.end());
     }
+    p.pack_runs.clear();
+    for (unsigned st = 0; st < n_stages; ++st)
+        for (size_t k = p.late_out_stage_off[st]; k < p.late_out_stage_off[st + 1]; ++k) {
+            const u32 sl = p.out_slot[p.late_out[k]];
+            if (k > p.late_out_stage_off[st] && p.pack_runs.back().slot + p.pack_runs.back().len == sl) ++p.pack_runs.back().len;
+            else p.pack_runs.push_back({(u32)k, sl, 1u});
+        }
     p.late_slot_runs.clear();
     for (size_t sl = 0; sl < p.n_slots; ++sl) {
         if (!taint[sl]) continue;
@@ -900,6 +966,25 @@ void prefault_late_slots(const vpbs_witness_plan& p, SlotState& s) {
 }  // namespace
 }  // namespace vpbs
 
+namespace vpbs {
+namespace {
+// packed_out[k] = value of the slot behind late_out[k] (0 where nothing set it), k in [lo, hi): range copies along pack_runs
+void pack_late_range(const vpbs_witness_plan& p, const SlotState& s, u64* packed_out, size_t lo, size_t hi) {
+    if (lo >= hi) return;
+    auto it = std::upper_bound(p.pack_runs.begin(), p.pack_runs.end(), lo,
+                               [](size_t k, const vpbs_witness_plan::PackRun& r) { return k < r.k; });
+    --it;   // the run that holds lo (runs cover every k from 0)
+    for (; it != p.pack_runs.end() && it->k < hi; ++it) {
+        const size_t k0 = std::max<size_t>(it->k, lo), k1 = std::min<size_t>((size_t)it->k + it->len, hi);
+        const u64* v = &s.val[it->slot + (k0 - it->k)];
+        const uint8_t* f = &s.is_set[it->slot + (k0 - it->k)];
+        u64* out = packed_out + k0;
+        for (size_t i = 0, n = k1 - k0; i < n; ++i) out[i] = f[i] ? v[i] : 0;
+    }
+}
+}  // namespace
+}  // namespace vpbs
+
 struct vpbs_witness_state {
     vpbs::SlotState s;
     unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
@@ -907,6 +992,7 @@ struct vpbs_witness_state {
     vpbs::LevelPool* awake = nullptr;   // the late pool was left spinning for the next stage of this state: whoever runs it (or frees the state) ends it
     ~vpbs_witness_state() {
         if (awake) awake->end();
+        vpbs::SlotBufPool::get().give(s);
     }
 };
 
@@ -971,11 +1057,29 @@ bool poseidon_rows_x8(const vpbs_witness_plan& p, SlotState& s, const u32* steps
         _mm512_store_si512(out, v);
         for (unsigned l = 0; l < cnt; ++l) s.set(rs[l][wire], out[l], (u32)(wire * s.n + row[l]));
     };
-    for (int round = 1; round < 4; ++round)
-        for (int i = 0; i < 12; ++i) scatter(gate[12 * (round - 1) + i], 29 + 12 * (round - 1) + i);
-    for (int q = 0; q < 22; ++q) scatter(gate[36 + q], 65 + q);
-    for (int round = 26; round < 30; ++round)
-        for (int i = 0; i < 12; ++i) scatter(gate[58 + 12 * (round - 26) + i], 87 + 12 * (round - 26) + i);
+    // wires 29 .. 134 = gate[0 .. 105] (S-box inputs of full rounds 1-3, of the 22 partial rounds, of full rounds 26-29).  Nothing but the
+    // wire matrix reads them, and on every row the plan found them on 106 consecutive slots of their own (poseidon_private_base) they go
+    // there as one range per row -- the checked single stores cost more than the permutation (9 against 8 us per eight rows, measured)
+    bool ranges = true;
+    for (unsigned l = 0; l < cnt; ++l) ranges = ranges && p.poseidon_private_base[row[l]] != NONE && !s.is_set[p.poseidon_private_base[row[l]]];
+    if (ranges) {
+        alignas(64) u64 lanes[106][8];
+        const V P = _mm512_set1_epi64((long long)gl::P);
+        for (int j = 0; j < 106; ++j) _mm512_store_si512(lanes[j], _mm512_min_epu64(gate[j], _mm512_sub_epi64(gate[j], P)));   // canonical, as set() leaves them
+        for (unsigned l = 0; l < cnt; ++l) {
+            const u32 base = p.poseidon_private_base[row[l]];
+            u64* dst = &s.val[base];
+            for (int j = 0; j < 106; ++j) dst[j] = lanes[j][l];
+            std::memset(&s.is_set[base], 1, 106);
+        }
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+    } else {
+        for (int round = 1; round < 4; ++round)
+            for (int i = 0; i < 12; ++i) scatter(gate[12 * (round - 1) + i], 29 + 12 * (round - 1) + i);
+        for (int q = 0; q < 22; ++q) scatter(gate[36 + q], 65 + q);
+        for (int round = 26; round < 30; ++round)
+            for (int i = 0; i < 12; ++i) scatter(gate[58 + 12 * (round - 26) + i], 87 + 12 * (round - 26) + i);
+    }
     for (int i = 0; i < 12; ++i) scatter(st[i], 12 + i);
     return true;
 }
@@ -1417,7 +1521,7 @@ static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_
         t0 = t1;
     };
     // values stay unwritten until a generator sets them (the pages are then first touched by the pool's threads, not zeroed here by one)
-    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
+    auto* st = new vpbs_witness_state{SlotBufPool::get().make(p.n_slots, p.n)};
     SlotState& s = st->s;
     lap("state");
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
@@ -1478,6 +1582,7 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
     // the wires of late_out[lo, hi) (a stage's share is one such range), thread t of `of`
     auto emit = [&](size_t lo, size_t hi, unsigned t, unsigned of) {
         const size_t cnt = hi - lo;
+        if (packed) return pack_late_range(p, s, wires_out, lo + cnt * t / of, lo + cnt * (t + 1) / of);
         for (size_t k = lo + cnt * t / of, end = lo + cnt * (t + 1) / of; k < end; ++k) {
             const u32 slot = p.out_slot[p.late_out[k]];
             wires_out[packed ? k : p.out_pos[p.late_out[k]]] = s.is_set[slot] ? s.val[slot] : 0;
@@ -1569,10 +1674,7 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
         const size_t lo = p.late_out_stage_off[stage - 1], hi = p.late_out_stage_off[stage];
         after = [&p, &s, packed_out, lo, hi](unsigned t, unsigned of) {
             const size_t cnt = hi - lo;
-            for (size_t k = lo + cnt * t / of, end = lo + cnt * (t + 1) / of; k < end; ++k) {
-                const u32 slot = p.out_slot[p.late_out[k]];
-                packed_out[k] = s.is_set[slot] ? s.val[slot] : 0;
-            }
+            pack_late_range(p, s, packed_out, lo + cnt * t / of, lo + cnt * (t + 1) / of);
         };
     }
     // the stage before the last leaves the pool spinning: the last one starts when the proof returns, a fraction of a millisecond later, and
@@ -1609,7 +1711,7 @@ int vpbs_witness_state_from_late_inputs(const vpbs_witness_plan* plan, const uin
     using namespace vpbs;
     if (!plan || !plan->is_split || !state_out || (!values && !plan->late_in_slots.empty())) return VPBS_ERR_INVALID;
     const vpbs_witness_plan& p = *plan;
-    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
+    auto* st = new vpbs_witness_state{SlotBufPool::get().make(p.n_slots, p.n)};
     for (size_t k = 0; k < p.late_in_slots.size(); ++k) {
         if (values[k] >= gl::P) {
             delete st;

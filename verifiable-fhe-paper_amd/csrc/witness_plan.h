@@ -203,6 +203,9 @@ struct vpbs_witness_plan {
     std::vector<u32> row_gate;                  // [n]
     std::vector<u64> consts;                    // [n][max_consts]: the gate constants of every row
     std::vector<u32> row_off, row_slots;        // row -> offset into row_slots: the slot of every wire of a row that owns generators
+    // PoseidonGate rows: the slot of wire 29 when wires 29 .. 134 (the S-box inputs: wires nothing else refers to) sit on 106 consecutive slots of
+    // their own -- the eight-lane generator then stores them as one range per row instead of 106 checked single stores; NONE otherwise
+    std::vector<u32> poseidon_private_base;     // [n]
     struct Gadget {
         unsigned kind, p0;
         u32 at, n_in, n_out;                    // gadget_slots / gadget_pos [at, at + n_in) inputs, then n_out outputs
@@ -308,6 +311,12 @@ struct vpbs_witness_plan {
     // runs [first, first + count) of consecutive value slots that only the late phase writes: a fresh state's pages under them are touched
     // by whoever creates the state (the early thread, the stager) instead of faulting in one by one on the critical path of the late phase
     std::vector<std::pair<u32, u32>> late_slot_runs;
+    // the packed late wires as copies of slot ranges: entry (k, slot, len) = late_out[k + i] holds slot + i, i < len; ordered by k, cut at the
+    // stage boundaries.  A PoseidonGate row's 110 private wires are one run: packing is a few thousand range copies, not 618 000 lookups
+    struct PackRun {
+        u32 k, slot, len;
+    };
+    std::vector<PackRun> pack_runs;
     // what every scheduled step writes (slots; wire index for row steps, NONE for gadget outputs): kept for building dev_early
     std::vector<u32> step_out, step_out_w, step_out_off;
 };
