@@ -285,6 +285,46 @@ def test_hash_chain_matches_oracle_and_reference_semantics():
         assert not api.hash_chain(items, claimed=bad)[1]
 
 
+def test_hash_chains_of_concurrent_callers_share_lanes_and_agree_with_the_oracle():
+    """Nine threads walk nine different chains at once, eight links per call (vpbs_hash_chain_links; items of 200, 64 and 65 elements: long
+    enough to share the lanes of the eight-lane host Poseidon where the CPU has AVX-512 and the process counts as short of CPUs; one chain
+    of short items never shares, one has a different number of links): every chain ends in the oracle's value and every link equals
+    hash_no_pad of the concatenation, whoever happened to run whose batch."""
+    import threading
+    rng = np.random.default_rng(11)
+    shapes = [(16, 200)] * 5 + [(16, 64), (16, 65), (12, 200), (20, 5)]
+    chains = [rng.integers(0, P, size=sh, dtype=np.uint64) for sh in shapes]
+    want = []
+    for items in chains:
+        w = np.zeros(4, np.uint64)
+        orc.lib().orc_hash_chain(orc.ptr(np.ascontiguousarray(items)), items.shape[0], items.shape[1], orc.ptr(w))
+        want.append(w)
+    for attempt in range(4):
+        api.lib().vpbs_host_set_blocking_sync(1 if attempt < 3 else 0)   # sharing is for processes short of CPUs; the last pass: every caller alone
+        got = [None] * len(chains)
+        start = threading.Barrier(len(chains))
+
+        def walk(i):
+            start.wait()
+            seg = 8 if chains[i].shape[0] % 8 == 0 else 4
+            h, links = np.zeros(4, np.uint64), []
+            for k in range(0, chains[i].shape[0], seg):
+                out = api.hash_chain_links(h, chains[i][k:k + seg])
+                links.append(out)
+                h = out[-1].copy()
+            got[i] = np.concatenate(links)
+        threads = [threading.Thread(target=walk, args=(i,)) for i in range(len(chains))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for g, w, items in zip(got, want, chains):
+            assert (g[-1] == w).all()
+            assert (g[3] == api.hash_no_pad(np.concatenate([g[2], items[3]]))).all()
+    api.lib().vpbs_host_set_blocking_sync(-1)
+    assert (api.hash_chain(chains[0])[0] == want[0]).all()
+
+
 def test_recorded_bench_line_keeps_the_contract():
     """profiles/r04_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  The parsed
     headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs); since round 4 the roofline object has the contract's form

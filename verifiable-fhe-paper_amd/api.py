@@ -192,6 +192,7 @@ SIGNATURES = {
     "vpbs_challenger_get": (_u64, [C.POINTER(ChallengerStateC)]),
     "vpbs_hash_no_pad": (None, [U64P, _sz, U64P]),
     "vpbs_hash_chain": (_i, [U64P, _sz, _sz, U64P, U64P]),
+    "vpbs_hash_chain_links": (_i, [U64P, C.POINTER(U64P), _sz, _sz, U64P]),
     "vpbs_fri_params_standard": (None, [_ui, C.POINTER(FriParams)]),
     "vpbs_fri_proof_words": (_sz, [C.POINTER(FriParams), _ui, C.POINTER(_sz), _sz]),
     "vpbs_fri_prove": (_i, [_vp, C.POINTER(_vp), _sz, C.POINTER(FriInstanceC), C.POINTER(FriParams),
@@ -730,6 +731,18 @@ def hash_chain(items, claimed=None):
     if rc < 0:
         raise VpbsError("vpbs_hash_chain failed")
     return out, rc == 1
+
+
+def hash_chain_links(prefix, items):
+    """links of a hash chain from `prefix` on: out[k] = hash_no_pad(h_{k-1} || items[k]) -> [n_links][4] (vpbs_hash_chain_links: concurrent
+    callers of the same shape share AVX-512 lanes when the process is short of CPUs)"""
+    it = _u64(items)
+    pre = _u64(prefix)
+    out = np.zeros((it.shape[0], 4), np.uint64)
+    ptrs = (U64P * it.shape[0])(*[_ptr(it[k]) for k in range(it.shape[0])])
+    if lib().vpbs_hash_chain_links(_ptr(pre), ptrs, it.shape[0], it.shape[1], _ptr(out)) != 0:
+        raise VpbsError("vpbs_hash_chain_links failed")
+    return out
 
 
 def verify_step(proof, cs_cap, ncols, circuit_digest, public_inputs, log_n, num_challenges=2, check_permutation=True, n_constants=0,

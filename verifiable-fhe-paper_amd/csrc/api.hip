@@ -4,6 +4,7 @@
 #include <sys/prctl.h>
 #include <time.h>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -175,6 +176,148 @@ hipError_t stream_sync(hipStream_t s) {
         if (i < 64) continue;
         nap(0);
     }
+}
+}  // namespace vpbs
+
+// ---- links of hash chains for several callers at once ----
+// The bootstrapping-key hash chain of a vPBS is 730 x 2 049 DEPENDENT permutations (h_s = hash_no_pad(h_{s-1} || GGSW_s),
+// ivc_based_vpbs.rs:64-78): one scalar permutation after the other, 2.3 ms of CPU per chained proof -- a sixth of what a rank with two CPUs
+// has.  The chains of ONE process are independent of each other, though: callers that ask for the same number of links while a batch is
+// being hashed are taken together by the next batch, one chain per AVX-512 lane (0.41 instead of 1.28 us per permutation with eight of
+// them), all their links in lockstep.  Whoever finds no batch in progress runs the next one for everybody waiting (no thread of its own);
+// fewer than three jobs go one by one.  For processes that are short of CPUs only (see hash_links_shared).
+namespace vpbs {
+namespace {
+struct SpongeJob {
+    const u64* prefix;          // [4]
+    const u64* const* items;    // [n_links] pointers to item_len words each
+    size_t n_links, len;
+    u64* out;                   // [n_links][4]
+    bool done = false;
+};
+void sponge_scalar(const SpongeJob& j) {
+    const u64* h = j.prefix;
+    for (size_t k = 0; k < j.n_links; ++k) {
+        u64 s[12] = {0};
+        const size_t total = 4 + j.len;
+        for (size_t off = 0; off < total; off += 8) {
+            const size_t blk = total - off < 8 ? total - off : 8;
+            for (size_t i = 0; i < blk; ++i) s[i] = off + i < 4 ? h[off + i] : j.items[k][off + i - 4];
+            poseidon::permute_host(s);
+        }
+        for (int i = 0; i < 4; ++i) j.out[4 * k + i] = s[i];
+        h = j.out + 4 * k;
+    }
+}
+#if defined(VPBS_HAVE_POSEIDON_X8)
+std::mutex g_sponge_mu;
+std::condition_variable g_sponge_cv;
+std::vector<SpongeJob*> g_sponge_queue;
+bool g_sponge_busy = false;
+size_t g_sponge_last = 1, g_sponge_prev = 0;   // jobs in the last batch and in the one before
+__attribute__((target("avx512f,avx512dq"))) void sponge_lanes(SpongeJob* const* jobs, unsigned cnt) {   // 3 <= cnt <= 8 jobs of one shape
+    using poseidon_x8::V;
+    const size_t total = 4 + jobs[0]->len, n_links = jobs[0]->n_links;
+    alignas(64) u64 buf[8][8];
+    const SpongeJob* lane[8];
+    for (unsigned l = 0; l < 8; ++l) lane[l] = jobs[l < cnt ? l : 0];   // spare lanes repeat the first job
+    for (size_t k = 0; k < n_links; ++k) {
+        const u64 *item[8], *prefix[8];
+        for (unsigned l = 0; l < 8; ++l) {
+            item[l] = lane[l]->items[k];
+            prefix[l] = k ? lane[l]->out + 4 * (k - 1) : lane[l]->prefix;
+        }
+        V s[12];
+        for (int i = 0; i < 12; ++i) s[i] = _mm512_setzero_si512();
+        for (size_t off = 0; off < total; off += 8) {
+            const size_t blk = total - off < 8 ? total - off : 8;
+            if (off == 0 || blk < 8) {   // the block with the prefix, a short last block: word by word
+                for (unsigned l = 0; l < 8; ++l)
+                    for (size_t i = 0; i < blk; ++i) buf[i][l] = off + i < 4 ? prefix[l][off + i] : item[l][off + i - 4];
+                for (size_t i = 0; i < blk; ++i) s[i] = _mm512_load_si512(buf[i]);   // overwrite mode: the rate words are replaced
+            } else {   // eight words of every lane's item in one load each, transposed in registers (lane-major -> word-major)
+                V r[8], t[8], v[8];
+                for (unsigned l = 0; l < 8; ++l) {
+                    r[l] = _mm512_loadu_si512(item[l] + off - 4);
+                    _mm_prefetch(reinterpret_cast<const char*>(item[l] + off - 4 + 64), _MM_HINT_T0);   // eight blocks ahead
+                }
+                for (int q = 0; q < 4; ++q) {
+                    t[2 * q] = _mm512_unpacklo_epi64(r[2 * q], r[2 * q + 1]);
+                    t[2 * q + 1] = _mm512_unpackhi_epi64(r[2 * q], r[2 * q + 1]);
+                }
+                for (int odd = 0; odd < 2; ++odd) {
+                    v[4 * odd + 0] = _mm512_shuffle_i64x2(t[0 + odd], t[2 + odd], 0x88);
+                    v[4 * odd + 1] = _mm512_shuffle_i64x2(t[0 + odd], t[2 + odd], 0xdd);
+                    v[4 * odd + 2] = _mm512_shuffle_i64x2(t[4 + odd], t[6 + odd], 0x88);
+                    v[4 * odd + 3] = _mm512_shuffle_i64x2(t[4 + odd], t[6 + odd], 0xdd);
+                    s[0 + odd] = _mm512_shuffle_i64x2(v[4 * odd + 0], v[4 * odd + 2], 0x88);
+                    s[4 + odd] = _mm512_shuffle_i64x2(v[4 * odd + 0], v[4 * odd + 2], 0xdd);
+                    s[2 + odd] = _mm512_shuffle_i64x2(v[4 * odd + 1], v[4 * odd + 3], 0x88);
+                    s[6 + odd] = _mm512_shuffle_i64x2(v[4 * odd + 1], v[4 * odd + 3], 0xdd);
+                }
+            }
+            poseidon_x8::permute(s, nullptr);
+        }
+        for (int i = 0; i < 4; ++i) {
+            _mm512_store_si512(buf[i], s[i]);
+            for (unsigned l = 0; l < cnt; ++l) jobs[l]->out[4 * k + i] = buf[i][l];
+        }
+    }
+}
+#endif
+}  // namespace
+
+// out[k] = hash_no_pad(h_{k-1} || items[k]), h_{-1} = prefix, k < n_links
+void hash_links_shared(const u64 prefix[4], const u64* const* items, size_t n_links, size_t item_len, u64* out) {
+    if (n_links == 0) return;
+    SpongeJob job{prefix, items, n_links, item_len, out};
+#if defined(VPBS_HAVE_POSEIDON_X8)
+    // only where CPU time is what the process is short of (the switch of the sleeping waits: AUTO below 8 CPUs): a batch runs on ONE thread
+    // while the other callers sleep, so with CPUs to spare every caller hashing its own links at once is sooner done
+    if (poseidon_x8::enabled() && item_len >= 64 && blocking_sync_mode()) {
+        std::unique_lock<std::mutex> lk(g_sponge_mu);
+        g_sponge_queue.push_back(&job);
+        g_sponge_cv.notify_all();   // a caller collecting its batch may be waiting for this one
+        while (!job.done) {
+            if (g_sponge_busy) {
+                g_sponge_cv.wait(lk);
+                continue;
+            }
+            g_sponge_busy = true;   // this caller runs the next batch: up to eight waiting jobs of the first one's shape
+            // the callers of the last batch were all released at once and are on their way back: the first one here gives the others a
+            // moment (a hundredth of what the batch will take, 50 us .. 1 ms) before it settles for fewer lanes.  The last TWO batches
+            // together say how many to expect: otherwise two groups of four keep alternating, each hashing while the other waits
+            const size_t expect = std::min<size_t>(8, g_sponge_last + g_sponge_prev);
+            if (g_sponge_queue.size() < expect) {
+                const long us = std::min<long>(1000, std::max<long>(50, (long)(n_links * (item_len / 8) * 3 / 100)));
+                g_sponge_cv.wait_for(lk, std::chrono::microseconds(us), [expect] { return g_sponge_queue.size() >= expect; });
+            }
+            SpongeJob* batch[8];
+            unsigned cnt = 0;
+            const size_t len = g_sponge_queue.front()->len, links = g_sponge_queue.front()->n_links;
+            for (auto it = g_sponge_queue.begin(); it != g_sponge_queue.end() && cnt < 8;) {
+                if ((*it)->len == len && (*it)->n_links == links) {
+                    batch[cnt++] = *it;
+                    it = g_sponge_queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            if (cnt >= 3) sponge_lanes(batch, cnt);
+            else
+                for (unsigned i = 0; i < cnt; ++i) sponge_scalar(*batch[i]);
+            lk.lock();
+            for (unsigned i = 0; i < cnt; ++i) batch[i]->done = true;
+            g_sponge_prev = g_sponge_last;
+            g_sponge_last = cnt;
+            g_sponge_busy = false;
+            g_sponge_cv.notify_all();
+        }
+        return;
+    }
+#endif
+    sponge_scalar(job);
 }
 }  // namespace vpbs
 
@@ -1078,21 +1221,23 @@ int vpbs_k_poseidon_host(uint64_t* states, size_t n) {
     return 0;
 }
 
+int vpbs_hash_chain_links(const uint64_t prefix[4], const uint64_t* const* items, size_t n_links, size_t item_len, uint64_t* out) {
+    if (!prefix || (n_links && (!items || !out))) return VPBS_ERR_INVALID;
+    for (size_t k = 0; k < n_links; ++k)
+        if (!items[k] && item_len) return VPBS_ERR_INVALID;
+    vpbs::hash_links_shared(prefix, items, n_links, item_len, out);
+    return VPBS_OK;
+}
+
 int vpbs_hash_chain(const uint64_t* items, size_t n_items, size_t item_len, const uint64_t claimed[4], uint64_t out[4]) {
     if (n_items && !items) return VPBS_ERR_INVALID;
     u64 h[4] = {0, 0, 0, 0};
-    u64 s[12];
     for (size_t k = 0; k < n_items; ++k) {
         // hash_no_pad(h || item): overwrite-mode sponge over the 4 + item_len elements, without materialising the concatenation
-        for (int i = 0; i < 12; ++i) s[i] = 0;
         const u64* item = items + k * item_len;
-        const size_t total = 4 + item_len;
-        for (size_t off = 0; off < total; off += 8) {
-            const size_t len = total - off < 8 ? total - off : 8;
-            for (size_t i = 0; i < len; ++i) s[i] = off + i < 4 ? h[off + i] : item[off + i - 4];
-            poseidon::permute_host(s);
-        }
-        for (int i = 0; i < 4; ++i) h[i] = s[i];
+        u64 next[4];
+        vpbs::hash_links_shared(h, &item, 1, item_len, next);
+        std::memcpy(h, next, sizeof h);
     }
     if (out) std::memcpy(out, h, sizeof h);
     if (!claimed) return 1;

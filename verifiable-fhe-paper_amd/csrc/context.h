@@ -41,6 +41,8 @@ int blocking_sync_mode();                 // 0 spin, 1 block
 hipError_t stream_sync(hipStream_t s);    // drop-in for hipStreamSynchronize
 void stream_sync_forget(hipStream_t s);   // before hipStreamDestroy: the stream's completion word (api.hip) is freed
 int sync_word_mode();                     // 1: waits read a word the device writes (default); 0: they go through the runtime
+// out[k] = hash_no_pad(h_{k-1} || items[k]), h_{-1} = prefix; concurrent callers with long items share the lanes of the eight-lane host Poseidon
+void hash_links_shared(const u64 prefix[4], const u64* const* items, size_t n_links, size_t item_len, u64* out);
 void blocking_sync_budget_changed();      // the process's CPU budget was set: AUTO decides again
 }  // namespace vpbs
 

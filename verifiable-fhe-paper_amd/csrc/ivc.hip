@@ -518,21 +518,29 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
     // thread H: the two hash chains of verify_hash_output (:64-78), h_s = hash_no_pad(h_{s-1} || item_s), one permutation after the other
     std::thread hasher([&] {
         name_thread("vpbs-hash");
-        std::vector<u64> in(4 + ggsw_len), in2(5);
+        std::vector<u64> in2(5);
         u64 hb[4] = {0, 0, 0, 0}, hl[4] = {0, 0, 0, 0};
-        for (unsigned s = 0; s < steps && !failed; ++s) {
-            std::memcpy(in.data(), hb, 32);
-            std::memcpy(in.data() + 4, ggsw_of(s), 8 * ggsw_len);
-            vpbs_hash_no_pad(in.data(), in.size(), hb);
-            std::memcpy(in2.data(), hl, 32);
-            in2[4] = mask_of(s);
-            vpbs_hash_no_pad(in2.data(), 5, hl);
-            u64* q = pis.data() + (size_t)(s + 1) * n_pi + 2 * kn + 1;
-            std::memcpy(q, hb, 32);
-            std::memcpy(q + 4, hl, 32);
+        // the key chain in segments of eight links: the chains of one process walk theirs side by side (vpbs_hash_chain_links)
+        constexpr unsigned SEG = 8;
+        const u64* items[SEG];
+        u64 links[4 * SEG];
+        for (unsigned s0 = 0; s0 < steps && !failed; s0 += SEG) {
+            const unsigned cnt = std::min(SEG, steps - s0);
+            for (unsigned i = 0; i < cnt; ++i) items[i] = ggsw_of(s0 + i);
+            if (vpbs_hash_chain_links(hb, items, cnt, ggsw_len, links) != 0) return fail("hash chain of the bootstrapping key: malformed arguments");
+            std::memcpy(hb, links + 4 * (cnt - 1), 32);
+            for (unsigned i = 0; i < cnt; ++i) {
+                const unsigned s = s0 + i;
+                std::memcpy(in2.data(), hl, 32);
+                in2[4] = mask_of(s);
+                vpbs_hash_no_pad(in2.data(), 5, hl);
+                u64* q = pis.data() + (size_t)(s + 1) * n_pi + 2 * kn + 1;
+                std::memcpy(q, links + 4 * i, 32);
+                std::memcpy(q + 4, hl, 32);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                hashed = s + 1;
+                hashed = s0 + cnt;
             }
             cv.notify_all();
         }
