@@ -1,15 +1,17 @@
 #!/bin/bash
 # ThreadSanitizer run of the library's HOST code that runs on several threads: the split witness plans (level pools, chain lanes, concurrent
-# runs of one plan) through the CPU tests that exercise them.  Only witness.hip is instrumented (the rest of the host code is single-threaded
-# per context); device code is compiled without sanitizer.
+# runs of one plan, hash-chain links shared between callers) through the CPU tests that exercise them.  witness.hip and api.hip are instrumented
+# (the rest of the host code is single-threaded per context); device code is compiled without sanitizer.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=/tmp/vpbs_tsan; mkdir -p $OUT; rm -f $OUT/report.*   # reports of earlier runs are not this run's
 cd "$ROOT/verifiable-fhe-paper_amd/csrc"
-for f in ntt hash fri permutation quotient gates witness_device tfhe keygen comm_rccl api prover verifier ivc; do
+for f in ntt hash fri permutation quotient gates witness_device tfhe keygen comm_rccl prover verifier ivc; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
 done
-/opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=thread -Wno-unused-function -Wno-pass-failed -c witness.hip -o $OUT/witness.o &
+for f in witness api; do   # api.hip: the hash-chain links that concurrent callers share (hash_links_shared), the completion words' table
+  /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=thread -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
+done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -o $OUT/libvpbs_hip.so $OUT/*.o
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.tsan-x86_64.so" | head -1)
@@ -19,7 +21,7 @@ trap 'cp $OUT/real.so "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so"' EXIT
 cd "$ROOT"
 # lanes forced on for every circuit size; the reports of the uninstrumented interpreter are not ours
 VPBS_LANE_MIN_ROWS=1 TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path=$OUT/report" LD_PRELOAD=$RT \
-  python -m pytest tests/test_step_circuit_cpu.py tests/test_cyclic_cpu.py -k "split_plan or ivc_chain or tampered" -x -q -m "not gpu" -p no:cacheprovider
+  python -m pytest tests/test_step_circuit_cpu.py tests/test_cyclic_cpu.py tests/test_host_cpu.py -k "split_plan or ivc_chain or tampered or hash_chains_of_concurrent" -x -q -m "not gpu" -p no:cacheprovider
 python3 - "$OUT" <<'PY'
 import glob, sys
 n = ours = 0
