@@ -82,41 +82,6 @@ struct SlotState {
     bool ready(u32 slot) const { return __atomic_load_n(&is_set[slot], __ATOMIC_ACQUIRE) != 0; }
 };
 
-// The value and flag arrays of finished states, kept for the next state of the same size: a chained proof every 8 ms means a fresh 16 MB
-// pair every 8 ms per chain otherwise, and first-touching those pages (kernel zeroing, page faults) was a third of the stager thread's CPU
-// time.  Process-wide, at most 1 GiB retained; the flags are cleared on reuse, the values need not be (nothing reads an unset slot).
-struct SlotBufPool {
-    std::mutex m;
-    std::vector<std::pair<Buf<u64>, Buf<uint8_t>>> free;
-    size_t bytes = 0;
-    static SlotBufPool& get() {
-        static SlotBufPool* pool = new SlotBufPool();   // never destroyed: states may be freed while the process exits
-        return *pool;
-    }
-    SlotState make(size_t n_slots, size_t n) {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            for (size_t i = 0; i < free.size(); ++i)
-                if (free[i].first.size() == n_slots) {
-                    SlotState s{std::move(free[i].first), std::move(free[i].second), n, {}};
-                    free.erase(free.begin() + (long)i);
-                    bytes -= 9 * n_slots;
-                    std::memset(s.is_set.data(), 0, n_slots);
-                    return s;
-                }
-        }
-        return SlotState{Buf<u64>(n_slots, false), Buf<uint8_t>(n_slots, true), n, {}};
-    }
-    void give(SlotState& s) {
-        if (!s.val.data() || !s.is_set.data()) return;
-        std::lock_guard<std::mutex> lk(m);
-        const size_t b = 9 * s.val.size();
-        if (bytes + b > (size_t(1) << 30)) return;   // the arrays die with the state
-        bytes += b;
-        free.emplace_back(std::move(s.val), std::move(s.is_set));
-    }
-};
-
 struct SlotRow {
     SlotState& s;
     const u32* rs;
@@ -992,7 +957,6 @@ struct vpbs_witness_state {
     vpbs::LevelPool* awake = nullptr;   // the late pool was left spinning for the next stage of this state: whoever runs it (or frees the state) ends it
     ~vpbs_witness_state() {
         if (awake) awake->end();
-        vpbs::SlotBufPool::get().give(s);
     }
 };
 
@@ -1521,7 +1485,7 @@ static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_
         t0 = t1;
     };
     // values stay unwritten until a generator sets them (the pages are then first touched by the pool's threads, not zeroed here by one)
-    auto* st = new vpbs_witness_state{SlotBufPool::get().make(p.n_slots, p.n)};
+    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
     SlotState& s = st->s;
     lap("state");
     for (size_t i = 0; i < p.preset_slot.size(); ++i)
@@ -1711,7 +1675,7 @@ int vpbs_witness_state_from_late_inputs(const vpbs_witness_plan* plan, const uin
     using namespace vpbs;
     if (!plan || !plan->is_split || !state_out || (!values && !plan->late_in_slots.empty())) return VPBS_ERR_INVALID;
     const vpbs_witness_plan& p = *plan;
-    auto* st = new vpbs_witness_state{SlotBufPool::get().make(p.n_slots, p.n)};
+    auto* st = new vpbs_witness_state{SlotState{Buf<u64>(p.n_slots, false), Buf<uint8_t>(p.n_slots, true), p.n, {}}};
     for (size_t k = 0; k < p.late_in_slots.size(); ++k) {
         if (values[k] >= gl::P) {
             delete st;
