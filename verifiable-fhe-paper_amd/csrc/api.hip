@@ -92,6 +92,14 @@ __global__ void sync_word_kernel(volatile u64* word, u64 seq) {
 std::mutex g_sync_words_mu;
 std::unordered_map<hipStream_t, std::unique_ptr<SyncWord>> g_sync_words;
 std::atomic<int> g_sync_word_mode{-1};   // vpbs_host_set_sync_word: -1 = environment (VPBS_SYNC_WORD), default on
+// VPBS_TRACE_SYNC: at exit, the waits that went through completion words and how many of them the 200 ms look at the runtime had to end
+// (a stream that was through without its word having moved: never seen; a soak prints 0)
+std::atomic<unsigned long> g_sync_waits{0}, g_sync_rescued{0};
+const bool g_sync_trace = [] {
+    if (!getenv("VPBS_TRACE_SYNC")) return false;
+    atexit([] { fprintf(stderr, "[sync] %lu waits on completion words, %lu ended by the runtime check\n", g_sync_waits.load(), g_sync_rescued.load()); });
+    return true;
+}();
 int sync_word_mode() {
     const int m = g_sync_word_mode.load(std::memory_order_relaxed);
     if (m >= 0) return m;
@@ -149,6 +157,7 @@ hipError_t stream_sync(hipStream_t s) {
                 const auto t_begin = std::chrono::steady_clock::now();
                 auto t_check = t_begin + std::chrono::milliseconds(200);
                 long waited_ns = 0;
+                g_sync_waits.fetch_add(1, std::memory_order_relaxed);
                 for (unsigned i = 0;; ++i) {
                     if (*w->host >= seq) return hipSuccess;
                     if (block && i >= 64) nap(waited_ns);
@@ -158,7 +167,10 @@ hipError_t stream_sync(hipStream_t s) {
                         waited_ns = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_begin).count();
                         if (now >= t_check) {
                             const hipError_t q = hipStreamQuery(s);
-                            if (q != hipErrorNotReady && *w->host < seq) return q == hipSuccess ? hipStreamSynchronize(s) : q;
+                            if (q != hipErrorNotReady && *w->host < seq) {   // the stream is through (or broken) and the word has not moved
+                                g_sync_rescued.fetch_add(1, std::memory_order_relaxed);
+                                return q == hipSuccess ? hipStreamSynchronize(s) : q;
+                            }
                             t_check = now + std::chrono::milliseconds(200);
                         }
                     }
