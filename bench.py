@@ -1125,9 +1125,11 @@ def main():
     # older, from 12 CPUs on.
     cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)          # this rank's share of the CPUs the container may use
     if args.device_witness < 0:
-        # 16 steps per batch inside the bench window (the timed region then holds whole batches and the run-in / tail stay short); whole
-        # chains (ivc_full_chains, tools/prove_ivc.py) use 64, which costs ~10 % less device time per step
-        args.device_witness = 16 if cpus < 12 else 0
+        # The batch (steps whose early phases run on the device at once) is half the timed steps, 8 .. 64: the timed region then holds two
+        # whole batches -- what a chain in steady state runs per that many proofs.  (A batch of 64 around a window of 60 steps would leave the
+        # early phases' device time outside the clock: 0.155 / 0.163 vPBS/s at 2 / 4 CPUs instead of the 0.145 / 0.152 of whole chains,
+        # tools/experiments/bench_batch_few_cpus.sh.)  Whole chains (ivc_full_chains, tools/prove_ivc.py) use 64: ~5 % less device time per step.
+        args.device_witness = max(8, min(64, args.steps // 2)) if cpus < 12 else 0
     if args.chains <= 0:
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
         # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most

@@ -525,6 +525,12 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
         const u64* items[SEG];
         u64 links[4 * SEG];
         for (unsigned s0 = 0; s0 < steps && !failed; s0 += SEG) {
+            {   // three batches ahead of the chain, no further: the batcher needs two, and the chains' hashing is spread over their whole
+                // length instead of a burst of 1.9 s of CPU per chain at the start (which a timed window further on would not see)
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || s0 < consumed + 3 * B; });
+                if (failed) return;
+            }
             const unsigned cnt = std::min(SEG, steps - s0);
             for (unsigned i = 0; i < cnt; ++i) items[i] = ggsw_of(s0 + i);
             if (vpbs_hash_chain_links(hb, items, cnt, ggsw_len, links) != 0) return fail("hash chain of the bootstrapping key: malformed arguments");
