@@ -357,8 +357,9 @@ unsigned vpbs_host_cpu_budget(void);
 int vpbs_host_set_late_threads(unsigned threads);
 /* How the library's host threads wait for the device.  0: hipStreamSynchronize (spins: lowest latency, one CPU per waiting thread -- a chain's
  * proving thread waits most of the time); 1: blocking (the thread polls the stream and sleeps in between: a wait ends up to ~50 us late,
- * next to no CPU while waiting); -1: default = the environment variable VPBS_BLOCKING_SYNC, else blocking when the process may use fewer than 8
- * CPUs.  Process-wide; returns the mode in force (vpbs_host_blocking_sync: the same without changing anything).  Measured with four chains per GPU on 2 CPUs: the spinning proving threads alone took both
+ * next to no CPU while waiting); -1: default = the environment variable VPBS_BLOCKING_SYNC, else AUTO: blocking when the process may use fewer
+ * than 8 CPUs (that is what vpbs_host_blocking_sync reports), and above that for every wait that finds more threads waiting for the device
+ * than a quarter of the CPUs -- one chain spins for its latency, eight chains on ten CPUs sleep.  Process-wide; returns the mode in force (vpbs_host_blocking_sync: the same without changing anything).  Measured with four chains per GPU on 2 CPUs: the spinning proving threads alone took both
  * CPUs (tools/prove_ivc.py VPBS_CPU_BY_ROLE). */
 int vpbs_host_set_blocking_sync(int on);
 int vpbs_host_blocking_sync(void);

@@ -71,7 +71,27 @@ int blocking_sync_mode() {
     }
     return a;
 }
-void blocking_sync_budget_changed() { g_blocking_auto.store(-1, std::memory_order_relaxed); }
+std::atomic<int> g_budget_cached{-1};    // the CPU budget as AUTO last saw it (read per wait)
+void blocking_sync_budget_changed() {
+    g_blocking_auto.store(-1, std::memory_order_relaxed);
+    g_budget_cached.store(-1, std::memory_order_relaxed);
+}
+// One wait's answer.  Explicit setting and environment as blocking_sync_mode(); AUTO sleeps below 8 CPUs, and above that whenever the threads
+// waiting for the device right now are more than a quarter of the CPUs: spinning is for the ONE chain that wants its latency, not for eight
+// proving threads on ten CPUs (measured: 0.137-0.141 vPBS/s spinning, 0.153-0.157 sleeping, 80 against 20-27 CPU-ms per proof;
+// tools/experiments/blocking_at_8_cpus.sh).  Six chains on 16 CPUs sleep as well: same throughput, half the CPU time.
+std::atomic<int> g_sync_waiters{0};
+static bool this_wait_sleeps(int waiters) {
+    if (g_blocking_sync.load(std::memory_order_relaxed) >= 0 || blocking_sync_mode()) return blocking_sync_mode() != 0;
+    static const bool env_says_spin = getenv("VPBS_BLOCKING_SYNC") != nullptr;   // set to 0: blocking_sync_mode() returned 0 because of it
+    if (env_says_spin) return false;
+    int budget = g_budget_cached.load(std::memory_order_relaxed);
+    if (budget < 0) {
+        budget = (int)vpbs_host_cpu_budget();
+        g_budget_cached.store(budget, std::memory_order_relaxed);
+    }
+    return waiters * 4 > budget;
+}
 
 // ---- completion words ----
 // Every wait INSIDE the runtime (hipStreamSynchronize, and equally the first hipStreamQuery on a busy stream) hands the stream's last command
@@ -147,7 +167,12 @@ static void nap(long waited_ns) {
     (void)nanosleep(&ts, nullptr);
 }
 hipError_t stream_sync(hipStream_t s) {
-    const bool block = blocking_sync_mode() != 0;
+    struct Waiter {
+        int n;
+        Waiter() : n(g_sync_waiters.fetch_add(1, std::memory_order_relaxed) + 1) {}
+        ~Waiter() { g_sync_waiters.fetch_sub(1, std::memory_order_relaxed); }
+    } waiter;
+    const bool block = this_wait_sleeps(waiter.n);
     if (sync_word_mode()) {
         if (SyncWord* w = sync_word_of(s)) {
             const u64 seq = w->seq.fetch_add(1, std::memory_order_relaxed) + 1;
