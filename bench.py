@@ -1132,10 +1132,12 @@ def main():
         args.device_witness = max(8, min(64, args.steps // 2)) if cpus < 12 else 0
     if args.chains <= 0:
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
-        # 16 CPUs (tools/experiments/chains_ab.sh): a chain per two CPUs, six at most
+        # 16 CPUs with spinning waits (tools/experiments/chains_ab.sh)
         # device pipeline: eight chains at every share (a chain's late phase and the scatter of its values are serial with its proof, and with
         # few CPUs they are long: 4 CPUs 0.145-0.149 with six chains, 0.152 with eight or ten; 2 CPUs 0.140 either way: tools/experiments/hw_queues_dw2.sh)
-        args.chains = 8 if args.device_witness else max(1, min(6, cpus // 2))
+        # host pipeline since the waits sleep (round 4): 6 / 7 / 8 / 9 / 10 / 12 chains = 8.17 / 8.02 / 7.99 / 8.21 / 8.13 / 8.19 ms per chained proof
+        # on 16 CPUs (tools/experiments/host_chains_16cpus.sh): a chain per two CPUs, eight at most (one per hardware queue)
+        args.chains = 8 if args.device_witness else max(1, min(8, cpus // 2))
 
     out, state = None, None
     if args.workload == "ivc":
