@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 # GPU (tools/experiments/hwq_ab.sh), 4 / 8 / 16 / 24 queues = 8.45-8.54 / 8.35-8.40 / 8.69-8.75 / 8.73-8.78 ms per chained proof with the host
 # witness pipeline and 8.72-8.74 / 8.32-8.35 / 8.31-8.32 / 8.58-8.66 with the device pipeline; with the waits on completion words (round 4) the
 # device pipeline -- a chain there has six streams -- gains from 16: 8.70 -> 8.48 on 16 CPUs, 9.49 -> 9.21 on 4 (tools/experiments/hw_queues_dw.sh),
-# the host pipeline loses (8.17 -> 8.38).  Read by the runtime when it starts: decided here, from the CPU share that later picks the pipeline.
+# the host pipeline loses (six chains 8.17 -> 8.38; eight chains 7.94-8.10 / 8.08-8.11 / 8.17-8.21 with 8 / 12 / 16: tools/experiments/host8_queues.sh).
+# Read by the runtime when it starts: decided here, from the CPU share that later picks the pipeline.
 def _cpu_share_before_hip():
     """this rank's share of the CPUs the container may use, without touching the library (the HIP runtime reads its environment when it starts):
     affinity mask and cgroup CPU quota, divided among the ranks of the node -- the figure vpbs_host_cpu_budget() / world gives later"""
