@@ -15,7 +15,8 @@ prover alone; the full-size parity check against the CPU oracle is made on that 
 
 Multi-GPU: independent chains per GPU ("replicas", weak scaling, no data-path collective; SURVEY.md 8e batch mode); --mode sharded: ONE
 chain whose every step proof is coset-sharded over the GPUs.
-Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: under torch.distributed.run, one rank per GPU)
+Launch: python bench.py [--gpus N --steps K --warmup W].  N > 1: either under torch.distributed.run (one rank per GPU; RANK / WORLD_SIZE in the
+environment), or plainly -- the process then is the PARENT: it touches no GPU and starts torch.distributed.run as a child (launch_ranks).
 """
 import argparse
 import json
@@ -44,6 +45,78 @@ def _cpu_share_before_hip():
         pass
     return max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
 
+
+def visible_gpus(top="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process could open, counted WITHOUT opening one (the launching parent must never initialise the device): the KFD topology
+    under /sys (a node with simd_count > 0 is a GPU), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.
+    Returns None where the topology is not readable -- the caller then lets the ranks find out."""
+    try:
+        nodes = os.listdir(top)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(top, node, "properties")) if len(line.split()) >= 2)
+        except OSError:      # not readable here: no count is better than a wrong one (a false refusal would waste a multi-GPU lease)
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no RANK / WORLD_SIZE in the environment): this process is the PARENT.
+    It touches no GPU -- it has imported neither torch nor the prover library at this point -- and starts the ranks as a CHILD process,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`
+    (one process per GPU over RCCL; never an exec: a process that has initialised the GPU must not be replaced, and this one stays clean
+    anyway), relays rank 0's single JSON line on stdout, everything else on stderr, and exits with the launcher's code.  Under an external
+    launcher (the driver's torch.distributed.run) the ranks find RANK / WORLD_SIZE and this function is never reached."""
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--device", type=int, default=None)
+    ap.add_argument("--mode", default="replicas")
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1 or known.mode == "sharded-replay" or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    if known.device is None:
+        have = visible_gpus()
+        if have is not None and have < known.gpus:
+            print("bench.py: --gpus %d but only %d GPU(s) visible (KFD topology / *_VISIBLE_DEVICES); pass --device D to run all ranks on one "
+                  "device on purpose" % (known.gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), VPBS_BENCH_SELF_LAUNCHED="1")
+    proc =subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = launch_ranks(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if _cpu_share_before_hip() < 12 else "8")
 
@@ -1041,6 +1114,49 @@ def subprocess_json(cmd, env, timeout):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def launch_report(args, rank, local_rank, world, distributed):
+    """What ran, for the reader of an N-GPU line (every rank calls this: it holds a collective): the ranks the communication library itself
+    counted (a one-word all-reduce of ones over the process group -- RCCL for the default backend), its version, the devices, who started the
+    ranks, the CPUs each rank was given.  The pipeline chosen from that share is added by main() once it is decided."""
+    info = {"ranks": 1, "backend": None, "what": "one-word all-reduce of ones over the process group of this run"}
+    if distributed:
+        ones = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        devs = [None] * world
+        dist.all_gather_object(devs, "%s:%d" % (os.uname().nodename, local_rank))
+        info.update(ranks=int(ones.item()), backend="rccl (torch.distributed 'nccl')" if args.dist_backend == "nccl" else args.dist_backend,
+                    devices=devs)
+    else:
+        info["what"] = "no process group at N = 1"
+    try:
+        info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:   # noqa: BLE001
+        info["version"] = "unavailable (%s)" % type(e).__name__
+    return {"rccl": info,
+            "launched_by": "bench.py itself (child process: python -m torch.distributed.run, one rank per GPU)" if os.environ.get("VPBS_BENCH_SELF_LAUNCHED")
+                           else ("an external launcher (RANK / WORLD_SIZE in the environment)" if distributed else "a plain process")}
+
+
+def sharded_ceiling(world):
+    """--mode sharded is ONE chain split over the GPUs (strong scaling, a latency tool): what a rank still has to compute, measured by replay on
+    one GPU with the collectives answered from a recording -- the ceiling of the speed-up, communication excluded"""
+    for name in ("r05_sharded_rank_times.json", "r04_sharded_rank_times.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            w = d.get("worlds", {}).get(str(world))
+            if not w:
+                return {"from": "profiles/" + name, "error": "no replay for world %d" % world}
+            return {"from": "profiles/" + name, "single_gpu_ms_per_step": d["single_gpu"]["wall_ms"], "slowest_rank_ms_per_step": w["T_rank_ms"],
+                    "compute_only_speedup_ceiling": w["compute_speedup_vs_single_gpu"],
+                    "replicated_kernel_ms": w["kernel_ms_replicated_groups"], "sharded_kernel_ms": w["kernel_ms_sharded_groups"],
+                    "what": "per-rank compute + transcript round trips of the coset-sharded synthetic step, each rank alone on one MI355X, "
+                            "collectives answered from a recording (bench.py --mode sharded-replay): the work that does not shrink with the "
+                            "number of ranks (tree tops, FRI trees, iNTT, partial products, PoW) bounds the strong-scaling speed-up here; "
+                            "near-linear scaling of vPBS proofs/s is what --mode replicas (the default) gives"}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1105,17 +1221,26 @@ def main():
             import subprocess
             print("bench.py: %s -- running tools/export_circuits.py (the build step) first" % str(e)[:120], file=sys.stderr)
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_circuits.py")], stdout=subprocess.DEVNULL)
+    if world != args.gpus:
+        # an 8-GPU lease must not turn into an N = 1 line: --gpus is what the line will claim, the ranks are what runs
+        print("bench.py: --gpus %d but %d rank(s) are running (WORLD_SIZE); start it as `python bench.py --gpus N` (it launches its own ranks) "
+              "or under torch.distributed.run with --nproc-per-node N" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if distributed:
-        assert world == args.gpus, "WORLD_SIZE must equal --gpus"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.device is not None:
         local_rank = args.device
+    elif distributed and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):   # counting devices does not open one
+        print("bench.py: rank %d: %d ranks on this node but %d device(s) visible; pass --device D to run all ranks on one device on purpose"
+              % (rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     if distributed:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=vpbs_amd.sharding.group_timeout())
         else:
             dist.init_process_group(args.dist_backend, timeout=vpbs_amd.sharding.group_timeout())
+    launch = launch_report(args, rank, local_rank, world, distributed)
     log_n = args.log_n
     secondary = rank == 0 and world == 1 and log_n == LOG_N
     # What a rank's share of the host CPUs carries (measured on one MI355X with the affinity mask as the share and 8 hardware queues,
@@ -1125,6 +1250,7 @@ def main():
     # share is below 12 CPUs -- the ranks of a multi-GPU node on a small container -- and the host pipeline, equal there and two rounds
     # older, from 12 CPUs on.
     cpus = vpbs_amd.api.host_set_cpu_budget(0) // max(1, world)          # this rank's share of the CPUs the container may use
+    dw_given = args.device_witness >= 0
     if args.device_witness < 0:
         # The batch (steps whose early phases run on the device at once) is half the timed steps, 8 .. 64: the timed region then holds two
         # whole batches -- what a chain in steady state runs per that many proofs.  (A batch of 64 around a window of 60 steps would leave the
@@ -1139,6 +1265,23 @@ def main():
         # host pipeline since the waits sleep (round 4): 6 / 7 / 8 / 9 / 10 / 12 chains = 8.17 / 8.02 / 7.99 / 8.21 / 8.13 / 8.19 ms per chained proof
         # on 16 CPUs (tools/experiments/host_chains_16cpus.sh): a chain per two CPUs, eight at most (one per hardware queue)
         args.chains = 8 if args.device_witness else max(1, min(8, cpus // 2))
+        chains_why = "auto"
+    else:
+        chains_why = "--chains / VPBS_BENCH_CHAINS"
+    launch["cpus_per_rank"] = cpus
+    launch["pipeline"] = {
+        "early_witness_phase": "device, %d steps per batch" % args.device_witness if args.device_witness else "host (a second thread per chain)",
+        "chains_per_gpu": 1 if (distributed and args.mode == "sharded") else args.chains, "chains_chosen_by": chains_why,
+        "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+        "why": ("--device-witness / VPBS_BENCH_DEVICE_WITNESS given" if dw_given else
+                "this rank's share of the host is %d CPU(s) (affinity mask and cgroup quota / ranks of the node): %s"
+                % (cpus, "below 12 the host cannot carry the early witness phases of eight chains, so they run on the device in batches and the "
+                         "host keeps the late phase (measured: 0.146-0.151 vPBS/s per GPU at 2 CPUs, 0.155-0.157 at 4; host pipeline there "
+                         "0.074 / 0.086)" if args.device_witness else
+                         "from 12 up the host pipeline is the faster one (0.166-0.172 against 0.161-0.163 on 16 CPUs), one chain per two CPUs, "
+                         "eight at most"))}
+    if distributed and args.mode == "sharded":
+        launch["sharded_ceiling"] = sharded_ceiling(world)
 
     out, state = None, None
     if args.workload == "ivc":
@@ -1179,6 +1322,7 @@ def main():
         out, state = measure_step(args, rank, local_rank, world, distributed, log_n)
 
     if rank == 0:
+        out.update(launch)
         if secondary and state is not None and not args.no_survey_size:
             out["survey_degree_2pow15"] = survey_size_leg(local_rank, args if args.workload == "step" else sargs, state)
         gpu_proof = state["gpu_proof"] if state is not None else None

@@ -577,6 +577,34 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert "cpu_baseline" not in d                                                              # N = 1 only
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher around it: the parent starts torch.distributed.run as a child process
+    and relays rank 0's line -- n_gpus = 2, the communication library's own count of the ranks, the CPUs per rank and the pipeline chosen.
+    Both ranks on the one device of the test box (--device 0), gloo for the process group."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, entry.ROOT + "/bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--device", "0",
+                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE line on stdout, everything else went to stderr
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"]) == (2, 12, 2, "weak")
+    assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["devices"]) == 2
+    assert d["launched_by"].startswith("bench.py itself") and d["cpus_per_rank"] >= 1
+    assert d["pipeline"]["chains_per_gpu"] == 1 and d["pipeline"]["early_witness_phase"].startswith("host")
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 * d["value"] + 1e-12
+    # more ranks than devices without --device: refused before any rank starts (the box shows one GPU)
+    import torch
+    n_dev = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, entry.ROOT + "/bench.py", "--gpus", str(2 * n_dev), "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "visible" in r.stderr
+
+
 def test_graft_entry_smoke_runs():
     """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- in its own process (it opens its own context)"""
     import subprocess

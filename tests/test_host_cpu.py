@@ -357,6 +357,76 @@ def test_recorded_bench_line_keeps_the_contract():
     assert d["ivc_chain_n2048"]["ms_per_step"] > d["ivc_single_chain"]["ms_per_step"] and d["ivc_chain"]["decrypted"] == d["ivc_chain"]["message"]
 
 
+def test_bench_parent_starts_the_ranks_without_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus N` outside a launcher is the PARENT of its ranks: it must import nothing that could open
+    the device -- neither torch nor the prover library -- start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+    process (never an exec) and relay one JSON line and the exit code.  Checked with stand-ins for `torch` and `vpbs_amd` at the head of
+    PYTHONPATH that record which process imported them: only the child may."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = tmp_path / "imports.log"
+    (tmp_path / "torch" / "distributed").mkdir(parents=True)
+    stamp = "import os\nopen(%r, 'a').write('%%s %%d %%d\\n' %% (__name__, os.getpid(), os.getppid()))\n" % str(log)
+    (tmp_path / "torch" / "__init__.py").write_text(stamp)
+    (tmp_path / "torch" / "distributed" / "__init__.py").write_text("")
+    (tmp_path / "vpbs_amd.py").write_text(stamp)
+    (tmp_path / "torch" / "distributed" / "run.py").write_text(
+        "import json, os, sys\n"
+        "print('rank chatter that is not the line')\n"
+        "print(json.dumps({'metric': 'm', 'argv': sys.argv[1:], 'self': os.environ.get('VPBS_BENCH_SELF_LAUNCHED'), 'pid': os.getpid(),\n"
+        "                  'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["PYTHONPATH"] = str(tmp_path)
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--device", "0", "--steps", "3"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=env)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0, err[-2000:]
+    lines = out.strip().splitlines()
+    assert len(lines) == 1 and "rank chatter" in err
+    d = json.loads(lines[0])
+    a = d["argv"]
+    assert a[a.index("--nproc-per-node") + 1] == "4" and a[a.index("--master-addr") + 1] == "127.0.0.1" and "--nnodes=1" in a
+    assert a[-6:] == ["--gpus", "4", "--device", "0", "--steps", "3"] and a[-7] == os.path.join(root, "bench.py")
+    assert d["self"] == "1" and d["ipc"] == "0" and d["pid"] != p.pid
+    seen = [ln.split() for ln in log.read_text().splitlines()]
+    assert seen and all(int(pid) != p.pid for _, pid, _ in seen)          # the parent imported neither stand-in
+    assert all(int(ppid) == p.pid for _, _, ppid in seen)                   # ... its child did (a child process, not an exec)
+    # the launcher's exit code is the parent's
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--device", "0"], capture_output=True, text=True,
+                       env=dict(env, FAKE_RC="7"), timeout=120)
+    assert r.returncode == 7
+    # fewer devices visible than ranks asked for and no --device: refused before anything starts (fake KFD topology: one GPU node, one CPU node)
+    top = tmp_path / "kfd"
+    for i, simd in enumerate((0, 256)):
+        (top / str(i)).mkdir(parents=True)
+        (top / str(i) / "properties").write_text("cpu_cores_count %d\nsimd_count %d\n" % (16 if simd == 0 else 0, simd))
+    sys.path.insert(0, root)
+    try:
+        import importlib
+        spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        sys.path.remove(root)
+    saved = {k: os.environ.pop(k, None) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    try:
+        assert bench.visible_gpus(str(top)) == 1 and bench.visible_gpus(str(tmp_path / "absent")) is None
+        os.environ["HIP_VISIBLE_DEVICES"] = ""                  # this container's own setting: no device
+        assert bench.visible_gpus(str(top)) == 0
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1"               # a mask cannot add devices
+        assert bench.visible_gpus(str(top)) == 1
+    finally:
+        os.environ.pop("HIP_VISIBLE_DEVICES", None)
+        os.environ.update({k: v for k, v in saved.items() if v is not None})
+    # under a launcher (RANK / WORLD_SIZE present) or at N = 1 the process is a rank, not a parent
+    assert bench.launch_ranks(["--gpus", "1"]) is None
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        assert bench.launch_ranks(["--gpus", "2"]) is None
+    finally:
+        del os.environ["WORLD_SIZE"]
+
+
 def test_proof_bytes_round_trip_and_verify():
     """data format behind the path: an (oracle) step proof serialised with the restated ProofWithPublicInputs::to_bytes layout is parsed
     back by the product (vpbs_step_proof_from_bytes) into the very arrays it came from, public inputs included, and the parsed proof
