@@ -529,7 +529,12 @@ typedef struct {
  * vpbs_rccl_available when no librccl.so can be loaded).  Cap hashes, query records and the quotient values move between device buffers
  * with ncclAllGather / ncclAllReduce on the context's stream.  Rank 0 makes the 128-byte id (ncclGetUniqueId) and the host hands it to
  * the other ranks (torch.distributed broadcast in bench.py, the launcher's channel in a C++ / Rust host); every rank of the node then
- * creates its communicator.  stage_words > 0: device staging for the on-device quotient (nc * local LDE length words per rank). */
+ * creates its communicator.  stage_words > 0: device staging for the on-device quotient (nc * local LDE length words per rank).
+ * VPBS_RCCL_LIB (environment, read once): the library to bind instead of the process's / the system's librccl.so -- the only candidate then.
+ * A collective that gets no answer within VPBS_COMM_TIMEOUT_S seconds (default 60) aborts the communicator (ncclCommAbort) and fails; every
+ * later call on it fails at once.  After that the context's stream may still hold the copies queued around the aborted collective:
+ * vpbs_comm_rccl_destroy gives them a bounded wait, and a stream that does not drain marks the context unusable (vpbs_last_error says so).
+ * The rank must then exit non-zero -- a process that has touched the GPU is never restarted in place. */
 int vpbs_rccl_available(void);
 int vpbs_rccl_unique_id(uint8_t id_out[128]);
 int vpbs_comm_rccl_create(vpbs_ctx* ctx, const uint8_t unique_id[128], unsigned rank, unsigned world, size_t stage_words, vpbs_comm* out);

@@ -201,6 +201,34 @@ def test_sharded_step_failure_semantics(world):
     assert "SHARDED_FAILURE_OK world=%d" % world in r.stdout
 
 
+def test_a_failed_launch_is_not_swallowed_by_the_next_wait():
+    """ADVICE r04: vpbs::stream_sync (every wait of the library: d2h_sync, vpbs_ctx_synchronize, the destructors) used to call hipGetLastError
+    after queuing its completion marker and so CLEARED a launch failure left pending on the thread -- the stage-end checks then saw success
+    and a proof could be built on buffers no kernel had written.  A launch that fails ahead of a wait (here: a null kernel through the same
+    HIP runtime, on this thread) must come back from the wait as an error, and the thread's error state must still hold it afterwards."""
+    import torch  # noqa: F401  (its bundled HIP runtime is the one the library is bound to)
+    c = vpbs_amd.Context(0, log_n_max=10)
+    c.synchronize()
+
+    class Dim3(ctypes.Structure):
+        _fields_ = [("x", ctypes.c_uint), ("y", ctypes.c_uint), ("z", ctypes.c_uint)]
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipLaunchKernel.argtypes = [ctypes.c_void_p, Dim3, Dim3, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipLaunchKernel.restype = ctypes.c_int
+    hip.hipPeekAtLastError.restype = ctypes.c_int
+    hip.hipGetLastError.restype = ctypes.c_int
+    assert hip.hipPeekAtLastError() == 0
+    rc = hip.hipLaunchKernel(None, Dim3(1, 1, 1), Dim3(1, 1, 1), None, 0, None)
+    assert rc != 0 and hip.hipPeekAtLastError() == rc, rc            # a launch-class error is pending on this thread
+    with pytest.raises(api.VpbsError):
+        c.synchronize()
+    assert hip.hipPeekAtLastError() == rc                              # reported, not consumed
+    assert hip.hipGetLastError() == rc and hip.hipPeekAtLastError() == 0
+    c.synchronize()                                                    # the state cleared by its owner: waits work again
+    c.close()
+
+
 def test_hand_scheduled_arithmetic_on_edge_values():
     """ADVICE r03: the non-canonical-residue paths of the inline-asm products (gl::mul_nc, dot2_nc, mad_nc, add_nn, fold96), of the gate
     kernels' lazy algebra products (times7, mul_lazy, fma2, select_lerp) and the permutation built from them, over every pair of
@@ -857,6 +885,43 @@ def test_context_options_choose_between_bit_identical_arrangements(ctx):
         for name, v in defaults.items():
             ctx.set_option(name, v)
     cs.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_communicator_world_gt1_on_one_gpu(world):
+    """csrc/comm_rccl.hip with MORE than one rank before hardware day.  The library binds the collective library named by
+    VPBS_RCCL_LIB -- here tests/fake_rccl.c, a test-only stand-in whose ranks are processes sharing this box's GPU and exchanging through
+    shared memory, stream-ordered like the real calls -- and vpbs_prove_step_sharded runs through vpbs_comm_rccl_create at world 2 / 4 / 8:
+    proofs bit-identical to the single-GPU proof, a failing rank => its own error there and VPBS_ERR_PEER everywhere else."""
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    fake = entry.build_fake_rccl()
+    script = os.path.join(ROOT, "tests", "fake_rccl_world_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                        "--master-port", str(29580 + world), script], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, VPBS_RCCL_LIB=fake, VPBS_TEST_SCENARIO="parity", VPBS_COMM_TIMEOUT_S="60"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "FAKE_RCCL_WORLD_OK world=%d" % world in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_communicator_times_out_on_an_absent_peer(world):
+    """A peer that never arrives: the survivors' collective polls its stream, gives up after VPBS_COMM_TIMEOUT_S = 3 s, aborts the
+    communicator (ncclCommAbort) and the sharded step returns an error on every surviving rank; later calls on the dead communicator fail at
+    once; vpbs_comm_rccl_destroy's bounded wait lets the stream drain before the staging buffers go back to the pool."""
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    fake = entry.build_fake_rccl()
+    script = os.path.join(ROOT, "tests", "fake_rccl_world_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                        "--master-port", str(29590 + world), script], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, VPBS_RCCL_LIB=fake, VPBS_TEST_SCENARIO="absent", VPBS_COMM_TIMEOUT_S="3"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "FAKE_RCCL_ABSENT_OK world=%d" % world in r.stdout
 
 
 @pytest.mark.gpu

@@ -103,7 +103,8 @@ static bool this_wait_sleeps(int waiters) {
 struct SyncWord {
     volatile u64* host = nullptr;   // hipHostMalloc, mapped: the device writes, the host reads
     u64* dev = nullptr;
-    std::atomic<u64> seq{0};
+    std::mutex mu;                  // a sequence number and the launch of its marker are one step
+    u64 seq = 0;
 };
 __global__ void sync_word_kernel(volatile u64* word, u64 seq) {
     __threadfence_system();
@@ -166,6 +167,21 @@ static void nap(long waited_ns) {
     timespec ts{0, std::min(200000L, std::max(30000L, waited_ns / 16))};
     (void)nanosleep(&ts, nullptr);
 }
+static bool launch_class_error(hipError_t e) {
+    switch (e) {
+        case hipErrorInvalidConfiguration:
+        case hipErrorLaunchOutOfResources:
+        case hipErrorLaunchFailure:
+        case hipErrorInvalidDeviceFunction:
+        case hipErrorIllegalAddress:
+        case hipErrorNoBinaryForGpu:
+        case hipErrorSharedObjectInitFailed:
+        case hipErrorLaunchTimeOut:
+            return true;
+        default:
+            return false;
+    }
+}
 hipError_t stream_sync(hipStream_t s) {
     struct Waiter {
         int n;
@@ -175,16 +191,31 @@ hipError_t stream_sync(hipStream_t s) {
     const bool block = this_wait_sleeps(waiter.n);
     if (sync_word_mode()) {
         if (SyncWord* w = sync_word_of(s)) {
-            const u64 seq = w->seq.fetch_add(1, std::memory_order_relaxed) + 1;
-            hipLaunchKernelGGL(sync_word_kernel, dim3(1), dim3(1), 0, s, w->dev, seq);
-            if (hipGetLastError() == hipSuccess) {
+            // A launch that failed earlier on this thread (bad configuration, out of resources) left its error pending and the buffers it should
+            // have written untouched: the wait reports it instead of waiting for work that was never queued -- and it must not CONSUME the
+            // thread's error state either (hipGetLastError here once hid such failures from the checks at the end of the stages: ADVICE r04).
+            // Only errors a launch or the device raises count: other calls of the process (a peer-access probe of the collective library, a
+            // stream query that answered "not ready") may leave benign codes behind which are not this library's to judge.
+            if (const hipError_t pending = hipPeekAtLastError(); launch_class_error(pending)) return pending;
+            // the sequence number is taken and its marker queued as one step: two threads waiting on the same stream see their markers in
+            // the order of their numbers, so the word never moves backwards and nobody returns before its own marker
+            u64 seq;
+            hipError_t launched;
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                seq = ++w->seq;
+                u64* word = w->dev;
+                void* args[] = {&word, &seq};
+                launched = hipLaunchKernel(reinterpret_cast<const void*>(&sync_word_kernel), dim3(1), dim3(1), args, 0, s);
+            }
+            if (launched == hipSuccess) {
                 // the runtime is asked only once in a long while: a stream that faulted never writes its word
                 const auto t_begin = std::chrono::steady_clock::now();
                 auto t_check = t_begin + std::chrono::milliseconds(200);
                 long waited_ns = 0;
                 g_sync_waits.fetch_add(1, std::memory_order_relaxed);
                 for (unsigned i = 0;; ++i) {
-                    if (*w->host >= seq) return hipSuccess;
+                    if (__atomic_load_n(w->host, __ATOMIC_ACQUIRE) >= seq) return hipSuccess;   // acquire: the copies in front of the marker are visible
                     if (block && i >= 64) nap(waited_ns);
                     else __builtin_ia32_pause();
                     if ((i & 0xff) == 0xff || (block && i >= 64)) {
@@ -192,7 +223,7 @@ hipError_t stream_sync(hipStream_t s) {
                         waited_ns = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_begin).count();
                         if (now >= t_check) {
                             const hipError_t q = hipStreamQuery(s);
-                            if (q != hipErrorNotReady && *w->host < seq) {   // the stream is through (or broken) and the word has not moved
+                            if (q != hipErrorNotReady && __atomic_load_n(w->host, __ATOMIC_ACQUIRE) < seq) {   // the stream is through (or broken) and the word has not moved
                                 g_sync_rescued.fetch_add(1, std::memory_order_relaxed);
                                 return q == hipSuccess ? hipStreamSynchronize(s) : q;
                             }

@@ -35,23 +35,29 @@ struct Rccl {
     decltype(&ncclGetErrorString) error_string = nullptr;
 };
 
-// The RCCL that is already in the process wins (a PyTorch process has loaded its own copy, built against the HIP runtime this library
-// binds to as well); otherwise the system one.
+// VPBS_RCCL_LIB names the library to bind (a site's own RCCL build; the test suite's stand-in that runs several ranks on one GPU) and is
+// the only candidate then: a path that does not load is an error, not a reason to fall back.  Otherwise the RCCL that is already in the
+// process wins (a PyTorch process has loaded its own copy, built against the HIP runtime this library binds to as well), then the system one.
 Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) {
-            r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-            if (r.handle) {
-                r.where = std::string(n) + " (already loaded)";
-                break;
+        if (const char* forced = std::getenv("VPBS_RCCL_LIB"); forced && *forced) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            r.where = std::string(forced) + (r.handle ? " (VPBS_RCCL_LIB)" : " (VPBS_RCCL_LIB: not loadable)");
+        } else {
+            const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) {
+                r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+                if (r.handle) {
+                    r.where = std::string(n) + " (already loaded)";
+                    break;
+                }
             }
-        }
-        for (size_t i = 0; !r.handle && i < sizeof names / sizeof *names; ++i) {
-            r.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) r.where = names[i];
+            for (size_t i = 0; !r.handle && i < sizeof names / sizeof *names; ++i) {
+                r.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+                if (r.handle) r.where = names[i];
+            }
         }
         if (!r.handle) return;
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.handle, "ncclGetUniqueId"));
@@ -229,7 +235,23 @@ int vpbs_comm_rccl_create(vpbs_ctx* ctx, const uint8_t unique_id[128], unsigned 
 void vpbs_comm_rccl_destroy(vpbs_comm* comm) {
     if (!comm || !comm->user || comm->allgather != &allgather_host) return;
     auto* c = static_cast<RcclComm*>(comm->user);
-    if (!c->dead) (void)vpbs::stream_sync(c->ctx->stream);
+    if (!c->dead) {
+        (void)vpbs::stream_sync(c->ctx->stream);
+    } else {
+        // The aborted collective's neighbours (the staging copies) may still be queued on the stream and they name the buffers released below:
+        // a bounded wait for the stream to drain; a stream that does not is left alone and the context says so.
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(c->ctx->stream)) == hipErrorNotReady &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0)
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (q != hipSuccess) {
+            c->ctx->err = "the stream did not drain after an aborted collective: this context must not be used again (exit non-zero)";
+            delete c;                           // the device buffers stay allocated: nothing may be handed the blocks a queued copy still names
+            std::memset(comm, 0, sizeof *comm);
+            return;
+        }
+    }
     if (Rccl* r = rccl(); r && c->comm) r->comm_destroy(c->comm);   // an aborted communicator is gone already
     c->ctx->release(c->d_small);
     if (c->d_stage_local) c->ctx->release(c->d_stage_local);
