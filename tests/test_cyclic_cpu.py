@@ -141,17 +141,40 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
                 partial[:sh.proof_words][stage_of[:sh.proof_words] > k] = 0xBAD   # words of later stages do not exist yet
                 staged.run_late_stage(st3, k, partial, packed)
             assert (staged.run_late_packed(st3, values, packed) == wires.reshape(-1)[staged.late_positions()]).all(), ahead
-        if cond:   # a wrong word of the FIRST section is noticed by the first stage already (the transcript and the cap connections are there)
-            bad = values.copy()
-            bad[5] ^= np.uint64(1)       # a word of the wires cap
-            st3 = staged.run_early(values, np.empty_like(wires))
-            try:
-                staged.run_late_stage(st3, 1, bad)
-                staged.run_late_stage(st3, 2, bad)
-                with pytest.raises(api.VpbsError):
-                    staged.run_late_packed(st3, bad)
-            except api.VpbsError:
-                api.lib().vpbs_witness_state_free(st3)
+        if cond and len(proofs) < 3:
+            # A wrong word of a section is noticed by the stage that reads it (the first section by the first stage already: the transcript and
+            # the cap connections are there) -- and the failure is the STATE's from then on: whether a slot mismatch or a generator
+            # that rejected its inputs (a gadget's range check, a PoseidonGate swap wire that is no bit), every later stage reports it again and
+            # run_late_packed fails instead of returning a witness built on a half-run stage.
+            tamper = {"wires cap": 5, "an opening": sh.caps_words + 3, "first FRI cap": fri0 + 1,
+                      "final polynomial": fri0 + sh.fri_words - 1 - 2 * sh.final_len, "proof-of-work witness": fri0 + sh.fri_words - 1}
+            kinds = set()
+            for what, at in tamper.items():
+                bad = values.copy()
+                bad[at] ^= np.uint64(1)
+                st3 = staged.run_early(values, np.empty_like(wires))
+                failed_at, first = None, ""
+                for k in range(1, R + 3):
+                    try:
+                        staged.run_late_stage(st3, k, bad)
+                    except api.VpbsError as e:
+                        failed_at, first = k, str(e)
+                        break
+                if what in ("wires cap", "an opening"):
+                    assert failed_at == 1, (what, failed_at)
+                if failed_at is None:            # a word that only moves a challenge: the query rounds (the last stage, in run_late) notice
+                    with pytest.raises(api.VpbsError):
+                        staged.run_late_packed(st3, bad)
+                    continue
+                kinds.add(first.split(": ", 1)[-1][:40])
+                if failed_at < R + 2:
+                    with pytest.raises(api.VpbsError, match="had failed"):
+                        staged.run_late_stage(st3, failed_at + 1, bad)
+                with pytest.raises(api.VpbsError, match="had failed"):
+                    staged.run_late_packed(st3, bad)                       # consumes the state
+            assert kinds, kinds
+            if os.environ.get("VPBS_TEST_VERBOSE"):
+                print("late-stage failures seen:", kinds)
         early_values = values.copy()
         early_values[:cy.shape.proof_words] = 0xDEAD                  # the late entries are not read by the early phase
         two = np.empty_like(wires)

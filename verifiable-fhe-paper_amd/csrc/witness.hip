@@ -955,6 +955,8 @@ struct vpbs_witness_state {
     unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
     unsigned stages_packed = 0; // ... and how many of them have their wires in the caller's packed buffer already
     vpbs::LevelPool* awake = nullptr;   // the late pool was left spinning for the next stage of this state: whoever runs it (or frees the state) ends it
+    int failed = 0;             // a stage run ahead failed with this status (a generator rejected its inputs; not only slot mismatches are sticky):
+    std::string failure;        // ... every later stage and run_late[_packed] report it again instead of building on a half-run stage
     ~vpbs_witness_state() {
         if (awake) awake->end();
     }
@@ -1533,6 +1535,12 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
         delete state;   // consumed whatever happens (header: only a state that never reached run_late is freed by the caller)
         return VPBS_ERR_INVALID;
     }
+    if (state->failed) {   // a stage that ran ahead failed: its generators did not all run, nothing later may be built on it
+        const int rc_ahead = state->failed;
+        report(err, err_len, "a late stage run ahead had failed: " + state->failure);
+        delete state;
+        return rc_ahead;
+    }
     const vpbs_witness_plan& p = *plan;
     SlotState& s = state->s;
     const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
@@ -1622,6 +1630,10 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
         report(err, err_len, "malformed arguments (stages run once each, in ascending order)");
         return VPBS_ERR_INVALID;
     }
+    if (state->failed) {
+        report(err, err_len, "an earlier late stage had failed: " + state->failure);
+        return state->failed;
+    }
     const vpbs_witness_plan& p = *plan;
     SlotState& s = state->s;
     const std::vector<u32>& pre = p.stage_presets[stage - 1];
@@ -1650,7 +1662,11 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
     const bool keep = stage + 1 == p.n_stages;
     const int rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg, presets, keep, keep ? &state->awake : nullptr);
     if (pack && rc == VPBS_OK) state->stages_packed = stage;
-    state->stages_done = stage;   // also after a failure: the state is only good for vpbs_witness_state_free / run_late (which reports again)
+    state->stages_done = stage;
+    if (rc != VPBS_OK) {          // the state is only good for vpbs_witness_state_free / run_late now, and both know: the failure is the state's
+        state->failed = rc;
+        state->failure = msg.empty() ? "stage " + std::to_string(stage) + " failed" : msg;
+    }
     report(err, err_len, msg);
     return rc;
 }
