@@ -479,6 +479,15 @@ const u64* vpbs_ctx::prescale(unsigned log_n, unsigned rb, u64 shift) {
     prescale_tables[key] = t;
     return t;
 }
+const u64* vpbs_ctx::lde_table(unsigned log_n, unsigned rb, u64 shift) {
+    auto key = std::make_tuple(log_n, rb, shift);
+    auto it = lde_tables.find(key);
+    if (it != lde_tables.end()) return it->second;
+    u64* t = alloc_words(vpbs::lde_table_words(log_n, rb));
+    vpbs::launch_lde_table(stream, t, log_n, rb, shift);
+    lde_tables[key] = t;
+    return t;
+}
 int vpbs_ctx::timer_id(const char* name) {
     for (size_t i = 0; i < timer_names.size(); ++i)
         if (timer_names[i] == name) return (int)i;
@@ -555,7 +564,7 @@ vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsign
             VPBS_HIP(hipMemcpyAsync(b->d_coeffs, d_in, sizeof(u64) * ncols * n, hipMemcpyDeviceToDevice, ctx->stream));
         }
         const u64* roots = ctx->roots(log_n, false);
-        const u64* ps = ctx->prescale(log_n, ctx->rate_bits, gl::GENERATOR);
+        const u64* ps = ctx->lde_table(log_n, ctx->rate_bits, gl::GENERATOR);
         {
             Timed t(ctx, "coset_lde");
             launch_coset_lde(ctx->stream, b->d_coeffs, b->d_lde, roots, ps, ncols, log_n, ctx->rate_bits, shard * b->blocks(),
@@ -652,6 +661,7 @@ void vpbs_ctx_destroy(vpbs_ctx* c) {
     if (c->d_clock_samples) c->release(c->d_clock_samples);
     for (auto& kv : c->root_tables) c->release(kv.second);
     for (auto& kv : c->prescale_tables) c->release(kv.second);
+    for (auto& kv : c->lde_tables) c->release(kv.second);
     for (auto& kv : c->l0_tables) c->release(kv.second);
     for (auto& kv : c->ring_tables) c->release(kv.second);
     c->resolve_timing();
@@ -964,7 +974,7 @@ int vpbs_k_coset_lde(vpbs_ctx* c, const uint64_t* coeffs, unsigned ncols, unsign
     return guarded(c, [&] {
         const size_t words = (size_t)ncols << log_n;
         DevTemp in(c, coeffs, words), out(c, nullptr, words << rate_bits);
-        vpbs::launch_coset_lde(c->stream, in.p, out.p, c->roots(log_n, false), c->prescale(log_n, rate_bits, shift), ncols, log_n,
+        vpbs::launch_coset_lde(c->stream, in.p, out.p, c->roots(log_n, false), c->lde_table(log_n, rate_bits, shift), ncols, log_n,
                                rate_bits);
         VPBS_HIP(hipMemcpyAsync(out_host, out.p, sizeof(u64) * (words << rate_bits), hipMemcpyDeviceToHost, c->stream));
         VPBS_HIP(vpbs::stream_sync(c->stream));

@@ -77,12 +77,14 @@ struct vpbs_ctx {
     // ---- tables ----
     std::map<std::pair<unsigned, bool>, vpbs::u64*> root_tables;                 // (log_n, inverse)
     std::map<std::tuple<unsigned, unsigned, vpbs::u64>, vpbs::u64*> prescale_tables;  // (log_n, rate_bits, shift)
+    std::map<std::tuple<unsigned, unsigned, vpbs::u64>, vpbs::u64*> lde_tables;       // (log_n, rate_bits, shift)
     std::map<unsigned, vpbs::u64*> ring_tables;  // log_N -> [ROOTS | INVROOTS] of the negacyclic NTT (params_{N}.rs), 2N words
     const vpbs::u64* ring_table(unsigned log_n_ring);
     std::map<unsigned, vpbs::u64*> l0_tables;  // log_n -> L_0 on the coset, leaf order
     const vpbs::u64* l0_table(unsigned log_n);
     const vpbs::u64* roots(unsigned log_n, bool inverse);
-    const vpbs::u64* prescale(unsigned log_n, unsigned rate_bits, vpbs::u64 shift);
+    const vpbs::u64* prescale(unsigned log_n, unsigned rate_bits, vpbs::u64 shift);    // plain powers (shift w_big^r)^i
+    const vpbs::u64* lde_table(unsigned log_n, unsigned rate_bits, vpbs::u64 shift);   // what launch_coset_lde reads (kernels.h)
 
     // ---- helper streams for the gate-constraint kernels (created on first use) ----
     hipStream_t gate_streams[2] = {nullptr, nullptr};

@@ -11,12 +11,18 @@ using gl::u64;
 
 // ---------- ntt.hip ----------
 // roots[j] = w^j, j < n, w = primitive n-th root (or its inverse for the inverse transform)
-// roots: root_table_words(log_n) words -- the n powers of w (w^-1 for inverse) followed by the transform kernels' round tables (twiddles in
-// the order the threads consume them, ntt.hip); every NTT launch below takes a table made here
+// roots: root_table_words(log_n) words -- the n powers of w (w^-1 for inverse) followed by the transform kernels' own tables for the PLAIN
+// transform of that direction (ntt.hip: from 2^12 points on the block twiddles tau^k of the radix-16 rounds, [round][k][block], with 1/n folded
+// into the first round of the inverse; at 2^11 the radix-8 round table)
 size_t root_table_words(unsigned log_n);
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse);
-// prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n
+// prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n  (a plain table of powers: the quotient's unshift table,
+// and the LDE table of transforms below 2^12 points)
 void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift);
+// the table launch_coset_lde wants for (log_n, rate_bits, shift): from 2^12 points on the block twiddles of every coset shift * w_big^r
+// (the shift is part of the twiddles: no prescale pass), [coset][round][k][block]; below that the prescale table
+size_t lde_table_words(unsigned log_n, unsigned rate_bits);
+void launch_lde_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift);
 // values -> coefficients, natural order in and out (PolynomialValues::ifft), batched over columns.
 // scratch: [ncols][n] device words (may alias nothing); in/out column-major.
 void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, const u64* inv_roots, unsigned ncols,
@@ -25,7 +31,8 @@ void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, co
 // i.e. out[c][j] = poly_c(shift * w_{big}^{brev_big(j)})   (PolynomialCoeffs::lde + coset_fft + reverse_index_bits)
 // block_first / n_blocks: compute only the leaf blocks [block_first, block_first + n_blocks) of the 2^rate_bits blocks
 // (a block = one coset = n consecutive leaves); out is then [ncols][n_blocks * n].  n_blocks = 0 means all blocks.
-void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* prescale, unsigned ncols,
+// lde_table: launch_lde_table's for the same (log_n, rate_bits, shift)
+void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* lde_table, unsigned ncols,
                       unsigned log_n, unsigned rate_bits, unsigned block_first = 0, unsigned n_blocks = 0);
 // batched negacyclic NTT of the reference (crypto/poly.rs:9-64): in place, [batch][n]; roots = ROOTS/INVROOTS table
 void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv);

@@ -201,7 +201,7 @@ void PolynomialBatch::prove_openings(vpbs_ctx* ctx, const FriInstanceInfo& insta
         t.values = words(2 * lde_len);
         {
             Timed tm(ctx, "fri_lde");
-            vpbs::launch_coset_lde(s, coeffs, t.values, ctx->roots(log_len, false), ctx->prescale(log_len, rate_bits, shift), 2, log_len,
+            vpbs::launch_coset_lde(s, coeffs, t.values, ctx->roots(log_len, false), ctx->lde_table(log_len, rate_bits, shift), 2, log_len,
                                    rate_bits);
         }
         const size_t dig_words = vpbs::merkle_layout(t.n_leaves, cap_h, t.level_off);
