@@ -635,6 +635,38 @@ STEP_ALGORITHMIC_MB = {"leaf hashing (3 launches)": 767.6, "Merkle levels": 100.
                        "FRI combine / divide / fold / LDE / openings / queries": 330.0, "FRI round trees": 26.0}
 
 
+def valu_budget(sclk_hz, step_ms):
+    """The WHOLE step against the bound that holds it: wave-level VALU instructions per step proof by kernel, from
+    the committed SQ_INSTS_VALU pass over the synthetic step (profiles/rNN_pmc_sq_kernels.csv: rocprofv3 --pmc, tools/pmc_kernels.sh; a
+    constant read from profiles/, like `traffic`), their sum / what 1024 SIMDs can issue at the clock measured inside this run's kernels =
+    the time the step's instruction stream needs when nothing waits; `frac` = that time / the measured wall time per step proof.  With
+    several chains per GPU every wait of one chain is filled by another, so frac is near 1 and throughput = instruction count."""
+    import csv
+    for name in ("r05_pmc_sq_kernels.csv", "r04_pmc_sq_kernels.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        rows = list(csv.DictReader(open(path)))
+        by = {r["kernel"]: r for r in rows}
+        if "leaf_hash_kernel" not in by:
+            continue
+        steps = float(by["leaf_hash_kernel"]["launches"]) / 3.0            # three leaf-hash launches per step proof
+        per = {k: float(r["SQ_INSTS_VALU"]) / steps / 1e9 for k, r in by.items() if float(r["SQ_INSTS_VALU"]) > 0}
+        total = sum(per.values())
+        top = dict(sorted(per.items(), key=lambda kv: -kv[1])[:8])
+        top["(all others)"] = total - sum(top.values())
+        issue = 256 * 4 / CEILING_CYCLES_PER_INSTR * sclk_hz                # wave64 instructions per second, chip-wide
+        floor_ms = total * 1e9 / issue * 1e3
+        return {"bound": "int-valu-issue (whole step)", "wave_instructions_per_step_G": total, "by_kernel_G": top,
+                "issue_peak_G_wave_instr_per_s": issue / 1e9, "shader_clock_mhz": sclk_hz / 1e6,
+                "instruction_time_ms_per_step": floor_ms, "measured_ms_per_step_proof": step_ms, "frac": floor_ms / step_ms,
+                "counters_from": "profiles/" + name + " (SQ_INSTS_VALU per kernel of the synthetic step / its step proofs; same kernels and "
+                                 "shapes as the chained step; a constant read from profiles/, not re-measured in this run)",
+                "what": "sum of the step's wave-level VALU instructions / (1024 SIMDs / %.2f cycles per instruction at the clock one wave of "
+                        "every timed leaf-hash launch measured) / wall time per step proof of the timed region" % CEILING_CYCLES_PER_INSTR}
+    return None
+
+
 def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches, measured_in, step_ms=None):
     """The dominant kernel (Poseidon leaf hashing), priced as the contract asks -- ALGORITHMIC bytes per launch / average launch duration against
     the HBM peak -- with the bound that really holds it (integer VALU issue) beside it as `int_valu_issue`.
@@ -682,6 +714,9 @@ def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches
            # kept at the top level for the scripts under tools/ that read them
            "int_issue_frac": achieved / peak, "shader_clock_mhz_in_kernel": sclk_mhz}
     if step_ms:
+        budget = valu_budget(sclk_hz, step_ms)
+        if budget is not None:
+            out["valu_budget"] = budget
         out["step_hbm_frac"] = step_total / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["step_algorithmic_bytes"] = {"total": step_total, "by_group_MB": STEP_ALGORITHMIC_MB,
                                          "what": "algorithmic bytes of one whole step proof / wall time per step proof of the timed region / 8 TB/s"}
@@ -1296,6 +1331,7 @@ def main():
             out["roofline"] = dict(r1["roofline"], measured_in="the ivc_single_chain leg of this run (one chain: every launch alone on the device; HIP "
                                                                "events on the prover's stream over its timed chained steps)",
                                    step_hbm_frac=conc.get("step_hbm_frac"), step_hbm_frac_single_chain=r1["roofline"].get("step_hbm_frac"),
+                                   valu_budget=conc.get("valu_budget"), valu_budget_single_chain=r1["roofline"].get("valu_budget"),
                                    concurrent_chains={"chains": args.chains, "kernel_ms_per_step": conc["kernel_ms_per_step"], "launches": conc["launches"],
                                                       "shader_clock_mhz_in_kernel": conc["shader_clock_mhz_in_kernel"],
                                                       "what": "the same kernel's event time per step proof inside the headline region, where launches "

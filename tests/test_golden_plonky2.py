@@ -64,7 +64,7 @@ def _switches(m):
     return {k: v for k, v in m.get("compat", {}).items()}
 
 
-def check_with_oracle(fx):
+def _check_with_oracle(fx):
     """the CPU oracle against the fixture"""
     import gates_oracle as go
     m = fx["meta"]
@@ -98,6 +98,37 @@ def check_with_oracle(fx):
         ch = [int(x) for x in p["challenges"]]
         zs = orc.partial_products(fx["witness_wires"][:m["n_routed"]], sig, ch[:nc], ch[nc:2 * nc])
         assert (zs == fx["zs_partial_products_values"]).all(), "Z / partial products"
+
+
+SWITCHES = ("fri_mul_final_by_x", "bytes_pi_len_prefix", "digest_domain_separator")
+
+
+def matching_positions(fx):
+    """Every position of the switch table (include/vpbs_prover.h `vpbs_compat`: 2^3 layouts) under which the CPU oracle reproduces the
+    fixture -- caps, openings, FRI words, circuit digest, proof bytes.  One capture run on a Rust machine has to settle SURVEY A.6 / A.8 without
+    a second: when the golden test fails under the recorded (or default) position, its message names the positions that WOULD match."""
+    import itertools
+    hits = []
+    for bits in itertools.product((0, 1), repeat=len(SWITCHES)):
+        pos = dict(zip(SWITCHES, bits))
+        trial = dict(fx, meta=dict(fx["meta"], compat={**orc.compat_dict(), **pos}))
+        try:
+            _check_with_oracle(trial)
+            hits.append(pos)
+        except AssertionError:
+            pass
+    return hits
+
+
+def check_with_oracle(fx):
+    try:
+        _check_with_oracle(fx)
+    except AssertionError as e:
+        hits = matching_positions(fx)
+        raise AssertionError("%s differs under the fixture's position %s of vpbs_compat; positions that reproduce the fixture: %s"
+                             % (e, json.dumps({**orc.compat_dict(), **_switches(fx["meta"])}),
+                                json.dumps(hits) if hits else "NONE of the 8 -- the difference is not one of the switches: see "
+                                "tools/plonky2_capture/README.md, 'What each captured file falsifies'")) from e
 
 
 def check_with_product(ctx, fx):
@@ -248,6 +279,21 @@ def test_public_api_capture_layout_converts_and_checks(tmp_path, position):
     assert fx["zs_partial_products_values"] is None and fx["meta"]["gates"]
     assert fx["meta"]["compat"] == {**orc.compat_dict(), **position} and fx["meta"]["forced_pow"] == int(p["fri"][-1])
     check_with_oracle(fx)
+    # a fixture whose recorded position is wrong (or absent: the defaults) fails with a message that names the position that WOULD match --
+    # one capture run settles SURVEY A.6 / A.8 without a second
+    assert matching_positions(fx) == [{k: {**orc.compat_dict(), **position}[k] for k in SWITCHES}]
+    wrong = dict(fx, meta=dict(fx["meta"], compat={**fx["meta"]["compat"], "fri_mul_final_by_x": 1 - fx["meta"]["compat"]["fri_mul_final_by_x"]}))
+    with pytest.raises(AssertionError, match="positions that reproduce the fixture") as ei:
+        check_with_oracle(wrong)
+    assert json.dumps({k: fx["meta"]["compat"][k] for k in SWITCHES}) in str(ei.value)
+    # --selftest: shapes against meta.json before any conversion; a truncated file and a missing one are named
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plonky2_capture", "to_fixture.py"), cap_dir, "--selftest"], capture_output=True, text=True)
+    assert r.returncode == 0 and "convertible" in r.stdout, r.stdout + r.stderr
+    with open(os.path.join(cap_dir, "step_000", "openings.u64"), "r+b") as f:
+        f.truncate(os.path.getsize(os.path.join(cap_dir, "step_000", "openings.u64")) - 16)
+    os.remove(os.path.join(cap_dir, "circuit", "representative_map.u64"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plonky2_capture", "to_fixture.py"), cap_dir, "--selftest"], capture_output=True, text=True)
+    assert r.returncode == 1 and "openings.u64 holds" in r.stdout and "representative_map.u64 missing" in r.stdout, r.stdout
     d = circuit_file.load(circ)
     assert (d.circuit.sigma_values() == sigma).all()                       # the forest -> copy constraints -> the captured sigma columns
     ok, msg = d.circuit.check_witness(fx["witness_wires"], api.hash_no_pad(fx["public_inputs"]))

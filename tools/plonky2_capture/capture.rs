@@ -157,6 +157,10 @@ pub fn prove_and_capture<F: RichField + Extendable<D>, C: GenericConfig<D, F = F
             Target::VirtualTarget { index } => (n * num_wires + index) as u64,
         }));
         write_u64(cdir.join("k_is.u64"), common_data.k_is.iter().map(c));
+        eprintln!("[vpbs capture] circuit: degree 2^{}, {} wires ({} routed), {} gate types, {} public inputs -> {}", common_data.degree_bits(),
+                  num_wires, num_routed, common_data.gates.len(), common_data.num_public_inputs, cdir.display());
     }
+    // one line per captured prove(): tools/plonky2_capture/README.md shows what a complete run prints
+    eprintln!("[vpbs capture] step {:03}: witness + proof ({} bytes) -> {}", step, proof_with_pis.to_bytes().len(), out.display());
     Ok(proof_with_pis)
 }

@@ -6,7 +6,8 @@
   * optionally the circuit as a STEPCIRC file (verifiable-fhe-paper_amd/circuit_file.py): gate per row from the selector columns, constants,
     copy constraints from the representative_map forest, public-input positions.  No generators: the witness of such a circuit comes from
     the Rust side (`generate_partial_witness`), the captured `witness_wires` being the first examples.
-usage: to_fixture.py CAPTURE_DIR OUT_FIXTURE_DIR [--step K] [--circuit OUT.bin]"""
+usage: to_fixture.py CAPTURE_DIR OUT_FIXTURE_DIR [--step K] [--circuit OUT.bin]
+       to_fixture.py CAPTURE_DIR --selftest        (shapes of every captured file against meta.json; nothing is converted)"""
 import json
 import os
 import re
@@ -123,6 +124,84 @@ def detect_compat(src, meta):
     return k, int(proof["fri"][-1])
 
 
+def expected_files(meta, kind):
+    """{file: word count (None: any positive multiple of `unit`)} of a capture directory, from its meta.json alone.  kind: "step" | "circuit"."""
+    n = 1 << meta["log_n"]
+    nc, nw, nr, nconst = meta["num_challenges"], meta["n_wires"], meta["n_routed"], meta["n_constants"]
+    qdf = meta.get("quotient_degree_factor", 8)
+    cap = 4 << meta.get("fri", {}).get("cap_height", meta.get("cap_height", 4))
+    if kind == "circuit":
+        # the forest covers the wire targets first (row * num_wires + column), then the virtual targets: at least n * num_wires entries
+        return {"constants_sigmas_values": (nconst + nr) * n, "representative_map": ("at least", n * nw), "public_input_targets": meta["n_public_inputs"]}
+    n_cs, n_zs, n_q = nconst + nr, nc * ((nr + qdf - 1) // qdf), nc * qdf
+    return {"witness_wires": nw * n, "constants_sigmas_values": n_cs * n, "constants_sigmas_cap": cap, "circuit_digest": 4,
+            "public_inputs": meta["n_public_inputs"], "caps": 3 * cap, "openings": ("openings", n_cs, nw, n_zs, n_q, nc), "fri": None}
+
+
+def selftest(cap_dir, steps=None):
+    """--selftest: the shapes of a capture directory against its own meta.json files, BEFORE any conversion (a run on the Rust machine is
+    expensive to repeat: this says at once whether everything a conversion needs was written, whole and in the expected sizes).  Returns the
+    list of problems (empty: the capture is convertible)."""
+    problems = []
+    dirs = sorted(d for d in os.listdir(cap_dir) if os.path.isdir(os.path.join(cap_dir, d)) and (d == "circuit" or re.fullmatch(r"step_\d+", d)))
+    if not any(d.startswith("step_") for d in dirs):
+        problems.append("no step_NNN directory under %s (was VPBS_CAPTURE_DIR set for the run?)" % cap_dir)
+    if "circuit" not in dirs:
+        problems.append("no circuit/ directory: capture.rs writes it at the first prove() of the cyclic circuit")
+    for d in dirs:
+        if steps is not None and d.startswith("step_") and int(d[5:]) not in steps:
+            continue
+        path = os.path.join(cap_dir, d)
+        mp = os.path.join(path, "meta.json")
+        if not os.path.exists(mp):
+            problems.append("%s: meta.json missing" % d)
+            continue
+        try:
+            meta = json.load(open(mp))
+        except ValueError as e:
+            problems.append("%s: meta.json does not parse (%s) -- a run cut off while writing?" % (d, e))
+            continue
+        need = ["log_n", "n_wires", "n_routed", "num_challenges", "n_constants", "n_public_inputs", "gate_ids"]
+        missing = [k for k in need if k not in meta]
+        if missing:
+            problems.append("%s: meta.json lacks %s" % (d, ", ".join(missing)))
+            continue
+        for name, want in expected_files(meta, "circuit" if d == "circuit" else "step").items():
+            f = os.path.join(path, name + ".u64")
+            if not os.path.exists(f):
+                problems.append("%s: %s.u64 missing" % (d, name))
+                continue
+            size = os.path.getsize(f)
+            if size % 8:
+                problems.append("%s: %s.u64 is %d bytes, not a whole number of u64 words" % (d, name, size))
+                continue
+            words = size // 8
+            if isinstance(want, tuple) and want[0] == "at least":
+                if words < want[1]:
+                    problems.append("%s: %s.u64 holds %d words, meta.json implies at least %d" % (d, name, words, want[1]))
+                continue
+            if isinstance(want, tuple):     # openings: constants + sigmas + wires + Z/pp + quotient at zeta, the Z's again at g zeta; 2 words each
+                _, n_cs, nw, n_zs, n_q, nc = want
+                want = 2 * (n_cs + nw + n_zs + n_q + nc)
+            if want is None:
+                if words == 0:
+                    problems.append("%s: %s.u64 is empty" % (d, name))
+            elif words != want:
+                problems.append("%s: %s.u64 holds %d words, meta.json implies %d" % (d, name, words, want))
+        if d != "circuit":
+            try:
+                for g in meta["gate_ids"]:
+                    parse_gate_id(g)
+            except ValueError as e:
+                problems.append("%s: %s" % (d, e))
+            a = np.fromfile(os.path.join(path, "witness_wires.u64"), dtype="<u8") if os.path.exists(os.path.join(path, "witness_wires.u64")) else None
+            if a is not None and a.size and int(a.max()) >= api.P:
+                problems.append("%s: witness_wires holds non-canonical field elements (>= p): written with to_noncanonical_u64?" % d)
+            if not os.path.exists(os.path.join(path, "proof_bytes.bin")):
+                problems.append("%s: proof_bytes.bin missing (the byte layout, SURVEY A.8, stays unpinned without it)" % d)
+    return problems
+
+
 def convert_step(cap_dir, step, out_dir):
     src = os.path.join(cap_dir, "step_%03d" % step)
     meta = json.load(open(os.path.join(src, "meta.json")))
@@ -214,7 +293,20 @@ def simulate_capture(cap_dir, gs, log_n, cs_values, n_constants, wires, desc, di
 
 def main():
     args = sys.argv[1:]
+    if "--selftest" in args:
+        cap_dir = [a for a in args if not a.startswith("--")][0]
+        problems = selftest(cap_dir)
+        for pr in problems:
+            print("selftest: " + pr)
+        print("selftest: %s" % ("%d problem(s): fix the capture before converting" % len(problems) if problems else
+                                 "capture directory is complete and its shapes agree with meta.json -- convertible"))
+        sys.exit(1 if problems else 0)
     cap_dir, out_dir = args[0], args[1]
+    problems = selftest(cap_dir, steps={int(args[args.index("--step") + 1]) if "--step" in args else 1})
+    if problems:
+        for pr in problems:
+            print("selftest: " + pr)
+        sys.exit("to_fixture.py: the capture directory is not convertible (run with --selftest for the whole list)")
     step = int(args[args.index("--step") + 1]) if "--step" in args else 1
     meta, gs = convert_step(cap_dir, step, out_dir)
     print("fixture: step %d, degree 2^%d, %d gates (ids and selector layout agree with the prover's), %d public inputs -> %s" %

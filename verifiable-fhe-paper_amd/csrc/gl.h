@@ -288,12 +288,46 @@ __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
         : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
+// lo + hi_lo 2^64 + hi_hi 2^96 (mod p) -> a u64 residue: the reduction tail of mul_nc on its own (8 VALU + 2 SALU), for values that are
+// 128 bits wide by construction (a field element times a power of two: the shifts inside the radix-16 NTT butterflies)
+__device__ __forceinline__ u64 reduce128_asm(u64 lo, u32 hi_lo, u32 hi_hi) {
+    u32 r0, r1;
+    asm("v_mad_u64_u32 " GL_P01 ", s[80:81], %3, -1, %2\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", %4\n\t"
+        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
+        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
+        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"(lo), "v"(hi_lo), "v"(hi_hi)
+        : GL_R0, GL_R1, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+    return ((u64)r1 << 32) | r0;
+}
+// lo + hi 2^64 (mod p) for hi < 2^32: u = hi (2^32 - 1) + lo as one v_mad_u64_u32, its carry-out selects the single +(2^32 - 1) correction
+// (the wrapped sum is below hi 2^32, so the corrected sum cannot wrap again).  4 VALU.
+__device__ __forceinline__ u64 reduce96_asm(u64 lo, u32 hi) {
+    u32 r0, r1;
+    asm("v_mad_u64_u32 " GL_P01 ", vcc, %3, -1, %2\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e64 %1, vcc, " GL_R1 ", 0, vcc"
+        : "=&v"(r0), "=&v"(r1)
+        : "v"(lo), "v"(hi)
+        : GL_R0, GL_R1, GL_R6, "vcc");
+    return ((u64)r1 << 32) | r0;
+}
 #else
 GL_HD u64 mul_nc(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide(a, b, lo, hi);
     return reduce128_nc(lo, hi);
 }
+GL_HD u64 reduce128_asm(u64 lo, u32 hi_lo, u32 hi_hi) { return reduce128_nc(lo, ((u64)hi_hi << 32) | hi_lo); }
+GL_HD u64 reduce96_asm(u64 lo, u32 hi) { return reduce128_nc(lo, hi); }
 // host forms of the device's fused products (same residue classes)
 GL_HD u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
     const unsigned __int128 s = (unsigned __int128)mul_nc(a, b) + mul_nc(c, d);

@@ -298,18 +298,12 @@ template <unsigned E>
 __device__ __forceinline__ u64 mul_2e(u64 x) {
     static_assert(E > 0 && E < 96 && E != 32 && E != 64, "shift out of range");
     if constexpr (E < 32) {
-        const u64 lo = x << E, hi = x >> (64 - E);  // x 2^E = lo + hi 2^64 = lo + hi (2^32 - 1)
-        const u64 t = (hi << 32) - hi;
-        u64 r = lo + t;
-        if (r < t) r += gl::EPS;
-        return gl::canon(r);
+        // x 2^E = lo + hi 2^64, hi < 2^E
+        return gl::canon(gl::reduce96_asm(x << E, (u32)(x >> (64 - E))));
     } else if constexpr (E < 64) {
-        const u64 lo = x << E, h = x >> (64 - E);   // h = h1 2^32 + h0: h 2^64 = h0 (2^32 - 1) - h1   (2^96 = -1)
-        const u64 h0 = h & gl::EPS, h1 = h >> 32;
-        const u64 t = (h0 << 32) - h0;
-        u64 r = lo + t;
-        if (r < t) r += gl::EPS;
-        return gl::sub(gl::canon(r), h1);
+        // x 2^E = lo + h 2^64, h = h1 2^32 + h0 < 2^E: the 128-bit reduction of a product (2^64 = 2^32 - 1, 2^96 = -1)
+        const u64 h = x >> (64 - E);
+        return gl::canon(gl::reduce128_asm(x << E, (u32)h, (u32)(h >> 32)));
     } else {
         constexpr unsigned F = E - 64;               // x 2^F = c 2^64 + b 2^32 + a  ->  (x 2^F) 2^64 = a (2^32 - 1) - b - c 2^32
         const u64 a = (x << F) & gl::EPS, b = (x >> (32 - F)) & gl::EPS, c = x >> (64 - F);
