@@ -29,6 +29,26 @@ __global__ void k_addnn(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(gl::add_nn(a[i], b[i]));
 }
+// the any-residue forms of the radix-16 NTT butterflies (round 5): add_a / sub_a with their rare second correction, the shift reductions
+__global__ void k_adda(const u64* a, const u64* b, u64* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gl::add_a(a[i], b[i]));
+}
+__global__ void k_suba(const u64* a, const u64* b, u64* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::canon(gl::sub_a(a[i], b[i]));
+}
+__global__ void k_subc(const u64* a, const u64* b, u64* out, int n) {   // gl::sub: canonical operands only
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl::sub(gl::canon(a[i]), gl::canon(b[i]));
+}
+__global__ void k_red(const u64* a, const u64* b, u64* out, int n) {    // out[2 i] = a + (b mod 2^32) 2^64, out[2 i + 1] = a + b 2^64
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[2 * i] = gl::canon(gl::reduce96_asm(a[i], (uint32_t)b[i]));
+        out[2 * i + 1] = gl::canon(gl::reduce128_asm(a[i], (uint32_t)b[i], (uint32_t)(b[i] >> 32)));
+    }
+}
 __global__ void k_times7(const u64* a, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(gates::times7(a[i]));
@@ -62,8 +82,17 @@ int main(int argc, char** argv) {
     std::mt19937_64 rng(1);
     std::vector<u64> a(n), b(n), out(n);
     const u64 edge[] = {0, 1, gl::P - 1, gl::P, ~0ull, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 1ull << 63};
+    // more of the top 2^32 of the u64 range (where a corrected sum or difference wraps a second time) and its neighbourhood
+    const u64 edge2[] = {gl::P + 1, ~0ull - 1, 0xFFFFFFFF00000002ull, 0xFFFFFFFEFFFFFFFFull, 0xFFFFFFFF7FFFFFFFull, 0xFFFFFFFFFFFF0000ull, 2, 0xFFFFFFFEull,
+                         0x1FFFFFFFFull, 0x7FFFFFFFFFFFFFFFull, 0x8000000000000001ull, 0xFFFFFFFE00000001ull};
     for (int i = 0; i < n; ++i) { a[i] = rng(); b[i] = rng(); }
     for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) { a[i * 9 + j] = edge[i]; b[i * 9 + j] = edge[j]; }
+    {
+        u64 all[21];
+        for (int i = 0; i < 9; ++i) all[i] = edge[i];
+        for (int i = 0; i < 12; ++i) all[9 + i] = edge2[i];
+        for (int i = 0; i < 21; ++i) for (int j = 0; j < 21; ++j) { a[128 + i * 21 + j] = all[i]; b[128 + i * 21 + j] = all[j]; }
+    }
     u64 *da, *db, *dout;
     CK(hipMalloc(&da, n * 8)); CK(hipMalloc(&db, n * 8)); CK(hipMalloc(&dout, n * 8));
     CK(hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
@@ -127,6 +156,37 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) if (out[i] != addm(a[i], b[i])) { if (bad < 5) printf("add_nn mismatch %d: %016lx + %016lx -> %016lx\n", i, a[i], b[i], out[i]); ++bad; }
         printf("add_nn: %d mismatches of %d\n", bad, n); total_bad += bad;
+        {   // any-residue add / sub (every pair of edge values wraps in some lanes of a wave and not in others), canonical sub, shift reductions
+            auto subm = [](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) + gl::P - (y % gl::P)) % gl::P); };
+            struct { const char* name; void (*k)(const u64*, const u64*, u64*, int); u64 (*want)(u64, u64); } cases[] = {
+                {"add_a", k_adda, +[](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) + (y % gl::P)) % gl::P); }},
+                {"sub_a", k_suba, +[](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) + gl::P - (y % gl::P)) % gl::P); }},
+                {"sub (asm)", k_subc, +[](u64 x, u64 y) { return (u64)(((unsigned __int128)(x % gl::P) + gl::P - (y % gl::P)) % gl::P); }}};
+            (void)subm;
+            for (auto& c : cases) {
+                bad = 0;
+                hipLaunchKernelGGL(c.k, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost));
+                for (int i = 0; i < n; ++i) if (out[i] != c.want(a[i], b[i])) { if (bad < 5) printf("%s mismatch %d: %016lx , %016lx -> %016lx\n", c.name, i, a[i], b[i], out[i]); ++bad; }
+                printf("%s: %d mismatches of %d\n", c.name, bad, n); total_bad += bad;
+            }
+            u64* dout2;
+            CK(hipMalloc(&dout2, 2 * n * 8));
+            std::vector<u64> out2(2 * n);
+            hipLaunchKernelGGL(k_red, dim3(n / 256), dim3(256), 0, 0, da, db, dout2, n);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(out2.data(), dout2, 2 * n * 8, hipMemcpyDeviceToHost));
+            bad = 0;
+            for (int i = 0; i < n; ++i) {
+                const unsigned __int128 two64 = (unsigned __int128)1 << 64;
+                const u64 w96 = (u64)((a[i] % gl::P + (unsigned __int128)(uint32_t)b[i] * (two64 % gl::P)) % gl::P);
+                const u64 w128 = (u64)((a[i] % gl::P + ((unsigned __int128)(b[i] % gl::P) * (two64 % gl::P)) % gl::P) % gl::P);
+                if (out2[2 * i] != w96 || out2[2 * i + 1] != w128) { if (bad < 5) printf("reduce mismatch %d: %016lx %016lx -> %016lx %016lx\n", i, a[i], b[i], out2[2 * i], out2[2 * i + 1]); ++bad; }
+            }
+            printf("reduce96 / reduce128: %d mismatches of %d\n", bad, n); total_bad += bad;
+            CK(hipFree(dout2));
+        }
         bad = 0;
         hipLaunchKernelGGL(k_times7, dim3(n / 256), dim3(256), 0, 0, da, dout, n);
         CK(hipDeviceSynchronize());

@@ -35,9 +35,24 @@ GL_HD u64 add(u64 a, u64 b) {
     return s;
 }
 GL_HD u64 sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_SUB_PLAIN)
+    // the borrow of the 64-bit difference selects the correction -(2^32 - 1) (= +p mod 2^64) directly: 5 VALU, where the compiler's form
+    // spends a sixth on a 64-bit compare to find the borrow again
+    u32 d0, d1, t;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&v"(t)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)d1 << 32) | d0;
+#else
     u64 d = a - b;
     if (a < b) d += P;
     return d;
+#endif
 }
 GL_HD u64 neg(u64 a) { return a ? P - a : 0; }
 
@@ -320,7 +335,54 @@ __device__ __forceinline__ u64 reduce96_asm(u64 lo, u32 hi) {
         : GL_R0, GL_R1, GL_R6, "vcc");
     return ((u64)r1 << 32) | r0;
 }
+// a + b and a - b for ANY u64 residues, a u64 residue out, always correct: the carry (borrow) of the 64-bit operation selects the correction
+// +-(2^32 - 1); the corrected value can wrap a second time only when both operands sit in the top 2^32 of the u64 range (for random data
+// once in 2^32 operations), and that case is a wave-level branch to a second correction that is practically never taken.  5 VALU each where
+// the canonical forms cost 6 / 5 and need canonical operands -- which costs every product and shift feeding them a 4-instruction canon.
+__device__ __forceinline__ u64 add_a(u64 a, u64 b) {
+    u32 r0, r1, t;
+    asm("v_add_co_u32_e32 %0, vcc, %3, %5\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32_e64 %1, vcc, 0, %1, vcc\n\t"
+        "s_cbranch_vccz .Lgl_add_a_%=\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32_e64 %1, vcc, 0, %1, vcc\n"
+        ".Lgl_add_a_%=:"
+        : "=&v"(r0), "=&v"(r1), "=&v"(t)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+__device__ __forceinline__ u64 sub_a(u64 a, u64 b) {
+    u32 r0, r1, t;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "s_cbranch_vccz .Lgl_sub_a_%=\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n"
+        ".Lgl_sub_a_%=:"
+        : "=&v"(r0), "=&v"(r1), "=&v"(t)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
 #else
+GL_HD u64 add_a(u64 a, u64 b) { return add_nn(a, b); }
+GL_HD u64 sub_a(u64 a, u64 b) {
+    u64 d = a - b;
+    if (a < b) {
+        const u64 e = d - EPS;
+        d = d < EPS ? e - EPS : e;
+    }
+    return d;
+}
 GL_HD u64 mul_nc(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide(a, b, lo, hi);

@@ -293,49 +293,51 @@ constexpr unsigned T16_LOG = 12, T16 = 1u << T16_LOG, T16_THREADS = 256;
 // bit 8 onto bit 4 (worked through in DESIGN.md 4).
 __device__ __forceinline__ constexpr unsigned swz(unsigned idx) { return idx ^ ((idx >> 4) & 15u) ^ (((idx >> 8) & 1u) << 4); }
 
-// x 2^E mod p for 0 < E < 96 (canonical in and out): the forms of gl::mul_2e24 / 48 / 72 for every multiple of 12
+// Inside a transform values are ARBITRARY u64 residues (gl::add_a / sub_a / mul_nc take and return any residue): no product, shift or sum
+// pays for a canonical form; the contiguous pass -- always the last -- canonicalises what it stores.
+// x 2^E mod p for 0 < E < 96 (any u64 in, a u64 residue out): the forms of gl::mul_2e24 / 48 / 72 for every multiple of 12
 template <unsigned E>
 __device__ __forceinline__ u64 mul_2e(u64 x) {
     static_assert(E > 0 && E < 96 && E != 32 && E != 64, "shift out of range");
     if constexpr (E < 32) {
         // x 2^E = lo + hi 2^64, hi < 2^E
-        return gl::canon(gl::reduce96_asm(x << E, (u32)(x >> (64 - E))));
+        return gl::reduce96_asm(x << E, (u32)(x >> (64 - E)));
     } else if constexpr (E < 64) {
         // x 2^E = lo + h 2^64, h = h1 2^32 + h0 < 2^E: the 128-bit reduction of a product (2^64 = 2^32 - 1, 2^96 = -1)
         const u64 h = x >> (64 - E);
-        return gl::canon(gl::reduce128_asm(x << E, (u32)h, (u32)(h >> 32)));
+        return gl::reduce128_asm(x << E, (u32)h, (u32)(h >> 32));
     } else {
         constexpr unsigned F = E - 64;               // x 2^F = c 2^64 + b 2^32 + a  ->  (x 2^F) 2^64 = a (2^32 - 1) - b - c 2^32
         const u64 a = (x << F) & gl::EPS, b = (x >> (32 - F)) & gl::EPS, c = x >> (64 - F);
-        const u64 pos = (a << 32) - a;
-        return gl::sub(pos, b + (c << 32));
+        const u64 pos = (a << 32) - a;               // < p
+        return gl::sub(pos, b + (c << 32));          // both canonical: the plain form
     }
 }
 
 // pure DFTs, natural order in, bit-reversed order out, in place; INV: with the inverse roots
 template <bool INV>
 __device__ __forceinline__ void dft4(u64& x0, u64& x1, u64& x2, u64& x3) {
-    const u64 b0 = gl::add(x0, x2), b2 = gl::sub(x0, x2), b1 = gl::add(x1, x3);
-    const u64 b3 = mul_2e<48>(INV ? gl::sub(x3, x1) : gl::sub(x1, x3));   // times w_4 = 2^48 (inverse: -2^48)
-    x0 = gl::add(b0, b1);
-    x1 = gl::sub(b0, b1);
-    x2 = gl::add(b2, b3);
-    x3 = gl::sub(b2, b3);
+    const u64 b0 = gl::add_a(x0, x2), b2 = gl::sub_a(x0, x2), b1 = gl::add_a(x1, x3);
+    const u64 b3 = mul_2e<48>(INV ? gl::sub_a(x3, x1) : gl::sub_a(x1, x3));   // times w_4 = 2^48 (inverse: -2^48)
+    x0 = gl::add_a(b0, b1);
+    x1 = gl::sub_a(b0, b1);
+    x2 = gl::add_a(b2, b3);
+    x3 = gl::sub_a(b2, b3);
 }
 template <bool INV>
 __device__ __forceinline__ void dft8(u64* x) {
     u64 a[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = gl::add(x[k], x[k + 4]);
-    a[4] = gl::sub(x[0], x[4]);
+    for (int k = 0; k < 4; ++k) a[k] = gl::add_a(x[k], x[k + 4]);
+    a[4] = gl::sub_a(x[0], x[4]);
     if (!INV) {
-        a[5] = mul_2e<24>(gl::sub(x[5], x[1]));   // (x1 - x5) w_8,   w_8 = -2^24
-        a[6] = mul_2e<48>(gl::sub(x[2], x[6]));   // w_8^2 = 2^48
-        a[7] = mul_2e<72>(gl::sub(x[7], x[3]));   // w_8^3 = -2^72
+        a[5] = mul_2e<24>(gl::sub_a(x[5], x[1]));   // (x1 - x5) w_8,   w_8 = -2^24
+        a[6] = mul_2e<48>(gl::sub_a(x[2], x[6]));   // w_8^2 = 2^48
+        a[7] = mul_2e<72>(gl::sub_a(x[7], x[3]));   // w_8^3 = -2^72
     } else {
-        a[5] = mul_2e<72>(gl::sub(x[1], x[5]));   // w_8^-1 = 2^72
-        a[6] = mul_2e<48>(gl::sub(x[6], x[2]));   // w_8^-2 = -2^48
-        a[7] = mul_2e<24>(gl::sub(x[3], x[7]));   // w_8^-3 = 2^24
+        a[5] = mul_2e<72>(gl::sub_a(x[1], x[5]));   // w_8^-1 = 2^72
+        a[6] = mul_2e<48>(gl::sub_a(x[6], x[2]));   // w_8^-2 = -2^48
+        a[7] = mul_2e<24>(gl::sub_a(x[3], x[7]));   // w_8^-3 = 2^24
     }
     dft4<INV>(a[0], a[1], a[2], a[3]);
     dft4<INV>(a[4], a[5], a[6], a[7]);
@@ -346,24 +348,24 @@ template <bool INV>
 __device__ __forceinline__ void dft16(u64* z) {
     u64 a[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = gl::add(z[k], z[k + 8]);
-    a[8] = gl::sub(z[0], z[8]);
+    for (int k = 0; k < 8; ++k) a[k] = gl::add_a(z[k], z[k + 8]);
+    a[8] = gl::sub_a(z[0], z[8]);
     if (!INV) {
-        a[9] = mul_2e<60>(gl::sub(z[9], z[1]));     // w_16   = -2^60
-        a[10] = mul_2e<24>(gl::sub(z[10], z[2]));   // w_16^2 = -2^24
-        a[11] = mul_2e<84>(gl::sub(z[3], z[11]));   // w_16^3 =  2^84
-        a[12] = mul_2e<48>(gl::sub(z[4], z[12]));   // w_16^4 =  2^48
-        a[13] = mul_2e<12>(gl::sub(z[5], z[13]));   // w_16^5 =  2^12
-        a[14] = mul_2e<72>(gl::sub(z[14], z[6]));   // w_16^6 = -2^72
-        a[15] = mul_2e<36>(gl::sub(z[15], z[7]));   // w_16^7 = -2^36
+        a[9] = mul_2e<60>(gl::sub_a(z[9], z[1]));     // w_16   = -2^60
+        a[10] = mul_2e<24>(gl::sub_a(z[10], z[2]));   // w_16^2 = -2^24
+        a[11] = mul_2e<84>(gl::sub_a(z[3], z[11]));   // w_16^3 =  2^84
+        a[12] = mul_2e<48>(gl::sub_a(z[4], z[12]));   // w_16^4 =  2^48
+        a[13] = mul_2e<12>(gl::sub_a(z[5], z[13]));   // w_16^5 =  2^12
+        a[14] = mul_2e<72>(gl::sub_a(z[14], z[6]));   // w_16^6 = -2^72
+        a[15] = mul_2e<36>(gl::sub_a(z[15], z[7]));   // w_16^7 = -2^36
     } else {
-        a[9] = mul_2e<36>(gl::sub(z[1], z[9]));     // w_16^-1 =  2^36
-        a[10] = mul_2e<72>(gl::sub(z[2], z[10]));   // w_16^-2 =  2^72
-        a[11] = mul_2e<12>(gl::sub(z[11], z[3]));   // w_16^-3 = -2^12
-        a[12] = mul_2e<48>(gl::sub(z[12], z[4]));   // w_16^-4 = -2^48
-        a[13] = mul_2e<84>(gl::sub(z[13], z[5]));   // w_16^-5 = -2^84
-        a[14] = mul_2e<24>(gl::sub(z[6], z[14]));   // w_16^-6 =  2^24
-        a[15] = mul_2e<60>(gl::sub(z[7], z[15]));   // w_16^-7 =  2^60
+        a[9] = mul_2e<36>(gl::sub_a(z[1], z[9]));     // w_16^-1 =  2^36
+        a[10] = mul_2e<72>(gl::sub_a(z[2], z[10]));   // w_16^-2 =  2^72
+        a[11] = mul_2e<12>(gl::sub_a(z[11], z[3]));   // w_16^-3 = -2^12
+        a[12] = mul_2e<48>(gl::sub_a(z[12], z[4]));   // w_16^-4 = -2^48
+        a[13] = mul_2e<84>(gl::sub_a(z[13], z[5]));   // w_16^-5 = -2^84
+        a[14] = mul_2e<24>(gl::sub_a(z[6], z[14]));   // w_16^-6 =  2^24
+        a[15] = mul_2e<60>(gl::sub_a(z[7], z[15]));   // w_16^-7 =  2^60
     }
     dft8<INV>(a);
     dft8<INV>(a + 8);
@@ -387,15 +389,15 @@ __device__ __forceinline__ void round16(u64 (&x)[16], const u64* __restrict__ tw
 #pragma unroll
     for (unsigned sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
-        for (unsigned k = SCALE0 ? 0 : 1; k < M; ++k) x[sub * M + k] = gl::mul(x[sub * M + k], t[sub * M + k]);
+        for (unsigned k = SCALE0 ? 0 : 1; k < M; ++k) x[sub * M + k] = gl::mul_nc(x[sub * M + k], t[sub * M + k]);
         u64* z = x + sub * M;
         if constexpr (Q == 4) dft16<INV>(z);
         else if constexpr (Q == 3) dft8<INV>(z);
         else if constexpr (Q == 2) dft4<INV>(z[0], z[1], z[2], z[3]);
         else {
             const u64 u = z[0], v = z[1];
-            z[0] = gl::add(u, v);
-            z[1] = gl::sub(u, v);
+            z[0] = gl::add_a(u, v);
+            z[1] = gl::sub_a(u, v);
         }
     }
 }
@@ -482,7 +484,7 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
         } else {
             __syncthreads();
 #pragma unroll
-            for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j)] = x[j];
+            for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j)] = gl::canon(x[j]);   // the transform's results leave in canonical form
             __syncthreads();
             u64* dst_col = out + blockIdx.y * out_col_stride;
             if (bitrev_out) {
