@@ -61,12 +61,12 @@ __global__ void k_alg(const u64* a, const u64* b, u64* out, int n) {   // out[4 
     out[4 * i] = gl::canon(m.a);
     out[4 * i + 1] = gl::canon(m.b);
     const gates::Alg<u64> f = gates::fma2(x, y, v, p);
-    out[4 * i + 2] = f.a;
-    out[4 * i + 3] = f.b;
+    out[4 * i + 2] = gl::canon(f.a);   // residues since round 5 (the evaluators' consumers take any residue)
+    out[4 * i + 3] = gl::canon(f.b);
 }
 __global__ void k_lerp(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = gates::select_lerp(gl::canon(a[i]), gl::canon(b[i]), a[(i + 5) % n]);
+    if (i < n) out[i] = gl::canon(gates::select_lerp(a[i], b[i], a[(i + 5) % n]));   // any residues in, a residue out
 }
 __global__ void k_perm(u64* st, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

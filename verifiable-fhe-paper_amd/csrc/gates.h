@@ -31,14 +31,33 @@ template <> struct Fld<u64> {
 template <> struct Fld<Ext> {
     static GL_HD Ext lift(u64 c) { return gl::ext(c); }
 };
+// The evaluators' arithmetic.  Generic form (GF(p^2) at zeta in the verifier, any host use): the canonical gl:: operations.  Base field on the
+// GPU: ANY u64 residues in and out (gl::add_a / sub_a / mul_nc / dot2_nc / mad_nc) -- wires and constants arrive canonical, everything computed
+// from them is a residue, and every consumer takes residues: these operations themselves, the Poseidon layers of poseidon.h and the sink
+// (its multiply-accumulate splits a u64 into halves whatever its value).  No product pays the 4-instruction canon that a canonical
+// addition or subtraction downstream would need, and the additions cost 5 instructions instead of 6 (round 5).
+template <class F> GL_HD F fadd(F a, F b) { return gl::add(a, b); }
+template <class F> GL_HD F fsub(F a, F b) { return gl::sub(a, b); }
+template <class F> GL_HD F fmul(F a, F b) { return gl::mul(a, b); }
+template <class F> GL_HD F fdot2(F a, F b, F c, F d) { return gl::add(gl::mul(a, b), gl::mul(c, d)); }   // a b + c d
+template <class F> GL_HD F fmad(F a, F b, F c) { return gl::add(gl::mul(a, b), c); }                       // a b + c
+#if defined(__HIP_DEVICE_COMPILE__)
+GL_HD u64 fadd(u64 a, u64 b) { return gl::add_a(a, b); }
+GL_HD u64 fsub(u64 a, u64 b) { return gl::sub_a(a, b); }
+GL_HD u64 fmul(u64 a, u64 b) { return gl::mul_nc(a, b); }
+GL_HD u64 fdot2(u64 a, u64 b, u64 c, u64 d) { return gl::dot2_nc(a, b, c, d); }   // the two 128-bit products added before ONE reduction
+GL_HD u64 fmad(u64 a, u64 b, u64 c) { return gl::mad_nc(a, b, c); }
+#endif
 // field element times a base-field constant.  On the GPU a constant below 2^32 (MDS entries, 7, bases, weights are NOT) takes
 // two multiply-adds and one fold instead of a full modular multiplication.
 GL_HD u64 mulc(u64 a, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_constant_p(c) && c < (1ull << 26))
-        return gl::canon(poseidon::fold96((u64)(u32)a * (u32)c, (u64)(u32)(a >> 32) * (u32)c));
-#endif
+        return poseidon::fold96((u64)(u32)a * (u32)c, (u64)(u32)(a >> 32) * (u32)c);   // any residue in, a residue out
+    return gl::mul_nc(a, c);
+#else
     return gl::mul(a, c);
+#endif
 }
 GL_HD Ext mulc(Ext a, u64 c) { return gl::mul(a, c); }
 
@@ -46,8 +65,8 @@ GL_HD Ext mulc(Ext a, u64 c) { return gl::mul(a, c); }
 template <class F> struct Alg {
     F a, b;
 };
-template <class F> GL_HD Alg<F> operator+(Alg<F> x, Alg<F> y) { return Alg<F>{gl::add(x.a, y.a), gl::add(x.b, y.b)}; }
-template <class F> GL_HD Alg<F> operator-(Alg<F> x, Alg<F> y) { return Alg<F>{gl::sub(x.a, y.a), gl::sub(x.b, y.b)}; }
+template <class F> GL_HD Alg<F> operator+(Alg<F> x, Alg<F> y) { return Alg<F>{fadd(x.a, y.a), fadd(x.b, y.b)}; }
+template <class F> GL_HD Alg<F> operator-(Alg<F> x, Alg<F> y) { return Alg<F>{fsub(x.a, y.a), fsub(x.b, y.b)}; }
 template <class F> GATES_FN Alg<F> operator*(Alg<F> x, Alg<F> y) {
     return Alg<F>{gl::add(gl::mul(x.a, y.a), mulc(gl::mul(x.b, y.b), 7)), gl::add(gl::mul(x.a, y.b), gl::mul(x.b, y.a))};
 }
@@ -55,32 +74,30 @@ template <class F> GATES_FN Alg<F> operator*(Alg<F> x, Alg<F> y) {
 // Base field on the GPU: (a + b X)(c + d X) = (a c + 7 b d) + (a d + b c) X as two FUSED products -- the 128-bit products of a component
 // are added before ONE reduction (gl::dot2_nc: 29 instructions instead of two multiplications and a modular addition, 48) -- and 7 d is
 // two multiply-adds and a fold.  times7 / mul_lazy expose the pieces for loops that multiply by one fixed element (the ReducingGates'
-// alpha) and whose consumers accept any u64 residue; operator* itself returns canonical components like the generic form.
+// alpha); like every base-field operation of the GPU evaluators they take and return u64 residues.
 GL_HD u64 times7(u64 x) { return poseidon::fold96((u64)(u32)x * 7u, (u64)(u32)(x >> 32) * 7u); }   // any residue in, a residue out
-// x * y with y7 = times7(y.b): components are u64 RESIDUES, not canonical -- fine as the first operand of gl::add / gl::sub with a
-// canonical second operand and as a constraint handed to the sink, nowhere else
+// x * y with y7 = times7(y.b)
 GL_HD Alg<u64> mul_lazy(Alg<u64> x, Alg<u64> y, u64 y7) {
     return Alg<u64>{gl::dot2_nc(x.a, y.a, x.b, y7), gl::dot2_nc(x.a, y.b, x.b, y.a)};
 }
 GL_HD Alg<u64> operator*(Alg<u64> x, Alg<u64> y) {   // a plain overload: preferred to the template above for the base field
-    const Alg<u64> r = mul_lazy(x, y, times7(y.b));
-    return Alg<u64>{gl::canon(r.a), gl::canon(r.b)};
+    return mul_lazy(x, y, times7(y.b));
 }
-// e t + v p (the step of the barycentric interpolation), canonical components
+// e t + v p (the step of the barycentric interpolation)
 GL_HD Alg<u64> fma2(Alg<u64> e, Alg<u64> t, Alg<u64> v, Alg<u64> p) {
     const Alg<u64> x = mul_lazy(e, t, times7(t.b)), y = mul_lazy(v, p, times7(p.b));
-    return Alg<u64>{gl::canon(gl::add_nn(x.a, y.a)), gl::canon(gl::add_nn(x.b, y.b))};
+    return Alg<u64>{gl::add_a(x.a, y.a), gl::add_a(x.b, y.b)};
 }
-// x + b (y - x) for canonical x, y and any residue b (RandomAccessGate's binary selection): one fused multiply-add
-GL_HD u64 select_lerp(u64 x, u64 y, u64 b) { return gl::canon(gl::mad_nc(b, gl::sub(y, x), x)); }
+// x + b (y - x) (RandomAccessGate's binary selection): one fused multiply-add
+GL_HD u64 select_lerp(u64 x, u64 y, u64 b) { return gl::mad_nc(b, gl::sub_a(y, x), x); }
 #endif
 template <class F> GL_HD F times7(F x) { return mulc(x, 7); }
 template <class F> GATES_FN Alg<F> mul_lazy(Alg<F> x, Alg<F> y, F) { return x * y; }
 template <class F> GATES_FN Alg<F> fma2(Alg<F> e, Alg<F> t, Alg<F> v, Alg<F> p) { return e * t + v * p; }
 template <class F> GL_HD F select_lerp(F x, F y, F b) { return gl::add(x, gl::mul(b, gl::sub(y, x))); }
-template <class F> GL_HD Alg<F> scale(Alg<F> x, F s) { return Alg<F>{gl::mul(x.a, s), gl::mul(x.b, s)}; }  // scalar_mul
+template <class F> GL_HD Alg<F> scale(Alg<F> x, F s) { return Alg<F>{fmul(x.a, s), fmul(x.b, s)}; }  // scalar_mul
 template <class F> GL_HD Alg<F> scalec(Alg<F> x, u64 c) { return Alg<F>{mulc(x.a, c), mulc(x.b, c)}; }
-template <class F> GL_HD Alg<F> sub_base(Alg<F> x, u64 c) { return Alg<F>{gl::sub(x.a, Fld<F>::lift(c)), x.b}; }
+template <class F> GL_HD Alg<F> sub_base(Alg<F> x, u64 c) { return Alg<F>{fsub(x.a, Fld<F>::lift(c)), x.b}; }
 
 // ---- Poseidon layers over F (hash/poseidon.rs constant_layer / sbox_layer / mds_layer and their *_field forms) ----
 template <class F> struct Pos {
@@ -104,7 +121,7 @@ template <class F> struct Pos {
 #if defined(__HIP_DEVICE_COMPILE__)
 // base field on the GPU: the multiply-add MDS and the hand-scheduled S-box of the hashing kernels (poseidon.h)
 template <> struct Pos<u64> {
-    static __device__ __forceinline__ u64 sbox(u64 x) { return gl::canon(poseidon::sbox(x)); }
+    static __device__ __forceinline__ u64 sbox(u64 x) { return poseidon::sbox(x); }
     static __device__ __forceinline__ void mds_then_constants(u64* s, int next_round) {
         if (next_round >= 0) {
             u64 kc[12];
@@ -114,8 +131,6 @@ template <> struct Pos<u64> {
         } else {
             poseidon::mds_add_const(s, nullptr);
         }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
     }
 };
 #endif
@@ -130,11 +145,11 @@ template <class F, class S> GL_HD void push_alg(S& s, Alg<F> x) {
 
 // gates/constant.rs: local_constants[i] - wire_output(i)
 template <class F, class V, class S> GATES_FN void eval_constant(const vpbs_gate& g, const V& v, S& s) {
-    for (unsigned i = 0; i < g.p0; ++i) s.push(gl::sub(v.constant(i), v.wire(i)));
+    for (unsigned i = 0; i < g.p0; ++i) s.push(fsub(v.constant(i), v.wire(i)));
 }
 // gates/public_input.rs: wires 0..4 - public_inputs_hash
 template <class F, class V, class S> GATES_FN void eval_public_input(const vpbs_gate&, const V& v, S& s) {
-    for (unsigned i = 0; i < 4; ++i) s.push(gl::sub(v.wire(i), Fld<F>::lift(v.pi_hash(i))));
+    for (unsigned i = 0; i < 4; ++i) s.push(fsub(v.wire(i), Fld<F>::lift(v.pi_hash(i))));
 }
 // gates/arithmetic_base.rs: output - (m0 m1 c0 + addend c1), wires 4i .. 4i+3
 template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_gate& g, const V& v, S& s) {
@@ -142,7 +157,7 @@ template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_ga
 #pragma unroll 4
     for (unsigned i = 0; i < g.p0; ++i) {
         const F m0 = v.wire(4 * i), m1 = v.wire(4 * i + 1), addend = v.wire(4 * i + 2), out = v.wire(4 * i + 3);
-        s.push(gl::sub(out, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(addend, c1))));
+        s.push(fsub(out, fdot2(fmul(m0, m1), c0, addend, c1)));
     }
 }
 // gates/base_sum.rs: reduce_with_powers(limbs, B) - sum; then prod_{k < B} (limb - k) per limb
@@ -158,10 +173,10 @@ template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate
         for (unsigned u = 0; u < 8; ++u) l[u] = lo + u < hi ? v.wire(1 + lo + u) : Fld<F>::lift(0);
 #pragma unroll
         for (unsigned u = 8; u-- > 0;)
-            if (lo + u < hi) acc = gl::add(mulc(acc, B), l[u]);
+            if (lo + u < hi) acc = fadd(B == 2 ? fadd(acc, acc) : mulc(acc, B), l[u]);
         hi = lo;
     }
-    s.push(gl::sub(acc, v.wire(0)));
+    s.push(fsub(acc, v.wire(0)));
     for (unsigned i0 = 0; i0 < n; i0 += 8) {
         F l[8];
 #pragma unroll
@@ -170,7 +185,7 @@ template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate
         for (unsigned u = 0; u < 8; ++u) {
             if (i0 + u >= n) break;
             F prod = l[u];
-            for (unsigned k = 1; k < B; ++k) prod = gl::mul(prod, gl::sub(l[u], Fld<F>::lift(k)));
+            for (unsigned k = 1; k < B; ++k) prod = fmul(prod, fsub(l[u], Fld<F>::lift(k)));
             s.push(prod);
         }
     }
@@ -181,26 +196,26 @@ template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate
 // every constraint -- unchanged.
 template <class F, class V, class S> GATES_FN void eval_poseidon(const vpbs_gate&, const V& v, S& s) {
     const F swap = v.wire(24);
-    s.push(gl::mul(swap, gl::sub(swap, Fld<F>::lift(1))));
+    s.push(fmul(swap, fsub(swap, Fld<F>::lift(1))));
     F st[12];
 #pragma unroll
     for (unsigned i = 0; i < 4; ++i) {
         const F lhs = v.wire(i), rhs = v.wire(i + 4), delta = v.wire(25 + i);
-        s.push(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
-        st[i] = gl::add(lhs, delta);
-        st[i + 4] = gl::sub(rhs, delta);
+        s.push(fsub(fmul(swap, fsub(rhs, lhs)), delta));
+        st[i] = fadd(lhs, delta);
+        st[i + 4] = fsub(rhs, delta);
     }
 #pragma unroll
     for (unsigned i = 8; i < 12; ++i) st[i] = v.wire(i);
 #pragma unroll
-    for (unsigned i = 0; i < 12; ++i) st[i] = gl::add(st[i], Fld<F>::lift(poseidon::rc(i)));  // constant_layer(round 0)
+    for (unsigned i = 0; i < 12; ++i) st[i] = fadd(st[i], Fld<F>::lift(poseidon::rc(i)));  // constant_layer(round 0)
     int round = 0;
     for (unsigned r = 0; r < 4; ++r, ++round) {  // first full rounds
         if (r != 0) {
 #pragma unroll
             for (unsigned i = 0; i < 12; ++i) {
                 const F in = v.wire(29 + 12 * (r - 1) + i);
-                s.push(gl::sub(st[i], in));
+                s.push(fsub(st[i], in));
                 st[i] = in;
             }
         }
@@ -210,7 +225,7 @@ template <class F, class V, class S> GATES_FN void eval_poseidon(const vpbs_gate
     }
     for (unsigned r = 0; r < 22; ++r, ++round) {  // partial rounds
         const F in = v.wire(65 + r);
-        s.push(gl::sub(st[0], in));
+        s.push(fsub(st[0], in));
         st[0] = Pos<F>::sbox(in);
         Pos<F>::mds_then_constants(st, round + 1);
     }
@@ -218,7 +233,7 @@ template <class F, class V, class S> GATES_FN void eval_poseidon(const vpbs_gate
 #pragma unroll
         for (unsigned i = 0; i < 12; ++i) {
             const F in = v.wire(87 + 12 * r + i);
-            s.push(gl::sub(st[i], in));
+            s.push(fsub(st[i], in));
             st[i] = in;
         }
 #pragma unroll
@@ -226,7 +241,7 @@ template <class F, class V, class S> GATES_FN void eval_poseidon(const vpbs_gate
         Pos<F>::mds_then_constants(st, round + 1 < 30 ? round + 1 : -1);
     }
 #pragma unroll
-    for (unsigned i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), st[i]));
+    for (unsigned i = 0; i < 12; ++i) s.push(fsub(v.wire(12 + i), st[i]));
 }
 // gates/poseidon_mds.rs: output_r - (MDS applied to 12 algebra elements); inputs 0..24, outputs 24..48
 template <class F, class V, class S> GATES_FN void eval_poseidon_mds(const vpbs_gate&, const V& v, S& s) {
@@ -250,7 +265,8 @@ template <class F, class V, class S> GATES_FN void eval_arithmetic_ext(const vpb
     for (unsigned i = 0; i < g.p0; ++i) {
         const Alg<F> m0 = wire_alg<F>(v, 8 * i), m1 = wire_alg<F>(v, 8 * i + 2), addend = wire_alg<F>(v, 8 * i + 4),
                      out = wire_alg<F>(v, 8 * i + 6);
-        push_alg(s, out - (scale(m0 * m1, c0) + scale(addend, c1)));
+        const Alg<F> mm = m0 * m1;
+        push_alg(s, out - Alg<F>{fdot2(mm.a, c0, addend.a, c1), fdot2(mm.b, c0, addend.b, c1)});
     }
 }
 // gates/multiplication_extension.rs: wires 6i: m0, m1, output
@@ -271,8 +287,8 @@ template <class F, class V, class S> GATES_FN void eval_reducing(const vpbs_gate
 #pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + n + 2 * i);
-        Alg<F> c = mul_lazy(acc, alpha, alpha7);   // residues (GPU): every use below has a canonical wire as its second operand
-        c.a = gl::add(c.a, v.wire(6 + i));
+        Alg<F> c = mul_lazy(acc, alpha, alpha7);
+        c.a = fadd(c.a, v.wire(6 + i));
         push_alg(s, c - next);
         acc = next;
     }
@@ -286,7 +302,7 @@ template <class F, class V, class S> GATES_FN void eval_reducing_ext(const vpbs_
 #pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
         const Alg<F> next = wire_alg<F>(v, i == n - 1 ? 0 : 6 + 2 * n + 2 * i);
-        push_alg(s, mul_lazy(acc, alpha, alpha7) + wire_alg<F>(v, 6 + 2 * i) - next);   // residue + canonical wire - canonical wire
+        push_alg(s, mul_lazy(acc, alpha, alpha7) + wire_alg<F>(v, 6 + 2 * i) - next);
         acc = next;
     }
 }
@@ -302,12 +318,12 @@ template <class F, unsigned BITS, class V, class S> GATES_FN void eval_random_ac
 #pragma unroll
         for (unsigned b = 0; b < BITS; ++b) {
             bit[b] = v.wire(bit0 + b);
-            s.push(gl::mul(bit[b], gl::sub(bit[b], Fld<F>::lift(1))));
+            s.push(fmul(bit[b], fsub(bit[b], Fld<F>::lift(1))));
         }
         F idx = Fld<F>::lift(0);
 #pragma unroll
-        for (unsigned b = BITS; b-- > 0;) idx = gl::add(gl::add(idx, idx), bit[b]);
-        s.push(gl::sub(idx, v.wire(base)));
+        for (unsigned b = BITS; b-- > 0;) idx = fadd(fadd(idx, idx), bit[b]);
+        s.push(fsub(idx, v.wire(base)));
         F items[vec];
 #pragma unroll
         for (unsigned i = 0; i < vec; ++i) items[i] = v.wire(base + 2 + i);
@@ -317,9 +333,9 @@ template <class F, unsigned BITS, class V, class S> GATES_FN void eval_random_ac
             for (unsigned i = 0; i < (vec >> (b + 1)); ++i)
                 items[i] = select_lerp(items[2 * i], items[2 * i + 1], bit[b]);
         }
-        s.push(gl::sub(items[0], v.wire(base + 1)));
+        s.push(fsub(items[0], v.wire(base + 1)));
     }
-    for (unsigned i = 0; i < extra; ++i) s.push(gl::sub(v.constant(i), v.wire((2 + vec) * copies + i)));
+    for (unsigned i = 0; i < extra; ++i) s.push(fsub(v.constant(i), v.wire((2 + vec) * copies + i)));
 }
 template <class F, class V, class S> GATES_FN void eval_random_access(const vpbs_gate& g, const V& v, S& s) {
     switch (g.p0) {
@@ -335,17 +351,18 @@ template <class F, class V, class S> GATES_FN void eval_random_access(const vpbs
 template <class F, class V, class S> GATES_FN void eval_exponentiation(const vpbs_gate& g, const V& v, S& s) {
     const unsigned n = g.p0;
     const F base = v.wire(0), one = Fld<F>::lift(1);
+    const F base_m1 = fsub(base, one);    // bit base + (1 - bit) = bit (base - 1) + 1
     F prev = one;
 #pragma unroll 4
     for (unsigned i = 0; i < n; ++i) {
-        const F sq = i == 0 ? one : gl::mul(prev, prev);
+        const F sq = i == 0 ? one : fmul(prev, prev);
         const F bit = v.wire(1 + (n - 1 - i));
-        const F computed = gl::mul(sq, gl::add(gl::mul(bit, base), gl::sub(one, bit)));
+        const F computed = fmul(sq, fmad(bit, base_m1, one));
         const F cur = v.wire(2 + n + i);
-        s.push(gl::sub(computed, cur));
+        s.push(fsub(computed, cur));
         prev = cur;
     }
-    s.push(gl::sub(v.wire(1 + n), prev));
+    s.push(fsub(v.wire(1 + n), prev));
 }
 // gates/coset_interpolation.rs.  Wires: shift 0, values 1..1+2*2^bits, evaluation_point, evaluation_value, then the
 // intermediate (eval, prod) pairs and the shifted evaluation point.  domain / weights: two_adic_subgroup(bits) and its
@@ -411,8 +428,8 @@ inline const CosetTables& coset_tables(unsigned bits) {
 template <class F> GL_HD F compute_filter(const vpbs_gate& g, F sel, bool many_selectors) {
     F f = Fld<F>::lift(1);
     for (unsigned i = g.group_start; i < g.group_end; ++i)
-        if (i != g.index) f = gl::mul(f, gl::sub(Fld<F>::lift(i), sel));
-    if (many_selectors) f = gl::mul(f, gl::sub(Fld<F>::lift(VPBS_UNUSED_SELECTOR), sel));
+        if (i != g.index) f = fmul(f, fsub(Fld<F>::lift(i), sel));
+    if (many_selectors) f = fmul(f, fsub(Fld<F>::lift(VPBS_UNUSED_SELECTOR), sel));
     return f;
 }
 

@@ -95,8 +95,8 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_md
     poseidon::mds_add_const(b, nullptr);
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        s.push(gl::sub(v.wire(24 + 2 * r), gl::canon(a[r])));
-        s.push(gl::sub(v.wire(25 + 2 * r), gl::canon(b[r])));
+        s.push(gl::sub_a(v.wire(24 + 2 * r), a[r]));
+        s.push(gl::sub_a(v.wire(25 + 2 * r), b[r]));
     }
 }
 
@@ -127,7 +127,7 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_ga
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const u64 in = v.wire(29 + 12 * (r - 1) + i);
-                s.push(gl::sub(gl::canon(st[i]), in));
+                s.push(gl::sub_a(st[i], in));
                 st[i] = in;
             }
         }
@@ -139,7 +139,7 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_ga
         u64 w[3], x[2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) w[i] = v.wire(65 + 3 * g + i);
-        s.push(gl::sub(gl::canon(st[0]), w[0]));
+        s.push(gl::sub_a(st[0], w[0]));
         poseidon::partial_group3_core<true>(st, g, w, x);
         s.push(gl::sub(x[0], w[1]));
         s.push(gl::sub(x[1], w[2]));
@@ -149,7 +149,7 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_ga
 #pragma unroll
         for (int i = 0; i < 12; ++i) kc[i] = rc(12 * 26 + i);
         const u64 in = v.wire(65 + 21);
-        s.push(gl::sub(gl::canon(st[0]), in));
+        s.push(gl::sub_a(st[0], in));
         st[0] = poseidon::sbox(in);
         poseidon::mds_add_const(st, kc);
     }
@@ -161,7 +161,7 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_ga
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const u64 in = v.wire(87 + 12 * r + i);
-            s.push(gl::sub(gl::canon(st[i]), in));
+            s.push(gl::sub_a(st[i], in));
             st[i] = in;
         }
 #pragma unroll
@@ -169,7 +169,7 @@ template <class Vars, class DevSink> __device__ __forceinline__ void poseidon_ga
         poseidon::mds_add_const(st, r < 3 ? kc : nullptr);
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), gl::canon(st[i])));
+    for (int i = 0; i < 12; ++i) s.push(gl::sub_a(v.wire(12 + i), st[i]));
 }
 
 // The PoseidonGate in independent pieces (the one-launch tile kernel gives them to different waves): every full round's S-box inputs are
@@ -205,7 +205,7 @@ template <int PART, class Vars, class DevSink> __device__ __forceinline__ void p
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const u64 in = v.wire(29 + 12 * r + i);
-                s.push(gl::sub(gl::canon(st[i]), in));
+                s.push(gl::sub_a(st[i], in));
                 st[i] = in;
             }
         }
@@ -227,7 +227,7 @@ template <int PART, class Vars, class DevSink> __device__ __forceinline__ void p
             u64 w[3], x[2];
 #pragma unroll
             for (int i = 0; i < 3; ++i) w[i] = v.wire(65 + 3 * g + i);
-            s.push(gl::sub(gl::canon(st[0]), w[0]));
+            s.push(gl::sub_a(st[0], w[0]));
             poseidon::partial_group3_core<true>(st, g, w, x);
             s.push(gl::sub(x[0], w[1]));
             s.push(gl::sub(x[1], w[2]));
@@ -237,12 +237,12 @@ template <int PART, class Vars, class DevSink> __device__ __forceinline__ void p
 #pragma unroll
             for (int i = 0; i < 12; ++i) kc[i] = rc(12 * 26 + i);
             const u64 in = v.wire(65 + 21);
-            s.push(gl::sub(gl::canon(st[0]), in));
+            s.push(gl::sub_a(st[0], in));
             st[0] = poseidon::sbox(in);
             poseidon::mds_add_const(st, kc);
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s.push(gl::sub(gl::canon(st[i]), v.wire(87 + i)));
+        for (int i = 0; i < 12; ++i) s.push(gl::sub_a(st[i], v.wire(87 + i)));
     }
     if constexpr (PART == 3) {
         s.idx = 75;
@@ -259,11 +259,11 @@ template <int PART, class Vars, class DevSink> __device__ __forceinline__ void p
             poseidon::mds_add_const(st, r < 3 ? kc : nullptr);
             if (r < 3) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) s.push(gl::sub(gl::canon(st[i]), v.wire(87 + 12 * (r + 1) + i)));
+                for (int i = 0; i < 12; ++i) s.push(gl::sub_a(st[i], v.wire(87 + 12 * (r + 1) + i)));
             }
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s.push(gl::sub(v.wire(12 + i), gl::canon(st[i])));
+        for (int i = 0; i < 12; ++i) s.push(gl::sub_a(v.wire(12 + i), st[i]));
     }
 }
 
