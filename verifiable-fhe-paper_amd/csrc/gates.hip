@@ -56,14 +56,16 @@ struct LazyAcc {
             : "v"(c0), "v"(c1), "s"(a0), "s"(a1)
             : "vcc");
     }
-    // e + 2^32 m + 2^64 h + 2^64 ce + 2^96 cm + 2^128 ch  (mod p), canonical;  2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32
+    // e + 2^32 m + 2^64 h + 2^64 ce + 2^96 cm + 2^128 ch  (mod p), a u64 residue;  2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32.
+    // The six pieces are first added as ONE 160-bit integer lo + H_lo 2^64 + hh 2^96 + top 2^128 (plain carries), which then takes a single
+    // 128-bit reduction and one subtraction -- a third of the instructions of reducing the pieces one by one (round 5).
     __device__ __forceinline__ u64 reduce() const {
-        u64 r = gl::canon(gl::reduce128_nc(e, h));                                   // e + 2^64 h
-        r = gl::add(r, gl::canon(gl::reduce128_nc(m << 32, m >> 32)));               // 2^32 m
-        r = gl::add(r, gl::mul((u64)ce, gl::EPS));
-        r = gl::sub(r, (u64)cm);
-        r = gl::sub(r, gl::canon((u64)ch << 32));
-        return r;
+        const u64 lo = e + (m << 32);
+        const u64 t = (m >> 32) + ce + (lo < e ? 1u : 0u);     // < 2^34
+        const u64 H = h + t;
+        const u64 hh = (H >> 32) + cm;                          // < 2^33
+        const u64 top = (u64)ch + (H < t ? 1u : 0u) + (hh >> 32);   // wrap-around counts: a few hundred at most
+        return gl::sub_a(gl::reduce128_asm(lo, (u32)H, (u32)hh), top << 32);
     }
 };
 template <int NC> struct DevSinkT {
