@@ -767,6 +767,7 @@ def measure_ivc(args, rank, local_rank, world, distributed):
     # one chain per GPU with the CPUs to spare: 14 threads for the late witness phase (its last stage is 28 independent FRI queries); several
     # chains per GPU: the default of 8 (14 each cost six chains 4 % of their throughput: tools/experiments/chains6_late_ab.sh)
     api.host_set_late_threads(api.late_threads_for(n_chains, api.host_cpu_budget()))
+    api.host_set_early_threads(api.early_threads_for(n_chains))
     chains, comm, native_comm = [], None, False
     for ci in range(n_chains):
         ctx = vpbs_amd.Context(local_rank, log_n_max=16)

@@ -355,6 +355,12 @@ unsigned vpbs_host_cpu_budget(void);
  * and has 16 CPUs sets 14 (two queries per thread: 11.5 instead of 12.1 ms per chained step); with several chains per GPU the default is the
  * better setting.  Results never depend on it. */
 int vpbs_host_set_late_threads(unsigned threads);
+/* Threads of the EARLY phase's pool for pools created afterwards (0 = default as above; VPBS_EARLY_THREADS overrides both; an explicit
+ * `threads` argument of run_early wins).  The early phase of a chained step runs AHEAD of the step's proof: with c chains per GPU a chain has
+ * c proof times to finish it in, and a pool spins between the phase's hundreds of dependency levels.  A host that runs four chains or more
+ * per process sets 1 (measured with eight chains on 16 CPUs: the same 7.6 ms per chained proof with 1, 2, 4 or 8 threads, 42 instead of 78
+ * CPU-ms per proof; tools/experiments/early_threads_ab.sh); one chain alone keeps the default.  Results never depend on it. */
+int vpbs_host_set_early_threads(unsigned threads);
 /* How the library's host threads wait for the device.  0: hipStreamSynchronize (spins: lowest latency, one CPU per waiting thread -- a chain's
  * proving thread waits most of the time); 1: blocking (the thread polls the stream and sleeps in between: a wait ends up to ~50 us late,
  * next to no CPU while waiting); -1: default = the environment variable VPBS_BLOCKING_SYNC, else AUTO: blocking when the process may use fewer

@@ -238,7 +238,7 @@ def generate():
 EXCERPT = [
     ("context, compatibility table, errors, host settings",
      ["vpbs_ctx_create", "vpbs_ctx_destroy", "vpbs_last_error", "vpbs_compat_default", "vpbs_ctx_set_compat", "vpbs_ctx_set_option", "vpbs_host_set_cpu_budget",
-      "vpbs_host_set_late_threads", "vpbs_host_set_blocking_sync", "vpbs_host_set_sync_word", "vpbs_hash_no_pad", "vpbs_hash_pad", "vpbs_hash_chain",
+      "vpbs_host_set_late_threads", "vpbs_host_set_early_threads", "vpbs_host_set_blocking_sync", "vpbs_host_set_sync_word", "vpbs_hash_no_pad", "vpbs_hash_pad", "vpbs_hash_chain",
       "vpbs_hash_chain_links", "vpbs_circuit_digest"]),
     ("PolynomialBatch / OpeningSet / prove_openings (fri/oracle.rs): the seam inside the patched plonky2",
      ["vpbs_commit_values", "vpbs_commit_coeffs", "vpbs_batch_free", "vpbs_batch_lde_rows", "vpbs_batch_eval_ext", "vpbs_batch_open", "vpbs_fri_proof_words",

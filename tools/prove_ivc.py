@@ -334,6 +334,7 @@ def main():
     n_chains = int(os.environ.get("VPBS_IVC_CHAINS", "1")) if world == 1 else 1
     # one chain on a host with the CPUs: 14 threads for the late witness phase (28 independent FRI queries in its last stage); several chains: the default
     api.host_set_late_threads(api.late_threads_for(n_chains, api.host_cpu_budget() // max(1, world)))
+    api.host_set_early_threads(api.early_threads_for(n_chains))
     torch.cuda.set_device(device)
     dist, comm, native, dist_device = None, None, False, None
     t_setup = time.perf_counter()

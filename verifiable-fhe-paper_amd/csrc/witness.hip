@@ -1430,6 +1430,7 @@ unsigned usable_cpus() {
 }
 
 std::atomic<unsigned> g_late_threads{0};   // vpbs_host_set_late_threads (0: default)
+std::atomic<unsigned> g_early_threads{0};  // vpbs_host_set_early_threads (0: default)
 unsigned default_phase_threads();
 // The late phase's pool: VPBS_LATE_THREADS, else vpbs_host_set_late_threads, else the default of every phase.  The last late stage of an
 // in-circuit verifier is 28 independent queries (strands): a host that runs ONE chain and has the CPUs asks for 14 (two queries per thread;
@@ -1461,6 +1462,10 @@ int vpbs_host_set_cpu_budget(unsigned cpus) {
 unsigned vpbs_host_cpu_budget(void) { return vpbs::usable_cpus(); }
 int vpbs_host_set_late_threads(unsigned threads) {
     vpbs::g_late_threads.store(threads);
+    return VPBS_OK;
+}
+int vpbs_host_set_early_threads(unsigned threads) {
+    vpbs::g_early_threads.store(threads);
     return VPBS_OK;
 }
 
@@ -1496,7 +1501,8 @@ static int run_early_impl(const vpbs_witness_plan* plan, const uint64_t* preset_
     std::string msg = s.error;
     if (threads == 0) {   // the environment variable overrides the default; the pool keeps the size of the phase's first run either way
         static const char* const e = std::getenv("VPBS_EARLY_THREADS");
-        threads = e ? (unsigned)std::max(1, atoi(e)) : default_phase_threads();
+        const unsigned set = g_early_threads.load();
+        threads = e ? (unsigned)std::max(1, atoi(e)) : (set ? set : default_phase_threads());
     }
     // the generators, then every wire takes its class's value: the late classes are still zero and are overwritten by run_late
     auto fill = [&](unsigned t, unsigned of) {
