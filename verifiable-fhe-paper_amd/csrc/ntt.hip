@@ -289,9 +289,12 @@ constexpr unsigned T16_LOG = 12, T16 = 1u << T16_LOG, T16_THREADS = 256;
 
 // LDS swizzle of the 4096-element tile (GF(2)-linear, a bijection).  A thread of a round owns the 16 indices base | (j << o); the lanes of
 // a ds_write_b64 group (16 lanes) / ds_read_b64 group (32 lanes) differ in the lowest 4 / 5 index bits outside [o, o + 4).  For every
-// o in 0..8 and for the linear order of the final read those lanes land on distinct bank pairs: bits 7..4 are folded onto bits 3..0 and
-// bit 8 onto bit 4 (worked through in DESIGN.md 4).
-__device__ __forceinline__ constexpr unsigned swz(unsigned idx) { return idx ^ ((idx >> 4) & 15u) ^ (((idx >> 8) & 1u) << 4); }
+// o in 0..8, for the linear order of the forward transform's final read and for the bit-reversed order of the inverse transform's (lanes
+// differ in bits 11..7) those lanes land on distinct bank pairs: bits 7..4 are folded onto bits 3..0, bit 8 onto bit 4 and bits 11..9
+// onto bits 2..0 (worked through in DESIGN.md 4).
+__device__ __forceinline__ constexpr unsigned swz(unsigned idx) {
+    return idx ^ ((idx >> 4) & 15u) ^ (((idx >> 8) & 1u) << 4) ^ ((idx >> 9) & 7u);
+}
 
 // Inside a transform values are ARBITRARY u64 residues (gl::add_a / sub_a / mul_nc take and return any residue): no product, shift or sum
 // pays for a canonical form; the contiguous pass -- always the last -- canonicalises what it stores.
@@ -414,13 +417,12 @@ struct Pass16 {
 
 // One pass of S = 4 (NR - 1) + QL stages.  STRIDED: stages [0, S) of the transform, rows = the top S index bits, a tile = all 2^S rows x
 // 2^(12-S) adjacent columns.  Otherwise: the last S stages, a tile = 4096 consecutive elements.  INV: inverse roots; the first round of the
-// first pass of an inverse transform also carries the factor 1/n (SCALE0).  bitrev_out (contiguous pass of an inverse transform): the result
-// goes to natural order.  in_block_stride: elements between the inputs of two leaf blocks (0: all cosets read one coefficient column; n: the
+// first pass of an inverse transform also carries the factor 1/n (SCALE0).  The contiguous pass of an inverse transform writes natural order.  in_block_stride: elements between the inputs of two leaf blocks (0: all cosets read one coefficient column; n: the
 // contiguous pass continuing in place).
 template <unsigned NR, unsigned QL, bool STRIDED, bool INV, bool SCALE0>
 __global__ void __launch_bounds__(T16_THREADS)
 ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a forward transform continues in place */, Pass16 P, unsigned log_n, size_t in_col_stride, size_t in_block_stride,
-             size_t out_col_stride, unsigned rate_bits, unsigned block_first, int bitrev_out) {
+             size_t out_col_stride, unsigned rate_bits, unsigned block_first) {
     constexpr unsigned S = 4 * (NR - 1) + QL;
     static_assert(NR >= 2 && NR <= 3 && QL >= 1 && QL <= 4 && S <= 12, "pass shape");
     static_assert(!STRIDED || S <= 10, "a strided tile keeps at least four adjacent columns");
@@ -433,10 +435,16 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
     const u64* tw = P.tables + (size_t)coset * P.coset_words;
     const size_t n = (size_t)1 << log_n;
     const size_t row_stride = n >> (STRIDED ? S : 0);       // strided: elements between two rows of the tile
-    const size_t tile_base = STRIDED ? ((size_t)blockIdx.x << LOG_C) : ((size_t)blockIdx.x << T16_LOG);
+    // The contiguous pass of an INVERSE transform writes natural order, position brev_L(g) for the element at g: its tile is not 4096
+    // consecutive elements but the 2^(12-S) blocks of 2^S elements whose block numbers differ in their TOP bits -- after the bit reversal
+    // those are the lowest address bits, so the tile's results form runs of 2^(12-S) consecutive elements (128 bytes at 2^16 points)
+    // instead of 4096 single words 2^(L-12) elements apart.
+    constexpr bool BITREV = INV && !STRIDED;
+    const size_t tile_base = STRIDED ? ((size_t)blockIdx.x << LOG_C) : (BITREV ? ((size_t)blockIdx.x << S) : ((size_t)blockIdx.x << T16_LOG));
     // global element of tile index idx
     auto gidx = [&](unsigned idx) -> size_t {
         if constexpr (STRIDED) return (size_t)(idx >> LOG_C) * row_stride + tile_base + (idx & ((1u << LOG_C) - 1u));
+        else if constexpr (BITREV && S < T16_LOG) return ((size_t)(idx >> S) << (log_n - T16_LOG + S)) | tile_base | (idx & ((1u << S) - 1u));
         else return tile_base + idx;
     };
     const u64* src = in + blockIdx.y * in_col_stride + blockIdx.z * in_block_stride;   // in_block_stride 0: every coset reads the same coefficients
@@ -449,7 +457,7 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
         const size_t step = STRIDED ? (row_stride << (o - LOG_C)) : ((size_t)1 << o);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = src[g0 + j * step];
-        const unsigned b = (unsigned)((STRIDED ? 0 : (tile_base >> (o + 4))) + (base >> (o + 4)));
+        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (g0 >> (o + 4)));   // the index bits above the butterfly's: its block
         round16<4, INV, SCALE0>(x, tw + P.round_off[0], (size_t)1 << P.round_t[0], b);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j << o)] = x[j];
@@ -461,7 +469,7 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = tile[swz(base) ^ swz(j << o)];
         __syncthreads();
-        const unsigned b = (unsigned)((STRIDED ? 0 : (tile_base >> (o + 4))) + (base >> (o + 4)));
+        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (gidx(base) >> (o + 4)));
         round16<4, INV, false>(x, tw + P.round_off[1], (size_t)1 << P.round_t[1], b);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j << o)] = x[j];
@@ -473,7 +481,7 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
         const unsigned base = owner_base(tid, o);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = tile[swz(base) ^ swz(j << o)];
-        const unsigned b = (unsigned)((STRIDED ? 0 : (tile_base >> (o + 4))) + (base >> (o + 4)));
+        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (gidx(base) >> (o + 4)));
         round16<QL, INV, false>(x, tw + P.round_off[NR - 1], (size_t)1 << P.round_t[NR - 1], b);
         if constexpr (STRIDED) {
             // rows base_row + j: the lanes of a wave still cover the adjacent columns
@@ -487,11 +495,14 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
             for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j)] = gl::canon(x[j]);   // the transform's results leave in canonical form
             __syncthreads();
             u64* dst_col = out + blockIdx.y * out_col_stride;
-            if (bitrev_out) {
+            if constexpr (BITREV) {
+                // e = (brev_S(u) << (12-S)) | brev(block-in-tile): consecutive e = consecutive addresses inside a run; the tile index it names is brev_12(e)
+                const size_t run_base = (size_t)gl::bitrev32(blockIdx.x, log_n - T16_LOG) << (T16_LOG - S);
 #pragma unroll
                 for (unsigned j = 0; j < 16; ++j) {
-                    const unsigned t = j * T16_THREADS + tid;
-                    dst_col[gl::bitrev32((unsigned)(tile_base + t), log_n)] = tile[swz(t)];
+                    const unsigned e = j * T16_THREADS + tid;
+                    const unsigned t = __brev(e) >> (32 - T16_LOG);
+                    dst_col[((size_t)(e >> (T16_LOG - S)) << (log_n - S)) | run_base | (e & ((1u << (T16_LOG - S)) - 1u))] = tile[swz(t)];
                 }
             } else {
                 u64* dst = dst_col + ((size_t)blockIdx.z << log_n) + tile_base;
@@ -587,11 +598,11 @@ void launch_table16(hipStream_t s, u64* table, unsigned log_n, unsigned n_cosets
 
 template <bool STRIDED, bool INV, bool SCALE0>
 void launch_pass16(hipStream_t s, unsigned nr, unsigned ql, dim3 grid, const u64* in, u64* out, const Pass16& P, unsigned log_n, size_t in_stride,
-                   size_t in_block_stride, size_t out_stride, unsigned rate_bits, unsigned block_first, int bitrev_out) {
+                   size_t in_block_stride, size_t out_stride, unsigned rate_bits, unsigned block_first) {
 #define VPBS_PASS16(NR_, QL_)                                                                                                              \
     if (nr == NR_ && ql == QL_) {                                                                                                          \
         hipLaunchKernelGGL((ntt16_kernel<NR_, QL_, STRIDED, INV, SCALE0>), grid, dim3(T16_THREADS), 0, s, in, out, P, log_n, in_stride,     \
-                           in_block_stride, out_stride, rate_bits, block_first, bitrev_out);                                               \
+                           in_block_stride, out_stride, rate_bits, block_first);                                                           \
         return;                                                                                                                            \
     }
     VPBS_PASS16(2, 1) VPBS_PASS16(2, 2) VPBS_PASS16(2, 3) VPBS_PASS16(2, 4)
@@ -623,18 +634,18 @@ void run_transform16(hipStream_t s, const u64* in, u64* out, u64* scratch, const
     const unsigned tiles = (unsigned)(n >> T16_LOG);
     if (!p.A) {
         launch_pass16<false, INV, INV>(s, p.c_nr, p.c_ql, dim3(tiles, ncols, n_blocks), in, out, cp, log_n, in_stride, (size_t)0, out_stride, rate_bits,
-                                       block_first, INV ? 1 : 0);
+                                       block_first);
         return;
     }
     if (INV) {
         // strided pass into scratch ([ncols][n]), contiguous pass from there to natural order in `out`
-        launch_pass16<true, true, true>(s, p.s_nr, p.s_ql, dim3(tiles, ncols, 1), in, scratch, sp, log_n, in_stride, (size_t)0, n, 0u, 0u, 0);
-        launch_pass16<false, true, false>(s, p.c_nr, p.c_ql, dim3(tiles, ncols, 1), (const u64*)scratch, out, cp, log_n, n, (size_t)0, out_stride, 0u, 0u, 1);
+        launch_pass16<true, true, true>(s, p.s_nr, p.s_ql, dim3(tiles, ncols, 1), in, scratch, sp, log_n, in_stride, (size_t)0, n, 0u, 0u);
+        launch_pass16<false, true, false>(s, p.c_nr, p.c_ql, dim3(tiles, ncols, 1), (const u64*)scratch, out, cp, log_n, n, (size_t)0, out_stride, 0u, 0u);
     } else {
         launch_pass16<true, false, false>(s, p.s_nr, p.s_ql, dim3(tiles, ncols, n_blocks), in, out, sp, log_n, in_stride, (size_t)0, out_stride,
-                                          rate_bits, block_first, 0);
+                                          rate_bits, block_first);
         launch_pass16<false, false, false>(s, p.c_nr, p.c_ql, dim3(tiles, ncols, n_blocks), (const u64*)out, out, cp, log_n, out_stride, n, out_stride,
-                                           rate_bits, block_first, 0);
+                                           rate_bits, block_first);
     }
 }
 }  // namespace
