@@ -683,7 +683,7 @@ def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches
     peak = 256 * 4 * 64 / CEILING_CYCLES_PER_INSTR * sclk_hz / 1e12
     hbm = bytes_step / secs / 1e9
     traffic, traffic_from = None, None
-    for tname in ("r04_pmc_leaf_hash.json", "r03_pmc_leaf_hash.json", "r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
+    for tname in ("r05_pmc_leaf_hash.json", "r04_pmc_leaf_hash.json", "r03_pmc_leaf_hash.json", "r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
