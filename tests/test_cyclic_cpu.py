@@ -141,6 +141,28 @@ def run_chain(cy, dm, C, D, prove_c, prove_d, keys, ct, acc_init, check=True):
                 partial[:sh.proof_words][stage_of[:sh.proof_words] > k] = 0xBAD   # words of later stages do not exist yet
                 staged.run_late_stage(st3, k, partial, packed)
             assert (staged.run_late_packed(st3, values, packed) == wires.reshape(-1)[staged.late_positions()]).all(), ahead
+        if cond and len(proofs) == 1:
+            # Two states of ONE plan with stages run ahead: the stage before the last leaves the late pool's workers spinning for
+            # "its" state.  B takes the pool after A was promised it; freeing A then must not put the workers of B's runs to sleep (A holds a
+            # token the later run invalidated, not the pool), and B's late phase completes with the right wires.
+            ma, mb = np.empty_like(wires), np.empty_like(wires)
+            st_a = staged.run_early(values, ma)
+            for k in range(1, R + 3):
+                staged.run_late_stage(st_a, k, values)
+            st_b = staged.run_early(values, mb)
+            for k in range(1, R + 3):
+                staged.run_late_stage(st_b, k, values)
+            api.lib().vpbs_witness_state_free(st_a)
+            assert (staged.run_late_packed(st_b, values) == wires.reshape(-1)[staged.late_positions()]).all()
+            # ... and a state that outlives a re-split of its plan still frees cleanly (it shares the pool's ownership)
+            other = cy.built.circuit.witness_plan(cy.positions)
+            other.split(stage_of)
+            st_c = other.run_early(values, ma)
+            for k in range(1, R + 3):
+                other.run_late_stage(st_c, k, values)
+            other.split(late)                      # one-stage split: the staged pools are dropped
+            api.lib().vpbs_witness_state_free(st_c)
+            other.free()
         if cond and len(proofs) < 3:
             # A wrong word of a section is noticed by the stage that reads it (the first section by the first stage already: the transcript and
             # the cap connections are there) -- and the failure is the STATE's from then on: whether a slot mismatch or a generator

@@ -954,12 +954,18 @@ struct vpbs_witness_state {
     vpbs::SlotState s;
     unsigned stages_done = 0;   // late stages that have run on this state (vpbs_witness_plan_run_late_stage)
     unsigned stages_packed = 0; // ... and how many of them have their wires in the caller's packed buffer already
-    vpbs::LevelPool* awake = nullptr;   // the late pool was left spinning for the next stage of this state: whoever runs it (or frees the state) ends it
+    // the late pool was left spinning for the next stage of this state: the state holds a share of the pool and the token of that promise;
+    // whoever runs the stage (or frees the state) ends the spinning -- unless another run took the pool meanwhile (LevelPool::end_if_still_kept)
+    std::shared_ptr<vpbs::LevelPool> awake;
+    unsigned long awake_token = 0;
+    void release_awake() {
+        if (awake) awake->end_if_still_kept(awake_token);
+        awake.reset();
+        awake_token = 0;
+    }
     int failed = 0;             // a stage run ahead failed with this status (a generator rejected its inputs; not only slot mismatches are sticky):
     std::string failure;        // ... every later stage and run_late[_packed] report it again instead of building on a half-run stage
-    ~vpbs_witness_state() {
-        if (awake) awake->end();
-    }
+    ~vpbs_witness_state() { release_awake(); }
 };
 
 namespace vpbs {
@@ -1089,7 +1095,7 @@ bool lanes_of_phase_empty(const vpbs_witness_plan& p, int ph) { return p.lane_st
 int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s, unsigned threads,
                const std::function<void(unsigned, unsigned)>& after, std::string& err,
                const std::function<void(unsigned, unsigned)>& before = std::function<void(unsigned, unsigned)>(), bool keep_awake = false,
-               LevelPool** awake_out = nullptr) {
+               vpbs_witness_state* awake_for = nullptr) {
     constexpr u32 PAR_MIN_COST = 600;   // ~6 us of work: four PoseidonGate rows
     const vpbs_witness_plan::Phase& P = stage ? p.late_stage[stage - 1] : p.phase[ph];
     const unsigned mc = std::max(1u, p.max_consts);
@@ -1097,16 +1103,24 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
     static const bool trace = std::getenv("VPBS_TRACE_WITNESS") != nullptr;
     const char* name = ph ? "late" : "early";
     LevelPool* pool = nullptr;
+    std::shared_ptr<LevelPool> pool_share;
     std::unique_lock<std::mutex> busy;
     if (threads > 1) {
         {
             std::lock_guard<std::mutex> lk(p.pool_mutex);
             if (!p.pool[ph]) p.pool[ph].reset(new LevelPool(threads, ph ? "vpbs-late-pool" : "vpbs-early-pool"));   // the phase's pool keeps the size of its first run
-            pool = p.pool[ph].get();
+            pool_share = p.pool[ph];
+            pool = pool_share.get();
         }
         busy = std::unique_lock<std::mutex>(pool->busy, std::try_to_lock);
         if (!busy.owns_lock()) pool = nullptr;   // another run of this phase has the threads: this one goes alone
+        else pool->taken_by_a_run();             // a promise an earlier run left behind is void: the workers are this run's
     }
+    auto promise_awake = [&] {
+        if (!awake_for) return;
+        awake_for->awake = pool_share;
+        awake_for->awake_token = pool->keep_awake_token();
+    };
     if (!pool) {   // alone: the plan's own schedule order (generators of a row's neighbourhood together: far fewer cache misses than level order)
         if (before) before(0, 1);
         if (s.failed()) {
@@ -1224,8 +1238,8 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         int rc = failed.load() || s.failed() ? VPBS_ERR_INVALID : VPBS_OK;
         const double t_mid = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0;
         if (rc == VPBS_OK && after) pool->share([&](unsigned t) { after(t, threads); });
-        if (keep_awake && rc == VPBS_OK) {
-            if (awake_out) *awake_out = pool;
+        if (keep_awake && rc == VPBS_OK && awake_for) {
+            promise_awake();
         } else {
             pool->end();
         }
@@ -1386,9 +1400,9 @@ int run_levels(const vpbs_witness_plan& p, int ph, unsigned stage, SlotState& s,
         pool_awake = true;
         pool->share([&](unsigned t) { after(t, threads); });
     }
-    if (keep_awake && rc == VPBS_OK) {
+    if (keep_awake && rc == VPBS_OK && awake_for) {
         if (!pool_awake) pool->begin();   // spinning by the time the next stage arrives
-        if (awake_out) *awake_out = pool;
+        promise_awake();
     } else if (pool_awake) {
         pool->end();
     }
@@ -1583,10 +1597,7 @@ static int run_late_impl(const vpbs_witness_plan* plan, vpbs_witness_state* stat
         };
         const size_t lo = p.late_out_stage_off[stage - 1], hi = p.late_out_stage_off[stage];
         rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, [&](unsigned t, unsigned of) { emit(lo, hi, t, of); }, msg, presets);
-        if (state->awake) {   // the pool had been left spinning for this stage: asleep again now (end() twice is harmless)
-            state->awake->end();
-            state->awake = nullptr;
-        }
+        state->release_awake();   // the pool had been left spinning for this stage: asleep again now (unless another run took it meanwhile)
         lap("presets + generators + late wires");
     }
     if (trace) {
@@ -1661,12 +1672,9 @@ int vpbs_witness_plan_run_late_stage(const vpbs_witness_plan* plan, vpbs_witness
     }
     // the stage before the last leaves the pool spinning: the last one starts when the proof returns, a fraction of a millisecond later, and
     // waking sleeping workers would cost it more than that
-    if (state->awake) {
-        state->awake->end();
-        state->awake = nullptr;
-    }
+    state->release_awake();
     const bool keep = stage + 1 == p.n_stages;
-    const int rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg, presets, keep, keep ? &state->awake : nullptr);
+    const int rc = run_levels(p, 1, p.n_stages > 1 ? stage : 0, s, late_threads, after, msg, presets, keep, keep ? state : nullptr);
     if (pack && rc == VPBS_OK) state->stages_packed = stage;
     state->stages_done = stage;
     if (rc != VPBS_OK) {          // the state is only good for vpbs_witness_state_free / run_late now, and both know: the failure is the state's

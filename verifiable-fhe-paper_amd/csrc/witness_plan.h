@@ -56,6 +56,22 @@ struct LevelPool {
         std::lock_guard<std::mutex> lk(m);
         active.store(false, std::memory_order_release);
     }
+    // A run may leave the workers spinning for the run that follows within a fraction of a millisecond (the last late stage of a chained step).
+    // Whoever was promised that (a witness state) holds a TOKEN, not the pool: a run that takes the pool in between invalidates it (the
+    // workers are that run's now), so a state freed or advanced from another thread can never put the workers of somebody else's run to
+    // sleep; and the state shares ownership of the pool, so a plan that is re-split or freed first leaves nothing dangling.
+    unsigned long keep_awake_token() {
+        static std::atomic<unsigned long> next{1};
+        const unsigned long t = next.fetch_add(1, std::memory_order_relaxed);
+        awake_token.store(t, std::memory_order_release);
+        return t;
+    }
+    void taken_by_a_run() { awake_token.store(0, std::memory_order_release); }
+    void end_if_still_kept(unsigned long token) {
+        unsigned long t = token;
+        if (token && awake_token.compare_exchange_strong(t, 0, std::memory_order_acq_rel)) end();
+    }
+    std::atomic<unsigned long> awake_token{0};
     // every thread of the pool (the caller as number 0) runs job(t); returns when all have finished
     template <class Job> void share(Job&& j) {
         job = std::ref(j);
@@ -259,7 +275,8 @@ struct vpbs_witness_plan {
     };
     std::vector<Lane> lanes[2];
     std::vector<u32> lane_steps_sorted[2];      // all lane steps of a phase, ascending (a run without threads for the lanes)
-    mutable std::unique_ptr<vpbs::LevelPool> pool[2], lane_pool[2];
+    mutable std::shared_ptr<vpbs::LevelPool> pool[2];      // shared with the witness states a run left the workers spinning for
+    mutable std::unique_ptr<vpbs::LevelPool> lane_pool[2];
     mutable std::mutex pool_mutex;              // creation of the pools (first run of a phase)
 
     // ---- the same schedule by dependency level, for the device (vpbs_witness_device_*): every generator of level L only reads slots
