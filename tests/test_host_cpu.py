@@ -326,12 +326,12 @@ def test_hash_chains_of_concurrent_callers_share_lanes_and_agree_with_the_oracle
 
 
 def test_recorded_bench_line_keeps_the_contract():
-    """profiles/r04_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  The parsed
+    """profiles/r05_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  The parsed
     headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs); since round 4 the roofline object has the contract's form
     (bound hbm: algorithmic bytes per launch / launch duration / 8 TB/s, the PMC traffic and its source named) with the integer-issue pricing
     beside it, the whole step priced against HBM, and a sustained figure (whole chains) next to the burst."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_latest.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_latest.json")
     d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):
@@ -347,6 +347,13 @@ def test_recorded_bench_line_keeps_the_contract():
     i = r["int_valu_issue"]
     assert i["bound"] == "int-valu-issue" and abs(i["frac"] - i["achieved"] / i["peak"]) < 1e-9 and 0 < i["frac"] <= 1.0
     assert 0.01 < r["step_hbm_frac"] < 0.2
+    # round 5: the WHOLE step against the bound that holds it (wave-level VALU instructions per step by kernel / issue rate / measured time), and
+    # what ran: ranks counted by the communication library, who started them, CPUs per rank, the pipeline chosen
+    b = r["valu_budget"]
+    assert abs(sum(b["by_kernel_G"].values()) - b["wave_instructions_per_step_G"]) < 1e-6 and "r05_pmc_sq_kernels.csv" in b["counters_from"]
+    assert abs(b["frac"] - b["instruction_time_ms_per_step"] / b["measured_ms_per_step_proof"]) < 1e-9 and 0.8 < b["frac"] < 1.05
+    assert abs(b["measured_ms_per_step_proof"] - d["ms_per_step"] / chains) < 1e-6
+    assert d["rccl"]["ranks"] == d["n_gpus"] and d["cpus_per_rank"] >= 1 and d["pipeline"]["chains_per_gpu"] == chains and d["launched_by"]
     s = d["sustained"]
     assert s["chains"] == chains and abs(s["sustained_over_burst"] - s["vpbs_proofs_per_s"] / d["value"]) < 1e-9 and 0.9 < s["sustained_over_burst"] < 1.1
     c = d["cpu_baseline"]
