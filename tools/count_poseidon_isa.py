@@ -37,6 +37,23 @@ def main():
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z.*permute_batch_kernel.*:", l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
+    # the practically-never-taken second corrections of the asm arithmetic (gl.h: .Lgl_* labels): skipped by a forward wave-level branch --
+    # not part of the dynamic count
+    kept, skip_to, rare = [], None, 0
+    for l in body:
+        if skip_to is not None:
+            if l.strip().startswith(skip_to + ":"):
+                skip_to = None
+            elif re.match(r"^\s+v_", l):
+                rare += 1
+            continue
+        m = re.match(r"^\s+s_cbranch_\w+\s+(\.Lgl_\w+)", l)
+        if m:
+            skip_to = m.group(1)
+            continue
+        kept.append(l)
+    print("VALU instructions behind never-taken forward branches (excluded):", rare)
+    body = kept
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
     loops = []
     for i, l in enumerate(body):

@@ -154,6 +154,23 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 #define GL_Q23 "v[90:91]"
 #define GL_Q45 "v[92:93]"
 #endif
+// The reduction of the 128-bit value (P01 = low 64 bits, R4 = bits 64..95, R5 = bits 96..127) to outputs %0 / %1, shared by the product forms:
+//   u = R4 (2^32 - 1) + P01 as ONE v_mad_u64_u32 with carry-out c;  r = u - R5 with borrow b;  r += (c - b)(2^32 - 1).
+// b needs u < R5 < 2^32, i.e. one product in 2^32: the borrow's correction (r -= 2^32 - 1, applied FIRST so that the carry's correction
+// cannot wrap) sits behind a wave-level branch that is practically never taken, and the common path pays only the carry's correction:
+// 6 VALU where computing both corrections as one signed addend took 8 VALU + 2 SALU (round 5).
+#define GL_REDUCE_TAIL(UNIQ)                                                          \
+    "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"                \
+    "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"                         \
+    "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"                        \
+    "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[80:81]\n\t"                                  \
+    "s_cbranch_vccz .Lgl_red_" UNIQ "\n\t"                                               \
+    "v_cndmask_b32_e64 " GL_R6 ", 0, -1, vcc\n\t"                                       \
+    "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R6 "\n\t"                         \
+    "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n"                           \
+    ".Lgl_red_" UNIQ ":\n\t"                                                             \
+    "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R7 "\n\t"                                \
+    "v_addc_co_u32_e64 %1, vcc, " GL_R1 ", 0, vcc"
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     u32 r0, r1;
     asm("v_mad_u64_u32 " GL_P01 ", vcc, %2, %4, 0\n\t"
@@ -164,16 +181,7 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
         "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R2 "\n\t"
         "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_R3 ", vcc\n\t"
         "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_R6 ", vcc\n\t"
-        "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
-        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
-        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
-        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
-        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
-        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
+        GL_REDUCE_TAIL("%=")
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
         : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
@@ -200,26 +208,30 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
         "v_add_co_u32_e32 v89, vcc, v89, v90\n\t"
         "v_addc_co_u32_e32 v92, vcc, v92, v91, vcc\n\t"
         "v_addc_co_u32_e32 v93, vcc, v93, v94, vcc\n\t"
+        // both reductions (GL_REDUCE_TAIL): the two borrows share ONE practically-never-taken branch
         "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
         "v_mad_u64_u32 v[88:89], s[86:87], v92, -1, v[88:89]\n\t"
         "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
         "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
-        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
-        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
+        "s_mov_b64 s[82:83], vcc\n\t"
         "v_sub_co_u32_e32 v88, vcc, v88, v93\n\t"
         "v_subbrev_co_u32_e32 v89, vcc, 0, v89, vcc\n\t"
-        "s_andn2_b64 s[88:89], s[86:87], vcc\n\t"
-        "s_andn2_b64 s[90:91], vcc, s[86:87]\n\t"
-        "v_cndmask_b32_e64 v86, 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 v94, 0, 1, s[90:91]\n\t"
-        "v_cndmask_b32_e64 v86, v86, -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 v94, v94, -1, s[88:89]\n\t"
-        "v_cndmask_b32_e64 v87, 0, -1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 v95, 0, -1, s[90:91]\n\t"
-        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
-        "v_addc_co_u32_e32 %1, vcc, v81, v87, vcc\n\t"
-        "v_add_co_u32_e32 %2, vcc, v88, v94\n\t"
-        "v_addc_co_u32_e32 %3, vcc, v89, v95, vcc"
+        "v_cndmask_b32_e64 v87, 0, -1, s[80:81]\n\t"
+        "v_cndmask_b32_e64 v95, 0, -1, s[86:87]\n\t"
+        "s_or_b64 s[84:85], s[82:83], vcc\n\t"
+        "s_cbranch_scc0 .Lgl_red2_%=\n\t"
+        "s_mov_b64 s[84:85], vcc\n\t"
+        "v_cndmask_b32_e64 v86, 0, -1, s[82:83]\n\t"
+        "v_sub_co_u32_e32 v80, vcc, v80, v86\n\t"
+        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
+        "v_cndmask_b32_e64 v94, 0, -1, s[84:85]\n\t"
+        "v_sub_co_u32_e32 v88, vcc, v88, v94\n\t"
+        "v_subbrev_co_u32_e32 v89, vcc, 0, v89, vcc\n"
+        ".Lgl_red2_%=:\n\t"
+        "v_add_co_u32_e32 %0, vcc, v80, v87\n\t"
+        "v_addc_co_u32_e64 %1, vcc, v81, 0, vcc\n\t"
+        "v_add_co_u32_e32 %2, vcc, v88, v95\n\t"
+        "v_addc_co_u32_e64 %3, vcc, v89, 0, vcc"
         : "=&v"(r0), "=&v"(r1), "=&v"(q0), "=&v"(q1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
           "v"((u32)(d >> 32))
@@ -256,16 +268,18 @@ __device__ __forceinline__ u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
         "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_Q4 ", vcc\n\t"
         "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_Q5 ", vcc\n\t"
         "v_addc_co_u32_e64 " GL_R6 ", vcc, 0, 0, vcc\n\t"
+        // as GL_REDUCE_TAIL with the 33-bit subtrahend R5 + R6 2^32 (the borrow needs u < 2^33: as rare)
         "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
         "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
         "v_subb_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R6 ", vcc\n\t"
-        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
-        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
-        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[80:81]\n\t"
+        "s_cbranch_vccz .Lgl_redd_%=\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n"
+        ".Lgl_redd_%=:\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R7 "\n\t"
+        "v_addc_co_u32_e64 %1, vcc, " GL_R1 ", 0, vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
           "v"((u32)(d >> 32))
@@ -288,38 +302,30 @@ __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
         "v_addc_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", %7, vcc\n\t"
         "v_addc_co_u32_e32 " GL_R4 ", vcc, 0, " GL_R4 ", vcc\n\t"
         "v_addc_co_u32_e32 " GL_R5 ", vcc, 0, " GL_R5 ", vcc\n\t"
-        "v_mad_u64_u32 " GL_P01 ", s[80:81], " GL_R4 ", -1, " GL_P01 "\n\t"
-        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R5 "\n\t"
-        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
-        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
-        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
-        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
+        GL_REDUCE_TAIL("%=")
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32))
         : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
-// lo + hi_lo 2^64 + hi_hi 2^96 (mod p) -> a u64 residue: the reduction tail of mul_nc on its own (8 VALU + 2 SALU), for values that are
+// lo + hi_lo 2^64 + hi_hi 2^96 (mod p) -> a u64 residue: the reduction tail of mul_nc on its own (6 VALU), for values that are
 // 128 bits wide by construction (a field element times a power of two: the shifts inside the radix-16 NTT butterflies)
 __device__ __forceinline__ u64 reduce128_asm(u64 lo, u32 hi_lo, u32 hi_hi) {
     u32 r0, r1;
     asm("v_mad_u64_u32 " GL_P01 ", s[80:81], %3, -1, %2\n\t"
         "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", %4\n\t"
         "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n\t"
-        "s_andn2_b64 s[82:83], s[80:81], vcc\n\t"
-        "s_andn2_b64 s[84:85], vcc, s[80:81]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", 0, 1, s[84:85]\n\t"
-        "v_cndmask_b32_e64 " GL_R6 ", " GL_R6 ", -1, s[82:83]\n\t"
-        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[84:85]\n\t"
-        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
-        "v_addc_co_u32_e32 %1, vcc, " GL_R1 ", " GL_R7 ", vcc"
+        "v_cndmask_b32_e64 " GL_R7 ", 0, -1, s[80:81]\n\t"
+        "s_cbranch_vccz .Lgl_red128_%=\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_subbrev_co_u32_e32 " GL_R1 ", vcc, 0, " GL_R1 ", vcc\n"
+        ".Lgl_red128_%=:\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R7 "\n\t"
+        "v_addc_co_u32_e64 %1, vcc, " GL_R1 ", 0, vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"(lo), "v"(hi_lo), "v"(hi_hi)
-        : GL_R0, GL_R1, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+        : GL_R0, GL_R1, GL_R6, GL_R7, "vcc", "scc", "s80", "s81");
     return ((u64)r1 << 32) | r0;
 }
 // lo + hi 2^64 (mod p) for hi < 2^32: u = hi (2^32 - 1) + lo as one v_mad_u64_u32, its carry-out selects the single +(2^32 - 1) correction

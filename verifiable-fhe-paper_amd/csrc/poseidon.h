@@ -74,19 +74,18 @@ GL_HD u64 sbox_ilp(u64 x) {
 // acc_lo + acc_hi * 2^32 (both < 2^58) folded to a u64 residue with 2^64 = 2^32 - 1
 GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // L = acc_lo + (acc_hi << 32) with carry into H = acc_hi >> 32; r = H * (2^32 - 1) + L as one v_mad_u64_u32 whose
-    // carry-out selects the single +(2^32 - 1) correction (H < 2^27, so the corrected sum cannot wrap again)
+    // acc_lo + (hi_lo + hi_hi 2^32) 2^32 = acc_lo + hi_hi 2^64 + hi_lo 2^32: T = hi_hi (2^32 - 1) + acc_lo as ONE v_mad_u64_u32 (below 2^59:
+    // no carry), then hi_lo joins T's high word; that carry selects the single +(2^32 - 1) correction (the wrapped value is below T, so the
+    // corrected sum cannot wrap again).  5 VALU (round 5; 7 before: the sum L was formed first, with a carry into H and a move to pair it).
     u32 r0, r1;
-    asm("v_add_co_u32_e32 v81, vcc, %3, %4\n\t"
-        "v_addc_co_u32_e64 v84, vcc, %5, 0, vcc\n\t"
-        "v_mov_b32_e32 v80, %2\n\t"
-        "v_mad_u64_u32 v[80:81], vcc, v84, -1, v[80:81]\n\t"
+    asm("v_mad_u64_u32 v[80:81], vcc, %4, -1, %2\n\t"
+        "v_add_co_u32_e32 v81, vcc, v81, %3\n\t"
         "v_cndmask_b32_e64 v86, 0, -1, vcc\n\t"
         "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
         "v_addc_co_u32_e64 %1, vcc, v81, 0, vcc"
         : "=&v"(r0), "=&v"(r1)
-        : "v"((u32)acc_lo), "v"((u32)(acc_lo >> 32)), "v"((u32)acc_hi), "v"((u32)(acc_hi >> 32))
-        : "v80", "v81", "v84", "v86", "vcc");
+        : "v"(acc_lo), "v"((u32)acc_hi), "v"((u32)(acc_hi >> 32))
+        : "v80", "v81", "v86", "vcc");
     return ((u64)r1 << 32) | r0;
 #else
     const u64 L = acc_lo + (acc_hi << 32);
@@ -101,13 +100,13 @@ GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
 // s <- MDS * s + k, where k = rc[k_off .. k_off+12) (k_off < 0: no constant).  s: any u64 residues.
 GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in registers (or nullptr) */) {
     u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u32 D8 = 8;
+    u32 C0D = 17 + 8;
 #if defined(__HIP_DEVICE_COMPILE__)
     // keep the coefficients opaque (SGPRs): otherwise hipcc strength-reduces x16 / x2 / x8 into v_lshl_add_u64 on
     // zero-extended register pairs, which costs two v_mov per term (-6 % instructions per permutation)
 #pragma unroll
     for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(C[i]));
-    asm volatile("" : "+s"(D8));
+    asm volatile("" : "+s"(C0D));
 #endif
     u32 lo[12], hi[12];
 #pragma unroll
@@ -125,12 +124,9 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
 #endif
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            acc_lo += (u64)lo[(i + r) % 12] * C[i];
-            acc_hi += (u64)hi[(i + r) % 12] * C[i];
-        }
-        if (r == 0) {  // MDS_MATRIX_DIAG[0] = 8
-            acc_lo += (u64)lo[0] * D8;
-            acc_hi += (u64)hi[0] * D8;
+            const u32 c = r == 0 && i == 0 ? C0D : C[i];   // row 0: MDS_MATRIX_DIAG[0] = 8 joins the circulant's entry for the same element
+            acc_lo += (u64)lo[(i + r) % 12] * c;
+            acc_hi += (u64)hi[(i + r) % 12] * c;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         if (kc)
@@ -173,9 +169,15 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
         a_lo += (u64)lo[j] * MDS1[0][j];
         a_hi += (u64)hi[j] * MDS1[0][j];
     }
-    const u64 x2 = gl::canon(fold96(a_lo, a_hi));
-    if (GATE || x_out) x_out[0] = x2;
-    const u64 d2 = gl::sub(gl::canon(sbox(GATE ? w[1] : x2)), x2);
+    // x2, x3 are canonical only where somebody asks for them (the gate's constraints, the generator's wires); the permutation itself runs on
+    // residues: S-box, the difference d (gl::sub_a takes any residues) and its 32-bit halves as multiplicands (round 5: 16 instructions
+    // per group fewer in the hashing kernels)
+    u64 x2 = fold96(a_lo, a_hi);
+    if (GATE || x_out) {
+        x2 = gl::canon(x2);
+        x_out[0] = x2;
+    }
+    const u64 d2 = gl::sub_a(sbox(GATE ? w[1] : x2), x2);
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
     // x3_0 = (M^2 y)[0] + M[0][0] d2 + (M c2)[0] + c3[0]
     u64 b_lo = (u32)k3, b_hi = k3 >> 32;
@@ -186,9 +188,12 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
     }
     b_lo += (u64)d2l * MDS1[0][0];
     b_hi += (u64)d2h * MDS1[0][0];
-    const u64 x3 = gl::canon(fold96(b_lo, b_hi));
-    if (GATE || x_out) x_out[1] = x3;
-    const u64 d3 = gl::sub(gl::canon(sbox(GATE ? w[2] : x3)), x3);
+    u64 x3 = fold96(b_lo, b_hi);
+    if (GATE || x_out) {
+        x3 = gl::canon(x3);
+        x_out[1] = x3;
+    }
+    const u64 d3 = gl::sub_a(sbox(GATE ? w[2] : x3), x3);
     const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
     // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec
 #pragma unroll
