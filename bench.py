@@ -171,7 +171,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # sustains ~2.25 GHz under this kernel, not the 2.4 GHz an idle probe or rocm-smi shows (round 2's first figures assumed 2.39 GHz and a
 # 4.2-cycle ceiling, two errors that cancelled), and ~2.0 GHz for several milliseconds after a pause (tools/experiments/idle_gap.py).
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-LEAF_HASH_INSTR_PER_PERM = 13721  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py; rounds 2-4: 15260)
+LEAF_HASH_INSTR_PER_PERM = 13335  # dynamic VALU instructions per permutation (tools/count_poseidon_isa.py; rounds 2-4: 15260)
 HALF_RATE_SHARE = 0.97            # of those, the share that issues at 4 cycles per wave64 instruction; the rest at 2
 CEILING_CYCLES_PER_INSTR = HALF_RATE_SHARE * 4.0 + (1 - HALF_RATE_SHARE) * 2.0
 SCLK_FALLBACK_HZ = 2.25e9         # only if the in-kernel measurement is unavailable

@@ -97,17 +97,148 @@ GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
 #endif
 }
 
-// s <- MDS * s + k, where k = rc[k_off .. k_off+12) (k_off < 0: no constant).  s: any u64 residues.
-GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in registers (or nullptr) */) {
-    u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u32 C0D = 17 + 8;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // keep the coefficients opaque (SGPRs): otherwise hipcc strength-reduces x16 / x2 / x8 into v_lshl_add_u64 on
-    // zero-extended register pairs, which costs two v_mov per term (-6 % instructions per permutation)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(C[i]));
-    asm volatile("" : "+s"(C0D));
+// One row of the MDS layer as ONE block of 24 multiply-adds: acc_lo = sum x_lo[i] C[i] + (k mod 2^58), acc_hi = sum x_hi[i] C[i] + ((k >> 58) << 26)
+// -- together k + sum x[i] C[i] in fold96's lo + hi 2^32 form.  Every coefficient of the circulant is an inline constant (<= 41; row 0's own
+// element: 17 + MDS_MATRIX_DIAG[0] = 25), so the coefficients need no registers at all, and the round constant rides in as the 64-bit addend
+// of the first multiply-add of each half (split by the scalar unit: no VALU) -- before round 5 it cost a multiply-add by 1 per half (the
+// compiler would not take it as an addend: zero-extended SGPR pairs for 24 halves spilled, and a chain started in inline asm is re-associated
+// into a separate sum + a 64-bit add).  x: the row's twelve inputs in circulant order (x[0] = the row's own element).
+// Bounds for fold96: acc_lo < 2^58 + 2^41, acc_hi < 2^32 + 2^41: T = hi_hi (2^32 - 1) + acc_lo stays far below 2^64.
+#define POSEIDON_ROW_OPERANDS                                                                                                              \
+    "v"(xl[0]), "v"(xl[1]), "v"(xl[2]), "v"(xl[3]), "v"(xl[4]), "v"(xl[5]), "v"(xl[6]), "v"(xl[7]), "v"(xl[8]), "v"(xl[9]), "v"(xl[10]),   \
+    "v"(xl[11]), "v"(xh[0]), "v"(xh[1]), "v"(xh[2]), "v"(xh[3]), "v"(xh[4]), "v"(xh[5]), "v"(xh[6]), "v"(xh[7]), "v"(xh[8]), "v"(xh[9]),  \
+    "v"(xh[10]), "v"(xh[11])
+template <bool ROW0, bool WITH_K>
+__device__ __forceinline__ void mds_row(const u32* xl, const u32* xh, u64 k, u64& acc_lo, u64& acc_hi) {
+    if constexpr (WITH_K) {
+        if constexpr (ROW0)
+            asm("s_mov_b32 s82, %26\n\t"
+            "s_and_b32 s83, %27, 0x03ffffff\n\t"
+            "s_and_b32 s84, %27, 0xfc000000\n\t"
+            "s_mov_b32 s85, 0\n\t"
+            "v_mad_u64_u32 %0, vcc, %2, 25, s[82:83]\n\t"
+            "v_mad_u64_u32 %1, vcc, %14, 25, s[84:85]\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+                : "=&v"(acc_lo), "=&v"(acc_hi)
+                : POSEIDON_ROW_OPERANDS, "s"((u32)k), "s"((u32)(k >> 32))
+                : "vcc", "scc", "s82", "s83", "s84", "s85");
+        else
+            asm("s_mov_b32 s82, %26\n\t"
+            "s_and_b32 s83, %27, 0x03ffffff\n\t"
+            "s_and_b32 s84, %27, 0xfc000000\n\t"
+            "s_mov_b32 s85, 0\n\t"
+            "v_mad_u64_u32 %0, vcc, %2, 17, s[82:83]\n\t"
+            "v_mad_u64_u32 %1, vcc, %14, 17, s[84:85]\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+                : "=&v"(acc_lo), "=&v"(acc_hi)
+                : POSEIDON_ROW_OPERANDS, "s"((u32)k), "s"((u32)(k >> 32))
+                : "vcc", "scc", "s82", "s83", "s84", "s85");
+    } else {
+        if constexpr (ROW0)
+            asm("v_mad_u64_u32 %0, vcc, %2, 25, 0\n\t"
+            "v_mad_u64_u32 %1, vcc, %14, 25, 0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+                : "=&v"(acc_lo), "=&v"(acc_hi)
+                : POSEIDON_ROW_OPERANDS
+                : "vcc");
+        else
+            asm("v_mad_u64_u32 %0, vcc, %2, 17, 0\n\t"
+            "v_mad_u64_u32 %1, vcc, %14, 17, 0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+                : "=&v"(acc_lo), "=&v"(acc_hi)
+                : POSEIDON_ROW_OPERANDS
+                : "vcc");
+    }
+}
 #endif
+
+// s <- MDS * s + k (kc: the 12 constants, already in registers; nullptr: none).  s: any u64 residues.
+GL_HD void mds_add_const(u64* s, const u64* kc) {
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -116,29 +247,77 @@ GL_HD void mds_add_const(u64* s, const u64* kc /* 12 constants, already in regis
     }
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        const u64 k = kc ? kc[r] : 0;
+        u64 acc_lo, acc_hi;
 #if defined(__HIP_DEVICE_COMPILE__)
-        u64 acc_lo = 0, acc_hi = 0;  // the constant joins below as a multiply-add by 1 on 32-bit scalars (see partial_group3_core)
-#else
-        u64 acc_lo = (u32)k, acc_hi = k >> 32;
-#endif
+        u32 xl[12], xh[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            const u32 c = r == 0 && i == 0 ? C0D : C[i];   // row 0: MDS_MATRIX_DIAG[0] = 8 joins the circulant's entry for the same element
+            xl[i] = lo[(i + r) % 12];
+            xh[i] = hi[(i + r) % 12];
+        }
+        if (kc) {
+            if (r == 0) mds_row<true, true>(xl, xh, kc[r], acc_lo, acc_hi);
+            else mds_row<false, true>(xl, xh, kc[r], acc_lo, acc_hi);
+        } else {
+            if (r == 0) mds_row<true, false>(xl, xh, 0, acc_lo, acc_hi);
+            else mds_row<false, false>(xl, xh, 0, acc_lo, acc_hi);
+        }
+#else
+        const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        const u64 k = kc ? kc[r] : 0;
+        acc_lo = (u32)k, acc_hi = k >> 32;
+        for (int i = 0; i < 12; ++i) {
+            const u32 c = r == 0 && i == 0 ? C[0] + 8 : C[i];   // row 0: MDS_MATRIX_DIAG[0] = 8 joins the circulant's entry for the same element
             acc_lo += (u64)lo[(i + r) % 12] * c;
             acc_hi += (u64)hi[(i + r) % 12] * c;
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (kc)
-            asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
-                "v_mad_u64_u32 %1, vcc, %3, 1, %1"
-                : "+v"(acc_lo), "+v"(acc_hi)
-                : "s"((u32)k), "s"((u32)(k >> 32))
-                : "vcc");
 #endif
         s[r] = fold96(acc_lo, acc_hi);
     }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// One half (low or high 32-bit words) of a row of a fused partial-round group: acc = d3 M1 + d2 m2 + sum x[j] m3[j] + k_part as ONE block of
+// 14 multiply-adds whose first takes the constant's share as its 64-bit addend (M1, an entry of M itself, is an inline constant; the
+// entries of M^2 and M^3 are scalar operands): no multiply-add by 1 for the constant (round 5).
+template <unsigned M1>
+__device__ __forceinline__ u64 group_row_half(u32 d3, u32 d2, u32 m2, u64 k_part, const u32* x, const u32* m3) {
+    static_assert(M1 <= 64, "inline constant");
+    u64 acc;
+    asm("v_mad_u64_u32 %0, vcc, %1, %29, %4\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %17, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %6, %18, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, %19, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %8, %20, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %9, %21, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %10, %22, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, %23, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %12, %24, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %13, %25, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %14, %26, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %15, %27, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %16, %28, %0"
+        : "=&v"(acc)
+        : "v"(d3), "v"(d2), "s"(m2), "s"(k_part), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+          "v"(x[9]), "v"(x[10]), "v"(x[11]), "s"(m3[0]), "s"(m3[1]), "s"(m3[2]), "s"(m3[3]), "s"(m3[4]), "s"(m3[5]), "s"(m3[6]), "s"(m3[7]), "s"(m3[8]),
+          "s"(m3[9]), "s"(m3[10]), "s"(m3[11]), "n"(M1)
+        : "vcc");
+    return acc;
+}
+template <int I> struct GroupRow {
+    static __device__ __forceinline__ void run(u64* s, const u64* kv, const u32* lo, const u32* hi, u32 d2l, u32 d2h, u32 d3l, u32 d3h) {
+        u32 m3[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) m3[j] = MDS3[I][j];
+        const u64 k = kv[I];
+        const u64 acc_lo = group_row_half<MDS1[I][0]>(d3l, d2l, MDS2[I][0], k & ((1ull << 58) - 1), lo, m3);
+        const u64 acc_hi = group_row_half<MDS1[I][0]>(d3h, d2h, MDS2[I][0], (k >> 58) << 26, hi, m3);
+        s[I] = fold96(acc_lo, acc_hi);
+        if constexpr (I + 1 < 12) GroupRow<I + 1>::run(s, kv, lo, hi, d2l, d2h, d3l, d3h);
+    }
+};
+#endif
 
 // Three consecutive partial rounds in one dense pass (derivation and bounds: tools/gen_poseidon_partial_groups.py).
 // The MDS entries are so small that M^2 and M^3 still fit 32-bit multiplicands with room in 64-bit accumulators, so
@@ -196,17 +375,13 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
     const u64 d3 = gl::sub_a(sbox(GATE ? w[2] : x3), x3);
     const u32 d3l = (u32)d3, d3h = (u32)(d3 >> 32);
     // x1' = M^3 y + d2 (M^2 e0) + d3 (M e0) + kvec
+#if defined(__HIP_DEVICE_COMPILE__)
+    GroupRow<0>::run(s, kv, lo, hi, d2l, d2h, d3l, d3h);
+#else
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const u64 k = kv[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-        // The group constant enters as one more multiply-add (k_half * 1) on a 32-bit scalar.  As the accumulators' initial value it
-        // needs a zero-extended SGPR PAIR per half: 48 SGPRs for the group, which hipcc spills to VGPR lanes and reads back with
-        // 48 v_readlane (+ wait states) per group.
-        u64 acc_lo = 0, acc_hi = 0;
-#else
         u64 acc_lo = (u32)k, acc_hi = k >> 32;
-#endif
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             acc_lo += (u64)lo[j] * MDS3[i][j];
@@ -214,15 +389,9 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
         }
         acc_lo += (u64)d2l * MDS2[i][0] + (u64)d3l * MDS1[i][0];
         acc_hi += (u64)d2h * MDS2[i][0] + (u64)d3h * MDS1[i][0];
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
-            "v_mad_u64_u32 %1, vcc, %3, 1, %1"
-            : "+v"(acc_lo), "+v"(acc_hi)
-            : "s"((u32)k), "s"((u32)(k >> 32))
-            : "vcc");
-#endif
         s[i] = fold96(acc_lo, acc_hi);
     }
+#endif
 }
 GL_HD void partial_group3(u64* s, int g) { partial_group3_core<false>(s, g, nullptr, nullptr); }
 
@@ -251,12 +420,16 @@ GL_HD void permute(u64* s) {
     }
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; ++r) {
         u64 kc[12];
-        const int next = r + 1 < N_ROUNDS ? 12 * (r + 1) : 0;  // the last round adds nothing (zeros selected below)
+        const bool last = r + 1 >= N_ROUNDS;                    // the last round adds nothing: zeros ride in as its constants
+        const int next = last ? 0 : 12 * (r + 1);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) kc[i] = rc(next + i);
+        for (int i = 0; i < 12; ++i) {
+            const u64 k = rc(next + i);
+            kc[i] = last ? 0 : k;
+        }
 #pragma unroll
         for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
-        mds_add_const(s, r + 1 < N_ROUNDS ? kc : nullptr);
+        mds_add_const(s, kc);
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
