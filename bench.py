@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 # process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise: measured with six chains per
 # GPU (tools/experiments/hwq_ab.sh), 4 / 8 / 16 / 24 queues = 8.45-8.54 / 8.35-8.40 / 8.69-8.75 / 8.73-8.78 ms per chained proof with the host
 # witness pipeline and 8.72-8.74 / 8.32-8.35 / 8.31-8.32 / 8.58-8.66 with the device pipeline; with the waits on completion words (round 4) the
-# device pipeline -- a chain there has six streams -- gains from 16: 8.70 -> 8.48 on 16 CPUs, 9.49 -> 9.21 on 4 (tools/experiments/hw_queues_dw.sh),
-# the host pipeline loses (six chains 8.17 -> 8.38; eight chains 7.94-8.10 / 8.08-8.11 / 8.17-8.21 with 8 / 12 / 16: tools/experiments/host8_queues.sh).
+# device pipeline -- a chain there has six streams -- gains from 16: 8.70 -> 8.48 on 16 CPUs, 9.49 -> 9.21 on 4 (tools/experiments/ivc_matrix.sh --preset hw_queues_dw),
+# the host pipeline loses (six chains 8.17 -> 8.38; eight chains 7.94-8.10 / 8.08-8.11 / 8.17-8.21 with 8 / 12 / 16: tools/experiments/ivc_matrix.sh --preset host8_queues).
 # Read by the runtime when it starts: decided here, from the CPU share that later picks the pipeline.
 def _cpu_share_before_hip():
     """this rank's share of the CPUs the container may use, without touching the library (the HIP runtime reads its environment when it starts):
@@ -1297,9 +1297,9 @@ def main():
         # host pipeline: 3 / 4 / 5 / 6 / 8 / 10 chains per GPU = 8.89 / 8.58 / 8.51-8.65 / 8.42-8.52 / 8.60-8.68 / 9.5 ms per chained proof on
         # 16 CPUs with spinning waits (tools/experiments/chains_ab.sh)
         # device pipeline: eight chains at every share (a chain's late phase and the scatter of its values are serial with its proof, and with
-        # few CPUs they are long: 4 CPUs 0.145-0.149 with six chains, 0.152 with eight or ten; 2 CPUs 0.140 either way: tools/experiments/hw_queues_dw2.sh)
+        # few CPUs they are long: 4 CPUs 0.145-0.149 with six chains, 0.152 with eight or ten; 2 CPUs 0.140 either way: tools/experiments/ivc_matrix.sh --preset hw_queues_dw2)
         # host pipeline since the waits sleep (round 4): 6 / 7 / 8 / 9 / 10 / 12 chains = 8.17 / 8.02 / 7.99 / 8.21 / 8.13 / 8.19 ms per chained proof
-        # on 16 CPUs (tools/experiments/host_chains_16cpus.sh): a chain per two CPUs, eight at most (one per hardware queue)
+        # on 16 CPUs (tools/experiments/ivc_matrix.sh --preset host_chains_16cpus): a chain per two CPUs, eight at most (one per hardware queue)
         args.chains = 8 if args.device_witness else max(1, min(8, cpus // 2))
         chains_why = "auto"
     else:
