@@ -240,7 +240,7 @@ def test_hand_scheduled_arithmetic_on_edge_values():
     exe = entry.build_asm_edge_tool()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ASM_EDGE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    for name in ("mul_nc", "dot2_nc", "mad_nc", "fold96", "add_nn", "add_a", "sub_a", "sub (asm)", "reduce96 / reduce128", "times7", "mul_lazy / fma2", "select_lerp",
+    for name in ("mul_nc", "mul2_nc", "dot2_nc", "mad_nc", "fold96", "add_nn", "add_a", "sub_a", "sub (asm)", "reduce96 / reduce128", "times7", "mul_lazy / fma2", "select_lerp",
                  "permute"):
         assert name + ": 0 mismatch" in r.stdout, (name, r.stdout)
 

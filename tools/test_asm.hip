@@ -12,6 +12,14 @@ __global__ void k_mul(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(gl::mul_nc(a[i], b[i]));
 }
+__global__ void k_mul2(const u64* a, const u64* b, u64* out, int n) {   // the interleaved pair of products (sbox2): both streams, one shared rare branch
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 r, q;
+    gl::mul2_nc(a[i], b[i], b[(i + 1) % n], a[(i + 2) % n], r, q);
+    out[2 * i] = gl::canon(r);
+    out[2 * i + 1] = gl::canon(q);
+}
 __global__ void k_dot2(const u64* a, const u64* b, u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl::canon(gl::dot2_nc(a[i], b[i], b[(i + 7) % n], a[(i + 13) % n]));
@@ -107,6 +115,20 @@ int main(int argc, char** argv) {
             if (out[i] != want) { if (bad < 5) printf("mul mismatch %d: %016lx * %016lx -> %016lx want %016lx\n", i, a[i], b[i], out[i], want); ++bad; }
         }
         printf("mul_nc: %d mismatches of %d\n", bad, n); total_bad += bad;
+        // mul2_nc: the edge pairs reach the borrow's correction in either stream alone and in both (e.g. 2^63 * 2^63 = 2^126: low 96 bits zero)
+        u64* dout2;
+        CK(hipMalloc(&dout2, 2 * n * 8));
+        std::vector<u64> out2(2 * n);
+        hipLaunchKernelGGL(k_mul2, dim3(n / 256), dim3(256), 0, 0, da, db, dout2, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out2.data(), dout2, 2 * n * 8, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (int i = 0; i < n; ++i) {
+            const u64 w0 = (u64)(((unsigned __int128)a[i] * b[i]) % gl::P), w1 = (u64)(((unsigned __int128)b[(i + 1) % n] * a[(i + 2) % n]) % gl::P);
+            if (out2[2 * i] != w0 || out2[2 * i + 1] != w1) { if (bad < 5) printf("mul2 mismatch %d\n", i); ++bad; }
+        }
+        printf("mul2_nc: %d mismatches of %d\n", bad, n); total_bad += bad;
+        CK(hipFree(dout2));
     }
     if (argc < 2 || argv[1][0] == 'd') {   // the fused products of the gate kernels: a b + c d and a b + c with one reduction
         bad = 0;
