@@ -33,6 +33,9 @@ def main():
         open(src, "w").write(SRC)
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", src, "-o", out],
                               stderr=subprocess.DEVNULL)
+        # -S does not ASSEMBLE inline asm: an operand the assembler rejects (gfx950: VGPR pairs must be 64-bit aligned) only shows with -c
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-c", "--cuda-device-only", src, "-o",
+                               os.path.join(d, "t.o")], stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z.*permute_batch_kernel.*:", l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])

@@ -287,10 +287,14 @@ __device__ __forceinline__ u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
     return ((u64)r1 << 32) | r0;
 }
-// a * b + c with one reduction (the product plus a 64-bit addend stays below 2^128).  Any residues in, a residue out; 20 VALU + 2 SALU.
+// a * b + c with one reduction (the product plus a 64-bit addend stays below 2^128).  Any residues in, a residue out; 16 VALU.
 __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
     u32 r0, r1;
-    asm("v_mad_u64_u32 " GL_P01 ", vcc, %2, %4, 0\n\t"
+    // c is the 64-bit addend of the first multiply-add (T = a0 b0 + c, carry kc); kc joins the high half as a carry-in: two adds where
+    // adding c to the assembled product took four (round 5).  (The fully chained form -- every partial product taking the previous one's
+    // high word as its addend, 6 instead of 8 VALU for the assembly -- needs the register pairs {T1, 0} and {U1, k}, and gfx950 wants VGPR
+    // pairs 64-bit aligned: a result's high word always sits in an odd register.)
+    asm("v_mad_u64_u32 " GL_P01 ", s[82:83], %2, %4, %6\n\t"
         "v_mad_u64_u32 " GL_P23 ", vcc, %2, %5, 0\n\t"
         "v_mad_u64_u32 " GL_P23 ", s[80:81], %3, %4, " GL_P23 "\n\t"
         "v_mad_u64_u32 " GL_P45 ", vcc, %3, %5, 0\n\t"
@@ -298,13 +302,11 @@ __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
         "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", " GL_R2 "\n\t"
         "v_addc_co_u32_e32 " GL_R4 ", vcc, " GL_R4 ", " GL_R3 ", vcc\n\t"
         "v_addc_co_u32_e32 " GL_R5 ", vcc, " GL_R5 ", " GL_R6 ", vcc\n\t"
-        "v_add_co_u32_e32 " GL_R0 ", vcc, " GL_R0 ", %6\n\t"
-        "v_addc_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", %7, vcc\n\t"
-        "v_addc_co_u32_e32 " GL_R4 ", vcc, 0, " GL_R4 ", vcc\n\t"
-        "v_addc_co_u32_e32 " GL_R5 ", vcc, 0, " GL_R5 ", vcc\n\t"
+        "v_addc_co_u32_e64 " GL_R4 ", vcc, " GL_R4 ", 0, s[82:83]\n\t"
+        "v_addc_co_u32_e64 " GL_R5 ", vcc, " GL_R5 ", 0, vcc\n\t"
         GL_REDUCE_TAIL("%=")
         : "=&v"(r0), "=&v"(r1)
-        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32))
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"(c)
         : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
     return ((u64)r1 << 32) | r0;
 }
