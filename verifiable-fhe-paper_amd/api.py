@@ -405,9 +405,13 @@ def early_threads_for(chains, cpus=None):
 
 
 def late_threads_for(chains, cpus=None):
-    """what the tools ask for: 14 for a single chain on a host with at least 16 CPUs for this process, the default otherwise"""
+    """what the tools ask for: 14 for a single chain on a host with at least 16 CPUs for this process (its latency is the late phase's); 4
+    from four chains per process on (round 5: eight chains on 16 CPUs prove 7.0 ms per chained proof with 4 or 8 late threads each, at 34-38
+    instead of 40-47 CPU-ms per proof -- tools/experiments/ivc_matrix.sh VPBS_LATE_THREADS=4:16:8:0:200); the default otherwise"""
     cpus = host_cpu_budget() if cpus is None else cpus
-    return 14 if chains == 1 and cpus >= 16 else 0
+    if chains == 1 and cpus >= 16:
+        return 14
+    return 4 if chains >= 4 else 0
 
 
 def hash_pad(x=()):
