@@ -411,7 +411,7 @@ def late_threads_for(chains, cpus=None):
     cpus = host_cpu_budget() if cpus is None else cpus
     if chains == 1 and cpus >= 16:
         return 14
-    return 4 if chains >= 4 else 0
+    return 4 if chains >= 4 and cpus >= 8 else 0      # fewer CPUs: the default (half the CPUs: one thread at 2 CPUs) is already below 4
 
 
 def hash_pad(x=()):
