@@ -379,16 +379,21 @@ __device__ __forceinline__ void dft16(u64* z) {
 // One register round of radix 2^Q on the thread's 16 values: x[(sub << Q) | k] is element k of butterfly `sub` (the 4 - Q owned bits above the
 // active ones select the butterfly and are the low bits of its block index).  tw: this round's table, row k = tau^k over `nb` blocks; SCALE0:
 // row 0 holds a factor for element 0 as well (1/n in the first round of an inverse transform), otherwise row 0 is not read.
-template <unsigned Q, bool INV, bool SCALE0>
-__device__ __forceinline__ void round16(u64 (&x)[16], const u64* __restrict__ tw, size_t nb, unsigned b_thread) {
+template <unsigned Q, bool SCALE0>
+__device__ __forceinline__ void round16_twiddles(u64 (&t)[16], const u64* __restrict__ tw, size_t nb, unsigned b_thread) {
     constexpr unsigned M = 1u << Q, SUBS = 16u >> Q;
-    u64 t[16];
 #pragma unroll
     for (unsigned sub = 0; sub < SUBS; ++sub) {
         const size_t b = (size_t)b_thread * SUBS + sub;
 #pragma unroll
         for (unsigned k = SCALE0 ? 0 : 1; k < M; ++k) t[sub * M + k] = tw[(size_t)k * nb + b];
     }
+}
+// the round itself on twiddles that are already on their way (a pass requests the next round's before it crosses LDS: the loads then fly
+// while the tile is exchanged instead of standing in front of the round's first products)
+template <unsigned Q, bool INV, bool SCALE0>
+__device__ __forceinline__ void round16(u64 (&x)[16], const u64 (&t)[16]) {
+    constexpr unsigned M = 1u << Q, SUBS = 16u >> Q;
 #pragma unroll
     for (unsigned sub = 0; sub < SUBS; ++sub) {
 #pragma unroll
@@ -448,29 +453,36 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
         else return tile_base + idx;
     };
     const u64* src = in + blockIdx.y * in_col_stride + blockIdx.z * in_block_stride;   // in_block_stride 0: every coset reads the same coefficients
-    u64 x[16];
+    u64 x[16], t[16];
+    constexpr unsigned O0 = TOP - 3, O1 = NR == 3 ? TOP - 7 : O_LAST;
+    auto block_of = [&](unsigned base, unsigned o) -> unsigned {   // the index bits above the thread's butterflies: their block
+        return (unsigned)(STRIDED ? (base >> (o + 4)) : (gidx(base) >> (o + 4)));
+    };
     // round 0: straight from global memory (a wave's lanes cover the adjacent columns / elements: 128-byte runs at least)
     {
-        constexpr unsigned o = TOP - 3;
+        constexpr unsigned o = O0;
         const unsigned base = owner_base(tid, o);
         const size_t g0 = gidx(base);
         const size_t step = STRIDED ? (row_stride << (o - LOG_C)) : ((size_t)1 << o);
+        round16_twiddles<4, SCALE0>(t, tw + P.round_off[0], (size_t)1 << P.round_t[0], block_of(base, o));
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = src[g0 + j * step];
-        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (g0 >> (o + 4)));   // the index bits above the butterfly's: its block
-        round16<4, INV, SCALE0>(x, tw + P.round_off[0], (size_t)1 << P.round_t[0], b);
+        round16<4, INV, SCALE0>(x, t);
+        // the next round's twiddles are requested before the tile crosses LDS
+        if constexpr (NR == 3) round16_twiddles<4, false>(t, tw + P.round_off[1], (size_t)1 << P.round_t[1], block_of(owner_base(tid, O1), O1));
+        else round16_twiddles<QL, false>(t, tw + P.round_off[1], (size_t)1 << P.round_t[1], block_of(owner_base(tid, O1), O1));
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j << o)] = x[j];
     }
     __syncthreads();
     if constexpr (NR == 3) {
-        constexpr unsigned o = TOP - 7;
+        constexpr unsigned o = O1;
         const unsigned base = owner_base(tid, o);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = tile[swz(base) ^ swz(j << o)];
         __syncthreads();
-        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (gidx(base) >> (o + 4)));
-        round16<4, INV, false>(x, tw + P.round_off[1], (size_t)1 << P.round_t[1], b);
+        round16<4, INV, false>(x, t);
+        round16_twiddles<QL, false>(t, tw + P.round_off[2], (size_t)1 << P.round_t[2], block_of(owner_base(tid, O_LAST), O_LAST));
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) tile[swz(base) ^ swz(j << o)] = x[j];
         __syncthreads();
@@ -481,8 +493,7 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
         const unsigned base = owner_base(tid, o);
 #pragma unroll
         for (unsigned j = 0; j < 16; ++j) x[j] = tile[swz(base) ^ swz(j << o)];
-        const unsigned b = (unsigned)(STRIDED ? (base >> (o + 4)) : (gidx(base) >> (o + 4)));
-        round16<QL, INV, false>(x, tw + P.round_off[NR - 1], (size_t)1 << P.round_t[NR - 1], b);
+        round16<QL, INV, false>(x, t);
         if constexpr (STRIDED) {
             // rows base_row + j: the lanes of a wave still cover the adjacent columns
             u64* dst = out + blockIdx.y * out_col_stride + ((size_t)blockIdx.z << log_n);
@@ -501,15 +512,15 @@ ntt16_kernel(const u64* in, u64* out /* may be `in`: the contiguous pass of a fo
 #pragma unroll
                 for (unsigned j = 0; j < 16; ++j) {
                     const unsigned e = j * T16_THREADS + tid;
-                    const unsigned t = __brev(e) >> (32 - T16_LOG);
-                    dst_col[((size_t)(e >> (T16_LOG - S)) << (log_n - S)) | run_base | (e & ((1u << (T16_LOG - S)) - 1u))] = tile[swz(t)];
+                    const unsigned ti = __brev(e) >> (32 - T16_LOG);
+                    dst_col[((size_t)(e >> (T16_LOG - S)) << (log_n - S)) | run_base | (e & ((1u << (T16_LOG - S)) - 1u))] = tile[swz(ti)];
                 }
             } else {
                 u64* dst = dst_col + ((size_t)blockIdx.z << log_n) + tile_base;
 #pragma unroll
                 for (unsigned j = 0; j < 16; ++j) {
-                    const unsigned t = j * T16_THREADS + tid;
-                    dst[t] = tile[swz(t)];
+                    const unsigned ti = j * T16_THREADS + tid;
+                    dst[ti] = tile[swz(ti)];
                 }
             }
         }
