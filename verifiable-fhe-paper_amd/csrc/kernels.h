@@ -13,7 +13,7 @@ using gl::u64;
 // roots[j] = w^j, j < n, w = primitive n-th root (or its inverse for the inverse transform)
 // roots: root_table_words(log_n) words -- the n powers of w (w^-1 for inverse) followed by the transform kernels' own tables for the PLAIN
 // transform of that direction (ntt.hip: from 2^12 points on the block twiddles tau^k of the radix-16 rounds, [round][k][block], with 1/n folded
-// into the first round of the inverse; at 2^11 the radix-8 round table)
+// into the first round of the inverse)
 size_t root_table_words(unsigned log_n);
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse);
 // prescale[r][i] = (shift * w_{log_n+rate_bits}^r)^i, r < 2^rate_bits, i < n  (a plain table of powers: the quotient's unshift table,

@@ -7,9 +7,8 @@
 // Design (MI355X): decimation-in-frequency, natural order in, bit-reversed order out -- which IS plonky2's leaf order,
 // so the transpose + reverse_index_bits passes of the reference disappear.  The rate-8 LDE is computed as 8
 // independent size-n coset transforms of coeff_i * (7 w^r)^i (never a zero-padded size-8n transform).
-// A transform is two launches: a strided pass (stages 0..log_r-1, tile = R rows x C adjacent columns in LDS, 128-B
-// row segments coalesced) and a contiguous pass (remaining stages on 2048-element tiles, in place).  Twiddles are
-// read from an HBM table of w^j (L2-resident: 128 KiB at n = 2^15).
+// From 2^12 points on a transform is two launches of radix-16 register rounds (a strided pass and a contiguous pass over 4096-element
+// tiles; below); smaller transforms run in one workgroup.
 #include <cstdlib>
 
 #define GL_ASM_SCRATCH_LOW 1  // these kernels need ~40 VGPRs of their own: keep the asm scratch block low (occupancy)
@@ -33,196 +32,39 @@ __global__ void prescale_table_kernel(u64* table, unsigned log_n, unsigned rate_
     if (i < ((size_t)1 << log_n)) table[((size_t)r << log_n) + i] = gl::pow(gl::mul(shift, gl::pow(w_big, r)), i);
 }
 
-// Register radix-8 rounds over an LDS tile of TILE elements (THREADS x 8).  A round performs up to three consecutive
-// DIF stages on the 8 values a thread holds, so the tile crosses LDS once per 3 stages instead of once per stage.
-// Stage "bits": the butterfly distance of a stage is 2^bit in tile-index space.  In a round with stage bits
-// b1 > b2 > b3 the thread owns the 8 tile indices that differ only in those bits; rounds with fewer than three stages
-// left fill the spare positions with unused low/high bits (those values just ride along).
-// tw(idx_lo, stage) returns the twiddle-table index of the butterfly whose low element sits at tile index idx_lo.
-// LDS swizzle: physical slot = idx ^ ((idx >> 3) & 31).  It is GF(2)-linear and a bijection on every aligned group of
-// 32 elements, and it makes all three lane patterns of the radix-8 rounds conflict-free for ds_read/write_b64
-// (lanes varying index bits {0..4}, {0,1,2,6,7} or {3..7}: see DESIGN.md) -- the unswizzled tile had 4- and 8-way
-// bank conflicts in the second and third round.
-__device__ __forceinline__ unsigned sw(unsigned idx) { return idx ^ ((idx >> 3) & 31u); }
-
-__device__ __forceinline__ unsigned insert_zero_bit(unsigned x, unsigned pos) {
-    return ((x >> pos) << (pos + 1)) | (x & ((1u << pos) - 1));
-}
-
-// A full round (three stages) is evaluated as a true radix-8 butterfly: the three radix-2 twiddles of element k factor as
-// W1 w_8^k, W2 w_4^(k&1), W4 with W1 = w^e1 the twiddle of the round's first butterfly, W2 = W1^2, W4 = W1^4 -- so the
-// 8th roots are applied inside (w_8 = -2^24, w_4 = 2^48, w_8^3 = -2^72: shifts, gl::mul_2e*), and each output gets ONE table
-// twiddle w^(j e1), j = 1..7: 7 modular multiplications + 5 shifts per 8 elements instead of 12 multiplications.
-// `inverse`: the table holds powers of w^-1, whose 8th roots are the conjugates (w_8^-1 = 2^72, w_4^-1 = -2^48, w_8^-3 = 2^24).
-// Where a round's twiddles come from.  Gathering w^(j e1) from the table of all n powers costs a 64-line memory instruction per twiddle in
-// the rounds whose exponents differ from lane to lane (the SQ counters of round 1 showed these kernels waiting, not computing: VALU issue
-// share 0.12).  Which twiddles a thread needs depends only on (transform size, pass, tile, round, thread) -- not on the column or the
-// coset -- so they are laid out once per transform size in exactly the order the threads consume them: rt[(round slot)][thread], a
-// coalesced 512-byte load per wave and twiddle, shared by every column and coset through L2.  RECORD: the pass that writes that layout
-// (run once per transform size on a dummy tile, by the same code that later reads it).
-template <bool RECORD> struct TwSource {
-    const u64* roots;   // w^i, i < n
-    u64* rt;            // this block's round table (slots x THREADS)
-    unsigned slot;
-    __device__ __forceinline__ u64 get(unsigned exponent) {
-        u64* p = rt + (size_t)slot * THREADS + threadIdx.x;
-        ++slot;
-        if (RECORD) {
-            const u64 v = roots[exponent];
-            *p = v;
-            return v;
-        }
-        return *p;
-    }
-};
-// twiddle slots a pass of n_stages stages uses per thread: 7 per full round, 4 per stage of a partial one
-__host__ __device__ inline unsigned round_slots(unsigned n_stages) { return 7 * (n_stages / 3) + 4 * (n_stages % 3); }
-
-template <bool RECORD, typename TwIndex>
-__device__ __forceinline__ void dif_rounds(u64* tile, unsigned n_stages, unsigned first_bit, TwSource<RECORD> tw, bool inverse,
-                                           TwIndex tw_index) {
-    // stage j (0-based inside this pass) has distance bit first_bit - j
-    for (unsigned j0 = 0; j0 < n_stages; j0 += 3) {
-        const unsigned ns = n_stages - j0 < 3 ? n_stages - j0 : 3;
-        // active bits, descending; spare bits chosen below the lowest active bit or above the highest
-        unsigned b[3];
-        b[0] = first_bit - j0;
-        b[1] = ns > 1 ? b[0] - 1 : (b[0] >= 1 ? b[0] - 1 : b[0] + 1);
-        b[2] = ns > 2 ? b[0] - 2 : (b[0] >= 2 ? b[0] - 2 : b[0] + (ns > 1 ? 1 : 2));
-        // sort descending so that zero-bit insertion goes from the lowest position up
-        unsigned p0 = b[0], p1 = b[1], p2 = b[2];
-        if (p0 < p1) { unsigned t = p0; p0 = p1; p1 = t; }
-        if (p1 < p2) { unsigned t = p1; p1 = p2; p2 = t; }
-        if (p0 < p1) { unsigned t = p0; p0 = p1; p1 = t; }
-        unsigned base = insert_zero_bit(insert_zero_bit(insert_zero_bit(threadIdx.x, p2), p1), p0);
-        const unsigned pbase = sw(base);  // sw is linear: sw(base | kbits) = sw(base) ^ sw(kbits), kbits wave-uniform
-        // element k: bit b[0] <- k>>2, b[1] <- (k>>1)&1, b[2] <- k&1   (b[] in stage order, not sorted order)
-        u64 x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = tile[pbase ^ sw((((k >> 2) & 1u) << b[0]) | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]))];
-        if (ns == 3) {
-            const unsigned e1 = tw_index(base, j0);  // exponent of W1; < n/8 because the three active bits of `base` are zero
-            u64 a[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = gl::add(x[k], x[k + 4]);
-            const u64 d0 = gl::sub(x[0], x[4]);
-            a[4] = d0;
-            if (!inverse) {
-                a[5] = gl::mul_2e24(gl::sub(x[5], x[1]));  // (x1 - x5) w_8,   w_8 = -2^24
-                a[6] = gl::mul_2e48(gl::sub(x[2], x[6]));  // (x2 - x6) w_8^2
-                a[7] = gl::mul_2e72(gl::sub(x[7], x[3]));  // (x3 - x7) w_8^3, w_8^3 = -2^72
-            } else {
-                a[5] = gl::mul_2e72(gl::sub(x[1], x[5]));
-                a[6] = gl::mul_2e48(gl::sub(x[6], x[2]));
-                a[7] = gl::mul_2e24(gl::sub(x[3], x[7]));
-            }
-            u64 bq[8];
-#pragma unroll
-            for (int h = 0; h < 8; h += 4) {
-                bq[h] = gl::add(a[h], a[h + 2]);
-                bq[h + 2] = gl::sub(a[h], a[h + 2]);
-                bq[h + 1] = gl::add(a[h + 1], a[h + 3]);
-                bq[h + 3] = gl::mul_2e48(inverse ? gl::sub(a[h + 3], a[h + 1]) : gl::sub(a[h + 1], a[h + 3]));  // times w_4
-            }
-            // outputs: element k carries W_j with j = bit-reversal of k over 3 bits
-            // the seven twiddles are requested together, ahead of the butterfly arithmetic that precedes their use
-            const u64 t4 = tw.get(4 * e1), t2 = tw.get(2 * e1), t6 = tw.get(6 * e1), t1 = tw.get(e1), t5 = tw.get(5 * e1), t3 = tw.get(3 * e1),
-                      t7 = tw.get(7 * e1);
-            x[0] = gl::add(bq[0], bq[1]);
-            x[1] = gl::mul(gl::sub(bq[0], bq[1]), t4);
-            x[2] = gl::mul(gl::add(bq[2], bq[3]), t2);
-            x[3] = gl::mul(gl::sub(bq[2], bq[3]), t6);
-            x[4] = gl::mul(gl::add(bq[4], bq[5]), t1);
-            x[5] = gl::mul(gl::sub(bq[4], bq[5]), t5);
-            x[6] = gl::mul(gl::add(bq[6], bq[7]), t3);
-            x[7] = gl::mul(gl::sub(bq[6], bq[7]), t7);
-        } else {
-        // stage A: pairs (k, k+4)
-        {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned lo = base | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]);
-                const u64 u = x[k], v = x[k + 4];
-                x[k] = gl::add(u, v);
-                x[k + 4] = gl::mul(gl::sub(u, v), tw.get(tw_index(lo, j0)));
-            }
-        }
-        if (ns > 1) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k & 2) continue;  // pairs (k, k+2)
-                const unsigned lo = base | (((k >> 2) & 1u) << b[0]) | ((k & 1u) << b[2]);
-                const u64 u = x[k], v = x[k + 2];
-                x[k] = gl::add(u, v);
-                x[k + 2] = gl::mul(gl::sub(u, v), tw.get(tw_index(lo, j0 + 1)));
-            }
-        }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tile[pbase ^ sw((((k >> 2) & 1u) << b[0]) | (((k >> 1) & 1u) << b[1]) | ((k & 1u) << b[2]))] = x[k];
-        __syncthreads();
-    }
-}
-
-// Contiguous pass: stages [s_begin, log_n) on blocks of B = n >> s_begin elements; one workgroup owns
-// min(TILE, n) consecutive elements.  If s_begin == 0 the input is read from `in` (with optional prescale), else the
-// transform continues in place in `out`.  bitrev_out: scatter to natural order and scale (inverse transform).
-template <bool RECORD>
+// Transforms below 2^12 points (FRI's last rounds, small test circuits): ONE workgroup per column and coset, the whole transform in LDS as
+// radix-2 decimation-in-frequency sweeps, natural order in, bit-reversed order out (forward) or natural order out + 1/n (inverse).  Not a
+// hot path: every transform of the prover's commitments has 2^12 points or more and takes the radix-16 passes below.
 __global__ void __launch_bounds__(THREADS)
-ntt_contig_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale,
-                  const u64* __restrict__ roots, u64* __restrict__ round_tables, unsigned log_n, unsigned s_begin, size_t in_col_stride,
-                  size_t out_col_stride, unsigned rate_bits, int bitrev_out, u64 scale, unsigned block_first) {
+ntt_small_kernel(const u64* __restrict__ in, u64* __restrict__ out, const u64* __restrict__ prescale, const u64* __restrict__ roots,
+                 unsigned log_n, size_t in_col_stride, size_t out_col_stride, unsigned rate_bits, int inverse, u64 scale, unsigned block_first) {
     __shared__ u64 tile[TILE];
-    // one table for every tile: ((base + lo) & (half - 1)) << s does not depend on the tile (base is a multiple of 2 half)
-    TwSource<RECORD> tw{roots, round_tables, 0};
     const unsigned n = 1u << log_n;
-    const unsigned tile_elems = n < TILE ? n : TILE;
-    const unsigned base = blockIdx.x * tile_elems;
-    const unsigned coset = gl::bitrev32(block_first + blockIdx.z, rate_bits);
-    const size_t coset_off = (size_t)blockIdx.z << log_n;
-    u64* dst_col = out + blockIdx.y * out_col_stride;
-    if (RECORD) {
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[sw(t)] = 0;
-    } else if (s_begin == 0) {
-        const u64* src = in + blockIdx.y * in_col_stride;
-        const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) {
-            u64 x = src[base + t];
-            if (ps) x = gl::mul(x, ps[base + t]);
-            tile[sw(t)] = x;
-        }
-    } else {
-        // in place continuation; for the inverse transform the strided pass wrote to `in` (scratch)
-        const u64* src = bitrev_out ? in + blockIdx.y * in_col_stride : dst_col + coset_off;
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) tile[sw(t)] = src[base + t];
+    const unsigned coset = gl::bitrev32(block_first + blockIdx.z, rate_bits);   // leaf block B holds coset brev(B)
+    const u64* src = in + blockIdx.y * in_col_stride;
+    const u64* ps = prescale ? prescale + ((size_t)coset << log_n) : nullptr;
+    for (unsigned t = threadIdx.x; t < n; t += THREADS) {
+        u64 x = src[t];
+        if (ps) x = gl::mul(x, ps[t]);
+        tile[t] = x;
     }
     __syncthreads();
-    if (tile_elems == TILE) {
-        // stage s: distance n >> (s+1) = tile bit log_n - 1 - s
-        dif_rounds(tile, log_n - s_begin, log_n - 1 - s_begin, tw, bitrev_out != 0, [=](unsigned lo, unsigned j) {
-            const unsigned s = s_begin + j;
-            const unsigned half = n >> (s + 1);
-            return ((base + lo) & (half - 1)) << s;
-        });
-    } else {
-        // small transforms (n < 2048): plain radix-2 sweeps
-        for (unsigned s = s_begin; s < log_n; ++s) {
-            const unsigned half = n >> (s + 1);
-            for (unsigned k = threadIdx.x; k < tile_elems / 2; k += THREADS) {
-                const unsigned lo = ((k / half) * 2 * half) + (k % half);
-                const u64 u = tile[sw(lo)], v = tile[sw(lo + half)];
-                tile[sw(lo)] = gl::add(u, v);
-                tile[sw(lo + half)] = gl::mul(gl::sub(u, v), roots[((base + lo) & (half - 1)) << s]);
-            }
-            __syncthreads();
+    for (unsigned s = 0; s < log_n; ++s) {
+        const unsigned half = n >> (s + 1);
+        for (unsigned k = threadIdx.x; k < n / 2; k += THREADS) {
+            const unsigned lo = ((k / half) * 2 * half) + (k % half);
+            const u64 u = tile[lo], v = tile[lo + half];
+            tile[lo] = gl::add(u, v);
+            tile[lo + half] = gl::mul(gl::sub(u, v), roots[(lo & (half - 1)) << s]);
         }
+        __syncthreads();
     }
-    if (RECORD) return;
-    if (bitrev_out) {
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS)
-            dst_col[gl::bitrev32(base + t, log_n)] = gl::mul(tile[sw(t)], scale);
+    u64* dst_col = out + blockIdx.y * out_col_stride;
+    if (inverse) {
+        for (unsigned t = threadIdx.x; t < n; t += THREADS) dst_col[gl::bitrev32(t, log_n)] = gl::mul(tile[t], scale);
     } else {
-        for (unsigned t = threadIdx.x; t < tile_elems; t += THREADS) dst_col[coset_off + base + t] = tile[sw(t)];
+        u64* dst = dst_col + ((size_t)blockIdx.z << log_n);
+        for (unsigned t = threadIdx.x; t < n; t += THREADS) dst[t] = tile[t];
     }
 }
 
@@ -662,13 +504,10 @@ void run_transform16(hipStream_t s, const u64* in, u64* out, u64* scratch, const
 }  // namespace
 
 // ---- tables ----
-// Transforms below 2^12 points run as ONE launch of the radix-8 tile kernel above (2^11: register rounds with a round table recorded behind
-// the powers; smaller: radix-2 sweeps).  From 2^12 on: the radix-16 passes, whose tables sit behind the powers as well.
-static size_t small_round_words(unsigned log_n) { return log_n == TILE_LOG ? (size_t)round_slots(log_n) * THREADS : 0; }
-
+// The n powers of the root; from 2^12 points on the radix-16 passes' tables for the plain transform of that direction follow them.
 size_t root_table_words(unsigned log_n) {
     const size_t n = (size_t)1 << log_n;
-    return n + (uses_radix16(log_n) ? plan16(log_n).coset_words : small_round_words(log_n));
+    return n + (uses_radix16(log_n) ? plan16(log_n).coset_words : 0);
 }
 
 void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse) {
@@ -676,13 +515,7 @@ void launch_root_table(hipStream_t s, u64* roots, unsigned log_n, bool inverse) 
     if (inverse) w = gl::inv(w);
     const size_t cnt = (size_t)1 << log_n;
     hipLaunchKernelGGL(root_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, roots, log_n, w);
-    if (uses_radix16(log_n)) {
-        launch_table16(s, roots + cnt, log_n, 0, 1, inverse);   // the plain transform of this direction: shift 1, one coset, 1/n for the inverse
-    } else if (small_round_words(log_n)) {
-        // the round table: the transform kernel itself in RECORD mode, one column, on a dummy tile
-        hipLaunchKernelGGL(ntt_contig_kernel<true>, dim3(1, 1, 1), dim3(THREADS), 0, s, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr,
-                           (const u64*)roots, roots + cnt, log_n, 0u, (size_t)0, (size_t)0, 0u, inverse ? 1 : 0, (u64)1, 0u);
-    }
+    if (uses_radix16(log_n)) launch_table16(s, roots + cnt, log_n, 0, 1, inverse);   // shift 1, one coset, 1/n for the inverse
 }
 
 void launch_prescale_table(hipStream_t s, u64* table, unsigned log_n, unsigned rate_bits, u64 shift) {
@@ -706,8 +539,8 @@ void launch_intt(hipStream_t s, const u64* values, u64* coeffs, u64* scratch, co
         run_transform16<true>(s, values, coeffs, scratch, inv_roots + n, ncols, log_n, 0, n, n, 0, 1);
         return;
     }
-    hipLaunchKernelGGL(ntt_contig_kernel<false>, dim3(1, ncols, 1), dim3(THREADS), 0, s, values, coeffs, (const u64*)nullptr, inv_roots,
-                       const_cast<u64*>(inv_roots) + n, log_n, 0u, n, n, 0u, 1, gl::inv((u64)n), 0u);
+    hipLaunchKernelGGL(ntt_small_kernel, dim3(1, ncols, 1), dim3(THREADS), 0, s, values, coeffs, (const u64*)nullptr, inv_roots, log_n, n, n, 0u, 1,
+                       gl::inv((u64)n), 0u);
 }
 
 void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roots, const u64* lde_table, unsigned ncols,
@@ -719,8 +552,8 @@ void launch_coset_lde(hipStream_t s, const u64* coeffs, u64* out, const u64* roo
         run_transform16<false>(s, coeffs, out, nullptr, lde_table, ncols, log_n, rate_bits, n, n * n_blocks, block_first, n_blocks);
         return;
     }
-    hipLaunchKernelGGL(ntt_contig_kernel<false>, dim3(1, ncols, n_blocks), dim3(THREADS), 0, s, coeffs, out, lde_table, roots,
-                       const_cast<u64*>(roots) + n, log_n, 0u, n, n * n_blocks, rate_bits, 0, (u64)1, block_first);
+    hipLaunchKernelGGL(ntt_small_kernel, dim3(1, ncols, n_blocks), dim3(THREADS), 0, s, coeffs, out, lde_table, roots, log_n, n, n * n_blocks, rate_bits,
+                       0, (u64)1, block_first);
 }
 
 void launch_negacyclic(hipStream_t s, u64* data, const u64* table, unsigned batch, unsigned log_n, bool inverse, u64 ninv) {
