@@ -212,15 +212,13 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
         "v_mad_u64_u32 v[80:81], s[80:81], v84, -1, v[80:81]\n\t"
         "v_mad_u64_u32 v[88:89], s[86:87], v92, -1, v[88:89]\n\t"
         "v_sub_co_u32_e32 v80, vcc, v80, v85\n\t"
-        "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
-        "s_mov_b64 s[82:83], vcc\n\t"
+        "v_subbrev_co_u32_e64 v81, s[82:83], 0, v81, vcc\n\t"
         "v_sub_co_u32_e32 v88, vcc, v88, v93\n\t"
-        "v_subbrev_co_u32_e32 v89, vcc, 0, v89, vcc\n\t"
+        "v_subbrev_co_u32_e64 v89, s[84:85], 0, v89, vcc\n\t"
         "v_cndmask_b32_e64 v87, 0, -1, s[80:81]\n\t"
         "v_cndmask_b32_e64 v95, 0, -1, s[86:87]\n\t"
-        "s_or_b64 s[84:85], s[82:83], vcc\n\t"
+        "s_or_b64 s[88:89], s[82:83], s[84:85]\n\t"
         "s_cbranch_scc0 .Lgl_red2_%=\n\t"
-        "s_mov_b64 s[84:85], vcc\n\t"
         "v_cndmask_b32_e64 v86, 0, -1, s[82:83]\n\t"
         "v_sub_co_u32_e32 v80, vcc, v80, v86\n\t"
         "v_subbrev_co_u32_e32 v81, vcc, 0, v81, vcc\n\t"
