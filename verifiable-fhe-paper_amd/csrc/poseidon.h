@@ -17,11 +17,13 @@ using gl::u64;
 
 constexpr int WIDTH = 12, RATE = 8, N_ROUNDS = 30, HALF_FULL = 4, N_PARTIAL = 22;
 
-static const u64 RC_HOST[360] = {
+// 360 round constants + 12 zeros: the constants "after the last round" (the last MDS layer adds nothing, and a zero block keeps the second half's
+// rounds uniform: no select in front of the scalar loads' first use)
+static const u64 RC_HOST[372] = {
 #include "poseidon_constants.inc"
 };
 #if defined(__HIPCC__)
-static __constant__ u64 RC_DEV[360] = {
+static __constant__ u64 RC_DEV[372] = {
 #include "poseidon_constants.inc"
 };
 #endif
@@ -327,8 +329,7 @@ template <int I> struct GroupRow {
 // w[0..3) instead of the computed values, and the computed inputs of rounds 2 and 3 are returned (canonical) in x_out[0..2)
 // for the constraints "computed - wire" (round 1's input is s[0] on entry).  GATE = false with x_out != nullptr is the witness
 // generator's form: the plain permutation that also reports those two S-box inputs (the gate's wires).
-template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w, u64* x_out) {
-    const PartialGroup& G = partial_group(g);
+template <bool GATE> GL_HD void partial_group3_core(u64* s, const PartialGroup& G, const u64* w, u64* x_out) {
     // request the group's constants before the first S-box (scalar-load latency hidden under it)
     const u64 k2 = G.k2, k3 = G.k3;
     u64 kv[12];
@@ -393,6 +394,9 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
     }
 #endif
 }
+template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w, u64* x_out) {
+    partial_group3_core<GATE>(s, partial_group(g), w, x_out);
+}
 GL_HD void partial_group3(u64* s, int g) { partial_group3_core<false>(s, g, nullptr, nullptr); }
 
 // in/out: canonical field elements
@@ -410,7 +414,11 @@ GL_HD void permute(u64* s) {
         mds_add_const(s, kc);
     }
     // 22 partial rounds = 7 fused groups of 3 (rounds 4..24) + round 25
-    for (int g = 0; g < 7; ++g) partial_group3(s, g);
+    {
+        // (the table's address is re-derived by the compiler in front of every group -- one scalar load from the constant pool; making the
+        // pointer opaque to stop that turns the group's constants into vector loads: measured, worse)
+        for (int g = 0; g < 7; ++g) partial_group3(s, g);
+    }
     {
         u64 kc[12];
 #pragma unroll
@@ -420,13 +428,9 @@ GL_HD void permute(u64* s) {
     }
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; ++r) {
         u64 kc[12];
-        const bool last = r + 1 >= N_ROUNDS;                    // the last round adds nothing: zeros ride in as its constants
-        const int next = last ? 0 : 12 * (r + 1);
+        const int next = 12 * (r + 1);                          // r = 29: the zero block behind the constants (the last round adds nothing)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const u64 k = rc(next + i);
-            kc[i] = last ? 0 : k;
-        }
+        for (int i = 0; i < 12; ++i) kc[i] = rc(next + i);
 #pragma unroll
         for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
         mds_add_const(s, kc);
