@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: whole-chain throughput of tools/prove_ivc.py over a MATRIX of host configurations -- the one runner behind the round-4/5
 # host-side findings (CPU share of a rank, chains per GPU, hardware queues, sleeping waits, device witness batch).  One line per run:
 # ms per chained proof, vPBS/s, late phase / proof split, CPU-ms per proof (VPBS_CPU_BY_ROLE), host load.
-# usage: ivc_matrix.sh RUN [RUN ...] | ivc_matrix.sh --preset NAME
+# usage: [BY_ROLE=1] ivc_matrix.sh RUN [RUN ...] | ivc_matrix.sh --preset NAME     (BY_ROLE=1 adds the CPU-ms per proof of every thread role)
 #   RUN = "[VAR=value,VAR=value:]cpus:chains:device_witness:steps"   (cpus = taskset mask size, 16 = no mask)
 # Presets = the argument lists of the one-off scripts this replaces (their names are what profiles/README.md and older records cite):
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
@@ -26,5 +26,6 @@ for run in "${runs[@]}"; do
   pre=""; [ "$cpus" != "16" ] && pre="taskset -c 0-$(( cpus - 1 ))"
   env $envs VPBS_CPU_BY_ROLE=1 VPBS_IVC_CHAINS=$chains VPBS_IVC_DEVICE_WITNESS=$dw timeout -k 5 400 $pre python3 tools/prove_ivc.py 1024 728 16 $steps 2>/dev/null | tail -1 | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); s=d['ms_per_step_split']; c=d.get('cpu_by_role') or {}
-print('[$envs] cpus=$cpus chains=$chains dw=$dw', round(d['ms_per_step']/d['chains'],3), 'ms/proof', round(d['chains']*1e3/d['ms_per_step']/730,4), 'vPBS/s  late', round(s['witness_late_phase_host'],2), 'prove', round(s['prove_step'],2), 'cpu-ms/proof', c.get('cpu_ms_per_chained_step'), 'load', round(d['host']['loadavg']))"
+print('[$envs] cpus=$cpus chains=$chains dw=$dw', round(d['ms_per_step']/d['chains'],3), 'ms/proof', round(d['chains']*1e3/d['ms_per_step']/730,4), 'vPBS/s  late', round(s['witness_late_phase_host'],2), 'prove', round(s['prove_step'],2), 'cpu-ms/proof', c.get('cpu_ms_per_chained_step'), 'load', round(d['host']['loadavg']))
+if '${BY_ROLE:-}': print('    by role', c.get('cpu_ms_per_chained_step_by_role'))"
 done

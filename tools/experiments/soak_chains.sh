@@ -1,0 +1,20 @@
+#!/bin/bash
+# Soak of the final round-5 kernels (residue arithmetic with rare wrap paths, radix-16 NTT, fused Poseidon groups): whole 730-step chains in the
+# arrangements a deployment uses, every chain's last proof verified by vpbs_verify_pbs and decrypted by the tool, completion-word waits counted
+# (VPBS_TRACE_SYNC).  One line per arrangement; the condensed record is profiles/r05_soak.json.
+# usage (GPU box): tools/experiments/soak_chains.sh [out_dir]
+out=${1:-gpurun_out/soak_r05}; mkdir -p $out
+run() { # name mask chains device_witness N log_degree
+  local pre=""; [ -n "$2" ] && pre="taskset -c $2"
+  VPBS_TRACE_SYNC=1 VPBS_IVC_CHAINS=$3 VPBS_IVC_DEVICE_WITNESS=$4 timeout -k 5 900 $pre python tools/prove_ivc.py ${5:-1024} 728 ${6:-16} 730 > $out/$1.json 2> $out/$1.err
+  echo "$1 rc=$? $(grep -a '\[sync\]' $out/$1.err | tail -1) $(tail -1 $out/$1.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['chains'], 'chains', round(d['seconds'],1), 's', round(d['vpbs_proofs_per_s'],4), 'vPBS/s; decrypted', [d['decrypted']==d['message']]+[c['decrypted']==c['message'] for c in d['other_chains']], 'load', round(d['host']['loadavg']))")"
+}
+run host8_a "" 8 0
+run dw8_a "" 8 64
+run dw8_2cpus "0-1" 8 64
+run single_a "" 1 0
+run host8_b "" 8 0
+run dw8_4cpus "0-3" 8 64
+run single_n2048 "" 1 0 2048 17
+run host8_c "" 8 0
