@@ -68,18 +68,24 @@ struct LazyAcc {
         return gl::sub_a(gl::reduce128_asm(lo, (u32)H, (u32)hh), top << 32);
     }
 };
+// The sink multiplies every constraint into NC running sums WITHOUT asking how many challenges there are: with fewer than NC challenges the
+// spare sums repeat the last challenge's powers (row[] points there) and are never read.  A run-time `a < nc` around each multiply-accumulate
+// made the compiler keep two copies of every accumulator (three 64-bit moves per constraint and challenge) and a branch per challenge.
 template <int NC> struct DevSinkT {
-    const u64* apow;  // [nc][pow_stride]
-    unsigned pow_stride, nc, idx;
+    const u64* row[NC];  // challenge a's powers of alpha (challenge nc - 1's for a >= nc)
+    unsigned idx;
     LazyAcc acc[NC];
+    __device__ __forceinline__ DevSinkT(const u64* apow, unsigned pow_stride, unsigned nc) : idx(0), acc{} {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) row[a] = apow + (size_t)((unsigned)a < nc ? (unsigned)a : (nc ? nc - 1 : 0)) * pow_stride;
+    }
     __device__ __forceinline__ void push(u64 c) {
         const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
 #pragma unroll
-        for (int a = 0; a < NC; ++a)
-            if ((unsigned)a < nc) {
-                const u64 p = apow[a * pow_stride + idx];
-                acc[a].mac(c0, c1, (u32)p, (u32)(p >> 32));
-            }
+        for (int a = 0; a < NC; ++a) {
+            const u64 p = row[a][idx];
+            acc[a].mac(c0, c1, (u32)p, (u32)(p >> 32));
+        }
         ++idx;
     }
 };
@@ -295,7 +301,7 @@ gate_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_
     const size_t j = j0 + blockIdx.x * (size_t)THREADS + threadIdx.x;
     if (j >= j1) return;
     DevVars v{wires, consts + (size_t)num_selectors * len, len, j, pih};
-    DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
+    DevSinkT<NC> s(apow, pow_stride, nc);
     eval_kind<KIND>(g, tables, v, s);
     const u64 filter = gates::compute_filter<u64>(g, consts[(size_t)g.selector_index * len + j], num_selectors > 1);
 #pragma unroll
@@ -360,7 +366,7 @@ gate_fused_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts,
         size_t jj = j;
         asm volatile("" : "+v"(jj));
         DevVars v{wires, consts + (size_t)num_selectors * len, len, jj, pih};
-        DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
+        DevSinkT<NC> s(apow, pow_stride, nc);
         switch (g.kind) {  // wave-uniform
 #define VPBS_FUSED_CASE(K) case K: eval_kind<K>(g, plan.tables, v, s); break;
             VPBS_FUSED_CASE(VPBS_GATE_CONSTANT)
@@ -405,9 +411,11 @@ struct TilePlan {
     unsigned wave_first[TILE_WAVES + 1];
     unsigned n_wires, n_consts;        // columns staged: wires [0, n_wires), then constants_sigmas columns [0, n_consts)
 };
+using LdsWords = const __attribute__((address_space(3))) u64*;   // a pointer the compiler KNOWS is LDS: ds_read_b64 with the column as the
+                                                                 // instruction's offset (a generic pointer reads through flat_load + 64-bit adds)
 struct LdsVars {
     using F = u64;
-    const u64* lds;    // [n_wires + n_consts][64], this lane's column of it
+    LdsWords lds;      // [n_wires + n_consts][64], this lane's column of it
     unsigned n_wires, first_const;   // first_const: LDS column of the first gate constant (n_wires + num_selectors)
     PiHash pih;
     __device__ __forceinline__ u64 wire(unsigned i) const { return lds[i * TILE_PTS]; }
@@ -448,10 +456,11 @@ gate_tile_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, 
     for (unsigned u = plan.wave_first[wave]; u < plan.wave_first[wave + 1]; ++u) {
         const vpbs_gate& g = plan.gates[u];
         const unsigned long long t_unit = prof ? __builtin_amdgcn_s_memtime() : 0;
-        const u64* base = lds + lane;
-        asm volatile("" : "+v"(base));   // opaque per unit: keeps the cases' LDS addresses from being hoisted and kept live across all of them
+        unsigned lds_at = (unsigned)(uintptr_t)(LdsWords)(lds + lane);   // the 32-bit LDS address of this lane's column
+        asm volatile("" : "+v"(lds_at));   // opaque per unit: keeps the cases' LDS addresses from being hoisted and kept live across all of them
+        const LdsWords base = (LdsWords)(uintptr_t)lds_at;
         LdsVars v{base, plan.n_wires, plan.n_wires + num_selectors, pih};
-        DevSinkT<NC> s{apow, pow_stride, nc, 0, {}};
+        DevSinkT<NC> s(apow, pow_stride, nc);
         if (g.kind == VPBS_GATE_POSEIDON && plan.part[u]) {
             switch (plan.part[u]) {
                 case 1: poseidon_gate_part<1>(v, s); break;
