@@ -39,14 +39,17 @@ l0_table_kernel(const u64* __restrict__ roots_big, QuotientConsts k, unsigned lo
 
 // grid (8n / 256).  apow: [nc][n_terms + 1] powers of alpha_a.  q: [nc][8n] in leaf order.
 // DEG: compile-time chunk size (8 = plonky2's quotient_degree_factor) so that the 16 loads of a chunk are issued
-// together; DEG = 0 selects the generic run-time loop.
-template <unsigned DEG>
+// together; DEG = 0 selects the generic run-time loop.  NCT: the number of challenges when it is plonky2's standard 2 (0 = run-time nc): the
+// `c < nc` tests around every per-challenge operation then fold away, and with them the copies of the running products the compiler kept
+// around each predicated update.
+template <unsigned DEG, unsigned NCT>
 __global__ void __launch_bounds__(THREADS)
 quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ zs_pp,
                      const u64* __restrict__ roots_big, const u64* __restrict__ l0_table, const u64* __restrict__ gate_terms,
                      const u64* __restrict__ apow,
-                     QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc,
+                     QuotientConsts k, unsigned n_routed, unsigned log_n, unsigned rate_bits, unsigned max_degree, unsigned nc_given,
                      size_t leaf_offset, size_t local_len, u64* __restrict__ q, int raw) {
+    const unsigned nc = NCT ? NCT : nc_given;
     // The column arrays hold the leaves [leaf_offset, leaf_offset + local_len) only (a whole number of cosets; the full
     // LDE when unsharded): `big` below is their column stride and j the LOCAL leaf index.
     const unsigned log_big = log_n + rate_bits;
@@ -205,12 +208,9 @@ void launch_quotient_values(hipStream_t s, const u64* wires_lde, const u64* sigm
         k.gamma[c] = gammas[c];
     }
     const dim3 grid((unsigned)((local_len + THREADS - 1) / THREADS));
-    if (max_degree == 8)
-        hipLaunchKernelGGL(quotient_perm_kernel<8>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
-                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local, raw ? 1 : 0);
-    else
-        hipLaunchKernelGGL(quotient_perm_kernel<0>, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table,
-                           d_gate_terms, d_apow, k, n_routed, log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local, raw ? 1 : 0);
+    const auto kernel = max_degree == 8 ? (nc == 2 ? quotient_perm_kernel<8, 2> : quotient_perm_kernel<8, 0>) : quotient_perm_kernel<0, 0>;
+    hipLaunchKernelGGL(kernel, grid, dim3(THREADS), 0, s, wires_lde, sigmas_lde, zs_pp_lde, roots_big, l0_table, d_gate_terms, d_apow, k, n_routed,
+                       log_n, rate_bits, max_degree, nc, leaf_offset, local_len, q_leaf_local, raw ? 1 : 0);
 }
 
 void launch_quotient_combine(hipStream_t s, u64* q_local, const u64* g0, const u64* g1, const u64* g2, const u64* apow_last, unsigned log_n,
