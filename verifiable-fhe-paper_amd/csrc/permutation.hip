@@ -11,6 +11,7 @@
 // wire and sigma columns (coalesced across rows); exact arithmetic => bit-identical to the sequential reference.
 #define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
+#include "poseidon.h"   // fold96: 7 x on residues
 
 namespace vpbs {
 namespace {
@@ -54,6 +55,66 @@ pp_row_kernel(const u64* __restrict__ chunk_q, size_t n, unsigned n_chunks, u64*
         if (k < num_prods) pp[((size_t)c * num_prods + k) * n + i] = run;
     }
     rowprod[(size_t)c * n + i] = run;
+}
+
+// The standard shape (80 routed wires in 10 chunks of 8) in ONE kernel, one thread per (row, challenge): the ten chunk quotients share ONE
+// field inversion (Montgomery's trick: prefix products of the denominators, one inverse, back-substitution -- what plonky2's
+// batch_multiplicative_inverse does across rows), the running products of pp_row_kernel follow in registers, and everything in between is
+// computed on u64 residues (gl::add_a / mul_nc / mad_nc; stored values canonical).  An inversion is 72 multiplications against the chunk's own
+// 24: 2.0 k -> 0.78 k instructions per (row, challenge, chunk), and chunk_q is neither written nor read.  Field results are exact, so the
+// values equal those of the three-kernel path bit for bit (a zero denominator raises the flag, and the step fails, on either path).
+template <unsigned DEG, unsigned CHUNKS>
+__global__ void __launch_bounds__(THREADS)
+pp_rows_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigmas, const u64* __restrict__ roots, unsigned log_n,
+               const u64* __restrict__ betas, const u64* __restrict__ gammas, u64* __restrict__ pp, u64* __restrict__ rowprod,
+               unsigned* __restrict__ zero_flag) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x;
+    const unsigned c = blockIdx.y;
+    if (i >= n) return;
+    const u64 beta = betas[c], gamma = gammas[c];
+    const u64 x = i < n / 2 ? roots[i] : gl::neg(roots[i - n / 2]);
+    u64 t = gl::mul_nc(beta, x);   // beta k_j x, k_j = 7^j: a residue
+    u64 num[CHUNKS], den[CHUNKS];
+#pragma unroll
+    for (unsigned k = 0; k < CHUNKS; ++k) {
+        u64 wv[DEG], sv[DEG];
+#pragma unroll
+        for (unsigned u = 0; u < DEG; ++u) {
+            wv[u] = wires[(size_t)(k * DEG + u) * n + i];
+            sv[u] = sigmas[(size_t)(k * DEG + u) * n + i];
+        }
+        u64 nu = 0, de = 0;
+#pragma unroll
+        for (unsigned u = 0; u < DEG; ++u) {
+            const u64 wg = gl::add_a(wv[u], gamma);
+            const u64 a = gl::add_a(wg, t), b = gl::mad_nc(beta, sv[u], wg);
+            nu = u ? gl::mul_nc(nu, a) : a;
+            de = u ? gl::mul_nc(de, b) : b;
+            t = poseidon::fold96((u64)(u32)t * 7u, (u64)(u32)(t >> 32) * 7u);
+        }
+        num[k] = nu;
+        den[k] = de;
+    }
+    u64 pre[CHUNKS];
+    pre[0] = den[0];
+#pragma unroll
+    for (unsigned k = 1; k < CHUNKS; ++k) pre[k] = gl::mul_nc(pre[k - 1], den[k]);
+    if (gl::canon(pre[CHUNKS - 1]) == 0) atomicOr(zero_flag, 1u);  // plonky2's batch inverse would panic here
+    u64 inv_rest = gl::inv(pre[CHUNKS - 1]);   // 1 / (den[0] .. den[k]) as k runs down
+#pragma unroll
+    for (unsigned k = CHUNKS - 1; k > 0; --k) {
+        num[k] = gl::mul_nc(num[k], gl::mul_nc(inv_rest, pre[k - 1]));   // num[k] / den[k]
+        inv_rest = gl::mul_nc(inv_rest, den[k]);
+    }
+    u64 run = gl::mul_nc(num[0], inv_rest);
+    u64* out = pp + (size_t)c * (CHUNKS - 1) * n + i;
+#pragma unroll
+    for (unsigned k = 0; k + 1 < CHUNKS; ++k) {
+        if (k) run = gl::mul_nc(run, num[k]);
+        out[(size_t)k * n] = gl::canon(run);
+    }
+    rowprod[(size_t)c * n + i] = gl::mul(run, num[CHUNKS - 1]);
 }
 
 __device__ u64 block_product(u64 v, u64* sh) {
@@ -116,9 +177,14 @@ void launch_partial_products(hipStream_t s, const u64* wires, const u64* sigmas,
     u64* block_prod = scratch + (size_t)num_challenges * n;          // [nc][blocks]
     u64* chunk_q = block_prod + (size_t)num_challenges * blocks;     // [nc][n_chunks][n]
     u64* pp = out + (size_t)num_challenges * n;
+    if (max_degree == 8 && n_routed == 80) {
+        hipLaunchKernelGGL((pp_rows_kernel<8, 10>), dim3(blocks, num_challenges), dim3(THREADS), 0, s, wires, sigmas, roots, log_n, d_betas, d_gammas, pp,
+                           rowprod, d_zero_flag);
+    } else {
     hipLaunchKernelGGL(pp_chunk_kernel, dim3(blocks, num_challenges, n_chunks), dim3(THREADS), 0, s, wires, sigmas, roots, n_routed, log_n,
                        max_degree, d_betas, d_gammas, chunk_q, d_zero_flag);
     hipLaunchKernelGGL(pp_row_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)chunk_q, n, n_chunks, pp, rowprod);
+    }
     hipLaunchKernelGGL(pp_block_prod_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, n, block_prod);
     hipLaunchKernelGGL(pp_finish_kernel, dim3(blocks, num_challenges), dim3(THREADS), 0, s, (const u64*)rowprod, (const u64*)block_prod, n,
                        num_prods, num_challenges, out);
