@@ -650,8 +650,13 @@ def valu_budget(sclk_hz, step_ms):
         by = {r["kernel"]: r for r in rows}
         if "leaf_hash_kernel" not in by:
             continue
-        steps = float(by["leaf_hash_kernel"]["launches"]) / 3.0            # three leaf-hash launches per step proof
-        per = {k: float(r["SQ_INSTS_VALU"]) / steps / 1e9 for k, r in by.items() if float(r["SQ_INSTS_VALU"]) > 0}
+        if "valu_per_step_proof" in rows[0]:   # exact: whole periods of the step's kernel sequence, setup excluded (tools/pmc_table.py)
+            per = {k: float(r["valu_per_step_proof"]) / 1e9 for k, r in by.items() if float(r["valu_per_step_proof"]) > 0}
+            basis = "SQ_INSTS_VALU of the dispatches between the first and the last quotient_perm_kernel dispatch / the periods between them"
+        else:                                   # tables of earlier rounds: all launches (the setup commitment's too) / (leaf-hash launches / 3)
+            steps = float(by["leaf_hash_kernel"]["launches"]) / 3.0
+            per = {k: float(r["SQ_INSTS_VALU"]) / steps / 1e9 for k, r in by.items() if float(r["SQ_INSTS_VALU"]) > 0}
+            basis = "SQ_INSTS_VALU per kernel over all launches / (leaf-hash launches / 3)"
         total = sum(per.values())
         top = dict(sorted(per.items(), key=lambda kv: -kv[1])[:8])
         top["(all others)"] = total - sum(top.values())
@@ -660,7 +665,7 @@ def valu_budget(sclk_hz, step_ms):
         return {"bound": "int-valu-issue (whole step)", "wave_instructions_per_step_G": total, "by_kernel_G": top,
                 "issue_peak_G_wave_instr_per_s": issue / 1e9, "shader_clock_mhz": sclk_hz / 1e6,
                 "instruction_time_ms_per_step": floor_ms, "measured_ms_per_step_proof": step_ms, "frac": floor_ms / step_ms,
-                "counters_from": "profiles/" + name + " (SQ_INSTS_VALU per kernel of the synthetic step / its step proofs; same kernels and "
+                "counters_from": "profiles/" + name + " (" + basis + ", synthetic step; same kernels and "
                                  "shapes as the chained step; a constant read from profiles/, not re-measured in this run)",
                 "what": "sum of the step's wave-level VALU instructions / (1024 SIMDs / %.2f cycles per instruction at the clock one wave of "
                         "every timed leaf-hash launch measured) / wall time per step proof of the timed region" % CEILING_CYCLES_PER_INSTR}

@@ -12,6 +12,7 @@
 // (the reference's get_lde_values path moves 283 MB per step through the host).  Streaming, ~180 columns x 8 B per point.
 #define GL_ASM_SCRATCH_LOW 1  // low asm scratch block: these kernels need few registers of their own (occupancy)
 #include "kernels.h"
+#include "poseidon.h"   // fold96: 7 x on residues
 
 namespace vpbs {
 namespace {
@@ -89,10 +90,10 @@ quotient_perm_kernel(const u64* __restrict__ wires, const u64* __restrict__ sigm
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if ((unsigned)c >= nc) continue;
-                const u64 wg = gl::add(w, k.gamma[c]);                       // canonical: shared by numerator and denominator
-                num[c] = gl::mul_nc(num[c], gl::add(wg, sid[c]));            // w + beta k_j x + gamma
+                const u64 wg = gl::add_a(w, k.gamma[c]);                     // a residue: shared by numerator and denominator
+                num[c] = gl::mul_nc(num[c], gl::add_a(wg, sid[c]));          // w + beta k_j x + gamma
                 den[c] = gl::mul_nc(den[c], gl::mad_nc(k.beta[c], s, wg));   // w + beta sigma_j + gamma, one reduction
-                sid[c] = gl::mul7(sid[c]);
+                sid[c] = poseidon::fold96((u64)(u32)sid[c] * 7u, (u64)(u32)(sid[c] >> 32) * 7u);   // 7 x on a residue: two multiply-adds and a fold
             }
         };
         if (DEG != 0 && (kk + 1) * DEG <= n_routed) {
