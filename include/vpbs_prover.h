@@ -59,7 +59,9 @@ typedef enum {
                                      the 16-lane Poseidon form: a third of the latency for 3.7 x the instructions.  Default 2^14: right
                                      for a context that has the GPU to itself.  A context that SHARES the GPU with other chains should
                                      lower it (2048): the other chains hide the latency, only the instruction count is left
-                                     (six chains: 8.33 -> 8.14-8.22 ms per chained proof).                              VPBS_WIDE_THRESHOLD */
+                                     (six chains: 8.33 -> 8.14-8.22 ms per chained proof).  Below the default the proof-of-work search
+                                     also runs its range in rounds of 2^15 candidates that stop once a smaller nonce is known (a third
+                                     fewer permutations, each round one permutation deep) instead of all at once.        VPBS_WIDE_THRESHOLD */
     VPBS_OPT_MERKLE_CLIMB = 4,    /* 1 (default): the upper levels of a tree in fused multi-level launches; 0: per level. VPBS_MERKLE_CLIMB  */
     VPBS_OPT_GATES_TILE = 5       /* 1 (default): the one-launch gate kernel stages a 64-point tile of every column in LDS and its eight
                                      waves share the gates; 0: the (tile x item) kernel that leaves the re-reads to the caches.  VPBS_GATES_TILE */

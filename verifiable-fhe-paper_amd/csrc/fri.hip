@@ -61,10 +61,14 @@ eval_partial_kernel(const u64* __restrict__ coeffs, size_t n, size_t col_stride,
     __shared__ u64 sh[2 * THREADS];
     const u64* col = coeffs + blockIdx.y * col_stride;
     const size_t begin = (size_t)blockIdx.x * chunk_len;
-    gl::Ext acc = gl::ext(0);
-    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS)
-        acc = gl::add(acc, gl::mul(load_ext(zpow, i), col[i]));
-    const gl::Ext tot = block_sum(acc, sh);
+    gl::LazyAcc a0{}, a1{};   // sum of coefficient x power, reduced once per thread (16 instead of ~45 instructions per term)
+    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS) {
+        const gl::Ext z = load_ext(zpow, i);
+        const u64 v = col[i];
+        a0.mac_v(v, z.c0);
+        a1.mac_v(v, z.c1);
+    }
+    const gl::Ext tot = block_sum(gl::Ext{gl::canon(a0.reduce()), gl::canon(a1.reduce())}, sh);
     if (threadIdx.x == 0) store_ext(partial, (size_t)blockIdx.y * gridDim.x + blockIdx.x, tot);
 }
 __global__ void eval_finish_kernel(const u64* __restrict__ partial, unsigned chunks, unsigned ncols, u64* __restrict__ out) {
@@ -85,10 +89,14 @@ eval_partial_multi_kernel(EvalSegments segs, size_t n, unsigned chunk_len, u64* 
     const u64* col = segs.seg[k].coeffs + (size_t)c * segs.seg[k].col_stride;
     const u64* zpow = segs.seg[k].zpow;
     const size_t begin = (size_t)blockIdx.x * chunk_len;
-    gl::Ext acc = gl::ext(0);
-    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS)
-        acc = gl::add(acc, gl::mul(load_ext(zpow, i), col[i]));
-    const gl::Ext tot = block_sum(acc, sh);
+    gl::LazyAcc a0{}, a1{};   // sum of coefficient x power, reduced once per thread (16 instead of ~45 instructions per term)
+    for (size_t i = begin + threadIdx.x; i < begin + chunk_len && i < n; i += THREADS) {
+        const gl::Ext z = load_ext(zpow, i);
+        const u64 v = col[i];
+        a0.mac_v(v, z.c0);
+        a1.mac_v(v, z.c1);
+    }
+    const gl::Ext tot = block_sum(gl::Ext{gl::canon(a0.reduce()), gl::canon(a1.reduce())}, sh);
     if (threadIdx.x == 0) store_ext(partial, (size_t)blockIdx.y * gridDim.x + blockIdx.x, tot);
 }
 
@@ -101,10 +109,15 @@ combine_kernel(const u64* const* __restrict__ polys, unsigned n_polys, const u64
     if (i >= n) return;
     const unsigned per = (n_polys + gridDim.y - 1) / gridDim.y;
     const unsigned j0 = blockIdx.y * per, j1 = j0 + per < n_polys ? j0 + per : n_polys;
-    gl::Ext acc = gl::ext(0);
-    for (unsigned j = j0; j < j1; ++j) acc = gl::add(acc, gl::mul(load_ext(alpha_pows, j), polys[j][i]));
-    part0[blockIdx.y * n + i] = acc.c0;
-    part1[blockIdx.y * n + i] = acc.c1;
+    gl::LazyAcc a0{}, a1{};   // sum of alpha^j f_j[i], reduced once (the powers are wave-uniform: scalar operands)
+    for (unsigned j = j0; j < j1; ++j) {
+        const gl::Ext a = load_ext(alpha_pows, j);
+        const u64 v = polys[j][i];
+        a0.mac((u32)v, (u32)(v >> 32), (u32)a.c0, (u32)(a.c0 >> 32));
+        a1.mac((u32)v, (u32)(v >> 32), (u32)a.c1, (u32)(a.c1 >> 32));
+    }
+    part0[blockIdx.y * n + i] = gl::canon(a0.reduce());
+    part1[blockIdx.y * n + i] = gl::canon(a1.reduce());
 }
 __global__ void __launch_bounds__(THREADS)
 combine_finish_kernel(const u64* __restrict__ part0, const u64* __restrict__ part1, unsigned groups, size_t n,

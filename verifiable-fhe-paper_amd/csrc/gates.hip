@@ -36,38 +36,8 @@ struct DevVars {
     __device__ __forceinline__ u64 constant(unsigned i) const { return consts[(size_t)i * stride + j]; }
     __device__ __forceinline__ u64 pi_hash(unsigned i) const { return pih.h[i]; }
 };
-// reduce_with_powers over the constraints, with the reduction mod p deferred to the end of the gate: the four 32x32
-// partial products of constraint * alpha^i are accumulated with v_mad_u64_u32 into three 64-bit lanes at bit offsets 0 / 32 /
-// 64 (carries counted on the side), 8-12 instructions per (constraint, challenge) instead of a full modular multiply-add.
-struct LazyAcc {
-    u64 e, m, h;      // sum of c0*a0 | c0*a1 + c1*a0 | c1*a1   (mod 2^64 each)
-    u32 ce, cm, ch;   // wrap-arounds of e, m, h
-    __device__ __forceinline__ void mac(u32 c0, u32 c1, u32 a0, u32 a1) {
-        // a0 / a1 (halves of a power of alpha) are wave-uniform: scalar operands
-        asm("v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
-            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
-            "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
-            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
-            "v_mad_u64_u32 %1, vcc, %7, %8, %1\n\t"
-            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
-            "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\t"
-            "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc"
-            : "+v"(e), "+v"(m), "+v"(h), "+v"(ce), "+v"(cm), "+v"(ch)
-            : "v"(c0), "v"(c1), "s"(a0), "s"(a1)
-            : "vcc");
-    }
-    // e + 2^32 m + 2^64 h + 2^64 ce + 2^96 cm + 2^128 ch  (mod p), a u64 residue;  2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32.
-    // The six pieces are first added as ONE 160-bit integer lo + H_lo 2^64 + hh 2^96 + top 2^128 (plain carries), which then takes a single
-    // 128-bit reduction and one subtraction -- a third of the instructions of reducing the pieces one by one (round 5).
-    __device__ __forceinline__ u64 reduce() const {
-        const u64 lo = e + (m << 32);
-        const u64 t = (m >> 32) + ce + (lo < e ? 1u : 0u);     // < 2^34
-        const u64 H = h + t;
-        const u64 hh = (H >> 32) + cm;                          // < 2^33
-        const u64 top = (u64)ch + (H < t ? 1u : 0u) + (hh >> 32);   // wrap-around counts: a few hundred at most
-        return gl::sub_a(gl::reduce128_asm(lo, (u32)H, (u32)hh), top << 32);
-    }
-};
+// gl::LazyAcc (gl.h): reduce_with_powers over the constraints with the reduction mod p deferred to the end of the gate
+using gl::LazyAcc;
 // The sink multiplies every constraint into NC running sums WITHOUT asking how many challenges there are: with fewer than NC challenges the
 // spare sums repeat the last challenge's powers (row[] points there) and are never read.  A run-time `a < nc` around each multiply-accumulate
 // made the compiler keep two copies of every accumulator (three 64-bit moves per constraint and challenge) and a branch per challenge.

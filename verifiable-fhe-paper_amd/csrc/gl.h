@@ -412,6 +412,55 @@ GL_HD void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64& q) {
 #endif
 GL_HD u64 mul(u64 a, u64 b) { return canon(mul_nc(a, b)); }
 
+#if defined(__HIPCC__)
+// A sum of 64 x 64-bit products with the reduction mod p deferred to the end (device code): the four 32 x 32 partial products of c * a are
+// accumulated with v_mad_u64_u32 into three 64-bit lanes at bit offsets 0 / 32 / 64 (their wrap-arounds counted on the side), 8 instructions
+// per product instead of a full modular multiply-add (~20-45).  Users: the gate kernels' reduce_with_powers over the constraints (a = a power
+// of alpha, wave-uniform: scalar operands, mac) and the FRI sums over polynomials and coefficients (fri.hip: vector operands, mac_v).
+struct LazyAcc {
+    u64 e, m, h;      // sum of c0*a0 | c0*a1 + c1*a0 | c1*a1   (mod 2^64 each)
+    u32 ce, cm, ch;   // wrap-arounds of e, m, h
+    __device__ __forceinline__ void mac(u32 c0, u32 c1, u32 a0, u32 a1) {   // a0 / a1 wave-uniform
+        asm("v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %7, %8, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\t"
+            "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc"
+            : "+v"(e), "+v"(m), "+v"(h), "+v"(ce), "+v"(cm), "+v"(ch)
+            : "v"(c0), "v"(c1), "s"(a0), "s"(a1)
+            : "vcc");
+    }
+    __device__ __forceinline__ void mac_v(u64 c, u64 a) {   // any two u64 residues, per lane
+        asm("v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %7, %8, %1\n\t"
+            "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\t"
+            "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc"
+            : "+v"(e), "+v"(m), "+v"(h), "+v"(ce), "+v"(cm), "+v"(ch)
+            : "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)a), "v"((u32)(a >> 32))
+            : "vcc");
+    }
+    // e + 2^32 m + 2^64 h + 2^64 ce + 2^96 cm + 2^128 ch  (mod p), a u64 residue;  2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32.
+    // The six pieces are first added as ONE 160-bit integer lo + H_lo 2^64 + hh 2^96 + top 2^128 (plain carries), which then takes a single
+    // 128-bit reduction and one subtraction -- a third of the instructions of reducing the pieces one by one (round 5).  Good for up to 2^31
+    // products (top, the count of wrap-arounds, is shifted by 32).
+    __device__ __forceinline__ u64 reduce() const {
+        const u64 lo = e + (m << 32);
+        const u64 t = (m >> 32) + ce + (lo < e ? 1u : 0u);     // < 2^34
+        const u64 H = h + t;
+        const u64 hh = (H >> 32) + cm;                          // < 2^33
+        const u64 top = (u64)ch + (H < t ? 1u : 0u) + (hh >> 32);   // wrap-around counts
+        return sub_a(reduce128_asm(lo, (u32)H, (u32)hh), top << 32);
+    }
+};
+#endif
+
 // x * 2^24, x * 2^48, x * 2^72 (canonical in and out).  These are the 8th roots of unity up to sign: w_8 = 2^120 = -2^24,
 // w_8^2 = w_4 = 2^48, w_8^3 = -2^72 (2^96 = -1), so a radix-8 NTT butterfly needs shifts, not multiplications, inside.
 GL_HD u64 mul_2e24(u64 x) {

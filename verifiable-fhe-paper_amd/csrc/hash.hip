@@ -203,8 +203,8 @@ struct PowState {
 
 // Candidates start .. start + count in ascending rounds of `stride`: thread i tries start + i, start + i + stride, ...  Before each permutation it
 // looks at *result and leaves when a SMALLER valid nonce is already known (so the answer is still the smallest valid nonce of the range): with a
-// 16-bit grind the expected answer is near 2^16 and the expected work is that plus half a round, not the whole 2^17 range the one-shot grid
-// hashed (0.0275 -> ~0.017 G wave-instructions per step proof); a round is one permutation deep, as a launch of that size was.
+// 16-bit grind the expected answer is near 2^16 and the expected work that plus half a round, not the whole 2^17 range.  stride = count is the
+// one-shot grid (launch_pow_search chooses).
 __global__ void __launch_bounds__(THREADS)
 pow_search_kernel(PowState st, unsigned pos, unsigned pow_bits, u64 start, u64 count, u64 stride, unsigned long long* result) {
     const u64 i = blockIdx.x * (u64)THREADS + threadIdx.x;
@@ -289,10 +289,16 @@ void launch_permute_batch(hipStream_t s, u64* states, size_t n) {
 void launch_hash_rows(hipStream_t s, const u64* rows, size_t n, unsigned len, u64* out) {
     hipLaunchKernelGGL(hash_rows_kernel, dim3((n + THREADS - 1) / THREADS), dim3(THREADS), 0, s, rows, n, len, out);
 }
-void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count, u64* d_result) {
+void launch_pow_search(hipStream_t s, const Tuning& tune, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count,
+                       u64* d_result) {
     PowState st;
     for (int k = 0; k < 12; ++k) st.s[k] = state12_host[k];
-    const u64 stride = std::min<u64>(count, (u64)1 << 15);   // 512 waves: half the SIMDs hold one each, a round is one permutation deep
+    // The same choice as the 16-lane Poseidon form (Tuning::wide_threshold): a context that has the GPU to itself hashes the whole range at
+    // once (two waves per SIMD: 68 us for 2^17 candidates; rounds of 2^16 at one wave per SIMD take as long EACH, 94 us per proof on average,
+    // rounds of 2^15 180 us); a context that shares the GPU with other chains (threshold lowered) runs rounds of 2^15 -- the others fill the
+    // gaps and only the instruction count is left, which the early exits cut by a third.
+    const bool shared_gpu = tune.wide_threshold < ((size_t)1 << 14);
+    const u64 stride = shared_gpu ? std::min<u64>(count, (u64)1 << 15) : count;
     hipLaunchKernelGGL(pow_search_kernel, dim3((unsigned)((stride + THREADS - 1) / THREADS)), dim3(THREADS), 0, s, st, pos, pow_bits,
                        start, count, stride, reinterpret_cast<unsigned long long*>(d_result));
 }

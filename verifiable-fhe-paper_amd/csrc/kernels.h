@@ -140,7 +140,8 @@ void launch_permute_batch(hipStream_t s, u64* states, size_t n);
 void launch_hash_rows(hipStream_t s, const u64* rows, size_t n, unsigned len, u64* out);
 // proof-of-work search: smallest nonce in [start, start+count) whose response has >= pow_bits leading zeros.
 // state12: duplex state with the pending inputs already overwritten; pos: slot of the nonce. *result = min nonce or ~0
-void launch_pow_search(hipStream_t s, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count,
+// tune.wide_threshold below its default (a context that shares the GPU): the range in rounds of 2^15 with early exits instead of at once
+void launch_pow_search(hipStream_t s, const Tuning& tune, const u64* state12_host, unsigned pos, unsigned pow_bits, u64 start, u64 count,
                        u64* d_result);
 
 // ---------- fri.hip ----------

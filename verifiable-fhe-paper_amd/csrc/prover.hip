@@ -72,7 +72,7 @@ u64 fri_proof_of_work(vpbs_ctx* ctx, Challenger& ch, unsigned pow_bits, u64 forc
             }
             Timed t(ctx, "pow_search");
             VPBS_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(u64), ctx->stream));
-            vpbs::launch_pow_search(ctx->stream, st, pos, pow_bits, start, span, d_res);
+            vpbs::launch_pow_search(ctx->stream, ctx->tune, st, pos, pow_bits, start, span, d_res);
             ctx->d2h_sync(&witness, d_res, sizeof(u64));
         }
         ctx->release(d_res);
