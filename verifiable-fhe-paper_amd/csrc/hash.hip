@@ -49,8 +49,10 @@ leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, s
                 for (int k = 0; k < 8; ++k)
                     if (c0 + 8 + k < ncols) nxt[k] = lde[(size_t)(c0 + 8 + k) * col_stride + j];
             }
-            poseidon::permute(s);
+            poseidon::permute_residues(s);   // the capacity goes on as residues; only the digest is made canonical
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = gl::canon(s[k]);
     }
     ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * j);
     d[0] = make_ulonglong2(s[0], s[1]);
@@ -79,8 +81,10 @@ fri_leaf_hash_kernel(const u64* __restrict__ v0, const u64* __restrict__ v1, siz
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (m0 + k < arity) { s[2 * k] = v0[base + m0 + k]; s[2 * k + 1] = v1[base + m0 + k]; }
-            poseidon::permute(s);
+            poseidon::permute_residues(s);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = gl::canon(s[k]);
     }
     ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * l);
     d[0] = make_ulonglong2(s[0], s[1]);
@@ -94,7 +98,9 @@ merkle_level_kernel(const u64* __restrict__ children, u64* __restrict__ parents,
     const ulonglong2* c = reinterpret_cast<const ulonglong2*>(children + 8 * i);
     const ulonglong2 a = c[0], b = c[1], e = c[2], f = c[3];
     u64 s[12] = {a.x, a.y, b.x, b.y, e.x, e.y, f.x, f.y, 0, 0, 0, 0};
-    poseidon::permute(s);
+    poseidon::permute_residues(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = gl::canon(s[k]);   // the digest; the other eight words are dropped
     ulonglong2* d = reinterpret_cast<ulonglong2*>(parents + 4 * i);
     d[0] = make_ulonglong2(s[0], s[1]);
     d[1] = make_ulonglong2(s[2], s[3]);
@@ -191,10 +197,10 @@ hash_rows_kernel(const u64* __restrict__ rows, size_t n, unsigned len, u64* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (c0 + k < len) s[k] = row[c0 + k];
-        poseidon::permute(s);
+        poseidon::permute_residues(s);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[4 * i + k] = s[k];
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = gl::canon(s[k]);
 }
 
 struct PowState {
@@ -215,9 +221,9 @@ pow_search_kernel(PowState st, unsigned pos, unsigned pow_bits, u64 start, u64 c
         u64 s[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) s[k] = (unsigned)k == pos ? cand : st.s[k];
-        poseidon::permute(s);
+        poseidon::permute_residues(s);
         // pow_response = last element of squeeze() = state[7]; leading_zeros(response) >= pow_bits
-        if (pow_bits == 0 || (s[7] >> (64 - pow_bits)) == 0) {
+        if (pow_bits == 0 || (gl::canon(s[7]) >> (64 - pow_bits)) == 0) {
             atomicMin(result, (unsigned long long)cand);
             return;   // this thread's later candidates are larger
         }

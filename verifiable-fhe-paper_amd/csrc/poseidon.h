@@ -399,8 +399,9 @@ template <bool GATE> GL_HD void partial_group3_core(u64* s, int g, const u64* w,
 }
 GL_HD void partial_group3(u64* s, int g) { partial_group3_core<false>(s, g, nullptr, nullptr); }
 
-// in/out: canonical field elements
-GL_HD void permute(u64* s) {
+// in: any u64 residues; out: u64 residues (the caller makes canonical what leaves the sponge -- a chain of absorbs needs that for the digest
+// only: 48 instructions per permutation otherwise)
+GL_HD void permute_residues(u64* s) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_nc(s[i], rc(i));
     // the next round's constants are requested (scalar loads) BEFORE the S-boxes so their latency hides under ~800
@@ -435,6 +436,10 @@ GL_HD void permute(u64* s) {
         for (int i = 0; i < 12; i += 2) sbox2(s[i], s[i + 1]);
         mds_add_const(s, kc);
     }
+}
+// in: any residues (canonical inputs included); out: canonical field elements
+GL_HD void permute(u64* s) {
+    permute_residues(s);
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::canon(s[i]);
 }
