@@ -364,6 +364,41 @@ def test_recorded_bench_line_keeps_the_contract():
     assert d["ivc_chain_n2048"]["ms_per_step"] > d["ivc_single_chain"]["ms_per_step"] and d["ivc_chain"]["decrypted"] == d["ivc_chain"]["message"]
 
 
+def test_pmc_table_counts_one_step_proof_exactly(tmp_path):
+    """tools/pmc_table.py: `valu_per_step_proof` = SQ_INSTS_VALU of the dispatches between the first and the last quotient_perm_kernel dispatch /
+    the periods between them -- the setup commitment's launches (before the first step) and the tail are not in it, whatever their size"""
+    import csv
+    import subprocess
+    d = tmp_path / "pmc" / "runc"
+    d.mkdir(parents=True)
+    rows, disp = [], [0]
+
+    def launch(kernel, valu):
+        disp[0] += 1
+        for name, v in (("SQ_INSTS_VALU", valu), ("SQ_WAVES", 10)):
+            rows.append({"Dispatch_Id": disp[0], "Kernel_Name": "vpbs::(anonymous namespace)::%s(unsigned long*)" % kernel, "Counter_Name": name,
+                         "Counter_Value": v})
+
+    launch("leaf_hash_kernel", 999)          # setup: a commitment of another shape
+    launch("merkle_level_kernel", 77)
+    for step in range(4):                     # four identical step proofs
+        for k in range(3):
+            launch("leaf_hash_kernel", 100 + k)
+        launch("merkle_level_kernel", 10)
+        launch("quotient_perm_kernel", 7)
+        launch("gate_tile_kernel", 50)
+    with open(d / "1_counter_collection.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), str(tmp_path / "pmc")], capture_output=True, text=True, check=True)
+    table = {r["kernel"]: r for r in csv.DictReader(out.stdout.splitlines())}
+    assert float(table["leaf_hash_kernel"]["valu_per_step_proof"]) == 100 + 101 + 102      # not (999 + 4 * 303) / (13 / 3)
+    assert float(table["merkle_level_kernel"]["valu_per_step_proof"]) == 10
+    assert float(table["gate_tile_kernel"]["valu_per_step_proof"]) == 50 and float(table["quotient_perm_kernel"]["valu_per_step_proof"]) == 7
+    assert int(table["leaf_hash_kernel"]["launches"]) == 13 and float(table["leaf_hash_kernel"]["SQ_INSTS_VALU"]) == 999 + 4 * 303
+
+
 def test_bench_parent_starts_the_ranks_without_touching_the_gpu(tmp_path):
     """`python bench.py --gpus N` outside a launcher is the PARENT of its ranks: it must import nothing that could open
     the device -- neither torch nor the prover library -- start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
