@@ -635,14 +635,17 @@ STEP_ALGORITHMIC_MB = {"leaf hashing (3 launches)": 767.6, "Merkle levels": 100.
                        "FRI combine / divide / fold / LDE / openings / queries": 330.0, "FRI round trees": 26.0}
 
 
-def valu_budget(sclk_hz, step_ms):
+def valu_budget(sclk_hz, step_ms, shared_gpu=False):
     """The WHOLE step against the bound that holds it: wave-level VALU instructions per step proof by kernel, from
     the committed SQ_INSTS_VALU pass over the synthetic step (profiles/rNN_pmc_sq_kernels.csv: rocprofv3 --pmc, tools/pmc_kernels.sh; a
     constant read from profiles/, like `traffic`), their sum / what 1024 SIMDs can issue at the clock measured inside this run's kernels =
     the time the step's instruction stream needs when nothing waits; `frac` = that time / the measured wall time per step proof.  With
     several chains per GPU every wait of one chain is filled by another, so frac is near 1 and throughput = instruction count."""
     import csv
-    for name in ("r05_pmc_sq_kernels.csv", "r04_pmc_sq_kernels.csv"):
+    # shared_gpu: the counters of the settings a context runs with beside other chains (16-lane Poseidon threshold 2048, PoW in rounds:
+    # tools/pmc_kernels.sh's third pass) -- the eight-chain headline's own instruction stream; else the defaults of a context alone on the GPU
+    names = (("r05_pmc_sq_kernels_shared_gpu.csv",) if shared_gpu else ()) + ("r05_pmc_sq_kernels.csv", "r04_pmc_sq_kernels.csv")
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -672,7 +675,7 @@ def valu_budget(sclk_hz, step_ms):
     return None
 
 
-def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches, measured_in, step_ms=None):
+def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches, measured_in, step_ms=None, shared_gpu=False):
     """The dominant kernel (Poseidon leaf hashing), priced as the contract asks -- ALGORITHMIC bytes per launch / average launch duration against
     the HBM peak -- with the bound that really holds it (integer VALU issue) beside it as `int_valu_issue`.
     per_step_ms: HIP-event time of its three launches per step proof; bytes_step / perms: algorithmic bytes and permutations per step;
@@ -719,7 +722,7 @@ def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches
            # kept at the top level for the scripts under tools/ that read them
            "int_issue_frac": achieved / peak, "shader_clock_mhz_in_kernel": sclk_mhz}
     if step_ms:
-        budget = valu_budget(sclk_hz, step_ms)
+        budget = valu_budget(sclk_hz, step_ms, shared_gpu)
         if budget is not None:
             out["valu_budget"] = budget
         out["step_hbm_frac"] = step_total / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -925,7 +928,7 @@ def measure_ivc(args, rank, local_rank, world, distributed):
                                               if args.device_witness else "on the host (a second thread per chain)"},
             "roofline": roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, dominant["count"],
                                     "the timed chained steps of this run (HIP events on each prover's stream)",
-                                    step_ms=elapsed / (Kt * n_chains) * 1e3),
+                                    step_ms=elapsed / (Kt * n_chains) * 1e3, shared_gpu=n_chains > 1 and "VPBS_WIDE_THRESHOLD" not in os.environ),
             "chain_ms_per_step_split": {"witness_late_phase_host": t0s["late_witness_ms"], "late_rows_to_device": t0s["late_rows_upload_ms"],
                                         "prove_step": t0s["prove_step_ms"], "witness_early_phase_on_a_second_thread": t0s["early_witness_ms"],
                                         "base_proof_once": t0s["base_proof_ms"],
