@@ -350,7 +350,9 @@ def test_recorded_bench_line_keeps_the_contract():
     # round 5: the WHOLE step against the bound that holds it (wave-level VALU instructions per step by kernel / issue rate / measured time), and
     # what ran: ranks counted by the communication library, who started them, CPUs per rank, the pipeline chosen
     b = r["valu_budget"]
-    assert abs(sum(b["by_kernel_G"].values()) - b["wave_instructions_per_step_G"]) < 1e-6 and "r05_pmc_sq_kernels.csv" in b["counters_from"]
+    assert abs(sum(b["by_kernel_G"].values()) - b["wave_instructions_per_step_G"]) < 1e-6 and "r05_pmc_sq_kernels_shared_gpu.csv" in b["counters_from"]   # several chains per GPU: the counter pass with THEIR settings
+    assert "r05_pmc_sq_kernels.csv" in r["valu_budget_single_chain"]["counters_from"]
+    assert b["wave_instructions_per_step_G"] < r["valu_budget_single_chain"]["wave_instructions_per_step_G"]
     assert abs(b["frac"] - b["instruction_time_ms_per_step"] / b["measured_ms_per_step_proof"]) < 1e-9 and 0.8 < b["frac"] < 1.05
     assert abs(b["measured_ms_per_step_proof"] - d["ms_per_step"] / chains) < 1e-6
     assert d["rccl"]["ranks"] == d["n_gpus"] and d["cpus_per_rank"] >= 1 and d["pipeline"]["chains_per_gpu"] == chains and d["launched_by"]
