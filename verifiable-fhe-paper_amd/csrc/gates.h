@@ -161,8 +161,10 @@ template <class F, class V, class S> GATES_FN void eval_arithmetic(const vpbs_ga
     }
 }
 // gates/base_sum.rs: reduce_with_powers(limbs, B) - sum; then prod_{k < B} (limb - k) per limb
-template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate& g, const V& v, S& s) {
-    const unsigned n = g.p0, B = g.p1;
+// BASE: the base when it is known at compile time (2: every BaseSumGate of the reference's circuits -- the doubling and the single factor
+// limb (limb - 1) then need no loop over the base and no multiplication by it), 0: g.p1 at run time
+template <class F, unsigned BASE, class V, class S> GATES_FN void eval_base_sum_b(const vpbs_gate& g, const V& v, S& s) {
+    const unsigned n = g.p0, B = BASE ? BASE : g.p1;
     // limbs are read in batches of 8 so that the loads of a batch are in flight together (the GPU thread is otherwise bound by
     // one memory latency per limb)
     F acc = Fld<F>::lift(0);
@@ -189,6 +191,10 @@ template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate
             s.push(prod);
         }
     }
+}
+template <class F, class V, class S> GATES_FN void eval_base_sum(const vpbs_gate& g, const V& v, S& s) {
+    if (g.p1 == 2) eval_base_sum_b<F, 2>(g, v, s);
+    else eval_base_sum_b<F, 0>(g, v, s);
 }
 // gates/poseidon.rs.  Wires: input 0..12, output 12..24, swap 24, delta 25..29, full_sbox_0(r=1..3) 29.., partial_sbox
 // 65..87, full_sbox_1(r=0..3) 87..135.  The partial rounds are evaluated in the plain form (add constants, S-box on
