@@ -1,9 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun -- 'bash tools/refresh_profiles_r05.sh [quick]'): the rocprofv3 passes behind profiles/r05_*.  Counter passes are
-# their own runs (kernel trace only).  Condensed afterwards in the authoring container:
-#   python tools/summarize_profiles.py r05 gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
-#   python tools/pmc_table.py gpurun_out/pmc_a gpurun_out/pmc_b > profiles/r05_pmc_sq_kernels.csv
-#   python tools/pmc_table.py gpurun_out/pmc_shared > profiles/r05_pmc_sq_kernels_shared_gpu.csv
+# their own runs (kernel trace only).  Condensed afterwards in the authoring container by `python tools/condense_profiles_r05.py` (drops what
+# earlier calls left in gpurun_out/, then summarize_profiles.py r05 + pmc_table.py for the three counter tables + the copies into profiles/)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
 CMD="python3 bench.py --workload step --steps 10 --warmup 2 --no-cpu-baseline --no-survey-size --no-step-circuit --no-batch128 --no-whole-pbs --no-ivc --batch-chains 1"
