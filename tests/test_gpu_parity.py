@@ -301,7 +301,8 @@ def _pow_valid(ch, gb, batches, gp, ctx, w):
 
 
 # ---------- permutation argument (a12) ----------
-@pytest.mark.parametrize("log_n,n_routed,deg,nc", [(3, 10, 4, 2), (8, 80, 8, 2), (11, 80, 8, 2), (9, 17, 8, 1), (10, 8, 8, 3), (16, 80, 8, 2)])
+@pytest.mark.parametrize("log_n,n_routed,deg,nc", [(3, 10, 4, 2), (8, 80, 8, 2), (11, 80, 8, 2), (9, 17, 8, 1), (10, 8, 8, 3), (16, 80, 8, 2),
+                                                   (7, 80, 8, 1), (6, 80, 8, 3), (5, 72, 8, 2), (5, 80, 4, 2)])   # (80, 8): one kernel, one inversion per row; else three kernels
 def test_partial_products_match_oracle(ctx, log_n, n_routed, deg, nc):
     wires, sig = rand_field(n_routed + 3, 1 << log_n), rand_field(n_routed, 1 << log_n)
     betas, gammas = [int(x) for x in rand_field(nc)], [int(x) for x in rand_field(nc)]
@@ -311,12 +312,14 @@ def test_partial_products_match_oracle(ctx, log_n, n_routed, deg, nc):
     assert (got[:nc, 0] == 1).all()  # Z(1) = 1
 
 
-def test_partial_products_zero_denominator_is_an_error(ctx):
-    wires, sig = rand_field(8, 16), rand_field(8, 16)
+@pytest.mark.parametrize("n_routed,col", [(8, 3), (80, 3), (80, 79)])   # three-kernel path; the one-kernel path (shared inversion), first / last chunk
+def test_partial_products_zero_denominator_is_an_error(ctx, n_routed, col):
+    wires, sig = rand_field(n_routed, 16), rand_field(n_routed, 16)
     beta, gamma = 5, 9
-    wires[3][7] = (-(beta * int(sig[3][7]) + gamma)) % P   # den_3(row 7) = 0
+    wires[col][7] = (-(beta * int(sig[col][7]) + gamma)) % P   # den_col(row 7) = 0
     with pytest.raises(api.VpbsError):
         ctx.partial_products(wires, sig, [beta], [gamma])
+    ctx.partial_products(rand_field(n_routed, 16), rand_field(n_routed, 16), [beta], [gamma])   # the flag does not stick to the context
 
 
 # ---------- quotient, permutation part (a13) ----------
@@ -327,17 +330,17 @@ def _leaf_order(nat, log_big):
 
 @pytest.mark.parametrize("log_n,n_routed,n_constants,with_gates", [(4, 8, 0, False), (6, 20, 3, True), (9, 80, 5, False), (8, 80, 5, True),
                                                                   (16, 80, 4, False)])
-def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, with_gates):
+def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, with_gates, nc=2):
     import torch
     n = 1 << log_n
     wires_v, sig_v, const_v = rand_field(n_routed + 4, n), rand_field(n_routed, n), rand_field(n_constants, n)
-    betas, gammas, alphas = ([int(x) for x in rand_field(2)] for _ in range(3))
+    betas, gammas, alphas = ([int(x) for x in rand_field(nc)] for _ in range(3))
     zs_v = orc.partial_products(wires_v[:n_routed], sig_v, betas, gammas)
     cs = ctx.commit_values(np.concatenate([const_v, sig_v]) if n_constants else sig_v)
     wb, zb = ctx.commit_values(wires_v), ctx.commit_values(zs_v)
     gate_nat, gate_dev = None, None
     if with_gates:
-        gate_nat = rand_field(2, 8 * n)
+        gate_nat = rand_field(nc, 8 * n)
         gate_dev = torch.from_numpy(_leaf_order(gate_nat, log_n + 3).view(np.int64)).cuda()
         torch.cuda.synchronize()
     got = ctx.quotient_permutation(cs, n_constants, wb, zb, n_routed, betas, gammas, alphas,
@@ -345,6 +348,12 @@ def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, 
     want = orc.quotient_permutation(wb.coeffs()[:n_routed], cs.coeffs()[n_constants:], zb.coeffs(), betas, gammas, alphas,
                                     gate_terms=gate_nat)
     assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("nc,with_gates", [(1, True), (3, False), (4, True)])
+def test_quotient_permutation_other_challenge_counts(ctx, nc, with_gates):
+    """plonky2's standard two challenges run a kernel specialised for them; any other count the run-time form"""
+    test_quotient_permutation_matches_oracle(ctx, 7, 80, 3, with_gates, nc=nc)
 
 
 def _copy_constraint_instance(log_n, n_routed):
