@@ -280,6 +280,18 @@ def test_fri_prove_bit_exact(ctx, log_n, over):
     assert orc.verify_fri([o.cap() for o in ob], [o.ncols for o in ob], batches, [openings[:total], openings[total:]], ch_v, op, log_n, got)
 
 
+@pytest.mark.parametrize("log_n,over", [(9, {}), (7, {"pow_bits": 5, "num_query_rounds": 3}), (12, {"pow_bits": 17})])
+def test_fri_prove_bit_exact_with_the_settings_of_a_shared_gpu(ctx, log_n, over):
+    """VPBS_OPT_WIDE_THRESHOLD below its default: the one-lane Poseidon form on small tree levels and the proof-of-work search in rounds of 2^15
+    candidates with early exits -- the smallest valid nonce, the same proof (pow_bits 17: the first range of 2^18 takes up to eight rounds)"""
+    before = ctx.get_option("wide_threshold")
+    ctx.set_option("wide_threshold", 2048)
+    try:
+        test_fri_prove_bit_exact(ctx, log_n, over)
+    finally:
+        ctx.set_option("wide_threshold", before)
+
+
 def test_fri_forced_pow_and_invalid(ctx):
     ob, gb, ch, gch, batches, openings, op, gp = _fri_case(ctx, 6, (4, 6, 3, 2), pow_bits=6)
     g2 = gch.clone()
