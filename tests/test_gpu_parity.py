@@ -159,6 +159,8 @@ def test_commit_edge_shapes(ctx, log_n, ncols):
         leaf, sib = got.open(idx)
         wleaf, wsib = want.open(idx)
         assert (leaf == wleaf).all() and sib.shape == wsib.shape and (sib == wsib).all()
+    zeta = rand_field(2)   # the openings' power table at tiny degrees: fewer than 16 entries per thread of its walk, or per table
+    assert (got.eval_ext(zeta) == want.eval_ext(zeta)).all()
     got.free()
 
 
