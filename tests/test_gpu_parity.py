@@ -327,6 +327,10 @@ def _pow_valid(ch, gb, batches, gp, ctx, w):
 def test_partial_products_match_oracle(ctx, log_n, n_routed, deg, nc):
     wires, sig = rand_field(n_routed + 3, 1 << log_n), rand_field(n_routed, 1 << log_n)
     betas, gammas = [int(x) for x in rand_field(nc)], [int(x) for x in rand_field(nc)]
+    # rows of boundary values: the one-kernel path multiplies and inverts on u64 residues
+    wires[:, 1], sig[:, 1] = P - 1, P - 1
+    wires[:, 2], sig[:, 2] = 0, (1 << 32) - 1
+    wires[:, 3], sig[:, 3] = P - (1 << 32), 1 << 32
     got = ctx.partial_products(wires[:n_routed], sig, betas, gammas, deg)
     want = orc.partial_products(wires[:n_routed], sig, betas, gammas, deg)
     assert got.shape == want.shape and (got == want).all()
