@@ -360,6 +360,8 @@ def test_quotient_permutation_matches_oracle(ctx, log_n, n_routed, n_constants, 
     n = 1 << log_n
     wires_v, sig_v, const_v = rand_field(n_routed + 4, n), rand_field(n_routed, n), rand_field(n_constants, n)
     betas, gammas, alphas = ([int(x) for x in rand_field(nc)] for _ in range(3))
+    wires_v[:, 1], sig_v[:, 1] = P - 1, P - 1          # boundary values: the kernel's inner loop runs on u64 residues
+    wires_v[:, 2], sig_v[:, 2] = 0, (1 << 32) - 1
     zs_v = orc.partial_products(wires_v[:n_routed], sig_v, betas, gammas)
     cs = ctx.commit_values(np.concatenate([const_v, sig_v]) if n_constants else sig_v)
     wb, zb = ctx.commit_values(wires_v), ctx.commit_values(zs_v)
