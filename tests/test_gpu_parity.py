@@ -107,6 +107,7 @@ def test_negacyclic_golden(ctx, path):
                                                      (16, 3, True), (16, 2, False)])
 def test_commit_matches_oracle(ctx, log_n, ncols, from_values):
     data = rand_field(ncols, 1 << log_n)
+    data[0] = P - 1   # a column of the largest field element (as coefficients: every term of the openings' lazy sums at its maximum)
     want = orc.Batch(data, 3, 4, from_values=from_values)
     got = (ctx.commit_values if from_values else ctx.commit_coeffs)(data)
     assert (got.cap_at_commit == want.cap()).all() and (got.cap() == want.cap()).all()
