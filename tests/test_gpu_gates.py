@@ -57,6 +57,8 @@ def test_gate_terms_match_oracle(ctx, log_n, spec, nc):
     gs, ps = go.GateSet(spec), api.GateSet(spec)
     n_const = gs.num_selectors + gs.num_constants
     consts, wires = rand_field(n_const + 3, n), rand_field(135, n)   # + 3 columns standing in for sigmas
+    wires[:, 1], wires[:, 2] = P - 1, 0                              # trace rows of boundary values (the LDE of the columns stays generic)
+    wires[::2, 3], wires[1::2, 3] = (1 << 32) - 1, P - (1 << 32)
     pi_hash, alphas = [int(x) for x in rand_field(4)], [int(x) for x in rand_field(nc)]
     cs, wb = ctx.commit_values(consts), ctx.commit_values(wires)
     got = _leaf_to_natural(_device_gate_terms(ctx, cs, wb, ps, pi_hash, alphas), log_n + 3)
