@@ -712,7 +712,9 @@ static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, unsigned max_
 // Relative cost of a gate's constraints in the tile kernel: microseconds of a launch over 2^19 points in which ONE wave per workgroup
 // evaluates that gate alone (tools/time_gates.py, staging time subtracted) -- a lone wave runs at its dependent-instruction latency, so the
 // figure follows the instruction count (~0.07 per instruction) -- scaled by the gate's parameters.  TILE_UNIT_COST: what every work unit
-// carries besides (selector filter, the reductions of the lazily folded sums, dispatch: ~700 instructions).  (The s_memtime spans that
+// carried besides when the weights were taken (selector filter, the reductions of the lazily folded sums, dispatch: ~700 instructions then;
+// ~150 since the single 160-bit reduction and the branch-free sink -- the weights are relative, the balance they give was re-measured: the
+// kernel alone runs at 0.93 of its instruction time).  (The s_memtime spans that
 // VPBS_TRACE_GATES prints are NOT such a measure: a wave's span stretches with whatever shares its SIMD.)
 constexpr double TILE_UNIT_COST = 50;
 static double tile_weight(const vpbs_gate& g) {
