@@ -1427,7 +1427,15 @@ def main():
             parity, out["cpu_baseline"] = cpu_baseline(gpu_proof)
             out["parity_checked_full_size"] = parity is not None
             out["parity_full_size"] = parity
-        print(json.dumps(out))
+        # The line is a record (numbers and short identifiers, < 4 kB: tools/bench_record.py); the legs, the per-kernel tables and every sentence
+        # that explains them are the detail: bench_detail.json next to this script (and under gpurun_out/), a short summary on stderr.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_record
+        line = bench_record.dumps(bench_record.compact_record(out))
+        wrote = bench_record.write_detail(out)
+        print("bench.py: detail -> %s" % (", ".join(wrote) or "(not writable)"), file=sys.stderr)
+        sys.stderr.flush()
+        print(line, flush=True)
     elif state is not None:
         for ctx in state["ctxs"]:
             ctx.close()

@@ -14,6 +14,9 @@
  * by the caller; vpbs_batch handles are device-resident and owned by the library until vpbs_batch_free.
  * A vpbs_ctx is bound to one device and one HIP stream and is NOT re-entrant: use one ctx per host thread.
  * `_dev` variants take device pointers valid on the ctx's device and enqueue on the ctx's stream.
+ * A HIP failure pending on the calling thread (a launch refused for its configuration or for resources -- this library's or another one's)
+ * is reported by the first call of this library that waits on the device or ends a stage, as VPBS_ERR_DEVICE; the call that reports it
+ * also clears it from the thread's HIP error state: one call fails, the next ones start clean, and the host needs no hipGetLastError.
  */
 #ifndef VPBS_PROVER_H
 #define VPBS_PROVER_H

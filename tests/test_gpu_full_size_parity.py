@@ -40,7 +40,20 @@ def flat(p):
 
 
 def test_cyclic_step_circuit_at_paper_parameters_bit_exact_against_the_oracle():
-    """One CHAINED step of the IVC at N = 1024 (46 656 gate rows of 12 gate types, degree 2^16, 4173 public inputs): base proof and step 0 on
+    _cyclic_chained_step_parity(N, LOG_N, 192716)     # the proof size of the chain (DESIGN: the paper's "~200 kB", ivc_based_vpbs.rs:488)
+
+
+def test_cyclic_step_circuit_n2048_bit_exact_against_the_oracle():
+    """VERDICT r05 next 4 -- BASELINE config 5's ring, N = 2048 (src/ntt/params_2048.rs; pad to the next power of two as ivc_based_vpbs.rs:54-57 does
+    by trial): 88 311 gate rows -> degree 2^17, LDE 2^20, 8 269 public inputs.  Until now this size was only VERIFIED (test_step_circuit_n2048,
+    test_ivc_chain_tool[2048]); here one chained step is compared word for word with the C oracle: caps, challenges, openings, FRI words and all
+    232 012 bytes -- the NTT shapes [4 4 | 4 4 1] / [4 4 | 4 4 4], the 2^20-leaf trees, the 2^17 partial products, quotient and FRI schedule
+    (final polynomial 2^5 coefficients) inside one proof."""
+    _cyclic_chained_step_parity(2048, 17, 232012)
+
+
+def _cyclic_chained_step_parity(N, LOG_N, proof_bytes):
+    """One CHAINED step of the IVC (at N = 1024: 46 656 gate rows of 12 gate types, degree 2^16, 4173 public inputs): base proof and step 0 on
     the GPU, then the wires of step 1 -- whose in-circuit verifier checks step 0's proof -- from the host witness plan; that one witness is
     proven by vpbs_prove_step and by the C oracle (its own FFTs, Merkle trees, partial products, gate constraints of the circuit's real gate
     set and selectors, quotient, openings, FRI), and the two proofs are the same words and the same bytes."""
@@ -88,7 +101,7 @@ def test_cyclic_step_circuit_at_paper_parameters_bit_exact_against_the_oracle():
     assert (np.asarray(want["cs_cap"], np.uint64).reshape(-1) == np.asarray(cyc.cap, np.uint64).reshape(-1)).all()
     blob = ctx.step_proof_to_bytes(si, cyc.d.n_constants, proof)
     compare(proof, want, blob, step_oracle.to_bytes(want, want["ncols"], cyc.d.n_constants, pis, LOG_N), "cyclic circuit, chained step 1")
-    assert len(blob) == 192716                        # the proof size of the chain (DESIGN: the paper's "~200 kB", ivc_based_vpbs.rs:488)
+    assert len(blob) == proof_bytes
     assert cyc.verify(proof, pis) and step_oracle.verify_step(proof, want["cs_cap"], want["ncols"], cyc.vk[:4], pis, LOG_N)
     ctx.close()
 

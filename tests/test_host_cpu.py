@@ -366,6 +366,65 @@ def test_recorded_bench_line_keeps_the_contract():
     assert d["ivc_chain_n2048"]["ms_per_step"] > d["ivc_single_chain"]["ms_per_step"] and d["ivc_chain"]["decrypted"] == d["ivc_chain"]["message"]
 
 
+def _recorded_details():
+    """full results of bench.py runs on the GPU box (bench_detail.json), kept under profiles/: one GPU, two ranks on one device, the sharded mode"""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = [os.path.join(root, "profiles", "r05_bench_latest.json")] + sorted(glob.glob(os.path.join(root, "profiles", "r06_bench_detail*.json")))
+    return [(os.path.basename(p), json.load(open(p))) for p in paths]
+
+
+def test_bench_line_is_a_compact_record():
+    """the line bench.py prints is a record the driver parses -- under 4 kB, finite numbers and short identifiers, the contract
+    keys, BASELINE.json's metric verbatim -- built by tools/bench_record.py from the full result, which goes to bench_detail.json.  Checked on every
+    recorded detail (N = 1; two ranks on one device; --mode sharded) and on a worst case: every string of the detail blown up to a paragraph."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_record
+    metric = json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    details = _recorded_details()
+    assert details
+
+    def blow_up(x):
+        if isinstance(x, dict):
+            return {k: blow_up(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [blow_up(v) for v in x]
+        if isinstance(x, str):
+            return x + " " + "and a long explanation of why, " * 40
+        return x
+
+    for name, d in details + [("blown up " + n, blow_up(x)) for n, x in details]:
+        line = bench_record.dumps(bench_record.compact_record(d))
+        assert len(line) < 4096 and "\n" not in line and line.startswith('{"metric"'), name
+        r = json.loads(line)
+        assert r["metric"] == metric and r["higher_is_better"] is True and r["vs_baseline"] is None
+        assert r["dtype"] == "u64" and r["data"] == "synthetic" and r["scaling"][:4] in ("weak", "stro")
+        assert r["n_gpus"] == d["n_gpus"] and r["steps"] == d["steps"] and r["warmup"] == d["warmup"]
+        assert abs(r["value"] - d["value"]) <= 1e-5 * d["value"] and abs(r["ms_per_step"] - d["ms_per_step"]) <= 1e-5 * d["ms_per_step"]
+        c = r["config"]
+        assert 0 < len(c["workload"]) <= 200 and "model" not in c and c["chains_per_gpu"] >= 1
+        if not name.startswith("blown up"):
+            assert r["unit"] == "vPBS proofs/s" and c["parallelism"] in ("replicas", "coset-sharded") and r["scaling"] in ("weak", "strong")
+        f = r["roofline"]
+        assert f["bound"][:3] == "hbm" and f["unit"][:4] == "GB/s" and f["peak"] == 8000.0 and f["kernel"] == "leaf_hash_kernel"
+        assert abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-6 and 0 < f["frac"] < 0.1
+        assert abs(f["achieved"] - f["algorithmic_bytes_per_launch"] / (f["launch_ms_avg"] * 1e-3) / 1e9) < 1e-4 * f["achieved"]
+        assert f["traffic"] is None or 0.9 < f["traffic"] / f["algorithmic_bytes_per_launch"] < 1.1
+        if "cpu_baseline" in d:
+            b = r["cpu_baseline"]
+            assert b["cores"] >= 1 and b["value"] > 0 and b["runs"] >= 1 and 0 < len(b["sample"]) <= 120
+        assert r["rccl"]["ranks"] == r["n_gpus"]
+    # NaN / Infinity never reach the line; an oversized one is refused, not printed
+    d = dict(details[0][1], value=float("nan"))
+    assert json.loads(bench_record.dumps(bench_record.compact_record(d)))["value"] is None
+    with pytest.raises(ValueError):
+        bench_record.dumps(dict(bench_record.compact_record(details[0][1]), junk="x" * 5000))
+
+
 def test_pmc_table_counts_one_step_proof_exactly(tmp_path):
     """tools/pmc_table.py: `valu_per_step_proof` = SQ_INSTS_VALU of the dispatches between the first and the last quotient_perm_kernel dispatch /
     the periods between them -- the setup commitment's launches (before the first step) and the tail are not in it, whatever their size"""

@@ -19,12 +19,18 @@ struct DeviceError {
     std::string what;
 };
 
+// The call that REPORTS a failure clears it: the waits only peek at the thread's pending error (vpbs::stream_sync), so that the
+// stage-end checks still see a failed launch -- but once it has been turned into a DeviceError, and from there into the status and
+// vpbs_last_error() of the entry point, it is consumed here.  A non-sticky failure (bad configuration, out of resources; this library's or
+// another one's on the same thread) is thus reported by exactly one call; a C++ or Rust host needs no hipGetLastError of its own to go on.
 #define VPBS_HIP(expr)                                                                                         \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
-        if (e_ != hipSuccess)                                                                                  \
+        if (e_ != hipSuccess) {                                                                                \
+            (void)hipGetLastError();                                                                           \
             throw ::vpbs::DeviceError{e_ == hipErrorOutOfMemory ? VPBS_ERR_OOM : VPBS_ERR_DEVICE,              \
                                       std::string(#expr) + ": " + hipGetErrorString(e_)};                      \
+        }                                                                                                      \
     } while (0)
 #define VPBS_REQUIRE(cond, msg)                                         \
     do {                                                                \
