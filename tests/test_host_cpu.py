@@ -425,6 +425,79 @@ def test_bench_line_is_a_compact_record():
         bench_record.dumps(dict(bench_record.compact_record(details[0][1]), junk="x" * 5000))
 
 
+def _kernel_resources(src, tmp_path):
+    """hipcc -Rpass-analysis=kernel-resource-usage over one source of csrc/ (device code only, gfx950): {kernel name: {remark key: int}} and the
+    path of the ISA listing"""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "verifiable-fhe-paper_amd", "csrc")
+    out = str(tmp_path / (src + ".s"))
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage",
+                        "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark: [^:]*:\d+:\d+:\s+(.*?)\s*\[-Rpass-analysis", line) or re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        text = m.group(1)
+        if text.startswith("Function Name:"):
+            cur = kernels.setdefault(text.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in text:
+            k, v = text.rsplit(":", 1)
+            try:
+                cur[k.strip()] = int(v)
+            except ValueError:
+                pass
+    return kernels, out
+
+
+def test_hash_and_gate_kernels_do_not_spill(tmp_path):
+    """leaf_hash_kernel had 66 SGPR spills -- ~140 v_readlane / v_writelane per permutation in its sponge loop (the
+    compiler split all 24 constants of a partial-round group on the scalar unit ahead of the S-boxes and parked the halves in VGPR lanes; the first
+    round's and round 25's constants, loop-invariant, were loaded once and read back from lanes by every permutation) -- and gate_tile_kernel<2>
+    spilled six VGPRs to scratch.  Now: no VGPR spill and no scratch in any of the hot kernels; what is left of the scalar spills in the sponge
+    kernels are kernel arguments touched once per absorb (counted in the ISA of the loop: at most 16 lane moves per permutation of ~13.3 k
+    instructions); the gate tile kernel dispatches its work units on scalar registers (s_cbranch, not exec masks)."""
+    kernels, asm = _kernel_resources("hash.hip", tmp_path)
+
+    def find(part):
+        hits = [v for k, v in kernels.items() if part in k]
+        assert len(hits) == 1, (part, list(kernels))
+        return hits[0]
+    for part, limit in (("16leaf_hash_kernelILb0EE", 16), ("20fri_leaf_hash_kernelE", 16), ("19merkle_level_kernelE", 8), ("16hash_rows_kernelE", 8)):
+        k = find(part)
+        assert k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0 and k["SGPRs Spill"] <= limit, (part, k)
+        assert k["Occupancy [waves/SIMD]"] >= 4, (part, k)
+    # the sponge loop of the launched leaf kernel: lane moves between the loop header and its back edge
+    text = open(asm).read()
+    body = text[text.index("leaf_hash_kernelILb0EE"):]
+    body = body[:body.index("s_endpgm")]
+    lines = body.splitlines()
+    header = next(i for i, l in enumerate(lines) if "=>This Loop Header: Depth=1" in l)
+    label = lines[header].split(":")[0].strip().lstrip(".L")        # blocks of the loop carry "Header=BBn_m" / "Parent Loop BBn_m" remarks
+    last = max(i for i, l in enumerate(lines) if ("Header=" + label) in l or ("Parent Loop " + label) in l)
+    end = next((i for i in range(last + 1, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i])), len(lines))
+    loop = lines[header:end]
+    is_move = lambda l: "v_readlane_b32" in l or "v_writelane_b32" in l
+    lane_moves = sum(1 for l in loop if is_move(l))
+    valu = sum(1 for l in loop if re.match(r"\s+v_", l))
+    # the round loops inside (full rounds x 4, partial groups x 7, full rounds x 4: the blocks remarked "Inner Loop Header: Depth=2", each up to
+    # the next label) run several times per permutation: not one lane move in them
+    inner = 0
+    for i, l in enumerate(loop):
+        m = re.match(r"(\.LBB\d+_\d+):", l)
+        if m and i + 1 < len(loop) and "Inner Loop Header: Depth=2" in loop[i + 1]:
+            j = max(k for k in range(i, len(loop)) if re.search(r"s_cbranch_\w+\s+" + re.escape(m.group(1)) + r"\s*$", loop[k]))   # its back edge
+            inner += sum(1 for x in loop[i:j] if is_move(x))
+    assert valu > 3000 and lane_moves <= 16 and inner == 0, (lane_moves, inner, valu)
+    kernels, asm = _kernel_resources("gates.hip", tmp_path)
+    k = [v for name, v in kernels.items() if "gate_tile_kernelILi2EE" in name][0]
+    assert k["VGPRs Spill"] == 0 and k["ScratchSize [bytes/lane]"] == 0 and k["Occupancy [waves/SIMD]"] >= 4, k
+    text = open(asm).read()
+    body = text[text.index("gate_tile_kernelILi2EE"):]
+    body = body[:body.index("s_endpgm")]
+    assert "s_cbranch_scc" in body and len(re.findall(r"v_cmp_eq_u32_e32 vcc, \d+, v\d+\n\s+s_and_saveexec", body)) == 0
+
+
 def test_pmc_table_counts_one_step_proof_exactly(tmp_path):
     """tools/pmc_table.py: `valu_per_step_proof` = SQ_INSTS_VALU of the dispatches between the first and the last quotient_perm_kernel dispatch /
     the periods between them -- the setup commitment's launches (before the first step) and the tail are not in it, whatever their size"""

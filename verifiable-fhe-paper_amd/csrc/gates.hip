@@ -398,7 +398,10 @@ gate_tile_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, 
                  const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out,
                  unsigned long long* __restrict__ prof /* VPBS_TRACE_GATES: shader cycles per work unit, [TILE_MAX_UNITS]; else nullptr */) {
     __shared__ u64 lds[TILE_MAX_COLS * TILE_PTS];
-    const unsigned lane = threadIdx.x & (TILE_PTS - 1), wave = threadIdx.x / TILE_PTS;
+    // the wave's number as a SCALAR (readfirstlane): its work units, their gates' kinds and parameters then live in scalar registers and the
+    // dispatch over the kinds is a scalar branch -- as a vector value the compiler treated `u` as divergent: the gate descriptor came through
+    // global_load into VGPRs and every case of the switch ran under exec masks with the sinks' accumulators merged by moves behind it
+    const unsigned lane = threadIdx.x & (TILE_PTS - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TILE_PTS);
     const size_t j = (size_t)blockIdx.x * TILE_PTS + lane;
     // stage the tile: wave w copies columns w, w + 8, ... -- six 512-byte rows requested before the first is written to LDS, so that a
     // wave pays three memory round trips for its 18 columns, not eighteen

@@ -100,7 +100,7 @@ GL_HD u64 reduce128_nc(u64 lo, u64 hi) {
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 // Hand-scheduled gfx950 forms (bit-identical residues are not required between forms; all results are congruent mod p
-// and every consumer accepts any u64 residue).  They use fixed scratch registers v80..v87 / s[80:85], declared as
+// and every consumer accepts any u64 residue).  They use fixed scratch registers v80..v87 / s[80:87], declared as
 // clobbers, because a 64-bit inline-asm operand cannot name its halves and v_mad_u64_u32 needs aligned pairs.
 //   product: 4 v_mad_u64_u32 (the a1*b0 term is accumulated onto a0*b1 with its carry-out kept in an SGPR pair) + 3 adds
 //   reduce : u = hi_lo * (2^32-1) + lo as ONE v_mad_u64_u32 with carry-out c; r = u - hi_hi with borrow b;
@@ -184,7 +184,7 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
         GL_REDUCE_TAIL("%=")
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
-        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81");   // only what the form writes: every named scalar is one the allocator loses
     return ((u64)r1 << 32) | r0;
 }
 // Two independent products with their instruction streams interleaved (second register set v88..v95 / s[86:91]): used
@@ -217,7 +217,7 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
         "v_subbrev_co_u32_e64 v89, s[84:85], 0, v89, vcc\n\t"
         "v_cndmask_b32_e64 v87, 0, -1, s[80:81]\n\t"
         "v_cndmask_b32_e64 v95, 0, -1, s[86:87]\n\t"
-        "s_or_b64 s[88:89], s[82:83], s[84:85]\n\t"
+        "s_or_b64 s[80:81], s[82:83], s[84:85]\n\t"    // (for SCC only; s[80:81] is dead here)
         "s_cbranch_scc0 .Lgl_red2_%=\n\t"
         "v_cndmask_b32_e64 v86, 0, -1, s[82:83]\n\t"
         "v_sub_co_u32_e32 v80, vcc, v80, v86\n\t"
@@ -234,7 +234,7 @@ __device__ __forceinline__ void mul2_nc(u64 a, u64 b, u64 c, u64 d, u64& r, u64&
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
           "v"((u32)(d >> 32))
         : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "vcc", "scc",
-          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
     r = ((u64)r1 << 32) | r0;
     q = ((u64)q1 << 32) | q0;
 }
@@ -282,7 +282,7 @@ __device__ __forceinline__ u64 dot2_nc(u64 a, u64 b, u64 c, u64 d) {
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"((u32)c), "v"((u32)(c >> 32)), "v"((u32)d),
           "v"((u32)(d >> 32))
         : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, GL_Q0, GL_Q1, GL_Q2, GL_Q3, GL_Q4, GL_Q5, GL_Q6, "vcc", "scc",
-          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+          "s80", "s81", "s86", "s87");
     return ((u64)r1 << 32) | r0;
 }
 // a * b + c with one reduction (the product plus a 64-bit addend stays below 2^128).  Any residues in, a residue out; 16 VALU.
@@ -305,7 +305,7 @@ __device__ __forceinline__ u64 mad_nc(u64 a, u64 b, u64 c) {
         GL_REDUCE_TAIL("%=")
         : "=&v"(r0), "=&v"(r1)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)), "v"(c)
-        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85");
+        : GL_R0, GL_R1, GL_R2, GL_R3, GL_R4, GL_R5, GL_R6, GL_R7, "vcc", "scc", "s80", "s81", "s82", "s83");
     return ((u64)r1 << 32) | r0;
 }
 // lo + hi_lo 2^64 + hi_hi 2^96 (mod p) -> a u64 residue: the reduction tail of mul_nc on its own (6 VALU), for values that are

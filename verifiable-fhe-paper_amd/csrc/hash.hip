@@ -14,6 +14,9 @@ namespace vpbs {
 namespace {
 constexpr unsigned THREADS = 256;
 
+// SAMPLE: the timing form (bench.py's in-kernel clock) -- the same code with two counters read at both ends; the form the prover launches
+// carries neither the pointer nor the two 64-bit start values through its 15 k instructions (seven scalar registers the sponge loop wants)
+template <bool SAMPLE>
 __global__ void __launch_bounds__(THREADS)
 leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* __restrict__ digests,
                  u64* __restrict__ clock_sample) {
@@ -21,7 +24,7 @@ leaf_hash_kernel(const u64* __restrict__ lde, unsigned ncols, size_t n_leaves, s
     if (j >= n_leaves) return;
     // timing runs only: one wave in the middle of the grid reports the shader cycles and the 100 MHz ticks of its own lifetime -- the clock the
     // chip really sustains under this kernel (a light probe kernel reads the boost clock instead)
-    const bool sample = clock_sample != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    const bool sample = SAMPLE && clock_sample != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
     u64 c0 = 0, r0 = 0;
     if (sample) {
         r0 = __builtin_amdgcn_s_memrealtime();
@@ -232,8 +235,12 @@ pow_search_kernel(PowState st, unsigned pos, unsigned pow_bits, u64 start, u64 c
 }  // namespace
 
 void launch_leaf_hash(hipStream_t s, const u64* lde, unsigned ncols, size_t n_leaves, size_t col_stride, u64* digests, u64* clock_sample) {
-    hipLaunchKernelGGL(leaf_hash_kernel, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
-                       col_stride, digests, clock_sample);
+    if (clock_sample)
+        hipLaunchKernelGGL(leaf_hash_kernel<true>, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
+                           col_stride, digests, clock_sample);
+    else
+        hipLaunchKernelGGL(leaf_hash_kernel<false>, dim3((n_leaves + THREADS - 1) / THREADS), dim3(THREADS), 0, s, lde, ncols, n_leaves,
+                           col_stride, digests, clock_sample);
 }
 // the defaults of a context's launch heuristics: below wide_threshold independent permutations a launch is latency-bound and the 16-lane
 // form wins (measured)
