@@ -644,11 +644,17 @@ def valu_budget(sclk_hz, step_ms, shared_gpu=False):
     import csv
     # shared_gpu: the counters of the settings a context runs with beside other chains (16-lane Poseidon threshold 2048, PoW in rounds:
     # tools/pmc_kernels.sh's third pass) -- the eight-chain headline's own instruction stream; else the defaults of a context alone on the GPU
-    names = (("r05_pmc_sq_kernels_shared_gpu.csv",) if shared_gpu else ()) + ("r05_pmc_sq_kernels.csv", "r04_pmc_sq_kernels.csv")
-    for name in names:
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_sources
+    paths = [kernel_sources.newest_profile("pmc_sq_kernels_shared_gpu.csv") if shared_gpu else None, kernel_sources.newest_profile("pmc_sq_kernels.csv")]
+    # the counters are constants read from profiles/: do they belong to the device code of this checkout?  (tools/refresh_profiles.sh records the
+    # fingerprint of the kernel sources next to them; the CPU suite fails on a mismatch, the line carries the answer)
+    src = kernel_sources.newest_profile("pmc_sources.json")
+    fresh = bool(src) and json.load(open(src)).get("sha256") == kernel_sources.fingerprint()["sha256"]
+    for path in paths:
+        if not path or not os.path.exists(path):
             continue
+        name = os.path.basename(path)
         rows = list(csv.DictReader(open(path)))
         by = {r["kernel"]: r for r in rows}
         if "leaf_hash_kernel" not in by:
@@ -668,6 +674,7 @@ def valu_budget(sclk_hz, step_ms, shared_gpu=False):
         return {"bound": "int-valu-issue (whole step)", "wave_instructions_per_step_G": total, "by_kernel_G": top,
                 "issue_peak_G_wave_instr_per_s": issue / 1e9, "shader_clock_mhz": sclk_hz / 1e6,
                 "instruction_time_ms_per_step": floor_ms, "measured_ms_per_step_proof": step_ms, "frac": floor_ms / step_ms,
+                "counters_match_kernel_sources": fresh,
                 "counters_from": "profiles/" + name + " (" + basis + ", synthetic step; same kernels and "
                                  "shapes as the chained step; a constant read from profiles/, not re-measured in this run)",
                 "what": "sum of the step's wave-level VALU instructions / (1024 SIMDs / %.2f cycles per instruction at the clock one wave of "
@@ -691,12 +698,16 @@ def roofline_of(per_step_ms, bytes_step, perms, sclk_mhz, sclk_samples, launches
     peak = 256 * 4 * 64 / CEILING_CYCLES_PER_INSTR * sclk_hz / 1e12
     hbm = bytes_step / secs / 1e9
     traffic, traffic_from = None, None
-    for tname in ("r05_pmc_leaf_hash.json", "r04_pmc_leaf_hash.json", "r03_pmc_leaf_hash.json", "r02_pmc_leaf_hash.json", "r01_pmc_leaf_hash.json"):
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
-            traffic_from = "profiles/" + tname
-            break
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_sources
+    tpath = kernel_sources.newest_profile("pmc_leaf_hash.json")
+    if tpath:
+        # the counters were taken on whole launches at degree 2^16 (2^19 leaves); a rank of the coset-sharded step hashes its share of the
+        # leaves per launch: the constant is scaled to the launch this run timed (it IS proportional: traffic = 1.00 x algorithmic bytes)
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_avg")
+        if traffic is not None:
+            traffic *= bytes_step / float(leaf_hash_bytes_per_step(LOG_N))
+        traffic_from = "profiles/" + os.path.basename(tpath)
     step_total = sum(STEP_ALGORITHMIC_MB.values()) * 1e6
     out = {"bound": "hbm", "kernel": "leaf_hash_kernel (Poseidon sponge over LDE rows, 3 launches per step proof)",
            "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "traffic": traffic,
@@ -1240,6 +1251,8 @@ def main():
                          "rank alone on the device with its collectives answered from a recording (tools/sharded_replay.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device ordinal (testing N > 1 on one GPU)")
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json next to this script, and a copy under "
+                                                   "gpurun_out/ where that directory exists); stdout carries the compact record only")
     ap.add_argument("--log-n", type=int, default=LOG_N, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -1432,7 +1445,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_record
         line = bench_record.dumps(bench_record.compact_record(out))
-        wrote = bench_record.write_detail(out)
+        wrote = bench_record.write_detail(out, path=args.detail)
         print("bench.py: detail -> %s" % (", ".join(wrote) or "(not writable)"), file=sys.stderr)
         sys.stderr.flush()
         print(line, flush=True)

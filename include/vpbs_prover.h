@@ -57,7 +57,8 @@ void* vpbs_ctx_stream(vpbs_ctx* ctx); /* hipStream_t, for callers that share dev
 typedef enum {
     VPBS_OPT_GATE_LANES = 0,      /* 1 (default) | 3: streams of the gate-constraint stage (= vpbs_ctx_set_gate_lanes).  VPBS_GATE_LANES     */
     VPBS_OPT_GATES_FUSED = 1,     /* 1 (default): all gate constraints in one launch; 0: one launch per gate type.       VPBS_GATES_FUSED    */
-    VPBS_OPT_GATE_ITEMS = 2,      /* 1..8 (default 5): work items per point tile of the one-launch gate kernel.          VPBS_GATE_ITEMS     */
+    VPBS_OPT_GATE_ITEMS = 2,      /* reserved: tuned the (tile x item) gate kernel of rounds 2-4, removed in round 6; 1..8 is still
+                                     accepted and read back, and has no effect.                                          VPBS_GATE_ITEMS     */
     VPBS_OPT_WIDE_THRESHOLD = 3,  /* launches with at most this many independent permutations (Merkle / FRI tree levels, FRI leaves) use
                                      the 16-lane Poseidon form: a third of the latency for 3.7 x the instructions.  Default 2^14: right
                                      for a context that has the GPU to itself.  A context that SHARES the GPU with other chains should
@@ -67,7 +68,8 @@ typedef enum {
                                      fewer permutations, each round one permutation deep) instead of all at once.        VPBS_WIDE_THRESHOLD */
     VPBS_OPT_MERKLE_CLIMB = 4,    /* 1 (default): the upper levels of a tree in fused multi-level launches; 0: per level. VPBS_MERKLE_CLIMB  */
     VPBS_OPT_GATES_TILE = 5       /* 1 (default): the one-launch gate kernel stages a 64-point tile of every column in LDS and its eight
-                                     waves share the gates; 0: the (tile x item) kernel that leaves the re-reads to the caches.  VPBS_GATES_TILE */
+                                     waves share the gates; 0: one launch per gate type, as VPBS_OPT_GATES_FUSED = 0 (also what a gate
+                                     set that does not fit a tile plan gets).                                            VPBS_GATES_TILE */
 } vpbs_option;
 int vpbs_ctx_set_option(vpbs_ctx* ctx, int option, uint64_t value);
 int vpbs_ctx_get_option(const vpbs_ctx* ctx, int option, uint64_t* value_out);

@@ -67,7 +67,7 @@ def test_merkle_cap(ctx, leaf_len, n_leaves, cap_h):
 
 
 # ---------- NTT ----------
-@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])   # 19 = the quotient's transform at degree 2^16
+@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])   # 19 = the quotient's transform at degree 2^16; 22 = the launchers' limit
 def test_intt(ctx, log_n):
     vals = rand_field(3, 1 << log_n)
     got = ctx.intt(vals)
@@ -77,7 +77,7 @@ def test_intt(ctx, log_n):
 
 @pytest.mark.parametrize("log_n,rate_bits,shift", [(1, 3, 7), (3, 3, 7), (7, 3, pow(7, 256, P)), (11, 3, pow(7, 16, P)), (12, 3, 7),
                                                    (13, 0, 7), (15, 3, 7), (10, 1, 49), (14, 2, 7), (16, 3, 7), (17, 1, 7), (18, 0, 49),
-                                                   (19, 1, pow(7, 16, P)), (20, 0, 7)])
+                                                   (19, 1, pow(7, 16, P)), (20, 0, 7), (21, 0, 7), (22, 0, 7)])   # 21 / 22: the strided NR = 3 shapes
 def test_coset_lde_leaf_order(ctx, log_n, rate_bits, shift):
     coeffs = rand_field(2, 1 << log_n)
     got = ctx.coset_lde(coeffs, rate_bits, shift)

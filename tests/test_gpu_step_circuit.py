@@ -535,25 +535,37 @@ def test_ivc_chain_tool_sharded_over_two_ranks(device_witness):
     assert d["n_gpus"] == 2 and d["step_proofs"] == 8 and d["decrypted"] == d["message"] == 1
 
 
-def test_bench_with_the_early_witness_phases_on_the_device():
+def _bench_line_and_detail(stdout, detail_path):
+    """the ONE compact record on stdout (< 4 kB: VERDICT r05 next 1) and the full result bench.py wrote to --detail"""
+    import json
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, stdout[-2000:]
+    line, d = json.loads(lines[0]), json.load(open(detail_path))
+    assert line["detail"] == "bench_detail.json" and abs(line["value"] - d["value"]) <= 1e-5 * d["value"] and line["n_gpus"] == d["n_gpus"]
+    assert line["metric"].startswith("vPBS proofs/sec at N=1024") and line["roofline"]["bound"] == "hbm" and line["roofline"]["kernel"] == "leaf_hash_kernel"
+    return line, d
+
+
+def test_bench_with_the_early_witness_phases_on_the_device(tmp_path):
     """bench.py --device-witness: the headline workload through the device pipeline (what a rank with a small CPU share runs by default);
     the same contract line, every chain's last proof checked after the clock"""
-    import json
     import subprocess
     import sys
     import __graft_entry__ as entry
+    detail = str(tmp_path / "detail.json")
     r = subprocess.run([sys.executable, entry.ROOT + "/bench.py", "--steps", "10", "--warmup", "3", "--chains", "2", "--device-witness", "4",
                         "--no-single-chain", "--no-step-micro", "--no-cpu-baseline", "--no-survey-size", "--no-step-circuit", "--no-batch128",
-                        "--no-whole-pbs", "--no-ivc"], capture_output=True, text=True, timeout=1500)
+                        "--no-whole-pbs", "--no-ivc", "--detail", detail], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    line, d = _bench_line_and_detail(r.stdout, detail)
+    assert line["steps"] == 10 and line["config"]["chains_per_gpu"] == 2 and line["config"]["witness"] == "device"
     assert d["steps"] == 10 and d["config"]["chains_per_gpu"] == 2 and d["config"]["early_witness_phase"].startswith("on the device, 4 steps")
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 and d["chain_checks"]["proof_bytes"] == 192716
     # the window sits in the pipeline's steady state: two batches of run-in before the warm-up, two batches of tail after the clock (ADVICE r03)
     assert d["config"]["run_in_steps"] == 8 and d["config"]["tail_steps"] == 8 and "ON THE DEVICE" in d["config"]["stages"]
 
 
-def test_bench_contract_with_two_ranks_sharing_the_gpu():
+def test_bench_contract_with_two_ranks_sharing_the_gpu(tmp_path):
     """The driver's multi-GPU launch of bench.py (torch.distributed.run, one rank per GPU, replicas: independent chains per rank, no
     data-path collective) with both ranks on the one device of the test box (--device 0, gloo for the barriers): ONE JSON line from rank 0,
     n_gpus = 2, exactly --steps timed chained steps, value = the chains of BOTH ranks over the slower rank's time, every chain's last proof
@@ -564,12 +576,12 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     import __graft_entry__ as entry
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", entry.ROOT + "/bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--device", "0",
-                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0"], capture_output=True, text=True, timeout=1500,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0", "--detail", str(tmp_path / "detail.json")],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(r.stdout, str(tmp_path / "detail.json"))
+    assert (line["n_gpus"], line["steps"], line["warmup"], line["scaling"], line["vs_baseline"]) == (2, 12, 2, "weak", None)
+    assert line["config"]["parallelism"] == "replicas" and "cpu_baseline" not in line and line["rccl"]["ranks"] == 2
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["vs_baseline"]) == (2, 12, 2, "weak", None)
     assert d["config"]["chains_per_gpu"] == 1 and "vpbs_ivc_prove_pbs" in d["config"]["workload"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"] / 730) < 1e-9 * d["value"] + 1e-12       # both ranks' chains over the MAX time
@@ -577,7 +589,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert "cpu_baseline" not in d                                                              # N = 1 only
 
 
-def test_bench_launches_its_own_ranks():
+def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` WITHOUT a launcher around it: the parent starts torch.distributed.run as a child process
     and relays rank 0's line -- n_gpus = 2, the communication library's own count of the ranks, the CPUs per rank and the pipeline chosen.
     Both ranks on the one device of the test box (--device 0), gloo for the process group."""
@@ -587,11 +599,14 @@ def test_bench_launches_its_own_ranks():
     import __graft_entry__ as entry
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, entry.ROOT + "/bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--device", "0",
-                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0"], capture_output=True, text=True, timeout=1500, env=env)
+                        "--dist-backend", "gloo", "--chains", "1", "--device-witness", "0", "--detail", str(tmp_path / "detail.json")],
+                       capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 1, r.stdout[-2000:]                       # ONE line on stdout, everything else went to stderr
-    d = json.loads(lines[0])
+    line, d = _bench_line_and_detail(r.stdout, str(tmp_path / "detail.json"))
+    assert (line["n_gpus"], line["steps"], line["warmup"], line["scaling"]) == (2, 12, 2, "weak") and line["rccl"] == {"ranks": 2, "version": line["rccl"]["version"], "backend": "gloo"}
+    assert line["launched_by"].startswith("bench.py itself") and line["cpus_per_rank"] >= 1 and line["config"]["witness"] == "host"
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"]) == (2, 12, 2, "weak")
     assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["devices"]) == 2
     assert d["launched_by"].startswith("bench.py itself") and d["cpus_per_rank"] >= 1

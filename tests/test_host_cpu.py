@@ -425,6 +425,25 @@ def test_bench_line_is_a_compact_record():
         bench_record.dumps(dict(bench_record.compact_record(details[0][1]), junk="x" * 5000))
 
 
+def test_counter_files_belong_to_the_kernels_as_they_stand():
+    """`roofline.traffic` and `valu_budget.by_kernel_G` are constants read from profiles/ (counter passes are their own
+    rocprofv3 runs).  The newest counter set carries the fingerprint of the device sources it was measured on (tools/refresh_profiles.sh ->
+    profiles/rNN_pmc_sources.json); any edit of a kernel source after that fails here until the counters are taken again."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_sources
+    src = kernel_sources.newest_profile("pmc_sources.json")
+    assert src, "no profiles/rNN_pmc_sources.json: run tools/refresh_profiles.sh on the GPU box and tools/condense_profiles.py here"
+    tag = os.path.basename(src)[:3]
+    for suffix in ("pmc_sq_kernels.csv", "pmc_sq_kernels_shared_gpu.csv", "pmc_leaf_hash.json"):     # what bench.py will read: the same round's
+        assert os.path.basename(kernel_sources.newest_profile(suffix)).startswith(tag), suffix
+    was, now = json.load(open(src)), kernel_sources.fingerprint()
+    changed = sorted(k for k in now["files"] if was["files"].get(k) != now["files"][k])
+    assert not changed, "device sources changed since the counters of %s were measured: %s -- refresh them (tools/refresh_profiles.sh)" % (tag, changed)
+
+
 def _kernel_resources(src, tmp_path):
     """hipcc -Rpass-analysis=kernel-resource-usage over one source of csrc/ (device code only, gfx950): {kernel name: {remark key: int}} and the
     path of the ISA listing"""

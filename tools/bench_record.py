@@ -71,6 +71,7 @@ def compact_record(d):
                      "algorithmic_bytes_per_launch": _num(r.get("algorithmic_bytes_per_launch"), 12), "launch_ms_avg": _num(r.get("launch_ms_avg")),
                      "launches": r.get("launches"), "int_issue_frac": _num(r.get("int_issue_frac")),
                      "valu_budget_frac": _num(_get(r, "valu_budget", "frac")),
+                     "counters_fresh": _get(r, "valu_budget", "counters_match_kernel_sources"),
                      "valu_budget_frac_single_chain": _num(_get(r, "valu_budget_single_chain", "frac")),
                      "step_hbm_frac": _num(r.get("step_hbm_frac")), "sclk_mhz": _num(r.get("shader_clock_mhz_in_kernel"), 5)},
         "ms_per_step_proof": _num(d.get("ms_per_step_proof")), "step_proofs_per_s": _num(d.get("step_proofs_per_s")),
@@ -136,11 +137,17 @@ def dumps(line):
     return s
 
 
-def write_detail(d, root=ROOT):
-    """the full result: next to bench.py, and under gpurun_out/ where that exists (the only directory that travels back from a GPU box)"""
-    paths = [os.path.join(root, "bench_detail.json")]
-    if os.path.isdir(os.path.join(root, "gpurun_out")):
-        paths.append(os.path.join(root, "gpurun_out", "bench_detail.json"))
+def write_detail(d, root=ROOT, path=None):
+    """the full result: to `path` when one is given (bench.py --detail), else next to bench.py and under gpurun_out/ where that exists (the only
+    directory that travels back from a GPU box)"""
+    if path == os.devnull:
+        return []
+    if path:
+        paths = [path]
+    else:
+        paths = [os.path.join(root, "bench_detail.json")]
+        if os.path.isdir(os.path.join(root, "gpurun_out")):
+            paths.append(os.path.join(root, "gpurun_out", "bench_detail.json"))
     written = []
     for p in paths:
         try:

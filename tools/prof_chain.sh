@@ -9,7 +9,7 @@ export GPU_MAX_HW_QUEUES=8   # what bench.py sets for itself; under the profiler
 rm -rf gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --chains $CH --steps 60 --warmup 6 \
   --no-single-chain --no-step-micro --no-cpu-baseline --no-survey-size --no-step-circuit --no-batch128 --no-whole-pbs --no-ivc \
-  > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}.err
+  --detail gpurun_out/prof_${TAG}_bench.json > /dev/null 2> gpurun_out/prof_${TAG}.err
 f=$(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/prof_${TAG}_kernel_stats.csv && head -25 "$f"
 python3 -c "

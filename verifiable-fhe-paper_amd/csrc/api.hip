@@ -444,7 +444,7 @@ const u64* vpbs_ctx::roots(unsigned log_n, bool inverse) {
     auto key = std::make_pair(log_n, inverse);
     auto it = root_tables.find(key);
     if (it != root_tables.end()) return it->second;
-    u64* t = alloc_words(vpbs::root_table_words(log_n));  // all n powers (the radix-8 rounds index up to w^(7n/8)) + the round tables
+    u64* t = alloc_words(vpbs::root_table_words(log_n));  // all n powers + the radix-16 rounds' block twiddle tables (ntt.hip root_table_words)
     vpbs::launch_root_table(stream, t, log_n, inverse);
     root_tables[key] = t;
     return t;

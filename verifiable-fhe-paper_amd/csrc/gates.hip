@@ -47,7 +47,7 @@ template <int NC> struct DevSinkT {
     LazyAcc acc[NC];
     __device__ __forceinline__ DevSinkT(const u64* apow, unsigned pow_stride, unsigned nc) : idx(0), acc{} {
 #pragma unroll
-        for (int a = 0; a < NC; ++a) row[a] = apow + (size_t)((unsigned)a < nc ? (unsigned)a : (nc ? nc - 1 : 0)) * pow_stride;
+        for (int a = 0; a < NC; ++a) row[a] = apow + (size_t)((unsigned)a < nc ? (unsigned)a : nc - 1) * pow_stride;   // nc >= 1: checked where the kernels are launched
     }
     __device__ __forceinline__ void push(u64 c) {
         const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
@@ -297,83 +297,17 @@ void launch_one(hipStream_t s, const u64* wires, const u64* consts, size_t len, 
                            pih, out, accumulate);
 }
 
-// ---- all gates in ONE launch (the default path) ----
-// The per-gate launches above make every gate re-read its wires from HBM (the 135 wire columns are touched 7.6 times between them, and each
-// launch read-modify-writes the output).  Here a launch covers (point tile x work item): an item is a group of gates evaluated one after the
-// other by the same thread, and the blocks of one tile are numbered so that they are dispatched back to back to the SAME XCD (workgroups go
-// round-robin over the 8 XCDs): the tile's columns are fetched into that XCD's L2 once and the other items of the tile hit there (or in the
-// memory-side cache) instead of HBM.  Every item writes its own output plane [nc][len] exactly once (no read-modify-write); the caller sums
-// the planes (quotient_combine_kernel / sum_planes_kernel).
-constexpr unsigned FUSED_MAX_GATES = 20, FUSED_MAX_ITEMS = 8, FUSED_TILE = THREADS;
-struct FusedPlan {
-    vpbs_gate gates[FUSED_MAX_GATES];  // ordered by item
-    gates::CosetTables tables;         // the CosetInterpolationGate's domain / weights (at most one such gate per plan)
-    unsigned item_first[FUSED_MAX_ITEMS + 1];
-    unsigned n_items;
-};
-template <int NC>
-__global__ void __launch_bounds__(THREADS, 4)   // 4 waves per SIMD: at most 128 VGPRs
-gate_fused_kernel(const u64* __restrict__ wires, const u64* __restrict__ consts, size_t len, FusedPlan plan, unsigned num_selectors,
-                  const u64* __restrict__ apow, unsigned pow_stride, unsigned nc, PiHash pih, u64* __restrict__ out, int xcd_map) {
-    unsigned tile, item;
-    if (xcd_map) {  // block b runs on XCD b % 8: consecutive blocks OF ONE XCD are the items of one tile
-        const unsigned xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        item = i % plan.n_items;
-        tile = (i / plan.n_items) * 8 + xcd;
-    } else {
-        tile = blockIdx.x / plan.n_items;
-        item = blockIdx.x % plan.n_items;
-    }
-    const size_t j = (size_t)tile * FUSED_TILE + threadIdx.x;
-    if (j >= len) return;
-    u64 total[NC];
-#pragma unroll
-    for (int a = 0; a < NC; ++a) total[a] = 0;
-    for (unsigned gi = plan.item_first[item]; gi < plan.item_first[item + 1]; ++gi) {
-        const vpbs_gate& g = plan.gates[gi];
-        // the point index is made opaque per gate: otherwise the column addresses (the same for every gate) are hoisted out of the loop
-        // as loop invariants and live across all the cases (235 VGPRs instead of ~100)
-        size_t jj = j;
-        asm volatile("" : "+v"(jj));
-        DevVars v{wires, consts + (size_t)num_selectors * len, len, jj, pih};
-        DevSinkT<NC> s(apow, pow_stride, nc);
-        switch (g.kind) {  // wave-uniform
-#define VPBS_FUSED_CASE(K) case K: eval_kind<K>(g, plan.tables, v, s); break;
-            VPBS_FUSED_CASE(VPBS_GATE_CONSTANT)
-            VPBS_FUSED_CASE(VPBS_GATE_PUBLIC_INPUT)
-            VPBS_FUSED_CASE(VPBS_GATE_ARITHMETIC)
-            VPBS_FUSED_CASE(VPBS_GATE_BASE_SUM)
-            VPBS_FUSED_CASE(VPBS_GATE_POSEIDON)
-            VPBS_FUSED_CASE(VPBS_GATE_POSEIDON_MDS)
-            VPBS_FUSED_CASE(VPBS_GATE_ARITHMETIC_EXT)
-            VPBS_FUSED_CASE(VPBS_GATE_MUL_EXT)
-            VPBS_FUSED_CASE(VPBS_GATE_REDUCING)
-            VPBS_FUSED_CASE(VPBS_GATE_REDUCING_EXT)
-            VPBS_FUSED_CASE(VPBS_GATE_RANDOM_ACCESS)
-            VPBS_FUSED_CASE(VPBS_GATE_EXPONENTIATION)
-            VPBS_FUSED_CASE(VPBS_GATE_COSET_INTERPOLATION)
-#undef VPBS_FUSED_CASE
-            default: break;
-        }
-        const u64 filter = gates::compute_filter<u64>(g, consts[(size_t)g.selector_index * len + jj], num_selectors > 1);
-#pragma unroll
-        for (int a = 0; a < NC; ++a)
-            if ((unsigned)a < nc) total[a] = gl::add(total[a], gl::mul(filter, s.acc[a].reduce()));
-    }
-#pragma unroll
-    for (int a = 0; a < NC; ++a)
-        if ((unsigned)a < nc) out[((size_t)item * nc + a) * len + j] = total[a];
-}
-
 // ---- all gates in ONE launch, the tile's columns staged in LDS (the default path) ----
-// The (tile x item) kernel above leaves the re-reads of a tile's columns to the caches: the counters show 4.7 x the algorithmic bytes leaving
-// the XCDs' L2 and the waves waiting on memory 43 % of their cycles.  Here a workgroup of eight waves owns 64 LDE points: it copies the
+// The per-gate launches above make every gate re-read its wires from HBM (the 135 wire columns are touched 7.6 times between them, and each
+// launch read-modify-writes the output); a (tile x item) kernel that left the re-reads to the caches (rounds 2-4, removed in round 6: the
+// counters showed 4.7 x the algorithmic bytes leaving the XCDs' L2 and the waves waiting on memory 43 % of their cycles) was the step between.
+// Here a workgroup of eight waves owns 64 LDE points: it copies the
 // 135 wire values and the selector / gate-constant values of those points into LDS ONCE (coalesced 512-byte rows, [column][64]), and
 // after one barrier every wave evaluates ITS share of the gates for the same 64 points out of LDS (ds_read_b64 at constant offsets: no
 // address arithmetic, ~100 cycles instead of a trip to L2 / HBM).  The shares are balanced by weight; the PoseidonGate -- a third of the
 // work -- is cut into three independent pieces (poseidon_gate_part).  The waves' sums are added through LDS and ONE plane is written.
 // HBM traffic = the algorithmic bytes; 73 KB of LDS per workgroup, two workgroups per CU = 4 waves per SIMD.
-constexpr unsigned TILE_PTS = 64, TILE_WAVES = 8, TILE_MAX_COLS = 135 + 8, TILE_MAX_UNITS = FUSED_MAX_GATES + 2;
+constexpr unsigned TILE_PTS = 64, TILE_WAVES = 8, TILE_MAX_COLS = 135 + 8, TILE_MAX_GATES = 20, TILE_MAX_UNITS = TILE_MAX_GATES + 2;
 struct TilePlan {
     vpbs_gate gates[TILE_MAX_UNITS];   // work units ordered by wave
     uint8_t part[TILE_MAX_UNITS];      // 0: the whole gate; 1..3: a piece of the PoseidonGate
@@ -673,42 +607,6 @@ void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_ld
     }
 }
 
-// Work items of the one-launch path: the gates with constraints, heaviest first, packed into n_items groups of about equal weight (the
-// PoseidonGate is an item by itself).  Fewer items = fewer output planes; more items = more blocks sharing one tile's columns in L2.
-// Returns false when the gate set does not fit the plan (more gates than FUSED_MAX_GATES, or two CosetInterpolationGates).
-static bool make_fused_plan(const vpbs_gate* gs, unsigned n_gates, unsigned max_items, FusedPlan& plan) {
-    std::vector<unsigned> order;
-    unsigned n_coset = 0, total = 0, heaviest = 1;
-    for (unsigned i = 0; i < n_gates; ++i) {
-        if (!gs[i].num_constraints) continue;
-        order.push_back(i);
-        total += gate_weight(gs[i]);
-        heaviest = std::max(heaviest, gate_weight(gs[i]));
-        if (gs[i].kind == VPBS_GATE_COSET_INTERPOLATION) {
-            if (n_coset++) return false;
-            plan.tables = gates::coset_tables(gs[i].p0);
-        }
-    }
-    if (order.empty() || order.size() > FUSED_MAX_GATES) return false;
-    const unsigned n_items = std::max(1u, std::min({(unsigned)order.size(), (total + heaviest - 1) / heaviest, max_items, FUSED_MAX_ITEMS}));
-    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return gate_weight(gs[a]) > gate_weight(gs[b]); });
-    std::vector<std::vector<unsigned>> bins(n_items);
-    std::vector<unsigned> load(n_items, 0);
-    for (unsigned i : order) {
-        const unsigned b = (unsigned)(std::min_element(load.begin(), load.end()) - load.begin());
-        bins[b].push_back(i);
-        load[b] += gate_weight(gs[i]);
-    }
-    unsigned k = 0;
-    for (unsigned b = 0; b < n_items; ++b) {
-        plan.item_first[b] = k;
-        for (unsigned i : bins[b]) plan.gates[k++] = gs[i];
-    }
-    plan.item_first[n_items] = k;
-    plan.n_items = n_items;
-    return true;
-}
-
 // Work units of the LDS-tile kernel: every gate with constraints, the PoseidonGate as three pieces, packed heaviest first into the eight
 // waves of a workgroup.  False when the gate set does not fit (too many gates, two CosetInterpolationGates, more constant columns than
 // the tile holds).
@@ -798,11 +696,10 @@ unsigned gate_terms_planes(const vpbs_gate* gs, unsigned n_gates, unsigned num_s
         TilePlan tp{};
         if (make_tile_plan(gs, n_gates, num_selectors, tp)) return 1;
     }
-    FusedPlan plan{};
-    return make_fused_plan(gs, n_gates, tune.gate_items, plan) ? plan.n_items : 0;
+    return 0;   // the gate set does not fit a tile plan: the caller takes the per-gate launches
 }
 
-// d_planes: [n_items][nc][len]; returns the number of planes written (0: the gate set does not fit the one-launch path, nothing launched)
+// d_planes: [1][nc][len]; returns the number of planes written (0: the gate set does not fit a tile plan or the tile kernel is switched off, nothing launched)
 unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gs,
                                  unsigned n_gates, unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc,
                                  u64* d_planes) {
@@ -817,10 +714,18 @@ unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* w
                 (void)hipMalloc(&prof, sizeof(unsigned long long) * TILE_MAX_UNITS);
                 (void)hipMemsetAsync(prof, 0, sizeof(unsigned long long) * TILE_MAX_UNITS, s);
             }
-            if (nc <= 2)
-                hipLaunchKernelGGL((gate_tile_kernel<2>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof);
-            else
-                hipLaunchKernelGGL((gate_tile_kernel<4>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof);
+            // NC = nc exactly: the branch-free sink accumulates NC sums per constraint whether they are read or not (one or three challenges
+            // under NC = 2 / 4 paid eight multiply-adds per constraint for a sum nobody reads: ADVICE r05).  nc = 0 never gets here (callers check).
+            if (nc < 1 || nc > 4) return 0;
+#define VPBS_TILE_LAUNCH(NC_) \
+    hipLaunchKernelGGL((gate_tile_kernel<NC_>), grid, block, 0, s, wires_lde, consts_lde, len, tp, num_selectors, d_apow, pow_stride, nc, pih, d_planes, prof)
+            switch (nc) {
+                case 1: VPBS_TILE_LAUNCH(1); break;
+                case 2: VPBS_TILE_LAUNCH(2); break;
+                case 3: VPBS_TILE_LAUNCH(3); break;
+                default: VPBS_TILE_LAUNCH(4); break;
+            }
+#undef VPBS_TILE_LAUNCH
             if (trace) {
                 unsigned long long h[TILE_MAX_UNITS];
                 (void)vpbs::stream_sync(s);
@@ -839,19 +744,7 @@ unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* w
             return 1;
         }
     }
-    const unsigned max_items = tune.gate_items;
-    FusedPlan plan{};
-    if (!make_fused_plan(gs, n_gates, max_items, plan)) return 0;
-    const unsigned n_tiles = (unsigned)((len + FUSED_TILE - 1) / FUSED_TILE);
-    const int xcd_map = n_tiles % 8 == 0;
-    const dim3 grid(n_tiles * plan.n_items);
-    if (nc <= 2)
-        hipLaunchKernelGGL((gate_fused_kernel<2>), grid, dim3(THREADS), 0, s, wires_lde, consts_lde, len, plan, num_selectors, d_apow, pow_stride, nc, pih,
-                           d_planes, xcd_map);
-    else
-        hipLaunchKernelGGL((gate_fused_kernel<4>), grid, dim3(THREADS), 0, s, wires_lde, consts_lde, len, plan, num_selectors, d_apow, pow_stride, nc, pih,
-                           d_planes, xcd_map);
-    return plan.n_items;
+    return 0;
 }
 
 void launch_sum_planes(hipStream_t s, const u64* d_planes, unsigned n_planes, size_t words, u64* d_out) {

@@ -77,7 +77,7 @@ struct Tuning {
     size_t fri_leaf_wide_threshold = (size_t)1 << 14;   // the same for the FRI round leaves (several dependent permutations per leaf)
     bool merkle_climb = true;                  // the latency-bound upper levels of a tree in fused multi-level launches
     bool gates_fused = true;                   // all gate constraints in one launch (false: one launch per gate type)
-    unsigned gate_items = 5;                   // work items per point tile of the (tile x item) one-launch gate kernel
+    unsigned gate_items = 5;                   // reserved (VPBS_OPT_GATE_ITEMS: the kernel it tuned was removed in round 6); kept so the option reads back
     bool gates_tile = true;                    // the one-launch gate kernel that stages a 64-point tile of every column in LDS
     static Tuning from_env();
 };
@@ -102,10 +102,10 @@ struct GateLanes {
 void launch_gate_terms(hipStream_t s, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                        unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_out,
                        GateLanes* lanes = nullptr);
-// The same sum in ONE launch over (point tile x work item) with an XCD-aware block numbering (gates.hip): every item writes its own plane
-// d_planes[item][nc][len]; the sum over the planes is the value launch_gate_terms would produce.  gate_terms_planes: how many planes the gate
-// set needs (0 = not supported by this path, use launch_gate_terms).
-// With tune.gates_tile (default) and len a multiple of 64: the LDS-tile kernel, one plane (gates.hip); otherwise the (tile x item) kernel.
+// The same sum in ONE launch, the LDS-tile kernel (gates.hip): a workgroup stages 64 points of every column in LDS and its eight waves share the
+// gates; it writes one plane d_planes[nc][len] = the value launch_gate_terms would produce.  gate_terms_planes: how many planes the gate set
+// needs -- 1, or 0 = not supported by this path (tune.gates_tile off, len not a multiple of 64, a gate set that fits no tile plan): use
+// launch_gate_terms.
 unsigned gate_terms_planes(const vpbs_gate* gates, unsigned n_gates, unsigned num_selectors, const Tuning& tune, size_t len);
 unsigned launch_gate_terms_fused(hipStream_t s, const Tuning& tune, const u64* wires_lde, const u64* consts_lde, size_t len, const vpbs_gate* gates, unsigned n_gates,
                                  unsigned num_selectors, const u64 pi_hash[4], const u64* d_apow, unsigned pow_stride, unsigned nc, u64* d_planes);

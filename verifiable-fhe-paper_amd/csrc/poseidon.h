@@ -80,14 +80,16 @@ GL_HD u64 fold96(u64 acc_lo, u64 acc_hi) {
     // no carry), then hi_lo joins T's high word; that carry selects the single +(2^32 - 1) correction (the wrapped value is below T, so the
     // corrected sum cannot wrap again).  5 VALU (round 5; 7 before: the sum L was formed first, with a carry into H and a move to pair it).
     u32 r0, r1;
-    asm("v_mad_u64_u32 v[80:81], vcc, %4, -1, %2\n\t"
-        "v_add_co_u32_e32 v81, vcc, v81, %3\n\t"
-        "v_cndmask_b32_e64 v86, 0, -1, vcc\n\t"
-        "v_add_co_u32_e32 %0, vcc, v80, v86\n\t"
-        "v_addc_co_u32_e64 %1, vcc, v81, 0, vcc"
+    // (scratch through gl.h's names: a translation unit built with GL_ASM_SCRATCH_LOW -- quotient.hip, permutation.hip -- keeps its register
+    // budget; with v80 / v81 / v86 spelled out here those kernels were pushed to 87 VGPRs whatever the setting: ADVICE r05)
+    asm("v_mad_u64_u32 " GL_P01 ", vcc, %4, -1, %2\n\t"
+        "v_add_co_u32_e32 " GL_R1 ", vcc, " GL_R1 ", %3\n\t"
+        "v_cndmask_b32_e64 " GL_R6 ", 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, " GL_R0 ", " GL_R6 "\n\t"
+        "v_addc_co_u32_e64 %1, vcc, " GL_R1 ", 0, vcc"
         : "=&v"(r0), "=&v"(r1)
         : "v"(acc_lo), "v"((u32)acc_hi), "v"((u32)(acc_hi >> 32))
-        : "v80", "v81", "v86", "vcc");
+        : GL_R0, GL_R1, GL_R6, "vcc");
     return ((u64)r1 << 32) | r0;
 #else
     const u64 L = acc_lo + (acc_hi << 32);

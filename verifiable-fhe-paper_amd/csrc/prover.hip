@@ -379,7 +379,7 @@ void gate_terms_device(vpbs_ctx* ctx, vpbs_batch* cs, vpbs_batch* wires, const v
     const size_t len = wires->lde_len();
     u64* lane_buf = nullptr;
     const unsigned n_planes = ctx->tune.gates_fused ? vpbs::gate_terms_planes(gs, n_gates, num_selectors, ctx->tune, len) : 0;
-    if (n_planes) {  // one launch over (tile x item), then the sum of the items' planes
+    if (n_planes) {  // one launch (the LDS-tile kernel: one plane)
         u64* planes = nullptr;
         try {
             planes = ctx->alloc_words((size_t)n_planes * nc * len);
@@ -870,6 +870,7 @@ static int prove_step_impl(vpbs_ctx* ctx, const vpbs_step_inputs* in, const vpbs
         const unsigned log_n = in->log_n, nc = in->num_challenges;
         const size_t n = (size_t)1 << log_n;
         VPBS_REQUIRE(in->constants_sigmas->log_n == log_n, "constants_sigmas degree mismatch");
+        VPBS_REQUIRE(nc >= 1 && nc <= 4, "num_challenges must be 1 .. 4");
         VPBS_REQUIRE(nc <= in->n_zs_partial_products, "num_challenges exceeds the Z/partial-product batch");
         const size_t cap_words = (size_t)4 << ctx->cap_height;
 

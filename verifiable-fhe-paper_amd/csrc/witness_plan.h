@@ -60,18 +60,27 @@ struct LevelPool {
     // Whoever was promised that (a witness state) holds a TOKEN, not the pool: a run that takes the pool in between invalidates it (the
     // workers are that run's now), so a state freed or advanced from another thread can never put the workers of somebody else's run to
     // sleep; and the state shares ownership of the pool, so a plan that is re-split or freed first leaves nothing dangling.
+    // Token and `active` change together under `m`: with the compare outside the lock a state could win it, a run could then
+    // take the pool, void the token and begin(), and the state's end() -- late -- would put that run's workers to sleep under its share().
     unsigned long keep_awake_token() {
         static std::atomic<unsigned long> next{1};
         const unsigned long t = next.fetch_add(1, std::memory_order_relaxed);
-        awake_token.store(t, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(m);
+        awake_token = t;
         return t;
     }
-    void taken_by_a_run() { awake_token.store(0, std::memory_order_release); }
-    void end_if_still_kept(unsigned long token) {
-        unsigned long t = token;
-        if (token && awake_token.compare_exchange_strong(t, 0, std::memory_order_acq_rel)) end();
+    void taken_by_a_run() {
+        std::lock_guard<std::mutex> lk(m);
+        awake_token = 0;
     }
-    std::atomic<unsigned long> awake_token{0};
+    void end_if_still_kept(unsigned long token) {
+        std::lock_guard<std::mutex> lk(m);
+        if (token && awake_token == token) {
+            awake_token = 0;
+            active.store(false, std::memory_order_release);
+        }
+    }
+    unsigned long awake_token = 0;   // guarded by m
     // every thread of the pool (the caller as number 0) runs job(t); returns when all have finished
     template <class Job> void share(Job&& j) {
         job = std::ref(j);
