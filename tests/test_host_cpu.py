@@ -326,12 +326,13 @@ def test_hash_chains_of_concurrent_callers_share_lanes_and_agree_with_the_oracle
 
 
 def test_recorded_bench_line_keeps_the_contract():
-    """profiles/r05_bench_latest.json is the line `python bench.py` printed on the GPU box: the keys the driver and the judge read.  The parsed
+    """profiles/r06_bench_detail_n1.json is the full result `python bench.py` wrote on the GPU box (since round 6 the DETAIL file; stdout carries the
+    compact record built from it, test_bench_line_is_a_compact_record): the keys the judge reads.  The
     headline is the IVC chain (chained step proofs through vpbs_ivc_prove_pbs); since round 4 the roofline object has the contract's form
     (bound hbm: algorithmic bytes per launch / launch duration / 8 TB/s, the PMC traffic and its source named) with the integer-issue pricing
     beside it, the whole step priced against HBM, and a sustained figure (whole chains) next to the burst."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_latest.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_bench_detail_n1.json")
     d = json.load(open(path))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):
@@ -350,8 +351,8 @@ def test_recorded_bench_line_keeps_the_contract():
     # round 5: the WHOLE step against the bound that holds it (wave-level VALU instructions per step by kernel / issue rate / measured time), and
     # what ran: ranks counted by the communication library, who started them, CPUs per rank, the pipeline chosen
     b = r["valu_budget"]
-    assert abs(sum(b["by_kernel_G"].values()) - b["wave_instructions_per_step_G"]) < 1e-6 and "r05_pmc_sq_kernels_shared_gpu.csv" in b["counters_from"]   # several chains per GPU: the counter pass with THEIR settings
-    assert "r05_pmc_sq_kernels.csv" in r["valu_budget_single_chain"]["counters_from"]
+    assert abs(sum(b["by_kernel_G"].values()) - b["wave_instructions_per_step_G"]) < 1e-6 and "r06_pmc_sq_kernels_shared_gpu.csv" in b["counters_from"]   # several chains per GPU: the counter pass with THEIR settings
+    assert "r06_pmc_sq_kernels.csv" in r["valu_budget_single_chain"]["counters_from"]
     assert b["wave_instructions_per_step_G"] < r["valu_budget_single_chain"]["wave_instructions_per_step_G"]
     assert abs(b["frac"] - b["instruction_time_ms_per_step"] / b["measured_ms_per_step_proof"]) < 1e-9 and 0.8 < b["frac"] < 1.05
     assert abs(b["measured_ms_per_step_proof"] - d["ms_per_step"] / chains) < 1e-6

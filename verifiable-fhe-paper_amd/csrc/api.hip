@@ -1157,8 +1157,13 @@ __global__ void __launch_bounds__(256) scatter_words_kernel(vpbs::u64* __restric
     if (i < count) dst[pos[i]] = val[i];
 }
 }  // namespace
-int vpbs_device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count,
-                        uint64_t* d_stage) {
+}  // extern "C"
+namespace vpbs {
+// the copy + scatter of vpbs_device_scatter QUEUED on the context's stream; wait = false returns at once: everything later on that stream
+// (the step proof) is ordered behind it, and the caller leaves host_values / d_stage alone until it has waited on the context for
+// something queued afterwards.  The IVC driver's form: with several chains per GPU the wait was 2-5 ms of standing in the device's queue
+// behind the other chains' kernels, on every chain's critical path, for a result nobody reads on the host.
+int device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count, uint64_t* d_stage, bool wait) {
     if (!c || !d_dst || !d_positions || !host_values || !d_stage) return VPBS_ERR_INVALID;
     if (count == 0) return VPBS_OK;
     return guarded(c, [&] {
@@ -1166,8 +1171,14 @@ int vpbs_device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_position
         hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d_dst,
                            reinterpret_cast<const uint32_t*>(d_positions), d_stage, count);
         VPBS_HIP(hipGetLastError());
-        VPBS_HIP(vpbs::stream_sync(c->stream));
+        if (wait) VPBS_HIP(vpbs::stream_sync(c->stream));
     });
+}
+}  // namespace vpbs
+extern "C" {
+int vpbs_device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count,
+                        uint64_t* d_stage) {
+    return vpbs::device_scatter(c, d_dst, d_positions, host_values, count, d_stage, true);
 }
 void vpbs_device_free(vpbs_ctx* c, uint64_t* d_ptr) {
     if (c && d_ptr) {

@@ -173,4 +173,6 @@ size_t merkle_layout(size_t n_leaves, unsigned cap_height, std::vector<size_t>& 
 vpbs_batch* commit_device(vpbs_ctx* ctx, const u64* d_in, unsigned ncols, unsigned log_n, bool is_values, unsigned shard = 0,
                           unsigned n_shards = 1);
 void batch_cap_to_host(vpbs_batch* b, u64* cap_out);
+// vpbs_device_scatter's copy + kernel on the context's stream; wait = false: queued only (api.hip)
+int device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count, uint64_t* d_stage, bool wait);
 }  // namespace vpbs

@@ -28,6 +28,12 @@
 
 #include "../../include/vpbs_prover.h"
 
+// The one thing this driver takes from the library beside the public header: vpbs_device_scatter's copy + kernel QUEUED on the context's
+// stream without the wait (api.hip).  A host that writes its own loop over the C ABI calls vpbs_device_scatter and pays the wait.
+namespace vpbs {
+int device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count, uint64_t* d_stage, bool wait);
+}
+
 namespace {
 using u64 = uint64_t;
 
@@ -749,7 +755,9 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             t = now();
             c_late += thread_cpu() - c0;
             c0 = thread_cpu();
-            rc = vpbs_device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
+            // queued, not waited for: the proof is ordered behind it on the context's stream, and the packed buffer is next written a whole
+            // proof (several waits on this stream) later -- by the late stages of the NEXT step, which start at this proof's first section
+            rc = vpbs::device_scatter(ctx, v->d_bufs[k], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage, false);
             if (rc != 0) return stop_step(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);
             t_rows += now() - t;
             c_rows += thread_cpu() - c0;
@@ -1035,7 +1043,7 @@ long vpbs_ivc_prove_pbs(vpbs_ivc* v, const uint64_t* testv, const uint64_t* ct, 
         }
         t_late += now() - t;
         t = now();
-        rc = vpbs_device_scatter(ctx, v->d_bufs[r.buf], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage);
+        rc = vpbs::device_scatter(ctx, v->d_bufs[r.buf], v->d_late_pos, v->late_vals, v->late_count, v->d_late_stage, false);   // queued ahead of the proof (see the device pipeline's loop)
         if (rc != 0) {
             abandon_step(rc);
             return stop(std::string("upload of the late wires: ") + vpbs_last_error(ctx), rc);

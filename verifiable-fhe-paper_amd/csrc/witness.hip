@@ -901,6 +901,26 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
                          P.order.size(), pos_rows, P.level_off.size() - 1, wide);
         }
     }
+    if (std::getenv("VPBS_TRACE_WITNESS") && p.dev_late.supported) {
+        // the late phase as the DEVICE walks it (wd_walk_kernel: one level at a time, a level costs its slowest share): PoseidonGate rows per level
+        const auto& ds = p.dev_late;
+        size_t rows = 0, rowops = 0, gt32 = 0, gt64 = 0, gt128 = 0, passes512 = 0, passes1024 = 0, passes4096 = 0, with_rowops = 0;
+        for (u32 l = 1; l <= ds.n_levels; ++l) {
+            const size_t c = ds.poseidon_off[l + 1] - ds.poseidon_off[l], ro = ds.rowops_off[l + 1] - ds.rowops_off[l];
+            rows += c;
+            rowops += ro;
+            with_rowops += ro != 0;
+            gt32 += c > 32;
+            gt64 += c > 64;
+            gt128 += c > 128;
+            passes512 += (c + 31) / 32;
+            passes1024 += (c + 63) / 64;
+            passes4096 += (c + 255) / 256;
+        }
+        std::fprintf(stderr, "[witness split] device late schedule: %u levels, %zu PoseidonGate rows (levels with > 32 / 64 / 128 rows: %zu / %zu / %zu; "
+                     "row passes with 512 / 1024 / 4096 threads: %zu / %zu / %zu), %zu row operations on %zu levels, %zu arithmetic, %zu bits, %zu misc\n",
+                     ds.n_levels, rows, gt32, gt64, gt128, passes512, passes1024, passes4096, rowops, with_rowops, ds.arith.size(), ds.bits.size(), ds.misc.size());
+    }
     p.is_split = true;
     return VPBS_OK;
 }
