@@ -1,9 +1,9 @@
 #!/bin/bash
-# Soak of the final round-5 kernels (residue arithmetic with rare wrap paths, radix-16 NTT, fused Poseidon groups): whole 730-step chains in the
+# Soak of the final kernels (round 5 wrote it; round 6 re-ran it after the spill / scalar-dispatch / queued-scatter changes) --  (residue arithmetic with rare wrap paths, radix-16 NTT, fused Poseidon groups): whole 730-step chains in the
 # arrangements a deployment uses, every chain's last proof verified by vpbs_verify_pbs and decrypted by the tool, completion-word waits counted
-# (VPBS_TRACE_SYNC).  One line per arrangement; the condensed record is profiles/r05_soak.json.
+# (VPBS_TRACE_SYNC).  One line per arrangement; the condensed record is profiles/rNN_soak.json.
 # usage (GPU box): tools/experiments/soak_chains.sh [out_dir]
-out=${1:-gpurun_out/soak_r05}; mkdir -p $out
+out=${1:-gpurun_out/soak}; mkdir -p $out
 run() { # name mask chains device_witness N log_degree
   local pre=""; [ -n "$2" ] && pre="taskset -c $2"
   VPBS_TRACE_SYNC=1 VPBS_IVC_CHAINS=$3 VPBS_IVC_DEVICE_WITNESS=$4 timeout -k 5 900 $pre python tools/prove_ivc.py ${5:-1024} 728 ${6:-16} 730 > $out/$1.json 2> $out/$1.err
