@@ -917,6 +917,19 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             passes1024 += (c + 63) / 64;
             passes4096 += (c + 255) / 256;
         }
+        {   // the row operations (one thread each in the walk) by gate kind: how many, on how many levels
+            std::map<unsigned, std::pair<size_t, size_t>> by_kind;
+            for (u32 l = 1; l <= ds.n_levels; ++l) {
+                std::map<unsigned, size_t> here;
+                for (u32 i = ds.rowops_off[l]; i < ds.rowops_off[l + 1]; ++i) ++here[p.gates[p.row_gate[ds.rowops[i].row]].kind];
+                for (auto& kv : here) {
+                    by_kind[kv.first].first += kv.second;
+                    ++by_kind[kv.first].second;
+                }
+            }
+            for (auto& kv : by_kind)
+                std::fprintf(stderr, "[witness split] device late schedule: gate kind %u: %zu row operations on %zu levels\n", kv.first, kv.second.first, kv.second.second);
+        }
         std::fprintf(stderr, "[witness split] device late schedule: %u levels, %zu PoseidonGate rows (levels with > 32 / 64 / 128 rows: %zu / %zu / %zu; "
                      "row passes with 512 / 1024 / 4096 threads: %zu / %zu / %zu), %zu row operations on %zu levels, %zu arithmetic, %zu bits, %zu misc\n",
                      ds.n_levels, rows, gt32, gt64, gt128, passes512, passes1024, passes4096, rowops, with_rowops, ds.arith.size(), ds.bits.size(), ds.misc.size());

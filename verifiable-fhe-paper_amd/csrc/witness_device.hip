@@ -24,12 +24,19 @@ struct Launch {
     __device__ u32 instance(size_t gid) const { return (first ? *first : 0u) + (u32)(gid % n); }
 };
 
-struct Vals {
+// PLAIN = false: volatile loads -- inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line).
+// PLAIN = true (the walk of the late phase): ordinary loads; everything a level reads was stored in an earlier level, and the barrier between
+// levels releases / acquires at device scope (the stores are out of the CU, the reader's L1 is invalidated).  The compiler may then request
+// the operands of a long generator (a ReducingGate's 43 coefficients, an interpolation's 16 points) together instead of one round trip each.
+template <bool PLAIN> struct ValsT {
     u64* v;
     unsigned* err;
     u32 batch, b;   // batch: the stride between slots
-    // volatile: inside the chain kernel a row reads what other lanes of the same group stored a moment ago (no stale L1 line)
-    __device__ u64 get(u32 slot) const { return *(volatile const u64*)(v + (size_t)(slot & ~Plan::CHECK) * batch + b); }
+    __device__ u64 get(u32 slot) const {
+        const u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
+        if constexpr (PLAIN) return *p;
+        else return *(volatile const u64*)p;
+    }
     __device__ void set(u32 slot, u64 x) const {
         if (x >= gl::P) x -= gl::P;
         u64* p = v + (size_t)(slot & ~Plan::CHECK) * batch + b;
@@ -43,6 +50,7 @@ struct Vals {
         }
     }
 };
+using Vals = ValsT<false>;
 
 // compare_pass 0: the presets that write their class; 1: the ones that find it written (a class preset twice: the cyclic circuit's own verifier
 // data and the tail of the inner proof's public inputs) and compare -- in a launch of their own, after the writers
@@ -63,7 +71,7 @@ __global__ void __launch_bounds__(WT) wd_const_kernel(u64* v, unsigned* err, con
     a.set(ops[gid / L.n].out, ops[gid / L.n].value);
 }
 
-__device__ __forceinline__ void do_arith(const Vals& a, const Plan::ArithOp& op) {
+template <class V> __device__ __forceinline__ void do_arith(const V& a, const Plan::ArithOp& op) {
     a.set(op.out, gl::add(gl::mul(gl::mul(a.get(op.x), a.get(op.y)), op.c0), gl::mul(a.get(op.z), op.c1)));
 }
 __global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, const Plan::ArithOp* ops, u32 n_ops, Launch L) {
@@ -72,7 +80,7 @@ __global__ void __launch_bounds__(WT) wd_arith_kernel(u64* v, unsigned* err, con
     do_arith(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n]);
 }
 
-__device__ __forceinline__ void do_bits(const Vals& a, const Plan::BitsOp& op, const u32* aux) {
+template <class V> __device__ __forceinline__ void do_bits(const V& a, const Plan::BitsOp& op, const u32* aux) {
     u64 x = a.get(op.in);
     const u64 mask = ((u64)1 << op.bits) - 1;
     for (u32 k = 0; k < op.n_out; ++k) {
@@ -88,8 +96,8 @@ __global__ void __launch_bounds__(WT) wd_bits_kernel(u64* v, unsigned* err, cons
 }
 
 // every gate generator without a special form: gen_run (the host's code) through the row's slot table, one thread per instance
-struct DevRow {
-    Vals a;
+template <class V> struct DevRow {
+    V a;
     const u32* rs;
     __device__ u64 get(unsigned w) const { return a.get(rs[w]); }
     __device__ void set(unsigned w, u64 x) const { a.set(rs[w], x); }
@@ -104,10 +112,10 @@ struct RowTables {
     u32 max_consts;
 };
 
-__device__ __forceinline__ void do_rowop(const Vals& a, const Plan::RowOp& op, const RowTables& t, const u32* row_slots) {
+template <class V> __device__ __forceinline__ void do_rowop(const V& a, const Plan::RowOp& op, const RowTables& t, const u32* row_slots) {
     const u32 gi = t.row_gate[op.row];
     const vpbs_gate g = t.gates[gi];
-    DevRow r{a, row_slots + t.row_off[op.row]};
+    DevRow<V> r{a, row_slots + t.row_off[op.row]};
     gen_run(g, op.sub, t.consts + (size_t)op.row * t.max_consts, r, g.kind == VPBS_GATE_COSET_INTERPOLATION ? t.coset + gi : nullptr);
 }
 __global__ void __launch_bounds__(64) wd_rowop_kernel(u64* v, unsigned* err, const Plan::RowOp* ops, RowTables t, const u32* row_slots, u32 n_ops,
@@ -125,7 +133,7 @@ __device__ __forceinline__ u64 shfl64(u64 x, unsigned src_lane) {
     return ((u64)hi << 32) | lo;
 }
 
-__device__ void poseidon_generate_wide(const Vals& a, const u32* rs) {
+template <class V> __device__ void poseidon_generate_wide(const V& a, const u32* rs) {
     const unsigned lane = threadIdx.x & 63u, l = lane & 15u, base = lane & ~15u;
     const bool own = l < 12;
     const unsigned lm = own ? l : 0;
@@ -194,7 +202,7 @@ __global__ void __launch_bounds__(64) wd_poseidon_chain_kernel(u64* v, unsigned*
     }
 }
 
-__device__ __forceinline__ void do_misc(const Vals& a, const Plan::MiscOp& op, const u32* aux) {
+template <class V> __device__ __forceinline__ void do_misc(const V& a, const Plan::MiscOp& op, const u32* aux) {
     unsigned* err = a.err;
     const u32 *in = aux + op.at, *out = in + op.n_in;
     switch (op.kind) {
@@ -239,29 +247,53 @@ __global__ void __launch_bounds__(WT) wd_misc_kernel(u64* v, unsigned* err, cons
     do_misc(Vals{v, err, L.stride, L.instance(gid)}, ops[gid / L.n], aux);
 }
 
-// A whole schedule walked by ONE workgroup, a barrier between levels: for the late phase of a single instance (~160 levels of a few
+// A whole schedule walked by a FEW workgroups, a barrier between levels: for the late phase of a single instance (~160 levels of a few
 // hundred operations each) the per-level launches of the batch form cost 6.9 ms of launch latency; here a level costs its slowest
-// operation.  The PoseidonGate rows of a level take 16 lanes each.  Everything goes through global memory: a workgroup's barrier orders it.
-constexpr unsigned WALK_THREADS = 512;
+// operation.  Round 4 walked it with ONE workgroup of 512 threads: 9.9 ms alone on the device (profiles/r06_few_cpus.json) -- 228 passes of 32
+// PoseidonGate rows in the 16-lane form (13 us each) and, on every level, ~55 row operations of ONE thread each whose operands came through
+// volatile loads one round trip at a time.  Now WALK_GROUPS workgroups share a level (256 PoseidonGate rows per pass: 138 passes), values are
+// read with ordinary loads, and the barrier is the walk's own: a counter in device memory that only grows (group g adds one per level and
+// waits for groups x level), release before / acquire after at device scope.  The groups need not start together -- an early one spins at its
+// first barrier until the last is placed (the other streams' kernels do not wait for the walk, so their workgroups retire and make room).
+constexpr unsigned WALK_THREADS = 512, WALK_GROUPS = 8;
 struct WalkOffsets {
     const u32 *arith, *bits, *poseidon, *misc, *rowops;   // [n_levels + 2] each
 };
+__device__ __forceinline__ void walk_barrier(unsigned* counter, unsigned groups, unsigned& round) {
+    __threadfence();      // this thread's stores are visible device-wide before its group arrives
+    __syncthreads();
+    ++round;
+    if (groups > 1) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < groups * round) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        __threadfence();  // acquire for every thread of the group: ordinary loads behind the barrier must not hit lines cached before it
+    }
+}
 __global__ void __launch_bounds__(WALK_THREADS) wd_walk_kernel(u64* v, unsigned* err, const Plan::ConstOp* consts, u32 n_consts, const Plan::ArithOp* arith,
                                                                 const Plan::BitsOp* bits, const u32* poseidon, const Plan::MiscOp* misc,
                                                                 const Plan::RowOp* rowops, const u32* aux, const u32* row_slots, WalkOffsets off,
-                                                                RowTables t, u32 n_levels, Launch L) {
-    const unsigned tid = threadIdx.x;
-    const Vals a{v, err, L.stride, L.instance(0)};   // L.n == 1
-    for (u32 i = tid; i < n_consts; i += WALK_THREADS) a.set(consts[i].out, consts[i].value);
-    __syncthreads();
+                                                                RowTables t, u32 n_levels, Launch L, unsigned* counter) {
+    // the walk is latency: a few waves whose every level waits for its slowest lane, on CUs they share with the other chains' hash kernels
+    // (four waves per SIMD that only want throughput).  Highest wave priority: the CU's arbiter issues the walk's instructions first.
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned groups = gridDim.x, threads = groups * WALK_THREADS, tid = blockIdx.x * WALK_THREADS + threadIdx.x;
+    unsigned round = 0;
+    const ValsT<true> a{v, err, L.stride, L.instance(0)};   // L.n == 1
+    for (u32 i = tid; i < n_consts; i += threads) a.set(consts[i].out, consts[i].value);
+    walk_barrier(counter, groups, round);
     for (u32 l = 1; l <= n_levels; ++l) {
-        for (u32 i = off.arith[l] + tid; i < off.arith[l + 1]; i += WALK_THREADS) do_arith(a, arith[i]);
-        for (u32 i = off.bits[l] + tid; i < off.bits[l + 1]; i += WALK_THREADS) do_bits(a, bits[i], aux);
-        for (u32 i = off.misc[l] + tid; i < off.misc[l + 1]; i += WALK_THREADS) do_misc(a, misc[i], aux);
-        for (u32 i = off.rowops[l] + tid; i < off.rowops[l + 1]; i += WALK_THREADS) do_rowop(a, rowops[i], t, row_slots);
-        for (u32 i = off.poseidon[l] + (tid >> 4); i < off.poseidon[l + 1]; i += WALK_THREADS / 16) poseidon_generate_wide(a, row_slots + poseidon[i]);
-        __threadfence_block();
-        __syncthreads();
+        // the PoseidonGate rows first in the thread numbering (16 lanes each, whole groups of 16 from thread 0 on), the one-thread operations
+        // from the LAST thread downwards: on a level that has both, the long single-thread generators do not queue behind a row in their wave
+        for (u32 i = off.poseidon[l] + (tid >> 4); i < off.poseidon[l + 1]; i += threads / 16) poseidon_generate_wide(a, row_slots + poseidon[i]);
+        const unsigned rt = threads - 1 - tid;
+        for (u32 i = off.rowops[l] + rt; i < off.rowops[l + 1]; i += threads) do_rowop(a, rowops[i], t, row_slots);
+        for (u32 i = off.arith[l] + rt; i < off.arith[l + 1]; i += threads) do_arith(a, arith[i]);
+        for (u32 i = off.bits[l] + rt; i < off.bits[l + 1]; i += threads) do_bits(a, bits[i], aux);
+        for (u32 i = off.misc[l] + rt; i < off.misc[l + 1]; i += threads) do_misc(a, misc[i], aux);
+        walk_barrier(counter, groups, round);
     }
 }
 
@@ -419,7 +451,7 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
         }
         d->val = ctx->alloc_words((plan->n_slots + 1) * (size_t)max_batch);   // + the scratch slot the other phase's presets are routed to
         d->owned.push_back(d->val);
-        d->err = static_cast<unsigned*>(ctx->alloc_bytes(2 * sizeof(unsigned)));   // flags, first conflicting slot + 1
+        d->err = static_cast<unsigned*>(ctx->alloc_bytes(4 * sizeof(unsigned)));   // flags, first conflicting slot + 1, the walk's barrier counter, spare
         d->owned.push_back(d->err);
         VPBS_HIP(vpbs::stream_sync(ctx->stream));
         *out = d.release();
@@ -479,7 +511,7 @@ void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const 
     vpbs_ctx* ctx = d->ctx;
     hipStream_t s = ctx->stream;
     const size_t n_preset = d->plan->preset_slot.size();
-    VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));
+    VPBS_HIP(hipMemsetAsync(d->err, 0, 4 * sizeof(unsigned), s));   // flags, first conflicting slot + 1, the walk's barrier counter, spare
     if (n_preset) {
         d_vals = ctx->alloc_words(n_preset * L.n);
         VPBS_HIP(hipMemcpyAsync(d_vals, preset_val, sizeof(u64) * n_preset * L.n, hipMemcpyHostToDevice, s));
@@ -487,10 +519,15 @@ void run_schedule(vpbs_witness_device* d, const Plan::DeviceSchedule& ds, const 
             hipLaunchKernelGGL(wd_preset_kernel, dim3((unsigned)((n_preset * L.n + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->err, k.preset_slot, d_vals,
                                (u32)n_preset, L, pass);
     }
-    if (walk) {   // one instance: one workgroup walks the levels
-        hipLaunchKernelGGL(wd_walk_kernel, dim3(1), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(), k.arith, k.bits, k.poseidon,
+    if (walk) {   // one instance: a few workgroups walk the levels (VPBS_WALK_GROUPS: 1 .. 32, default 8; a development switch)
+        static const unsigned groups = [] {
+            const char* e = std::getenv("VPBS_WALK_GROUPS");
+            const long g = e ? std::strtol(e, nullptr, 10) : (long)WALK_GROUPS;
+            return (unsigned)std::min(32l, std::max(1l, g));
+        }();
+        hipLaunchKernelGGL(wd_walk_kernel, dim3(groups), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(), k.arith, k.bits, k.poseidon,
                            k.misc, k.rowops, k.aux, k.row_slots, WalkOffsets{k.arith_off, k.bits_off, k.poseidon_off, k.misc_off, k.rowops_off}, d->tables,
-                           ds.n_levels, L);
+                           ds.n_levels, L, d->err + 2);
         VPBS_HIP(hipGetLastError());
     } else if (!graph || graph_key != key) {   // the level launches are a static sequence: captured once per batch size (stride), replayed afterwards
         if (graph) {
