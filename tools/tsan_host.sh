@@ -4,15 +4,20 @@
 # (the rest of the host code is single-threaded per context); device code is compiled without sanitizer.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-OUT=/tmp/vpbs_tsan; mkdir -p $OUT; rm -f $OUT/report.*   # reports of earlier runs are not this run's
+OUT=/tmp/vpbs_tsan; mkdir -p $OUT; rm -f $OUT/report.* $OUT/*.o   # reports and objects of earlier runs are not this run's
+pids=""
 cd "$ROOT/verifiable-fhe-paper_amd/csrc"
 for f in ntt hash fri permutation quotient gates witness_device tfhe keygen comm_rccl prover verifier ivc; do
-  /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
+  # -O3 as in the product build: the Poseidon row blocks take wave-uniform constants as "s" operands, which only the optimised build proves
+  # uniform (at -O1 witness_device.hip does not assemble -- rounds 5's runs linked a stale object without noticing; set -e now sees it)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
+  pids="$pids $!"
 done
 for f in witness api; do   # api.hip: the hash-chain links that concurrent callers share (hash_links_shared), the completion words' table
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=thread -Wno-unused-function -Wno-pass-failed -c $f.hip -o $OUT/$f.o &
+  pids="$pids $!"
 done
-wait
+for p in $pids; do wait $p; done   # a failed compile ends the run (plain `wait` returns 0 whatever the jobs did)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -o $OUT/libvpbs_hip.so $OUT/*.o
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.tsan-x86_64.so" | head -1)
 cp "$ROOT/verifiable-fhe-paper_amd/libvpbs_hip.so" $OUT/real.so
