@@ -1231,7 +1231,9 @@ def main():
                          "(vpbs_ivc_set_device_witness; the host keeps the late phase); 0 = host pipeline; -1 (default) = auto: on the device "
                          "where this rank's CPU share is too small to carry the host pipeline")
     ap.add_argument("--device-late", action="store_true", default=os.environ.get("VPBS_BENCH_DEVICE_LATE", "") not in ("", "0"),
-                    help="with --device-witness: the late witness phase on the device too (the host generates no witness)")
+                    help="with --device-witness: the late witness phase on the device too (the host generates no witness).  Automatic where this "
+                         "rank has ONE CPU (measured with round 6's staged walk: 1 CPU 0.164 against 0.127 with the late phase on the host; 2 and 4 "
+                         "CPUs equal, 0.173-0.175 / 0.185; from 12 CPUs on the host pipeline is faster); VPBS_BENCH_DEVICE_LATE=0 keeps it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-micro", action="store_true", help="ivc workload: skip the synthetic step legs (step_micro, its batch, the parity check at full size)")
     ap.add_argument("--no-single-chain", action="store_true", help="ivc workload: skip the one-chain latency measurement")
@@ -1325,6 +1327,8 @@ def main():
         chains_why = "auto"
     else:
         chains_why = "--chains / VPBS_BENCH_CHAINS"
+    if args.device_witness and cpus < 2 and os.environ.get("VPBS_BENCH_DEVICE_LATE", "") != "0":
+        args.device_late = True
     launch["cpus_per_rank"] = cpus
     launch["pipeline"] = {
         "early_witness_phase": "device, %d steps per batch" % args.device_witness if args.device_witness else "host (a second thread per chain)",

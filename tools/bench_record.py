@@ -64,7 +64,8 @@ def compact_record(d):
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload_id(d), "chains_per_gpu": cfg.get("chains_per_gpu"),
                    "parallelism": mode.split(":")[0] if mode else None,
-                   "witness": "device" if str(cfg.get("early_witness_phase", "")).startswith(("on the device", "device")) else "host"},
+                   "witness": ("device+late" if "late phase there as well" in str(cfg.get("early_witness_phase", "")) else "device")
+                              if str(cfg.get("early_witness_phase", "")).startswith(("on the device", "device")) else "host"},
         "roofline": {"bound": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" ")[0] or None,
                      "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")), "unit": r.get("unit"), "frac": _num(r.get("frac")),
                      "traffic": _num(r.get("traffic"), 9),

@@ -32,6 +32,9 @@
 // stream without the wait (api.hip).  A host that writes its own loop over the C ABI calls vpbs_device_scatter and pays the wait.
 namespace vpbs {
 int device_scatter(vpbs_ctx* c, uint64_t* d_dst, const uint64_t* d_positions, const uint64_t* host_values, size_t count, uint64_t* d_stage, bool wait);
+// ... and the late witness phase on the device stage by stage (witness_device.hip): queued as the previous proof's sections become final
+unsigned witness_device_late_stages(const vpbs_witness_device* d);
+int witness_device_run_late_stage(vpbs_witness_device* d, unsigned instance, unsigned stage, const uint64_t* preset_val, int wait);
 }
 
 namespace {
@@ -696,6 +699,31 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             h->ahead->post((unsigned)sec);
         }
     } hook{&ahead, &mu, &staged, &states, &next_state, values.data()};
+    // The same idea with the late phase on the DEVICE (round 6): the stages of the next step's late phase are queued on its witness object's
+    // stream as the sections of the proof in progress become final (the prover writes them straight into `values`); when the proof returns only
+    // the last stage -- the query rounds: 33 of the 162 dependency levels -- is left to queue and wait for.
+    struct DevHook {
+        vpbs_ivc* v;
+        std::mutex* mu;
+        const unsigned* batches_run;
+        unsigned B;
+        const u64* values;
+        unsigned step = 0, queued = 0;   // the step being proven; stages of step + 1 queued so far
+        static void section(void* user, int sec) {
+            auto* h = static_cast<DevHook*>(user);
+            const unsigned next = h->step + 1;
+            {
+                std::lock_guard<std::mutex> lk(*h->mu);
+                if (*h->batches_run <= next / h->B) return;   // the next step's early batch has not run yet: its late phase runs whole, after the proof
+            }
+            vpbs_witness_device* dev = h->v->wdev[(next / h->B) & 1];
+            const unsigned n = vpbs::witness_device_late_stages(dev);
+            while (h->queued < (unsigned)sec && h->queued + 1 < n) {   // the last stage waits for the return
+                if (vpbs::witness_device_run_late_stage(dev, next % h->B, h->queued + 1, h->values, 0) != 0) return;   // run_late reports it
+                ++h->queued;
+            }
+        }
+    } dev_hook{v, &mu, &batches_run, B, values.data()};
     // a rank of a SHARDED chain that cannot start a step's proof takes part in the step's collectives on the failing side (see the host pipeline)
     auto stop_step = [&](const std::string& m, int why) {
         if (cyc.comm) {
@@ -769,6 +797,13 @@ static long prove_pbs_device_witness(vpbs_ivc* v, const uint64_t* testv, const u
             hook.step = s;
             in.on_section = &Hook::section;
             in.on_section_user = &hook;
+        }
+        static const bool dev_ahead = !std::getenv("VPBS_DEVICE_LATE_AHEAD") || std::atoi(std::getenv("VPBS_DEVICE_LATE_AHEAD")) != 0;   // A-B switch
+        if (v->staged && v->dw_late && dev_ahead && s + 1 < steps) {
+            dev_hook.step = s;
+            dev_hook.queued = 0;
+            in.on_section = &DevHook::section;
+            in.on_section_user = &dev_hook;
         }
         rc = cyc.prove(in, caps, openings, fri);
         if (rc != 0) {

@@ -876,6 +876,34 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
         for (size_t i = 0; i < early_preset.size(); ++i) early_preset[i] = !p.preset_late[i];
         for (size_t sl = 0; sl < p.n_slots; ++sl) early_known[sl] = !taint[sl];
         build_device_schedule(p, p.dev_late, p.step_out, p.step_out_w, p.step_out_off, early_step.data(), early_preset.data(), early_known.data());
+        // ... and stage by stage: stage k over what the early phase and the stages before it have set (the slots the stages REALLY write,
+        // in stage order -- a class two stages write is written by the first to run and compared by the other, whatever the schedule order)
+        p.dev_late_stage.clear();
+        p.late_row_slots.clear();
+        if (n_stages > 1 && p.dev_late.supported) {
+            std::vector<uint8_t> known(early_known), skip_step(p.schedule.size()), skip_preset(p.preset_slot.size());
+            p.dev_late_stage.assign(n_stages, {});
+            p.late_row_slots = p.row_slots;
+            for (unsigned k = 1; k <= n_stages; ++k) {
+                for (size_t i = 0; i < skip_step.size(); ++i) skip_step[i] = !(p.step_late[i] && p.step_stage[i] == k);
+                for (size_t i = 0; i < skip_preset.size(); ++i) skip_preset[i] = p.preset_late[i] != k;
+                auto& ds = p.dev_late_stage[k - 1];
+                build_device_schedule(p, ds, p.step_out, p.step_out_w, p.step_out_off, skip_step.data(), skip_preset.data(), known.data());
+                if (!ds.supported) {
+                    p.dev_late_stage.clear();
+                    p.late_row_slots.clear();
+                    break;
+                }
+                for (size_t j = 0; j < ds.row_slots.size(); ++j)
+                    if (ds.row_slots[j] != p.row_slots[j]) p.late_row_slots[j] = ds.row_slots[j];
+                std::vector<u32>().swap(ds.row_slots);   // the shared table stands for it
+                for (size_t i = 0; i < skip_preset.size(); ++i)
+                    if (!skip_preset[i]) known[p.preset_slot[i]] = 1;
+                for (size_t i = 0; i < skip_step.size(); ++i)
+                    if (!skip_step[i])
+                        for (u32 o = p.step_out_off[i]; o < p.step_out_off[i + 1]; ++o) known[p.step_out[o]] = 1;
+            }
+        }
     }
     if (std::getenv("VPBS_TRACE_WITNESS")) {
         std::vector<uint8_t> row_late(p.n, 0);
@@ -916,6 +944,16 @@ int plan_split(vpbs_witness_plan* pp, const uint8_t* late, std::string& err) {
             passes512 += (c + 31) / 32;
             passes1024 += (c + 63) / 64;
             passes4096 += (c + 255) / 256;
+        }
+        for (size_t k = 0; k < p.dev_late_stage.size(); ++k) {
+            const auto& sd = p.dev_late_stage[k];
+            size_t widest = 0;
+            for (u32 l = 1; l <= sd.n_levels; ++l)
+                widest = std::max<size_t>(widest, (sd.poseidon_off[l + 1] - sd.poseidon_off[l]) + (sd.arith_off[l + 1] - sd.arith_off[l]) +
+                                                      (sd.rowops_off[l + 1] - sd.rowops_off[l]) + (sd.misc_off[l + 1] - sd.misc_off[l]) + (sd.bits_off[l + 1] - sd.bits_off[l]));
+            std::fprintf(stderr, "[witness split] device late stage %zu: %u levels, %zu PoseidonGate rows, %zu row operations, %zu arithmetic, %zu bits, %zu misc, "
+                         "%zu constants; widest level %zu operations\n", k + 1, sd.n_levels, sd.poseidon.size(), sd.rowops.size(), sd.arith.size(), sd.bits.size(),
+                         sd.misc.size(), sd.consts.size(), widest);
         }
         {   // the row operations (one thread each in the walk) by gate kind: how many, on how many levels
             std::map<unsigned, std::pair<size_t, size_t>> by_kind;

@@ -1,5 +1,7 @@
 // Witness generation on the device for a batch of PartialWitnesses of one circuit (vpbs_witness_device_*): the level schedule a compiled
 // plan carries (witness_plan.h, built by witness.hip) replayed on the GPU with the generators of witness_gen.h.  SURVEY.md 8f-2.
+#include <cstring>
+
 #include "witness_plan.h"
 
 // ---- device witness generation: one circuit, a batch of PartialWitnesses -----------------------------------------------------------
@@ -260,6 +262,11 @@ struct WalkOffsets {
     const u32 *arith, *bits, *poseidon, *misc, *rowops;   // [n_levels + 2] each
 };
 __device__ __forceinline__ void walk_barrier(unsigned* counter, unsigned groups, unsigned& round) {
+    if (groups == 1) {    // one workgroup = one CU: its L1 serves every wave of it, the stores only have to be done before the barrier releases
+        __threadfence_block();
+        __syncthreads();
+        return;
+    }
     __threadfence();      // this thread's stores are visible device-wide before its group arrives
     __syncthreads();
     ++round;
@@ -345,6 +352,15 @@ struct vpbs_witness_device {
     bool has_late = false;
     vpbs::DevSched k_late;
     vpbs::u32* d_instance = nullptr;   // which instance the late graph works on (read by its kernels)
+    // the late phase stage by stage (plan->dev_late_stage): one schedule per stage over a shared row-slot table, the stage's presets as runs of
+    // preset indices (only those words are uploaded), the values buffer the preset kernels read, and per instance how many stages are queued
+    std::vector<vpbs::DevSched> k_stage;
+    std::vector<std::vector<std::pair<vpbs::u32, vpbs::u32>>> stage_runs;   // [stage][(first preset index, count)]
+    std::vector<unsigned> stage_groups;                                     // workgroups of the stage's walk
+    vpbs::u64* d_stage_vals = nullptr;                                      // [n_preset]
+    vpbs::u64* h_stage_vals = nullptr;                                      // [n_preset] pinned: a stage's words pass through it, so that queuing
+                                                                            // a stage never waits for the stream (a copy from pageable memory may)
+    std::vector<unsigned> stages_queued;                                    // [max_batch]
     hipGraphExec_t late_graph = nullptr;
     unsigned late_graph_stride = 0;
     unsigned max_batch = 0, batch = 0;
@@ -438,6 +454,31 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
                 d->d_instance = static_cast<u32*>(ctx->alloc_bytes(sizeof(u32)));
                 d->owned.push_back(d->d_instance);
                 d->has_late = true;
+                if (!plan->dev_late_stage.empty()) {
+                    const u32* shared = upload(ctx, plan->late_row_slots, d->owned);
+                    for (size_t k = 0; k < plan->dev_late_stage.size(); ++k) {
+                        const auto& sd = plan->dev_late_stage[k];
+                        DevSched ks = upload_schedule(ctx, sd, d->owned);
+                        ks.row_slots = shared;
+                        d->k_stage.push_back(ks);
+                        std::vector<std::pair<u32, u32>> runs;
+                        for (u32 i : plan->stage_presets[k]) {
+                            if (!runs.empty() && runs.back().first + runs.back().second == i) ++runs.back().second;
+                            else runs.push_back({i, 1u});
+                        }
+                        d->stage_runs.push_back(std::move(runs));
+                        // a thin stage (the transcript's chain: a handful of operations on each of its levels) is walked by ONE workgroup --
+                        // its levels then cost a workgroup barrier, not the device-wide one; a stage with wide levels by all of them
+                        // (by the AVERAGE lanes a level wants: stage 1 of the cyclic circuit has one level of a thousand operations among 162
+                        // that want fifty -- measured alone on the device, eight workgroups 3.37 ms, one workgroup with block-scope fences less)
+                        const size_t lanes = 16 * sd.poseidon.size() + sd.arith.size() + sd.rowops.size() + sd.misc.size() + sd.bits.size();
+                        d->stage_groups.push_back(sd.n_levels && lanes / sd.n_levels > 2 * WALK_THREADS ? WALK_GROUPS : 1u);
+                    }
+                    d->d_stage_vals = ctx->alloc_words(std::max<size_t>(1, plan->preset_slot.size()));
+                    d->owned.push_back(d->d_stage_vals);
+                    VPBS_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_stage_vals), sizeof(u64) * (plan->preset_slot.size() + 1), hipHostMallocDefault));   // + one word: the instance number on its way to the device
+                    d->stages_queued.assign(max_batch, 0);
+                }
             }
         }
         d->out_pos = upload(ctx, plan->out_pos, d->owned);
@@ -475,6 +516,7 @@ void vpbs_witness_device_free(vpbs_witness_device* d) {
     (void)vpbs::stream_sync(d->ctx->stream);
     if (d->graph) (void)hipGraphExecDestroy(d->graph);
     if (d->late_graph) (void)hipGraphExecDestroy(d->late_graph);
+    if (d->h_stage_vals) (void)hipHostFree(d->h_stage_vals);
     for (void* p : d->owned) d->ctx->release(p);
     delete d;
 }
@@ -582,9 +624,78 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
 
 int vpbs_witness_device_has_late(const vpbs_witness_device* d) { return d && d->has_late ? 1 : 0; }
 
+}  // extern "C"
+// The late phase of one instance STAGE BY STAGE (library-internal: the IVC driver's form; the C ABI's vpbs_witness_device_run_late runs the
+// stages back to back).  Stage numbers as in vpbs_witness_plan_split; a stage may be queued as soon as its presets -- that section of the
+// previous proof -- are final in preset_val: only those words are uploaded, the stage's presets are put in place and its levels walked, all on
+// the object's stream, and with wait = 0 the call returns at once (~20 us of enqueues).  Stages must be queued in order; the call for the LAST
+// stage (or any call with wait != 0) waits for everything queued and reports what the generators found.
+namespace vpbs {
+unsigned witness_device_late_stages(const vpbs_witness_device* d) { return d && d->has_late ? (unsigned)d->k_stage.size() : 0; }
+int witness_device_run_late_stage(vpbs_witness_device* d, unsigned instance, unsigned stage, const uint64_t* preset_val, int wait) {
+    if (!d || !d->has_late || d->k_stage.empty() || !preset_val || stage < 1 || stage > d->k_stage.size()) return VPBS_ERR_INVALID;
+    vpbs_ctx* ctx = d->ctx;
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (instance >= d->batch || d->stages_queued[instance] != stage - 1) return VPBS_ERR_INVALID;
+    try {
+        VPBS_HIP(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const DevSched& k = d->k_stage[stage - 1];
+        const Plan::DeviceSchedule& ds = d->plan->dev_late_stage[stage - 1];
+        const Launch L{d->batch, 1, d->d_instance};
+        if (stage == 1) {
+            u32* inst = reinterpret_cast<u32*>(d->h_stage_vals + d->plan->preset_slot.size());
+            *inst = instance;
+            VPBS_HIP(hipMemcpyAsync(d->d_instance, inst, sizeof(u32), hipMemcpyHostToDevice, s));
+            VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));   // the flags of the whole late phase
+        }
+        VPBS_HIP(hipMemsetAsync(d->err + 2, 0, 2 * sizeof(unsigned), s));   // the walk's barrier counter
+        for (const auto& run : d->stage_runs[stage - 1]) {
+            std::memcpy(d->h_stage_vals + run.first, preset_val + run.first, sizeof(u64) * run.second);
+            VPBS_HIP(hipMemcpyAsync(d->d_stage_vals + run.first, d->h_stage_vals + run.first, sizeof(u64) * run.second, hipMemcpyHostToDevice, s));
+            for (u32 pass = 0; pass < (k.preset_compares ? 2u : 1u); ++pass)
+                hipLaunchKernelGGL(wd_preset_kernel, dim3((run.second + WT - 1) / WT), dim3(WT), 0, s, d->val, d->err, k.preset_slot + run.first,
+                                   d->d_stage_vals + run.first, run.second, L, pass);
+        }
+        if (ds.n_levels || !ds.consts.empty())
+            hipLaunchKernelGGL(wd_walk_kernel, dim3(d->stage_groups[stage - 1]), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(),
+                               k.arith, k.bits, k.poseidon, k.misc, k.rowops, k.aux, k.row_slots,
+                               WalkOffsets{k.arith_off, k.bits_off, k.poseidon_off, k.misc_off, k.rowops_off}, d->tables, ds.n_levels, L, d->err + 2);
+        VPBS_HIP(hipGetLastError());
+        d->stages_queued[instance] = stage;
+        if (wait || stage == d->k_stage.size()) {
+            d->stages_queued[instance] = 0;
+            unsigned report[2] = {0, 0};
+            VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
+            VPBS_HIP(vpbs::stream_sync(s));
+            throw_on_flags(d, report);
+        }
+        return VPBS_OK;
+    } catch (const vpbs::DeviceError& e) {
+        d->stages_queued[instance] = 0;
+        (void)vpbs::stream_sync(ctx->stream);
+        ctx->err = e.what;
+        return e.status;
+    }
+}
+}  // namespace vpbs
+extern "C" {
+
 int vpbs_witness_device_run_late(vpbs_witness_device* d, unsigned instance, const uint64_t* preset_val) {
     if (!d || !d->has_late || !preset_val) return VPBS_ERR_INVALID;
     vpbs_ctx* ctx = d->ctx;
+    static const bool whole = std::getenv("VPBS_DEVICE_LATE_WHOLE") != nullptr;   // A-B: the late phase as ONE schedule (round 4's form)
+    if (!d->k_stage.empty() && !whole) {   // a staged plan: the stages back to back (those already queued for this instance are not repeated)
+        unsigned first;
+        {
+            std::lock_guard<std::mutex> lock(d->mu);
+            if (instance >= d->batch) return VPBS_ERR_INVALID;
+            first = d->stages_queued[instance] + 1;
+        }
+        int rc = VPBS_OK;
+        for (unsigned st = first; st <= d->k_stage.size() && rc == VPBS_OK; ++st) rc = vpbs::witness_device_run_late_stage(d, instance, st, preset_val, 0);
+        return rc;
+    }
     std::lock_guard<std::mutex> lock(d->mu);
     if (instance >= d->batch) return VPBS_ERR_INVALID;
     vpbs::u64* d_vals = nullptr;

@@ -333,6 +333,12 @@ struct vpbs_witness_plan {
     // ... and the LATE phase alone: the late steps over a value array in which the early phase's results already sit (the early-known
     // classes count as set: a late step that writes one compares), early presets routed to the scratch slot
     DeviceSchedule dev_late;
+    // ... and that late phase STAGE BY STAGE (a split with stage numbers): dev_late_stage[k - 1] holds the steps and presets of stage k over
+    // a value array in which the early phase and the stages before it have left their results, so that a host can queue a stage's walk
+    // as soon as that section of the previous proof is final -- what the host's own late phase does (LateAhead in ivc.hip).  Their
+    // row-slot tables are one shared array (late_row_slots: the plan's with every stage's CHECK marks; a wire is written by one step).
+    std::vector<DeviceSchedule> dev_late_stage;
+    std::vector<u32> late_row_slots;
     std::vector<u32> late_in_slots;
     // runs [first, first + count) of consecutive value slots that only the late phase writes: a fresh state's pages under them are touched
     // by whoever creates the state (the early thread, the stager) instead of faulting in one by one on the critical path of the late phase
