@@ -609,6 +609,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
         d->batch = batch;
+        std::fill(d->stages_queued.begin(), d->stages_queued.end(), 0u);   // a new batch: no instance has late stages in flight (a chain that gave up may have left some)
         VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, ctx->stream));
         run_schedule(d, *d->ds, d->k, d->graph, d->graph_batch, batch, Launch{batch, batch, nullptr}, preset_val, d_vals);
         return VPBS_OK;
@@ -653,18 +654,19 @@ int witness_device_run_late_stage(vpbs_witness_device* d, unsigned instance, uns
         for (const auto& run : d->stage_runs[stage - 1]) {
             std::memcpy(d->h_stage_vals + run.first, preset_val + run.first, sizeof(u64) * run.second);
             VPBS_HIP(hipMemcpyAsync(d->d_stage_vals + run.first, d->h_stage_vals + run.first, sizeof(u64) * run.second, hipMemcpyHostToDevice, s));
-            for (u32 pass = 0; pass < (k.preset_compares ? 2u : 1u); ++pass)
+        }
+        for (u32 pass = 0; pass < (k.preset_compares ? 2u : 1u); ++pass)   // every writer of the stage before the first comparer, whichever run holds it
+            for (const auto& run : d->stage_runs[stage - 1])
                 hipLaunchKernelGGL(wd_preset_kernel, dim3((run.second + WT - 1) / WT), dim3(WT), 0, s, d->val, d->err, k.preset_slot + run.first,
                                    d->d_stage_vals + run.first, run.second, L, pass);
-        }
         if (ds.n_levels || !ds.consts.empty())
             hipLaunchKernelGGL(wd_walk_kernel, dim3(d->stage_groups[stage - 1]), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(),
                                k.arith, k.bits, k.poseidon, k.misc, k.rowops, k.aux, k.row_slots,
                                WalkOffsets{k.arith_off, k.bits_off, k.poseidon_off, k.misc_off, k.rowops_off}, d->tables, ds.n_levels, L, d->err + 2);
         VPBS_HIP(hipGetLastError());
-        d->stages_queued[instance] = stage;
-        if (wait || stage == d->k_stage.size()) {
-            d->stages_queued[instance] = 0;
+        const bool last = stage == d->k_stage.size();
+        d->stages_queued[instance] = last ? 0 : stage;
+        if (wait || last) {
             unsigned report[2] = {0, 0};
             VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
             VPBS_HIP(vpbs::stream_sync(s));
