@@ -304,6 +304,18 @@ __global__ void __launch_bounds__(WALK_THREADS) wd_walk_kernel(u64* v, unsigned*
     }
 }
 
+// one instance's column of the batch's value array as an array of its own (and the slots only the late phase writes, back): the batch layout
+// val[slot][instance] makes every access of a single-instance walk a line of its own (stride = the batch); the staged late phase therefore
+// works on a compact copy -- a PoseidonGate row's 110 private wires are then 880 consecutive bytes -- and the wires are gathered from it
+__global__ void __launch_bounds__(WT) wd_column_kernel(const u64* __restrict__ v, u32 batch, u32 b, size_t n, u64* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (i < n) out[i] = v[i * batch + b];
+}
+__global__ void __launch_bounds__(WT) wd_column_back_kernel(u64* __restrict__ v, u32 batch, u32 b, const u32* __restrict__ slots, size_t n, const u64* __restrict__ one) {
+    const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
+    if (i < n) v[(size_t)slots[i] * batch + b] = one[slots[i]];
+}
+
 // wires[pos] = val[slot][b] for every position that carries a slot (the matrix is zeroed first)
 __global__ void __launch_bounds__(WT) wd_gather_kernel(const u64* v, const u32* pos, const u32* slot, size_t count, u32 batch, u32 b, u64* wires) {
     const size_t i = blockIdx.x * (size_t)WT + threadIdx.x;
@@ -361,6 +373,10 @@ struct vpbs_witness_device {
     vpbs::u64* h_stage_vals = nullptr;                                      // [n_preset] pinned: a stage's words pass through it, so that queuing
                                                                             // a stage never waits for the stream (a copy from pageable memory may)
     std::vector<unsigned> stages_queued;                                    // [max_batch]
+    vpbs::u64* val_one = nullptr;                                           // [n_slots + 1]: the compact copy the staged late phase works on
+    int one_instance = -1;                                                  // whose column it holds (-1: nobody's)
+    const vpbs::u32* d_late_slots = nullptr;                                // the slots only the late phase writes (copied back after the last stage)
+    size_t n_late_slots = 0;
     hipGraphExec_t late_graph = nullptr;
     unsigned late_graph_stride = 0;
     unsigned max_batch = 0, batch = 0;
@@ -478,6 +494,13 @@ static int device_create(vpbs_ctx* ctx, const vpbs_witness_plan* plan, unsigned 
                     d->owned.push_back(d->d_stage_vals);
                     VPBS_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_stage_vals), sizeof(u64) * (plan->preset_slot.size() + 1), hipHostMallocDefault));   // + one word: the instance number on its way to the device
                     d->stages_queued.assign(max_batch, 0);
+                    d->val_one = ctx->alloc_words(plan->n_slots + 1);
+                    d->owned.push_back(d->val_one);
+                    std::vector<u32> late_slots;
+                    for (const auto& run : plan->late_slot_runs)
+                        for (u32 i = 0; i < run.second; ++i) late_slots.push_back(run.first + i);
+                    d->n_late_slots = late_slots.size();
+                    d->d_late_slots = upload(ctx, late_slots, d->owned);
                 }
             }
         }
@@ -609,6 +632,7 @@ int vpbs_witness_device_run(vpbs_witness_device* d, const uint64_t* preset_val, 
         using namespace vpbs;
         VPBS_HIP(hipSetDevice(ctx->device));
         d->batch = batch;
+        d->one_instance = -1;
         std::fill(d->stages_queued.begin(), d->stages_queued.end(), 0u);   // a new batch: no instance has late stages in flight (a chain that gave up may have left some)
         VPBS_HIP(hipMemsetAsync(d->val, 0, sizeof(u64) * (d->plan->n_slots + 1) * batch, ctx->stream));
         run_schedule(d, *d->ds, d->k, d->graph, d->graph_batch, batch, Launch{batch, batch, nullptr}, preset_val, d_vals);
@@ -643,13 +667,14 @@ int witness_device_run_late_stage(vpbs_witness_device* d, unsigned instance, uns
         hipStream_t s = ctx->stream;
         const DevSched& k = d->k_stage[stage - 1];
         const Plan::DeviceSchedule& ds = d->plan->dev_late_stage[stage - 1];
-        const Launch L{d->batch, 1, d->d_instance};
+        const Launch L{1, 1, nullptr};   // the compact copy: stride 1, instance 0
+        const size_t n_val = d->plan->n_slots + 1;
         if (stage == 1) {
-            u32* inst = reinterpret_cast<u32*>(d->h_stage_vals + d->plan->preset_slot.size());
-            *inst = instance;
-            VPBS_HIP(hipMemcpyAsync(d->d_instance, inst, sizeof(u32), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(wd_column_kernel, dim3((unsigned)((n_val + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->batch, instance, n_val, d->val_one);
+            d->one_instance = (int)instance;
             VPBS_HIP(hipMemsetAsync(d->err, 0, 2 * sizeof(unsigned), s));   // the flags of the whole late phase
         }
+        if (d->one_instance != (int)instance) throw DeviceError{VPBS_ERR_INVALID, "late stages of two instances interleaved on one device witness object"};
         VPBS_HIP(hipMemsetAsync(d->err + 2, 0, 2 * sizeof(unsigned), s));   // the walk's barrier counter
         for (const auto& run : d->stage_runs[stage - 1]) {
             std::memcpy(d->h_stage_vals + run.first, preset_val + run.first, sizeof(u64) * run.second);
@@ -657,15 +682,18 @@ int witness_device_run_late_stage(vpbs_witness_device* d, unsigned instance, uns
         }
         for (u32 pass = 0; pass < (k.preset_compares ? 2u : 1u); ++pass)   // every writer of the stage before the first comparer, whichever run holds it
             for (const auto& run : d->stage_runs[stage - 1])
-                hipLaunchKernelGGL(wd_preset_kernel, dim3((run.second + WT - 1) / WT), dim3(WT), 0, s, d->val, d->err, k.preset_slot + run.first,
+                hipLaunchKernelGGL(wd_preset_kernel, dim3((run.second + WT - 1) / WT), dim3(WT), 0, s, d->val_one, d->err, k.preset_slot + run.first,
                                    d->d_stage_vals + run.first, run.second, L, pass);
         if (ds.n_levels || !ds.consts.empty())
-            hipLaunchKernelGGL(wd_walk_kernel, dim3(d->stage_groups[stage - 1]), dim3(WALK_THREADS), 0, s, d->val, d->err, k.consts, (u32)ds.consts.size(),
+            hipLaunchKernelGGL(wd_walk_kernel, dim3(d->stage_groups[stage - 1]), dim3(WALK_THREADS), 0, s, d->val_one, d->err, k.consts, (u32)ds.consts.size(),
                                k.arith, k.bits, k.poseidon, k.misc, k.rowops, k.aux, k.row_slots,
                                WalkOffsets{k.arith_off, k.bits_off, k.poseidon_off, k.misc_off, k.rowops_off}, d->tables, ds.n_levels, L, d->err + 2);
         VPBS_HIP(hipGetLastError());
         const bool last = stage == d->k_stage.size();
         d->stages_queued[instance] = last ? 0 : stage;
+        if (last && d->n_late_slots)   // the batch's array holds the instance's final values as well (readers of single positions, a later gather)
+            hipLaunchKernelGGL(wd_column_back_kernel, dim3((unsigned)((d->n_late_slots + WT - 1) / WT)), dim3(WT), 0, s, d->val, d->batch, instance, d->d_late_slots,
+                               d->n_late_slots, d->val_one);
         if (wait || last) {
             unsigned report[2] = {0, 0};
             VPBS_HIP(hipMemcpyAsync(report, d->err, sizeof report, hipMemcpyDeviceToHost, s));
@@ -730,8 +758,12 @@ int vpbs_witness_device_wires(vpbs_witness_device* d, unsigned instance, uint64_
         VPBS_HIP(hipSetDevice(ctx->device));
         const size_t count = d->plan->out_pos.size();
         VPBS_HIP(hipMemsetAsync(d_wires, 0, sizeof(u64) * d->plan->total, ctx->stream));
-        hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
-                           d->batch, instance, d_wires);
+        if (d->one_instance == (int)instance && d->stages_queued[instance] == 0)   // its late phase ran on the compact copy: every value is there, close together
+            hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val_one, d->out_pos, d->out_slot, count,
+                               1u, 0u, d_wires);
+        else
+            hipLaunchKernelGGL(wd_gather_kernel, dim3((unsigned)((count + WT - 1) / WT)), dim3(WT), 0, ctx->stream, d->val, d->out_pos, d->out_slot, count,
+                               d->batch, instance, d_wires);
         VPBS_HIP(vpbs::stream_sync(ctx->stream));
         return VPBS_OK;
     } catch (const vpbs::DeviceError& e) {
